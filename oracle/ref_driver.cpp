@@ -1,0 +1,109 @@
+/*
+ * ref_driver.cpp -- drives the REFERENCE's own C entry point
+ * polychord_c_interface (src/polychord/interfaces.h:2-45) with C likelihoods that
+ * restate the Fortran examples (gaussian.f90, rastrigin.f90, twin_gaussian.f90),
+ * exactly as SURVEY.md 8(c) prescribes.  Used (a) to generate tests/golden/*.json
+ * in this container and (b) as bench.py's cpu_baseline kind="reference" on the GPU box.
+ * Test infrastructure only.
+ *
+ * usage: ref_driver <like> <nDims> <nDerived> <nlive> <nrepeats> <seed> <clustering> <base_dir> <root> [write_dead]
+ * prints one JSON line: {"logZ":..,"logZerr":..,"ndead":..,"nlike":..,"wall":..}
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <chrono>
+#include <sys/resource.h>
+#include <sys/stat.h>
+
+extern "C" void polychord_c_interface(
+    double (*)(double *, int, double *, int), void (*)(double *, double *, int),
+    void (*)(int, int, int, double *, double *, double *, double, double),
+    int, int, int, int, bool, int, double, double, int, double, bool, bool, bool, bool, bool, bool, bool,
+    bool, bool, bool, bool, double, bool, int, int, char *, char *, int, double *, int *, int, double *,
+    int *, int, int &);
+extern "C" void pc_shim_reset(unsigned) __attribute__((weak));
+extern "C" unsigned long pc_shim_consumed(void) __attribute__((weak));
+
+static long g_calls = 0;
+static double g_lo = 0.0, g_hi = 1.0;
+static const double LOG_TWO_PI = 1.8378770664093453;
+
+static double gaussian(double *th, int D, double *phi, int nDer)
+{   // likelihoods/examples/gaussian.f90:12-41
+    g_calls++;
+    const double mu = 0.5, sigma = 0.1;
+    double s = 0, r2 = 0;
+    for (int d = 0; d < D; ++d) { double z = (th[d] - mu) / sigma; s += z * z; r2 += (th[d] - mu) * (th[d] - mu); }
+    if (nDer >= 1) phi[0] = std::sqrt(r2);
+    if (nDer >= 2) phi[1] = std::log(std::pow(phi[0], (double)D) * std::pow(std::sqrt(3.14159265358979323846), (double)D) / std::tgamma(1.0 + D / 2.0));
+    return -(double)D * (std::log(sigma) + LOG_TWO_PI / 2.0) - s / 2.0;
+}
+static double rastrigin(double *th, int D, double *, int)
+{   // likelihoods/examples/rastrigin.f90:20-35
+    g_calls++;
+    double s = 0;
+    for (int d = 0; d < D; ++d) s += std::log(4991.21750) + th[d] * th[d] - 10.0 * std::cos(6.283185307179586 * th[d]);
+    return -s;
+}
+static double twin(double *th, int D, double *phi, int nDer)
+{   // likelihoods/examples/twin_gaussian.f90:14-56
+    g_calls++;
+    const double sigma = 0.1;
+    double n = -(double)D * (std::log(sigma) + LOG_TWO_PI / 2.0), s1 = 0, s2 = 0;
+    for (int d = 0; d < D; ++d) {
+        double m1 = d < 2 ? -0.5 : 0.0, m2 = d < 2 ? 0.5 : 0.0;
+        double z1 = (th[d] - m1) / sigma, z2 = (th[d] - m2) / sigma; s1 += z1 * z1; s2 += z2 * z2;
+    }
+    if (nDer >= 1) phi[0] = th[0] > 0.5 ? 1.0 : -1.0;
+    double a = n - s1 / 2, b = n - s2 / 2;
+    double la = a > b ? a + std::log(std::exp(b - a) + 1) : b + std::log(std::exp(a - b) + 1);
+    return la - std::log(2.0);
+}
+static void prior(double *cube, double *theta, int D) { for (int d = 0; d < D; ++d) theta[d] = g_lo + (g_hi - g_lo) * cube[d]; }
+static void dumper(int, int, int, double *, double *, double *, double, double) {}
+
+int main(int argc, char **argv)
+{
+    if (argc < 10) { std::fprintf(stderr, "usage: %s like nDims nDerived nlive nrepeats seed clustering base_dir root [write_dead]\n", argv[0]); return 2; }
+    struct rlimit rl; getrlimit(RLIMIT_STACK, &rl); rl.rlim_cur = rl.rlim_max; setrlimit(RLIMIT_STACK, &rl);
+    std::string like = argv[1];
+    int nDims = atoi(argv[2]), nDer = atoi(argv[3]), nlive = atoi(argv[4]), nrep = atoi(argv[5]), seed = atoi(argv[6]);
+    bool clustering = atoi(argv[7]) != 0;
+    std::string base = argv[8], root = argv[9];
+    bool write_dead = argc > 10 && atoi(argv[10]) != 0;
+    mkdir(base.c_str(), 0755); mkdir((base + "/clusters").c_str(), 0755);
+    double (*fn)(double *, int, double *, int) = gaussian;
+    if (like == "rastrigin") { fn = rastrigin; g_lo = -5.12; g_hi = 5.12; }
+    else if (like == "twin_gaussian") { fn = twin; g_lo = -1.0; g_hi = 1.0; }
+    double grade_frac[1] = { 1.0 }; int grade_dims[1] = { nDims };
+    double loglikes[1] = { 0 }; int nlives[1] = { 0 };
+    int comm = 0;
+    if (pc_shim_reset) pc_shim_reset((unsigned)seed);
+    auto t0 = std::chrono::steady_clock::now();
+    polychord_c_interface(fn, prior, dumper, nlive, nrep, -1, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
+                          false, false, false, false, false, false, true, false, write_dead, false, false,
+                          0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
+                          1, grade_frac, grade_dims, 0, loglikes, nlives, seed, comm);
+    double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // parse <base>/<root>.stats (read_write.F90:842-889)
+    std::string fn_stats = base + "/" + root + ".stats";
+    FILE *f = std::fopen(fn_stats.c_str(), "r");
+    double logZ = 0, err = 0; long ndead = 0, nlike = 0; int ncl = 0; char line[512];
+    while (f && std::fgets(line, sizeof line, f)) {
+        if (std::strncmp(line, "log(Z)", 6) == 0 && std::strstr(line, "+/-")) {
+            const char *eq = std::strchr(line, '='); if (eq) std::sscanf(eq + 1, "%lf +/- %lf", &logZ, &err);
+        }
+        if (std::strstr(line, "ndead:")) std::sscanf(std::strstr(line, "ndead:") + 6, "%ld", &ndead);
+        if (std::strstr(line, "nlike:")) std::sscanf(std::strstr(line, "nlike:") + 6, "%ld", &nlike);
+        if (std::strstr(line, "ncluster:")) std::sscanf(std::strstr(line, "ncluster:") + 9, "%d", &ncl);
+    }
+    if (f) std::fclose(f);
+    std::printf("{\"like\":\"%s\",\"nDims\":%d,\"nlive\":%d,\"num_repeats\":%d,\"seed\":%d,\"logZ\":%.15g,\"logZerr\":%.15g,"
+                "\"ndead\":%ld,\"nlike\":%ld,\"ncluster\":%d,\"calls\":%ld,\"rng_consumed\":%lu,\"wall\":%.4f}\n",
+                like.c_str(), nDims, nlive, nrep, seed, logZ, err, ndead, nlike, ncl, g_calls,
+                pc_shim_consumed ? pc_shim_consumed() : 0ul, wall);
+    return 0;
+}
