@@ -1,0 +1,128 @@
+/*
+ * polychord_hip.h -- C ABI of libpolychord_hip.so, the MI355X-native nested-sampling engine
+ * that is a drop-in behind PolyChordLite's own C boundary.
+ *
+ * Part 1 re-declares, symbol for symbol, what the reference exports from its Fortran
+ * ISO_C_BINDING shim (reference src/polychord/interfaces.h:2-56, implemented in
+ * src/polychord/interfaces.F90:285-436 and :496-519).  A caller linked against the
+ * reference's libchord.so links against libpolychord_hip.so unchanged.
+ *
+ * Part 2 is the engine's own plain-C surface (no torch types, plain pointers and sizes): device
+ * likelihood selectors, the batched engine entry used by bench.py / tests, and kernel-level entry
+ * points for parity tests.
+ */
+#ifndef POLYCHORD_HIP_H
+#define POLYCHORD_HIP_H
+#include <stdbool.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===== Part 1: the reference's C boundary ================================================== */
+
+/* loglikelihood(theta, nDims, phi, nDerived) -> logL      (interfaces.h:3, interfaces.F90:291-300) */
+typedef double (*polychord_loglike_fn)(double *theta, int nDims, double *phi, int nDerived);
+/* prior(cube, theta, nDims): hypercube -> physical        (interfaces.h:4, interfaces.F90:302-309) */
+typedef void (*polychord_prior_fn)(double *cube, double *theta, int nDims);
+/* dumper(ndead, nlive, npars, live, dead, logweights, logZ, logZerr)
+ *                                                          (interfaces.h:5, interfaces.F90:311-322) */
+typedef void (*polychord_dumper_fn)(int ndead, int nlive, int npars, double *live, double *dead,
+                                    double *logweights, double logZ, double logZerr);
+
+/* replaces polychord_c_interface (interfaces.h:2-45, interfaces.F90:285-436).  Scalars by value,
+ * `comm` by reference (an MPI_Fint in the reference's MPI build; ignored here, ranks are processes
+ * of torch.distributed / one GPU each).  Strings are NUL-terminated. */
+void polychord_c_interface(
+    polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
+    int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
+    double precision_criterion, double logzero, int max_ndead, double boost_posterior,
+    bool posteriors, bool equals, bool cluster_posteriors, bool write_resume, bool write_paramnames,
+    bool read_resume, bool write_stats, bool write_live, bool write_dead, bool write_prior,
+    bool maximise, double compression_factor, bool synchronous, int nDims, int nDerived,
+    char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
+    double *loglikes, int *nlives, int seed, int *comm);
+
+/* replaces polychord_c_interface_ini (interfaces.h:47-56, interfaces.F90:496-519) */
+void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, void (*setup_loglikelihood)(void),
+                               char *inifile, int *comm);
+
+/* ===== Part 2: engine surface =============================================================== */
+
+enum { PCHIP_LIKE_CALLBACK = 0, PCHIP_LIKE_GAUSSIAN = 1, PCHIP_LIKE_RASTRIGIN = 2,
+       PCHIP_LIKE_TWIN_GAUSSIAN = 3, PCHIP_LIKE_CORR_GAUSSIAN = 4 };
+
+/* Built-in likelihoods that run fused on the device.  These are ordinary host functions with the
+ * reference's callback signature (they evaluate the same formula on the host); when one of them
+ * is passed as `loglikelihood` to polychord_c_interface the engine recognises the pointer and
+ * evaluates the likelihood inside the slice-sampling kernel instead of calling back.
+ * (likelihoods/examples/gaussian.f90:12-41, rastrigin.f90:20-35, twin_gaussian.f90:14-56,
+ *  random_gaussian.f90:17-30) */
+double polychord_hip_gaussian(double *theta, int nDims, double *phi, int nDerived);
+double polychord_hip_rastrigin(double *theta, int nDims, double *phi, int nDerived);
+double polychord_hip_twin_gaussian(double *theta, int nDims, double *phi, int nDerived);
+double polychord_hip_corr_gaussian(double *theta, int nDims, double *phi, int nDerived);
+/* parameters of the built-ins (process-global like the reference's setup_loglikelihood state) */
+void polychord_hip_set_gaussian(double mu, double sigma);
+void polychord_hip_set_corr_gaussian(int nDims, const double *invcov_rowmajor, const double *mean, double logdetcov);
+/* uniform box prior evaluated on the device; pass polychord_hip_uniform_prior as `prior` */
+void polychord_hip_uniform_prior(double *cube, double *theta, int nDims);
+void polychord_hip_set_uniform_prior(int nDims, const double *lo, const double *hi);
+/* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
+void polychord_hip_set_option(const char *name, double value);
+
+typedef struct {
+    int nDims, nDerived;
+    int nlive, num_repeats, nprior, nfail;
+    int do_clustering;
+    double precision_criterion, logzero;
+    int max_ndead;
+    double boost_posterior;
+    int posteriors, equals, cluster_posteriors;
+    double compression_factor;
+    int n_nlives; const double *loglikes; const int *nlives;
+    int seed;
+    int batch;          /* chains per synchronous nursery (the reference's nprocs-1); 0 = auto */
+    int device;         /* HIP device ordinal, -1 = current/0 */
+    int feedback;
+} pchip_settings;
+
+typedef struct {
+    int kind;                      /* PCHIP_LIKE_* */
+    double mu, sigma;
+    const double *invcov;          /* host, row-major D x D (corr gaussian) */
+    const double *mean;            /* host, D */
+    double logdetcov;
+    polychord_loglike_fn fn;       /* callback kind */
+} pchip_like;
+
+typedef struct {
+    int kind;                      /* 0 callback, 1 uniform box */
+    const double *lo, *hi;         /* host, D each; NULL => [0,1] */
+    polychord_prior_fn fn;
+} pchip_prior;
+
+typedef struct {
+    double logZ, varlogZ;
+    long ndead, nlike, niter, nbatches, nrounds, nupdates;
+    int ncluster, ncluster_dead, nTotal, batch;
+    double t_generate, t_loop, t_final, t_total;   /* host wall-clock of the phases, seconds */
+    double *dead, *logweights;     /* [ndead][nTotal] rows [cube|theta|phi|birth|logL], [ndead] */
+    double *live; int nlive_final; /* live set at termination, before the final kill-off */
+    double *logZp, *varlogZp; int nZp;
+    double *post_mean, *post_var;  /* [nDims] weighted posterior moments of theta */
+} pchip_result;
+
+void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
+int  pchip_device_count(void);
+/* full run with a device likelihood + uniform prior; returns 0 on success */
+int  pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, pchip_result *out);
+void pchip_result_free(pchip_result *r);
+/* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */
+int  pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
+                        unsigned batch, int nchains, const double *seeds, const double *chol,
+                        double contour, double *babies_out, double *nhats_out, int *nlike_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

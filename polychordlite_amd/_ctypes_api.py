@@ -1,0 +1,129 @@
+"""ctypes view of libpolychord_hip.so (include/polychord_hip.h) -- plumbing only.
+
+The product path is the HIP library; there is no Python/NumPy fallback.  Importing this module
+loads the shared object and fails loudly if it has not been built (`python -m polychordlite_amd.build`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpolychord_hip.so")
+
+LOGLIKE_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int)
+PRIOR_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+DUMPER_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                        C.POINTER(C.c_double), C.c_double, C.c_double)
+
+LIKE_CALLBACK, LIKE_GAUSSIAN, LIKE_RASTRIGIN, LIKE_TWIN_GAUSSIAN, LIKE_CORR_GAUSSIAN = range(5)
+LIKE_KINDS = {"gaussian": LIKE_GAUSSIAN, "rastrigin": LIKE_RASTRIGIN, "twin_gaussian": LIKE_TWIN_GAUSSIAN,
+              "corr_gaussian": LIKE_CORR_GAUSSIAN}
+
+
+class Settings(C.Structure):
+    _fields_ = [("nDims", C.c_int), ("nDerived", C.c_int), ("nlive", C.c_int), ("num_repeats", C.c_int),
+                ("nprior", C.c_int), ("nfail", C.c_int), ("do_clustering", C.c_int),
+                ("precision_criterion", C.c_double), ("logzero", C.c_double), ("max_ndead", C.c_int),
+                ("boost_posterior", C.c_double), ("posteriors", C.c_int), ("equals", C.c_int),
+                ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
+                ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
+                ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int)]
+
+
+class Like(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mu", C.c_double), ("sigma", C.c_double), ("invcov", C.POINTER(C.c_double)),
+                ("mean", C.POINTER(C.c_double)), ("logdetcov", C.c_double), ("fn", C.c_void_p)]
+
+
+class Prior(C.Structure):
+    _fields_ = [("kind", C.c_int), ("lo", C.POINTER(C.c_double)), ("hi", C.POINTER(C.c_double)), ("fn", C.c_void_p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("logZ", C.c_double), ("varlogZ", C.c_double), ("ndead", C.c_long), ("nlike", C.c_long),
+                ("niter", C.c_long), ("nbatches", C.c_long), ("nrounds", C.c_long), ("nupdates", C.c_long),
+                ("ncluster", C.c_int), ("ncluster_dead", C.c_int), ("nTotal", C.c_int), ("batch", C.c_int),
+                ("t_generate", C.c_double), ("t_loop", C.c_double), ("t_final", C.c_double), ("t_total", C.c_double),
+                ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)),
+                ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
+                ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
+                ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libpolychord_hip.so (RTLD_GLOBAL so that the HIP runtime is shared with torch)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m polychordlite_amd.build` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.pchip_settings_default.argtypes = [C.POINTER(Settings), C.c_int, C.c_int]
+    lib.pchip_settings_default.restype = None
+    lib.pchip_device_count.restype = C.c_int
+    lib.pchip_run.argtypes = [C.POINTER(Settings), C.POINTER(Like), C.POINTER(Prior), C.POINTER(Result)]
+    lib.pchip_run.restype = C.c_int
+    lib.pchip_result_free.argtypes = [C.POINTER(Result)]
+    lib.pchip_result_free.restype = None
+    lib.pchip_slice_chains.argtypes = [C.POINTER(Settings), C.POINTER(Like), C.POINTER(Prior), C.c_uint, C.c_int,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.pchip_slice_chains.restype = C.c_int
+    lib.polychord_hip_set_gaussian.argtypes = [C.c_double, C.c_double]
+    lib.polychord_hip_set_uniform_prior.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.polychord_hip_set_corr_gaussian.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+    lib.polychord_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_problem(kind, nDims, nDerived=0, lo=None, hi=None, mu=0.5, sigma=0.1, invcov=None, mean=None, logdet=0.0):
+    """(Like, Prior, keepalive) for a built-in device likelihood and a uniform box prior."""
+    keep = []
+    L = Like()
+    L.kind = LIKE_KINDS[kind]
+    L.mu, L.sigma, L.logdetcov = mu, sigma, logdet
+    if invcov is not None:
+        ic = np.ascontiguousarray(invcov, dtype=np.float64)
+        mn = np.ascontiguousarray(mean, dtype=np.float64)
+        keep += [ic, mn]
+        L.invcov, L.mean = dptr(ic), dptr(mn)
+    P = Prior()
+    P.kind = 1
+    if lo is not None:
+        lo_a = np.ascontiguousarray(np.broadcast_to(lo, (nDims,)), dtype=np.float64)
+        hi_a = np.ascontiguousarray(np.broadcast_to(hi, (nDims,)), dtype=np.float64)
+        keep += [lo_a, hi_a]
+        P.lo, P.hi = dptr(lo_a), dptr(hi_a)
+    return L, P, keep
+
+
+def run(settings, like, prior):
+    """pchip_run -> dict of numpy copies (the C result is freed)."""
+    lib = load()
+    r = Result()
+    rc = lib.pchip_run(C.byref(settings), C.byref(like), C.byref(prior), C.byref(r))
+    if rc != 0:
+        raise RuntimeError(f"pchip_run failed with code {rc}")
+    nT, nd, D = r.nTotal, r.ndead, settings.nDims
+    out = dict(logZ=r.logZ, logZerr=float(np.sqrt(abs(r.varlogZ))), varlogZ=r.varlogZ, ndead=nd, nlike=r.nlike,
+               niter=r.niter, nbatches=r.nbatches, nrounds=r.nrounds, nupdates=r.nupdates, ncluster=r.ncluster,
+               ncluster_dead=r.ncluster_dead, nTotal=nT, batch=r.batch, t_generate=r.t_generate, t_loop=r.t_loop,
+               t_final=r.t_final, t_total=r.t_total,
+               dead=np.ctypeslib.as_array(r.dead, shape=(nd, nT)).copy(),
+               logweights=np.ctypeslib.as_array(r.logweights, shape=(nd,)).copy(),
+               live=np.ctypeslib.as_array(r.live, shape=(max(r.nlive_final, 1), nT))[:r.nlive_final].copy(),
+               logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
+               post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),
+               post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy())
+    lib.pchip_result_free(C.byref(r))
+    return out

@@ -1,0 +1,254 @@
+// pc_abi.hip -- the drop-in boundary: the reference's C symbols on top of the HIP engine.
+//
+//   polychord_c_interface      replaces src/polychord/interfaces.F90:285-436 (prototype interfaces.h:2-45)
+//   polychord_c_interface_ini  replaces src/polychord/interfaces.F90:496-519 (prototype interfaces.h:47-56)
+// Output files follow src/polychord/read_write.F90 (formats E24.15E3 / I8, utils.F90:19-21):
+//   <root>.stats (:809-910), <root>_dead.txt / <root>_dead-birth.txt (:679-719),
+//   <root>_phys_live.txt / -birth (:621-676), <root>.paramnames is written by the Python layer.
+// Fatal conditions follow abort.F90:19-29: message on stderr, exit status 1.
+#include "../../include/polychord_hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <sys/stat.h>
+#include <chrono>
+
+namespace {
+
+struct Builtins {
+    double g_mu = 0.5, g_sigma = 0.1;                 // likelihoods/examples/gaussian.f90:25-26
+    int cg_D = 0; std::vector<double> cg_invcov, cg_mean; double cg_logdet = 0.0;
+    int up_D = 0; std::vector<double> up_lo, up_hi;
+    int batch = 0, device = -1;
+} G;
+
+const double LOG_TWO_PI = 1.8378770664093453;
+
+[[noreturn]] void halt_program(const char *msg)
+{   // abort.F90:19-29
+    std::fprintf(stderr, "%s\n", msg);
+    std::exit(1);
+}
+
+// Fortran E24.15E3:  "  0.626931681801488E-001"
+std::string fmt_e24(double v)
+{
+    char buf[64];
+    if (v == 0.0 || !std::isfinite(v)) {
+        if (!std::isfinite(v)) { std::snprintf(buf, sizeof buf, "%24s", std::isnan(v) ? "NaN" : (v > 0 ? "Infinity" : "-Infinity")); return buf; }
+        return std::string("   0.000000000000000E+000");
+    }
+    char t[64];
+    std::snprintf(t, sizeof t, "%.14E", std::fabs(v));     // d.ddddddddddddddE+XX
+    const char *e = std::strchr(t, 'E');
+    int ex = std::atoi(e + 1) + 1;
+    std::string digits;
+    digits += t[0];
+    digits.append(t + 2, 14);
+    std::snprintf(buf, sizeof buf, "%s0.%sE%c%03d", v < 0 ? "-" : "", digits.c_str(), ex < 0 ? '-' : '+', std::abs(ex));
+    char out[64];
+    std::snprintf(out, sizeof out, "%24s", buf);
+    return out;
+}
+
+void write_rows(const std::string &path, const pchip_result &r, int nDims, int nDer, bool birth, bool live)
+{
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) halt_program(("polychord_hip: cannot open " + path).c_str());
+    const int nT = r.nTotal, p0 = nDims, l0 = nT - 1, b0 = nT - 2;
+    const long n = live ? 0 : r.ndead;       // every live point has been killed when the run ends
+    for (long i = 0; i < n; ++i) {
+        const double *row = r.dead + (size_t)i * nT;
+        std::string line;
+        if (birth || live) {                 // read_write.F90:707-716: theta, phi, logL, birth
+            for (int k = 0; k < nDims + nDer; ++k) line += fmt_e24(row[p0 + k]);
+            line += fmt_e24(row[l0]);
+            if (birth) line += fmt_e24(row[b0]);
+        } else {                              // read_write.F90:698-703: logL, theta, phi
+            line += fmt_e24(row[l0]);
+            for (int k = 0; k < nDims + nDer; ++k) line += fmt_e24(row[p0 + k]);
+        }
+        std::fprintf(f, "%s\n", line.c_str());
+    }
+    std::fclose(f);
+}
+
+void write_stats(const std::string &path, const pchip_result &r, int nposterior, int nequals)
+{   // read_write.F90:842-889
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) halt_program(("polychord_hip: cannot open " + path).c_str());
+    std::fprintf(f, "Evidence estimates:\n===================\n");
+    std::fprintf(f, "  - The evidence Z is a log-normally distributed, with location and scale parameters mu and sigma.\n");
+    std::fprintf(f, "  - We denote this as log(Z) = mu +/- sigma.\n\nGlobal evidence:\n----------------\n\n");
+    std::fprintf(f, "log(Z)       = %s +/- %s\n\n\n", fmt_e24(r.logZ).c_str(), fmt_e24(std::sqrt(std::fabs(r.varlogZ))).c_str());
+    std::fprintf(f, "Local evidences:\n----------------\n\n");
+    for (int p = 0; p < r.nZp; ++p) {
+        const int idx = p + 1 + 0;                        // no cluster is still active at the end
+        char lab[32];
+        std::snprintf(lab, sizeof lab, "log(Z_%d)", idx);
+        std::fprintf(f, "%-13s= %s +/- %s\n", lab, fmt_e24(r.logZp[p]).c_str(), fmt_e24(std::sqrt(std::fabs(r.varlogZp[p]))).c_str());
+    }
+    std::fprintf(f, "\n\nRun-time information:\n---------------------\n\n");
+    std::fprintf(f, " ncluster:   %8d /%8d\n", 0, r.ncluster_dead);
+    std::fprintf(f, " nposterior: %8d\n", nposterior);
+    std::fprintf(f, " nequals:    %8d\n", nequals);
+    std::fprintf(f, " ndead:      %8ld\n", r.ndead);
+    std::fprintf(f, " nlive:      %8d\n", 0);
+    std::fprintf(f, " nlike:      %8ld\n", r.nlike);
+    std::fprintf(f, " <nlike>:    %8.2f   (%8.2f per slice )\n", 0.0, 0.0);
+    std::fclose(f);
+}
+
+}  // namespace
+
+extern "C" {
+
+double polychord_hip_gaussian(double *th, int D, double *phi, int nDer)
+{   // likelihoods/examples/gaussian.f90:12-41
+    double s = 0, r2 = 0;
+    for (int d = 0; d < D; ++d) { const double z = (th[d] - G.g_mu) / G.g_sigma; s += z * z; r2 += (th[d] - G.g_mu) * (th[d] - G.g_mu); }
+    if (nDer >= 1) phi[0] = std::sqrt(r2);
+    if (nDer >= 2) phi[1] = std::log(std::pow(phi[0], (double)D) * std::pow(std::sqrt(3.14159265358979323846), (double)D) / std::tgamma(1.0 + D / 2.0));
+    return -(double)D * (std::log(G.g_sigma) + LOG_TWO_PI / 2.0) - s / 2.0;
+}
+double polychord_hip_rastrigin(double *th, int D, double *, int)
+{   // likelihoods/examples/rastrigin.f90:20-35
+    double s = 0;
+    for (int d = 0; d < D; ++d) s += std::log(4991.21750) + th[d] * th[d] - 10.0 * std::cos(6.283185307179586 * th[d]);
+    return -s;
+}
+double polychord_hip_twin_gaussian(double *th, int D, double *phi, int nDer)
+{   // likelihoods/examples/twin_gaussian.f90:14-56
+    const double sg = G.g_sigma;
+    const double n = -(double)D * (std::log(sg) + LOG_TWO_PI / 2.0);
+    double s1 = 0, s2 = 0;
+    for (int d = 0; d < D; ++d) {
+        const double m1 = d < 2 ? -0.5 : 0.0, m2 = d < 2 ? 0.5 : 0.0, z1 = (th[d] - m1) / sg, z2 = (th[d] - m2) / sg;
+        s1 += z1 * z1; s2 += z2 * z2;
+    }
+    if (nDer >= 1) phi[0] = th[0] > 0.5 ? 1.0 : -1.0;
+    const double a = n - s1 / 2, b = n - s2 / 2;
+    return (a > b ? a + std::log(std::exp(b - a) + 1) : b + std::log(std::exp(a - b) + 1)) - std::log(2.0);
+}
+double polychord_hip_corr_gaussian(double *th, int D, double *, int)
+{   // likelihoods/examples/random_gaussian.f90:17-30, utils.F90:1028-1048
+    if (G.cg_D != D) halt_program("polychord_hip: polychord_hip_set_corr_gaussian was not called for this nDims");
+    double q = 0;
+    for (int a = 0; a < D; ++a) {
+        double t = 0;
+        for (int b = 0; b < D; ++b) t += G.cg_invcov[(size_t)a * D + b] * (th[b] - G.cg_mean[b]);
+        q += (th[a] - G.cg_mean[a]) * t;
+    }
+    return -((double)D * LOG_TWO_PI + G.cg_logdet) / 2.0 - q / 2.0;
+}
+void polychord_hip_set_gaussian(double mu, double sigma) { G.g_mu = mu; G.g_sigma = sigma; }
+void polychord_hip_set_corr_gaussian(int D, const double *invcov, const double *mean, double logdet)
+{
+    G.cg_D = D; G.cg_invcov.assign(invcov, invcov + (size_t)D * D); G.cg_mean.assign(mean, mean + D); G.cg_logdet = logdet;
+}
+void polychord_hip_uniform_prior(double *cube, double *theta, int D)
+{   // priors.f90:40-55
+    for (int d = 0; d < D; ++d) {
+        const double lo = d < G.up_D ? G.up_lo[d] : 0.0, hi = d < G.up_D ? G.up_hi[d] : 1.0;
+        theta[d] = lo + (hi - lo) * cube[d];
+    }
+}
+void polychord_hip_set_uniform_prior(int D, const double *lo, const double *hi)
+{
+    G.up_D = D; G.up_lo.assign(lo, lo + D); G.up_hi.assign(hi, hi + D);
+}
+void polychord_hip_set_option(const char *name, double value)
+{
+    if (!std::strcmp(name, "batch")) G.batch = (int)value;
+    else if (!std::strcmp(name, "device")) G.device = (int)value;
+    else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
+}
+
+void polychord_c_interface(
+    polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
+    int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
+    double precision_criterion, double logzero, int max_ndead, double boost_posterior,
+    bool posteriors, bool equals, bool cluster_posteriors, bool write_resume, bool write_paramnames,
+    bool read_resume, bool write_stats_f, bool write_live, bool write_dead, bool write_prior,
+    bool maximise, double compression_factor, bool synchronous, int nDims, int nDerived,
+    char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
+    double *loglikes, int *nlives, int seed, int *comm)
+{
+    (void)write_resume; (void)write_paramnames; (void)read_resume; (void)write_prior; (void)maximise;
+    (void)synchronous; (void)comm; (void)grade_frac;
+    if (num_repeats < 1) halt_program("You need to set num_repeats. Suggestion: 5*nDims");     // settings.f90:216
+    if (nGrade > 1 || (nGrade == 1 && grade_dims && grade_dims[0] != nDims))
+        halt_program("polychord_hip: fast/slow parameter grades are not supported by the HIP engine yet");
+    pchip_settings s;
+    pchip_settings_default(&s, nDims, nDerived);
+    s.nlive = nlive; s.num_repeats = num_repeats; s.nprior = nprior; s.nfail = nfail; s.do_clustering = do_clustering;
+    s.feedback = feedback; s.precision_criterion = precision_criterion; s.logzero = logzero; s.max_ndead = max_ndead;
+    s.boost_posterior = boost_posterior; s.posteriors = posteriors; s.equals = equals; s.cluster_posteriors = cluster_posteriors;
+    s.compression_factor = compression_factor; s.n_nlives = n_nlives; s.loglikes = loglikes; s.nlives = nlives;
+    s.seed = seed >= 0 ? seed : (int)(std::chrono::system_clock::now().time_since_epoch().count() & 0x7fffffff); // random_utils.F90:62-79
+    s.batch = G.batch; s.device = G.device;
+    pchip_like L{}; pchip_prior P{};
+    if (loglikelihood == polychord_hip_gaussian) { L.kind = PCHIP_LIKE_GAUSSIAN; L.mu = G.g_mu; L.sigma = G.g_sigma; }
+    else if (loglikelihood == polychord_hip_rastrigin) L.kind = PCHIP_LIKE_RASTRIGIN;
+    else if (loglikelihood == polychord_hip_twin_gaussian) { L.kind = PCHIP_LIKE_TWIN_GAUSSIAN; L.sigma = G.g_sigma; }
+    else if (loglikelihood == polychord_hip_corr_gaussian) {
+        if (G.cg_D != nDims) halt_program("polychord_hip: polychord_hip_set_corr_gaussian was not called for this nDims");
+        L.kind = PCHIP_LIKE_CORR_GAUSSIAN; L.invcov = G.cg_invcov.data(); L.mean = G.cg_mean.data(); L.logdetcov = G.cg_logdet;
+    } else { L.kind = PCHIP_LIKE_CALLBACK; L.fn = loglikelihood; }
+    if (prior == polychord_hip_uniform_prior) {
+        P.kind = 1;
+        if (G.up_D == nDims) { P.lo = G.up_lo.data(); P.hi = G.up_hi.data(); }
+    } else { P.kind = 0; P.fn = prior; }
+    const std::string base = base_dir ? base_dir : "chains", root = file_root ? file_root : "test";
+    if (write_stats_f || write_dead || write_live) {
+        struct stat sb;
+        if (stat(base.c_str(), &sb) != 0) halt_program(("PolyChord Error: " + base + " does not exist").c_str()); // read_write.F90:28-38
+    }
+    if (L.kind == PCHIP_LIKE_CALLBACK || P.kind == 0)
+        halt_program("polychord_hip: host-callback likelihoods/priors are not wired to the device proposer yet; "
+                     "pass polychord_hip_<name> built-ins (no CPU fallback exists by design)");
+    pchip_result r;
+    if (pchip_run(&s, &L, &P, &r) != 0) halt_program("polychord_hip: engine failure");
+    if (write_stats_f) write_stats(base + "/" + root + ".stats", r, 0, 0);
+    if (write_dead) {
+        write_rows(base + "/" + root + "_dead.txt", r, nDims, nDerived, false, false);
+        write_rows(base + "/" + root + "_dead-birth.txt", r, nDims, nDerived, true, false);
+    }
+    if (write_live) {
+        write_rows(base + "/" + root + "_phys_live.txt", r, nDims, nDerived, false, true);
+        write_rows(base + "/" + root + "_phys_live-birth.txt", r, nDims, nDerived, true, true);
+    }
+    if (dumper) {   // nested_sampling.F90:546-590: columns [theta, phi, birth, logL]; weights normalised
+        const int npars = nDims + nDerived + 2, nT = r.nTotal;
+        std::vector<double> dead((size_t)r.ndead * npars), lw(r.ndead);
+        double m = -1.7e308;
+        for (long i = 0; i < r.ndead; ++i) { lw[i] = r.logweights[i] + r.dead[(size_t)i * nT + nT - 1]; if (lw[i] > m) m = lw[i]; }
+        double sum = 0;
+        for (long i = 0; i < r.ndead; ++i) sum += std::exp(lw[i] - m);
+        const double lse = m + std::log(sum);
+        for (long i = 0; i < r.ndead; ++i) {
+            lw[i] -= lse;
+            std::memcpy(&dead[(size_t)i * npars], r.dead + (size_t)i * nT + nDims, sizeof(double) * (nDims + nDerived));
+            dead[(size_t)i * npars + nDims + nDerived] = r.dead[(size_t)i * nT + nT - 2];
+            dead[(size_t)i * npars + nDims + nDerived + 1] = r.dead[(size_t)i * nT + nT - 1];
+        }
+        double dummy = 0;
+        dumper((int)r.ndead, 0, npars, &dummy, dead.data(), lw.data(), r.logZ, std::sqrt(std::fabs(r.varlogZ)));
+    }
+    if (feedback >= 1) {
+        std::printf("polychord_hip: log(Z) = %.6f +/- %.6f  ndead = %ld  nlike = %ld  (%.3f s, batch %d)\n",
+                    r.logZ, std::sqrt(std::fabs(r.varlogZ)), r.ndead, r.nlike, r.t_total, r.batch);
+    }
+    pchip_result_free(&r);
+}
+
+void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, void (*setup_loglikelihood)(void), char *inifile, int *comm)
+{
+    (void)loglikelihood; (void)setup_loglikelihood; (void)inifile; (void)comm;
+    halt_program("polychord_hip: polychord_c_interface_ini: the ini reader is not part of this build yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,779 @@
+// pc_contract.hip -- nested-sampling contraction on the device.
+//
+//   k_consume   ONE workgroup walks the nursery in the reference's order and takes every decision
+//               of replace_point / delete_outermost_point / update_evidence / find_min_loglikelihoods /
+//               more_samples_needed / delete_cluster (run_time_info.f90:716-817, 211-296, 883-909,
+//               507-598; nested_sampling.F90:239-341, 514-543).  The live logL column and the
+//               (cluster, list position) labels of every slot sit in LDS; the independent log-space
+//               updates of one death are spread over lanes; min-logL scans are DPP argmin butterflies.
+//               No point row is moved here: the kernel emits a PLAN.
+//   k_apply_*   execute the plan in parallel over the whole chip (dead rows, phantoms, new live rows).
+//   k_clean_* / k_cov_* / k_chol   the "update" step: clean_phantoms (run_time_info.f90:820-877) as a
+//               threshold test + deterministic stream compaction, calculate_covmats (:601-641) as a
+//               two-pass mean / centred SYRK with fixed-order reduction, calc_cholesky (utils.F90:621-649).
+#include "pc_state.h"
+
+// ------------------------------------------------------------------------------------------
+// block-level helpers (NT threads; NT == 64 needs no barrier traffic)
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ vk_t block_argmin(vk_t v, vk_t *scratch)
+{
+    v = wave_argmin(v);
+    if (NT == 64) return v;
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wid] = v;
+    __syncthreads();
+    vk_t r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = vk_min(r, scratch[i]);
+    __syncthreads();
+    return r;
+}
+
+struct ConsumeShared {
+    double *sL; int *sC; int *sP;                      // per slot
+    double *cLogLp, *cLogXp, *cLogZp, *cLogZXp, *cLogZp2, *cLogZpXp, *cLseRef, *cLseSum, *cThr;
+    int *cN, *cMinSlot; unsigned *cUid;
+    double *jobres;                                     // [NT] results of the lane-parallel jobs
+    vk_t *red;                                          // [16]
+    double *xbuf;                                       // [D] cube coordinates of the point being identified
+    int *misc;                                          // small scratch
+};
+
+// nearest live point over ALL clusters (identify_cluster, run_time_info.f90:913-949); ties keep the
+// first point in (cluster, list position) order like the reference's strict '<' scan.
+template <int NT>
+__device__ int block_identify(const PcState &S, const ConsumeShared &H, const double *pt_row, int nc)
+{
+    if (nc == 1) return 0;
+    const int tid = threadIdx.x, D = S.D;
+    for (int d = tid; d < D; d += NT) H.xbuf[d] = pt_row[d];
+    __syncthreads();
+    vk_t best{PC_HUGE, 0x7fffffff};
+    for (int s = tid; s < S.Ncap; s += NT) {
+        const int c = H.sC[s];
+        if (c < 0) continue;
+        const int src = S.slot_src[s];
+        const double *q = (src >= 0) ? S.babies + ((size_t)src * S.nr + (S.nr - 1)) * S.nT : S.live + (size_t)s * S.nT;
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) { const double t = H.xbuf[d] - q[d]; d2 += t * t; }
+        best = vk_min(best, vk_t{d2, c * S.Ncap + H.sP[s]});
+    }
+    best = block_argmin<NT>(best, H.red);
+    __syncthreads();
+    return best.k / S.Ncap;
+}
+
+// dynamic nlive target (run_time_info.f90:766-771)
+__device__ __forceinline__ int nlive_target(const PcState &S, double logL)
+{
+    int best = -1;
+    for (int i = 0; i < S.n_nlives; ++i)
+        if (logL > S.dyn_loglikes[i] && (best < 0 || S.dyn_loglikes[i] > S.dyn_loglikes[best])) best = i;
+    return best < 0 ? S.N : S.dyn_nlives[best];
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ncap = S.Ncap, maxc = S.maxc, nr = S.nr, nT = S.nT;
+    ConsumeShared H;
+    {
+        char *p = smem;
+        H.sL = (double *)p; p += sizeof(double) * Ncap;
+        double **cd[] = { &H.cLogLp, &H.cLogXp, &H.cLogZp, &H.cLogZXp, &H.cLogZp2, &H.cLogZpXp, &H.cLseRef, &H.cLseSum, &H.cThr };
+        for (int i = 0; i < 9; ++i) { *cd[i] = (double *)p; p += sizeof(double) * maxc; }
+        H.jobres = (double *)p; p += sizeof(double) * NT;
+        H.xbuf = (double *)p; p += sizeof(double) * S.D;
+        H.red = (vk_t *)p; p += sizeof(vk_t) * 16;
+        H.sC = (int *)p; p += sizeof(int) * Ncap;
+        H.sP = (int *)p; p += sizeof(int) * Ncap;
+        H.cN = (int *)p; p += sizeof(int) * maxc;
+        H.cMinSlot = (int *)p; p += sizeof(int) * maxc;
+        H.cUid = (unsigned *)p; p += sizeof(unsigned) * maxc;
+        H.misc = (int *)p;
+    }
+    PcCtl *ctl = S.ctl;
+    // ---- stage the state in LDS
+    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
+    int nc = ctl->ncluster;
+    for (int c = tid; c < maxc; c += NT) {
+        H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
+        H.cLogZp2[c] = S.logZp2[c]; H.cLogZpXp[c] = S.logZpXp[c]; H.cLseRef[c] = S.lse_ref[c]; H.cLseSum[c] = S.lse_sum[c];
+        H.cThr[c] = S.death_thr[c]; H.cN[c] = S.cl_n[c]; H.cMinSlot[c] = S.imin_slot[c]; H.cUid[c] = S.cl_uid[c];
+    }
+    // replicated scalars (every thread runs the same scalar code on the same inputs)
+    int i_nursery = ctl->i_nursery, epoch = ctl->admin_epoch, failures = ctl->failures, ndead = ctl->ndead,
+        nph = ctl->nphantom, nc_dead = ctl->ncluster_dead;
+    long long nlike = ctl->nlike, niter = ctl->niter;
+    double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
+    unsigned next_uid = ctl->next_cluster_uid;
+    int status = PC_ST_RUNNING, error = PC_ERR_NONE, cluster_deleted = 0;
+    const int seg_hi = i_nursery - 1;
+    double live_logZ_val = S.logzero;
+    const double log2v = log(2.0);
+    __syncthreads();
+
+    // ================================================================================
+    // one death: delete_outermost_point (run_time_info.f90:789-817) without the row copy
+    // ================================================================================
+    auto kill_lowest = [&](int plan_w) {
+        // cluster with the lowest contour (minpos: first minimum)
+        int cd = 0;
+        for (int c = 1; c < nc; ++c) if (H.cLogLp[c] < H.cLogLp[cd]) cd = c;
+        const int n = H.cN[cd];
+        const double L = H.cLogLp[cd];
+        const int slot_del = H.cMinSlot[cd];
+        const int pos_del = H.sP[slot_del];
+        // ---- update_evidence (run_time_info.f90:211-296): every log-space accumulation reads only
+        //      pre-update values, so they are independent jobs: one lane each.
+        const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
+        const double Xp = H.cLogXp[cd], XX = S.XpXq[(size_t)cd * maxc + cd];
+        const double logweight = Xp - l1;
+        {
+            double a = 0.0, b = 0.0, c3 = 0.0; bool has = false, has3 = false;
+            if (tid == 0) { a = logZ; b = Xp + L - l1; has = true; }
+            else if (tid == 1) { a = H.cLogZp[cd]; b = Xp + L - l1; has = true; }
+            else if (tid == 2) { a = logZ2; b = log2v + H.cLogZXp[cd] + L - l1; c3 = log2v + XX + 2 * L - l1 - l2; has = has3 = true; }
+            else if (tid == 3) { a = H.cLogZXp[cd] + l0 - l1; b = XX + L + l0 - l1 - l2; has = true; }
+            else if (tid == 4) { a = H.cLogZp2[cd]; b = log2v + H.cLogZpXp[cd] + L - l1; c3 = log2v + XX + 2 * L - l1 - l2; has = has3 = true; }
+            else if (tid == 5) { a = H.cLogZpXp[cd] + l0 - l1; b = XX + L + l0 - l1 - l2; has = true; }
+            else if (tid == 6) { a = exp(L - H.cLseRef[cd]); }                       // live logsumexp bookkeeping
+            else if (tid >= 8 && tid - 8 < nc && tid - 8 != cd && tid - 8 < NT - 8) {
+                const int q = tid - 8;
+                a = H.cLogZXp[q]; b = S.XpXq[(size_t)cd * maxc + q] + L - l1; has = true;
+            }
+            double r = a;
+            if (has) r = pc_logaddexp(a, b);
+            if (has3) r = pc_logaddexp(r, c3);
+            H.jobres[tid] = r;
+        }
+        __syncthreads();
+        // clusters beyond the lane budget (nc > NT-8): serial tail, rare
+        for (int q = NT - 8 + tid; q < nc; q += NT)
+            if (q != cd) H.cLogZXp[q] = pc_logaddexp(H.cLogZXp[q], S.XpXq[(size_t)cd * maxc + q] + L - l1);
+        logZ = H.jobres[0]; logZ2 = H.jobres[2];
+        const double nZp = H.jobres[1], nZXp = H.jobres[3], nZp2 = H.jobres[4], nZpXp = H.jobres[5], edel = H.jobres[6];
+        __syncthreads();
+        if (tid == 0) {
+            H.cLogZp[cd] = nZp; H.cLogZXp[cd] = nZXp; H.cLogZp2[cd] = nZp2; H.cLogZpXp[cd] = nZpXp;
+            H.cLogXp[cd] = Xp + l0 - l1;
+            H.cLseSum[cd] -= edel;
+            H.cThr[cd] = L;
+            H.cN[cd] = n - 1;
+            H.sC[slot_del] = -1;
+        }
+        for (int q = tid; q < nc; q += NT) {
+            if (q == cd) { if (true) S.XpXq[(size_t)cd * maxc + cd] = XX + l0 - l2; }
+            else {
+                if (q < NT - 8) H.cLogZXp[q] = H.jobres[8 + q];
+                const double v = S.XpXq[(size_t)cd * maxc + q] + l0 - l1;
+                S.XpXq[(size_t)cd * maxc + q] = v; S.XpXq[(size_t)q * maxc + cd] = v;
+            }
+        }
+        __syncthreads();
+        // ---- delete_point (array_utils.f90:433-458): the last list element moves into the hole;
+        //      find_min_loglikelihoods (run_time_info.f90:883-909) for the shrunk cluster, one pass.
+        vk_t best{PC_HUGE, 0x7fffffff};
+        for (int s = tid; s < Ncap; s += NT) {
+            if (H.sC[s] != cd) continue;
+            int p = H.sP[s];
+            if (p == n - 1) { p = pos_del; H.sP[s] = p; }
+            best = vk_min(best, vk_t{H.sL[s], p});
+        }
+        best = block_argmin<NT>(best, H.red);
+        __syncthreads();
+        // slot of the new minimum: the one whose (logL,pos) equals the winner
+        if (n - 1 > 0) {
+            for (int s = tid; s < Ncap; s += NT)
+                if (H.sC[s] == cd && H.sP[s] == best.k) H.misc[0] = s;
+            __syncthreads();
+            if (tid == 0) { H.cMinSlot[cd] = H.misc[0]; H.cLogLp[cd] = best.v; }
+        } else if (tid == 0) { H.cMinSlot[cd] = -1; H.cLogLp[cd] = PC_HUGE; }
+        __syncthreads();
+        // posterior-stack columns (calculate.f90:53-79): volume after the update, logZ after the update
+        double mX = H.cLogXp[0];
+        for (int c = 1; c < nc; ++c) mX = fmax(mX, H.cLogXp[c]);
+        double sX = 0.0;
+        for (int c = 0; c < nc; ++c) sX += exp(H.cLogXp[c] - mX);
+        const double lseX = (nc == 1) ? H.cLogXp[0] : mX + log(sX);
+        if (ndead >= S.Dcap) { error = PC_ERR_DEAD_CAP; status = PC_ST_ERROR; }
+        if (status != PC_ST_ERROR) {
+            if (plan_w >= 0) {
+                if (tid == 0) {
+                    const int src = S.slot_src[slot_del];
+                    S.pl_dead_idx[plan_w] = ndead;
+                    S.pl_dead_src[plan_w] = (src >= 0) ? -(1 + src) : slot_del;
+                    S.pl_logw[plan_w] = logweight; S.pl_postX[plan_w] = lseX; S.pl_postZ[plan_w] = logZ;
+                    S.pl_dead_cuid[plan_w] = H.cUid[cd];
+                }
+            } else {   // kill-off / trimming: rows are current in live[], copy immediately
+                const double *row = S.live + (size_t)slot_del * nT;
+                double *dst = S.dead + (size_t)ndead * nT;
+                for (int e = tid; e < nT; e += NT) dst[e] = row[e];
+                if (tid == 0) {
+                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lseX; S.dead_postZ[ndead] = logZ;
+                    S.dead_cuid[ndead] = H.cUid[cd];
+                }
+            }
+        }
+        ndead++;
+        return slot_del;
+    };
+
+    // delete_cluster (run_time_info.f90:507-598): drop the first empty cluster, keep the others' order
+    auto drop_empty_cluster = [&]() -> bool {
+        int p = -1;
+        for (int c = 0; c < nc; ++c) if (H.cN[c] == 0) { p = c; break; }
+        if (p < 0) return false;
+        __syncthreads();
+        if (tid == 0) {
+            if (nc_dead < S.maxc_dead) {
+                S.logZp_dead[nc_dead] = H.cLogZp[p]; S.logZp2_dead[nc_dead] = H.cLogZp2[p];
+            }
+        }
+        nc_dead++;
+        // XpXq compaction (row-major in place is safe: targets are lexicographically <= sources)
+        if (tid == 0) {
+            for (int a = 0, na = 0; a < nc; ++a) {
+                if (a == p) continue;
+                for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; S.XpXq[(size_t)na * maxc + nb] = S.XpXq[(size_t)a * maxc + b]; nb++; }
+                na++;
+            }
+            for (int c = p; c < nc - 1; ++c) {
+                H.cLogLp[c] = H.cLogLp[c + 1]; H.cLogXp[c] = H.cLogXp[c + 1]; H.cLogZp[c] = H.cLogZp[c + 1];
+                H.cLogZXp[c] = H.cLogZXp[c + 1]; H.cLogZp2[c] = H.cLogZp2[c + 1]; H.cLogZpXp[c] = H.cLogZpXp[c + 1];
+                H.cLseRef[c] = H.cLseRef[c + 1]; H.cLseSum[c] = H.cLseSum[c + 1]; H.cThr[c] = H.cThr[c + 1];
+                H.cN[c] = H.cN[c + 1]; H.cMinSlot[c] = H.cMinSlot[c + 1]; H.cUid[c] = H.cUid[c + 1];
+            }
+        }
+        const int DD = S.D * S.D;
+        for (int c = p; c < nc - 1; ++c) {
+            for (int e = tid; e < DD; e += NT) {
+                S.chol[(size_t)c * DD + e] = S.chol[(size_t)(c + 1) * DD + e];
+                S.cov[(size_t)c * DD + e] = S.cov[(size_t)(c + 1) * DD + e];
+            }
+            __syncthreads();
+        }
+        for (int s = tid; s < Ncap; s += NT) if (H.sC[s] > p) H.sC[s] -= 1;
+        nc--;
+        cluster_deleted = 1;
+        __syncthreads();
+        return true;
+    };
+
+    if (final_mode == 1) {
+        // nested_sampling.F90:381-384: kill every remaining live point, lowest first
+        while (nc > 0 && status == PC_ST_RUNNING) {
+            kill_lowest(-1);
+            drop_empty_cluster();
+        }
+        status = PC_ST_DONE;
+    } else if (final_mode == 2) {
+        // nested_sampling.F90:201-205: nprior > nlive, trim the initial set down to nlive
+        while (H.cN[0] > S.N && status == PC_ST_RUNNING) kill_lowest(-1);
+    }
+
+    // ================================================================================
+    // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
+    // ================================================================================
+    while (!final_mode && status == PC_ST_RUNNING) {
+        // ---- more_samples_needed (nested_sampling.F90:514-543) + failures guard (:239)
+        bool more = true;
+        if (S.max_ndead == 0) more = false;
+        else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
+        else if (S.use_prec) {
+            // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally
+            double v = S.logzero;
+            for (int c = 0; c < nc; ++c)
+                if (H.cN[c] > 0) v = pc_logaddexp(v, H.cLseRef[c] + log(H.cLseSum[c]) - log((double)H.cN[c] + 0.0) + H.cLogXp[c]);
+            live_logZ_val = v;
+            if (v < S.log_prec + logZ) more = false;
+        }
+        if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
+        if (i_nursery == 0) break;                      // batch exhausted: host launches the next one
+
+        const int w = i_nursery - 1;
+        i_nursery--;
+        nlike += S.ch_nlike[w];
+        niter++;
+        if (tid == 0) { S.pl_dead_idx[w] = -1; S.pl_ph_base[w] = nph; for (int m = 0; m < PC_MASK_WORDS; ++m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m] = 0ull; }
+        __syncthreads();
+        if (S.ch_epoch[w] != epoch) continue;           // nested_sampling.F90:313 epoch guard
+
+        const int ca = S.ch_cluster[w];
+        // ---- replace_point (run_time_info.f90:716-787)
+        double Lg = H.cLogLp[0];
+        for (int c = 1; c < nc; ++c) Lg = fmin(Lg, H.cLogLp[c]);
+        const double *blog = S.baby_logL + (size_t)w * nr;
+        // phantoms: babies 1..nr-1 that beat the global contour and fall in the seed cluster's cell
+        int nph_add = 0;
+        if (nc == 1) {
+            for (int base = 0; base < nr - 1; base += NT) {
+                const int i = base + tid;
+                const bool f = (i < nr - 1) && (blog[i] > Lg);
+                const unsigned long long m = __ballot(f);
+                if (lane == 0 && m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + (base >> 6) + (tid >> 6)] = m;
+                if (NT == 64) nph_add += __popcll(m);
+            }
+            if (NT > 64) {   // count after the masks are visible
+                __syncthreads();
+                for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m]);
+            }
+        } else {
+            for (int i = 0; i < nr - 1; ++i) {
+                if (!(blog[i] > Lg)) continue;
+                const int id = block_identify<NT>(S, H, S.babies + ((size_t)w * nr + i) * nT, nc);
+                if (id == ca) {
+                    if (tid == 0) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + (i >> 6)] |= (1ull << (i & 63));
+                    nph_add++;
+                }
+            }
+        }
+        if (nph + nph_add > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
+        if (tid == 0) S.pl_ph_cuid[w] = H.cUid[ca];
+        nph += nph_add;
+
+        const double Llast = blog[nr - 1];
+        bool replaced = false;
+        if (Llast > Lg) {
+            const int id = block_identify<NT>(S, H, S.babies + ((size_t)w * nr + nr - 1) * nT, nc);
+            if (id == ca) {
+                const int nl = nlive_target(S, Lg);
+                int tot = 0;
+                for (int c = 0; c < nc; ++c) tot += H.cN[c];
+                int free_slot = -1;
+                if (tot >= (nl > 1 ? nl : 1)) { free_slot = kill_lowest(w); replaced = true; tot--; }
+                if (status == PC_ST_ERROR) break;
+                if (tot < nl) {
+                    if (free_slot < 0) {               // growing live set: take any free slot
+                        if (tid == 0) H.misc[1] = -1;
+                        __syncthreads();
+                        for (int s = tid; s < Ncap; s += NT) if (H.sC[s] < 0) atomicMax(&H.misc[1], s);
+                        __syncthreads();
+                        free_slot = H.misc[1];
+                        if (free_slot < 0) { status = PC_ST_ERROR; error = PC_ERR_NOSLOT; break; }
+                    }
+                    // add_point + find_min_loglikelihoods for the receiving cluster
+                    if (tid == 0) {
+                        const int pos = H.cN[ca];
+                        H.sL[free_slot] = Llast; H.sC[free_slot] = ca; H.sP[free_slot] = pos;
+                        H.cN[ca] = pos + 1;
+                        if (pos == 0 || Llast < H.cLogLp[ca]) { H.cLogLp[ca] = Llast; H.cMinSlot[ca] = free_slot; }
+                        // live logsumexp of the cluster
+                        if (pos == 0) { H.cLseRef[ca] = Llast; H.cLseSum[ca] = 1.0; }
+                        else if (Llast > H.cLseRef[ca]) { H.cLseSum[ca] = H.cLseSum[ca] * exp(H.cLseRef[ca] - Llast) + 1.0; H.cLseRef[ca] = Llast; }
+                        else H.cLseSum[ca] += exp(Llast - H.cLseRef[ca]);
+                        S.slot_src[free_slot] = w;
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
+            // failed spawn: the last baby is recorded as dead with zero weight (run_time_info.f90:781-785)
+            if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
+            if (tid == 0) {
+                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = -(1 + w);
+                S.pl_logw[w] = S.logzero; S.pl_postX[w] = 0.0; S.pl_postZ[w] = 0.0; S.pl_dead_cuid[w] = 0xFFFFFFFFu;
+            }
+            ndead++;
+        }
+        failures = replaced ? 0 : failures + 1;
+
+        // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
+        double mX = H.cLogXp[0];
+        for (int c = 1; c < nc; ++c) mX = fmax(mX, H.cLogXp[c]);
+        double sX = 0.0;
+        for (int c = 0; c < nc; ++c) sX += exp(H.cLogXp[c] - mX);
+        const double lx = (nc == 1) ? H.cLogXp[0] : mX + log(sX);
+        const bool update = lx <= lx_last + S.log_cf;
+        if (update) lx_last = lx;
+        if (drop_empty_cluster()) epoch++;
+        if (nc == 0) { status = PC_ST_DONE; break; }
+        if (update) { status = PC_ST_UPDATE; break; }
+    }
+
+    // ---- write the state back
+    __syncthreads();
+    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
+    for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
+    for (int c = tid; c < maxc; c += NT) {
+        S.logLp[c] = H.cLogLp[c]; S.logXp[c] = H.cLogXp[c]; S.logZp[c] = H.cLogZp[c]; S.logZXp[c] = H.cLogZXp[c];
+        S.logZp2[c] = H.cLogZp2[c]; S.logZpXp[c] = H.cLogZpXp[c]; S.lse_ref[c] = H.cLseRef[c]; S.lse_sum[c] = H.cLseSum[c];
+        S.death_thr[c] = H.cThr[c]; S.cl_n[c] = H.cN[c]; S.imin_slot[c] = H.cMinSlot[c]; S.cl_uid[c] = H.cUid[c];
+    }
+    if (tid == 0) {
+        ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->admin_epoch = epoch;
+        ctl->failures = failures; ctl->ncluster = nc; ctl->ncluster_dead = nc_dead; ctl->ndead = ndead;
+        ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
+        ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
+        ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// apply the plan: dead rows + phantoms (reads live[] before k_apply_live overwrites slots)
+// one wave per consumed chain
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
+{
+    const PcCtl *ctl = S.ctl;
+    const int w = ctl->seg_lo + blockIdx.x;
+    if (w > ctl->seg_hi) return;
+    const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
+    const int di = S.pl_dead_idx[w];
+    if (di >= 0) {
+        const int src = S.pl_dead_src[w];
+        const double *row = (src >= 0) ? S.live + (size_t)src * nT
+                                       : S.babies + ((size_t)(-src - 1) * nr + (nr - 1)) * nT;
+        double *dst = S.dead + (size_t)di * nT;
+        for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+        if (lane == 0) {
+            S.dead_logw[di] = S.pl_logw[w]; S.dead_postX[di] = S.pl_postX[w]; S.dead_postZ[di] = S.pl_postZ[w];
+            S.dead_cuid[di] = S.pl_dead_cuid[w];
+        }
+    }
+    int base = S.pl_ph_base[w];
+    const unsigned cuid = S.pl_ph_cuid[w];
+    for (int m = 0; m < (nr + 62) / 64; ++m) {
+        unsigned long long mask = S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m];
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int i = m * 64 + b;
+            const double *row = S.babies + ((size_t)w * nr + i) * nT;
+            double *dst = S.phantom + (size_t)base * nT;
+            for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+            if (lane == 0) {
+                S.ph_logL[base] = row[S.l0]; S.ph_cuid[base] = cuid;
+                S.ph_uid[base] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
+            }
+            base++;
+        }
+    }
+}
+
+// new live rows: every slot now owned by a chain's last baby
+__global__ __launch_bounds__(64) void k_apply_live(PcState S)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x, nT = S.nT, nr = S.nr;
+    const int src = S.slot_src[slot];
+    if (src < 0) return;
+    const double *row = S.babies + ((size_t)src * nr + (nr - 1)) * nT;
+    double *dst = S.live + (size_t)slot * nT;
+    for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+    __syncthreads();
+    if (lane == 0) S.slot_src[slot] = -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// install the initial live set: rows -> slots, labels, contour (generate.F90:291-320)
+// single workgroup; also trims nprior > nlive through k_consume(final)-like deaths on the host side
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_install_live(PcState S, const double *rows, int n)
+{
+    const int tid = threadIdx.x;
+    __shared__ vk_t red[4];
+    for (int s = tid; s < S.Ncap; s += 256) {
+        if (s < n) {
+            for (int e = 0; e < S.nT; ++e) S.live[(size_t)s * S.nT + e] = rows[(size_t)s * S.nT + e];
+            S.live_logL[s] = rows[(size_t)s * S.nT + S.l0]; S.live_cluster[s] = 0; S.live_pos[s] = s;
+            S.cl_list[s] = s;
+        } else { S.live_logL[s] = PC_HUGE; S.live_cluster[s] = -1; S.live_pos[s] = 0; }
+        S.slot_src[s] = -1;
+    }
+    __syncthreads();
+    vk_t best{PC_HUGE, 0x7fffffff};
+    double mx = -PC_HUGE;
+    for (int s = tid; s < n; s += 256) { best = vk_min(best, vk_t{S.live_logL[s], s}); mx = fmax(mx, S.live_logL[s]); }
+    best = block_argmin<256>(best, red);
+    __shared__ double smx[4];
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) smx[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    double sum = 0.0;
+    for (int s = tid; s < n; s += 256) sum += exp(S.live_logL[s] - mx);
+    sum = wave_sum<4>(sum);
+    __syncthreads();
+    if ((tid & 63) == 0) smx[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        S.cl_n[0] = n; S.logLp[0] = best.v; S.imin_slot[0] = best.k;
+        S.lse_ref[0] = mx; S.lse_sum[0] = (smx[0] + smx[1]) + (smx[2] + smx[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// update step 1: clean_phantoms (run_time_info.f90:820-877)
+// A phantom of cluster c is dropped iff some death of c since the last clean has a larger logL,
+// i.e. iff its logL < the logL of c's latest death; phantoms of dead clusters are dropped too.
+// Deterministic 3-kernel stream compaction into the alternate phantom buffer.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cluster_of_uid(const PcState &S, unsigned uid, int nc)
+{
+    for (int c = 0; c < nc; ++c) if (S.cl_uid[c] == uid) return c;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned char *keep, int *blk_count)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int nc = S.ctl->ncluster;
+    bool k = false;
+    if (j < nph) {
+        const int c = cluster_of_uid(S, S.ph_cuid[j], nc);
+        k = (c >= 0) && !(S.ph_logL[j] < S.death_thr[c]);
+        keep[j] = k ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(k);
+    __shared__ int cnt[4];
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total)
+{   // exclusive scan, single workgroup, fixed order
+    __shared__ int carry;
+    __shared__ int tmp[256];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? blk_count[i] : 0;
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int t = threadIdx.x >= off ? tmp[threadIdx.x - off] : 0;
+            __syncthreads();
+            tmp[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) blk_count[i] = carry + tmp[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += tmp[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const unsigned char *keep, const int *blk_off,
+                                                      double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                      int *dst_index /* [nph] or nullptr */)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool k = (j < nph) && keep[j];
+    const unsigned long long m = __ballot(k);
+    __shared__ int wcnt[4];
+    if (lane == 0) wcnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = blk_off[blockIdx.x];
+    for (int i = 0; i < wid; ++i) off += wcnt[i];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (dst_index && j < nph) dst_index[j] = k ? off : -1;
+    if (k) {
+        phL2[off] = S.ph_logL[j]; phC2[off] = S.ph_cuid[j]; phU2[off] = S.ph_uid[j];
+        const double *row = S.phantom + (size_t)j * S.nT;
+        double *dst = ph2 + (size_t)off * S.nT;
+        for (int e = 0; e < S.nT; ++e) dst[e] = row[e];
+    }
+}
+
+__global__ void k_reset_thresholds(PcState S) { if (threadIdx.x < S.maxc) S.death_thr[threadIdx.x] = -PC_HUGE; }
+
+// ------------------------------------------------------------------------------------------
+// update step 2: calculate_covmats (run_time_info.f90:601-641), two passes, fixed-order sums
+// pass A: per (chunk, cluster) partial sums of cube coordinates; pass B: centred outer products
+// rows = live slots followed by phantoms.  partial buffers: [nchunk][nc][D] and [nchunk][nc][D*D]
+// ------------------------------------------------------------------------------------------
+#define PC_COV_ROWS 256          /* rows per chunk */
+
+__device__ __forceinline__ const double *cov_row(const PcState &S, int r, int nlive_slots, int nc, int &c)
+{
+    if (r < nlive_slots) { c = S.live_cluster[r]; return S.live + (size_t)r * S.nT; }
+    const int j = r - nlive_slots;
+    c = cluster_of_uid(S, S.ph_cuid[j], nc);
+    return S.phantom + (size_t)j * S.nT;
+}
+
+__global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, int nph, double *psum, int *pcnt)
+{
+    // grid (nchunk, nc); thread d < D sums coordinate d over the chunk's rows of cluster c, in row order
+    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
+    const int r0 = chunk * PC_COV_ROWS, r1 = min(nrows, r0 + PC_COV_ROWS);
+    __shared__ int rc[PC_COV_ROWS];
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) { int cc; cov_row(S, r, S.Ncap, nc, cc); rc[r - r0] = cc; }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r)
+            if (rc[r - r0] == c) { int cc; s += cov_row(S, r, S.Ncap, nc, cc)[d]; }
+        psum[((size_t)chunk * nc + c) * D + d] = s;
+    }
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int r = r0; r < r1; ++r) n += (rc[r - r0] == c);
+        pcnt[(size_t)chunk * nc + c] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cov_mean_final(PcState S, int nchunk, const double *psum, const int *pcnt,
+                                                       double *mean /* [nc][D] */, int *count /* [nc] */)
+{
+    const int c = blockIdx.x, nc = gridDim.x, D = S.D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += psum[((size_t)k * nc + c) * D + d];
+        int n = 0;
+        for (int k = 0; k < nchunk; ++k) n += pcnt[(size_t)k * nc + c];
+        mean[(size_t)c * D + d] = s / (double)n;
+        if (d == 0) count[c] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, const double *mean, double *pcov)
+{
+    // grid (nchunk, nc); LDS tile of centred rows, thread (a,b) accumulates over rows in order
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
+    const int r0 = chunk * PC_COV_ROWS, r1 = min(nrows, r0 + PC_COV_ROWS);
+    double *tile = (double *)smem;               // [rows][D+1]
+    int *rc = (int *)(tile + (size_t)PC_COV_ROWS * (D + 1));
+    __shared__ int nsel;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int r = r0; r < r1; ++r) { int cc; cov_row(S, r, S.Ncap, nc, cc); if (cc == c) rc[n++] = r; }
+        nsel = n;
+    }
+    __syncthreads();
+    const int n = nsel;
+    for (int e = threadIdx.x; e < n * D; e += 256) {
+        const int i = e / D, d = e % D; int cc;
+        tile[(size_t)i * (D + 1) + d] = cov_row(S, rc[i], S.Ncap, nc, cc)[d] - mean[(size_t)c * D + d];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < D * D; p += 256) {
+        const int a = p / D, b = p % D;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += tile[(size_t)i * (D + 1) + a] * tile[(size_t)i * (D + 1) + b];
+        pcov[((size_t)chunk * nc + c) * D * D + p] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count)
+{
+    // one workgroup per cluster: fixed-order sum of the partials, then calc_cholesky (utils.F90:621-649)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D;
+    double *A = (double *)smem, *L = A + DD;
+    __shared__ int bad;
+    const double n = (double)count[c];
+    for (int p = threadIdx.x; p < DD; p += 256) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += pcov[((size_t)k * nc + c) * DD + p];
+        A[p] = s / n; L[p] = 0.0;
+        S.cov[(size_t)c * DD + p] = A[p];
+    }
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int i = 0; i < D; ++i) {
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int k = 0; k < i; ++k) s += L[i * D + k] * L[i * D + k];
+            const double dii = A[i * D + i] - s;
+            if (dii <= 0.0) bad = 1; else L[i * D + i] = sqrt(dii);
+        }
+        __syncthreads();
+        if (bad) break;
+        for (int j = i + 1 + threadIdx.x; j < D; j += 256) {
+            double t = 0.0;
+            for (int k = 0; k < i; ++k) t += L[i * D + k] * L[j * D + k];
+            L[j * D + i] = (A[i * D + j] - t) / L[i * D + i];
+        }
+        __syncthreads();
+    }
+    if (bad) {   // no Cholesky factor: scaled identity (utils.F90:633-638)
+        double tr = 0.0;
+        for (int k = 0; k < D; ++k) tr += A[k * D + k];
+        for (int p = threadIdx.x; p < DD; p += 256) L[p] = (p / D == p % D) ? sqrt(tr) : 0.0;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < DD; p += 256) S.chol[(size_t)c * DD + p] = L[p];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static size_t consume_lds(const PcState *S, int NT)
+{
+    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
+           sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8) + 64;
+}
+
+extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hipStream_t st)
+{
+    if (wide) {
+        const size_t sh = consume_lds(S, 1024);
+        if (sh > 160 * 1024) return 1;
+        hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode);
+    } else {
+        const size_t sh = consume_lds(S, 64);
+        if (sh > 160 * 1024) return 1;
+        hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode);
+    }
+    return 0;
+}
+
+extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64), 0, st, *S, batch);
+    hipLaunchKernelGGL(k_apply_live, dim3(S->Ncap), dim3(64), 0, st, *S);
+}
+
+extern "C" void pc_launch_install_live(const PcState *S, const double *rows, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_install_live, dim3(1), dim3(256), 0, st, *S, rows, n);
+}
+
+// phantom clean: returns nothing; *d_total (device int) receives the surviving count
+extern "C" void pc_launch_clean(const PcState *S, int nph, unsigned char *keep, int *blk, int *d_total, double *ph2,
+                                double *phL2, unsigned *phC2, unsigned long long *phU2, int *dst_index, hipStream_t st)
+{
+    const int nblk = (nph + 255) / 256;
+    if (nblk > 0) {
+        hipLaunchKernelGGL(k_clean_flag, dim3(nblk), dim3(256), 0, st, *S, nph, keep, blk);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, blk, nblk, d_total);
+        hipLaunchKernelGGL(k_clean_scatter, dim3(nblk), dim3(256), 0, st, *S, nph, keep, blk, ph2, phL2, phC2, phU2, dst_index);
+    } else {
+        hipMemsetAsync(d_total, 0, sizeof(int), st);
+    }
+}
+
+extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
+}
+
+extern "C" int pc_cov_nchunk(const PcState *S, int nph) { return (S->Ncap + nph + PC_COV_ROWS - 1) / PC_COV_ROWS; }
+
+extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum, int *pcnt, double *mean, int *count,
+                                 double *pcov, hipStream_t st)
+{
+    const int nrows = S->Ncap + nph, nchunk = (nrows + PC_COV_ROWS - 1) / PC_COV_ROWS, D = S->D;
+    hipLaunchKernelGGL(k_cov_mean_partial, dim3(nchunk, nc), dim3(256), 0, st, *S, nrows, nph, psum, pcnt);
+    hipLaunchKernelGGL(k_cov_mean_final, dim3(nc), dim3(256), 0, st, *S, nchunk, psum, pcnt, mean, count);
+    const size_t sh = sizeof(double) * (size_t)PC_COV_ROWS * (D + 1) + sizeof(int) * PC_COV_ROWS;
+    if (sh > 160 * 1024) return 1;
+    hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, mean, pcov);
+    const size_t sh2 = sizeof(double) * 2 * (size_t)D * D;
+    hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(256), sh2, st, *S, nchunk, pcov, count);
+    return 0;
+}

@@ -1,0 +1,438 @@
+// pc_engine.hip -- host side of the MI355X nested-sampling engine.
+//
+// Replaces the administrator loop of NestedSampling (src/polychord/nested_sampling.F90:15-510) and
+// the MPI live-point farm (mpi_utils.F90:322-600): the host only enqueues kernels and reads one
+// small control block per round; every point, every evidence accumulator and every decision lives
+// on the device.  One round = [K0 directions | K1 slice chains] (when the nursery is empty)
+// + [K2 consume | K3 apply] + (on an update) [clean phantoms | covariance + Cholesky].
+#include "pc_state.h"
+#include "../../include/polychord_hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <chrono>
+
+extern "C" {
+int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
+int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
+int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
+int pc_launch_consume(const PcState *, int, int, hipStream_t);
+void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
+void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
+void pc_launch_clean(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *,
+                     unsigned long long *, int *, hipStream_t);
+void pc_launch_reset_thresholds(const PcState *, hipStream_t);
+int pc_cov_nchunk(const PcState *, int);
+int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    std::fprintf(stderr, "polychord_hip: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+    std::abort(); } } while (0)
+
+namespace {
+
+template <class T> T *dalloc(size_t n)
+{
+    T *p = nullptr;
+    HIPCHK(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)));
+    return p;
+}
+template <class T> void dfree(T *&p) { if (p) hipFree((void *)p); p = nullptr; }
+
+struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
+
+struct Engine {
+    pchip_settings cfg{};
+    PcState S{};
+    hipStream_t st = nullptr;
+    PcCtl *h_ctl = nullptr;       // pinned mirror
+    // alternate phantom buffers + scratch for the update step
+    double *ph2 = nullptr, *phL2 = nullptr; unsigned *phC2 = nullptr; unsigned long long *phU2 = nullptr;
+    unsigned char *keep = nullptr; int *blk = nullptr, *d_total = nullptr;
+    double *psum = nullptr, *mean = nullptr, *pcov = nullptr; int *pcnt = nullptr, *count = nullptr;
+    size_t cov_chunks_cap = 0;
+    double *d_lo = nullptr, *d_hi = nullptr, *d_invcovT = nullptr, *d_mean = nullptr;
+    double *d_dynL = nullptr; int *d_dynN = nullptr;
+    Timing tm;
+    int B = 0;
+
+    void alloc_phantom_side(int Pcap)
+    {
+        ph2 = dalloc<double>((size_t)Pcap * S.nT); phL2 = dalloc<double>(Pcap); phC2 = dalloc<unsigned>(Pcap);
+        phU2 = dalloc<unsigned long long>(Pcap); keep = dalloc<unsigned char>(Pcap); blk = dalloc<int>((Pcap + 255) / 256 + 1);
+    }
+
+    void setup(const pchip_settings &c, const pchip_like &like, const pchip_prior &prior)
+    {
+        cfg = c;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+            std::fprintf(stderr, "polychord_hip: no HIP device available -- this engine has no CPU path\n");
+            std::abort();
+        }
+        HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
+        HIPCHK(hipStreamCreate(&st));
+        const int D = c.nDims, nDer = c.nDerived;
+        S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
+        S.p0 = D; S.d0 = 2 * D; S.b0 = 2 * D + nDer; S.l0 = S.b0 + 1;
+        int nmax = c.nlive;
+        for (int i = 0; i < c.n_nlives; ++i) nmax = std::max(nmax, c.nlives[i]);
+        const int nprior = c.nprior <= 0 ? c.nlive : c.nprior;
+        S.Ncap = std::max(nmax, nprior);
+        B = c.batch > 0 ? c.batch : std::max(1, std::min(1024, c.nlive / 2));
+        S.B = B;
+        S.maxc = c.do_clustering ? 128 : 4;
+        S.maxc_dead = 4096;
+        S.Pcap = (int)std::min<long long>(2000000000LL / S.nT, 4LL * S.nr * S.Ncap + 4LL * B * S.nr + 1024);
+        S.Dcap = 64 * S.Ncap + 4 * B + 1024;
+        S.k0 = (uint32_t)c.seed; S.k1 = 0x504F4C59u;
+        S.logzero = c.logzero; S.use_prec = c.precision_criterion > 0;
+        S.log_prec = S.use_prec ? std::log(c.precision_criterion) : 0.0;
+        S.log_cf = std::log(c.compression_factor);
+        S.max_ndead = c.max_ndead; S.nfail = c.nfail <= 0 ? c.nlive : c.nfail;
+        S.seed_override = 0;
+        // dynamic nlive tables
+        S.n_nlives = c.n_nlives;
+        if (c.n_nlives > 0) {
+            d_dynL = dalloc<double>(c.n_nlives); d_dynN = dalloc<int>(c.n_nlives);
+            HIPCHK(hipMemcpy(d_dynL, c.loglikes, sizeof(double) * c.n_nlives, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_dynN, c.nlives, sizeof(int) * c.n_nlives, hipMemcpyHostToDevice));
+        }
+        S.dyn_loglikes = d_dynL; S.dyn_nlives = d_dynN;
+        // likelihood / prior
+        S.like.kind = like.kind; S.like.mu = like.mu; S.like.sigma = like.sigma; S.like.logdetcov = like.logdetcov;
+        S.like.invcov = nullptr; S.like.mean = nullptr;
+        if (like.kind == PC_LIKE_CORR_GAUSSIAN) {
+            std::vector<double> T((size_t)D * D);
+            for (int a = 0; a < D; ++a) for (int b = 0; b < D; ++b) T[(size_t)b * D + a] = like.invcov[(size_t)a * D + b];
+            d_invcovT = dalloc<double>((size_t)D * D); d_mean = dalloc<double>(D);
+            HIPCHK(hipMemcpy(d_invcovT, T.data(), sizeof(double) * D * D, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_mean, like.mean, sizeof(double) * D, hipMemcpyHostToDevice));
+            S.like.invcov = d_invcovT; S.like.mean = d_mean;
+        }
+        S.prior.kind = prior.kind; S.prior.lo = nullptr; S.prior.hi = nullptr;
+        if (prior.kind == 1 && prior.lo && prior.hi) {
+            d_lo = dalloc<double>(D); d_hi = dalloc<double>(D);
+            HIPCHK(hipMemcpy(d_lo, prior.lo, sizeof(double) * D, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_hi, prior.hi, sizeof(double) * D, hipMemcpyHostToDevice));
+            S.prior.lo = d_lo; S.prior.hi = d_hi;
+        }
+        // state arrays
+        const int Ncap = S.Ncap, maxc = S.maxc, nT = S.nT, nr = S.nr;
+        S.live = dalloc<double>((size_t)Ncap * nT); S.live_logL = dalloc<double>(Ncap);
+        S.live_cluster = dalloc<int>(Ncap); S.live_pos = dalloc<int>(Ncap);
+        S.cl_list = dalloc<int>((size_t)maxc * Ncap); S.cl_n = dalloc<int>(maxc);
+        S.logZp = dalloc<double>(maxc); S.logXp = dalloc<double>(maxc); S.logZXp = dalloc<double>(maxc);
+        S.logZp2 = dalloc<double>(maxc); S.logZpXp = dalloc<double>(maxc); S.logLp = dalloc<double>(maxc);
+        S.XpXq = dalloc<double>((size_t)maxc * maxc); S.imin_slot = dalloc<int>(maxc);
+        S.lse_ref = dalloc<double>(maxc); S.lse_sum = dalloc<double>(maxc); S.death_thr = dalloc<double>(maxc);
+        S.cl_uid = dalloc<unsigned>(maxc);
+        S.chol = dalloc<double>((size_t)maxc * D * D); S.cov = dalloc<double>((size_t)maxc * D * D);
+        S.logZp_dead = dalloc<double>(S.maxc_dead); S.logZp2_dead = dalloc<double>(S.maxc_dead);
+        S.phantom = dalloc<double>((size_t)S.Pcap * nT); S.ph_logL = dalloc<double>(S.Pcap);
+        S.ph_cuid = dalloc<unsigned>(S.Pcap); S.ph_uid = dalloc<unsigned long long>(S.Pcap);
+        alloc_phantom_side(S.Pcap);
+        S.dead = dalloc<double>((size_t)S.Dcap * nT); S.dead_logw = dalloc<double>(S.Dcap);
+        S.dead_postX = dalloc<double>(S.Dcap); S.dead_postZ = dalloc<double>(S.Dcap); S.dead_cuid = dalloc<unsigned>(S.Dcap);
+        S.babies = dalloc<double>((size_t)B * nr * nT); S.baby_logL = dalloc<double>((size_t)B * nr);
+        S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
+        S.ch_contour = dalloc<double>(B);
+        S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
+        S.pl_dead_idx = dalloc<int>(B); S.pl_dead_src = dalloc<int>(B); S.pl_logw = dalloc<double>(B);
+        S.pl_postX = dalloc<double>(B); S.pl_postZ = dalloc<double>(B); S.pl_dead_cuid = dalloc<unsigned>(B);
+        S.pl_ph_base = dalloc<int>(B); S.pl_ph_mask = dalloc<unsigned long long>((size_t)B * PC_MASK_WORDS);
+        S.pl_ph_cuid = dalloc<unsigned>(B); S.slot_src = dalloc<int>(Ncap);
+        S.ctl = dalloc<PcCtl>(1);
+        d_total = dalloc<int>(1);
+        HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(PcCtl)));
+        // per-cluster initial values (initialise_run_time_info, run_time_info.f90:164-206)
+        std::vector<double> lz(maxc, c.logzero), zero(maxc, 0.0), hugeneg(maxc, -PC_HUGE);
+        std::vector<double> xq((size_t)maxc * maxc, 0.0), eye((size_t)maxc * D * D, 0.0);
+        for (int m = 0; m < maxc; ++m) for (int d = 0; d < D; ++d) eye[(size_t)m * D * D + d * D + d] = 1.0;
+        HIPCHK(hipMemcpy(S.logZp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logZXp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logZp2, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logZpXp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logLp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logXp, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.lse_ref, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.lse_sum, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.death_thr, hugeneg.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.XpXq, xq.data(), sizeof(double) * maxc * maxc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.chol, eye.data(), sizeof(double) * maxc * D * D, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.cov, eye.data(), sizeof(double) * maxc * D * D, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(S.cl_n, 0, sizeof(int) * maxc));
+        HIPCHK(hipMemset(S.cl_uid, 0, sizeof(unsigned) * maxc));
+        HIPCHK(hipMemset(S.imin_slot, 0, sizeof(int) * maxc));
+        PcCtl c0{};
+        c0.status = PC_ST_RUNNING; c0.ncluster = 1; c0.logZ = c.logzero; c0.logZ2 = c.logzero;
+        c0.logX_last_update = 0.0; c0.next_cluster_uid = 1; c0.live_logZ = c.logzero;
+        HIPCHK(hipMemcpy(S.ctl, &c0, sizeof(PcCtl), hipMemcpyHostToDevice));
+        *h_ctl = c0;
+    }
+
+    void read_ctl()
+    {
+        HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+
+    void ensure_capacity()
+    {   // the next batch may append B*nr phantoms and B dead points
+        if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) {
+            const int nd = S.Dcap * 2;
+            auto grow = [&](auto *&p, size_t per) {
+                using T = std::remove_reference_t<decltype(*p)>;
+                T *q = dalloc<T>((size_t)nd * per);
+                HIPCHK(hipMemcpyAsync(q, p, sizeof(T) * (size_t)h_ctl->ndead * per, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                hipFree(p); p = q;
+            };
+            grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1);
+            S.Dcap = nd;
+        }
+        if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) {
+            std::fprintf(stderr, "polychord_hip: phantom capacity exceeded (%d + %d*%d > %d)\n", h_ctl->nphantom, B, S.nr, S.Pcap);
+            std::abort();
+        }
+    }
+
+    // clean_phantoms + calculate_covmats (nested_sampling.F90:326-368 minus file output / clustering)
+    void do_update()
+    {
+        tm.updates++;
+        const int nph = h_ctl->nphantom, nc = h_ctl->ncluster;
+        pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
+        int total = 0;
+        HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
+        h_ctl->nphantom = total;
+        HIPCHK(hipMemcpyAsync(&S.ctl->nphantom, &h_ctl->nphantom, sizeof(int), hipMemcpyHostToDevice, st));
+        pc_launch_reset_thresholds(&S, st);
+        covmats(total, nc);
+    }
+
+    void covmats(int nph, int nc)
+    {
+        const size_t nchunk = pc_cov_nchunk(&S, nph);
+        if (nchunk * nc > cov_chunks_cap) {
+            dfree(psum); dfree(pcnt); dfree(pcov); dfree(mean); dfree(count);
+            cov_chunks_cap = nchunk * nc * 2;
+            psum = dalloc<double>(cov_chunks_cap * S.D); pcnt = dalloc<int>(cov_chunks_cap);
+            pcov = dalloc<double>(cov_chunks_cap * S.D * S.D);
+            mean = dalloc<double>((size_t)S.maxc * S.D); count = dalloc<int>(S.maxc);
+        }
+        if (pc_launch_covmats(&S, nph, nc, psum, pcnt, mean, count, pcov, st)) {
+            std::fprintf(stderr, "polychord_hip: covariance tile exceeds LDS (nDims too large)\n"); std::abort();
+        }
+    }
+
+    void generate_live()
+    {   // GenerateLivePoints (generate.F90:150-183): keep the first nprior valid prior samples
+        const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT;
+        double *rows = dalloc<double>((size_t)nprior * nT), *rl = dalloc<double>(nprior);
+        std::vector<double> keep_rows; keep_rows.reserve((size_t)nprior * nT);
+        std::vector<double> hrows((size_t)nprior * nT), hl(nprior);
+        int have = 0, attempt0 = 0;
+        long long nlike = 0;
+        bool direct = true;
+        while (have < nprior) {
+            if (pc_launch_generate_live(&S, attempt0, nprior, rows, rl, st)) { std::fprintf(stderr, "polychord_hip: nDims > 256 unsupported\n"); std::abort(); }
+            HIPCHK(hipMemcpyAsync(hl.data(), rl, sizeof(double) * nprior, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            int nvalid = 0;
+            for (int i = 0; i < nprior; ++i) nvalid += hl[i] > cfg.logzero;
+            if (nvalid == nprior && have == 0) { have = nprior; nlike = nprior; break; }   // common case: all valid
+            direct = false;
+            HIPCHK(hipMemcpy(hrows.data(), rows, sizeof(double) * (size_t)nprior * nT, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nprior && have < nprior; ++i)
+                if (hl[i] > cfg.logzero) { keep_rows.insert(keep_rows.end(), hrows.begin() + (size_t)i * nT, hrows.begin() + (size_t)(i + 1) * nT); have++; nlike++; }
+            attempt0 += nprior;
+        }
+        if (!direct) HIPCHK(hipMemcpy(rows, keep_rows.data(), sizeof(double) * (size_t)nprior * nT, hipMemcpyHostToDevice));
+        pc_launch_install_live(&S, rows, nprior, st);
+        h_ctl->nlike = nlike; h_ctl->nlike_device = nlike;
+        HIPCHK(hipMemcpyAsync(&S.ctl->nlike, &h_ctl->nlike, sizeof(long long), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        dfree(rows); dfree(rl);
+        if (nprior > cfg.nlive) {      // nested_sampling.F90:201-205
+            pc_launch_consume(&S, 2, 0, st);
+            read_ctl();
+        }
+    }
+
+    int run(pchip_result *out)
+    {
+        using clk = std::chrono::steady_clock;
+        auto t0 = clk::now();
+        generate_live();
+        auto t1 = clk::now();
+        unsigned batch = 0;
+        const int wide = 0;
+        long long nlike_dev = h_ctl->nlike;
+        while (true) {
+            if (h_ctl->status == PC_ST_DONE) break;
+            if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
+            if (h_ctl->i_nursery == 0) {
+                ensure_capacity();
+                if (pc_launch_nhats(&S, batch, B, st) || pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                batch++; tm.batches++;
+            }
+            if (pc_launch_consume(&S, 0, (h_ctl->ncluster > 1 || cfg.do_clustering) ? 1 : wide, st)) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
+            pc_launch_apply(&S, batch - 1, B, st);
+            read_ctl();
+            tm.rounds++;
+            if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; }
+        }
+        auto t2 = clk::now();
+        // snapshot of the live set at termination, then nested_sampling.F90:381-384
+        const int nT = S.nT;
+        std::vector<double> hlive((size_t)S.Ncap * nT); std::vector<int> hcl(S.Ncap);
+        HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
+        const int nc_end = h_ctl->ncluster;
+        pc_launch_consume(&S, 1, 0, st);
+        read_ctl();
+        auto t3 = clk::now();
+        tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
+        tm.t_loop = std::chrono::duration<double>(t2 - t1).count();
+        tm.t_final = std::chrono::duration<double>(t3 - t2).count();
+        tm.t_total = std::chrono::duration<double>(t3 - t0).count();
+        // ---- results (calculate_logZ_estimate, run_time_info.f90:652-678)
+        std::memset(out, 0, sizeof(*out));
+        out->logZ = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2);
+        out->varlogZ = h_ctl->logZ2 - 2 * h_ctl->logZ;
+        out->ndead = h_ctl->ndead; out->nlike = h_ctl->nlike; out->niter = h_ctl->niter;
+        out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
+        out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
+        out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
+        (void)nlike_dev;
+        out->dead = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, h_ctl->ndead) * nT);
+        out->logweights = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
+        HIPCHK(hipMemcpy(out->dead, S.dead, sizeof(double) * (size_t)h_ctl->ndead * nT, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out->logweights, S.dead_logw, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
+        int nl = 0;
+        for (int s = 0; s < S.Ncap; ++s) nl += hcl[s] >= 0;
+        out->nlive_final = nl;
+        out->live = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, nl) * nT);
+        for (int s = 0, k = 0; s < S.Ncap; ++s) if (hcl[s] >= 0) { std::memcpy(out->live + (size_t)k * nT, hlive.data() + (size_t)s * nT, sizeof(double) * nT); k++; }
+        const int ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead);
+        out->nZp = ncd;
+        out->logZp = (double *)std::malloc(sizeof(double) * std::max(1, ncd));
+        out->varlogZp = (double *)std::malloc(sizeof(double) * std::max(1, ncd));
+        std::vector<double> zp(std::max(1, ncd)), zp2(std::max(1, ncd));
+        HIPCHK(hipMemcpy(zp.data(), S.logZp_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(zp2.data(), S.logZp2_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
+        for (int i = 0; i < ncd; ++i) { out->logZp[i] = 2 * zp[i] - 0.5 * zp2[i]; out->varlogZp[i] = zp2[i] - 2 * zp[i]; }
+        // posterior moments of theta from the dead points
+        const int D = S.D;
+        out->post_mean = (double *)std::calloc(D, sizeof(double)); out->post_var = (double *)std::calloc(D, sizeof(double));
+        double m = -PC_HUGE;
+        for (long i = 0; i < out->ndead; ++i)
+            if (out->logweights[i] > cfg.logzero) m = std::max(m, out->logweights[i] + out->dead[(size_t)i * nT + S.l0]);
+        double sw = 0.0;
+        for (long i = 0; i < out->ndead; ++i) {
+            if (!(out->logweights[i] > cfg.logzero)) continue;
+            const double wgt = std::exp(out->logweights[i] + out->dead[(size_t)i * nT + S.l0] - m);
+            sw += wgt;
+            for (int d = 0; d < D; ++d) { const double th = out->dead[(size_t)i * nT + S.p0 + d]; out->post_mean[d] += wgt * th; out->post_var[d] += wgt * th * th; }
+        }
+        for (int d = 0; d < D; ++d) { out->post_mean[d] /= sw; out->post_var[d] = out->post_var[d] / sw - out->post_mean[d] * out->post_mean[d]; }
+        return 0;
+    }
+
+    void destroy()
+    {
+        double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
+                          &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
+                          &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL,
+                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.pl_logw, &S.pl_postX, &S.pl_postZ, &ph2, &phL2, &psum, &mean,
+                          &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
+        for (auto p : dd) dfree(*p);
+        int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
+                       &S.ch_seed_slot, &S.pl_dead_idx, &S.pl_dead_src, &S.pl_ph_base, &S.slot_src, &blk, &d_total, &pcnt, &count, &d_dynN };
+        for (auto p : ii) dfree(*p);
+        unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &S.pl_dead_cuid, &S.pl_ph_cuid, &phC2 };
+        for (auto p : uu) dfree(*p);
+        dfree(S.ph_uid); dfree(S.pl_ph_mask); dfree(phU2); dfree(keep); dfree(S.ctl);
+        if (h_ctl) hipHostFree(h_ctl); h_ctl = nullptr;
+        if (st) hipStreamDestroy(st); st = nullptr;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void pchip_settings_default(pchip_settings *s, int nDims, int nDerived)
+{   // defaults of the reference's C++ Settings (src/polychord/c_interface.cpp:6-39)
+    std::memset(s, 0, sizeof(*s));
+    s->nDims = nDims; s->nDerived = nDerived; s->nlive = 500; s->num_repeats = 5 * nDims; s->nprior = -1; s->nfail = -1;
+    s->precision_criterion = 0.001; s->logzero = -1e30; s->max_ndead = -1; s->compression_factor = 0.36787944117144233;
+    s->seed = -1; s->batch = 0; s->device = -1;
+}
+
+int pchip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, pchip_result *out)
+{
+    if (s->num_repeats < 1) { std::fprintf(stderr, "polychord_hip: You need to set num_repeats. Suggestion: 5*nDims\n"); return 1; } // settings.f90:216
+    if (s->num_repeats > 64 * PC_MASK_WORDS) { std::fprintf(stderr, "polychord_hip: num_repeats > %d unsupported\n", 64 * PC_MASK_WORDS); return 1; }
+    if (like->kind == PC_LIKE_CALLBACK || prior->kind != 1) { std::fprintf(stderr, "polychord_hip: pchip_run needs a device likelihood and a uniform prior\n"); return 1; }
+    Engine E;
+    E.setup(*s, *like, *prior);
+    const int rc = E.run(out);
+    E.destroy();
+    return rc;
+}
+
+void pchip_result_free(pchip_result *r)
+{
+    std::free(r->dead); std::free(r->logweights); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
+    std::free(r->post_mean); std::free(r->post_var);
+    std::memset(r, 0, sizeof(*r));
+}
+
+// kernel-level entry for the parity tests: run K0 + K1 for `nchains` chains, chain c seeded from
+// seeds[c] (row of nTotal doubles), all under the same Cholesky factor and contour.
+int pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, unsigned batch,
+                       int nchains, const double *seeds, const double *chol, double contour, double *babies_out,
+                       double *nhats_out, int *nlike_out)
+{
+    pchip_settings c = *s;
+    c.nlive = nchains; c.nprior = nchains; c.batch = nchains; c.do_clustering = 0;
+    Engine E;
+    E.setup(c, *like, *prior);
+    PcState &S = E.S;
+    const int nT = S.nT, D = S.D, nr = S.nr;
+    HIPCHK(hipMemcpy(S.live, seeds, sizeof(double) * (size_t)nchains * nT, hipMemcpyHostToDevice));
+    std::vector<double> ll(nchains); std::vector<int> idn(nchains), zero(nchains, 0);
+    for (int i = 0; i < nchains; ++i) { ll[i] = seeds[(size_t)i * nT + S.l0]; idn[i] = i; }
+    HIPCHK(hipMemcpy(S.live_logL, ll.data(), sizeof(double) * nchains, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.live_cluster, zero.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.live_pos, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.cl_list, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.cl_n, &nchains, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.logLp, &contour, sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(S.chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice));
+    S.seed_override = 1;
+    int rc = pc_launch_nhats(&S, batch, nchains, E.st) || pc_launch_slice(&S, batch, nchains, E.st);
+    HIPCHK(hipStreamSynchronize(E.st));
+    HIPCHK(hipMemcpy(babies_out, S.babies, sizeof(double) * (size_t)nchains * nr * nT, hipMemcpyDeviceToHost));
+    if (nhats_out) HIPCHK(hipMemcpy(nhats_out, S.nhat, sizeof(double) * (size_t)nchains * nr * D, hipMemcpyDeviceToHost));
+    if (nlike_out) HIPCHK(hipMemcpy(nlike_out, S.ch_nlike, sizeof(int) * nchains, hipMemcpyDeviceToHost));
+    E.destroy();
+    return rc;
+}
+
+}  // extern "C"

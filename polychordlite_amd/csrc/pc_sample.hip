@@ -1,0 +1,473 @@
+// pc_sample.hip -- the parallel half of the engine: prior sampling of the initial live set,
+// random whitened directions (K0) and the batched slice-sampling chains (K1).
+//
+// One nursery batch = B independent chains, all seeded from one snapshot of the live set:
+// exactly the reference's synchronous farm with nprocs-1 = B
+// (src/polychord/nested_sampling.F90:262-286), but the "workers" are wavefronts.
+//
+//   K0 k_nhats   one workgroup per (chain, basis); thread i owns basis vector i in registers.
+//                Restates generate_nhats (chordal_sampling.f90:94-145), random_orthonormal_basis
+//                (random_utils.F90:381-403, row-oriented but arithmetically identical Gram-Schmidt),
+//                GenerateSeed (generate.F90:19-55) and the whitening nhats = L.nhats
+//                (chordal_sampling.f90:73-82).
+//   K1 k_slice   one wavefront per chain; lane d owns cube coordinate d (+64k).  Restates
+//                SliceSampling / slice_sample (chordal_sampling.f90:7-92, 163-273) and
+//                calculate_point (calculate.f90:6-50); likelihood sums are DPP butterflies.
+#include "pc_state.h"
+
+// ------------------------------------------------------------------------------------------
+// likelihood on a wave: lane owns DPL coordinates (dim = lane + 64*k)
+// ------------------------------------------------------------------------------------------
+template <int DPL>
+struct LaneDims {
+    double lo[DPL], span[DPL];   // uniform prior box (priors.f90:40-55)
+    double mean[DPL];            // corr gaussian mean / twin gaussian means are derived
+    bool on[DPL];
+};
+
+template <int DPL, int NROWS>
+__device__ __forceinline__ double wsum(double v) { return (DPL > 1) ? wave_sum<4>(v) : wave_sum<NROWS>(v); }
+
+// returns logL of theta (uniform over the wave).  ybuf: per-wave LDS scratch of >= D doubles.
+template <int DPL, int NROWS>
+__device__ __forceinline__ double like_eval(const PcState &S, const double (&th)[DPL], const LaneDims<DPL> &ld,
+                                            int lane, double *ybuf)
+{
+    const int D = S.D;
+    const PcLike &L = S.like;
+    if (L.kind == PC_LIKE_GAUSSIAN) {            // gaussian.f90:25-34
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) if (ld.on[k]) { const double z = (th[k] - L.mu) / L.sigma; s += z * z; }
+        s = wsum<DPL, NROWS>(s);
+        return -(double)D * (log(L.sigma) + PC_LOG_TWO_PI / 2.0) - s / 2.0;
+    } else if (L.kind == PC_LIKE_RASTRIGIN) {    // rastrigin.f90:33
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k)
+            if (ld.on[k]) s += log(4991.21750) + th[k] * th[k] - 10.0 * cos(PC_TWO_PI * th[k]);
+        s = wsum<DPL, NROWS>(s);
+        return -s;
+    } else if (L.kind == PC_LIKE_TWIN_GAUSSIAN) {  // twin_gaussian.f90:29-46
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k)
+            if (ld.on[k]) {
+                const int dim = lane + 64 * k;
+                const double m1 = dim < 2 ? -0.5 : 0.0, m2 = dim < 2 ? 0.5 : 0.0;
+                const double z1 = (th[k] - m1) / L.sigma, z2 = (th[k] - m2) / L.sigma;
+                s1 += z1 * z1; s2 += z2 * z2;
+            }
+        s1 = wsum<DPL, NROWS>(s1); s2 = wsum<DPL, NROWS>(s2);
+        const double norm = -(double)D * (log(L.sigma) + PC_LOG_TWO_PI / 2.0);
+        return pc_logaddexp(norm - s1 / 2.0, norm - s2 / 2.0) - log(2.0);
+    } else {                                      // random_gaussian.f90:17-30, utils.F90:1028-1048
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) if (ld.on[k]) ybuf[lane + 64 * k] = th[k] - ld.mean[k];
+        __syncthreads();                          // one wave per workgroup: cheap
+        double q = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k)
+            if (ld.on[k]) {
+                const int a = lane + 64 * k;
+                double t = 0.0;
+                // invcov is uploaded TRANSPOSED so that lanes read consecutive addresses
+                for (int b = 0; b < D; ++b) t += L.invcov[(size_t)b * D + a] * ybuf[b];
+                q += (th[k] - ld.mean[k]) * t;
+            }
+        q = wsum<DPL, NROWS>(q);
+        __syncthreads();
+        return -((double)D * PC_LOG_TWO_PI + L.logdetcov) / 2.0 - q / 2.0;
+    }
+}
+
+// derived parameters of an accepted point (lane-uniform results)
+template <int DPL, int NROWS>
+__device__ __forceinline__ void like_phi(const PcState &S, const double (&th)[DPL], const LaneDims<DPL> &ld,
+                                         int lane, double &phi0, double &phi1)
+{
+    phi0 = 0.0; phi1 = 0.0;
+    if (S.nDer == 0) return;
+    if (S.like.kind == PC_LIKE_GAUSSIAN) {        // gaussian.f90:36-37
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) if (ld.on[k]) r2 += (th[k] - S.like.mu) * (th[k] - S.like.mu);
+        r2 = wsum<DPL, NROWS>(r2);
+        phi0 = sqrt(r2);
+        if (S.nDer >= 2) phi1 = pc_log_ball(phi0, S.D);
+    } else if (S.like.kind == PC_LIKE_TWIN_GAUSSIAN) {   // twin_gaussian.f90:48-52
+        const double t0 = readlane_f64(th[0], 0);
+        phi0 = (t0 > 0.5) ? 1.0 : -1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// initial live points: GenerateLivePoints, linear mode (generate.F90:150-183)
+// one wave per attempt; attempts are the oracle's PC_DOM_LIVEGEN streams.
+// ------------------------------------------------------------------------------------------
+template <int DPL>
+__global__ __launch_bounds__(64) void k_generate_live(PcState S, int attempt0, double *rows /* [n][nT] */,
+                                                     double *rows_logL)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *ybuf = (double *)smem;
+    const int lane = threadIdx.x, a = blockIdx.x, attempt = attempt0 + a;
+    const int D = S.D, nT = S.nT;
+    LaneDims<DPL> ld;
+    double cube[DPL], th[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        const int dim = lane + 64 * k;
+        ld.on[k] = dim < D;
+        const double lo = (ld.on[k] && S.prior.lo) ? S.prior.lo[dim] : 0.0;
+        const double hi = (ld.on[k] && S.prior.hi) ? S.prior.hi[dim] : 1.0;
+        ld.lo[k] = lo; ld.span[k] = hi - lo;
+        ld.mean[k] = (ld.on[k] && S.like.mean) ? S.like.mean[dim] : 0.0;
+        cube[k] = ld.on[k] ? pc_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, (uint32_t)attempt, (uint32_t)dim) : 0.5;
+        th[k] = ld.lo[k] + ld.span[k] * cube[k];
+    }
+    const double logL = like_eval<DPL, 4>(S, th, ld, lane, ybuf);
+    double phi0, phi1;
+    like_phi<DPL, 4>(S, th, ld, lane, phi0, phi1);
+    double *row = rows + (size_t)a * nT;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k)
+        if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[S.p0 + lane + 64 * k] = th[k]; }
+    if (lane == 0) {
+        if (S.nDer >= 1) row[S.d0] = phi0;
+        if (S.nDer >= 2) row[S.d0 + 1] = phi1;
+        for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
+        row[S.b0] = S.logzero;                   // generate.F90:163
+        row[S.l0] = logL;
+        rows_logL[a] = logL;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: seed choice + random orthonormal bases + whitening
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, int chain, int &sel, int &slot)
+{   // GenerateSeed, generate.F90:42-53; random_integer_P random_utils.F90:548-576
+    const int nc = S.ctl->ncluster;
+    double m = S.logXp[0];
+    for (int c = 1; c < nc; ++c) m = fmax(m, S.logXp[c]);
+    double sum = 0.0;
+    for (int c = 0; c < nc; ++c) sum += exp(S.logXp[c] - m);
+    const double lse = m + log(sum);
+    double norm = 0.0;
+    for (int c = 0; c < nc; ++c) norm += exp(S.logXp[c] - lse);
+    const double u = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 0u);
+    double cdf = 0.0;
+    sel = nc - 1;
+    for (int c = 0; c < nc; ++c) { cdf += exp(S.logXp[c] - lse) / norm; if (u < cdf) { sel = c; break; } }
+    const double u2 = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+    const int n = S.cl_n[sel];
+    int idx = (int)ceil(u2 * n);
+    idx = idx < 1 ? 1 : (idx > n ? n : idx);
+    slot = S.cl_list[(size_t)sel * S.Ncap + idx - 1];
+    if (S.seed_override) slot = chain;
+}
+
+template <int DMAX, int NT>
+__global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = S.D, nr = S.nr;
+    double *G = (double *)smem;          // [D*D] deviates, vector-major
+    double *Q = G + (size_t)D * D;       // [D] broadcast of the finished vector
+    int *sh = (int *)(Q + D);            // [2] chosen cluster, seed slot
+    const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
+    if (tid == 0) {
+        int sel, slot;
+        select_seed(S, batch, chain, sel, slot);
+        sh[0] = sel; sh[1] = slot;
+        if (basis == 0) {
+            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
+            S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
+            S.ch_epoch[chain] = S.ctl->admin_epoch;
+            if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
+        }
+    }
+    // gaussian deviates: index (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT
+    const uint32_t e0 = (uint32_t)basis * D * D, e1 = e0 + (uint32_t)D * D;
+    for (uint32_t call = (e0 >> 1) + tid; call <= ((e1 - 1) >> 1); call += NT) {
+        double ua, ub;
+        pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+        const uint32_t ia = 2 * call, ib = 2 * call + 1;
+        if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
+        if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+    }
+    __syncthreads();
+    const int i = tid;
+    const bool active = i < D;
+    double v[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? G[(size_t)i * D + d] : 0.0;
+    // random_direction (random_utils.F90:276-298): normalise the raw deviates
+    {
+        double n2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
+        const double nrm = sqrt(n2);
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] / nrm;
+    }
+    // Gram-Schmidt, row oriented: once vector j is final it is removed from every later vector.
+    // Per vector this is the same sequence of projections as random_utils.F90:391-399.
+    for (int j = 0; j < D; ++j) {
+        if (i == j) {
+            double n2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
+            const double nrm = sqrt(n2);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) { v[d] = v[d] / nrm; Q[d] = v[d]; }
+        }
+        __syncthreads();
+        if (active && i > j) {
+            double dot = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) dot += v[d] * Q[d];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] - dot * Q[d];
+        }
+        __syncthreads();
+    }
+    // whitening  w = L.n  (chordal_sampling.f90:73).  The finished vectors go back to LDS
+    // (the deviate buffer is free now) so that the triangular product can index them.
+    const int col = basis * D + i;
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) G[(size_t)i * D + d] = v[d];
+    }
+    __syncthreads();
+    if (active && col < nr) {
+        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        double *mine = G + (size_t)i * D;
+        double n2 = 0.0;
+        for (int a = D - 1; a >= 0; --a) {          // in place: row a only needs n[0..a]
+            double t = 0.0;
+            for (int b = 0; b <= a; ++b) t += Lc[(size_t)a * D + b] * mine[b];
+            mine[a] = t;
+        }
+        for (int d = 0; d < D; ++d) n2 += mine[d] * mine[d];
+        const double w = sqrt(n2);                        // chordal_sampling.f90:80-82
+        double *out = S.nhat + ((size_t)chain * nr + col) * D;
+        for (int d = 0; d < D; ++d) out[d] = mine[d] / w;
+        S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: one slice-sampling chain per wavefront
+// ------------------------------------------------------------------------------------------
+template <int DPL, int NROWS>
+struct ChainCtx {
+    const PcState &S;
+    const LaneDims<DPL> &ld;
+    int lane;
+    double *ybuf;
+    int nlike;
+};
+
+// calculate_point (calculate.f90:6-50) at x0 + t*nh; leaves cube/theta of the trial in registers
+template <int DPL, int NROWS>
+__device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double (&x0)[DPL], const double (&nh)[DPL],
+                                          double t, double (&cube)[DPL], double (&th)[DPL])
+{
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        cube[k] = x0[k] + t * nh[k];
+        if (C.ld.on[k]) outside |= (cube[k] < 0.0) | (cube[k] > 1.0);
+    }
+    if (__ballot(outside) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) th[k] = 0.0;
+        return C.S.logzero;
+    }
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) th[k] = C.ld.lo[k] + C.ld.span[k] * cube[k];
+    const double logL = like_eval<DPL, NROWS>(C.S, th, C.ld, C.lane, C.ybuf);
+    if (logL > C.S.logzero) C.nlike++;
+    return logL;
+}
+
+template <int DPL, int NROWS>
+__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *ybuf = (double *)smem;                 // [D] (corr gaussian only)
+    int *sdeck = (int *)(ybuf + S.D);              // [nr] deck, only used when nr > 64
+    int *sj = sdeck + S.nr;                        // [nr]
+    const int lane = threadIdx.x, chain = blockIdx.x;
+    const int D = S.D, nr = S.nr, nT = S.nT;
+    const double logzero = S.logzero;
+
+    LaneDims<DPL> ld;
+    const int slot = S.ch_seed_slot[chain];
+    const double contour = S.ch_contour[chain];
+    double x0[DPL];
+    {
+        const double *seed = S.live + (size_t)slot * nT;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int dim = lane + 64 * k;
+            ld.on[k] = dim < D;
+            const double lo = (ld.on[k] && S.prior.lo) ? S.prior.lo[dim] : 0.0;
+            const double hi = (ld.on[k] && S.prior.hi) ? S.prior.hi[dim] : 1.0;
+            ld.lo[k] = lo; ld.span[k] = hi - lo;
+            ld.mean[k] = (ld.on[k] && S.like.mean) ? S.like.mean[dim] : 0.0;
+            x0[k] = ld.on[k] ? seed[dim] : 0.5;
+        }
+    }
+    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0};
+
+    // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
+    //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
+    int deck = lane;
+    const bool deck_in_regs = nr <= 64;
+    if (deck_in_regs) {
+        int jv = 0;
+        if (lane >= 1 && lane < nr) {
+            const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
+            int j = (int)ceil(u * lane);
+            jv = j < 1 ? 1 : (j > lane ? lane : j);
+        }
+        for (int i = nr - 1; i >= 1; --i) {
+            const int j = __builtin_amdgcn_readlane(jv, i);
+            const int di = __builtin_amdgcn_readlane(deck, i), dj = __builtin_amdgcn_readlane(deck, j);
+            deck = (lane == i) ? dj : ((lane == j) ? di : deck);
+        }
+    } else {
+        for (int i = lane; i < nr; i += 64) {
+            sdeck[i] = i;
+            if (i >= 1) {
+                const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
+                int j = (int)ceil(u * i);
+                sj[i] = j < 1 ? 1 : (j > i ? i : j);
+            }
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (int i = nr - 1; i >= 1; --i) { const int j = sj[i], t = sdeck[i]; sdeck[i] = sdeck[j]; sdeck[j] = t; }
+        __syncthreads();
+    }
+
+    double ua = 0.0, ub = 0.0;                     // uniforms of 4 consecutive slices, 32 each
+    double nh[DPL], nh_next[DPL], w_next;
+    {   // prefetch the first direction
+        const int v0 = deck_in_regs ? __builtin_amdgcn_readlane(deck, 0) : sdeck[0];
+        const double *p = S.nhat + ((size_t)chain * nr + v0) * D;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[lane + 64 * k] : 0.0;
+        w_next = S.nhat_w[(size_t)chain * nr + v0];
+    }
+
+    for (int s = 0; s < nr; ++s) {
+        const double w = w_next;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) nh[k] = nh_next[k];
+        if (s + 1 < nr) {                           // prefetch the next direction (hidden under this slice)
+            const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
+            const double *p = S.nhat + ((size_t)chain * nr + v1) * D;
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[lane + 64 * k] : 0.0;
+            w_next = S.nhat_w[(size_t)chain * nr + v1];
+        }
+        if ((s & 3) == 0) {                         // one Philox call per lane covers 4 slices x 32 uniforms
+            const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
+            pc_uniform2(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain,
+                        (sl * PC_SLICE_STRIDE) / 2 + (uint32_t)(lane & 15), ua, ub);
+        }
+        uint32_t kdraw = 0;
+        auto next_u = [&]() -> double {
+            const uint32_t k = kdraw++;
+            if (k < 32u) {
+                const int src = ((s & 3) << 4) + (int)(k >> 1);
+                return (k & 1u) ? readlane_f64(ub, src) : readlane_f64(ua, src);
+            }
+            return pc_uniform(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain, (uint32_t)s * PC_SLICE_STRIDE + k);
+        };
+
+        double cube[DPL], th[DPL];
+        // initial bracket (chordal_sampling.f90:213-219)
+        const double u0 = next_u();
+        double tR = (1 - u0) * w, tL = -(u0 * w);
+        double lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th);
+        double lL = eval_at<DPL, NROWS>(C, x0, nh, tL, cube, th);
+        // stepping out (:223-236)
+        int istep = 0;
+        while (lR >= contour && lR > logzero) { istep++; tR = w * istep; lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th); }
+        istep = 0;
+        while (lL >= contour && lL > logzero) { istep++; tL = -(w * istep); lL = eval_at<DPL, NROWS>(C, x0, nh, tL, cube, th); }
+        // shrinkage (:240-271)
+        double lnew = logzero;
+        bool ok = false;
+        for (int it = 0; it <= 100; ++it) {
+            const double dl = fabs(tL), dr = fabs(tR);
+            const double t = next_u() * (dr + dl) - dl;
+            lnew = eval_at<DPL, NROWS>(C, x0, nh, t, cube, th);
+            if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
+            else { ok = true; break; }
+        }
+        if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
+        // the baby becomes the next start point (chordal_sampling.f90:85-88)
+        double phi0, phi1;
+        like_phi<DPL, NROWS>(S, th, ld, lane, phi0, phi1);
+        double *row = S.babies + ((size_t)chain * nr + s) * nT;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            x0[k] = cube[k];
+            if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[S.p0 + lane + 64 * k] = th[k]; }
+        }
+        if (lane == 0) {
+            if (S.nDer >= 1) row[S.d0] = phi0;
+            if (S.nDer >= 2) row[S.d0 + 1] = phi1;
+            for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
+            row[S.b0] = contour;                    // nested_sampling.F90:260
+            row[S.l0] = lnew;
+            S.baby_logL[(size_t)chain * nr + s] = lnew;
+        }
+    }
+    if (lane == 0) S.ch_nlike[chain] = C.nlike;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, double *rows, double *rows_logL,
+                                       hipStream_t st)
+{
+    const size_t sh = sizeof(double) * S->D;
+    if (S->D <= 64) hipLaunchKernelGGL((k_generate_live<1>), dim3(n), dim3(64), sh, st, *S, attempt0, rows, rows_logL);
+    else if (S->D <= 128) hipLaunchKernelGGL((k_generate_live<2>), dim3(n), dim3(64), sh, st, *S, attempt0, rows, rows_logL);
+    else if (S->D <= 256) hipLaunchKernelGGL((k_generate_live<4>), dim3(n), dim3(64), sh, st, *S, attempt0, rows, rows_logL);
+    else return 1;
+    return 0;
+}
+
+extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    const int D = S->D, nb = (S->nr + D - 1) / D;
+    const size_t sh = sizeof(double) * ((size_t)D * D + D) + 16;
+    dim3 grid(nb, nchains);
+    if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
+    else if (D <= 64) hipLaunchKernelGGL((k_nhats<64, 64>), grid, dim3(64), sh, st, *S, batch);
+    else if (D <= 128) hipLaunchKernelGGL((k_nhats<128, 128>), grid, dim3(128), sh, st, *S, batch);
+    else return 1;
+    return 0;
+}
+
+extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    const size_t sh = sizeof(double) * S->D + sizeof(int) * 2 * (size_t)S->nr + 16;
+    const int D = S->D;
+    if (D <= 16) hipLaunchKernelGGL((k_slice<1, 1>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    else if (D <= 32) hipLaunchKernelGGL((k_slice<1, 2>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    else if (D <= 64) hipLaunchKernelGGL((k_slice<1, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    else if (D <= 128) hipLaunchKernelGGL((k_slice<2, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    else if (D <= 256) hipLaunchKernelGGL((k_slice<4, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    else return 1;
+    return 0;
+}

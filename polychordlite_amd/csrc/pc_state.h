@@ -1,0 +1,91 @@
+// pc_state.h -- device-resident sampler state of the MI355X nested-sampling engine.
+//
+// Replaces the reference's `run_time_info` type (src/polychord/run_time_info.f90:10-107):
+// instead of per-cluster 3-D Fortran arrays that are re-packed on every split/death, the
+// live set is a flat array of slots with (cluster, position-in-cluster-list) labels, so a
+// cluster split or death is a relabel, and phantoms / dead points are append-only arrays.
+// Everything below lives in HBM; the host only sees the small PcCtl block.
+#pragma once
+#include "pc_dev.h"
+
+enum { PC_ST_RUNNING = 0, PC_ST_DONE = 1, PC_ST_UPDATE = 2, PC_ST_ERROR = 4 };
+enum { PC_ERR_NONE = 0, PC_ERR_PHANTOM_CAP = 1, PC_ERR_DEAD_CAP = 2, PC_ERR_CLUSTER_CAP = 3, PC_ERR_NOSLOT = 4 };
+
+#define PC_MASK_WORDS 8          /* phantom mask words per chain: num_repeats <= 512 */
+
+struct PcCtl {                   // written by the consume kernel, read by the host after each round
+    int status;                  // PC_ST_*
+    int error;
+    int i_nursery;               // nursery entries still to be consumed (nested_sampling.F90:262-286)
+    int admin_epoch;             // administrator epoch (nested_sampling.F90:313)
+    int failures;                // consecutive failed spawns (nested_sampling.F90:315-319)
+    int ncluster;
+    int ncluster_dead;
+    int ndead;
+    int nphantom;                // rows used in the phantom array (incl. not yet cleaned ones)
+    int seg_hi, seg_lo;          // chains [seg_lo, seg_hi] (descending) consumed by the last segment
+    int cluster_deleted;         // a cluster died in the last segment (host bookkeeping hint)
+    unsigned batch_id;           // id of the batch in the nursery
+    unsigned next_cluster_uid;
+    long long nlike;             // RTI%nlike(1)
+    long long niter;             // consumed nursery entries
+    long long nlike_device;      // evaluations executed on the device (incl. dropped nursery)
+    double logZ, logZ2;          // run_time_info.f90:165-166 (log <Z>, log <Z^2>)
+    double logX_last_update;
+    double live_logZ;            // last evaluated termination estimate
+};
+
+struct PcState {
+    // ---- geometry / settings
+    int D, nDer, nT, nr, N, Ncap, B, maxc, Pcap, Dcap;
+    int b0, l0, p0, d0;          // 0-based offsets in a point row [cube|theta|phi|birth|logL]
+    uint32_t k0, k1;             // Philox key
+    double logzero, log_prec, log_cf;
+    int use_prec, max_ndead, nfail;
+    int n_nlives; const double *dyn_loglikes; const int *dyn_nlives;
+    PcLike like; PcPrior prior;
+    // ---- live set: slots
+    double *live;                // [Ncap][nT]
+    double *live_logL;           // [Ncap]
+    int *live_cluster;           // [Ncap] cluster index, -1 = free slot
+    int *live_pos;               // [Ncap] position in the cluster's list (reference ordering)
+    int *cl_list;                // [maxc][Ncap] slot ids in list order (rebuilt after every segment)
+    int *cl_n;                   // [maxc]
+    // ---- per-cluster evidence state (run_time_info.f90:60-100)
+    double *logZp, *logXp, *logZXp, *logZp2, *logZpXp, *logLp, *XpXq /* [maxc*maxc] */;
+    int *imin_slot;              // [maxc] slot of the lowest live point
+    double *lse_ref, *lse_sum;   // incremental logsumexp of the live logL of each cluster
+    double *death_thr;           // [maxc] logL of the last death in the cluster since the last clean
+    unsigned *cl_uid;            // [maxc] stable ids (phantoms carry these)
+    double *chol, *cov;          // [maxc][D*D] row-major lower Cholesky / covariance
+    double *logZp_dead, *logZp2_dead;   // [maxc_dead]
+    int maxc_dead;
+    // ---- phantoms (append-only between cleans)
+    double *phantom;             // [Pcap][nT]
+    double *ph_logL;             // [Pcap]
+    unsigned *ph_cuid;           // [Pcap] cluster uid
+    unsigned long long *ph_uid;  // [Pcap] (batch<<32 | chain*nr+baby)
+    // ---- dead points
+    double *dead;                // [Dcap][nT]
+    double *dead_logw;           // [Dcap]
+    double *dead_postX, *dead_postZ;   // posterior-stack columns (calculate.f90:53-79)
+    unsigned *dead_cuid;
+    // ---- nursery (one synchronous batch of B chains)
+    double *babies;              // [B][nr][nT]
+    double *baby_logL;           // [B][nr]
+    int *ch_cluster, *ch_epoch, *ch_nlike, *ch_seed_slot;
+    double *ch_contour;          // [B] contour each chain sampled under
+    double *nhat;                // [B][nr][D] whitened, normalised directions (generation order)
+    double *nhat_w;              // [B][nr] 3*|L n|
+    // ---- plan written by the consume kernel for the apply kernels
+    int *pl_dead_idx;            // [B] index in dead[] or -1
+    int *pl_dead_src;            // [B] >=0: live slot; <0: -(1+chain) whose last baby is the row
+    double *pl_logw, *pl_postX, *pl_postZ;
+    unsigned *pl_dead_cuid;
+    int *pl_ph_base;             // [B] first phantom row of the chain
+    unsigned long long *pl_ph_mask;     // [B][PC_MASK_WORDS]
+    unsigned *pl_ph_cuid;        // [B]
+    int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
+    int seed_override;           // test hook: chain c starts from slot c instead of a random seed
+    PcCtl *ctl;
+};
