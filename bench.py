@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- likelihood evaluations / second of the MI355X nested-sampling engine.
+
+Contract (see DESIGN.md "Measurement"):
+  * a STEP is one complete nested-sampling run of BASELINE.json configs[1]: 20-D Gaussian
+    (likelihoods/examples/gaussian.f90, ini/gaussian.ini priors), nlive = 2000, num_repeats = 40,
+    precision_criterion 1e-3, no clustering, fp64 throughout; step i uses seed = 1000 + i (+ rank*100003).
+  * metric  = likelihood evals/sec = sum of the reference's own counter RTI%nlike (calculate.f90:44)
+    over the timed steps / wall time (barrier + device sync on both sides, max over ranks).
+  * N > 1 GPUs: repeat-sharded: every rank runs independent runs with its own seeds; the
+    (logL, birth) records of all dead points are all-gathered over RCCL (torch.distributed "nccl") and
+    merged into one evidence by the replay recursion; scaling is "weak".
+  * roofline: the dominant kernel's algorithmic HBM bytes (258 B / evaluation at this
+    config) over its HIP-event time, against 8 TB/s.  This path is latency bound; the fraction says so.
+  * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by
+    oracle/Makefile) when the prebuilt binary is present, else the C restatement (oracle/liboracle.so),
+    on one host core, on a bounded sample (nlive = 500 instead of 2000: same evals/iteration).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_EVAL = 258.0
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(nDims, nDer, nr):
+    """reference (preferred) or restatement on ONE host core, bounded sample"""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    sample = "20-D Gaussian, nlive=500 (1/4 of the workload's live points), num_repeats=40, one full run, seed 7"
+    if os.path.exists(ref):
+        tmp = "/tmp/pc_ref_bench"
+        os.makedirs(tmp, exist_ok=True)
+        cmd = f"ulimit -s unlimited; {ref} gaussian {nDims} {nDer} 500 {nr} 7 0 {tmp} ref 0"
+        out = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, cwd=tmp)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if line:
+            j = json.loads(line[-1])
+            return {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
+                    "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off",
+                    "logZ": j["logZ"], "logZerr": j["logZerr"], "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"]}
+    from tests import oracle_api as orc
+    s = orc.settings(nDims, nDer, nlive=500, num_repeats=nr, seed=7, batch=1)
+    L, P, keep = orc.make_problem("gaussian", nDims)
+    t0 = time.time(); o = orc.run(s, L, P); dt = time.time() - t0
+    return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port",
+            "sample": sample + "; oracle/liboracle.so (C restatement, gcc -O2)", "logZ": o["logZ"],
+            "logZerr": o["logZerr"], "ndead": int(o["ndead"]), "nlike": int(o["nlike"]), "wall_s": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nlive", type=int, default=2000)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from polychordlite_amd import _ctypes_api as api
+    from polychordlite_amd.merge import merge_runs
+    lib = api.load()
+    if lib.pchip_device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
+
+    nDims, nDer, nr = 20, 2, 40
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
+    s.nlive = args.nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank; s.profile = 1
+    L, P, keep = api.make_problem("gaussian", nDims, nDer)
+
+    def one(i):
+        s.seed = 1000 + i + 100003 * rank
+        return api.run(s, L, P)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one(-1 - i)
+    sync()
+    t0 = time.perf_counter()
+    runs = [one(i) for i in range(args.steps)]
+    # repeat-sharded merge: all-gather (logL, birth) of every dead point of the last step's runs
+    merged = merge_runs(runs[-1], dist, torch, local_rank) if args.steps > 0 else None
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = dt
+    nlike = float(sum(r["nlike"] for r in runs))
+    if dist is not None:
+        t = torch.tensor([dt, nlike], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); tmax = float(tm[0])
+        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1])
+    if rank == 0:
+        value = nlike / tmax
+        k = runs[-1]["kernel_time"]
+        dom = max(k, key=lambda n: k[n]["total_s"]) if k else None
+        roof = None
+        if dom:
+            kt = sum(r["kernel_time"][dom]["total_s"] for r in runs)
+            kl = sum(r["kernel_time"][dom]["launches"] for r in runs)
+            evals = float(sum(r["nlike"] for r in runs))
+            achieved = evals * BYTES_PER_EVAL / kt / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": kt / max(kl, 1) * 1e6, "launches": kl,
+                    "bytes_per_launch": evals * BYTES_PER_EVAL / max(kl, 1),
+                    "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; "
+                            "algorithmic bytes = 258 B per likelihood evaluation"}
+        out = {"metric": "likelihood evals/sec, 20D Gaussian nlive=%d" % args.nlive, "value": value,
+               "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, "
+                                      "num_repeats=40, precision_criterion=1e-3, one full nested-sampling run per step"
+                                      % args.nlive,
+                          "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world},
+               "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
+               "logZ_truth": 0.0, "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
+               "merged": merged, "roofline": roof,
+               "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
+               "reference_cpu_evals_per_s_survey_container": 357e3}
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(nDims, nDer, nr)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,8 @@ typedef struct {
     int batch;          /* chains per synchronous nursery (the reference's nprocs-1); 0 = auto */
     int device;         /* HIP device ordinal, -1 = current/0 */
     int feedback;
+    int profile;        /* 1: HIP-event stopwatch around every kernel class (bench.py) */
+    int force_general;  /* 1: always use the general contraction kernel (tests) */
 } pchip_settings;
 
 typedef struct {
@@ -106,7 +108,11 @@ typedef struct {
     long ndead, nlike, niter, nbatches, nrounds, nupdates;
     int ncluster, ncluster_dead, nTotal, batch;
     double t_generate, t_loop, t_final, t_total;   /* host wall-clock of the phases, seconds */
+    double k_time_s[6]; long k_launches[6];        /* HIP-event time per kernel class: nhats, slice,
+                                                      consume, apply, clean, covmats (profile=1) */
     double *dead, *logweights;     /* [ndead][nTotal] rows [cube|theta|phi|birth|logL], [ndead] */
+    double *entry;                 /* [ndead] global contour when the point entered the live set
+                                      (== birth column when batch = 1); used by the multi-run merge */
     double *live; int nlive_final; /* live set at termination, before the final kill-off */
     double *logZp, *varlogZp; int nZp;
     double *post_mean, *post_var;  /* [nDims] weighted posterior moments of theta */

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""gen_golden.py -- produce tests/golden/*.json from the REFERENCE itself (run in the build container
+only; needs /root/reference and amdflang).  Fixtures are numbers only (inputs + expected outputs):
+
+  ref_units.json     unit vectors computed by the reference's Fortran modules (oracle/ref_units.f90)
+  ref_injected.json  full runs of the reference binary whose `random_number` is fed the oracle's
+                     sequential Philox stream (oracle/ref_rng_shim.c): logZ, logZerr, ndead, nlike,
+                     #likelihood callback invocations, #uniforms consumed -- the oracle in
+                     sequential mode must reproduce every integer exactly and logZ to ~1e-12
+  ref_native.json    the untouched reference (own compiler RNG), several seeds: distribution-level
+                     targets (logZ within sigma) and the CPU baseline timing of this container
+  ref_replay.json    (logL, birth) columns of one reference dead-birth file + its .stats evidence:
+                     pins the evidence recursion (SURVEY 8c "deterministic evidence replay")
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+TMP = "/tmp/pc_golden"
+
+
+def sh(cmd):
+    return subprocess.run(["bash", "-c", "ulimit -s unlimited; " + cmd], capture_output=True, text=True, cwd=TMP)
+
+
+def last_json(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError(out.stdout[-2000:] + out.stderr[-2000:])
+    return json.loads(lines[-1])
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    os.makedirs(TMP, exist_ok=True)
+    subprocess.check_call(["make", "-C", HERE, "ref", "_ref/ref_units"])
+    units = json.loads(subprocess.check_output([os.path.join(HERE, "_ref", "ref_units")], text=True))
+    json.dump(units, open(os.path.join(GOLD, "ref_units.json"), "w"), indent=1)
+
+    inj = os.path.join(HERE, "_ref", "ref_driver_inject")
+    nat = os.path.join(HERE, "_ref", "ref_driver")
+    cases = [  # like nDims nDerived nlive nrepeats seed clustering
+        ("gaussian", 20, 2, 500, 40, 7, 0), ("gaussian", 20, 2, 100, 20, 1, 0), ("gaussian", 4, 1, 100, 20, 2, 0),
+        ("gaussian", 20, 2, 200, 40, 3, 1),
+        ("rastrigin", 2, 0, 1000, 6, 7, 1), ("rastrigin", 2, 0, 300, 6, 2, 1), ("rastrigin", 4, 0, 200, 12, 5, 1),
+        ("twin_gaussian", 10, 1, 200, 20, 3, 1), ("twin_gaussian", 6, 1, 150, 12, 4, 1),
+    ]
+    injected = []
+    for c in cases:
+        j = last_json(sh(f"{inj} {c[0]} {c[1]} {c[2]} {c[3]} {c[4]} {c[5]} {c[6]} {TMP}/chains inj 0"))
+        j.update(nDerived=c[2], clustering=c[6])
+        j.pop("wall", None)
+        injected.append(j)
+        print("injected", j)
+    json.dump(injected, open(os.path.join(GOLD, "ref_injected.json"), "w"), indent=1)
+
+    native = []
+    for seed in range(1, 9):
+        j = last_json(sh(f"{nat} gaussian 20 2 500 40 {seed} 0 {TMP}/chains nat 0"))
+        j.update(nDerived=2, clustering=0)
+        native.append(j)
+        print("native", j)
+    for seed in (1, 2, 3):
+        j = last_json(sh(f"{nat} rastrigin 2 0 1000 6 {seed} 1 {TMP}/chains nat 0"))
+        j.update(nDerived=0, clustering=1)
+        native.append(j)
+        print("native", j)
+    j = last_json(sh(f"{nat} gaussian 20 2 2000 40 7 0 {TMP}/chains nat 0"))
+    j.update(nDerived=2, clustering=0)
+    native.append(j)
+    print("native", j)
+    json.dump(native, open(os.path.join(GOLD, "ref_native.json"), "w"), indent=1)
+
+    # evidence replay trace: small run with dead-birth output
+    j = last_json(sh(f"{nat} gaussian 4 1 100 20 11 0 {TMP}/chains rep 1"))
+    rows = [l.split() for l in open(f"{TMP}/chains/rep_dead-birth.txt")]
+    logL = [float(r[-2]) for r in rows]
+    birth = [float(r[-1]) for r in rows]
+    json.dump({"stats": j, "logL": logL, "birth": birth}, open(os.path.join(GOLD, "ref_replay.json"), "w"))
+    print("replay rows", len(rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@ DUMPER_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), 
                         C.POINTER(C.c_double), C.c_double, C.c_double)
 
 LIKE_CALLBACK, LIKE_GAUSSIAN, LIKE_RASTRIGIN, LIKE_TWIN_GAUSSIAN, LIKE_CORR_GAUSSIAN = range(5)
+KERNEL_CLASSES = ("k_nhats", "k_slice", "k_consume", "k_apply", "k_clean", "k_covmats")
 LIKE_KINDS = {"gaussian": LIKE_GAUSSIAN, "rastrigin": LIKE_RASTRIGIN, "twin_gaussian": LIKE_TWIN_GAUSSIAN,
               "corr_gaussian": LIKE_CORR_GAUSSIAN}
 
@@ -28,7 +29,8 @@ class Settings(C.Structure):
                 ("boost_posterior", C.c_double), ("posteriors", C.c_int), ("equals", C.c_int),
                 ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
-                ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int)]
+                ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
+                ("force_general", C.c_int)]
 
 
 class Like(C.Structure):
@@ -45,7 +47,8 @@ class Result(C.Structure):
                 ("niter", C.c_long), ("nbatches", C.c_long), ("nrounds", C.c_long), ("nupdates", C.c_long),
                 ("ncluster", C.c_int), ("ncluster_dead", C.c_int), ("nTotal", C.c_int), ("batch", C.c_int),
                 ("t_generate", C.c_double), ("t_loop", C.c_double), ("t_final", C.c_double), ("t_total", C.c_double),
-                ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)),
+                ("k_time_s", C.c_double * 6), ("k_launches", C.c_long * 6),
+                ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("entry", C.POINTER(C.c_double)),
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double))]
@@ -119,8 +122,11 @@ def run(settings, like, prior):
                niter=r.niter, nbatches=r.nbatches, nrounds=r.nrounds, nupdates=r.nupdates, ncluster=r.ncluster,
                ncluster_dead=r.ncluster_dead, nTotal=nT, batch=r.batch, t_generate=r.t_generate, t_loop=r.t_loop,
                t_final=r.t_final, t_total=r.t_total,
+               kernel_time={n: {"total_s": r.k_time_s[i], "launches": r.k_launches[i]}
+                            for i, n in enumerate(KERNEL_CLASSES) if r.k_launches[i] > 0},
                dead=np.ctypeslib.as_array(r.dead, shape=(nd, nT)).copy(),
                logweights=np.ctypeslib.as_array(r.logweights, shape=(nd,)).copy(),
+               entry=np.ctypeslib.as_array(r.entry, shape=(nd,)).copy(),
                live=np.ctypeslib.as_array(r.live, shape=(max(r.nlive_final, 1), nT))[:r.nlive_final].copy(),
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),

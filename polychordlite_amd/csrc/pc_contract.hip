@@ -32,7 +32,7 @@ __device__ __forceinline__ vk_t block_argmin(vk_t v, vk_t *scratch)
 }
 
 struct ConsumeShared {
-    double *sL; int *sC; int *sP;                      // per slot
+    double *sL, *sE; int *sC; int *sP;                 // per slot
     double *cLogLp, *cLogXp, *cLogZp, *cLogZXp, *cLogZp2, *cLogZpXp, *cLseRef, *cLseSum, *cThr;
     int *cN, *cMinSlot; unsigned *cUid;
     double *jobres;                                     // [NT] results of the lane-parallel jobs
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     {
         char *p = smem;
         H.sL = (double *)p; p += sizeof(double) * Ncap;
+        H.sE = (double *)p; p += sizeof(double) * Ncap;
         double **cd[] = { &H.cLogLp, &H.cLogXp, &H.cLogZp, &H.cLogZXp, &H.cLogZp2, &H.cLogZpXp, &H.cLseRef, &H.cLseSum, &H.cThr };
         for (int i = 0; i < 9; ++i) { *cd[i] = (double *)p; p += sizeof(double) * maxc; }
         H.jobres = (double *)p; p += sizeof(double) * NT;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
-    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
+    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sE[s] = S.live_entry[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
     int nc = ctl->ncluster;
     for (int c = tid; c < maxc; c += NT) {
         H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                     S.pl_dead_idx[plan_w] = ndead;
                     S.pl_dead_src[plan_w] = (src >= 0) ? -(1 + src) : slot_del;
                     S.pl_logw[plan_w] = logweight; S.pl_postX[plan_w] = lseX; S.pl_postZ[plan_w] = logZ;
-                    S.pl_dead_cuid[plan_w] = H.cUid[cd];
+                    S.pl_dead_cuid[plan_w] = H.cUid[cd]; S.pl_entry[plan_w] = H.sE[slot_del];
                 }
             } else {   // kill-off / trimming: rows are current in live[], copy immediately
                 const double *row = S.live + (size_t)slot_del * nT;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                 for (int e = tid; e < nT; e += NT) dst[e] = row[e];
                 if (tid == 0) {
                     S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lseX; S.dead_postZ[ndead] = logZ;
-                    S.dead_cuid[ndead] = H.cUid[cd];
+                    S.dead_cuid[ndead] = H.cUid[cd]; S.dead_entry[ndead] = H.sE[slot_del];
                 }
             }
         }
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                     // add_point + find_min_loglikelihoods for the receiving cluster
                     if (tid == 0) {
                         const int pos = H.cN[ca];
-                        H.sL[free_slot] = Llast; H.sC[free_slot] = ca; H.sP[free_slot] = pos;
+                        H.sL[free_slot] = Llast; H.sE[free_slot] = Lg; H.sC[free_slot] = ca; H.sP[free_slot] = pos;
                         H.cN[ca] = pos + 1;
                         if (pos == 0 || Llast < H.cLogLp[ca]) { H.cLogLp[ca] = Llast; H.cMinSlot[ca] = free_slot; }
                         // live logsumexp of the cluster
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
             if (tid == 0) {
                 S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = -(1 + w);
                 S.pl_logw[w] = S.logzero; S.pl_postX[w] = 0.0; S.pl_postZ[w] = 0.0; S.pl_dead_cuid[w] = 0xFFFFFFFFu;
+                S.pl_entry[w] = Lg;
             }
             ndead++;
         }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
 
     // ---- write the state back
     __syncthreads();
-    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
+    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_entry[s] = H.sE[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
     for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
     for (int c = tid; c < maxc; c += NT) {
         S.logLp[c] = H.cLogLp[c]; S.logXp[c] = H.cLogXp[c]; S.logZp[c] = H.cLogZp[c]; S.logZXp[c] = H.cLogZXp[c];
@@ -411,6 +413,196 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_consume_single: the same decisions as k_consume for the common case of ONE cluster with a
+// static number of live points, on ONE wavefront with no barriers:
+//   * evidence / volume accumulators live in registers; the six log-space updates of a death and
+//     the two exponentials of the live-evidence bookkeeping are evaluated in eight different lanes
+//     (one exp/log latency instead of eight) and exchanged with v_readlane;
+//   * every lane caches the minimum of its own stride of the LDS-resident logL column, so a death
+//     costs one 1/64 rescan + one DPP argmin instead of a pass over all live points;
+//   * list order (array_utils.f90:396-458 semantics) is an LDS pos<->slot map, O(1) per death;
+//   * the next chain's inputs are prefetched while the current one is processed;
+//   * the termination test (nested_sampling.F90:534, run_time_info.f90:683-709) is decided from the
+//     exponent of the running sum whenever that is unambiguous, and evaluated exactly otherwise.
+// ------------------------------------------------------------------------------------------
+#define PC_PRE 8   /* prefetch registers per lane: num_repeats <= 512 */
+
+__global__ __launch_bounds__(64) void k_consume_single(PcState S)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int Ncap = S.Ncap, nr = S.nr;
+    double *sL = (double *)smem;
+    double *sE = sL + Ncap;
+    int *sP = (int *)(sE + Ncap);
+    int *sList = sP + Ncap;
+    int *sSrc = sList + Ncap;
+    PcCtl *ctl = S.ctl;
+    for (int s = lane; s < Ncap; s += 64) { sL[s] = S.live_logL[s]; sE[s] = S.live_entry[s]; sP[s] = S.live_pos[s]; sSrc[s] = S.slot_src[s]; }
+    const int n = S.cl_n[0];
+    for (int p = lane; p < n; p += 64) sList[p] = S.cl_list[p];
+    int i_nursery = ctl->i_nursery, failures = ctl->failures, ndead = ctl->ndead, nph = ctl->nphantom;
+    const int epoch = ctl->admin_epoch;
+    long long nlike = ctl->nlike, niter = ctl->niter;
+    double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
+    double Xp = S.logXp[0], Zp = S.logZp[0], ZXp = S.logZXp[0], Zp2 = S.logZp2[0], ZpXp = S.logZpXp[0], XX = S.XpXq[0];
+    double lseRef = S.lse_ref[0], lseSum = S.lse_sum[0], thr = S.death_thr[0];
+    double Lmin = S.logLp[0]; int minSlot = S.imin_slot[0];
+    const unsigned cuid = S.cl_uid[0];
+    int status = PC_ST_RUNNING, error = PC_ERR_NONE;
+    const int seg_hi = i_nursery - 1;
+    double live_logZ_val = S.logzero;
+    const double log2v = log(2.0), ln2 = 0.6931471805599453;
+    const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
+    __syncthreads();
+    // per-lane minimum of the lane's stride (value, list position, slot)
+    double lm_v; int lm_p, lm_s;
+    auto rescan = [&]() {
+        lm_v = PC_HUGE; lm_p = 0x7fffffff; lm_s = -1;
+        for (int s = lane; s < Ncap; s += 64) {
+            const int p = sP[s];
+            if (p < 0) continue;
+            const double v = sL[s];
+            if (v < lm_v || (v == lm_v && p < lm_p)) { lm_v = v; lm_p = p; lm_s = s; }
+        }
+    };
+    // free slots are marked by pos = -1 in LDS for this kernel
+    for (int s = lane; s < Ncap; s += 64) if (S.live_cluster[s] < 0) sP[s] = -1;
+    __syncthreads();
+    rescan();
+
+    // prefetch registers for the chain about to be consumed
+    double pre[PC_PRE]; double preLast = 0.0; int preNlike = 0, preEpoch = 0;
+    auto prefetch = [&](int w) {
+        if (w < 0) return;
+        const double *b = S.baby_logL + (size_t)w * nr;
+#pragma unroll
+        for (int k = 0; k < PC_PRE; ++k) { const int i = k * 64 + lane; pre[k] = (i < nr - 1) ? b[i] : -PC_HUGE; }
+        preLast = b[nr - 1]; preNlike = S.ch_nlike[w]; preEpoch = S.ch_epoch[w];
+    };
+    prefetch(i_nursery - 1);
+
+    while (status == PC_ST_RUNNING) {
+        // ---- more_samples_needed
+        bool more = true;
+        if (S.max_ndead == 0) more = false;
+        else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
+        else if (S.use_prec) {
+            const double base = lseRef - l0 + Xp, tv = S.log_prec + logZ;
+            const int e = ((__double2hiint(lseSum) >> 20) & 0x7ff) - 1023;
+            if (base + (e + 1) * ln2 < tv - 1e-9) more = false;
+            else if (base + e * ln2 > tv + 1e-9) more = true;
+            else { live_logZ_val = base + log(lseSum); more = !(live_logZ_val < tv); }
+        }
+        if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
+        if (i_nursery == 0) break;
+
+        const int w = i_nursery - 1;
+        i_nursery--;
+        double cur[PC_PRE];
+#pragma unroll
+        for (int k = 0; k < PC_PRE; ++k) cur[k] = pre[k];
+        const double Llast = preLast;
+        nlike += preNlike; niter++;
+        const bool epoch_ok = (preEpoch == epoch);
+        prefetch(w - 1);
+        if (lane == 0) { S.pl_dead_idx[w] = -1; S.pl_ph_base[w] = nph; S.pl_ph_cuid[w] = cuid; }
+        if (!epoch_ok) {
+            if (lane == 0) for (int m = 0; m < (nr + 62) / 64; ++m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m] = 0ull;
+            continue;
+        }
+        const double Lg = Lmin;
+        // ---- phantoms (run_time_info.f90:747-757)
+        int nadd = 0;
+#pragma unroll
+        for (int k = 0; k < PC_PRE; ++k) {
+            if (k * 64 < nr - 1) {
+                const unsigned long long m = __ballot(cur[k] > Lg);
+                if (lane == 0) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + k] = m;
+                nadd += __popcll(m);
+            }
+        }
+        if (nph + nadd > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
+        nph += nadd;
+        bool replaced = false;
+        if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
+        if (Llast > Lg) {
+            // ---- delete_outermost_point + update_evidence: eight independent jobs in eight lanes
+            const double L = Lmin;
+            double a = -PC_HUGE, b = -PC_HUGE, c = -PC_HUGE;
+            const double cz = log2v + XX + 2 * L - l1 - l2;
+            if (lane == 0) { a = logZ; b = Xp + L - l1; }
+            else if (lane == 1) { a = Zp; b = Xp + L - l1; }
+            else if (lane == 2) { a = logZ2; b = log2v + ZXp + L - l1; c = cz; }
+            else if (lane == 3) { a = ZXp + l0 - l1; b = XX + L + l0 - l1 - l2; }
+            else if (lane == 4) { a = Zp2; b = log2v + ZpXp + L - l1; c = cz; }
+            else if (lane == 5) { a = ZpXp + l0 - l1; b = XX + L + l0 - l1 - l2; }
+            else if (lane == 6) { a = L - lseRef; }
+            else if (lane == 7) { a = fmin(Llast - lseRef, 0.0); }
+            const double m3 = (lane >= 6) ? 0.0 : fmax(a, fmax(b, c));
+            const double t1 = exp(a - m3), t2 = exp(b - m3), t3 = exp(c - m3);
+            const double r = m3 + log(t1 + t2 + t3);
+            const double logweight = Xp - l1;
+            logZ = readlane_f64(r, 0); Zp = readlane_f64(r, 1); logZ2 = readlane_f64(r, 2); ZXp = readlane_f64(r, 3);
+            Zp2 = readlane_f64(r, 4); ZpXp = readlane_f64(r, 5);
+            const double edel = readlane_f64(t1, 6), eadd = readlane_f64(t1, 7);
+            Xp = Xp + l0 - l1;
+            XX = XX + l0 - l2;
+            thr = L;
+            // ---- list bookkeeping: the last list entry moves into the hole, the baby is appended
+            const int slot = minSlot, pos_del = sP[slot], moved = sList[n - 1], src = sSrc[slot];
+            if (lane == 0) {
+                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = (src >= 0) ? -(1 + src) : slot;
+                S.pl_logw[w] = logweight; S.pl_postX[w] = Xp; S.pl_postZ[w] = logZ; S.pl_dead_cuid[w] = cuid;
+                S.pl_entry[w] = sE[slot];
+                sList[pos_del] = moved; sP[moved] = pos_del;
+                sL[slot] = Llast; sE[slot] = L; sP[slot] = n - 1; sList[n - 1] = slot; sSrc[slot] = w;
+            }
+            ndead++;
+            // live logsumexp bookkeeping (exact rescale when the baby is the new maximum)
+            if (Llast > lseRef) { lseSum = (lseSum - edel) * exp(lseRef - Llast) + 1.0; lseRef = Llast; }
+            else lseSum = lseSum - edel + eadd;
+            __syncthreads();
+            // ---- find_min_loglikelihoods: only the strides that changed are rescanned
+            if ((slot & 63) == lane || (moved & 63) == lane) rescan();
+            const vk_t best = wave_argmin(vk_t{lm_v, lm_p});
+            Lmin = best.v;
+            {   // slot of the winner: the lane whose cached minimum matches
+                const unsigned long long mm = __ballot(lm_v == best.v && lm_p == best.k);
+                const int wl = __ffsll((long long)mm) - 1;
+                minSlot = __builtin_amdgcn_readlane(lm_s, wl);
+            }
+            replaced = true;
+        } else {
+            if (lane == 0) {
+                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = -(1 + w);
+                S.pl_logw[w] = S.logzero; S.pl_postX[w] = 0.0; S.pl_postZ[w] = 0.0; S.pl_dead_cuid[w] = 0xFFFFFFFFu;
+                S.pl_entry[w] = Lg;
+            }
+            ndead++;
+        }
+        failures = replaced ? 0 : failures + 1;
+        // ---- update trigger (nested_sampling.F90:321); one cluster: logsumexp(logXp) = logXp
+        if (Xp <= lx_last + S.log_cf) { lx_last = Xp; status = PC_ST_UPDATE; }
+    }
+    __syncthreads();
+    for (int s = lane; s < Ncap; s += 64) {
+        S.live_logL[s] = sL[s]; S.live_entry[s] = sE[s]; S.slot_src[s] = sSrc[s];
+        if (sP[s] >= 0) { S.live_pos[s] = sP[s]; S.live_cluster[s] = 0; }
+    }
+    for (int p = lane; p < n; p += 64) S.cl_list[p] = sList[p];
+    if (lane == 0) {
+        S.logLp[0] = Lmin; S.imin_slot[0] = minSlot; S.logXp[0] = Xp; S.logZp[0] = Zp; S.logZXp[0] = ZXp;
+        S.logZp2[0] = Zp2; S.logZpXp[0] = ZpXp; S.XpXq[0] = XX; S.lse_ref[0] = lseRef; S.lse_sum[0] = lseSum;
+        S.death_thr[0] = thr;
+        ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->failures = failures;
+        ctl->ndead = ndead; ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = 0;
+        ctl->nlike = nlike; ctl->niter = niter; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
+        ctl->live_logZ = live_logZ_val;
     }
 }
 
@@ -433,7 +625,7 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
         for (int e = lane; e < nT; e += 64) dst[e] = row[e];
         if (lane == 0) {
             S.dead_logw[di] = S.pl_logw[w]; S.dead_postX[di] = S.pl_postX[w]; S.dead_postZ[di] = S.pl_postZ[w];
-            S.dead_cuid[di] = S.pl_dead_cuid[w];
+            S.dead_cuid[di] = S.pl_dead_cuid[w]; S.dead_entry[di] = S.pl_entry[w];
         }
     }
     int base = S.pl_ph_base[w];
@@ -480,9 +672,9 @@ __global__ __launch_bounds__(256) void k_install_live(PcState S, const double *r
     for (int s = tid; s < S.Ncap; s += 256) {
         if (s < n) {
             for (int e = 0; e < S.nT; ++e) S.live[(size_t)s * S.nT + e] = rows[(size_t)s * S.nT + e];
-            S.live_logL[s] = rows[(size_t)s * S.nT + S.l0]; S.live_cluster[s] = 0; S.live_pos[s] = s;
+            S.live_logL[s] = rows[(size_t)s * S.nT + S.l0]; S.live_cluster[s] = 0; S.live_pos[s] = s; S.live_entry[s] = S.logzero;
             S.cl_list[s] = s;
-        } else { S.live_logL[s] = PC_HUGE; S.live_cluster[s] = -1; S.live_pos[s] = 0; }
+        } else { S.live_logL[s] = PC_HUGE; S.live_cluster[s] = -1; S.live_pos[s] = 0; S.live_entry[s] = S.logzero; }
         S.slot_src[s] = -1;
     }
     __syncthreads();
@@ -710,7 +902,7 @@ __global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, c
 // ------------------------------------------------------------------------------------------
 static size_t consume_lds(const PcState *S, int NT)
 {
-    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
+    return sizeof(double) * (2 * (size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
            sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8) + 64;
 }
 
@@ -727,6 +919,15 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode);
     }
+    return 0;
+}
+
+extern "C" int pc_launch_consume_single(const PcState *S, hipStream_t st)
+{
+    const size_t sh = sizeof(double) * 2 * (size_t)S->Ncap + sizeof(int) * 3 * (size_t)S->Ncap + 64;
+    if (sh > 160 * 1024 || S->nr > 64 * PC_PRE) return 1;
+    hipFuncSetAttribute((const void *)k_consume_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_consume_single, dim3(1), dim3(64), sh, st, *S);
     return 0;
 }
 

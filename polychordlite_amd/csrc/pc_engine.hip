@@ -20,6 +20,7 @@ int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipSt
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
+int pc_launch_consume_single(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
 void pc_launch_clean(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *,
@@ -45,6 +46,26 @@ template <class T> void dfree(T *&p) { if (p) hipFree((void *)p); p = nullptr; }
 
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
 
+// HIP-event stopwatch per kernel class, on the engine's own stream (bench.py's roofline numbers)
+enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_N };
+struct KTimer {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    struct Span { int k; hipEvent_t a, b; };
+    std::vector<Span> open;
+    double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
+    hipEvent_t get() { if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); } return pool[used++]; }
+    hipEvent_t begin() { if (!on) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
+    void end(int k, hipEvent_t a) { if (!on) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
+    void collect() {   // call after a stream synchronisation
+        if (!on) return;
+        for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
+        open.clear(); used = 0;
+    }
+    void destroy() { for (auto e : pool) hipEventDestroy(e); pool.clear(); }
+};
+
 struct Engine {
     pchip_settings cfg{};
     PcState S{};
@@ -58,7 +79,9 @@ struct Engine {
     double *d_lo = nullptr, *d_hi = nullptr, *d_invcovT = nullptr, *d_mean = nullptr;
     double *d_dynL = nullptr; int *d_dynN = nullptr;
     Timing tm;
+    KTimer kt;
     int B = 0;
+    bool fast_ok = false;
 
     void alloc_phantom_side(int Pcap)
     {
@@ -76,6 +99,7 @@ struct Engine {
         }
         HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
         HIPCHK(hipStreamCreate(&st));
+        kt.on = c.profile != 0; kt.st = st;
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
         S.p0 = D; S.d0 = 2 * D; S.b0 = 2 * D + nDer; S.l0 = S.b0 + 1;
@@ -124,7 +148,7 @@ struct Engine {
         // state arrays
         const int Ncap = S.Ncap, maxc = S.maxc, nT = S.nT, nr = S.nr;
         S.live = dalloc<double>((size_t)Ncap * nT); S.live_logL = dalloc<double>(Ncap);
-        S.live_cluster = dalloc<int>(Ncap); S.live_pos = dalloc<int>(Ncap);
+        S.live_cluster = dalloc<int>(Ncap); S.live_pos = dalloc<int>(Ncap); S.live_entry = dalloc<double>(Ncap);
         S.cl_list = dalloc<int>((size_t)maxc * Ncap); S.cl_n = dalloc<int>(maxc);
         S.logZp = dalloc<double>(maxc); S.logXp = dalloc<double>(maxc); S.logZXp = dalloc<double>(maxc);
         S.logZp2 = dalloc<double>(maxc); S.logZpXp = dalloc<double>(maxc); S.logLp = dalloc<double>(maxc);
@@ -138,12 +162,13 @@ struct Engine {
         alloc_phantom_side(S.Pcap);
         S.dead = dalloc<double>((size_t)S.Dcap * nT); S.dead_logw = dalloc<double>(S.Dcap);
         S.dead_postX = dalloc<double>(S.Dcap); S.dead_postZ = dalloc<double>(S.Dcap); S.dead_cuid = dalloc<unsigned>(S.Dcap);
+        S.dead_entry = dalloc<double>(S.Dcap);
         S.babies = dalloc<double>((size_t)B * nr * nT); S.baby_logL = dalloc<double>((size_t)B * nr);
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         S.pl_dead_idx = dalloc<int>(B); S.pl_dead_src = dalloc<int>(B); S.pl_logw = dalloc<double>(B);
-        S.pl_postX = dalloc<double>(B); S.pl_postZ = dalloc<double>(B); S.pl_dead_cuid = dalloc<unsigned>(B);
+        S.pl_postX = dalloc<double>(B); S.pl_postZ = dalloc<double>(B); S.pl_entry = dalloc<double>(B); S.pl_dead_cuid = dalloc<unsigned>(B);
         S.pl_ph_base = dalloc<int>(B); S.pl_ph_mask = dalloc<unsigned long long>((size_t)B * PC_MASK_WORDS);
         S.pl_ph_cuid = dalloc<unsigned>(B); S.slot_src = dalloc<int>(Ncap);
         S.ctl = dalloc<PcCtl>(1);
@@ -179,6 +204,7 @@ struct Engine {
     {
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        kt.collect();
     }
 
     void ensure_capacity()
@@ -192,7 +218,7 @@ struct Engine {
                 HIPCHK(hipStreamSynchronize(st));
                 hipFree(p); p = q;
             };
-            grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1);
+            grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1); grow(S.dead_entry, 1);
             S.Dcap = nd;
         }
         if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) {
@@ -206,7 +232,9 @@ struct Engine {
     {
         tm.updates++;
         const int nph = h_ctl->nphantom, nc = h_ctl->ncluster;
+        hipEvent_t e0 = kt.begin();
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
+        kt.end(KT_CLEAN, e0);
         int total = 0;
         HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -214,7 +242,9 @@ struct Engine {
         h_ctl->nphantom = total;
         HIPCHK(hipMemcpyAsync(&S.ctl->nphantom, &h_ctl->nphantom, sizeof(int), hipMemcpyHostToDevice, st));
         pc_launch_reset_thresholds(&S, st);
+        hipEvent_t e1 = kt.begin();
         covmats(total, nc);
+        kt.end(KT_COV, e1);
     }
 
     void covmats(int nph, int nc)
@@ -275,16 +305,30 @@ struct Engine {
         unsigned batch = 0;
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
+        const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
+        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && !cfg.force_general;
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
             if (h_ctl->i_nursery == 0) {
                 ensure_capacity();
-                if (pc_launch_nhats(&S, batch, B, st) || pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                hipEvent_t e0 = kt.begin();
+                if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                kt.end(KT_NHATS, e0);
+                hipEvent_t e1 = kt.begin();
+                if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                kt.end(KT_SLICE, e1);
                 batch++; tm.batches++;
             }
-            if (pc_launch_consume(&S, 0, (h_ctl->ncluster > 1 || cfg.do_clustering) ? 1 : wide, st)) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
+            hipEvent_t e2 = kt.begin();
+            int rc2;
+            if (fast_ok && h_ctl->ncluster == 1) rc2 = pc_launch_consume_single(&S, st);
+            else rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
+            if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
+            kt.end(KT_CONSUME, e2);
+            hipEvent_t e3 = kt.begin();
             pc_launch_apply(&S, batch - 1, B, st);
+            kt.end(KT_APPLY, e3);
             read_ctl();
             tm.rounds++;
             if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; }
@@ -311,11 +355,14 @@ struct Engine {
         out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
         out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
+        for (int k = 0; k < KT_N; ++k) { out->k_time_s[k] = kt.total_ms[k] * 1e-3; out->k_launches[k] = kt.launches[k]; }
         (void)nlike_dev;
         out->dead = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, h_ctl->ndead) * nT);
         out->logweights = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
         HIPCHK(hipMemcpy(out->dead, S.dead, sizeof(double) * (size_t)h_ctl->ndead * nT, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out->logweights, S.dead_logw, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
+        out->entry = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
+        HIPCHK(hipMemcpy(out->entry, S.dead_entry, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
         int nl = 0;
         for (int s = 0; s < S.Ncap; ++s) nl += hcl[s] >= 0;
         out->nlive_final = nl;
@@ -351,7 +398,7 @@ struct Engine {
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL,
-                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.pl_logw, &S.pl_postX, &S.pl_postZ, &ph2, &phL2, &psum, &mean,
+                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.pl_logw, &S.pl_postX, &S.pl_postZ, &S.pl_entry, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
@@ -360,6 +407,7 @@ struct Engine {
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &S.pl_dead_cuid, &S.pl_ph_cuid, &phC2 };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.pl_ph_mask); dfree(phU2); dfree(keep); dfree(S.ctl);
+        kt.destroy();
         if (h_ctl) hipHostFree(h_ctl); h_ctl = nullptr;
         if (st) hipStreamDestroy(st); st = nullptr;
     }
@@ -398,7 +446,7 @@ int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior
 
 void pchip_result_free(pchip_result *r)
 {
-    std::free(r->dead); std::free(r->logweights); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
+    std::free(r->dead); std::free(r->logweights); std::free(r->entry); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
     std::free(r->post_mean); std::free(r->post_var);
     std::memset(r, 0, sizeof(*r));
 }

@@ -49,6 +49,7 @@ struct PcState {
     double *live_logL;           // [Ncap]
     int *live_cluster;           // [Ncap] cluster index, -1 = free slot
     int *live_pos;               // [Ncap] position in the cluster's list (reference ordering)
+    double *live_entry;          // [Ncap] global contour at the moment the point entered the live set
     int *cl_list;                // [maxc][Ncap] slot ids in list order (rebuilt after every segment)
     int *cl_n;                   // [maxc]
     // ---- per-cluster evidence state (run_time_info.f90:60-100)
@@ -70,6 +71,7 @@ struct PcState {
     double *dead_logw;           // [Dcap]
     double *dead_postX, *dead_postZ;   // posterior-stack columns (calculate.f90:53-79)
     unsigned *dead_cuid;
+    double *dead_entry;          // [Dcap] entry contour of the dead point (== birth when B = 1)
     // ---- nursery (one synchronous batch of B chains)
     double *babies;              // [B][nr][nT]
     double *baby_logL;           // [B][nr]
@@ -80,7 +82,7 @@ struct PcState {
     // ---- plan written by the consume kernel for the apply kernels
     int *pl_dead_idx;            // [B] index in dead[] or -1
     int *pl_dead_src;            // [B] >=0: live slot; <0: -(1+chain) whose last baby is the row
-    double *pl_logw, *pl_postX, *pl_postZ;
+    double *pl_logw, *pl_postX, *pl_postZ, *pl_entry;
     unsigned *pl_dead_cuid;
     int *pl_ph_base;             // [B] first phantom row of the chain
     unsigned long long *pl_ph_mask;     // [B][PC_MASK_WORDS]

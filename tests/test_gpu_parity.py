@@ -1,0 +1,171 @@
+"""GPU (-m gpu): the HIP engine, called through its C ABI, against the oracle on identical seeded
+inputs (the engine and the oracle draw the same Philox numbers, so trajectories coincide):
+  * kernel level: K0 directions + K1 slice chains == oracle pc_slice_chain, rel. error <= 1e-9
+  * run level: identical ndead / nlike / niter / nbatches, logZ to 1e-8, every dead row to 1e-7
+  * golden level: logZ within 3 sigma of the analytic truth and of the reference's own numbers
+  * properties at BASELINE size: evidence replay of the engine's own dead points == its logZ,
+    monotone death sequence, reproducibility for a fixed seed.
+Floating-point tolerance (north_star): fp64 everywhere; 1e-9 relative on kernel outputs, 1e-8 absolute
+on logZ; integers exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import oracle_api as orc
+
+pytestmark = pytest.mark.gpu
+
+BOX = {"gaussian": (None, None), "rastrigin": (-5.12, 5.12), "twin_gaussian": (-1.0, 1.0)}
+
+
+def _settings(api, D, nDer, **kw):
+    lib = api.load()
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+@pytest.mark.parametrize("kind,D,nDer,nr,nchains", [("gaussian", 20, 2, 40, 6), ("gaussian", 4, 1, 8, 3),
+                                                   ("gaussian", 2, 0, 5, 3), ("rastrigin", 10, 0, 30, 4),
+                                                   ("twin_gaussian", 30, 1, 40, 3), ("gaussian", 20, 2, 100, 2),
+                                                   ("gaussian", 33, 0, 40, 2)])
+def test_slice_chains_match_oracle(engine, kind, D, nDer, nr, nchains):
+    api = engine; lib = api.load(); olib = orc.load()
+    lo, hi = BOX[kind]
+    seed = 11
+    s = _settings(api, D, nDer, num_repeats=nr, seed=seed)
+    L, P, keep = api.make_problem(kind, D, nDer, lo, hi)
+    so = orc.settings(D, nDer, num_repeats=nr, seed=seed)
+    Lo, Po, keep2 = orc.make_problem(kind, D, lo, hi)
+    nT = 2 * D + nDer + 2
+    rng = np.random.default_rng(D * 1000 + nr)
+    lo_a = np.broadcast_to(0.0 if lo is None else lo, (D,)); hi_a = np.broadcast_to(1.0 if hi is None else hi, (D,))
+    seeds = np.zeros((nchains, nT))
+    for c in range(nchains):
+        cube = 0.5 + 0.04 * rng.standard_normal(D)
+        if kind == "twin_gaussian":
+            cube[:2] = 0.75 + 0.02 * rng.standard_normal(2)
+        th = np.ascontiguousarray(lo_a + (hi_a - lo_a) * cube)
+        phi = np.zeros(max(nDer, 1))
+        seeds[c, :D] = cube; seeds[c, D:2 * D] = th
+        seeds[c, nT - 1] = olib.pc_like_eval(C.byref(Lo), orc.dptr(th), D, orc.dptr(phi), nDer)
+        seeds[c, 2 * D:2 * D + nDer] = phi[:nDer]
+    contour = float(seeds[:, nT - 1].min()) - 4.0
+    A = rng.standard_normal((D, D)) * 0.02
+    chol = np.ascontiguousarray(np.linalg.cholesky(A @ A.T + 4e-4 * np.eye(D)))
+    babies = np.zeros((nchains, nr, nT)); nh = np.zeros((nchains, nr, D)); nl = np.zeros(nchains, dtype=np.int32)
+    rc = lib.pchip_slice_chains(C.byref(s), C.byref(L), C.byref(P), 5, nchains, api.dptr(seeds), api.dptr(chol), contour,
+                                api.dptr(babies), api.dptr(nh), nl.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0
+    for c in range(nchains):
+        ob, onh, on = orc.slice_chain(so, Lo, Po, seed, 5, c, seeds[c], chol, contour)
+        assert on == nl[c]
+        rel = np.abs(babies[c] - ob) / np.maximum(1.0, np.abs(ob))
+        assert rel.max() < 1e-9
+        assert np.all(ob[:, -1] >= contour)            # every baby is inside the contour it was born under
+        assert np.all(ob[:, -2] == contour)
+        # the shuffled oracle directions are exactly the generated set (unit vectors, first one fixed)
+        d = np.abs(nh[c][:, None, :] - onh[None, :, :]).max(-1).min(0)
+        assert d.max() < 1e-10
+        assert np.allclose(np.linalg.norm(nh[c], axis=1), 1.0, atol=1e-12)
+
+
+RUNS = [  # kind D nDer nlive nr B general
+    ("gaussian", 20, 2, 100, 20, 1, 0), ("gaussian", 20, 2, 200, 40, 16, 0), ("gaussian", 20, 2, 200, 40, 16, 1),
+    ("gaussian", 4, 1, 100, 20, 32, 0), ("gaussian", 20, 2, 500, 40, 128, 0), ("rastrigin", 4, 0, 200, 12, 50, 0),
+    ("twin_gaussian", 6, 1, 150, 12, 40, 1),
+]
+
+
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,B,general", RUNS)
+def test_full_run_matches_oracle(engine, kind, D, nDer, nlive, nr, B, general):
+    api = engine
+    lo, hi = BOX[kind]
+    s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B, force_general=general)
+    L, P, keep = api.make_problem(kind, D, nDer, lo, hi)
+    g = api.run(s, L, P)
+    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B)
+    Lo, Po, keep2 = orc.make_problem(kind, D, lo, hi)
+    o = orc.run(so, Lo, Po)
+    for k in ("ndead", "nlike", "niter", "nbatches", "ncluster_dead"):
+        assert g[k] == o[k], (k, g[k], o[k])
+    assert abs(g["logZ"] - o["logZ"]) < 1e-8
+    assert abs(g["logZerr"] - o["logZerr"]) < 1e-8
+    rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
+    assert rel.max() < 1e-7
+    ok = o["logweights"] > -1e29
+    assert np.array_equal(ok, g["logweights"] > -1e29)
+    assert np.abs(g["logweights"][ok] - o["logweights"][ok]).max() < 1e-9
+    assert np.allclose(g["post_mean"], o["post_mean"], atol=1e-8)
+
+
+def test_analytic_evidence_and_reference_numbers(engine, golden):
+    """20-D Gaussian, nlive 500 (ini/gaussian.ini): truth logZ = 0; the reference's 8 seeds give
+    mean 0.027 +- 0.186/sqrt(8); posterior mean 0.5, sd 0.1 per dimension."""
+    api = engine
+    ref = [c for c in golden["ref_native"] if c["like"] == "gaussian" and c["nlive"] == 500]
+    L, P, keep = api.make_problem("gaussian", 20, 2)
+    zs, nds = [], []
+    for seed in range(6):
+        s = _settings(api, 20, 2, nlive=500, num_repeats=40, seed=200 + seed, batch=128)
+        g = api.run(s, L, P)
+        assert abs(g["logZ"]) < 3 * g["logZerr"]
+        assert abs(g["logZerr"] - ref[0]["logZerr"]) < 0.02
+        assert np.all(np.abs(g["post_mean"] - 0.5) < 0.02) and np.all(np.abs(np.sqrt(g["post_var"]) - 0.1) < 0.02)
+        zs.append(g["logZ"]); nds.append(g["ndead"])
+    sig = ref[0]["logZerr"]
+    assert abs(np.mean(zs) - np.mean([c["logZ"] for c in ref])) < 3 * sig * np.sqrt(1 / 6 + 1 / 8)
+    # synchronous batches waste ~B/(2 nlive) of the spawns, so ndead is a little larger than linear mode
+    assert 0.98 * np.mean([c["ndead"] for c in ref]) < np.mean(nds) < 1.25 * np.mean([c["ndead"] for c in ref])
+
+
+def test_baseline_size_properties(engine):
+    """BASELINE configs[1] (20-D Gaussian nlive=2000): size-independent properties"""
+    api = engine
+    from polychordlite_amd.merge import evidence_replay, lived_records
+    s = _settings(api, 20, 2, nlive=2000, num_repeats=40, seed=77, batch=0)
+    L, P, keep = api.make_problem("gaussian", 20, 2)
+    g = api.run(s, L, P)
+    assert abs(g["logZ"]) < 3 * g["logZerr"] and 0.08 < g["logZerr"] < 0.11
+    lived = g["logweights"] > -1e29
+    d = g["dead"][lived]
+    assert np.all(np.diff(d[:, -1]) >= 0)                       # deaths are sorted by logL
+    assert np.all(d[:, -1] > d[:, -2])                          # each point lies above its birth contour
+    lz, var = evidence_replay(*lived_records(g))                # replay of its own records == its evidence
+    assert abs(lz - g["logZ"]) < 1e-6 and abs(var - g["varlogZ"]) < 1e-6
+    assert np.all((d[:, :20] >= 0) & (d[:, :20] <= 1))          # cube coordinates
+    assert np.allclose(d[:, 20:40], d[:, :20], atol=1e-15)      # uniform prior on [0,1] is the identity
+    g2 = api.run(s, L, P)                                        # same seed -> bit-identical run
+    assert g2["ndead"] == g["ndead"] and g2["nlike"] == g["nlike"] and g2["logZ"] == g["logZ"]
+    assert np.array_equal(g2["dead"], g["dead"])
+    s.seed = 78
+    g3 = api.run(s, L, P)
+    assert g3["logZ"] != g["logZ"]
+
+
+def test_edge_cases(engine):
+    api = engine
+    L, P, keep = api.make_problem("gaussian", 3, 0)
+    # max_ndead stops the run early (nested_sampling.F90:528)
+    s = _settings(api, 3, 0, nlive=50, num_repeats=6, seed=1, batch=8, max_ndead=120)
+    g = api.run(s, L, P)
+    so = orc.settings(3, 0, nlive=50, num_repeats=6, seed=1, batch=8, max_ndead=120)
+    Lo, Po, k2 = orc.make_problem("gaussian", 3)
+    o = orc.run(so, Lo, Po)
+    assert g["ndead"] == o["ndead"] and g["nlike"] == o["nlike"] and abs(g["logZ"] - o["logZ"]) < 1e-8
+    # nprior > nlive: the initial set is trimmed (nested_sampling.F90:201-205)
+    s = _settings(api, 3, 0, nlive=40, nprior=90, num_repeats=6, seed=2, batch=4)
+    g = api.run(s, L, P)
+    so = orc.settings(3, 0, nlive=40, nprior=90, num_repeats=6, seed=2, batch=4)
+    o = orc.run(so, Lo, Po)
+    assert g["ndead"] == o["ndead"] and g["nlike"] == o["nlike"] and abs(g["logZ"] - o["logZ"]) < 1e-8
+    # batch larger than nlive and a 1-D problem
+    L1, P1, k1 = api.make_problem("gaussian", 1, 0)
+    s = _settings(api, 1, 0, nlive=30, num_repeats=3, seed=3, batch=64)
+    g = api.run(s, L1, P1)
+    so = orc.settings(1, 0, nlive=30, num_repeats=3, seed=3, batch=64)
+    Lo1, Po1, k3 = orc.make_problem("gaussian", 1)
+    o = orc.run(so, Lo1, Po1)
+    assert g["ndead"] == o["ndead"] and g["nlike"] == o["nlike"] and abs(g["logZ"] - o["logZ"]) < 1e-8
