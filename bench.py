@@ -142,6 +142,8 @@ def main():
                "logZ_truth": 0.0, "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
                "merged": merged, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
+               "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
+               "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                "reference_cpu_evals_per_s_survey_container": 357e3}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(nDims, nDer, nr)

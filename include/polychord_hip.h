@@ -86,6 +86,7 @@ typedef struct {
     int feedback;
     int profile;        /* 1: HIP-event stopwatch around every kernel class (bench.py) */
     int force_general;  /* 1: always use the general contraction kernel (tests) */
+    int ablate;         /* developer timing hook: bit mask of contraction sub-steps to skip; 0 = product */
 } pchip_settings;
 
 typedef struct {
@@ -108,6 +109,7 @@ typedef struct {
     long ndead, nlike, niter, nbatches, nrounds, nupdates;
     int ncluster, ncluster_dead, nTotal, batch;
     double t_generate, t_loop, t_final, t_total;   /* host wall-clock of the phases, seconds */
+    double t_setup, t_results, t_teardown;         /* allocation / result download / free */
     double k_time_s[6]; long k_launches[6];        /* HIP-event time per kernel class: nhats, slice,
                                                       consume, apply, clean, covmats (profile=1) */
     double *dead, *logweights;     /* [ndead][nTotal] rows [cube|theta|phi|birth|logL], [ndead] */

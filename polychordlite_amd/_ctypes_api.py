@@ -30,7 +30,7 @@ class Settings(C.Structure):
                 ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
-                ("force_general", C.c_int)]
+                ("force_general", C.c_int), ("ablate", C.c_int)]
 
 
 class Like(C.Structure):
@@ -47,6 +47,7 @@ class Result(C.Structure):
                 ("niter", C.c_long), ("nbatches", C.c_long), ("nrounds", C.c_long), ("nupdates", C.c_long),
                 ("ncluster", C.c_int), ("ncluster_dead", C.c_int), ("nTotal", C.c_int), ("batch", C.c_int),
                 ("t_generate", C.c_double), ("t_loop", C.c_double), ("t_final", C.c_double), ("t_total", C.c_double),
+                ("t_setup", C.c_double), ("t_results", C.c_double), ("t_teardown", C.c_double),
                 ("k_time_s", C.c_double * 6), ("k_launches", C.c_long * 6),
                 ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("entry", C.POINTER(C.c_double)),
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
@@ -121,7 +122,7 @@ def run(settings, like, prior):
     out = dict(logZ=r.logZ, logZerr=float(np.sqrt(abs(r.varlogZ))), varlogZ=r.varlogZ, ndead=nd, nlike=r.nlike,
                niter=r.niter, nbatches=r.nbatches, nrounds=r.nrounds, nupdates=r.nupdates, ncluster=r.ncluster,
                ncluster_dead=r.ncluster_dead, nTotal=nT, batch=r.batch, t_generate=r.t_generate, t_loop=r.t_loop,
-               t_final=r.t_final, t_total=r.t_total,
+               t_final=r.t_final, t_total=r.t_total, t_setup=r.t_setup, t_results=r.t_results, t_teardown=r.t_teardown,
                kernel_time={n: {"total_s": r.k_time_s[i], "launches": r.k_launches[i]}
                             for i, n in enumerate(KERNEL_CLASSES) if r.k_launches[i] > 0},
                dead=np.ctypeslib.as_array(r.dead, shape=(nd, nT)).copy(),

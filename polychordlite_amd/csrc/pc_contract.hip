@@ -206,10 +206,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
             if (plan_w >= 0) {
                 if (tid == 0) {
                     const int src = S.slot_src[slot_del];
-                    S.pl_dead_idx[plan_w] = ndead;
-                    S.pl_dead_src[plan_w] = (src >= 0) ? -(1 + src) : slot_del;
-                    S.pl_logw[plan_w] = logweight; S.pl_postX[plan_w] = lseX; S.pl_postZ[plan_w] = logZ;
-                    S.pl_dead_cuid[plan_w] = H.cUid[cd]; S.pl_entry[plan_w] = H.sE[slot_del];
+                    S.plan[plan_w].dead_idx = ndead;
+                    S.plan[plan_w].dead_src = (src >= 0) ? -(1 + src) : slot_del;
+                    S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lseX; S.plan[plan_w].postZ = logZ;
+                    S.plan[plan_w].dead_cuid = H.cUid[cd]; S.plan[plan_w].entry = H.sE[slot_del];
                 }
             } else {   // kill-off / trimming: rows are current in live[], copy immediately
                 const double *row = S.live + (size_t)slot_del * nT;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         i_nursery--;
         nlike += S.ch_nlike[w];
         niter++;
-        if (tid == 0) { S.pl_dead_idx[w] = -1; S.pl_ph_base[w] = nph; for (int m = 0; m < PC_MASK_WORDS; ++m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m] = 0ull; }
+        if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
         __syncthreads();
         if (S.ch_epoch[w] != epoch) continue;           // nested_sampling.F90:313 epoch guard
 
@@ -317,25 +317,25 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                 const int i = base + tid;
                 const bool f = (i < nr - 1) && (blog[i] > Lg);
                 const unsigned long long m = __ballot(f);
-                if (lane == 0 && m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + (base >> 6) + (tid >> 6)] = m;
+                if (lane == 0 && m) S.plan[w].ph_mask[(base >> 6) + (tid >> 6)] = m;
                 if (NT == 64) nph_add += __popcll(m);
             }
             if (NT > 64) {   // count after the masks are visible
                 __syncthreads();
-                for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m]);
+                for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
             }
         } else {
             for (int i = 0; i < nr - 1; ++i) {
                 if (!(blog[i] > Lg)) continue;
                 const int id = block_identify<NT>(S, H, S.babies + ((size_t)w * nr + i) * nT, nc);
                 if (id == ca) {
-                    if (tid == 0) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + (i >> 6)] |= (1ull << (i & 63));
+                    if (tid == 0) S.plan[w].ph_mask[(i >> 6)] |= (1ull << (i & 63));
                     nph_add++;
                 }
             }
         }
         if (nph + nph_add > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
-        if (tid == 0) S.pl_ph_cuid[w] = H.cUid[ca];
+        if (tid == 0) S.plan[w].ph_cuid = H.cUid[ca];
         nph += nph_add;
 
         const double Llast = blog[nr - 1];
@@ -377,9 +377,9 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
             // failed spawn: the last baby is recorded as dead with zero weight (run_time_info.f90:781-785)
             if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
             if (tid == 0) {
-                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = -(1 + w);
-                S.pl_logw[w] = S.logzero; S.pl_postX[w] = 0.0; S.pl_postZ[w] = 0.0; S.pl_dead_cuid[w] = 0xFFFFFFFFu;
-                S.pl_entry[w] = Lg;
+                S.plan[w].dead_idx = ndead; S.plan[w].dead_src = -(1 + w);
+                S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
+                S.plan[w].entry = Lg;
             }
             ndead++;
         }
@@ -431,22 +431,28 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
 // ------------------------------------------------------------------------------------------
 #define PC_PRE 8   /* prefetch registers per lane: num_repeats <= 512 */
 
-__global__ __launch_bounds__(64) void k_consume_single(PcState S)
+__global__ __launch_bounds__(64) void k_consume_single(PcState S, int final_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
-    const int Ncap = S.Ncap, nr = S.nr;
-    double *sL = (double *)smem;
-    double *sE = sL + Ncap;
-    int *sP = (int *)(sE + Ncap);
-    int *sList = sP + Ncap;
-    int *sSrc = sList + Ncap;
+    const int Ncap = S.Ncap, nr = S.nr, nT = S.nT;
+    const int NS = (Ncap + 63) & ~63;          // padded stride count: every lane scans NS/64 slots
+    double *sL = (double *)smem;               // [NS] logL, +HUGE for free / padding slots
+    double *sE = sL + NS;                      // [NS] entry contour
+    int *sP = (int *)(sE + NS);                // [NS] list position, 0x7fffffff for free slots
+    int *sList = sP + NS;                      // [NS] position -> slot
+    int *sSrc = sList + NS;                    // [NS]
     PcCtl *ctl = S.ctl;
-    for (int s = lane; s < Ncap; s += 64) { sL[s] = S.live_logL[s]; sE[s] = S.live_entry[s]; sP[s] = S.live_pos[s]; sSrc[s] = S.slot_src[s]; }
-    const int n = S.cl_n[0];
+    for (int s = lane; s < NS; s += 64) {
+        const bool used = s < Ncap && S.live_cluster[s] >= 0;
+        sL[s] = used ? S.live_logL[s] : PC_HUGE; sE[s] = used ? S.live_entry[s] : S.logzero;
+        sP[s] = used ? S.live_pos[s] : 0x7fffffff; sSrc[s] = s < Ncap ? S.slot_src[s] : -1;
+    }
+    int n = S.cl_n[0];
     for (int p = lane; p < n; p += 64) sList[p] = S.cl_list[p];
     int i_nursery = ctl->i_nursery, failures = ctl->failures, ndead = ctl->ndead, nph = ctl->nphantom;
     const int epoch = ctl->admin_epoch;
+    int nc_dead = ctl->ncluster_dead, nc = ctl->ncluster;
     long long nlike = ctl->nlike, niter = ctl->niter;
     double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
     double Xp = S.logXp[0], Zp = S.logZp[0], ZXp = S.logZXp[0], Zp2 = S.logZp2[0], ZpXp = S.logZpXp[0], XX = S.XpXq[0];
@@ -457,23 +463,116 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
     const int seg_hi = i_nursery - 1;
     double live_logZ_val = S.logzero;
     const double log2v = log(2.0), ln2 = 0.6931471805599453;
-    const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
+    double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
     __syncthreads();
-    // per-lane minimum of the lane's stride (value, list position, slot)
-    double lm_v; int lm_p, lm_s;
-    auto rescan = [&]() {
-        lm_v = PC_HUGE; lm_p = 0x7fffffff; lm_s = -1;
-        for (int s = lane; s < Ncap; s += 64) {
-            const int p = sP[s];
-            if (p < 0) continue;
-            const double v = sL[s];
-            if (v < lm_v || (v == lm_v && p < lm_p)) { lm_v = v; lm_p = p; lm_s = s; }
+    // per-lane minimum of the lane's stride: (value, list position, slot)
+    double lm_v = PC_HUGE; int lm_p = 0x7fffffff, lm_s = -1;
+    {
+        double bv = PC_HUGE; int bp = 0x7fffffff, bs = -1;
+#pragma unroll 8
+        for (int s = lane; s < NS; s += 64) {
+            const double v = sL[s]; const int p = sP[s];
+            const bool t = (v < bv) | ((v == bv) & (p < bp));
+            bv = t ? v : bv; bp = t ? p : bp; bs = t ? s : bs;
         }
+        lm_v = bv; lm_p = bp; lm_s = bs;
+    }
+    // cooperative rescan of ONE stride (the one that lost its minimum): its NS/64 slots are read by
+    // NS/64 different lanes and reduced with a DPP argmin; the owner lane takes the result.
+    auto rescan_stride = [&](int owner) {
+        vk_t best{PC_HUGE, 0x7fffffff};
+        for (int j0 = 0; j0 < NS / 64; j0 += 64) {
+            const int j = j0 + lane;
+            const int s = owner + 64 * j;
+            const bool in = j < NS / 64;
+            const double v = in ? sL[in ? s : 0] : PC_HUGE; const int p = in ? sP[in ? s : 0] : 0x7fffffff;
+            best = vk_min(best, vk_t{v, p});
+        }
+        best = wave_argmin(best);
+        // slot of the winner: unique (value, position) pair inside the stride
+        int ws = -1;
+        for (int j0 = 0; j0 < NS / 64; j0 += 64) {
+            const int j = j0 + lane, s = owner + 64 * j;
+            const bool hit = (j < NS / 64) && sL[(j < NS / 64) ? s : 0] == best.v && sP[(j < NS / 64) ? s : 0] == best.k;
+            const unsigned long long mm = __ballot(hit);
+            if (mm) ws = owner + 64 * (j0 + __ffsll((long long)mm) - 1);
+        }
+        if (lane == owner) { lm_v = best.v; lm_p = best.k; lm_s = ws; }
     };
-    // free slots are marked by pos = -1 in LDS for this kernel
-    for (int s = lane; s < Ncap; s += 64) if (S.live_cluster[s] < 0) sP[s] = -1;
-    __syncthreads();
-    rescan();
+    auto refresh_min = [&]() {
+        const vk_t best = wave_argmin(vk_t{lm_v, lm_p});
+        Lmin = best.v;
+        const unsigned long long mm = __ballot(lm_v == best.v && lm_p == best.k);
+        const int wl = __ffsll((long long)mm) - 1;
+        minSlot = __builtin_amdgcn_readlane(lm_s, wl);
+    };
+
+    // one death of the lowest live point; `Ladd` = logL of the point that takes its slot (normal mode)
+    // or -HUGE (kill-off).  Eight independent log-space jobs, one per lane (update_evidence,
+    // run_time_info.f90:211-296), plus the logs needed by the next kill-off step.
+    const int AB = S.ablate;
+    auto evidence_jobs = [&](double L, double Ladd, double &edel, double &eadd, double &nl0, double &nl1, double &nl2) {
+        if (AB & 1) { edel = 0; eadd = 0; nl0 = l0; nl1 = l1; nl2 = l2; logZ += 1e-9; return; }
+        // uniform sub-expressions once, then branch-free per-lane selection
+        const double cz = log2v + XX + 2 * L - l1 - l2, bz = Xp + L - l1, bx = XX + L + l0 - l1 - l2, d01 = l0 - l1;
+        const double NH = -PC_HUGE;
+        double a = (lane == 0) ? logZ : (lane == 1) ? Zp : (lane == 2) ? logZ2 : (lane == 3) ? ZXp + d01
+                 : (lane == 4) ? Zp2 : (lane == 5) ? ZpXp + d01 : (lane == 6) ? L - lseRef
+                 : (lane == 7) ? fmin(Ladd - lseRef, 0.0) : 1.0;
+        double b = (lane <= 1) ? bz : (lane == 2) ? log2v + ZXp + L - l1 : (lane == 3 || lane == 5) ? bx
+                 : (lane == 4) ? log2v + ZpXp + L - l1 : NH;
+        double c = (lane == 2 || lane == 4) ? cz : NH;
+        const double m3 = (lane >= 6) ? 0.0 : fmax(a, fmax(b, c));
+        const double t1 = exp(a - m3), t2 = exp(b - m3), t3 = exp(c - m3);
+        // lanes 8..10: log(n-1), log(n), log(n+1) for a shrinking live set
+        const double larg = (lane >= 8 && lane <= 10) ? fmax((double)(n + lane - 9), 1e-300) : (t1 + t2 + t3);
+        const double r = m3 + log(larg);
+        logZ = readlane_f64(r, 0); Zp = readlane_f64(r, 1); logZ2 = readlane_f64(r, 2); ZXp = readlane_f64(r, 3);
+        Zp2 = readlane_f64(r, 4); ZpXp = readlane_f64(r, 5);
+        edel = readlane_f64(t1, 6); eadd = readlane_f64(t1, 7);
+        nl0 = readlane_f64(r, 8); nl1 = readlane_f64(r, 9); nl2 = readlane_f64(r, 10);
+    };
+
+    if (final_mode) {
+        // nested_sampling.F90:381-384: kill the remaining live points lowest first (no replacement)
+        while (n > 0) {
+            if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
+            const double L = Lmin;
+            const double logweight = Xp - l1;
+            double edel, eadd, nl0, nl1, nl2;
+            evidence_jobs(L, -PC_HUGE, edel, eadd, nl0, nl1, nl2);
+            Xp = Xp + l0 - l1; XX = XX + l0 - l2; thr = L;
+            const int slot = minSlot, pos_del = sP[slot], moved = sList[n - 1];
+            {   // rows are current in live[] (the plan was applied before this launch)
+                const double *row = S.live + (size_t)slot * nT;
+                double *dst = S.dead + (size_t)ndead * nT;
+                for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+                if (lane == 0) {
+                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = (n > 1) ? Xp : Xp; S.dead_postZ[ndead] = logZ;
+                    S.dead_cuid[ndead] = cuid; S.dead_entry[ndead] = sE[slot];
+                }
+            }
+            if (lane == 0) {
+                sList[pos_del] = moved; sP[moved] = pos_del;
+                sL[slot] = PC_HUGE; sP[slot] = 0x7fffffff;
+            }
+            ndead++; n--;
+            l0 = nl0; l1 = nl1; l2 = nl2;          // log(n), log(n+1), log(n+2) of the shrunk set
+            __builtin_amdgcn_wave_barrier();
+            if ((moved & 63) == lane && moved != slot) {
+                if (lm_s == moved) lm_p = pos_del;
+                else if (sL[moved] == lm_v && pos_del < lm_p) { lm_s = moved; lm_p = pos_del; }
+            }
+            rescan_stride(slot & 63);
+            refresh_min();
+        }
+        if (status == PC_ST_RUNNING) {
+            // delete_cluster (run_time_info.f90:507-598) for the last cluster
+            if (lane == 0 && nc_dead < S.maxc_dead) { S.logZp_dead[nc_dead] = Zp; S.logZp2_dead[nc_dead] = Zp2; }
+            nc_dead++; nc = 0;
+            status = PC_ST_DONE;
+        }
+    }
 
     // prefetch registers for the chain about to be consumed
     double pre[PC_PRE]; double preLast = 0.0; int preNlike = 0, preEpoch = 0;
@@ -484,14 +583,14 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
         for (int k = 0; k < PC_PRE; ++k) { const int i = k * 64 + lane; pre[k] = (i < nr - 1) ? b[i] : -PC_HUGE; }
         preLast = b[nr - 1]; preNlike = S.ch_nlike[w]; preEpoch = S.ch_epoch[w];
     };
-    prefetch(i_nursery - 1);
+    if (!final_mode) prefetch(i_nursery - 1);
 
     while (status == PC_ST_RUNNING) {
         // ---- more_samples_needed
         bool more = true;
         if (S.max_ndead == 0) more = false;
         else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
-        else if (S.use_prec) {
+        else if (S.use_prec && !(AB & 32)) {
             const double base = lseRef - l0 + Xp, tv = S.log_prec + logZ;
             const int e = ((__double2hiint(lseSum) >> 20) & 0x7ff) - 1023;
             if (base + (e + 1) * ln2 < tv - 1e-9) more = false;
@@ -509,10 +608,10 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
         const double Llast = preLast;
         nlike += preNlike; niter++;
         const bool epoch_ok = (preEpoch == epoch);
-        prefetch(w - 1);
-        if (lane == 0) { S.pl_dead_idx[w] = -1; S.pl_ph_base[w] = nph; S.pl_ph_cuid[w] = cuid; }
+        if (!(AB & 64)) prefetch(w - 1);
+        if (lane == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_cuid = cuid; }
         if (!epoch_ok) {
-            if (lane == 0) for (int m = 0; m < (nr + 62) / 64; ++m) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m] = 0ull;
+            if (lane == 0) for (int m = 0; m < (nr + 62) / 64; ++m) S.plan[w].ph_mask[m] = 0ull;
             continue;
         }
         const double Lg = Lmin;
@@ -520,9 +619,9 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
         int nadd = 0;
 #pragma unroll
         for (int k = 0; k < PC_PRE; ++k) {
-            if (k * 64 < nr - 1) {
+            if (k * 64 < nr - 1 && !(AB & 16)) {
                 const unsigned long long m = __ballot(cur[k] > Lg);
-                if (lane == 0) S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + k] = m;
+                if (lane == 0) S.plan[w].ph_mask[k] = m;
                 nadd += __popcll(m);
             }
         }
@@ -531,34 +630,20 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
         bool replaced = false;
         if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
         if (Llast > Lg) {
-            // ---- delete_outermost_point + update_evidence: eight independent jobs in eight lanes
+            // ---- delete_outermost_point + update_evidence, then add_point into the freed slot
             const double L = Lmin;
-            double a = -PC_HUGE, b = -PC_HUGE, c = -PC_HUGE;
-            const double cz = log2v + XX + 2 * L - l1 - l2;
-            if (lane == 0) { a = logZ; b = Xp + L - l1; }
-            else if (lane == 1) { a = Zp; b = Xp + L - l1; }
-            else if (lane == 2) { a = logZ2; b = log2v + ZXp + L - l1; c = cz; }
-            else if (lane == 3) { a = ZXp + l0 - l1; b = XX + L + l0 - l1 - l2; }
-            else if (lane == 4) { a = Zp2; b = log2v + ZpXp + L - l1; c = cz; }
-            else if (lane == 5) { a = ZpXp + l0 - l1; b = XX + L + l0 - l1 - l2; }
-            else if (lane == 6) { a = L - lseRef; }
-            else if (lane == 7) { a = fmin(Llast - lseRef, 0.0); }
-            const double m3 = (lane >= 6) ? 0.0 : fmax(a, fmax(b, c));
-            const double t1 = exp(a - m3), t2 = exp(b - m3), t3 = exp(c - m3);
-            const double r = m3 + log(t1 + t2 + t3);
             const double logweight = Xp - l1;
-            logZ = readlane_f64(r, 0); Zp = readlane_f64(r, 1); logZ2 = readlane_f64(r, 2); ZXp = readlane_f64(r, 3);
-            Zp2 = readlane_f64(r, 4); ZpXp = readlane_f64(r, 5);
-            const double edel = readlane_f64(t1, 6), eadd = readlane_f64(t1, 7);
+            double edel, eadd, nl0, nl1, nl2;
+            evidence_jobs(L, Llast, edel, eadd, nl0, nl1, nl2);
             Xp = Xp + l0 - l1;
             XX = XX + l0 - l2;
             thr = L;
             // ---- list bookkeeping: the last list entry moves into the hole, the baby is appended
             const int slot = minSlot, pos_del = sP[slot], moved = sList[n - 1], src = sSrc[slot];
             if (lane == 0) {
-                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = (src >= 0) ? -(1 + src) : slot;
-                S.pl_logw[w] = logweight; S.pl_postX[w] = Xp; S.pl_postZ[w] = logZ; S.pl_dead_cuid[w] = cuid;
-                S.pl_entry[w] = sE[slot];
+                S.plan[w].dead_idx = ndead; S.plan[w].dead_src = (src >= 0) ? -(1 + src) : slot;
+                S.plan[w].logw = logweight; S.plan[w].postX = Xp; S.plan[w].postZ = logZ; S.plan[w].dead_cuid = cuid;
+                S.plan[w].entry = sE[slot];
                 sList[pos_del] = moved; sP[moved] = pos_del;
                 sL[slot] = Llast; sE[slot] = L; sP[slot] = n - 1; sList[n - 1] = slot; sSrc[slot] = w;
             }
@@ -566,22 +651,21 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
             // live logsumexp bookkeeping (exact rescale when the baby is the new maximum)
             if (Llast > lseRef) { lseSum = (lseSum - edel) * exp(lseRef - Llast) + 1.0; lseRef = Llast; }
             else lseSum = lseSum - edel + eadd;
-            __syncthreads();
-            // ---- find_min_loglikelihoods: only the strides that changed are rescanned
-            if ((slot & 63) == lane || (moved & 63) == lane) rescan();
-            const vk_t best = wave_argmin(vk_t{lm_v, lm_p});
-            Lmin = best.v;
-            {   // slot of the winner: the lane whose cached minimum matches
-                const unsigned long long mm = __ballot(lm_v == best.v && lm_p == best.k);
-                const int wl = __ffsll((long long)mm) - 1;
-                minSlot = __builtin_amdgcn_readlane(lm_s, wl);
+            __builtin_amdgcn_wave_barrier();       // one wave: LDS is in order, only stop compiler motion
+            // ---- find_min_loglikelihoods: the stride that lost its minimum is rescanned; the list
+            //      entry that moved only changed its tie-break key
+            if ((moved & 63) == lane && moved != slot) {
+                if (lm_s == moved) lm_p = pos_del;
+                else if (sL[moved] == lm_v && pos_del < lm_p) { lm_s = moved; lm_p = pos_del; }
             }
+            if (!(AB & 2)) rescan_stride(slot & 63);
+            if (!(AB & 4)) refresh_min();
             replaced = true;
         } else {
             if (lane == 0) {
-                S.pl_dead_idx[w] = ndead; S.pl_dead_src[w] = -(1 + w);
-                S.pl_logw[w] = S.logzero; S.pl_postX[w] = 0.0; S.pl_postZ[w] = 0.0; S.pl_dead_cuid[w] = 0xFFFFFFFFu;
-                S.pl_entry[w] = Lg;
+                S.plan[w].dead_idx = ndead; S.plan[w].dead_src = -(1 + w);
+                S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
+                S.plan[w].entry = Lg;
             }
             ndead++;
         }
@@ -591,16 +675,18 @@ __global__ __launch_bounds__(64) void k_consume_single(PcState S)
     }
     __syncthreads();
     for (int s = lane; s < Ncap; s += 64) {
+        const bool used = sP[s] != 0x7fffffff;
         S.live_logL[s] = sL[s]; S.live_entry[s] = sE[s]; S.slot_src[s] = sSrc[s];
-        if (sP[s] >= 0) { S.live_pos[s] = sP[s]; S.live_cluster[s] = 0; }
+        S.live_pos[s] = used ? sP[s] : 0; S.live_cluster[s] = used ? 0 : -1;
     }
     for (int p = lane; p < n; p += 64) S.cl_list[p] = sList[p];
     if (lane == 0) {
         S.logLp[0] = Lmin; S.imin_slot[0] = minSlot; S.logXp[0] = Xp; S.logZp[0] = Zp; S.logZXp[0] = ZXp;
         S.logZp2[0] = Zp2; S.logZpXp[0] = ZpXp; S.XpXq[0] = XX; S.lse_ref[0] = lseRef; S.lse_sum[0] = lseSum;
-        S.death_thr[0] = thr;
+        S.death_thr[0] = thr; S.cl_n[0] = n;
         ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->failures = failures;
         ctl->ndead = ndead; ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = 0;
+        ctl->ncluster = nc; ctl->ncluster_dead = nc_dead;
         ctl->nlike = nlike; ctl->niter = niter; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
         ctl->live_logZ = live_logZ_val;
     }
@@ -616,22 +702,22 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
     const int w = ctl->seg_lo + blockIdx.x;
     if (w > ctl->seg_hi) return;
     const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
-    const int di = S.pl_dead_idx[w];
+    const int di = S.plan[w].dead_idx;
     if (di >= 0) {
-        const int src = S.pl_dead_src[w];
+        const int src = S.plan[w].dead_src;
         const double *row = (src >= 0) ? S.live + (size_t)src * nT
                                        : S.babies + ((size_t)(-src - 1) * nr + (nr - 1)) * nT;
         double *dst = S.dead + (size_t)di * nT;
         for (int e = lane; e < nT; e += 64) dst[e] = row[e];
         if (lane == 0) {
-            S.dead_logw[di] = S.pl_logw[w]; S.dead_postX[di] = S.pl_postX[w]; S.dead_postZ[di] = S.pl_postZ[w];
-            S.dead_cuid[di] = S.pl_dead_cuid[w]; S.dead_entry[di] = S.pl_entry[w];
+            S.dead_logw[di] = S.plan[w].logw; S.dead_postX[di] = S.plan[w].postX; S.dead_postZ[di] = S.plan[w].postZ;
+            S.dead_cuid[di] = S.plan[w].dead_cuid; S.dead_entry[di] = S.plan[w].entry;
         }
     }
-    int base = S.pl_ph_base[w];
-    const unsigned cuid = S.pl_ph_cuid[w];
+    int base = S.plan[w].ph_base;
+    const unsigned cuid = S.plan[w].ph_cuid;
     for (int m = 0; m < (nr + 62) / 64; ++m) {
-        unsigned long long mask = S.pl_ph_mask[(size_t)w * PC_MASK_WORDS + m];
+        unsigned long long mask = S.plan[w].ph_mask[m];
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
@@ -911,23 +997,27 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
     if (wide) {
         const size_t sh = consume_lds(S, 1024);
         if (sh > 160 * 1024) return 1;
-        hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        static size_t done1024 = 0;
+        if (sh > done1024) { hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1024 = sh; }
         hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode);
     } else {
         const size_t sh = consume_lds(S, 64);
         if (sh > 160 * 1024) return 1;
-        hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        static size_t done64 = 0;
+        if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
         hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode);
     }
     return 0;
 }
 
-extern "C" int pc_launch_consume_single(const PcState *S, hipStream_t st)
+extern "C" int pc_launch_consume_single(const PcState *S, int final_mode, hipStream_t st)
 {
-    const size_t sh = sizeof(double) * 2 * (size_t)S->Ncap + sizeof(int) * 3 * (size_t)S->Ncap + 64;
+    const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
+    const size_t sh = sizeof(double) * 2 * NS + sizeof(int) * 3 * NS + 64;
     if (sh > 160 * 1024 || S->nr > 64 * PC_PRE) return 1;
-    hipFuncSetAttribute((const void *)k_consume_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_consume_single, dim3(1), dim3(64), sh, st, *S);
+    static size_t done = 0;
+    if (sh > done) { hipFuncSetAttribute((const void *)k_consume_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    hipLaunchKernelGGL(k_consume_single, dim3(1), dim3(64), sh, st, *S, final_mode);
     return 0;
 }
 
@@ -971,10 +1061,12 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     hipLaunchKernelGGL(k_cov_mean_final, dim3(nc), dim3(256), 0, st, *S, nchunk, psum, pcnt, mean, count);
     const size_t sh = sizeof(double) * (size_t)PC_COV_ROWS * (D + 1) + sizeof(int) * PC_COV_ROWS;
     if (sh > 160 * 1024) return 1;
-    hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static size_t donep = 0;
+    if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
     hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, mean, pcov);
     const size_t sh2 = sizeof(double) * 2 * (size_t)D * D;
-    hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+    static size_t donec = 0;
+    if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
     hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(256), sh2, st, *S, nchunk, pcov, count);
     return 0;
 }

@@ -196,6 +196,9 @@ __device__ __forceinline__ vk_t wave_argmin(vk_t a)
 struct PcLike {
     int kind;
     double mu, sigma;        // gaussian mean/width; twin gaussian width
+    double norm;             // host-precomputed -D (log sigma + log(2 pi)/2)
+    double inv_sigma;        // 1 / sigma
+    double log_vn;           // log volume of the unit D-ball (utils.F90:754-760)
     const double *invcov;    // corr gaussian: device pointer, row-major D x D
     const double *mean;      // corr gaussian: device pointer (D)
     double logdetcov;
@@ -206,8 +209,7 @@ struct PcPrior {
 };
 
 // volume of the unit D-ball times r^D, in logs (gaussian.f90:36-37, utils.F90:754-760)
-__device__ __forceinline__ double pc_log_ball(double r, int D)
+__device__ __forceinline__ double pc_log_ball(double r, int D, double log_vn)
 {
-    const double Vn = pow(1.7724538509055159 /* sqrt(pi) */, (double)D) / tgamma(1.0 + D / 2.0);
-    return log(pow(r, (double)D) * Vn);
+    return (double)D * log(r) + log_vn;      // log( r^D V_D )
 }

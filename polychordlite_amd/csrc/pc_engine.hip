@@ -20,7 +20,7 @@ int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipSt
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
-int pc_launch_consume_single(const PcState *, hipStream_t);
+int pc_launch_consume_single(const PcState *, int, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
 void pc_launch_clean(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *,
@@ -118,7 +118,7 @@ struct Engine {
         S.log_prec = S.use_prec ? std::log(c.precision_criterion) : 0.0;
         S.log_cf = std::log(c.compression_factor);
         S.max_ndead = c.max_ndead; S.nfail = c.nfail <= 0 ? c.nlive : c.nfail;
-        S.seed_override = 0;
+        S.seed_override = 0; S.ablate = c.ablate;
         // dynamic nlive tables
         S.n_nlives = c.n_nlives;
         if (c.n_nlives > 0) {
@@ -129,6 +129,9 @@ struct Engine {
         S.dyn_loglikes = d_dynL; S.dyn_nlives = d_dynN;
         // likelihood / prior
         S.like.kind = like.kind; S.like.mu = like.mu; S.like.sigma = like.sigma; S.like.logdetcov = like.logdetcov;
+        S.like.norm = -(double)D * (std::log(like.sigma > 0 ? like.sigma : 1.0) + PC_LOG_TWO_PI / 2.0);
+        S.like.inv_sigma = like.sigma > 0 ? 1.0 / like.sigma : 1.0;
+        S.like.log_vn = 0.5 * D * std::log(3.14159265358979323846) - std::lgamma(1.0 + D / 2.0);
         S.like.invcov = nullptr; S.like.mean = nullptr;
         if (like.kind == PC_LIKE_CORR_GAUSSIAN) {
             std::vector<double> T((size_t)D * D);
@@ -167,10 +170,7 @@ struct Engine {
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
-        S.pl_dead_idx = dalloc<int>(B); S.pl_dead_src = dalloc<int>(B); S.pl_logw = dalloc<double>(B);
-        S.pl_postX = dalloc<double>(B); S.pl_postZ = dalloc<double>(B); S.pl_entry = dalloc<double>(B); S.pl_dead_cuid = dalloc<unsigned>(B);
-        S.pl_ph_base = dalloc<int>(B); S.pl_ph_mask = dalloc<unsigned long long>((size_t)B * PC_MASK_WORDS);
-        S.pl_ph_cuid = dalloc<unsigned>(B); S.slot_src = dalloc<int>(Ncap);
+        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
         HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(PcCtl)));
@@ -322,7 +322,7 @@ struct Engine {
             }
             hipEvent_t e2 = kt.begin();
             int rc2;
-            if (fast_ok && h_ctl->ncluster == 1) rc2 = pc_launch_consume_single(&S, st);
+            if (fast_ok && h_ctl->ncluster == 1) rc2 = pc_launch_consume_single(&S, 0, st);
             else rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
@@ -340,7 +340,7 @@ struct Engine {
         HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
         const int nc_end = h_ctl->ncluster;
-        pc_launch_consume(&S, 1, 0, st);
+        if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_single(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
         auto t3 = clk::now();
         tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
@@ -398,15 +398,15 @@ struct Engine {
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL,
-                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.pl_logw, &S.pl_postX, &S.pl_postZ, &S.pl_entry, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
+                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
-                       &S.ch_seed_slot, &S.pl_dead_idx, &S.pl_dead_src, &S.pl_ph_base, &S.slot_src, &blk, &d_total, &pcnt, &count, &d_dynN };
+                       &S.ch_seed_slot, &S.slot_src, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
-        unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &S.pl_dead_cuid, &S.pl_ph_cuid, &phC2 };
+        unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2 };
         for (auto p : uu) dfree(*p);
-        dfree(S.ph_uid); dfree(S.pl_ph_mask); dfree(phU2); dfree(keep); dfree(S.ctl);
+        dfree(S.ph_uid); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
         kt.destroy();
         if (h_ctl) hipHostFree(h_ctl); h_ctl = nullptr;
         if (st) hipStreamDestroy(st); st = nullptr;
@@ -437,10 +437,18 @@ int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior
     if (s->num_repeats < 1) { std::fprintf(stderr, "polychord_hip: You need to set num_repeats. Suggestion: 5*nDims\n"); return 1; } // settings.f90:216
     if (s->num_repeats > 64 * PC_MASK_WORDS) { std::fprintf(stderr, "polychord_hip: num_repeats > %d unsupported\n", 64 * PC_MASK_WORDS); return 1; }
     if (like->kind == PC_LIKE_CALLBACK || prior->kind != 1) { std::fprintf(stderr, "polychord_hip: pchip_run needs a device likelihood and a uniform prior\n"); return 1; }
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
     Engine E;
     E.setup(*s, *like, *prior);
+    auto t1 = clk::now();
     const int rc = E.run(out);
+    auto t2 = clk::now();
     E.destroy();
+    auto t3 = clk::now();
+    out->t_setup = std::chrono::duration<double>(t1 - t0).count();
+    out->t_teardown = std::chrono::duration<double>(t3 - t2).count();
+    out->t_results = std::chrono::duration<double>(t2 - t1).count() - out->t_total;
     return rc;
 }
 

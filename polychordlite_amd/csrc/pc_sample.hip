@@ -38,14 +38,14 @@ __device__ __forceinline__ double like_eval(const PcState &S, const double (&th)
     if (L.kind == PC_LIKE_GAUSSIAN) {            // gaussian.f90:25-34
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) if (ld.on[k]) { const double z = (th[k] - L.mu) / L.sigma; s += z * z; }
+        for (int k = 0; k < DPL; ++k) if (ld.on[k]) { const double z = (th[k] - L.mu) * L.inv_sigma; s += z * z; }
         s = wsum<DPL, NROWS>(s);
-        return -(double)D * (log(L.sigma) + PC_LOG_TWO_PI / 2.0) - s / 2.0;
+        return L.norm - s / 2.0;
     } else if (L.kind == PC_LIKE_RASTRIGIN) {    // rastrigin.f90:33
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k)
-            if (ld.on[k]) s += log(4991.21750) + th[k] * th[k] - 10.0 * cos(PC_TWO_PI * th[k]);
+            if (ld.on[k]) s += 8.515435146961291 /* log(4991.21750) */ + th[k] * th[k] - 10.0 * cos(PC_TWO_PI * th[k]);
         s = wsum<DPL, NROWS>(s);
         return -s;
     } else if (L.kind == PC_LIKE_TWIN_GAUSSIAN) {  // twin_gaussian.f90:29-46
@@ -55,12 +55,11 @@ __device__ __forceinline__ double like_eval(const PcState &S, const double (&th)
             if (ld.on[k]) {
                 const int dim = lane + 64 * k;
                 const double m1 = dim < 2 ? -0.5 : 0.0, m2 = dim < 2 ? 0.5 : 0.0;
-                const double z1 = (th[k] - m1) / L.sigma, z2 = (th[k] - m2) / L.sigma;
+                const double z1 = (th[k] - m1) * L.inv_sigma, z2 = (th[k] - m2) * L.inv_sigma;
                 s1 += z1 * z1; s2 += z2 * z2;
             }
         s1 = wsum<DPL, NROWS>(s1); s2 = wsum<DPL, NROWS>(s2);
-        const double norm = -(double)D * (log(L.sigma) + PC_LOG_TWO_PI / 2.0);
-        return pc_logaddexp(norm - s1 / 2.0, norm - s2 / 2.0) - log(2.0);
+        return pc_logaddexp(L.norm - s1 / 2.0, L.norm - s2 / 2.0) - 0.6931471805599453;
     } else {                                      // random_gaussian.f90:17-30, utils.F90:1028-1048
 #pragma unroll
         for (int k = 0; k < DPL; ++k) if (ld.on[k]) ybuf[lane + 64 * k] = th[k] - ld.mean[k];
@@ -94,7 +93,7 @@ __device__ __forceinline__ void like_phi(const PcState &S, const double (&th)[DP
         for (int k = 0; k < DPL; ++k) if (ld.on[k]) r2 += (th[k] - S.like.mu) * (th[k] - S.like.mu);
         r2 = wsum<DPL, NROWS>(r2);
         phi0 = sqrt(r2);
-        if (S.nDer >= 2) phi1 = pc_log_ball(phi0, S.D);
+        if (S.nDer >= 2) phi1 = pc_log_ball(phi0, S.D, S.like.log_vn);
     } else if (S.like.kind == PC_LIKE_TWIN_GAUSSIAN) {   // twin_gaussian.f90:48-52
         const double t0 = readlane_f64(th[0], 0);
         phi0 = (t0 > 0.5) ? 1.0 : -1.0;
@@ -208,9 +207,9 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         double n2 = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
-        const double nrm = sqrt(n2);
+        const double inrm = 1.0 / sqrt(n2);
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] / nrm;
+        for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] * inrm;
     }
     // Gram-Schmidt, row oriented: once vector j is final it is removed from every later vector.
     // Per vector this is the same sequence of projections as random_utils.F90:391-399.
@@ -219,9 +218,9 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
             double n2 = 0.0;
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
-            const double nrm = sqrt(n2);
+            const double inrm = 1.0 / sqrt(n2);
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) { v[d] = v[d] / nrm; Q[d] = v[d]; }
+            for (int d = 0; d < DMAX; ++d) if (d < D) { v[d] = v[d] * inrm; Q[d] = v[d]; }
         }
         __syncthreads();
         if (active && i > j) {
@@ -251,9 +250,9 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
             mine[a] = t;
         }
         for (int d = 0; d < D; ++d) n2 += mine[d] * mine[d];
-        const double w = sqrt(n2);                        // chordal_sampling.f90:80-82
+        const double w = sqrt(n2), iw = 1.0 / w;           // chordal_sampling.f90:80-82
         double *out = S.nhat + ((size_t)chain * nr + col) * D;
-        for (int d = 0; d < D; ++d) out[d] = mine[d] / w;
+        for (int d = 0; d < D; ++d) out[d] = mine[d] * iw;
         S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
     }
 }
@@ -452,7 +451,10 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
     const int D = S->D, nb = (S->nr + D - 1) / D;
     const size_t sh = sizeof(double) * ((size_t)D * D + D) + 16;
     dim3 grid(nb, nchains);
-    if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
+    if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64>), grid, dim3(64), sh, st, *S, batch);
+    else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64>), grid, dim3(64), sh, st, *S, batch);
+    else if (D <= 24) hipLaunchKernelGGL((k_nhats<24, 64>), grid, dim3(64), sh, st, *S, batch);
+    else if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 64) hipLaunchKernelGGL((k_nhats<64, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 128) hipLaunchKernelGGL((k_nhats<128, 128>), grid, dim3(128), sh, st, *S, batch);
     else return 1;

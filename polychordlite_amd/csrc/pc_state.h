@@ -35,6 +35,16 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     double live_logZ;            // last evaluated termination estimate
 };
 
+struct PcPlan {                  // one record per nursery chain, written by the consume kernel
+    int dead_idx;                // index in dead[] or -1
+    int dead_src;                // >=0: live slot; <0: -(1+chain) whose last baby is the row
+    int ph_base;                 // first phantom row of the chain
+    unsigned dead_cuid, ph_cuid;
+    int pad;
+    double logw, postX, postZ, entry;
+    unsigned long long ph_mask[PC_MASK_WORDS];
+};
+
 struct PcState {
     // ---- geometry / settings
     int D, nDer, nT, nr, N, Ncap, B, maxc, Pcap, Dcap;
@@ -80,14 +90,9 @@ struct PcState {
     double *nhat;                // [B][nr][D] whitened, normalised directions (generation order)
     double *nhat_w;              // [B][nr] 3*|L n|
     // ---- plan written by the consume kernel for the apply kernels
-    int *pl_dead_idx;            // [B] index in dead[] or -1
-    int *pl_dead_src;            // [B] >=0: live slot; <0: -(1+chain) whose last baby is the row
-    double *pl_logw, *pl_postX, *pl_postZ, *pl_entry;
-    unsigned *pl_dead_cuid;
-    int *pl_ph_base;             // [B] first phantom row of the chain
-    unsigned long long *pl_ph_mask;     // [B][PC_MASK_WORDS]
-    unsigned *pl_ph_cuid;        // [B]
+    PcPlan *plan;                // [B]
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
+    int ablate;                  // dev timing hook (bit mask), 0 in production
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     PcCtl *ctl;
 };
