@@ -592,9 +592,25 @@ static int replace_point(rti_t *R, const double *babies, const uint64_t *uids, i
     if (pt[R->l0] > logL) {
         if (identify_cluster(R, pt) == cluster_add) {
             int nl = nlive_target(R, logL);
-            if (total_live(R) >= (nl > 1 ? nl : 1)) { delete_outermost_point(R); replaced = 1; }
+            int cdel = -1, idel = -1;
+            if (total_live(R) >= (nl > 1 ? nl : 1)) {
+                cdel = 0;
+                for (int c = 1; c < R->ncluster; ++c) if (R->cl[c].logLp < R->cl[cdel].logLp) cdel = c;
+                idel = R->cl[cdel].imin;
+                delete_outermost_point(R); replaced = 1;
+            }
             if (total_live(R) < nl) {
-                pa_add(&R->cl[cluster_add].live, pt, uids[nb - 1]);
+                ptarr *lv = &R->cl[cluster_add].live;
+                pa_add(lv, pt, uids[nb - 1]);
+                if (!R->rng.sequential && replaced && cdel == cluster_add && idel < lv->n - 1) {
+                    /* KEYED MODE ONLY (the HIP engine's rule): the newcomer takes the list position of the
+                     * point it replaces instead of array_utils.f90:396-458's swap-with-last + append.
+                     * Same set of live points, different list order => which point a seed index selects;
+                     * the sequential mode used for pinning keeps the reference rule. */
+                    double *a = lv->a + (size_t)idel * R->nTotal, *b = lv->a + (size_t)(lv->n - 1) * R->nTotal;
+                    for (int e = 0; e < R->nTotal; ++e) { double t = a[e]; a[e] = b[e]; b[e] = t; }
+                    uint64_t tu = lv->uid[idel]; lv->uid[idel] = lv->uid[lv->n - 1]; lv->uid[lv->n - 1] = tu;
+                }
                 find_min_loglikelihoods(R);
             }
         }

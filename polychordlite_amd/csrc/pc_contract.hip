@@ -32,7 +32,7 @@ __device__ __forceinline__ vk_t block_argmin(vk_t v, vk_t *scratch)
 }
 
 struct ConsumeShared {
-    double *sL, *sE; int *sC; int *sP;                 // per slot
+    double *sL; int *sC; int *sP;                      // per slot
     double *cLogLp, *cLogXp, *cLogZp, *cLogZXp, *cLogZp2, *cLogZpXp, *cLseRef, *cLseSum, *cThr;
     int *cN, *cMinSlot; unsigned *cUid;
     double *jobres;                                     // [NT] results of the lane-parallel jobs
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     {
         char *p = smem;
         H.sL = (double *)p; p += sizeof(double) * Ncap;
-        H.sE = (double *)p; p += sizeof(double) * Ncap;
         double **cd[] = { &H.cLogLp, &H.cLogXp, &H.cLogZp, &H.cLogZXp, &H.cLogZp2, &H.cLogZpXp, &H.cLseRef, &H.cLseSum, &H.cThr };
         for (int i = 0; i < 9; ++i) { *cd[i] = (double *)p; p += sizeof(double) * maxc; }
         H.jobres = (double *)p; p += sizeof(double) * NT;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
-    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sE[s] = S.live_entry[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
+    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
     int nc = ctl->ncluster;
     for (int c = tid; c < maxc; c += NT) {
         H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
@@ -121,6 +120,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     // ================================================================================
     // one death: delete_outermost_point (run_time_info.f90:789-817) without the row copy
     // ================================================================================
+    int last_cd = -1, last_pos_del = -1;
     auto kill_lowest = [&](int plan_w) {
         // cluster with the lowest contour (minpos: first minimum)
         int cd = 0;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         const double L = H.cLogLp[cd];
         const int slot_del = H.cMinSlot[cd];
         const int pos_del = H.sP[slot_del];
+        last_cd = cd; last_pos_del = pos_del;
         // ---- update_evidence (run_time_info.f90:211-296): every log-space accumulation reads only
         //      pre-update values, so they are independent jobs: one lane each.
         const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                     S.plan[plan_w].dead_idx = ndead;
                     S.plan[plan_w].dead_src = (src >= 0) ? -(1 + src) : slot_del;
                     S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lseX; S.plan[plan_w].postZ = logZ;
-                    S.plan[plan_w].dead_cuid = H.cUid[cd]; S.plan[plan_w].entry = H.sE[slot_del];
+                    S.plan[plan_w].dead_cuid = H.cUid[cd];
                 }
             } else {   // kill-off / trimming: rows are current in live[], copy immediately
                 const double *row = S.live + (size_t)slot_del * nT;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                 for (int e = tid; e < nT; e += NT) dst[e] = row[e];
                 if (tid == 0) {
                     S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lseX; S.dead_postZ[ndead] = logZ;
-                    S.dead_cuid[ndead] = H.cUid[cd]; S.dead_entry[ndead] = H.sE[slot_del];
+                    S.dead_cuid[ndead] = H.cUid[cd]; S.dead_entry[ndead] = S.live_entry[slot_del];
                 }
             }
         }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         i_nursery--;
         nlike += S.ch_nlike[w];
         niter++;
-        if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
+        if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_count = 0; S.plan[w].contour = S.logzero; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
         __syncthreads();
         if (S.ch_epoch[w] != epoch) continue;           // nested_sampling.F90:313 epoch guard
 
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         double Lg = H.cLogLp[0];
         for (int c = 1; c < nc; ++c) Lg = fmin(Lg, H.cLogLp[c]);
         const double *blog = S.baby_logL + (size_t)w * nr;
+        if (tid == 0) S.plan[w].contour = Lg;
         // phantoms: babies 1..nr-1 that beat the global contour and fall in the seed cluster's cell
         int nph_add = 0;
         if (nc == 1) {
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                     // add_point + find_min_loglikelihoods for the receiving cluster
                     if (tid == 0) {
                         const int pos = H.cN[ca];
-                        H.sL[free_slot] = Llast; H.sE[free_slot] = Lg; H.sC[free_slot] = ca; H.sP[free_slot] = pos;
+                        H.sL[free_slot] = Llast; H.sC[free_slot] = ca; H.sP[free_slot] = pos;
                         H.cN[ca] = pos + 1;
                         if (pos == 0 || Llast < H.cLogLp[ca]) { H.cLogLp[ca] = Llast; H.cMinSlot[ca] = free_slot; }
                         // live logsumexp of the cluster
@@ -371,6 +373,16 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                         S.slot_src[free_slot] = w;
                     }
                     __syncthreads();
+                    // engine rule (oracle keyed mode): a point that replaces a death of its own cluster
+                    // takes the dead point's list position instead of being appended
+                    if (replaced && last_cd == ca && last_pos_del < H.cN[ca] - 1) {
+                        const int pos_new = H.cN[ca] - 1;
+                        for (int s = tid; s < Ncap; s += NT)
+                            if (s != free_slot && H.sC[s] == ca && H.sP[s] == last_pos_del) H.sP[s] = pos_new;
+                        __syncthreads();
+                        if (tid == 0) H.sP[free_slot] = last_pos_del;
+                        __syncthreads();
+                    }
                 }
             }
         } else {
@@ -379,7 +391,6 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
             if (tid == 0) {
                 S.plan[w].dead_idx = ndead; S.plan[w].dead_src = -(1 + w);
                 S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
-                S.plan[w].entry = Lg;
             }
             ndead++;
         }
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
 
     // ---- write the state back
     __syncthreads();
-    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_entry[s] = H.sE[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
+    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
     for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
     for (int c = tid; c < maxc; c += NT) {
         S.logLp[c] = H.cLogLp[c]; S.logXp[c] = H.cLogXp[c]; S.logZp[c] = H.cLogZp[c]; S.logZXp[c] = H.cLogZXp[c];
@@ -413,282 +424,6 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_consume_single: the same decisions as k_consume for the common case of ONE cluster with a
-// static number of live points, on ONE wavefront with no barriers:
-//   * evidence / volume accumulators live in registers; the six log-space updates of a death and
-//     the two exponentials of the live-evidence bookkeeping are evaluated in eight different lanes
-//     (one exp/log latency instead of eight) and exchanged with v_readlane;
-//   * every lane caches the minimum of its own stride of the LDS-resident logL column, so a death
-//     costs one 1/64 rescan + one DPP argmin instead of a pass over all live points;
-//   * list order (array_utils.f90:396-458 semantics) is an LDS pos<->slot map, O(1) per death;
-//   * the next chain's inputs are prefetched while the current one is processed;
-//   * the termination test (nested_sampling.F90:534, run_time_info.f90:683-709) is decided from the
-//     exponent of the running sum whenever that is unambiguous, and evaluated exactly otherwise.
-// ------------------------------------------------------------------------------------------
-#define PC_PRE 8   /* prefetch registers per lane: num_repeats <= 512 */
-
-__global__ __launch_bounds__(64) void k_consume_single(PcState S, int final_mode)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
-    const int Ncap = S.Ncap, nr = S.nr, nT = S.nT;
-    const int NS = (Ncap + 63) & ~63;          // padded stride count: every lane scans NS/64 slots
-    double *sL = (double *)smem;               // [NS] logL, +HUGE for free / padding slots
-    double *sE = sL + NS;                      // [NS] entry contour
-    int *sP = (int *)(sE + NS);                // [NS] list position, 0x7fffffff for free slots
-    int *sList = sP + NS;                      // [NS] position -> slot
-    int *sSrc = sList + NS;                    // [NS]
-    PcCtl *ctl = S.ctl;
-    for (int s = lane; s < NS; s += 64) {
-        const bool used = s < Ncap && S.live_cluster[s] >= 0;
-        sL[s] = used ? S.live_logL[s] : PC_HUGE; sE[s] = used ? S.live_entry[s] : S.logzero;
-        sP[s] = used ? S.live_pos[s] : 0x7fffffff; sSrc[s] = s < Ncap ? S.slot_src[s] : -1;
-    }
-    int n = S.cl_n[0];
-    for (int p = lane; p < n; p += 64) sList[p] = S.cl_list[p];
-    int i_nursery = ctl->i_nursery, failures = ctl->failures, ndead = ctl->ndead, nph = ctl->nphantom;
-    const int epoch = ctl->admin_epoch;
-    int nc_dead = ctl->ncluster_dead, nc = ctl->ncluster;
-    long long nlike = ctl->nlike, niter = ctl->niter;
-    double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
-    double Xp = S.logXp[0], Zp = S.logZp[0], ZXp = S.logZXp[0], Zp2 = S.logZp2[0], ZpXp = S.logZpXp[0], XX = S.XpXq[0];
-    double lseRef = S.lse_ref[0], lseSum = S.lse_sum[0], thr = S.death_thr[0];
-    double Lmin = S.logLp[0]; int minSlot = S.imin_slot[0];
-    const unsigned cuid = S.cl_uid[0];
-    int status = PC_ST_RUNNING, error = PC_ERR_NONE;
-    const int seg_hi = i_nursery - 1;
-    double live_logZ_val = S.logzero;
-    const double log2v = log(2.0), ln2 = 0.6931471805599453;
-    double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
-    __syncthreads();
-    // per-lane minimum of the lane's stride: (value, list position, slot)
-    double lm_v = PC_HUGE; int lm_p = 0x7fffffff, lm_s = -1;
-    {
-        double bv = PC_HUGE; int bp = 0x7fffffff, bs = -1;
-#pragma unroll 8
-        for (int s = lane; s < NS; s += 64) {
-            const double v = sL[s]; const int p = sP[s];
-            const bool t = (v < bv) | ((v == bv) & (p < bp));
-            bv = t ? v : bv; bp = t ? p : bp; bs = t ? s : bs;
-        }
-        lm_v = bv; lm_p = bp; lm_s = bs;
-    }
-    // cooperative rescan of ONE stride (the one that lost its minimum): its NS/64 slots are read by
-    // NS/64 different lanes and reduced with a DPP argmin; the owner lane takes the result.
-    auto rescan_stride = [&](int owner) {
-        vk_t best{PC_HUGE, 0x7fffffff};
-        for (int j0 = 0; j0 < NS / 64; j0 += 64) {
-            const int j = j0 + lane;
-            const int s = owner + 64 * j;
-            const bool in = j < NS / 64;
-            const double v = in ? sL[in ? s : 0] : PC_HUGE; const int p = in ? sP[in ? s : 0] : 0x7fffffff;
-            best = vk_min(best, vk_t{v, p});
-        }
-        best = wave_argmin(best);
-        // slot of the winner: unique (value, position) pair inside the stride
-        int ws = -1;
-        for (int j0 = 0; j0 < NS / 64; j0 += 64) {
-            const int j = j0 + lane, s = owner + 64 * j;
-            const bool hit = (j < NS / 64) && sL[(j < NS / 64) ? s : 0] == best.v && sP[(j < NS / 64) ? s : 0] == best.k;
-            const unsigned long long mm = __ballot(hit);
-            if (mm) ws = owner + 64 * (j0 + __ffsll((long long)mm) - 1);
-        }
-        if (lane == owner) { lm_v = best.v; lm_p = best.k; lm_s = ws; }
-    };
-    auto refresh_min = [&]() {
-        const vk_t best = wave_argmin(vk_t{lm_v, lm_p});
-        Lmin = best.v;
-        const unsigned long long mm = __ballot(lm_v == best.v && lm_p == best.k);
-        const int wl = __ffsll((long long)mm) - 1;
-        minSlot = __builtin_amdgcn_readlane(lm_s, wl);
-    };
-
-    // one death of the lowest live point; `Ladd` = logL of the point that takes its slot (normal mode)
-    // or -HUGE (kill-off).  Eight independent log-space jobs, one per lane (update_evidence,
-    // run_time_info.f90:211-296), plus the logs needed by the next kill-off step.
-    const int AB = S.ablate;
-    auto evidence_jobs = [&](double L, double Ladd, double &edel, double &eadd, double &nl0, double &nl1, double &nl2) {
-        if (AB & 1) { edel = 0; eadd = 0; nl0 = l0; nl1 = l1; nl2 = l2; logZ += 1e-9; return; }
-        // uniform sub-expressions once, then branch-free per-lane selection
-        const double cz = log2v + XX + 2 * L - l1 - l2, bz = Xp + L - l1, bx = XX + L + l0 - l1 - l2, d01 = l0 - l1;
-        const double NH = -PC_HUGE;
-        double a = (lane == 0) ? logZ : (lane == 1) ? Zp : (lane == 2) ? logZ2 : (lane == 3) ? ZXp + d01
-                 : (lane == 4) ? Zp2 : (lane == 5) ? ZpXp + d01 : (lane == 6) ? L - lseRef
-                 : (lane == 7) ? fmin(Ladd - lseRef, 0.0) : 1.0;
-        double b = (lane <= 1) ? bz : (lane == 2) ? log2v + ZXp + L - l1 : (lane == 3 || lane == 5) ? bx
-                 : (lane == 4) ? log2v + ZpXp + L - l1 : NH;
-        double c = (lane == 2 || lane == 4) ? cz : NH;
-        const double m3 = (lane >= 6) ? 0.0 : fmax(a, fmax(b, c));
-        const double t1 = exp(a - m3), t2 = exp(b - m3), t3 = exp(c - m3);
-        // lanes 8..10: log(n-1), log(n), log(n+1) for a shrinking live set
-        const double larg = (lane >= 8 && lane <= 10) ? fmax((double)(n + lane - 9), 1e-300) : (t1 + t2 + t3);
-        const double r = m3 + log(larg);
-        logZ = readlane_f64(r, 0); Zp = readlane_f64(r, 1); logZ2 = readlane_f64(r, 2); ZXp = readlane_f64(r, 3);
-        Zp2 = readlane_f64(r, 4); ZpXp = readlane_f64(r, 5);
-        edel = readlane_f64(t1, 6); eadd = readlane_f64(t1, 7);
-        nl0 = readlane_f64(r, 8); nl1 = readlane_f64(r, 9); nl2 = readlane_f64(r, 10);
-    };
-
-    if (final_mode) {
-        // nested_sampling.F90:381-384: kill the remaining live points lowest first (no replacement)
-        while (n > 0) {
-            if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
-            const double L = Lmin;
-            const double logweight = Xp - l1;
-            double edel, eadd, nl0, nl1, nl2;
-            evidence_jobs(L, -PC_HUGE, edel, eadd, nl0, nl1, nl2);
-            Xp = Xp + l0 - l1; XX = XX + l0 - l2; thr = L;
-            const int slot = minSlot, pos_del = sP[slot], moved = sList[n - 1];
-            {   // rows are current in live[] (the plan was applied before this launch)
-                const double *row = S.live + (size_t)slot * nT;
-                double *dst = S.dead + (size_t)ndead * nT;
-                for (int e = lane; e < nT; e += 64) dst[e] = row[e];
-                if (lane == 0) {
-                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = (n > 1) ? Xp : Xp; S.dead_postZ[ndead] = logZ;
-                    S.dead_cuid[ndead] = cuid; S.dead_entry[ndead] = sE[slot];
-                }
-            }
-            if (lane == 0) {
-                sList[pos_del] = moved; sP[moved] = pos_del;
-                sL[slot] = PC_HUGE; sP[slot] = 0x7fffffff;
-            }
-            ndead++; n--;
-            l0 = nl0; l1 = nl1; l2 = nl2;          // log(n), log(n+1), log(n+2) of the shrunk set
-            __builtin_amdgcn_wave_barrier();
-            if ((moved & 63) == lane && moved != slot) {
-                if (lm_s == moved) lm_p = pos_del;
-                else if (sL[moved] == lm_v && pos_del < lm_p) { lm_s = moved; lm_p = pos_del; }
-            }
-            rescan_stride(slot & 63);
-            refresh_min();
-        }
-        if (status == PC_ST_RUNNING) {
-            // delete_cluster (run_time_info.f90:507-598) for the last cluster
-            if (lane == 0 && nc_dead < S.maxc_dead) { S.logZp_dead[nc_dead] = Zp; S.logZp2_dead[nc_dead] = Zp2; }
-            nc_dead++; nc = 0;
-            status = PC_ST_DONE;
-        }
-    }
-
-    // prefetch registers for the chain about to be consumed
-    double pre[PC_PRE]; double preLast = 0.0; int preNlike = 0, preEpoch = 0;
-    auto prefetch = [&](int w) {
-        if (w < 0) return;
-        const double *b = S.baby_logL + (size_t)w * nr;
-#pragma unroll
-        for (int k = 0; k < PC_PRE; ++k) { const int i = k * 64 + lane; pre[k] = (i < nr - 1) ? b[i] : -PC_HUGE; }
-        preLast = b[nr - 1]; preNlike = S.ch_nlike[w]; preEpoch = S.ch_epoch[w];
-    };
-    if (!final_mode) prefetch(i_nursery - 1);
-
-    while (status == PC_ST_RUNNING) {
-        // ---- more_samples_needed
-        bool more = true;
-        if (S.max_ndead == 0) more = false;
-        else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
-        else if (S.use_prec && !(AB & 32)) {
-            const double base = lseRef - l0 + Xp, tv = S.log_prec + logZ;
-            const int e = ((__double2hiint(lseSum) >> 20) & 0x7ff) - 1023;
-            if (base + (e + 1) * ln2 < tv - 1e-9) more = false;
-            else if (base + e * ln2 > tv + 1e-9) more = true;
-            else { live_logZ_val = base + log(lseSum); more = !(live_logZ_val < tv); }
-        }
-        if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
-        if (i_nursery == 0) break;
-
-        const int w = i_nursery - 1;
-        i_nursery--;
-        double cur[PC_PRE];
-#pragma unroll
-        for (int k = 0; k < PC_PRE; ++k) cur[k] = pre[k];
-        const double Llast = preLast;
-        nlike += preNlike; niter++;
-        const bool epoch_ok = (preEpoch == epoch);
-        if (!(AB & 64)) prefetch(w - 1);
-        if (lane == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_cuid = cuid; }
-        if (!epoch_ok) {
-            if (lane == 0) for (int m = 0; m < (nr + 62) / 64; ++m) S.plan[w].ph_mask[m] = 0ull;
-            continue;
-        }
-        const double Lg = Lmin;
-        // ---- phantoms (run_time_info.f90:747-757)
-        int nadd = 0;
-#pragma unroll
-        for (int k = 0; k < PC_PRE; ++k) {
-            if (k * 64 < nr - 1 && !(AB & 16)) {
-                const unsigned long long m = __ballot(cur[k] > Lg);
-                if (lane == 0) S.plan[w].ph_mask[k] = m;
-                nadd += __popcll(m);
-            }
-        }
-        if (nph + nadd > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
-        nph += nadd;
-        bool replaced = false;
-        if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
-        if (Llast > Lg) {
-            // ---- delete_outermost_point + update_evidence, then add_point into the freed slot
-            const double L = Lmin;
-            const double logweight = Xp - l1;
-            double edel, eadd, nl0, nl1, nl2;
-            evidence_jobs(L, Llast, edel, eadd, nl0, nl1, nl2);
-            Xp = Xp + l0 - l1;
-            XX = XX + l0 - l2;
-            thr = L;
-            // ---- list bookkeeping: the last list entry moves into the hole, the baby is appended
-            const int slot = minSlot, pos_del = sP[slot], moved = sList[n - 1], src = sSrc[slot];
-            if (lane == 0) {
-                S.plan[w].dead_idx = ndead; S.plan[w].dead_src = (src >= 0) ? -(1 + src) : slot;
-                S.plan[w].logw = logweight; S.plan[w].postX = Xp; S.plan[w].postZ = logZ; S.plan[w].dead_cuid = cuid;
-                S.plan[w].entry = sE[slot];
-                sList[pos_del] = moved; sP[moved] = pos_del;
-                sL[slot] = Llast; sE[slot] = L; sP[slot] = n - 1; sList[n - 1] = slot; sSrc[slot] = w;
-            }
-            ndead++;
-            // live logsumexp bookkeeping (exact rescale when the baby is the new maximum)
-            if (Llast > lseRef) { lseSum = (lseSum - edel) * exp(lseRef - Llast) + 1.0; lseRef = Llast; }
-            else lseSum = lseSum - edel + eadd;
-            __builtin_amdgcn_wave_barrier();       // one wave: LDS is in order, only stop compiler motion
-            // ---- find_min_loglikelihoods: the stride that lost its minimum is rescanned; the list
-            //      entry that moved only changed its tie-break key
-            if ((moved & 63) == lane && moved != slot) {
-                if (lm_s == moved) lm_p = pos_del;
-                else if (sL[moved] == lm_v && pos_del < lm_p) { lm_s = moved; lm_p = pos_del; }
-            }
-            if (!(AB & 2)) rescan_stride(slot & 63);
-            if (!(AB & 4)) refresh_min();
-            replaced = true;
-        } else {
-            if (lane == 0) {
-                S.plan[w].dead_idx = ndead; S.plan[w].dead_src = -(1 + w);
-                S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
-                S.plan[w].entry = Lg;
-            }
-            ndead++;
-        }
-        failures = replaced ? 0 : failures + 1;
-        // ---- update trigger (nested_sampling.F90:321); one cluster: logsumexp(logXp) = logXp
-        if (Xp <= lx_last + S.log_cf) { lx_last = Xp; status = PC_ST_UPDATE; }
-    }
-    __syncthreads();
-    for (int s = lane; s < Ncap; s += 64) {
-        const bool used = sP[s] != 0x7fffffff;
-        S.live_logL[s] = sL[s]; S.live_entry[s] = sE[s]; S.slot_src[s] = sSrc[s];
-        S.live_pos[s] = used ? sP[s] : 0; S.live_cluster[s] = used ? 0 : -1;
-    }
-    for (int p = lane; p < n; p += 64) S.cl_list[p] = sList[p];
-    if (lane == 0) {
-        S.logLp[0] = Lmin; S.imin_slot[0] = minSlot; S.logXp[0] = Xp; S.logZp[0] = Zp; S.logZXp[0] = ZXp;
-        S.logZp2[0] = Zp2; S.logZpXp[0] = ZpXp; S.XpXq[0] = XX; S.lse_ref[0] = lseRef; S.lse_sum[0] = lseSum;
-        S.death_thr[0] = thr; S.cl_n[0] = n;
-        ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->failures = failures;
-        ctl->ndead = ndead; ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = 0;
-        ctl->ncluster = nc; ctl->ncluster_dead = nc_dead;
-        ctl->nlike = nlike; ctl->niter = niter; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
-        ctl->live_logZ = live_logZ_val;
     }
 }
 
@@ -711,7 +446,8 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
         for (int e = lane; e < nT; e += 64) dst[e] = row[e];
         if (lane == 0) {
             S.dead_logw[di] = S.plan[w].logw; S.dead_postX[di] = S.plan[w].postX; S.dead_postZ[di] = S.plan[w].postZ;
-            S.dead_cuid[di] = S.plan[w].dead_cuid; S.dead_entry[di] = S.plan[w].entry;
+            S.dead_cuid[di] = S.plan[w].dead_cuid;
+            S.dead_entry[di] = (src >= 0) ? S.live_entry[src] : S.plan[-src - 1].contour;
         }
     }
     int base = S.plan[w].ph_base;
@@ -744,7 +480,7 @@ __global__ __launch_bounds__(64) void k_apply_live(PcState S)
     double *dst = S.live + (size_t)slot * nT;
     for (int e = lane; e < nT; e += 64) dst[e] = row[e];
     __syncthreads();
-    if (lane == 0) S.slot_src[slot] = -1;
+    if (lane == 0) { S.slot_src[slot] = -1; S.live_entry[slot] = S.plan[src].contour; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -988,7 +724,7 @@ __global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, c
 // ------------------------------------------------------------------------------------------
 static size_t consume_lds(const PcState *S, int NT)
 {
-    return sizeof(double) * (2 * (size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
+    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
            sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8) + 64;
 }
 
@@ -1007,17 +743,6 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
         hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode);
     }
-    return 0;
-}
-
-extern "C" int pc_launch_consume_single(const PcState *S, int final_mode, hipStream_t st)
-{
-    const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
-    const size_t sh = sizeof(double) * 2 * NS + sizeof(int) * 3 * NS + 64;
-    if (sh > 160 * 1024 || S->nr > 64 * PC_PRE) return 1;
-    static size_t done = 0;
-    if (sh > done) { hipFuncSetAttribute((const void *)k_consume_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
-    hipLaunchKernelGGL(k_consume_single, dim3(1), dim3(64), sh, st, *S, final_mode);
     return 0;
 }
 

@@ -20,7 +20,9 @@ int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipSt
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
-int pc_launch_consume_single(const PcState *, int, hipStream_t);
+int pc_launch_consume_fast(const PcState *, int, hipStream_t);
+int pc_fast_fits(const PcState *);
+void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
 void pc_launch_clean(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *,
@@ -170,7 +172,7 @@ struct Engine {
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
-        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap);
+        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
         HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(PcCtl)));
@@ -306,7 +308,7 @@ struct Engine {
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
-        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && !cfg.force_general;
+        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && !cfg.force_general && pc_fast_fits(&S);
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
@@ -322,7 +324,8 @@ struct Engine {
             }
             hipEvent_t e2 = kt.begin();
             int rc2;
-            if (fast_ok && h_ctl->ncluster == 1) rc2 = pc_launch_consume_single(&S, 0, st);
+            const bool use_fast = fast_ok && h_ctl->ncluster == 1;
+            if (use_fast) { rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
@@ -340,7 +343,7 @@ struct Engine {
         HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
         const int nc_end = h_ctl->ncluster;
-        if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_single(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
+        if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
         auto t3 = clk::now();
         tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
@@ -357,6 +360,7 @@ struct Engine {
         out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
         for (int k = 0; k < KT_N; ++k) { out->k_time_s[k] = kt.total_ms[k] * 1e-3; out->k_launches[k] = kt.launches[k]; }
         (void)nlike_dev;
+        if (cfg.feedback >= 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) slow %lld (%lld steps) ins-rescan %lld (%lld) writeback %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
         out->dead = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, h_ctl->ndead) * nT);
         out->logweights = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
         HIPCHK(hipMemcpy(out->dead, S.dead, sizeof(double) * (size_t)h_ctl->ndead * nT, hipMemcpyDeviceToHost));
@@ -402,7 +406,7 @@ struct Engine {
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
-                       &S.ch_seed_slot, &S.slot_src, &blk, &d_total, &pcnt, &count, &d_dynN };
+                       &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2 };
         for (auto p : uu) dfree(*p);

@@ -33,6 +33,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     double logZ, logZ2;          // run_time_info.f90:165-166 (log <Z>, log <Z^2>)
     double logX_last_update;
     double live_logZ;            // last evaluated termination estimate
+    long long dbg[8];            // developer cycle counters of the contraction kernel
 };
 
 struct PcPlan {                  // one record per nursery chain, written by the consume kernel
@@ -40,8 +41,9 @@ struct PcPlan {                  // one record per nursery chain, written by the
     int dead_src;                // >=0: live slot; <0: -(1+chain) whose last baby is the row
     int ph_base;                 // first phantom row of the chain
     unsigned dead_cuid, ph_cuid;
-    int pad;
-    double logw, postX, postZ, entry;
+    int ph_count;                // -1: the apply side derives mask/count/base from `contour` (one cluster)
+    double logw, postX, postZ;
+    double contour;              // global contour when the chain was consumed (phantom test, entry contour)
     unsigned long long ph_mask[PC_MASK_WORDS];
 };
 
@@ -91,6 +93,7 @@ struct PcState {
     double *nhat_w;              // [B][nr] 3*|L n|
     // ---- plan written by the consume kernel for the apply kernels
     PcPlan *plan;                // [B]
+    int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
     int ablate;                  // dev timing hook (bit mask), 0 in production
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
