@@ -1,0 +1,275 @@
+// pc_cluster.hip -- kNN clustering of the live points on the device.
+//
+// Restates do_clustering / NN_clustering / compute_knn / do_clustering_k / relabel
+// (src/polychord/clustering.f90:15-324, utils.F90:713-749) and the data-parallel parts of
+// add_cluster (run_time_info.f90:303-505):
+//   k_similarity   S_ab = r_a + r_b - 2 x_a.x_b over the cube coordinates (calculate.f90:94-109),
+//                  one thread per pair, products and sums kept un-fused in dimension order so that the
+//                  neighbour ORDER equals the reference's;
+//   k_knn_sort     compute_knn for every row of a (sub)set at once: the insertion rule of
+//                  clustering.f90:156-172 (first slot with a strictly larger distance) is a stable sort
+//                  by (distance, index); one workgroup sorts one row in LDS (bitonic), which also makes
+//                  the "double k and recompute" step of NN_clustering free;
+//   k_nn_cluster   one workgroup runs the n = 2..k loop of NN_clustering (:53-76): connected components
+//                  of the "i in j's n-list or j in i's" graph by min-label hooking + pointer jumping in
+//                  LDS, relabel by first appearance, early exits;
+//   k_rebuild_lists / k_cluster_stats / k_ph_rehome   the array side of add_cluster: list order from
+//                  (cluster, position) labels, per-cluster contour + live log-sum-exp, and phantoms
+//                  re-homed to the cluster of their nearest live point (identify_cluster,
+//                  run_time_info.f90:444-453, 913-949).
+// The recursion over found clusters (clustering.f90:80-95) and the O(ncluster) evidence split
+// (run_time_info.f90:458-503) are driven from the host (pc_engine.hip); they touch a few integers.
+#include "pc_state.h"
+
+__global__ __launch_bounds__(256) void k_similarity(PcState S, const int *pts /* slots in list order */, int n, double *Sm)
+{
+    const int a = blockIdx.x, D = S.D;
+    const double *xa = S.live + (size_t)pts[a] * S.nT;
+    double ra = 0.0;
+    for (int d = 0; d < D; ++d) ra = __dadd_rn(ra, __dmul_rn(xa[d], xa[d]));
+    for (int b = blockIdx.y * 256 + threadIdx.x; b < n; b += gridDim.y * 256) {
+        const double *xb = S.live + (size_t)pts[b] * S.nT;
+        double rb = 0.0, s = 0.0;
+        for (int d = 0; d < D; ++d) { rb = __dadd_rn(rb, __dmul_rn(xb[d], xb[d])); s = __dadd_rn(s, __dmul_rn(xa[d], xb[d])); }
+        Sm[(size_t)a * n + b] = __dadd_rn(__dadd_rn(ra, rb), -__dmul_rn(2.0, s));
+    }
+}
+
+// rows of the sub-matrix S(gidx, gidx) sorted by (distance, local index): knn[a*m + r] = r-th neighbour
+__global__ __launch_bounds__(256) void k_knn_sort(const double *Sm, int nroot, const int *gidx, int m, int npow2, int *knn)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *kv = (double *)smem;
+    int *ki = (int *)(kv + npow2);
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const double *row = Sm + (size_t)gidx[a] * nroot;
+    for (int i = tid; i < npow2; i += 256) { kv[i] = (i < m) ? row[gidx[i]] : PC_HUGE; ki[i] = (i < m) ? i : 0x7fffffff; }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double x = kv[i], y = kv[l]; const int p = ki[i], q = ki[l];
+                    const bool gt = (x > y) || (x == y && p > q);
+                    if (gt == up) { kv[i] = y; kv[l] = x; ki[i] = q; ki[l] = p; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < m; i += 256) knn[(size_t)a * m + i] = ki[i];
+}
+
+// NN_clustering main loop for one point set (no recursion).  out[0] = number of clusters.
+__global__ __launch_bounds__(1024) void k_nn_cluster(const int *knn, int m, int *labels_out, int *out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *lab = (int *)smem;          // [m] component label (min index), then 1-based cluster label
+    int *old = lab + m;              // [m] previous clustering
+    int *rank = old + m;             // [m] scratch for the relabel prefix sums
+    __shared__ int sh_changed, sh_num, sh_same, sh_carry;
+    const int tid = threadIdx.x;
+    auto root = [&](int x) { while (lab[x] != x) x = lab[x]; return x; };
+    int k = m < 10 ? m : 10;
+    const int k0 = k;
+    int num = m;
+    for (int i = tid; i < m; i += 1024) { old[i] = i + 1; labels_out[i] = i + 1; }
+    __syncthreads();
+    for (int nn = 2; nn <= k0; ++nn) {
+        // ---- do_clustering_k (clustering.f90:100-130): components of the neighbour graph
+        for (int i = tid; i < m; i += 1024) lab[i] = i;
+        __syncthreads();
+        while (true) {
+            if (tid == 0) sh_changed = 0;
+            __syncthreads();
+            for (int e = tid; e < m * nn; e += 1024) {
+                const int i = e / nn, mm = e % nn;
+                const int j = knn[(size_t)i * m + mm];
+                // neighbours(): j's first entry (itself, clustering.f90:186) appears in i's list
+                if (knn[(size_t)j * m] != j) continue;         // duplicate points: handled below
+                const int ra = root(i), rb = root(j);
+                if (ra != rb) { atomicMin(&lab[ra > rb ? ra : rb], ra < rb ? ra : rb); sh_changed = 1; }
+            }
+            // points whose nearest entry is not themselves (exact duplicates): brute force
+            for (int j = tid; j < m; j += 1024) {
+                const int rep = knn[(size_t)j * m];
+                if (rep == j) continue;
+                for (int i = 0; i < m; ++i)
+                    for (int mm = 0; mm < nn; ++mm)
+                        if (knn[(size_t)i * m + mm] == rep) {
+                            const int ra = root(i), rb = root(j);
+                            if (ra != rb) { atomicMin(&lab[ra > rb ? ra : rb], ra < rb ? ra : rb); sh_changed = 1; }
+                        }
+            }
+            __syncthreads();
+            const int ch = sh_changed;
+            __syncthreads();
+            if (!ch) break;
+        }
+        for (int i = tid; i < m; i += 1024) rank[i] = root(i);
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) lab[i] = rank[i];
+        __syncthreads();
+        // ---- relabel (utils.F90:713-749): label = 1 + number of component minima below mine
+        if (tid == 0) sh_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < m; base += 1024) {
+            const int i = base + tid;
+            const int isroot = (i < m && lab[i] == i) ? 1 : 0;
+            // block inclusive scan in `rank`
+            __shared__ int scan[1024];
+            scan[tid] = isroot;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) { const int v = tid >= off ? scan[tid - off] : 0; __syncthreads(); scan[tid] += v; __syncthreads(); }
+            if (i < m) rank[i] = sh_carry + scan[tid];       // inclusive count of roots up to i
+            __syncthreads();
+            if (tid == 1023) sh_carry += scan[1023];
+            __syncthreads();
+        }
+        num = sh_carry;
+        if (tid == 0) sh_same = 1;
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) {
+            const int l = rank[lab[i]];                      // 1-based label of my component's minimum
+            labels_out[i] = l;
+            if (l != old[i]) sh_same = 0;
+        }
+        __syncthreads();
+        const int same = sh_same;
+        if (num == 1) break;                                  // clustering.f90:62-63
+        if (same) break;                                      // :64-65
+        if (nn == k) k = (2 * k < m) ? 2 * k : m;             // :66-69 (the sorted lists already hold any k)
+        for (int i = tid; i < m; i += 1024) old[i] = labels_out[i];
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = num; sh_num = num; }
+}
+
+// cl_list / cl_n from the (cluster, position) labels of every slot
+__global__ __launch_bounds__(256) void k_rebuild_lists(PcState S, int nc)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    if (tid < S.Ncap) { const int c = S.live_cluster[tid]; if (c >= 0) S.cl_list[(size_t)c * S.Ncap + S.live_pos[tid]] = tid; }
+    (void)nc;
+}
+
+// per-cluster count, contour (find_min_loglikelihoods) and live log-sum-exp; one workgroup per cluster
+__global__ __launch_bounds__(256) void k_cluster_stats(PcState S)
+{
+    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sv[256]; __shared__ int sk[256]; __shared__ int scount[256];
+    double bv = PC_HUGE; int bk = 0x7fffffff, bs = -1, cnt = 0; double mx = -PC_HUGE;
+    for (int s = tid; s < S.Ncap; s += 256) {
+        if (S.live_cluster[s] != c) continue;
+        cnt++;
+        const double v = S.live_logL[s]; const int p = S.live_pos[s];
+        if (v < bv || (v == bv && p < bk)) { bv = v; bk = p; bs = s; }
+        mx = fmax(mx, v);
+    }
+    sv[tid] = bv; sk[tid] = bk; scount[tid] = cnt;
+    __shared__ int ss[256]; __shared__ double smx[256];
+    ss[tid] = bs; smx[tid] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            if (sv[tid + off] < sv[tid] || (sv[tid + off] == sv[tid] && sk[tid + off] < sk[tid])) { sv[tid] = sv[tid + off]; sk[tid] = sk[tid + off]; ss[tid] = ss[tid + off]; }
+            scount[tid] += scount[tid + off]; smx[tid] = fmax(smx[tid], smx[tid + off]);
+        }
+        __syncthreads();
+    }
+    const double ref = smx[0];
+    double sum = 0.0;
+    for (int s = tid; s < S.Ncap; s += 256) if (S.live_cluster[s] == c) sum += exp(S.live_logL[s] - ref);
+    __shared__ double ssum[256];
+    ssum[tid] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) ssum[tid] += ssum[tid + off]; __syncthreads(); }
+    if (tid == 0) {
+        S.cl_n[c] = scount[0];
+        S.logLp[c] = scount[0] > 0 ? sv[0] : PC_HUGE; S.imin_slot[c] = ss[0];
+        S.lse_ref[c] = scount[0] > 0 ? ref : 0.0; S.lse_sum[c] = ssum[0];
+    }
+}
+
+// every phantom goes to the cluster of its nearest live point and survives only above that cluster's
+// contour (run_time_info.f90:444-453); one wavefront per phantom
+__global__ __launch_bounds__(64) void k_ph_rehome(PcState S, int nph, int nc, const unsigned *old_uids, int nold_uids)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= nph) return;
+    {   // phantoms of clusters that no longer exist are gone (run_time_info.f90:367-368 saves live clusters only)
+        const unsigned u = S.ph_cuid[j];
+        bool ok = false;
+        for (int q = 0; q < nold_uids; ++q) ok |= (old_uids[q] == u);
+        if (!ok) { if (lane == 0) S.ph_cuid[j] = 0xFFFFFFFFu; return; }
+    }
+    const double *x = S.phantom + (size_t)j * S.nT;
+    vk_t best{PC_HUGE, 0x7fffffff};
+    for (int s = lane; s < S.Ncap; s += 64) {
+        const int c = S.live_cluster[s];
+        if (c < 0) continue;
+        const double *q = S.live + (size_t)s * S.nT;
+        double d2 = 0.0;
+        for (int d = 0; d < S.D; ++d) { const double t = x[d] - q[d]; d2 += t * t; }
+        best = vk_min(best, vk_t{d2, c * S.Ncap + S.live_pos[s]});
+    }
+    best = wave_argmin(best);
+    if (lane == 0) {
+        const int c = best.k / S.Ncap;
+        S.ph_cuid[j] = (S.ph_logL[j] > S.logLp[c]) ? S.cl_uid[c] : 0xFFFFFFFFu;
+        (void)nc;
+    }
+}
+
+// number of phantoms per cluster uid (fixed order: one workgroup, serial accumulation per cluster)
+__global__ __launch_bounds__(256) void k_ph_count(PcState S, int nph, int nc, int *counts)
+{
+    __shared__ int sc[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const unsigned uid = S.cl_uid[c];
+    int cnt = 0;
+    for (int j = tid; j < nph; j += 256) cnt += (S.ph_cuid[j] == uid);
+    sc[tid] = cnt;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) sc[tid] += sc[tid + off]; __syncthreads(); }
+    if (tid == 0) counts[c] = sc[0];
+    (void)nc;
+}
+
+extern "C" {
+
+void pc_launch_similarity(const PcState *S, const int *pts, int n, double *Sm, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_similarity, dim3(n, (n + 1023) / 1024), dim3(256), 0, st, *S, pts, n, Sm);
+}
+
+int pc_launch_knn_cluster(const double *Sm, int nroot, const int *gidx, int m, int *knn, int *labels, int *out, hipStream_t st)
+{
+    int npow2 = 2;
+    while (npow2 < m) npow2 <<= 1;
+    const size_t sh = (size_t)npow2 * 12;
+    const size_t sh2 = (size_t)m * 12 + 64;
+    if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
+    static size_t d1 = 0, d2 = 0;
+    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
+    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    hipLaunchKernelGGL(k_knn_sort, dim3(m), dim3(256), sh, st, Sm, nroot, gidx, m, npow2, knn);
+    hipLaunchKernelGGL(k_nn_cluster, dim3(1), dim3(1024), sh2, st, knn, m, labels, out);
+    return 0;
+}
+
+void pc_launch_rebuild(const PcState *S, int nc, hipStream_t st)
+{
+    const int n = S->Ncap > S->maxc ? S->Ncap : S->maxc;
+    hipLaunchKernelGGL(k_rebuild_lists, dim3((n + 255) / 256), dim3(256), 0, st, *S, nc);
+    hipLaunchKernelGGL(k_cluster_stats, dim3(nc), dim3(256), 0, st, *S);
+}
+
+void pc_launch_ph_rehome(const PcState *S, int nph, int nc, const unsigned *old_uids, int nold_uids, int *counts, hipStream_t st)
+{
+    if (nph > 0) hipLaunchKernelGGL(k_ph_rehome, dim3(nph), dim3(64), 0, st, *S, nph, nc, old_uids, nold_uids);
+    hipLaunchKernelGGL(k_ph_count, dim3(nc), dim3(256), 0, st, *S, nph, nc, counts);
+}
+
+}  // extern "C"

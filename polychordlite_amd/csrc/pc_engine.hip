@@ -29,6 +29,10 @@ void pc_launch_clean(const PcState *, int, unsigned char *, int *, int *, double
                      unsigned long long *, int *, hipStream_t);
 void pc_launch_reset_thresholds(const PcState *, hipStream_t);
 int pc_cov_nchunk(const PcState *, int);
+void pc_launch_similarity(const PcState *, const int *, int, double *, hipStream_t);
+int pc_launch_knn_cluster(const double *, int, const int *, int, int *, int *, int *, hipStream_t);
+void pc_launch_rebuild(const PcState *, int, hipStream_t);
+void pc_launch_ph_rehome(const PcState *, int, int, const unsigned *, int, int *, hipStream_t);
 int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
 }
 
@@ -80,6 +84,10 @@ struct Engine {
     size_t cov_chunks_cap = 0;
     double *d_lo = nullptr, *d_hi = nullptr, *d_invcovT = nullptr, *d_mean = nullptr;
     double *d_dynL = nullptr; int *d_dynN = nullptr;
+    // clustering scratch (allocated on first use)
+    double *c_Sm = nullptr; int *c_pts = nullptr, *c_gidx = nullptr, *c_knn = nullptr, *c_lab = nullptr, *c_out = nullptr, *c_cnt = nullptr;
+    unsigned *c_olduid = nullptr; int c_cap = 0;
+    long nsplits = 0;
     Timing tm;
     KTimer kt;
     int B = 0;
@@ -244,9 +252,166 @@ struct Engine {
         h_ctl->nphantom = total;
         HIPCHK(hipMemcpyAsync(&S.ctl->nphantom, &h_ctl->nphantom, sizeof(int), hipMemcpyHostToDevice, st));
         pc_launch_reset_thresholds(&S, st);
+        if (cfg.do_clustering) { HIPCHK(hipStreamSynchronize(st)); do_clustering(); }
         hipEvent_t e1 = kt.begin();
-        covmats(total, nc);
+        covmats(total, h_ctl->ncluster);
         kt.end(KT_COV, e1);
+    }
+
+    // ---- kNN clustering (clustering.f90:253-324); heavy parts on the device (pc_cluster.hip)
+    static int relabel_host(std::vector<int> &lab)
+    {   // utils.F90:713-749
+        std::vector<int> map; std::vector<int> out(lab.size());
+        for (size_t i = 0; i < lab.size(); ++i) {
+            int f = -1;
+            for (size_t k = 0; k < map.size(); ++k) if (map[k] == lab[i]) { f = (int)k; break; }
+            if (f < 0) { map.push_back(lab[i]); f = (int)map.size() - 1; }
+            out[i] = f + 1;
+        }
+        lab.swap(out);
+        return (int)map.size();
+    }
+
+    // NN_clustering on the subset `gidx` (indices into the root cluster's point order); recursion
+    // over the found clusters as in clustering.f90:80-95
+    int nn_clustering(int nroot, const std::vector<int> &gidx, std::vector<int> &labels)
+    {
+        const int m = (int)gidx.size();
+        labels.assign(m, 1);
+        if (m <= 1) return 1;
+        HIPCHK(hipMemcpyAsync(c_gidx, gidx.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+        if (pc_launch_knn_cluster(c_Sm, nroot, c_gidx, m, c_knn, c_lab, c_out, st)) { std::fprintf(stderr, "polychord_hip: cluster too large for the LDS kNN sort\n"); std::abort(); }
+        int num = 0;
+        HIPCHK(hipMemcpyAsync(labels.data(), c_lab, sizeof(int) * m, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&num, c_out, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (num > 1) {
+            int ic = 1;
+            while (ic <= num) {
+                std::vector<int> pts, sub;
+                for (int j = 0; j < m; ++j) if (labels[j] == ic) { pts.push_back(j); sub.push_back(gidx[j]); }
+                std::vector<int> sl;
+                const int nnew = nn_clustering(nroot, sub, sl);
+                for (size_t a = 0; a < pts.size(); ++a) labels[pts[a]] = num + sl[a];
+                if (nnew == 1) ic++;
+                num = relabel_host(labels);
+            }
+        }
+        return num;
+    }
+
+    void ensure_cluster_scratch()
+    {
+        if (c_cap >= S.Ncap) return;
+        c_cap = S.Ncap;
+        c_Sm = dalloc<double>((size_t)c_cap * c_cap); c_pts = dalloc<int>(c_cap); c_gidx = dalloc<int>(c_cap);
+        c_knn = dalloc<int>((size_t)c_cap * c_cap); c_lab = dalloc<int>(c_cap); c_out = dalloc<int>(4);
+        c_cnt = dalloc<int>(S.maxc); c_olduid = dalloc<unsigned>(S.maxc);
+    }
+
+    template <class T> std::vector<T> dl(const T *p, size_t n)
+    {
+        std::vector<T> v(n);
+        HIPCHK(hipMemcpy(v.data(), p, sizeof(T) * n, hipMemcpyDeviceToHost));
+        return v;
+    }
+    template <class T> void ul(T *p, const std::vector<T> &v) { HIPCHK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice)); }
+
+    // add_cluster (run_time_info.f90:303-505): cluster p splits into nnew clusters appended at the end
+    void add_cluster(int p, const std::vector<int> &labels, int nnew)
+    {
+        const int nc = h_ctl->ncluster, nold = nc - 1, ncn = nc + nnew - 1, maxc = S.maxc, Ncap = S.Ncap;
+        if (ncn > maxc) { std::fprintf(stderr, "polychord_hip: more than %d clusters\n", maxc); std::abort(); }
+        nsplits++;
+        auto lc = dl(S.live_cluster, Ncap); auto lp = dl(S.live_pos, Ncap);
+        // position of every split point inside its new cluster = rank among equal labels in list order
+        std::vector<int> posnew(labels.size()), cnt(nnew, 0);
+        for (size_t a = 0; a < labels.size(); ++a) posnew[a] = cnt[labels[a] - 1]++;
+        for (int s = 0; s < Ncap; ++s) {
+            const int c = lc[s];
+            if (c < 0) continue;
+            if (c == p) { const int a = lp[s]; lc[s] = nold + labels[a] - 1; lp[s] = posnew[a]; }
+            else if (c > p) lc[s] = c - 1;
+        }
+        ul(S.live_cluster, lc); ul(S.live_pos, lp);
+        // per-cluster state: old clusters keep their order at 0..nold-1 (old_save/old_target, :371-376)
+        auto Xp = dl(S.logXp, maxc), ZXp = dl(S.logZXp, maxc), Zp = dl(S.logZp, maxc), Zp2 = dl(S.logZp2, maxc),
+             ZpXp = dl(S.logZpXp, maxc), thr = dl(S.death_thr, maxc), XQ = dl(S.XpXq, (size_t)maxc * maxc);
+        auto uid = dl(S.cl_uid, maxc);
+        std::vector<unsigned> olduid(uid.begin(), uid.begin() + nc);
+        HIPCHK(hipMemcpy(c_olduid, olduid.data(), sizeof(unsigned) * nc, hipMemcpyHostToDevice));
+        const double logXp = Xp[p], logXp2 = XQ[(size_t)p * maxc + p], logZp = Zp[p], logZp2 = Zp2[p], logZXp = ZXp[p], logZpXp = ZpXp[p];
+        std::vector<double> rowpq;
+        for (int q = 0; q < nc; ++q) if (q != p) rowpq.push_back(XQ[(size_t)p * maxc + q]);
+        auto shift = [&](std::vector<double> &v) { for (int c = p; c < nc - 1; ++c) v[c] = v[c + 1]; };
+        shift(Xp); shift(ZXp); shift(Zp); shift(Zp2); shift(ZpXp); shift(thr);
+        for (int c = p; c < nc - 1; ++c) uid[c] = uid[c + 1];
+        {
+            std::vector<double> t(XQ);
+            for (int a = 0, na = 0; a < nc; ++a) { if (a == p) continue; for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; XQ[(size_t)na * maxc + nb] = t[(size_t)a * maxc + b]; nb++; } na++; }
+        }
+        const int DD = S.D * S.D;
+        for (int c = p; c < nc - 1; ++c) {
+            HIPCHK(hipMemcpy(S.chol + (size_t)c * DD, S.chol + (size_t)(c + 1) * DD, sizeof(double) * DD, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(S.cov + (size_t)c * DD, S.cov + (size_t)(c + 1) * DD, sizeof(double) * DD, hipMemcpyDeviceToDevice));
+        }
+        for (int k = 0; k < nnew; ++k) { uid[nold + k] = h_ctl->next_cluster_uid++; thr[nold + k] = -PC_HUGE; }
+        ul(S.cl_uid, uid); ul(S.death_thr, thr);
+        // lists, contours, live log-sum-exp of every cluster; then the phantoms find their new homes
+        pc_launch_rebuild(&S, ncn, st);
+        pc_launch_ph_rehome(&S, h_ctl->nphantom, ncn, c_olduid, nc, c_cnt, st);
+        HIPCHK(hipStreamSynchronize(st));
+        auto nph = dl(c_cnt, ncn); auto nlv = dl(S.cl_n, ncn);
+        // 5) evidences and volumes split in proportion to nlive + nphantom (:458-503)
+        std::vector<double> logni(nnew), logni1(nnew);
+        for (int k = 0; k < nnew; ++k) { logni[k] = std::log((double)(nlv[nold + k] + nph[nold + k]) + 0.0); logni1[k] = std::log((double)(nlv[nold + k] + nph[nold + k]) + 1.0); }
+        double mx = logni[0];
+        for (int k = 1; k < nnew; ++k) mx = std::max(mx, logni[k]);
+        double sm = 0.0;
+        for (int k = 0; k < nnew; ++k) sm += std::exp(logni[k] - mx);
+        const double logn = mx + std::log(sm);
+        const double logn1 = logn > 0.0 ? logn + std::log(std::exp(0.0 - logn) + 1.0) : 0.0 + std::log(std::exp(logn - 0.0) + 1.0);
+        for (int k = 0; k < nnew; ++k) {
+            const int c = nold + k;
+            Xp[c] = logXp + logni[k] - logn; ZXp[c] = logZXp + logni[k] - logn; Zp[c] = logZp + logni[k] - logn;
+            Zp2[c] = logZp2 + logni[k] + logni1[k] - logn - logn1; ZpXp[c] = logZpXp + logni[k] + logni1[k] - logn - logn1;
+            for (int q = 0; q < nold; ++q) { XQ[(size_t)c * maxc + q] = rowpq[q] + logni[k] - logn; XQ[(size_t)q * maxc + c] = XQ[(size_t)c * maxc + q]; }
+        }
+        for (int a = 0; a < nnew; ++a)
+            for (int b = 0; b < nnew; ++b)
+                XQ[(size_t)(nold + a) * maxc + nold + b] = (a == b) ? logXp2 + logni[a] + logni1[a] - logn - logn1
+                                                                     : logXp2 + logni[a] + logni[b] - logn - logn1;
+        ul(S.logXp, Xp); ul(S.logZXp, ZXp); ul(S.logZp, Zp); ul(S.logZp2, Zp2); ul(S.logZpXp, ZpXp); ul(S.XpXq, XQ);
+        h_ctl->ncluster = ncn;
+    }
+
+    // do_clustering (clustering.f90:253-324)
+    bool do_clustering()
+    {
+        ensure_cluster_scratch();
+        bool found = false;
+        const int nold = h_ctl->ncluster;
+        int ic = 0;
+        while (ic < nold) {
+            if (ic >= h_ctl->ncluster) break;
+            int n = 0;
+            HIPCHK(hipMemcpy(&n, S.cl_n + ic, sizeof(int), hipMemcpyDeviceToHost));
+            if (n > 2) {
+                HIPCHK(hipMemcpyAsync(c_pts, S.cl_list + (size_t)ic * S.Ncap, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+                pc_launch_similarity(&S, c_pts, n, c_Sm, st);
+                std::vector<int> gidx(n), labels;
+                for (int i = 0; i < n; ++i) gidx[i] = i;
+                const int num = nn_clustering(n, gidx, labels);
+                if (num > 1) { found = true; add_cluster(ic, labels, num); }
+                else ic++;
+            } else ic++;
+        }
+        if (found) {
+            h_ctl->admin_epoch++;
+            h_ctl->status = PC_ST_RUNNING;
+            HIPCHK(hipMemcpy(S.ctl, h_ctl, sizeof(PcCtl), hipMemcpyHostToDevice));
+        }
+        return found;
     }
 
     void covmats(int nph, int nc)

@@ -72,26 +72,32 @@ def test_slice_chains_match_oracle(engine, kind, D, nDer, nr, nchains):
         assert np.allclose(np.linalg.norm(nh[c], axis=1), 1.0, atol=1e-12)
 
 
-RUNS = [  # kind D nDer nlive nr B general
-    ("gaussian", 20, 2, 100, 20, 1, 0), ("gaussian", 20, 2, 200, 40, 16, 0), ("gaussian", 20, 2, 200, 40, 16, 1),
-    ("gaussian", 4, 1, 100, 20, 32, 0), ("gaussian", 20, 2, 500, 40, 128, 0), ("rastrigin", 4, 0, 200, 12, 50, 0),
-    ("twin_gaussian", 6, 1, 150, 12, 40, 1),
+RUNS = [  # kind D nDer nlive nr B general clustering
+    ("gaussian", 20, 2, 100, 20, 1, 0, 0), ("gaussian", 20, 2, 200, 40, 16, 0, 0), ("gaussian", 20, 2, 200, 40, 16, 1, 0),
+    ("gaussian", 4, 1, 100, 20, 32, 0, 0), ("gaussian", 20, 2, 500, 40, 128, 0, 0), ("rastrigin", 4, 0, 200, 12, 50, 0, 0),
+    ("twin_gaussian", 6, 1, 150, 12, 40, 1, 0),
+    # kNN clustering on the device: cluster splits, deaths, phantom re-homing, evidence splitting
+    ("rastrigin", 2, 0, 300, 6, 1, 0, 1), ("rastrigin", 2, 0, 300, 6, 40, 0, 1), ("twin_gaussian", 6, 1, 150, 12, 30, 0, 1),
+    ("rastrigin", 4, 0, 200, 12, 50, 0, 1), ("gaussian", 20, 2, 200, 40, 16, 0, 1),
 ]
 
 
-@pytest.mark.parametrize("kind,D,nDer,nlive,nr,B,general", RUNS)
-def test_full_run_matches_oracle(engine, kind, D, nDer, nlive, nr, B, general):
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,B,general,clustering", RUNS)
+def test_full_run_matches_oracle(engine, kind, D, nDer, nlive, nr, B, general, clustering):
     api = engine
     lo, hi = BOX[kind]
-    s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B, force_general=general)
+    s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B, force_general=general,
+                  do_clustering=clustering)
     L, P, keep = api.make_problem(kind, D, nDer, lo, hi)
     g = api.run(s, L, P)
-    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B)
+    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=5, batch=B, do_clustering=clustering)
     Lo, Po, keep2 = orc.make_problem(kind, D, lo, hi)
     o = orc.run(so, Lo, Po)
-    for k in ("ndead", "nlike", "niter", "nbatches", "ncluster_dead"):
+    for k in ("ndead", "nlike", "niter", "nbatches", "ncluster", "ncluster_dead"):
         assert g[k] == o[k], (k, g[k], o[k])
     assert abs(g["logZ"] - o["logZ"]) < 1e-8
+    if clustering:   # per-cluster evidences of the dead clusters, in order of death
+        assert np.allclose(g["logZp"], o["logZp"], atol=1e-8)
     assert abs(g["logZerr"] - o["logZerr"]) < 1e-8
     rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
     assert rel.max() < 1e-7
