@@ -67,6 +67,9 @@ void polychord_hip_set_corr_gaussian(int nDims, const double *invcov_rowmajor, c
 /* uniform box prior evaluated on the device; pass polychord_hip_uniform_prior as `prior` */
 void polychord_hip_uniform_prior(double *cube, double *theta, int nDims);
 void polychord_hip_set_uniform_prior(int nDims, const double *lo, const double *hi);
+/* asks a running engine to stop at the next host callback boundary (used by language bindings when a
+ * user callback raised: the reference throws through the Fortran frames, _pypolychord.cpp:219-224) */
+void polychord_hip_request_stop(void);
 /* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
 void polychord_hip_set_option(const char *name, double value);
 

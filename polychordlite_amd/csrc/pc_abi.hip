@@ -207,11 +207,14 @@ void polychord_c_interface(
         struct stat sb;
         if (stat(base.c_str(), &sb) != 0) halt_program(("PolyChord Error: " + base + " does not exist").c_str()); // read_write.F90:28-38
     }
-    if (L.kind == PCHIP_LIKE_CALLBACK || P.kind == 0)
-        halt_program("polychord_hip: host-callback likelihoods/priors are not wired to the device proposer yet; "
-                     "pass polychord_hip_<name> built-ins (no CPU fallback exists by design)");
+    if (P.kind == 0 && L.kind != PCHIP_LIKE_CALLBACK) {
+        // a user prior with a built-in likelihood: evaluate both on the host (the device still proposes)
+        L.kind = PCHIP_LIKE_CALLBACK; L.fn = loglikelihood;
+    }
     pchip_result r;
-    if (pchip_run(&s, &L, &P, &r) != 0) halt_program("polychord_hip: engine failure");
+    const int rc = pchip_run(&s, &L, &P, &r);
+    if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
+    if (rc != 0) halt_program("polychord_hip: engine failure");
     if (write_stats_f) write_stats(base + "/" + root + ".stats", r, 0, 0);
     if (write_dead) {
         write_rows(base + "/" + root + "_dead.txt", r, nDims, nDerived, false, false);

@@ -33,12 +33,17 @@ void pc_launch_similarity(const PcState *, const int *, int, double *, hipStream
 int pc_launch_knn_cluster(const double *, int, const int *, int, int *, int *, int *, hipStream_t);
 void pc_launch_rebuild(const PcState *, int, hipStream_t);
 void pc_launch_ph_rehome(const PcState *, int, int, const unsigned *, int, int *, hipStream_t);
+void pc_launch_slice_tick(const PcState *, unsigned, int, void *, double *, int *, double *, const double *, const double *,
+                          const double *, int, int *, int *, hipStream_t);
+size_t pc_chain_state_size(void);
 int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     std::fprintf(stderr, "polychord_hip: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
     std::abort(); } } while (0)
+
+static volatile int g_stop_requested = 0;
 
 namespace {
 
@@ -72,8 +77,34 @@ struct KTimer {
     void destroy() { for (auto e : pool) hipEventDestroy(e); pool.clear(); }
 };
 
+// host copy of the device's counter RNG (pc_dev.h), used when the host evaluates the likelihood
+static void h_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, uint32_t slo, uint32_t idx)
+{
+    uint32_t o[4];
+    h_philox(idx >> 1, slo, shi, dom, k0, k1, o);
+    const uint64_t w = (idx & 1u) ? (((uint64_t)o[2] << 32) | o[3]) : (((uint64_t)o[0] << 32) | o[1]);
+    return ((double)(w >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
 struct Engine {
     pchip_settings cfg{};
+    // host-callback mode (device proposes, host evaluates): pc_callback.hip
+    polychord_loglike_fn cb_like = nullptr; polychord_prior_fn cb_prior = nullptr;
+    bool callback_mode = false;
+    void *d_cs = nullptr; double *d_x0s = nullptr, *d_prop = nullptr, *d_evL = nullptr, *d_evT = nullptr, *d_evP = nullptr;
+    int *d_decks = nullptr, *d_nneed = nullptr, *d_need = nullptr;
+    std::vector<double> h_prop, h_evL, h_evT, h_evP; std::vector<int> h_need;
+    long long cb_evals = 0; long cb_ticks = 0;
+    std::vector<double> h_lo, h_hi;
     PcState S{};
     hipStream_t st = nullptr;
     PcCtl *h_ctl = nullptr;       // pinned mirror
@@ -118,6 +149,7 @@ struct Engine {
         const int nprior = c.nprior <= 0 ? c.nlive : c.nprior;
         S.Ncap = std::max(nmax, nprior);
         B = c.batch > 0 ? c.batch : std::max(1, std::min(1024, c.nlive / 2));
+        if (c.batch <= 0 && (like.kind == PC_LIKE_CALLBACK || prior.kind != 1)) B = std::max(1, std::min(64, c.nlive / 4));
         S.B = B;
         S.maxc = c.do_clustering ? 128 : 4;
         S.maxc_dead = 4096;
@@ -151,6 +183,11 @@ struct Engine {
             HIPCHK(hipMemcpy(d_mean, like.mean, sizeof(double) * D, hipMemcpyHostToDevice));
             S.like.invcov = d_invcovT; S.like.mean = d_mean;
         }
+        callback_mode = (like.kind == PC_LIKE_CALLBACK) || (prior.kind != 1);
+        if (callback_mode) {
+            cb_like = like.fn; cb_prior = prior.fn;
+            if (!cb_like) { std::fprintf(stderr, "polychord_hip: callback mode needs a loglikelihood function pointer\n"); std::abort(); }
+        }
         S.prior.kind = prior.kind; S.prior.lo = nullptr; S.prior.hi = nullptr;
         if (prior.kind == 1 && prior.lo && prior.hi) {
             d_lo = dalloc<double>(D); d_hi = dalloc<double>(D);
@@ -183,6 +220,13 @@ struct Engine {
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
+        if (callback_mode) {
+            d_cs = (void *)dalloc<char>(pc_chain_state_size() * B); d_x0s = dalloc<double>((size_t)B * D); d_prop = dalloc<double>((size_t)B * D);
+            d_evL = dalloc<double>(B); d_evT = dalloc<double>((size_t)B * D); d_evP = dalloc<double>((size_t)B * std::max(1, nDer));
+            d_decks = dalloc<int>((size_t)B * nr); d_nneed = dalloc<int>(1); d_need = dalloc<int>(B);
+            h_prop.resize((size_t)B * D); h_evL.resize(B); h_evT.resize((size_t)B * D); h_evP.resize((size_t)B * std::max(1, nDer)); h_need.resize(B);
+            HIPCHK(hipMemset(d_cs, 0, pc_chain_state_size() * B));
+        }
         HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(PcCtl)));
         // per-cluster initial values (initialise_run_time_info, run_time_info.f90:164-206)
         std::vector<double> lz(maxc, c.logzero), zero(maxc, 0.0), hugeneg(maxc, -PC_HUGE);
@@ -429,6 +473,71 @@ struct Engine {
         }
     }
 
+    // prior + likelihood on the host for one hypercube point (calculate.f90:40-41)
+    double host_eval(const double *cube, double *theta, double *phi)
+    {
+        const int D = S.D;
+        if (cb_prior) cb_prior(const_cast<double *>(cube), theta, D);
+        else {
+            if ((int)h_lo.size() != D) {
+                h_lo.assign(D, 0.0); h_hi.assign(D, 1.0);
+                if (d_lo) { HIPCHK(hipMemcpy(h_lo.data(), d_lo, sizeof(double) * D, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(h_hi.data(), d_hi, sizeof(double) * D, hipMemcpyDeviceToHost)); }
+            }
+            for (int d = 0; d < D; ++d) theta[d] = h_lo[d] + (h_hi[d] - h_lo[d]) * cube[d];
+        }
+        cb_evals++;
+        return cb_like(theta, D, phi, S.nDer);
+    }
+
+    void generate_live_callback()
+    {   // GenerateLivePoints with host evaluations; same Philox streams as k_generate_live
+        const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT, D = S.D;
+        std::vector<double> rows((size_t)nprior * nT, 0.0);
+        int have = 0; uint32_t attempt = 0; long long nlike = 0;
+        while (have < nprior) {
+            double *row = rows.data() + (size_t)have * nT;
+            for (int d = 0; d < D; ++d) row[d] = h_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, attempt, (uint32_t)d);
+            const double logL = host_eval(row, row + S.p0, row + S.d0);
+            row[S.b0] = cfg.logzero; row[S.l0] = logL;
+            if (logL > cfg.logzero) { have++; nlike++; }
+            attempt++;
+            if (g_stop_requested) return;
+            if (attempt > 1000u * (uint32_t)nprior + 100000u) { std::fprintf(stderr, "polychord_hip: could not generate live points (likelihood is logzero everywhere?)\n"); std::abort(); }
+        }
+        double *drows = dalloc<double>((size_t)nprior * nT);
+        HIPCHK(hipMemcpy(drows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+        pc_launch_install_live(&S, drows, nprior, st);
+        h_ctl->nlike = nlike;
+        HIPCHK(hipMemcpyAsync(&S.ctl->nlike, &h_ctl->nlike, sizeof(long long), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        dfree(drows);
+        if (nprior > cfg.nlive) { pc_launch_consume(&S, 2, 0, st); read_ctl(); }
+    }
+
+    // one nursery batch in callback mode: tick the chains until all of them are done
+    void slice_callback(unsigned batch)
+    {
+        const int D = S.D, nDer = S.nDer;
+        int first = 1;
+        while (true) {
+            HIPCHK(hipMemsetAsync(d_nneed, 0, sizeof(int), st));
+            pc_launch_slice_tick(&S, batch, B, d_cs, d_x0s, d_decks, d_prop, d_evL, d_evT, d_evP, first, d_nneed, d_need, st);
+            first = 0; cb_ticks++;
+            int nneed = 0;
+            HIPCHK(hipMemcpyAsync(&nneed, d_nneed, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (nneed == 0) break;
+            HIPCHK(hipMemcpy(h_need.data(), d_need, sizeof(int) * B, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(h_prop.data(), d_prop, sizeof(double) * (size_t)B * D, hipMemcpyDeviceToHost));
+            if (g_stop_requested) return;
+            for (int c = 0; c < B; ++c)
+                if (h_need[c]) h_evL[c] = host_eval(h_prop.data() + (size_t)c * D, h_evT.data() + (size_t)c * D, h_evP.data() + (size_t)c * std::max(1, nDer));
+            HIPCHK(hipMemcpyAsync(d_evL, h_evL.data(), sizeof(double) * B, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_evT, h_evT.data(), sizeof(double) * (size_t)B * D, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_evP, h_evP.data(), sizeof(double) * (size_t)B * std::max(1, nDer), hipMemcpyHostToDevice, st));
+        }
+    }
+
     void generate_live()
     {   // GenerateLivePoints (generate.F90:150-183): keep the first nprior valid prior samples
         const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT;
@@ -467,7 +576,8 @@ struct Engine {
     {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
-        generate_live();
+        if (callback_mode) generate_live_callback(); else generate_live();
+        if (g_stop_requested) return 5;
         auto t1 = clk::now();
         unsigned batch = 0;
         const int wide = 0;
@@ -483,7 +593,8 @@ struct Engine {
                 if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_NHATS, e0);
                 hipEvent_t e1 = kt.begin();
-                if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
+                else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
                 batch++; tm.batches++;
             }
@@ -586,6 +697,8 @@ struct Engine {
 
 extern "C" {
 
+void polychord_hip_request_stop(void) { g_stop_requested = 1; }
+
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived)
 {   // defaults of the reference's C++ Settings (src/polychord/c_interface.cpp:6-39)
     std::memset(s, 0, sizeof(*s));
@@ -605,12 +718,14 @@ int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior
 {
     if (s->num_repeats < 1) { std::fprintf(stderr, "polychord_hip: You need to set num_repeats. Suggestion: 5*nDims\n"); return 1; } // settings.f90:216
     if (s->num_repeats > 64 * PC_MASK_WORDS) { std::fprintf(stderr, "polychord_hip: num_repeats > %d unsupported\n", 64 * PC_MASK_WORDS); return 1; }
-    if (like->kind == PC_LIKE_CALLBACK || prior->kind != 1) { std::fprintf(stderr, "polychord_hip: pchip_run needs a device likelihood and a uniform prior\n"); return 1; }
+    if (like->kind == PC_LIKE_CALLBACK && !like->fn) { std::fprintf(stderr, "polychord_hip: callback likelihood without a function pointer\n"); return 1; }
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
+    g_stop_requested = 0;
     Engine E;
     E.setup(*s, *like, *prior);
     auto t1 = clk::now();
+    std::memset(out, 0, sizeof(*out));
     const int rc = E.run(out);
     auto t2 = clk::now();
     E.destroy();

@@ -1,0 +1,135 @@
+"""`run` / `run_polychord` -- same signatures, defaults and errors as reference
+pypolychord/polychord.py (run_polychord :16-215, run :221-646)."""
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from . import _pypolychord
+from .settings import PolyChordSettings  # noqa: F401
+
+
+def default_prior(cube):
+    """identity prior on the unit hypercube (polychord.py:9-10)"""
+    return cube.copy()
+
+
+def default_dumper(live, dead, logweights, logZ, logZerr):
+    pass
+
+
+def make_paramnames_file(paramnames, filename):
+    """output.py:173-177"""
+    with open(filename, "w") as f:
+        for name, latex in paramnames:
+            f.write("%s   %s\n" % (name, latex))
+
+
+def _wrap(loglikelihood, prior):
+    builtin_like = getattr(loglikelihood, "symbol", None) is not None
+    builtin_prior = getattr(prior, "symbol", None) is not None
+
+    def wrap_loglikelihood(theta, phi):          # polychord.py:581-587
+        logL = loglikelihood(theta)
+        try:
+            logL, phi[:] = logL
+        except TypeError:
+            pass
+        return logL
+
+    def wrap_prior(cube, theta):                 # polychord.py:589-590
+        theta[:] = prior(cube)
+
+    if builtin_like:
+        wrap_loglikelihood.__wrapped_builtin__ = loglikelihood
+    if builtin_prior:
+        wrap_prior.__wrapped_builtin__ = prior
+    return wrap_loglikelihood, wrap_prior
+
+
+class _Output:
+    """minimal stand-in for PolyChordOutput (output.py:57-99): parses <root>.stats by line"""
+
+    def __init__(self, base_dir, file_root):
+        self.base_dir, self.file_root = base_dir, file_root
+        self.root = str(Path(base_dir) / file_root)
+        self.logZ = self.logZerr = None
+        self.logZs, self.logZerrs = [], []
+        try:
+            with open(self.root + ".stats") as f:
+                for line in f:
+                    if line.startswith("log(Z)") and "+/-" in line:
+                        a, b = line.split("=")[1].split("+/-")
+                        self.logZ, self.logZerr = float(a), float(b)
+                    elif line.startswith("log(Z_") and "+/-" in line:
+                        a, b = line.split("=")[1].replace("(Still Active)", "").split("+/-")
+                        self.logZs.append(float(a)); self.logZerrs.append(float(b))
+                    elif "ndead:" in line:
+                        self.ndead = int(line.split(":")[1])
+                    elif "nlike:" in line:
+                        self.nlike = int(line.split(":")[1].split()[0])
+        except OSError:
+            pass
+
+    def __repr__(self):
+        return f"log(Z) = {self.logZ} +/- {self.logZerr}"
+
+
+def run_polychord(loglikelihood, nDims, nDerived, settings, prior=default_prior, dumper=default_dumper):
+    """legacy interface (polychord.py:16-215)"""
+    Path(settings.cluster_dir).mkdir(parents=True, exist_ok=True)
+    if settings.cube_samples is not None:
+        raise NotImplementedError("cube_samples needs the resume-file reader, which this engine does not have yet")
+    wl, wp = _wrap(loglikelihood, prior)
+    settings.grade_dims = [int(d) for d in settings.grade_dims]
+    settings.nlives = {float(logL): int(nlive) for logL, nlive in settings.nlives.items()}
+    _pypolychord.run(wl, wp, dumper, nDims, nDerived, settings.nlive, settings.num_repeats, settings.nprior, settings.nfail,
+                     settings.do_clustering, settings.feedback, settings.precision_criterion, settings.logzero,
+                     settings.max_ndead, settings.boost_posterior, settings.posteriors, settings.equals,
+                     settings.cluster_posteriors, settings.write_resume, settings.write_paramnames, settings.read_resume,
+                     settings.write_stats, settings.write_live, settings.write_dead, settings.write_prior, settings.maximise,
+                     settings.compression_factor, settings.synchronous, settings.base_dir, settings.file_root,
+                     settings.grade_frac, settings.grade_dims, settings.nlives, settings.seed)
+    return _Output(settings.base_dir, settings.file_root)
+
+
+def run(loglikelihood, nDims, **kwargs):
+    """keyword interface (polychord.py:221-646)"""
+    paramnames = kwargs.pop("paramnames", None)
+    default_kwargs = {
+        "nDerived": 0, "prior": default_prior, "dumper": default_dumper, "nlive": nDims * 25, "num_repeats": nDims * 5,
+        "nprior": -1, "nfail": -1, "do_clustering": True, "feedback": 1, "precision_criterion": 0.001, "logzero": -1e30,
+        "max_ndead": -1, "boost_posterior": 0.0, "posteriors": True, "equals": True, "cluster_posteriors": True,
+        "write_resume": True, "write_paramnames": False, "read_resume": True, "write_stats": True, "write_live": True,
+        "write_dead": True, "write_prior": True, "maximise": False, "compression_factor": np.exp(-1), "synchronous": True,
+        "base_dir": "chains", "file_root": "test", "cluster_dir": "clusters", "grade_dims": [nDims], "nlives": {},
+        "seed": -1,
+    }
+    default_kwargs["grade_frac"] = ([1.0] * len(default_kwargs["grade_dims"]) if "grade_dims" not in kwargs
+                                    else [1.0] * len(kwargs["grade_dims"]))
+    if not kwargs.keys() <= default_kwargs.keys():
+        raise TypeError(f"{__name__} got unknown keyword arguments: {kwargs.keys() - default_kwargs.keys()}")
+    default_kwargs.update(kwargs)
+    kwargs = default_kwargs
+    (Path(kwargs["base_dir"]) / kwargs["cluster_dir"]).mkdir(parents=True, exist_ok=True)
+    if paramnames is not None:
+        make_paramnames_file(paramnames, Path(kwargs["base_dir"]) / (kwargs["file_root"] + ".paramnames"))
+    wl, wp = _wrap(loglikelihood, kwargs["prior"])
+    kwargs["grade_dims"] = [int(d) for d in list(kwargs["grade_dims"])]
+    if sum(kwargs["grade_dims"]) != nDims:
+        raise ValueError(f"grade_dims ({sum(kwargs['grade_dims'])}) must sum to nDims ({nDims})")
+    kwargs["nlives"] = {float(logL): int(nlive) for logL, nlive in kwargs["nlives"].items()}
+    _pypolychord.run(wl, wp, kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
+                     kwargs["nprior"], kwargs["nfail"], kwargs["do_clustering"], kwargs["feedback"],
+                     kwargs["precision_criterion"], kwargs["logzero"], kwargs["max_ndead"], kwargs["boost_posterior"],
+                     kwargs["posteriors"], kwargs["equals"], kwargs["cluster_posteriors"], kwargs["write_resume"],
+                     kwargs["write_paramnames"], kwargs["read_resume"], kwargs["write_stats"], kwargs["write_live"],
+                     kwargs["write_dead"], kwargs["write_prior"], kwargs["maximise"], kwargs["compression_factor"],
+                     kwargs["synchronous"], kwargs["base_dir"], kwargs["file_root"], kwargs["grade_frac"],
+                     kwargs["grade_dims"], kwargs["nlives"], kwargs["seed"])
+    try:
+        import anesthetic
+    except ImportError:
+        warnings.warn("anesthetic not installed. Cannot return NestedSamples object.")
+        return None
+    return anesthetic.read_chains(str(Path(kwargs["base_dir"]) / kwargs["file_root"]))

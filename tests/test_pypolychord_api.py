@@ -1,0 +1,119 @@
+"""The Python drop-in (polychordlite_amd.pypolychord) mirrors the reference's own test file
+tests/test_run_pypolychord.py: same call patterns (run_polychord / run), seed reproducibility,
+with/without derived parameters, grade_dims ValueError, unknown-kwarg TypeError."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from polychordlite_amd import pypolychord
+from polychordlite_amd.pypolychord import device_likelihoods as dl
+
+nDims, nlive = 4, 60
+
+
+def gaussian_likelihood(theta):
+    """reference tests/test_run_pypolychord.py:10-20 (4-D Gaussian, sigma 0.1, one derived parameter)"""
+    sigma = 0.1
+    n = theta.size
+    r2 = float(np.sum(theta ** 2))
+    logL = -np.log(2 * np.pi * sigma * sigma) * n / 2.0 - r2 / 2 / sigma / sigma
+    return float(logL), [r2]
+
+
+def uniform_prior(cube):
+    return -1.0 + 2.0 * cube
+
+
+# ---------------------------------------------------------------- CPU: surface / validation
+def test_settings_defaults_and_errors():
+    s = pypolychord.PolyChordSettings(nDims, 1)
+    assert (s.nlive, s.num_repeats, s.do_clustering, s.equals, s.base_dir, s.file_root) == (100, 20, True, True, "chains", "test")
+    assert abs(s.compression_factor - np.exp(-1)) < 1e-15 and s.cluster_dir.endswith("chains/clusters")
+    with pytest.raises(TypeError):
+        pypolychord.PolyChordSettings(nDims, 1, not_a_setting=3)
+    with pytest.raises(ValueError):
+        pypolychord.PolyChordSettings(nDims, 1, grade_dims=[1, 2])
+
+
+def test_run_rejects_bad_arguments(tmp_path):
+    with pytest.raises(ValueError):                      # reference test_grade_dims (tests/...:122-130)
+        pypolychord.run(gaussian_likelihood, nDims, nDerived=1, grade_dims=[1, 2], base_dir=str(tmp_path))
+    with pytest.raises(TypeError):                       # polychord.py:560-562
+        pypolychord.run(gaussian_likelihood, nDims, bogus_keyword=1)
+    with pytest.raises(TypeError):                       # _pypolychord.cpp:178-186
+        from polychordlite_amd.pypolychord import _pypolychord
+        _pypolychord.run(3, uniform_prior, lambda *a: None, *([0] * 34))
+    assert (tmp_path / "clusters").is_dir()              # polychord.py:566-568
+
+
+def test_builtin_functors_are_plain_callables():
+    g = dl.Gaussian(mu=0.5, sigma=0.1, nDerived=2)
+    logL, phi = g(np.full(20, 0.5))
+    assert abs(logL - 20 * (-np.log(0.1) - 0.5 * np.log(2 * np.pi))) < 1e-12 and phi[0] == 0.0
+    p = dl.UniformPrior(-1.0, 1.0)
+    assert np.allclose(p(np.array([0.0, 0.5, 1.0])), [-1.0, 0.0, 1.0])
+
+
+# ---------------------------------------------------------------- GPU: runs
+@pytest.mark.gpu
+def test_run_python_callbacks_seed_reproducibility(engine, tmp_path):
+    """reference test_seed: equal seeds -> identical runs, other seed -> different"""
+    outs = []
+    def dumper(live, dead, logweights, logZ, logZerr):
+        outs.append((dead.copy(), logweights.copy(), logZ, logZerr))
+    for seed in (1, 1, 2):
+        pypolychord.run(gaussian_likelihood, nDims, nDerived=1, prior=uniform_prior, dumper=dumper, nlive=nlive,
+                        num_repeats=8, seed=seed, do_clustering=False, read_resume=False, write_resume=False,
+                        base_dir=str(tmp_path), file_root=f"s{seed}", feedback=0)
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+    assert outs[0][2] != outs[2][2]
+    dead, logw, logZ, logZerr = outs[0]
+    assert dead.shape[1] == nDims + 1 + 2 and abs(np.logaddexp.reduce(logw)) < 1e-9
+    # analytic evidence: unit-normalised Gaussian inside U(-1,1)^4 -> log Z = -4 log 2
+    assert abs(logZ - (-4 * np.log(2))) < 4 * logZerr
+    txt = (tmp_path / "s1.stats").read_text().splitlines()
+    assert txt[8].startswith("log(Z)") and "+/-" in txt[8]           # output.py:57-99 parses by line number
+    rows = np.loadtxt(tmp_path / "s1_dead-birth.txt")
+    assert rows.shape == (dead.shape[0], nDims + 1 + 2) and np.allclose(rows[:, -2], dead[:, -1], rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_no_derived_gives_identical_samples(engine, tmp_path):
+    """reference test_no_derived (tests/...:93-119)"""
+    res = []
+    for nder, like in ((1, gaussian_likelihood), (0, lambda th: gaussian_likelihood(th)[0])):
+        got = []
+        pypolychord.run(like, nDims, nDerived=nder, prior=uniform_prior, dumper=lambda l, d, w, z, e: got.append((d.copy(), z)),
+                        nlive=nlive, num_repeats=8, seed=3, do_clustering=False, read_resume=False, write_resume=False,
+                        write_dead=False, write_live=False, write_stats=False, base_dir=str(tmp_path), feedback=0)
+        res.append(got[-1])
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][0][:, :nDims], res[1][0][:, :nDims])
+
+
+@pytest.mark.gpu
+def test_run_polychord_legacy_and_device_functor(engine, tmp_path):
+    """legacy interface + a likelihood fused on the device; a host callback computing the same
+    Gaussian must reproduce the device run (same Philox streams, same decisions)"""
+    D = 6
+    s = pypolychord.PolyChordSettings(D, 0, nlive=80, num_repeats=12, seed=5, do_clustering=False, read_resume=False,
+                                      write_resume=False, base_dir=str(tmp_path), file_root="dev", feedback=0)
+    out_dev = pypolychord.run_polychord(dl.Gaussian(0.5, 0.1), D, 0, s, dl.UniformPrior(0.0, 1.0))
+    s.file_root = "cb"
+    lib = engine.load(); lib.polychord_hip_set_option(b"batch", 40.0)
+    def host_gauss(theta):
+        return float(-D * (np.log(0.1) + 0.5 * np.log(2 * np.pi)) - 0.5 * np.sum(((theta - 0.5) / 0.1) ** 2))
+    out_cb = pypolychord.run_polychord(host_gauss, D, 0, s, lambda c: c.copy())
+    lib.polychord_hip_set_option(b"batch", 0.0)
+    assert out_dev.ndead == out_cb.ndead and out_dev.nlike == out_cb.nlike
+    assert abs(out_dev.logZ - out_cb.logZ) < 1e-9
+    assert abs(out_dev.logZ) < 4 * out_dev.logZerr
+
+
+@pytest.mark.gpu
+def test_python_exception_propagates(engine, tmp_path):
+    def bad(theta):
+        raise RuntimeError("boom")
+    with pytest.raises(RuntimeError):
+        pypolychord.run(bad, 3, nlive=20, num_repeats=3, base_dir=str(tmp_path), feedback=0, read_resume=False)
