@@ -14,7 +14,8 @@ Contract (see DESIGN.md "Measurement"):
     config) over its HIP-event time, against 8 TB/s.  This path is latency bound; the fraction says so.
   * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by
     oracle/Makefile) when the prebuilt binary is present, else the C restatement (oracle/liboracle.so),
-    on one host core, on a bounded sample (nlive = 500 instead of 2000: same evals/iteration).
+    on one host core (the reference is single threaded; its MPI farm does not speed this likelihood up,
+    BASELINE.md), on one full run of the same workload (about 10-25 s).
 """
 import argparse
 import ctypes as C
@@ -36,11 +37,11 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 def cpu_baseline(nDims, nDer, nr):
     """reference (preferred) or restatement on ONE host core, bounded sample"""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    sample = "20-D Gaussian, nlive=500 (1/4 of the workload's live points), num_repeats=40, one full run, seed 7"
+    sample = "the workload itself: 20-D Gaussian, nlive=2000, num_repeats=40, one full run, seed 7"
     if os.path.exists(ref):
         tmp = "/tmp/pc_ref_bench"
         os.makedirs(tmp, exist_ok=True)
-        cmd = f"ulimit -s unlimited; {ref} gaussian {nDims} {nDer} 500 {nr} 7 0 {tmp} ref 0"
+        cmd = f"ulimit -s unlimited; {ref} gaussian {nDims} {nDer} 2000 {nr} 7 0 {tmp} ref 0"
         out = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, cwd=tmp)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if line:
@@ -49,7 +50,7 @@ def cpu_baseline(nDims, nDer, nr):
                     "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off",
                     "logZ": j["logZ"], "logZerr": j["logZerr"], "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"]}
     from tests import oracle_api as orc
-    s = orc.settings(nDims, nDer, nlive=500, num_repeats=nr, seed=7, batch=1)
+    s = orc.settings(nDims, nDer, nlive=2000, num_repeats=nr, seed=7, batch=1)
     L, P, keep = orc.make_problem("gaussian", nDims)
     t0 = time.time(); o = orc.run(s, L, P); dt = time.time() - t0
     return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port",

@@ -614,11 +614,11 @@ __device__ __forceinline__ const double *cov_row(const PcState &S, int r, int nl
     return S.phantom + (size_t)j * S.nT;
 }
 
-__global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, int nph, double *psum, int *pcnt)
+__global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, int nph, double *psum, int *pcnt, int CR)
 {
     // grid (nchunk, nc); thread d < D sums coordinate d over the chunk's rows of cluster c, in row order
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
-    const int r0 = chunk * PC_COV_ROWS, r1 = min(nrows, r0 + PC_COV_ROWS);
+    const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
     __shared__ int rc[PC_COV_ROWS];
     for (int r = r0 + threadIdx.x; r < r1; r += 256) { int cc; cov_row(S, r, S.Ncap, nc, cc); rc[r - r0] = cc; }
     __syncthreads();
@@ -649,14 +649,14 @@ __global__ __launch_bounds__(256) void k_cov_mean_final(PcState S, int nchunk, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, const double *mean, double *pcov)
+__global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, const double *mean, double *pcov, int CR)
 {
     // grid (nchunk, nc); LDS tile of centred rows, thread (a,b) accumulates over rows in order
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
-    const int r0 = chunk * PC_COV_ROWS, r1 = min(nrows, r0 + PC_COV_ROWS);
+    const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
     double *tile = (double *)smem;               // [rows][D+1]
-    int *rc = (int *)(tile + (size_t)PC_COV_ROWS * (D + 1));
+    int *rc = (int *)(tile + (size_t)CR * (D + 1));
     __shared__ int nsel;
     if (threadIdx.x == 0) {
         int n = 0;
@@ -776,19 +776,26 @@ extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
     hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
 }
 
-extern "C" int pc_cov_nchunk(const PcState *S, int nph) { return (S->Ncap + nph + PC_COV_ROWS - 1) / PC_COV_ROWS; }
+static int cov_rows(const PcState *S)
+{   // rows per chunk: the centred tile [rows][D+1] must fit in LDS
+    int r = PC_COV_ROWS;
+    while (r > 8 && sizeof(double) * (size_t)r * (S->D + 1) + sizeof(int) * r > 120 * 1024) r >>= 1;
+    return r;
+}
+extern "C" int pc_cov_nchunk(const PcState *S, int nph) { const int r = cov_rows(S); return (S->Ncap + nph + r - 1) / r; }
 
 extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum, int *pcnt, double *mean, int *count,
                                  double *pcov, hipStream_t st)
 {
-    const int nrows = S->Ncap + nph, nchunk = (nrows + PC_COV_ROWS - 1) / PC_COV_ROWS, D = S->D;
-    hipLaunchKernelGGL(k_cov_mean_partial, dim3(nchunk, nc), dim3(256), 0, st, *S, nrows, nph, psum, pcnt);
+    const int CR = cov_rows(S);
+    const int nrows = S->Ncap + nph, nchunk = (nrows + CR - 1) / CR, D = S->D;
+    hipLaunchKernelGGL(k_cov_mean_partial, dim3(nchunk, nc), dim3(256), 0, st, *S, nrows, nph, psum, pcnt, CR);
     hipLaunchKernelGGL(k_cov_mean_final, dim3(nc), dim3(256), 0, st, *S, nchunk, psum, pcnt, mean, count);
-    const size_t sh = sizeof(double) * (size_t)PC_COV_ROWS * (D + 1) + sizeof(int) * PC_COV_ROWS;
+    const size_t sh = sizeof(double) * (size_t)CR * (D + 1) + sizeof(int) * CR;
     if (sh > 160 * 1024) return 1;
     static size_t donep = 0;
     if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
-    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, mean, pcov);
+    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, mean, pcov, CR);
     const size_t sh2 = sizeof(double) * 2 * (size_t)D * D;
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
