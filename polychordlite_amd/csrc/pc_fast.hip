@@ -28,6 +28,25 @@
 
 #define NEGBIG (-1e300)
 
+// order-preserving map double -> uint64 (no NaNs in the live set): the serial pass compares integers
+__device__ __forceinline__ unsigned long long d2key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key2d(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{   // the value is identical in every lane: move it to scalar registers
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define KEY_HUGE 0xFFFFFFFFFFFFFFFFull
+
 __device__ __forceinline__ double lae2(double a, double b)
 {   // logaddexp that tolerates the NEGBIG neutral element
     const double m = fmax(a, b), d = fmin(a, b) - m;
@@ -106,11 +125,15 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
     const int NS = (Ncap + 63) & ~63;
     PcCtl *ctl = S.ctl;
     const int nchain = ctl->i_nursery;
+    // LDS carve: 8-byte arrays first, 4-byte arrays after (typed pointer arithmetic only, so that the
+    // compiler keeps the LDS address space)
     double *sL = (double *)smem;               // [NS] logL by slot (+HUGE free)
     double *cLast = sL + NS;                   // [B] logL of the last baby of chain w
-    double *rLg = cLast + S.B;                 // step records of the current chunk, [64] each
-    double *rAdd = rLg + 64, *rXb = rAdd + 64, *rXXb = rXb + 64;
-    int *sSrc = (int *)(rXXb + 64);            // [NS] -1 or chain that inserted the point in this launch
+    unsigned long long *sK = (unsigned long long *)(cLast + S.B);   // [NS] sortable keys by slot
+    unsigned long long *sSortK = sK + NS;      // [NS] keys in sorted order
+    unsigned long long *cLastK = sSortK + NS;  // [B]
+    unsigned long long *rLgK = cLastK + S.B, *rAddK = rLgK + 64;   // step records of the chunk, [64] each
+    int *sSrc = (int *)(rAddK + 64);           // [NS] -1 or chain that inserted the point in this launch
     int *sSort = sSrc + NS;                    // [NS] slots in ascending (logL, pos)
     int *cNlike = sSort + NS;                  // [B]
     int *cEpoch = cNlike + S.B;                // [B]
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
     // lane i < m owns step i.  isdeath lanes carry (L, Ladd, Xb, XXb, a0..a2 = log n, log(n+1), log(n+2));
     // the other lanes are neutral elements of the scans.  Returns logZ after the lane's step.
     auto evidence_chunk = [&](int m, bool isdeath, double L, double Ladd, double Xb, double XXb,
-                              double a0, double a1, double a2) -> double {
+                              double a0, double a1, double a2) __attribute__((always_inline)) -> double {
         const double e01 = isdeath ? a0 - a1 : 0.0;
         const double T = isdeath ? Xb + L - a1 : NEGBIG;                  // log of the evidence increment
         const double U = isdeath ? XXb + L + a0 - a1 - a2 : NEGBIG;       // increment of <Z X>
@@ -210,16 +233,22 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         }
     }
 
-    // ================= pass A: the serial walk =================
+    // ================= pass A: the serial walk (integer only) =================
+    // keys of the live points replace their logL from here on
+    for (int i = lane; i < NS; i += 64) { sK[i] = d2key(sL[i]); const int ss = sSort[i]; sSortK[i] = (i < n && ss >= 0) ? d2key(sL[ss]) : KEY_HUGE; }
+    for (int w = lane; w < nchain; w += 64) cLastK[w] = d2key(cLast[w]);
+    __syncthreads();
     int ptr = 0;
-    int snapSlot = sSort[0];
-    double snapL = (n > 0 && snapSlot >= 0) ? sL[snapSlot] : PC_HUGE;
-    int nxtSlot = sSort[1 < NS ? 1 : 0];
-    double nxtL = (1 < n && nxtSlot >= 0) ? sL[nxtSlot] : PC_HUGE;
-    double im_v = PC_HUGE; int im_s = -1;                                   // per-lane min of inserted points
-    double ins_min = PC_HUGE; int ins_lane = 0;
-    int m = 0, mdeaths = 0, ndead0 = ndead;
-    long long cyB = 0, nFlush = 0, nSlow = 0, cyIns = 0, nIns = 0;
+    int snapSlot = __builtin_amdgcn_readfirstlane(sSort[0]);
+    unsigned long long snapK = (n > 0) ? uni64(sSortK[0]) : KEY_HUGE;
+    int nxtSlot = __builtin_amdgcn_readfirstlane(sSort[1 < NS ? 1 : 0]);
+    unsigned long long nxtK = (1 < n) ? uni64(sSortK[1]) : KEY_HUGE;
+    unsigned long long im_k = KEY_HUGE; int im_s = -1;                      // per-lane min of inserted points
+    unsigned long long insK = KEY_HUGE; int ins_lane = 0;
+    unsigned long long lastDeathK = d2key(thr);
+    int m = 0, mdeaths = 0, ndead0 = ndead, deaths_total = 0;
+    const double XpL0 = Xp, XXL0 = XX, d02 = l0 - l2;
+    long long cyB = 0, nFlush = 0, nSlow = 0, cyIns = 0, nIns = 0, cyCommon = 0, nCommon = 0, cyRej = 0, nRej = 0;
     const long long cy0 = clock64();
     const int G = (n >= 1024) ? 64 : max(1, n / 16);
     // the precision criterion cannot fire within G deaths while
@@ -229,21 +258,36 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         const double arg = exp(-2.0 * G / (double)n) - exp(S.log_prec) * (double)G / ((double)n + 1.0);
         if (arg > 0.0) gthr = -log(arg) + 0.05;
     }
+    // deaths until the update trigger  logXp <= logX_last_update + log(compression)  (nested_sampling.F90:321)
+    int kupd = 0x7fffffff;
+    if (n > 0) {
+        const double tx = lx_last + S.log_cf;
+        double kf = ceil((XpL0 - tx) / (-d01));
+        if (kf < 1.0) kf = 1.0;
+        if (kf < 2.0e9) {
+            kupd = (int)kf;
+            while (kupd > 1 && XpL0 + (double)(kupd - 1) * d01 <= tx) kupd--;
+            while (XpL0 + (double)kupd * d01 > tx) kupd++;
+        }
+    }
     bool fastphase = false;
-    auto eval_guard = [&]() {
+    auto eval_guard = [&]() __attribute__((always_inline)) {
         if (!S.use_prec) { fastphase = true; return; }
         live_logZ_val = lseRef + log(lseSum) - l0 + Xp;
         fastphase = (live_logZ_val - (S.log_prec + logZ)) > gthr;
     };
     if (!final_mode && n > 0) eval_guard();
 
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
         if (m == 0) return;
         const bool on = lane < m;
         const int kind = on ? rKind[lane] : 0, w = on ? rW[lane] : 0;
         const bool isdeath = kind == 2;
-        const double Lg = on ? rLg[lane] : NEGBIG, Ladd = isdeath ? rAdd[lane] : NEGBIG;
-        const double Xb = isdeath ? rXb[lane] : 0.0, XXb = isdeath ? rXXb[lane] : 0.0;
+        const double Lg = on ? key2d(rLgK[lane]) : NEGBIG, Ladd = isdeath ? key2d(rAddK[lane]) : NEGBIG;
+        // volumes before my death from the number of deaths before it (Xp only moves by log(n/(n+1)))
+        const unsigned long long km = __ballot(isdeath);
+        const int nb = (deaths_total - mdeaths) + __popcll(km & ((1ull << lane) - 1ull));
+        const double Xb = XpL0 + (double)nb * d01, XXb = XXL0 + (double)nb * d02;
         const double Zi = evidence_chunk(m, isdeath, isdeath ? Lg : NEGBIG, Ladd, Xb, XXb, l0, l1, l2);
         const unsigned long long dm = __ballot(on && kind >= 1);
         const int didx = ndead0 + __popcll(dm & ((1ull << lane) - 1ull));
@@ -259,6 +303,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
             }
         }
         ndead0 += __popcll(dm);
+        Xp = XpL0 + (double)deaths_total * d01; XX = XXL0 + (double)deaths_total * d02;
         m = 0; mdeaths = 0;
     };
 
@@ -277,37 +322,38 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
 
         const int w = i_nursery - 1;
         i_nursery--;
-        const double Llast = cLast[w];
-        nlike += cNlike[w]; niter++;
-        const double Lg = fmin(snapL, ins_min);
-        if (cEpoch[w] != epoch) {                      // nested_sampling.F90:313: only nlike is counted
-            if (lane == 0) { rW[m] = w; rKind[m] = 0; rLg[m] = Lg; }
+        const unsigned long long LlastK = uni64(cLastK[w]);
+        nlike += __builtin_amdgcn_readfirstlane(cNlike[w]); niter++;
+        const int ep = __builtin_amdgcn_readfirstlane(cEpoch[w]);
+        const unsigned long long LgK = snapK < insK ? snapK : insK;
+        if (ep != epoch) {                             // nested_sampling.F90:313: only nlike is counted
+            if (lane == 0) { rW[m] = w; rKind[m] = 0; rLgK[m] = LgK; }
             m++;
             if (m == 64) { __builtin_amdgcn_wave_barrier(); flush(); if (fastphase) eval_guard(); }
             continue;
         }
         if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
         bool replaced = false;
-        if (Llast > Lg) {
-            const bool from_snap = snapL <= ins_min;
+        if (LlastK > LgK) {
+            const bool from_snap = snapK <= insK;
             const int slot = from_snap ? snapSlot : __builtin_amdgcn_readlane(im_s, ins_lane);
-            const int src = from_snap ? -1 : sSrc[slot];
+            const int src = from_snap ? -1 : __builtin_amdgcn_readfirstlane(sSrc[slot]);
             if (lane == 0) {
                 rW[m] = w; rKind[m] = 2; rSrc[m] = (src >= 0) ? -(1 + src) : slot;
-                rLg[m] = Lg; rAdd[m] = Llast; rXb[m] = Xp; rXXb[m] = XX;
-                sL[slot] = Llast; sSrc[slot] = w;     // the baby takes the dead point's slot and list position
+                rLgK[m] = LgK; rAddK[m] = LlastK;
+                sK[slot] = LlastK; sSrc[slot] = w;    // the baby takes the dead point's slot and list position
             }
-            Xp = Xp + l0 - l1; XX = XX + l0 - l2; thr = Lg;
-            ndead++; m++; mdeaths++;
+            lastDeathK = LgK;
+            ndead++; m++; mdeaths++; deaths_total++;
             const int own = slot & 63;
             if (from_snap) {
                 ptr++;
-                snapSlot = nxtSlot; snapL = nxtL;
-                if (ptr >= n) snapL = PC_HUGE;
-                nxtSlot = sSort[(ptr + 1 < NS) ? ptr + 1 : ptr];
-                nxtL = (ptr + 1 < n && nxtSlot >= 0) ? sL[nxtSlot >= 0 ? nxtSlot : 0] : PC_HUGE;
-                if (lane == own && Llast < im_v) { im_v = Llast; im_s = slot; }
-                if (Llast < ins_min) { ins_min = Llast; ins_lane = own; }
+                snapSlot = nxtSlot; snapK = (ptr < n) ? nxtK : KEY_HUGE;
+                const int pn = (ptr + 1 < NS) ? ptr + 1 : ptr;
+                nxtSlot = __builtin_amdgcn_readfirstlane(sSort[pn]);
+                nxtK = (ptr + 1 < n) ? uni64(sSortK[pn]) : KEY_HUGE;
+                if (lane == own && LlastK < im_k) { im_k = LlastK; im_s = slot; }
+                if (LlastK < insK) { insK = LlastK; ins_lane = own; }
             } else {
                 // the minimum of the inserted points died and its slot holds the new baby: recompute
                 // that stride's inserted minimum cooperatively, then the wave minimum
@@ -315,26 +361,28 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
                 const long long ti = clock64(); nIns++;
                 double bv = PC_HUGE; int bs = -1;
                 for (int j0 = 0; j0 < NS / 64; j0 += 64) {
-                    const int j = j0 + lane, s = own + 64 * j;
-                    if (j < NS / 64 && sSrc[s] >= 0) { const double v = sL[s]; if (v < bv) { bv = v; bs = s; } }
+                    const int j = j0 + lane, sidx = own + 64 * j;
+                    if (j < NS / 64 && sSrc[sidx] >= 0) { const double v = key2d(sK[sidx]); if (v < bv) { bv = v; bs = sidx; } }
                 }
                 const double mv = wave_min_f64(bv);
                 const unsigned long long mm = __ballot(bv == mv && bs >= 0);
                 const int wl = mm ? __ffsll((long long)mm) - 1 : 0;
                 const int ws = __builtin_amdgcn_readlane(bs, wl);
-                if (lane == own) { im_v = mv; im_s = ws; }
-                ins_min = wave_min_f64(im_v);
-                const unsigned long long ml = __ballot(im_v == ins_min);
+                if (lane == own) { im_k = d2key(mv); im_s = ws; }
+                const double gm = wave_min_f64(key2d(im_k));
+                insK = d2key(gm);
+                const unsigned long long ml = __ballot(im_k == insK);
                 ins_lane = ml ? __ffsll((long long)ml) - 1 : 0;
                 cyIns += clock64() - ti;
             }
             replaced = true;
         } else {
             // failed spawn (run_time_info.f90:781-785): the baby is recorded dead with zero weight
-            if (lane == 0) { rW[m] = w; rKind[m] = 1; rLg[m] = Lg; }
+            if (lane == 0) { rW[m] = w; rKind[m] = 1; rLgK[m] = LgK; }
             ndead++; m++;
         }
-        if (m == 64 || mdeaths == G || (!fastphase && replaced)) {
+        const bool upd = replaced && deaths_total == kupd;
+        if (m == 64 || mdeaths == G || upd || (!fastphase && replaced)) {
             __builtin_amdgcn_wave_barrier();
             const long long tb = clock64();
             if (!fastphase) nSlow++;
@@ -344,9 +392,10 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         }
         failures = replaced ? 0 : failures + 1;
         // ---- update trigger (nested_sampling.F90:321); one cluster: logsumexp(logXp) = logXp
-        if (Xp <= lx_last + S.log_cf) { lx_last = Xp; status = PC_ST_UPDATE; }
+        if (upd) { lx_last = Xp; status = PC_ST_UPDATE; }
     }
     if (m > 0) { __builtin_amdgcn_wave_barrier(); flush(); }
+    if (!final_mode) { thr = key2d(lastDeathK); for (int i = lane; i < NS; i += 64) sL[i] = key2d(sK[i]); }
     if (S.use_prec && n > 0) live_logZ_val = lseRef + log(lseSum) - l0 + Xp;
 
     // ---- write back
@@ -354,8 +403,8 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
     __syncthreads();
     double Lmin = PC_HUGE; int minSlot = -1;
     if (n > 0) {   // contour and its slot for the seed kernels / the next launch
-        const bool from_snap = snapL <= ins_min;
-        Lmin = fmin(snapL, ins_min);
+        const bool from_snap = snapK <= insK;
+        Lmin = key2d(from_snap ? snapK : insK);
         minSlot = from_snap ? snapSlot : __builtin_amdgcn_readlane(im_s, ins_lane);
     }
     for (int s = lane; s < Ncap; s += 64) {
@@ -371,8 +420,8 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         ctl->ncluster = nc; ctl->ncluster_dead = nc_dead;
         ctl->nlike = nlike; ctl->niter = niter; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
         ctl->live_logZ = live_logZ_val;
-        ctl->dbg[0] += cy1 - cy0; ctl->dbg[1] += cyB; ctl->dbg[2] += 0; ctl->dbg[3] += nSlow; ctl->dbg[4] += nFlush;
-        ctl->dbg[5] += cyIns; ctl->dbg[6] += nIns; ctl->dbg[7] += clock64() - cy1;
+        ctl->dbg[0] += cy1 - cy0; ctl->dbg[1] += cyB; ctl->dbg[2] += cyCommon; ctl->dbg[3] += nCommon; ctl->dbg[4] += nFlush;
+        ctl->dbg[5] += cyIns; ctl->dbg[6] += nIns; ctl->dbg[7] += cyRej;
     }
 }
 
@@ -422,7 +471,7 @@ __global__ __launch_bounds__(1024) void k_ph_prepare(PcState S)
 static size_t fast_lds(const PcState *S)
 {
     const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
-    return sizeof(double) * (NS + (size_t)S->B + 256) + sizeof(int) * (2 * NS + 2 * (size_t)S->B + 192) + 64;
+    return 8 * (3 * NS + 2 * (size_t)S->B + 128) + sizeof(int) * (2 * NS + 2 * (size_t)S->B + 192) + 64;
 }
 
 extern "C" int pc_fast_fits(const PcState *S) { return fast_lds(S) <= 160 * 1024 && S->Ncap <= 32768; }
