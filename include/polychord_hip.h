@@ -123,10 +123,17 @@ typedef struct {
     double *post_mean, *post_var;  /* [nDims] weighted posterior moments of theta */
 } pchip_result;
 
+/* optional host hooks of a run */
+typedef struct {
+    polychord_dumper_fn dumper;   /* called at every update and at the end, like nested_sampling.F90:335,392 */
+} pchip_hooks;
+
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
 int  pchip_device_count(void);
 /* full run with a device likelihood + uniform prior; returns 0 on success */
 int  pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, pchip_result *out);
+int  pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
+                     const pchip_hooks *hooks, pchip_result *out);
 void pchip_result_free(pchip_result *r);
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */
 int  pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,

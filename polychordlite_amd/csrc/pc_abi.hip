@@ -144,6 +144,7 @@ double polychord_hip_corr_gaussian(double *th, int D, double *, int)
     }
     return -((double)D * LOG_TWO_PI + G.cg_logdet) / 2.0 - q / 2.0;
 }
+extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
 void polychord_hip_set_gaussian(double mu, double sigma) { G.g_mu = mu; G.g_sigma = sigma; }
 void polychord_hip_set_corr_gaussian(int D, const double *invcov, const double *mean, double logdet)
 {
@@ -203,7 +204,7 @@ void polychord_c_interface(
         if (G.up_D == nDims) { P.lo = G.up_lo.data(); P.hi = G.up_hi.data(); }
     } else { P.kind = 0; P.fn = prior; }
     const std::string base = base_dir ? base_dir : "chains", root = file_root ? file_root : "test";
-    if (write_stats_f || write_dead || write_live) {
+    if (write_stats_f || write_dead || write_live || posteriors || equals) {
         struct stat sb;
         if (stat(base.c_str(), &sb) != 0) halt_program(("PolyChord Error: " + base + " does not exist").c_str()); // read_write.F90:28-38
     }
@@ -212,10 +213,36 @@ void polychord_c_interface(
         L.kind = PCHIP_LIKE_CALLBACK; L.fn = loglikelihood;
     }
     pchip_result r;
-    const int rc = pchip_run(&s, &L, &P, &r);
+    pchip_hooks hooks{dumper};
+    const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);
     if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
     if (rc != 0) halt_program("polychord_hip: engine failure");
-    if (write_stats_f) write_stats(base + "/" + root + ".stats", r, 0, 0);
+    // weighted / equally weighted posteriors from the dead points (update_posteriors,
+    // run_time_info.f90:955-1066; write_posterior_file, read_write.F90:479-617).  A dead point is an
+    // equal-weight sample with probability weight/max weight; the uniform is keyed by its index so
+    // the thinning is reproducible.  Phantom-derived rows need boost_posterior > 0 (not built yet).
+    int nposterior = 0, nequals = 0;
+    if (posteriors || equals) {
+        if (boost_posterior != 0.0 && feedback >= 1)
+            std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");
+        const int nT = r.nTotal, np = nDims + nDerived;
+        double mx = -1.7e308;
+        for (long i = 0; i < r.ndead; ++i) if (r.logweights[i] > logzero) mx = std::max(mx, r.logweights[i] + r.dead[(size_t)i * nT + nT - 1]);
+        FILE *fp = posteriors ? std::fopen((base + "/" + root + ".txt").c_str(), "w") : nullptr;
+        FILE *fe = equals ? std::fopen((base + "/" + root + "_equal_weights.txt").c_str(), "w") : nullptr;
+        for (long i = 0; i < r.ndead; ++i) {
+            if (!(r.logweights[i] > logzero)) continue;
+            const double *row = r.dead + (size_t)i * nT;
+            const double wgt = std::exp(r.logweights[i] + row[nT - 1] - mx);
+            std::string tail = fmt_e24(-2 * row[nT - 1]);
+            for (int k = 0; k < np; ++k) tail += fmt_e24(row[nDims + k]);
+            if (fp && wgt > 0.0) { std::fprintf(fp, "%s%s\n", fmt_e24(wgt).c_str(), tail.c_str()); nposterior++; }
+            if (fe && polychord_hip_keyed_uniform((unsigned)s.seed, 6u, 0u, 0u, (unsigned)i) < wgt) { std::fprintf(fe, "%s%s\n", fmt_e24(1.0).c_str(), tail.c_str()); nequals++; }
+        }
+        if (fp) std::fclose(fp);
+        if (fe) std::fclose(fe);
+    }
+    if (write_stats_f) write_stats(base + "/" + root + ".stats", r, nposterior, nequals);
     if (write_dead) {
         write_rows(base + "/" + root + "_dead.txt", r, nDims, nDerived, false, false);
         write_rows(base + "/" + root + "_dead-birth.txt", r, nDims, nDerived, true, false);
@@ -223,23 +250,6 @@ void polychord_c_interface(
     if (write_live) {
         write_rows(base + "/" + root + "_phys_live.txt", r, nDims, nDerived, false, true);
         write_rows(base + "/" + root + "_phys_live-birth.txt", r, nDims, nDerived, true, true);
-    }
-    if (dumper) {   // nested_sampling.F90:546-590: columns [theta, phi, birth, logL]; weights normalised
-        const int npars = nDims + nDerived + 2, nT = r.nTotal;
-        std::vector<double> dead((size_t)r.ndead * npars), lw(r.ndead);
-        double m = -1.7e308;
-        for (long i = 0; i < r.ndead; ++i) { lw[i] = r.logweights[i] + r.dead[(size_t)i * nT + nT - 1]; if (lw[i] > m) m = lw[i]; }
-        double sum = 0;
-        for (long i = 0; i < r.ndead; ++i) sum += std::exp(lw[i] - m);
-        const double lse = m + std::log(sum);
-        for (long i = 0; i < r.ndead; ++i) {
-            lw[i] -= lse;
-            std::memcpy(&dead[(size_t)i * npars], r.dead + (size_t)i * nT + nDims, sizeof(double) * (nDims + nDerived));
-            dead[(size_t)i * npars + nDims + nDerived] = r.dead[(size_t)i * nT + nT - 2];
-            dead[(size_t)i * npars + nDims + nDerived + 1] = r.dead[(size_t)i * nT + nT - 1];
-        }
-        double dummy = 0;
-        dumper((int)r.ndead, 0, npars, &dummy, dead.data(), lw.data(), r.logZ, std::sqrt(std::fabs(r.varlogZ)));
     }
     if (feedback >= 1) {
         std::printf("polychord_hip: log(Z) = %.6f +/- %.6f  ndead = %ld  nlike = %ld  (%.3f s, batch %d)\n",

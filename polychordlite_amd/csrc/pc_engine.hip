@@ -14,6 +14,7 @@
 #include <vector>
 #include <string>
 #include <chrono>
+#include <algorithm>
 
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
@@ -104,6 +105,9 @@ struct Engine {
     int *d_decks = nullptr, *d_nneed = nullptr, *d_need = nullptr;
     std::vector<double> h_prop, h_evL, h_evT, h_evP; std::vector<int> h_need;
     long long cb_evals = 0; long cb_ticks = 0;
+    // host mirror of the dead points for the dumper hook (nested_sampling.F90:546-590)
+    polychord_dumper_fn dumper = nullptr;
+    std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<double> h_lo, h_hi;
     PcState S{};
     hipStream_t st = nullptr;
@@ -281,10 +285,54 @@ struct Engine {
         }
     }
 
+    // dump (nested_sampling.F90:546-590): live and dead points as [theta, phi, birth, logL] rows,
+    // posterior log-weights normalised to logsumexp 0
+    void call_dumper()
+    {
+        if (!dumper) return;
+        const int nT = S.nT, D = S.D, nDer = S.nDer, npars = D + nDer + 2, nd = h_ctl->ndead;
+        HIPCHK(hipStreamSynchronize(st));
+        if (nd > hm_ndead) {
+            std::vector<double> rows((size_t)(nd - hm_ndead) * nT), lw(nd - hm_ndead);
+            HIPCHK(hipMemcpy(rows.data(), S.dead + (size_t)hm_ndead * nT, sizeof(double) * rows.size(), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(lw.data(), S.dead_logw + hm_ndead, sizeof(double) * lw.size(), hipMemcpyDeviceToHost));
+            hm_dead.resize((size_t)nd * npars); hm_logw.resize(nd);
+            for (int i = hm_ndead; i < nd; ++i) {
+                const double *r = rows.data() + (size_t)(i - hm_ndead) * nT;
+                double *o = hm_dead.data() + (size_t)i * npars;
+                std::memcpy(o, r + S.p0, sizeof(double) * (D + nDer)); o[D + nDer] = r[S.b0]; o[D + nDer + 1] = r[S.l0];
+                hm_logw[i] = lw[i - hm_ndead] + r[S.l0];
+            }
+            hm_ndead = nd;
+        }
+        std::vector<double> lwn(hm_logw.begin(), hm_logw.begin() + nd);
+        double m = -PC_HUGE;
+        for (double v : lwn) m = std::max(m, v);
+        double sum = 0.0;
+        for (double v : lwn) sum += std::exp(v - m);
+        const double lse = m + std::log(sum);
+        for (double &v : lwn) v -= lse;
+        // live points ordered by cluster, then list position
+        auto lc = dl(S.live_cluster, S.Ncap); auto lp = dl(S.live_pos, S.Ncap); auto lr = dl(S.live, (size_t)S.Ncap * nT);
+        std::vector<std::pair<long long, int>> ord;
+        for (int s = 0; s < S.Ncap; ++s) if (lc[s] >= 0) ord.push_back({(long long)lc[s] * S.Ncap + lp[s], s});
+        std::sort(ord.begin(), ord.end());
+        std::vector<double> live(std::max<size_t>(1, ord.size()) * npars);
+        for (size_t k = 0; k < ord.size(); ++k) {
+            const double *r = lr.data() + (size_t)ord[k].second * nT;
+            double *o = live.data() + k * npars;
+            std::memcpy(o, r + S.p0, sizeof(double) * (D + nDer)); o[D + nDer] = r[S.b0]; o[D + nDer + 1] = r[S.l0];
+        }
+        const double lz = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2), var = h_ctl->logZ2 - 2 * h_ctl->logZ;
+        double dummy = 0.0;
+        dumper(nd, (int)ord.size(), npars, live.data(), nd > 0 ? hm_dead.data() : &dummy, nd > 0 ? lwn.data() : &dummy, lz, std::sqrt(std::fabs(var)));
+    }
+
     // clean_phantoms + calculate_covmats (nested_sampling.F90:326-368 minus file output / clustering)
     void do_update()
     {
         tm.updates++;
+        call_dumper();
         const int nph = h_ctl->nphantom, nc = h_ctl->ncluster;
         hipEvent_t e0 = kt.begin();
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
@@ -621,6 +669,7 @@ struct Engine {
         const int nc_end = h_ctl->ncluster;
         if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
+        call_dumper();
         auto t3 = clk::now();
         tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
         tm.t_loop = std::chrono::duration<double>(t2 - t1).count();
@@ -699,6 +748,11 @@ extern "C" {
 
 void polychord_hip_request_stop(void) { g_stop_requested = 1; }
 
+double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx)
+{   // the engine's counter RNG on the host (same numbers as pc_dev.h pc_uniform)
+    return h_uniform(seed, 0x504F4C59u, dom, shi, slo, idx);
+}
+
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived)
 {   // defaults of the reference's C++ Settings (src/polychord/c_interface.cpp:6-39)
     std::memset(s, 0, sizeof(*s));
@@ -716,6 +770,11 @@ int pchip_device_count(void)
 
 int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, pchip_result *out)
 {
+    return pchip_run_hooks(s, like, prior, nullptr, out);
+}
+
+int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, const pchip_hooks *hooks, pchip_result *out)
+{
     if (s->num_repeats < 1) { std::fprintf(stderr, "polychord_hip: You need to set num_repeats. Suggestion: 5*nDims\n"); return 1; } // settings.f90:216
     if (s->num_repeats > 64 * PC_MASK_WORDS) { std::fprintf(stderr, "polychord_hip: num_repeats > %d unsupported\n", 64 * PC_MASK_WORDS); return 1; }
     if (like->kind == PC_LIKE_CALLBACK && !like->fn) { std::fprintf(stderr, "polychord_hip: callback likelihood without a function pointer\n"); return 1; }
@@ -723,6 +782,7 @@ int pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior
     auto t0 = clk::now();
     g_stop_requested = 0;
     Engine E;
+    if (hooks) E.dumper = hooks->dumper;
     E.setup(*s, *like, *prior);
     auto t1 = clk::now();
     std::memset(out, 0, sizeof(*out));

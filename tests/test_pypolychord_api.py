@@ -59,13 +59,20 @@ def test_builtin_functors_are_plain_callables():
 @pytest.mark.gpu
 def test_run_python_callbacks_seed_reproducibility(engine, tmp_path):
     """reference test_seed: equal seeds -> identical runs, other seed -> different"""
-    outs = []
-    def dumper(live, dead, logweights, logZ, logZerr):
-        outs.append((dead.copy(), logweights.copy(), logZ, logZerr))
+    outs, calls = [], []
     for seed in (1, 1, 2):
+        mine = []
+        def dumper(live, dead, logweights, logZ, logZerr):
+            mine.append((dead.copy(), logweights.copy(), logZ, logZerr, live.shape[0]))
         pypolychord.run(gaussian_likelihood, nDims, nDerived=1, prior=uniform_prior, dumper=dumper, nlive=nlive,
                         num_repeats=8, seed=seed, do_clustering=False, read_resume=False, write_resume=False,
                         base_dir=str(tmp_path), file_root=f"s{seed}", feedback=0)
+        outs.append(mine[-1][:4]); calls.append(mine)
+    # the dumper is called at every update and at the end (nested_sampling.F90:335,392)
+    assert len(calls[0]) >= 5
+    nds = [c[0].shape[0] for c in calls[0]]
+    assert nds == sorted(nds) and nds[0] < nds[-1]
+    assert all(c[4] == nlive for c in calls[0][:-1]) and calls[0][-1][4] == 0     # all live points die at the end
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
     assert outs[0][2] != outs[2][2]
     dead, logw, logZ, logZerr = outs[0]
@@ -76,6 +83,13 @@ def test_run_python_callbacks_seed_reproducibility(engine, tmp_path):
     assert txt[8].startswith("log(Z)") and "+/-" in txt[8]           # output.py:57-99 parses by line number
     rows = np.loadtxt(tmp_path / "s1_dead-birth.txt")
     assert rows.shape == (dead.shape[0], nDims + 1 + 2) and np.allclose(rows[:, -2], dead[:, -1], rtol=1e-13)
+    # posterior files (read_write.F90:479-617): weight, -2 logL, theta, phi
+    post = np.loadtxt(tmp_path / "s1.txt"); eq = np.loadtxt(tmp_path / "s1_equal_weights.txt")
+    assert post.shape[1] == 2 + nDims + 1 and eq.shape[1] == post.shape[1]
+    assert post[:, 0].max() == 1.0 and np.all(eq[:, 0] == 1.0) and 10 < eq.shape[0] < post.shape[0]
+    wmean = np.average(post[:, 2:2 + nDims], axis=0, weights=post[:, 0])
+    assert np.all(np.abs(wmean) < 0.05)                                   # posterior is N(0, 0.1^2)
+    assert np.all(np.abs(eq[:, 2:2 + nDims].mean(axis=0)) < 0.1)
 
 
 @pytest.mark.gpu
