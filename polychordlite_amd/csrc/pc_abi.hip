@@ -258,10 +258,4 @@ void polychord_c_interface(
     pchip_result_free(&r);
 }
 
-void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, void (*setup_loglikelihood)(void), char *inifile, int *comm)
-{
-    (void)loglikelihood; (void)setup_loglikelihood; (void)inifile; (void)comm;
-    halt_program("polychord_hip: polychord_c_interface_ini: the ini reader is not part of this build yet");
-}
-
 }  // extern "C"

@@ -131,3 +131,31 @@ def test_python_exception_propagates(engine, tmp_path):
         raise RuntimeError("boom")
     with pytest.raises(RuntimeError):
         pypolychord.run(bad, 3, nlive=20, num_repeats=3, base_dir=str(tmp_path), feedback=0, read_resume=False)
+
+
+@pytest.mark.gpu
+def test_ini_front_end_and_cli(engine, tmp_path):
+    """configs/*.ini in the reference's ini grammar through polychord_c_interface_ini (CLI driver)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "tools", "polychord_hip_cli")
+    out = subprocess.run([cli, os.path.join(root, "configs", "gaussian.ini"), "gaussian"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    stats = (tmp_path / "chains" / "gaussian.stats").read_text().splitlines()
+    logZ, err = [float(x) for x in stats[8].split("=")[1].split("+/-")]
+    assert abs(logZ) < 3.5 * err and 0.15 < err < 0.22                 # truth 0; reference sigma 0.186
+    rows = np.loadtxt(tmp_path / "chains" / "gaussian_dead-birth.txt")
+    assert rows.shape[1] == 20 + 2 + 2
+    # 2-D Rastrigin with clustering (ini/rastrigin.ini of the reference): truth -2 ln 10.24 = -4.6526
+    out = subprocess.run([cli, os.path.join(root, "configs", "rastrigin_2d.ini"), "rastrigin"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    stats = (tmp_path / "chains" / "rastrigin_2d.stats").read_text().splitlines()
+    logZ, err = [float(x) for x in stats[8].split("=")[1].split("+/-")]
+    assert abs(logZ + 4.6526) < 4 * err + 0.05
+    nclusters = sum(1 for l in stats if l.startswith("log(Z_"))
+    assert nclusters >= 10                                            # the reference finds ~40 modes
+    # a missing mandatory key is a fatal error with exit status 1 (abort.F90:19-29)
+    bad = tmp_path / "bad.ini"; bad.write_text("num_repeats = 4\nP : a | a | 1 | uniform | 1 | 0 1\n")
+    out = subprocess.run([cli, str(bad), "gaussian"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 1 and "nlive" in out.stderr
