@@ -37,32 +37,81 @@ struct ConsumeShared {
     int *cN, *cMinSlot; unsigned *cUid;
     double *jobres;                                     // [NT] results of the lane-parallel jobs
     vk_t *red;                                          // [16]
-    double *xbuf;                                       // [D] cube coordinates of the point being identified
+    double *xbuf;                                       // [IDG][D] cube coordinates of the babies being identified
+    double *sX;                                         // [xrows][D] cube coordinates: all live points (xrows == Ncap) or one tile
+    int xrows;
+    double *gd2; int *gkey; int *ids;                   // [IDG][IDP] partial minima; [nr] cluster of each baby
     int *misc;                                          // small scratch
 };
 
-// nearest live point over ALL clusters (identify_cluster, run_time_info.f90:913-949); ties keep the
-// first point in (cluster, list position) order like the reference's strict '<' scan.
+// identify_cluster (run_time_info.f90:913-949) for ALL babies of a chain at once: the cluster of the
+// nearest live point over all clusters; ties keep the first point in (cluster, list position) order
+// like the reference's strict '<' scan.  Babies are taken in groups of IDG; inside a group IDP = NT/IDG
+// threads share one baby, each scanning a stride of the live slots; the live coordinates are served
+// from the LDS cache H.sX when it fits (updated on every insertion), else from HBM.
+#define PC_IDG 32
 template <int NT>
-__device__ int block_identify(const PcState &S, const ConsumeShared &H, const double *pt_row, int nc)
+__device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int w, const double *blog, double Lg, int nc)
 {
-    if (nc == 1) return 0;
-    const int tid = threadIdx.x, D = S.D;
-    for (int d = tid; d < D; d += NT) H.xbuf[d] = pt_row[d];
-    __syncthreads();
-    vk_t best{PC_HUGE, 0x7fffffff};
-    for (int s = tid; s < S.Ncap; s += NT) {
-        const int c = H.sC[s];
-        if (c < 0) continue;
-        const int src = S.slot_src[s];
-        const double *q = (src >= 0) ? S.babies + ((size_t)src * S.nr + (S.nr - 1)) * S.nT : S.live + (size_t)s * S.nT;
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) { const double t = H.xbuf[d] - q[d]; d2 += t * t; }
-        best = vk_min(best, vk_t{d2, c * S.Ncap + H.sP[s]});
+    const int tid = threadIdx.x, D = S.D, nr = S.nr, nT = S.nT;
+    constexpr int IDG = (NT >= 1024) ? PC_IDG : 4, IDP = NT / IDG;
+    for (int i = tid; i < nr; i += NT) H.ids[i] = -1;
+    if (nc == 1) { __syncthreads(); for (int i = tid; i < nr; i += NT) H.ids[i] = 0; __syncthreads(); return; }
+    for (int g0 = 0; g0 < nr; g0 += IDG) {
+        __syncthreads();
+        for (int e = tid; e < IDG * D; e += NT) {
+            const int g = e / D, d = e % D, i = g0 + g;
+            H.xbuf[e] = (i < nr) ? S.babies[((size_t)w * nr + i) * nT + d] : 0.0;
+        }
+        __syncthreads();
+        const int g = tid / IDP, p = tid % IDP, i = g0 + g;
+        double bd = PC_HUGE; int bk = 0x7fffffff;
+        const bool mine = i < nr && blog[i] > Lg;
+        const double *x = H.xbuf + (size_t)g * D;
+        if (H.xrows >= S.Ncap) {                       // every live coordinate is resident in LDS
+            if (mine)
+                for (int s = p; s < S.Ncap; s += IDP) {
+                    const int c = H.sC[s];
+                    if (c < 0) continue;
+                    const double *q = H.sX + (size_t)s * D;
+                    double d2 = 0.0;
+                    for (int d = 0; d < D; ++d) { const double t = x[d] - q[d]; d2 += t * t; }
+                    const int key = c * S.Ncap + H.sP[s];
+                    if (d2 < bd || (d2 == bd && key < bk)) { bd = d2; bk = key; }
+                }
+        } else {                                       // stream the live coordinates through an LDS tile
+            for (int t0 = 0; t0 < S.Ncap; t0 += H.xrows) {
+                const int tn = min(H.xrows, S.Ncap - t0);
+                __syncthreads();
+                for (int e = tid; e < tn * D; e += NT) {
+                    const int s = t0 + e / D, d = e % D, src = S.slot_src[s];
+                    H.sX[e] = (src >= 0) ? S.babies[((size_t)src * nr + (nr - 1)) * nT + d] : S.live[(size_t)s * nT + d];
+                }
+                __syncthreads();
+                if (mine)
+                    for (int sl = p; sl < tn; sl += IDP) {
+                        const int s = t0 + sl, c = H.sC[s];
+                        if (c < 0) continue;
+                        const double *q = H.sX + (size_t)sl * D;
+                        double d2 = 0.0;
+                        for (int d = 0; d < D; ++d) { const double t = x[d] - q[d]; d2 += t * t; }
+                        const int key = c * S.Ncap + H.sP[s];
+                        if (d2 < bd || (d2 == bd && key < bk)) { bd = d2; bk = key; }
+                    }
+            }
+        }
+        H.gd2[tid] = bd; H.gkey[tid] = bk;
+        __syncthreads();
+        if (tid < IDG && g0 + tid < nr) {
+            double md = PC_HUGE; int mk = 0x7fffffff;
+            for (int q = 0; q < IDP; ++q) {
+                const double v = H.gd2[tid * IDP + q]; const int k = H.gkey[tid * IDP + q];
+                if (v < md || (v == md && k < mk)) { md = v; mk = k; }
+            }
+            H.ids[g0 + tid] = (mk == 0x7fffffff) ? -1 : mk / S.Ncap;
+        }
     }
-    best = block_argmin<NT>(best, H.red);
     __syncthreads();
-    return best.k / S.Ncap;
 }
 
 // dynamic nlive target (run_time_info.f90:766-771)
@@ -75,7 +124,7 @@ __device__ __forceinline__ int nlive_target(const PcState &S, double logL)
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
+__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int cache_x)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,18 +136,23 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         double **cd[] = { &H.cLogLp, &H.cLogXp, &H.cLogZp, &H.cLogZXp, &H.cLogZp2, &H.cLogZpXp, &H.cLseRef, &H.cLseSum, &H.cThr };
         for (int i = 0; i < 9; ++i) { *cd[i] = (double *)p; p += sizeof(double) * maxc; }
         H.jobres = (double *)p; p += sizeof(double) * NT;
-        H.xbuf = (double *)p; p += sizeof(double) * S.D;
+        H.xbuf = (double *)p; p += sizeof(double) * S.D * PC_IDG;
+        H.gd2 = (double *)p; p += sizeof(double) * NT;
+        H.sX = (double *)p; H.xrows = cache_x; p += sizeof(double) * (size_t)cache_x * S.D;
         H.red = (vk_t *)p; p += sizeof(vk_t) * 16;
         H.sC = (int *)p; p += sizeof(int) * Ncap;
         H.sP = (int *)p; p += sizeof(int) * Ncap;
         H.cN = (int *)p; p += sizeof(int) * maxc;
         H.cMinSlot = (int *)p; p += sizeof(int) * maxc;
         H.cUid = (unsigned *)p; p += sizeof(unsigned) * maxc;
-        H.misc = (int *)p;
+        H.misc = (int *)p; p += sizeof(int) * 8;
+        H.gkey = (int *)p; p += sizeof(int) * NT;
+        H.ids = (int *)p;
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
     for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
+    if (H.xrows >= Ncap) for (int e = tid; e < Ncap * S.D; e += NT) H.sX[e] = S.live[(size_t)(e / S.D) * nT + e % S.D];
     int nc = ctl->ncluster;
     for (int c = tid; c < maxc; c += NT) {
         H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
@@ -282,22 +336,37 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
     // ================================================================================
     // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
     // ================================================================================
+    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0;
     while (!final_mode && status == PC_ST_RUNNING) {
+        const long long q0 = clock64();
         // ---- more_samples_needed (nested_sampling.F90:514-543) + failures guard (:239)
         bool more = true;
         if (S.max_ndead == 0) more = false;
         else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
         else if (S.use_prec) {
-            // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally
-            double v = S.logzero;
-            for (int c = 0; c < nc; ++c)
-                if (H.cN[c] > 0) v = pc_logaddexp(v, H.cLseRef[c] + log(H.cLseSum[c]) - log((double)H.cN[c] + 0.0) + H.cLogXp[c]);
-            live_logZ_val = v;
-            if (v < S.log_prec + logZ) more = false;
+            // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally.
+            // One cluster per lane, log-sum-exp over the wave; the other waves pick the result up from LDS.
+            if (tid < 64) {
+                double mxv = -PC_HUGE, acc = 0.0;
+                for (int c0 = 0; c0 < nc; c0 += 64) {
+                    const int c = c0 + tid;
+                    const double term = (c < nc && H.cN[c] > 0) ? H.cLseRef[c] + log(H.cLseSum[c]) - log((double)H.cN[c] + 0.0) + H.cLogXp[c] : -PC_HUGE;
+                    const double m2 = fmax(mxv, wave_max(term));
+                    acc = acc * exp(mxv - m2) + wave_sum<4>(term > -PC_HUGE ? exp(term - m2) : 0.0);
+                    mxv = m2;
+                }
+                const double v = (acc > 0.0) ? mxv + log(acc) : S.logzero;
+                if (tid == 0) H.jobres[0] = pc_logaddexp(S.logzero, v);
+            }
+            __syncthreads();
+            live_logZ_val = H.jobres[0];
+            __syncthreads();
+            if (live_logZ_val < S.log_prec + logZ) more = false;
         }
         if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
         if (i_nursery == 0) break;                      // batch exhausted: host launches the next one
 
+        const long long q1 = clock64(); cyT += q1 - q0;
         const int w = i_nursery - 1;
         i_nursery--;
         nlike += S.ch_nlike[w];
@@ -327,15 +396,14 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                 for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
             }
         } else {
-            for (int i = 0; i < nr - 1; ++i) {
-                if (!(blog[i] > Lg)) continue;
-                const int id = block_identify<NT>(S, H, S.babies + ((size_t)w * nr + i) * nT, nc);
-                if (id == ca) {
+            block_identify_all<NT>(S, H, w, blog, Lg, nc);
+            for (int i = 0; i < nr - 1; ++i)
+                if (blog[i] > Lg && H.ids[i] == ca) {
                     if (tid == 0) S.plan[w].ph_mask[(i >> 6)] |= (1ull << (i & 63));
                     nph_add++;
                 }
-            }
         }
+        const long long q2 = clock64(); cyI += q2 - q1;
         if (nph + nph_add > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
         if (tid == 0) S.plan[w].ph_cuid = H.cUid[ca];
         nph += nph_add;
@@ -343,7 +411,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         const double Llast = blog[nr - 1];
         bool replaced = false;
         if (Llast > Lg) {
-            const int id = block_identify<NT>(S, H, S.babies + ((size_t)w * nr + nr - 1) * nT, nc);
+            const int id = (nc == 1) ? 0 : H.ids[nr - 1];
             if (id == ca) {
                 const int nl = nlive_target(S, Lg);
                 int tot = 0;
@@ -372,6 +440,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
                         else H.cLseSum[ca] += exp(Llast - H.cLseRef[ca]);
                         S.slot_src[free_slot] = w;
                     }
+                    if (H.xrows >= Ncap) for (int d = tid; d < S.D; d += NT) H.sX[(size_t)free_slot * S.D + d] = S.babies[((size_t)w * nr + nr - 1) * nT + d];
                     __syncthreads();
                     // engine rule (oracle keyed mode): a point that replaces a death of its own cluster
                     // takes the dead point's list position instead of being appended
@@ -395,6 +464,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
             ndead++;
         }
         failures = replaced ? 0 : failures + 1;
+        const long long q3 = clock64(); cyK += q3 - q2;
 
         // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
         double mX = H.cLogXp[0];
@@ -405,6 +475,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         const bool update = lx <= lx_last + S.log_cf;
         if (update) lx_last = lx;
         if (drop_empty_cluster()) epoch++;
+        cyE += clock64() - q3;
         if (nc == 0) { status = PC_ST_DONE; break; }
         if (update) { status = PC_ST_UPDATE; break; }
     }
@@ -424,6 +495,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode)
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
+        ctl->dbg[0] += cyT; ctl->dbg[1] += cyI; ctl->dbg[2] += cyK; ctl->dbg[3] += cyE;
     }
 }
 
@@ -722,26 +794,31 @@ __global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, c
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-static size_t consume_lds(const PcState *S, int NT)
+static size_t consume_lds(const PcState *S, int NT, int xrows)
 {
-    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + NT + S->D) + sizeof(vk_t) * 16 +
-           sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8) + 64;
+    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + 2 * NT + (size_t)S->D * PC_IDG + (size_t)xrows * S->D) +
+           sizeof(vk_t) * 16 + sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8 + NT + S->nr) + 64;
 }
 
 extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hipStream_t st)
 {
     if (wide) {
-        const size_t sh = consume_lds(S, 1024);
+        // all live coordinates in LDS when they fit, else the largest tile that does
+        int cache_x = S->Ncap;
+        while (cache_x > 32 && consume_lds(S, 1024, cache_x) > 158 * 1024) cache_x = (cache_x + 1) / 2;
+        const size_t sh = consume_lds(S, 1024, cache_x);
         if (sh > 160 * 1024) return 1;
         static size_t done1024 = 0;
         if (sh > done1024) { hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1024 = sh; }
-        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode);
+        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x);
     } else {
-        const size_t sh = consume_lds(S, 64);
+        int xr = S->Ncap;
+        while (xr > 32 && consume_lds(S, 64, xr) > 158 * 1024) xr = (xr + 1) / 2;
+        const size_t sh = consume_lds(S, 64, xr);
         if (sh > 160 * 1024) return 1;
         static size_t done64 = 0;
         if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
-        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode);
+        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr);
     }
     return 0;
 }
