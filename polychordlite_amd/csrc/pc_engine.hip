@@ -23,6 +23,9 @@ int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
 int pc_fast_fits(const PcState *);
+int pc_par_fits(const PcState *);
+int pc_launch_sort_live(const PcState *, hipStream_t);
+int pc_launch_consume_par(const PcState *, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
@@ -221,7 +224,7 @@ struct Engine {
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
-        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64);
+        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
         if (callback_mode) {
@@ -631,7 +634,8 @@ struct Engine {
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
-        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && !cfg.force_general && pc_fast_fits(&S);
+        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && cfg.force_general != 1 && pc_fast_fits(&S);
+        const bool par_ok = fast_ok && cfg.force_general == 0 && pc_par_fits(&S);
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
@@ -649,7 +653,8 @@ struct Engine {
             hipEvent_t e2 = kt.begin();
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
-            if (use_fast) { rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
+            if (use_fast && par_ok) { rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_par(&S, st); pc_launch_ph_prepare(&S, st); }
+            else if (use_fast) { rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
@@ -736,7 +741,7 @@ struct Engine {
         for (auto p : ii) dfree(*p);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2 };
         for (auto p : uu) dfree(*p);
-        dfree(S.ph_uid); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
+        dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
         kt.destroy();
         if (h_ctl) hipHostFree(h_ctl); h_ctl = nullptr;
         if (st) hipStreamDestroy(st); st = nullptr;

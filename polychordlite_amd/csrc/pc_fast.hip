@@ -26,32 +26,7 @@
 // Exact ties in logL are broken by (sorted snapshot first, then lane order) instead of list position.
 #include "pc_state.h"
 
-#define NEGBIG (-1e300)
-
-// order-preserving map double -> uint64 (no NaNs in the live set): the serial pass compares integers
-__device__ __forceinline__ unsigned long long d2key(double x)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key2d(unsigned long long k)
-{
-    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
-{   // the value is identical in every lane: move it to scalar registers
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-#define KEY_HUGE 0xFFFFFFFFFFFFFFFFull
-
-__device__ __forceinline__ double lae2(double a, double b)
-{   // logaddexp that tolerates the NEGBIG neutral element
-    const double m = fmax(a, b), d = fmin(a, b) - m;
-    return m + log(1.0 + exp(d));
-}
+#include "pc_keys.h"
 
 __device__ __forceinline__ double wave_min_f64(double v)
 {
@@ -111,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2)
             __syncthreads();
         }
     const int NS = (S.Ncap + 63) & ~63;
-    for (int i = tid; i < NS; i += 1024) S.sort_slot[i] = (i < npow2) ? ks[i] : -1;
+    for (int i = tid; i < NS; i += 1024) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -476,17 +451,25 @@ static size_t fast_lds(const PcState *S)
 
 extern "C" int pc_fast_fits(const PcState *S) { return fast_lds(S) <= 160 * 1024 && S->Ncap <= 32768; }
 
-extern "C" int pc_launch_consume_fast(const PcState *S, int final_mode, hipStream_t st)
+extern "C" int pc_launch_sort_live(const PcState *S, hipStream_t st)
 {
     int npow2 = 64;
     while (npow2 < S->Ncap) npow2 <<= 1;
     const size_t shs = (size_t)npow2 * 16;
-    const size_t sh = fast_lds(S);
-    if (sh > 160 * 1024 || shs > 160 * 1024) return 1;
-    static size_t d1 = 0, d2 = 0;
+    if (shs > 160 * 1024) return 1;
+    static size_t d1 = 0;
     if (shs > d1) { (void)hipFuncSetAttribute((const void *)k_sort_live, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs); d1 = shs; }
-    if (sh > d2) { (void)hipFuncSetAttribute((const void *)k_consume_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d2 = sh; }
     hipLaunchKernelGGL(k_sort_live, dim3(1), dim3(1024), shs, st, *S, npow2);
+    return 0;
+}
+
+extern "C" int pc_launch_consume_fast(const PcState *S, int final_mode, hipStream_t st)
+{
+    const size_t sh = fast_lds(S);
+    if (sh > 160 * 1024) return 1;
+    static size_t d2 = 0;
+    if (sh > d2) { (void)hipFuncSetAttribute((const void *)k_consume_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d2 = sh; }
+    if (pc_launch_sort_live(S, st)) return 1;
     hipLaunchKernelGGL(k_consume_fast, dim3(1), dim3(64), sh, st, *S, final_mode);
     return 0;
 }

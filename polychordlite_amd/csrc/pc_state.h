@@ -94,6 +94,7 @@ struct PcState {
     // ---- plan written by the consume kernel for the apply kernels
     PcPlan *plan;                // [B]
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
+    unsigned long long *sort_key; // [NS] sortable logL keys (pc_keys.h) in the same order
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
     int ablate;                  // dev timing hook (bit mask), 0 in production
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
