@@ -686,63 +686,101 @@ __device__ __forceinline__ const double *cov_row(const PcState &S, int r, int nl
     return S.phantom + (size_t)j * S.nT;
 }
 
+__device__ __forceinline__ const double *cov_ptr(const PcState &S, int r)
+{
+    return (r < S.Ncap) ? S.live + (size_t)r * S.nT : S.phantom + (size_t)(r - S.Ncap) * S.nT;
+}
+
+// thread layout of the reductions below: DPc = coordinates handled side by side, G = 256 / DPc row groups
+__device__ __forceinline__ int cov_dpc(int D) { int p = 32; while (p < D && p < 256) p <<= 1; return p; }
+
 __global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, int nph, double *psum, int *pcnt, int CR)
 {
-    // grid (nchunk, nc); thread d < D sums coordinate d over the chunk's rows of cluster c, in row order
-    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
+    // grid (nchunk, nc); thread = (row group g, coordinate d): group g sums rows r0+g, r0+g+G, ... of
+    // cluster c in that order, the groups are added in order: a fixed summation tree
+    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x;
     const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
+    const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
     __shared__ int rc[PC_COV_ROWS];
-    for (int r = r0 + threadIdx.x; r < r1; r += 256) { int cc; cov_row(S, r, S.Ncap, nc, cc); rc[r - r0] = cc; }
-    __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
+    __shared__ double red[256];
+    int mine = 0;
+    for (int r = r0 + tid; r < r1; r += 256) { int cc; cov_row(S, r, S.Ncap, nc, cc); rc[r - r0] = cc; mine += (cc == c); }
+    const int cnt = __syncthreads_count(mine);
+    for (int d = tid % DPc; d < D; d += DPc) {
         double s = 0.0;
-        for (int r = r0; r < r1; ++r)
-            if (rc[r - r0] == c) { int cc; s += cov_row(S, r, S.Ncap, nc, cc)[d]; }
-        psum[((size_t)chunk * nc + c) * D + d] = s;
+        for (int r = r0 + g; r < r1; r += G)
+            if (rc[r - r0] == c) s += cov_ptr(S, r)[d];
+        if (G > 1) red[tid] = s; else psum[((size_t)chunk * nc + c) * D + d] = s;
     }
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int r = r0; r < r1; ++r) n += (rc[r - r0] == c);
-        pcnt[(size_t)chunk * nc + c] = n;
+    if (G > 1) {
+        __syncthreads();
+        if (tid < D) {
+            double s = 0.0;
+            for (int gg = 0; gg < G; ++gg) s += red[gg * DPc + tid];
+            psum[((size_t)chunk * nc + c) * D + tid] = s;
+        }
     }
+    if (tid == 0) pcnt[(size_t)chunk * nc + c] = cnt;
 }
 
-__global__ __launch_bounds__(256) void k_cov_mean_final(PcState S, int nchunk, const double *psum, const int *pcnt,
-                                                       double *mean /* [nc][D] */, int *count /* [nc] */)
+__global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int nchunk, const double *psum, const int *pcnt,
+                                                    double *mean /* [nc][D] */, int *count /* [nc] */, double *pcov, int CR)
 {
-    const int c = blockIdx.x, nc = gridDim.x, D = S.D;
-    for (int d = threadIdx.x; d < D; d += 256) {
-        double s = 0.0;
-        for (int k = 0; k < nchunk; ++k) s += psum[((size_t)k * nc + c) * D + d];
-        int n = 0;
-        for (int k = 0; k < nchunk; ++k) n += pcnt[(size_t)k * nc + c];
-        mean[(size_t)c * D + d] = s / (double)n;
-        if (d == 0) count[c] = n;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, const double *mean, double *pcov, int CR)
-{
-    // grid (nchunk, nc); LDS tile of centred rows, thread (a,b) accumulates over rows in order
+    // grid (nchunk, nc).  Every workgroup first reduces the chunk sums to the cluster mean (fixed order,
+    // identical in every workgroup), then accumulates the centred outer products of its own rows.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D;
+    const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
     double *tile = (double *)smem;               // [rows][D+1]
-    int *rc = (int *)(tile + (size_t)CR * (D + 1));
-    __shared__ int nsel;
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int r = r0; r < r1; ++r) { int cc; cov_row(S, r, S.Ncap, nc, cc); if (cc == c) rc[n++] = r; }
-        nsel = n;
+    double *mu = tile + (size_t)CR * (D + 1);    // [D]
+    double *red = mu + D;                        // [256]
+    int *rc = (int *)(red + 256);                // [CR] member rows, in row order
+    __shared__ int wcnt[4];
+    __shared__ int nred[256];
+    const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
+    // ---- mean
+    {
+        int nn = 0;
+        for (int k = tid; k < nchunk; k += 256) nn += pcnt[(size_t)k * nc + c];
+        nred[tid] = nn;
+    }
+    for (int d = tid % DPc; d < D; d += DPc) {
+        double s = 0.0;
+        for (int k = g; k < nchunk; k += G) s += psum[((size_t)k * nc + c) * D + d];
+        if (G > 1) red[tid] = s; else mu[d] = s;
     }
     __syncthreads();
-    const int n = nsel;
-    for (int e = threadIdx.x; e < n * D; e += 256) {
-        const int i = e / D, d = e % D; int cc;
-        tile[(size_t)i * (D + 1) + d] = cov_row(S, rc[i], S.Ncap, nc, cc)[d] - mean[(size_t)c * D + d];
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) nred[tid] += nred[tid + off]; __syncthreads(); }
+    const int ntot = nred[0];
+    if (G > 1 && tid < D) {
+        double s = 0.0;
+        for (int gg = 0; gg < G; ++gg) s += red[gg * DPc + tid];
+        mu[tid] = s;
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < D * D; p += 256) {
+    for (int d = tid; d < D; d += 256) {
+        const double m = mu[d] / (double)ntot;
+        mu[d] = m;
+        if (chunk == 0) mean[(size_t)c * D + d] = m;
+    }
+    if (chunk == 0 && tid == 0) count[c] = ntot;
+    // ---- member rows of this chunk, in row order (CR <= 256: one row per thread)
+    bool member = false;
+    { const int r = r0 + tid; int cc = -1; if (tid < CR && r < r1) cov_row(S, r, S.Ncap, nc, cc); member = (tid < CR && r < r1 && cc == c); }
+    const unsigned long long bm = __ballot(member);
+    if (lane == 0) wcnt[wv] = __popcll(bm);
+    __syncthreads();
+    int base = 0;
+    for (int x = 0; x < wv; ++x) base += wcnt[x];
+    const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (member) rc[base + __popcll(bm & ((1ull << lane) - 1ull))] = r0 + tid;
+    __syncthreads();
+    for (int e = tid; e < n * D; e += 256) {
+        const int i = e / D, d = e % D;
+        tile[(size_t)i * (D + 1) + d] = cov_ptr(S, rc[i])[d] - mu[d];
+    }
+    __syncthreads();
+    for (int p = tid; p < D * D; p += 256) {
         const int a = p / D, b = p % D;
         double s = 0.0;
         for (int i = 0; i < n; ++i) s += tile[(size_t)i * (D + 1) + a] * tile[(size_t)i * (D + 1) + b];
@@ -750,24 +788,38 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count)
+#define PC_CHOL_NT 1024
+__global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count)
 {
     // one workgroup per cluster: fixed-order sum of the partials, then calc_cholesky (utils.F90:621-649)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D;
-    double *A = (double *)smem, *L = A + DD;
+    const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D, tid = threadIdx.x;
+    double *A = (double *)smem, *L = A + DD, *red = L + DD;   // red [PC_CHOL_NT]
     __shared__ int bad;
     const double n = (double)count[c];
-    for (int p = threadIdx.x; p < DD; p += 256) {
+    // G groups of DDp threads; group g adds chunks g, g+G, ... in order, then the groups are added in order
+    int DDp = (DD + 63) & ~63;
+    if (DDp > PC_CHOL_NT) DDp = PC_CHOL_NT;
+    const int G = PC_CHOL_NT / DDp, g = tid / DDp;
+    for (int p0 = 0; p0 < DD; p0 += DDp) {
+        const int p = p0 + tid % DDp;
         double s = 0.0;
-        for (int k = 0; k < nchunk; ++k) s += pcov[((size_t)k * nc + c) * DD + p];
-        A[p] = s / n; L[p] = 0.0;
-        S.cov[(size_t)c * DD + p] = A[p];
+        if (p < DD && g < G)
+            for (int k = g; k < nchunk; k += G) s += pcov[((size_t)k * nc + c) * DD + p];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < DDp && p < DD) {
+            double t = 0.0;
+            for (int gg = 0; gg < G; ++gg) t += red[gg * DDp + tid];
+            A[p] = t / n; L[p] = 0.0;
+            S.cov[(size_t)c * DD + p] = A[p];
+        }
+        __syncthreads();
     }
-    if (threadIdx.x == 0) bad = 0;
+    if (tid == 0) bad = 0;
     __syncthreads();
     for (int i = 0; i < D; ++i) {
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             double s = 0.0;
             for (int k = 0; k < i; ++k) s += L[i * D + k] * L[i * D + k];
             const double dii = A[i * D + i] - s;
@@ -775,7 +827,7 @@ __global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, c
         }
         __syncthreads();
         if (bad) break;
-        for (int j = i + 1 + threadIdx.x; j < D; j += 256) {
+        for (int j = i + 1 + tid; j < D; j += PC_CHOL_NT) {
             double t = 0.0;
             for (int k = 0; k < i; ++k) t += L[i * D + k] * L[j * D + k];
             L[j * D + i] = (A[i * D + j] - t) / L[i * D + i];
@@ -785,10 +837,10 @@ __global__ __launch_bounds__(256) void k_cov_final_chol(PcState S, int nchunk, c
     if (bad) {   // no Cholesky factor: scaled identity (utils.F90:633-638)
         double tr = 0.0;
         for (int k = 0; k < D; ++k) tr += A[k * D + k];
-        for (int p = threadIdx.x; p < DD; p += 256) L[p] = (p / D == p % D) ? sqrt(tr) : 0.0;
+        for (int p = tid; p < DD; p += PC_CHOL_NT) L[p] = (p / D == p % D) ? sqrt(tr) : 0.0;
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < DD; p += 256) S.chol[(size_t)c * DD + p] = L[p];
+    for (int p = tid; p < DD; p += PC_CHOL_NT) S.chol[(size_t)c * DD + p] = L[p];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -867,15 +919,14 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     const int CR = cov_rows(S);
     const int nrows = S->Ncap + nph, nchunk = (nrows + CR - 1) / CR, D = S->D;
     hipLaunchKernelGGL(k_cov_mean_partial, dim3(nchunk, nc), dim3(256), 0, st, *S, nrows, nph, psum, pcnt, CR);
-    hipLaunchKernelGGL(k_cov_mean_final, dim3(nc), dim3(256), 0, st, *S, nchunk, psum, pcnt, mean, count);
-    const size_t sh = sizeof(double) * (size_t)CR * (D + 1) + sizeof(int) * CR;
+    const size_t sh = sizeof(double) * ((size_t)CR * (D + 1) + D + 256) + sizeof(int) * CR;
     if (sh > 160 * 1024) return 1;
     static size_t donep = 0;
     if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
-    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, mean, pcov, CR);
-    const size_t sh2 = sizeof(double) * 2 * (size_t)D * D;
+    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nchunk, psum, pcnt, mean, count, pcov, CR);
+    const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + PC_CHOL_NT);
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(256), sh2, st, *S, nchunk, pcov, count);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nchunk, pcov, count);
     return 0;
 }

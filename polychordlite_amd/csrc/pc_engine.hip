@@ -15,6 +15,9 @@
 #include <string>
 #include <chrono>
 #include <algorithm>
+#include <map>
+#include <unordered_map>
+#include <mutex>
 
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
@@ -51,13 +54,68 @@ static volatile int g_stop_requested = 0;
 
 namespace {
 
-template <class T> T *dalloc(size_t n)
-{
-    T *p = nullptr;
-    HIPCHK(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)));
-    return p;
-}
-template <class T> void dfree(T *&p) { if (p) hipFree((void *)p); p = nullptr; }
+// Process-wide cache of device blocks and pinned host blocks.  A run allocates ~70 buffers; hipMalloc /
+// hipFree cost O(100 us) each and hipFree synchronises the device, which is as long as the sampling
+// itself at the metric config.  Blocks are keyed by (device, rounded size) and handed back on free;
+// nothing relies on their contents (hipMalloc does not zero either).
+struct BlockCache {
+    std::mutex m;
+    std::multimap<std::pair<int, size_t>, void *> free_;
+    std::unordered_map<void *, std::pair<int, size_t>> owner;
+    size_t cached = 0, limit;
+    bool host;
+    BlockCache(bool h, size_t lim) : limit(lim), host(h) {}
+    static size_t round_up(size_t b)
+    {
+        if (b < 4096) return (b + 255) & ~(size_t)255;
+        if (b < (1u << 20)) return (b + 4095) & ~(size_t)4095;
+        return (b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    }
+    void *get(size_t bytes)
+    {
+        int dev = 0;
+        if (!host) (void)hipGetDevice(&dev);
+        const size_t sz = round_up(bytes ? bytes : 1);
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto it = free_.find({dev, sz});
+            if (it != free_.end()) { void *p = it->second; free_.erase(it); cached -= sz; return p; }
+        }
+        void *p = nullptr;
+        hipError_t e = host ? hipHostMalloc(&p, sz) : hipMalloc(&p, sz);
+        if (e != hipSuccess) {          // give the cached blocks back and retry once
+            trim();
+            e = host ? hipHostMalloc(&p, sz) : hipMalloc(&p, sz);
+        }
+        if (e != hipSuccess) { std::fprintf(stderr, "polychord_hip: out of %s memory (%zu bytes): %s\n", host ? "pinned host" : "device", sz, hipGetErrorString(e)); std::abort(); }
+        std::lock_guard<std::mutex> g(m);
+        owner[p] = {dev, sz};
+        return p;
+    }
+    bool put(void *p)                   // false: not one of ours
+    {
+        std::lock_guard<std::mutex> g(m);
+        auto it = owner.find(p);
+        if (it == owner.end()) return false;
+        if (cached + it->second.second > limit) { if (host) (void)hipHostFree(p); else (void)hipFree(p); owner.erase(it); return true; }
+        free_.insert({it->second, p}); cached += it->second.second;
+        return true;
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(m);
+        for (auto &kv : free_) { if (host) (void)hipHostFree(kv.second); else (void)hipFree(kv.second); owner.erase(kv.second); }
+        free_.clear(); cached = 0;
+    }
+};
+// never destroyed: the HIP runtime may already be gone when static destructors run
+BlockCache &dcache() { static BlockCache *c = new BlockCache(false, (size_t)48 << 30); return *c; }
+BlockCache &hcache() { static BlockCache *c = new BlockCache(true, (size_t)4 << 30); return *c; }
+
+template <class T> T *dalloc(size_t n) { return (T *)dcache().get(sizeof(T) * (n ? n : 1)); }
+template <class T> void dfree(T *&p) { if (p) dcache().put((void *)p); p = nullptr; }
+template <class T> T *halloc(size_t n) { return (T *)hcache().get(sizeof(T) * (n ? n : 1)); }
+void hfree(void *p) { if (p && !hcache().put(p)) std::free(p); }
 
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
 
@@ -234,7 +292,7 @@ struct Engine {
             h_prop.resize((size_t)B * D); h_evL.resize(B); h_evT.resize((size_t)B * D); h_evP.resize((size_t)B * std::max(1, nDer)); h_need.resize(B);
             HIPCHK(hipMemset(d_cs, 0, pc_chain_state_size() * B));
         }
-        HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(PcCtl)));
+        h_ctl = halloc<PcCtl>(1);
         // per-cluster initial values (initialise_run_time_info, run_time_info.f90:164-206)
         std::vector<double> lz(maxc, c.logzero), zero(maxc, 0.0), hugeneg(maxc, -PC_HUGE);
         std::vector<double> xq((size_t)maxc * maxc, 0.0), eye((size_t)maxc * D * D, 0.0);
@@ -277,7 +335,7 @@ struct Engine {
                 T *q = dalloc<T>((size_t)nd * per);
                 HIPCHK(hipMemcpyAsync(q, p, sizeof(T) * (size_t)h_ctl->ndead * per, hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipStreamSynchronize(st));
-                hipFree(p); p = q;
+                dfree(p); p = q;
             };
             grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1); grow(S.dead_entry, 1);
             S.Dcap = nd;
@@ -631,6 +689,7 @@ struct Engine {
         if (g_stop_requested) return 5;
         auto t1 = clk::now();
         unsigned batch = 0;
+        bool sort_valid = false;
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
@@ -653,9 +712,15 @@ struct Engine {
             hipEvent_t e2 = kt.begin();
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
-            if (use_fast && par_ok) { rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_par(&S, st); pc_launch_ph_prepare(&S, st); }
-            else if (use_fast) { rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
-            else rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
+            if (use_fast && par_ok) {
+                // the parallel contraction keeps the sorted order of the live set up to date itself
+                rc2 = 0;
+                if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }
+                rc2 = rc2 || pc_launch_consume_par(&S, st);
+                pc_launch_ph_prepare(&S, st);
+            }
+            else if (use_fast) { sort_valid = false; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
+            else { sort_valid = false; rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st); }
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
             hipEvent_t e3 = kt.begin();
@@ -691,12 +756,13 @@ struct Engine {
         for (int k = 0; k < KT_N; ++k) { out->k_time_s[k] = kt.total_ms[k] * 1e-3; out->k_launches[k] = kt.launches[k]; }
         (void)nlike_dev;
         if (cfg.feedback >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3]);
+        if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg par: stage+search %lld rank-sort %lld accept %lld merge+slots %lld evidence %lld triggers %lld publish %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4], h_ctl->dbg[5], h_ctl->dbg[6]);
         if (cfg.feedback == 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) accept-steps %lld (%lld) ins-rescan %lld (%lld) reject-steps cycles %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
-        out->dead = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, h_ctl->ndead) * nT);
-        out->logweights = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
+        out->dead = halloc<double>((size_t)std::max(1, h_ctl->ndead) * nT);
+        out->logweights = halloc<double>(std::max(1, h_ctl->ndead));
         HIPCHK(hipMemcpy(out->dead, S.dead, sizeof(double) * (size_t)h_ctl->ndead * nT, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out->logweights, S.dead_logw, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
-        out->entry = (double *)std::malloc(sizeof(double) * std::max(1, h_ctl->ndead));
+        out->entry = halloc<double>(std::max(1, h_ctl->ndead));
         HIPCHK(hipMemcpy(out->entry, S.dead_entry, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
         int nl = 0;
         for (int s = 0; s < S.Ncap; ++s) nl += hcl[s] >= 0;
@@ -743,7 +809,7 @@ struct Engine {
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
         kt.destroy();
-        if (h_ctl) hipHostFree(h_ctl); h_ctl = nullptr;
+        if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
         if (st) hipStreamDestroy(st); st = nullptr;
     }
 };
@@ -804,7 +870,7 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
 
 void pchip_result_free(pchip_result *r)
 {
-    std::free(r->dead); std::free(r->logweights); std::free(r->entry); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
+    hfree(r->dead); hfree(r->logweights); hfree(r->entry); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
     std::free(r->post_mean); std::free(r->post_var);
     std::memset(r, 0, sizeof(*r));
 }

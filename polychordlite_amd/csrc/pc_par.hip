@@ -43,29 +43,42 @@ __device__ __forceinline__ int prefix_bits(const u64 *words, int t)
     return c;
 }
 
-// inclusive block-wide prefix logaddexp of two independent values (their exp/log chains overlap).
+// Sums of exponentials are carried as (m, s) pairs meaning m + log(s): combining two pairs costs one
+// exp and no log (the log is taken once, where a value is needed).  Neutral element: (NEGBIG, 0).
+__device__ __forceinline__ void ls_comb(double &m, double &s, double m2, double s2)
+{
+    const double e = exp(-fabs(m - m2));
+    s = (m >= m2) ? s + s2 * e : s * e + s2;
+    m = fmax(m, m2);
+}
+__device__ __forceinline__ double ls_val(double m, double s) { return s > 0.0 ? m + log(s) : NEGBIG; }
+
+// inclusive block-wide prefix of two independent pair sequences (their exp chains overlap).
 // nact = number of leading threads that carry data (the rest hold the neutral element).
-__device__ __forceinline__ void block_scan_lae2(double &v, double &u, int lane, int wv, int nact, double *wtot)
+__device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &bm, double &bs, int lane, int wv, int nact, double *wtot)
 {
     if (wv * 64 < nact) {
         for (int k = 1; k < 64; k <<= 1) {
-            const double ov = __shfl_up(v, k), ou = __shfl_up(u, k);
-            const double nv = lae2(v, ov), nu = lae2(u, ou);
-            if (lane >= k) { v = nv; u = nu; }
+            const double oam = __shfl_up(am, k), oas = __shfl_up(as, k), obm = __shfl_up(bm, k), obs = __shfl_up(bs, k);
+            double nam = am, nas = as, nbm = bm, nbs = bs;
+            ls_comb(nam, nas, oam, oas); ls_comb(nbm, nbs, obm, obs);
+            if (lane >= k) { am = nam; as = nas; bm = nbm; bs = nbs; }
         }
     }
-    if (lane == 63) { wtot[wv] = v; wtot[PAR_W + wv] = u; }
+    if (lane == 63) { wtot[wv] = am; wtot[PAR_W + wv] = as; wtot[2 * PAR_W + wv] = bm; wtot[3 * PAR_W + wv] = bs; }
     __syncthreads();
     const int nw = (nact + 63) >> 6;
     if (wv > 0 && wv < nw) {
-        // every wave reduces the totals of the waves before it (<= 15 values, 4 levels)
+        // every wave reduces the totals of the waves before it (<= 15 pairs, 4 levels)
         const int l16 = lane & 15;
-        double tv = (l16 < wv) ? wtot[l16] : NEGBIG, tu = (l16 < wv) ? wtot[PAR_W + l16] : NEGBIG;
+        const bool on = l16 < wv;
+        double tam = on ? wtot[l16] : NEGBIG, tas = on ? wtot[PAR_W + l16] : 0.0;
+        double tbm = on ? wtot[2 * PAR_W + l16] : NEGBIG, tbs = on ? wtot[3 * PAR_W + l16] : 0.0;
         for (int k = 1; k < PAR_W; k <<= 1) {
-            const double ov = __shfl_xor(tv, k), ou = __shfl_xor(tu, k);
-            tv = lae2(tv, ov); tu = lae2(tu, ou);
+            const double oam = __shfl_xor(tam, k), oas = __shfl_xor(tas, k), obm = __shfl_xor(tbm, k), obs = __shfl_xor(tbs, k);
+            ls_comb(tam, tas, oam, oas); ls_comb(tbm, tbs, obm, obs);
         }
-        v = lae2(v, tv); u = lae2(u, tu);
+        ls_comb(am, as, tam, tas); ls_comb(bm, bs, tbm, tbs);
     }
     __syncthreads();
 }
@@ -121,6 +134,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const double log2v = 0.6931471805599453;
     const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0), d01 = l0 - l1, d02 = l0 - l2;
 
+    long long cyc[9]; int ncy = 0;
+    cyc[ncy++] = clock64();
     // ---- phase 0: stage the sorted snapshot and the candidates
     for (int i = tid; i < NS; i += PAR_NT) { sSortK[i] = (i < n) ? S.sort_key[i] : KEY_HUGE; sSort[i] = S.sort_slot[i]; }
     const bool inT = tid < T;
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
     rlo[tid] = rl;
 
+    cyc[ncy++] = clock64();
     // ---- phase 2: rank of every candidate (bitonic sort of (key, step); equal keys: earlier step = larger)
     for (int k = 2; k <= PAR_NT; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -161,6 +177,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     __syncthreads();
     const int rho = rnk[tid];
 
+    cyc[ncy++] = clock64();
     // ---- phase 3: acceptance.  In-chunk dependency masks by every wave, then wave 0 resolves the
     //      chunks in step order against the bitmap of accepted ranks.
     {
@@ -203,6 +220,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
     __syncthreads();
 
+    cyc[ncy++] = clock64();
     // ---- phase 4: counts
     const bool acc = (amask[wv] >> lane) & 1ull;
     const int kt = prefix_bits(amask, tid);               // acceptances (= deaths) before my step
@@ -244,6 +262,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         __syncthreads();
     }
 
+    cyc[ncy++] = clock64();
     // ---- phase 7: evidence of the K deaths (thread j = j-th death), update_evidence (run_time_info.f90:211-296)
     const bool isd = tid < K;
     double L = NEGBIG, Ladd = NEGBIG;
@@ -251,21 +270,29 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const double jd = (double)tid;
     const double Xb = Xp0 + jd * d01, XXb = XX0 + jd * d02;           // volumes before my death
     const double Sd = (jd + 1.0) * d01;
-    double PT = isd ? Xb + L - l1 : NEGBIG;                            // log of the evidence increment
-    double PV = isd ? (XXb + L + l0 - l1 - l2) - Sd : NEGBIG;          // increment of <Z X>, decay factored out
-    block_scan_lae2(PT, PV, lane, wv, K, wtot);
-    const double Zi = lae2(logZ0, PT), Zpi = lae2(Zp0, PT);
-    const double ZXi = Sd + lae2(ZXp0, PV), ZpXpi = Sd + lae2(ZpXp0, PV);
-    if (lane == 63) { wtot[32 + wv] = ZXi; wtot[48 + wv] = ZpXpi; }
+    // increments of logZ and of <Z X> (decay factored out) as pairs
+    double tM = isd ? Xb + L - l1 : NEGBIG, tS = isd ? 1.0 : 0.0;
+    double vM = isd ? (XXb + L + l0 - l1 - l2) - Sd : NEGBIG, vS = tS;
+    block_scan_ls2(tM, tS, vM, vS, lane, wv, K, wtot);
+    double ziM = tM, ziS = tS;
+    ls_comb(ziM, ziS, logZ0, 1.0);
+    const double Zi = ls_val(ziM, ziS);                                // logZ after my death
+    double zxM = vM, zxS = vS, zpxM = vM, zpxS = vS;                   // <Z X> = Sd + (zxM + log zxS)
+    ls_comb(zxM, zxS, ZXp0, 1.0); ls_comb(zpxM, zpxS, ZpXp0, 1.0);
+    if (lane == 63) { wtot[wv] = zxM; wtot[PAR_W + wv] = zxS; wtot[2 * PAR_W + wv] = zpxM; wtot[3 * PAR_W + wv] = zpxS; }
     __syncthreads();
-    double ZXprev = __shfl_up(ZXi, 1), ZpXpprev = __shfl_up(ZpXpi, 1);
-    if (lane == 0) { ZXprev = wv ? wtot[32 + wv - 1] : ZXp0; ZpXpprev = wv ? wtot[48 + wv - 1] : ZpXp0; }
+    double pzxM = __shfl_up(zxM, 1), pzxS = __shfl_up(zxS, 1), pzpxM = __shfl_up(zpxM, 1), pzpxS = __shfl_up(zpxS, 1);
+    if (lane == 0) {
+        pzxM = wv ? wtot[wv - 1] : ZXp0; pzxS = wv ? wtot[PAR_W + wv - 1] : 1.0;
+        pzpxM = wv ? wtot[2 * PAR_W + wv - 1] : ZpXp0; pzpxS = wv ? wtot[3 * PAR_W + wv - 1] : 1.0;
+    }
     __syncthreads();
     const double cz = log2v + XXb + 2 * L - l1 - l2;
-    double W = isd ? lae2(log2v + ZXprev + L - l1, cz) : NEGBIG;
-    double Wp = isd ? lae2(log2v + ZpXpprev + L - l1, cz) : NEGBIG;
-    block_scan_lae2(W, Wp, lane, wv, K, wtot);
-    const double Z2i = lae2(logZ20, W), Zp2i = lae2(Zp20, Wp);
+    const double cw = log2v + L - l1 + jd * d01;                        // + <Z X> before my death
+    double wM = isd ? cw + pzxM : NEGBIG, wS = isd ? pzxS : 0.0;
+    double wpM = isd ? cw + pzpxM : NEGBIG, wpS = isd ? pzpxS : 0.0;
+    if (isd) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
+    block_scan_ls2(wM, wS, wpM, wpS, lane, wv, K, wtot);
     // live log-sum-exp after every death (run_time_info.f90:683-709), one reference for the launch
     double refp;
     {
@@ -282,6 +309,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     sZi[tid] = Zi; sLse[tid] = lsei;
     __syncthreads();
 
+    cyc[ncy++] = clock64();
     // ---- phase 8: the first step at which the reference's loop would have stopped
     int kupd = 0x7fffffff;                                // deaths until logXp <= logX_last_update + log(compression)
     {
@@ -324,12 +352,19 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     if (T == PAR_NT && tid == 0) check(PAR_NT);
     __syncthreads();
 
+    cyc[ncy++] = clock64();
     // ---- phase 9: truncate at the trigger and publish
     const int code = ish[0];
     const int ts = code >> 2, pri = code & 3;
     const int Kp = prefix_bits(amask, ts), vps = prefix_bits(vmask, ts);
     const int status = (pri == 0) ? PC_ST_UPDATE : (pri == 1) ? PC_ST_DONE : (pri == 2) ? PC_ST_ERROR : PC_ST_RUNNING;
-    if (Kp > 0 && tid == Kp - 1) { fin[0] = Zi; fin[1] = Zpi; fin[2] = ZXi; fin[3] = ZpXpi; fin[4] = Z2i; fin[5] = Zp2i; fin[6] = lsei; fin[7] = L; }
+    if (Kp > 0 && tid == Kp - 1) {                        // state after the last death of the launch
+        double m = tM, q = tS;
+        ls_comb(m, q, Zp0, 1.0);
+        fin[0] = Zi; fin[1] = ls_val(m, q); fin[2] = Sd + ls_val(zxM, zxS); fin[3] = Sd + ls_val(zpxM, zpxS);
+        ls_comb(wM, wS, logZ20, 1.0); ls_comb(wpM, wpS, Zp20, 1.0);
+        fin[4] = ls_val(wM, wS); fin[5] = ls_val(wpM, wpS); fin[6] = lsei; fin[7] = L;
+    }
     if (inT && tid < ts) {
         atomicAdd(&ish[1], nl);
         PcPlan *pw = S.plan + w;
@@ -346,10 +381,26 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         }
     }
     for (int s = tid; s < Ncap; s += PAR_NT) S.slot_src[s] = -1;
+    if (lane == 0) accR[wv] = 0ull;
     __syncthreads();
-    if (acc && tid < ts && pos >= Kp) {                   // accepted and still alive at the end of the launch
+    const bool accT = acc && tid < ts;
+    if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));
+    __syncthreads();
+    int pos2 = 0;
+    if (accT) { const int q2 = prefix_bits(accR, rho); pos2 = q2 + rp; srtK[q2] = ck; }
+    __syncthreads();
+    if (accT && pos2 >= Kp) {                             // accepted and still alive at the end of the launch
         const int sl = slotA[tid];
         S.live_logL[sl] = key2d(ck); S.slot_src[sl] = w;
+        S.sort_key[pos2 - Kp] = ck; S.sort_slot[pos2 - Kp] = sl;
+    }
+    // the sorted order of the new live set: the survivors merged into what is left of the snapshot
+    for (int idx = tid; idx < n; idx += PAR_NT) {
+        const u64 sk = sSortK[idx];
+        int lo = 0, hi = Kp;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (aK[mid] < sk) lo = mid + 1; else hi = mid; }
+        const int p2 = idx + lo;
+        if (p2 >= Kp) { S.sort_key[p2 - Kp] = sk; S.sort_slot[p2 - Kp] = sSort[idx]; }
     }
     if (tid == 0) {
         const double Xp = Xp0 + (double)Kp * d01, XX = XX0 + (double)Kp * d02;
@@ -373,6 +424,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
         if (S.use_prec) ctl->live_logZ = refp + log(lse_e) - l0 + Xp;
+        cyc[ncy++] = clock64();
+        for (int x = 0; x + 1 < ncy && x < 8; ++x) ctl->dbg[x] += cyc[x + 1] - cyc[x];
     }
 }
 
