@@ -101,12 +101,18 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        one(-1 - i)
+        merge_runs(one(-1 - i), dist, torch, local_rank)
     sync()
     t0 = time.perf_counter()
-    runs = [one(i) for i in range(args.steps)]
-    # repeat-sharded merge: all-gather (logL, birth) of every dead point of the last step's runs
+    runs, step_ms = [], []
+    for i in range(args.steps):
+        ts0 = time.perf_counter()
+        runs.append(one(i))
+        step_ms.append((time.perf_counter() - ts0) * 1e3)
+    # repeat-sharded merge: all-gather (logL, entry contour) of every dead point of the last step's runs
+    tm0 = time.perf_counter()
     merged = merge_runs(runs[-1], dist, torch, local_rank) if args.steps > 0 else None
+    merge_ms = (time.perf_counter() - tm0) * 1e3
     sync()
     dt = time.perf_counter() - t0
     tmax = dt
@@ -141,7 +147,7 @@ def main():
                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world},
                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
                "logZ_truth": 0.0, "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
-               "merged": merged, "roofline": roof,
+               "merged": merged, "step_ms": step_ms, "merge_ms": merge_ms, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),

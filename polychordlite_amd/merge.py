@@ -32,6 +32,26 @@ def evidence_replay(logL, birth):
     return float(2 * logZ - 0.5 * logZ2), float(logZ2 - 2 * logZ)
 
 
+def evidence_replay_torch(torch, logL, birth):
+    """evidence_replay with torch ops on whatever device the records live on (the RCCL all-gather leaves
+    them in HBM; the sort, the counting and the log-space scans run there)."""
+    d, _ = torch.sort(logL.to(torch.float64))
+    b, _ = torch.sort(birth.to(torch.float64))
+    n = (torch.searchsorted(b, d, right=False) - torch.arange(d.numel(), device=d.device)).to(torch.float64)
+    n = torch.clamp(n, min=1.0)
+    l0, l1, l2 = torch.log(n), torch.log(n + 1.0), torch.log(n + 2.0)
+    zero = torch.zeros(1, dtype=torch.float64, device=d.device)
+    logX = torch.cat((zero, torch.cumsum(l0 - l1, 0)))
+    logXX = torch.cat((zero, torch.cumsum(l0 - l2, 0)))
+    Xm, XXm, Xi = logX[:-1], logXX[:-1], logX[1:]
+    logZ = torch.logsumexp(Xm + d - l1, 0)
+    ZX = torch.logcumsumexp(XXm + d + l0 - l1 - l2 - Xi, 0) + Xi
+    ZXm = torch.cat((torch.full((1,), -float("inf"), dtype=torch.float64, device=d.device), ZX[:-1]))
+    log2 = 0.6931471805599453
+    logZ2 = torch.logsumexp(torch.logaddexp(log2 + ZXm + d - l1, log2 + XXm + 2 * d - l1 - l2), 0)
+    return float(2 * logZ - 0.5 * logZ2), float(logZ2 - 2 * logZ)
+
+
 def lived_records(run):
     """(logL, birth) of the points that entered the live set (failed spawns carry weight logzero)."""
     dead, lw = run["dead"], run["logweights"]
@@ -44,24 +64,28 @@ def lived_records(run):
 
 def merge_runs(run, dist, torch, local_rank):
     logL, birth = lived_records(run)
+    on_gpu = torch is not None and torch.cuda.is_available()
     if dist is None:
-        lz, var = evidence_replay(logL, birth)
+        if on_gpu:
+            dev = torch.device("cuda", local_rank)
+            lz, var = evidence_replay_torch(torch, torch.from_numpy(np.ascontiguousarray(logL)).to(dev),
+                                            torch.from_numpy(np.ascontiguousarray(birth)).to(dev))
+        else:
+            lz, var = evidence_replay(logL, birth)
         return {"n_runs": 1, "logZ": lz, "logZerr": float(np.sqrt(abs(var))), "records": int(logL.size)}
     world = dist.get_world_size()
-    dev = torch.device("cuda", local_rank) if torch.cuda.is_available() and dist.get_backend() == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", local_rank) if on_gpu and dist.get_backend() == "nccl" else torch.device("cpu")
     cnt = torch.tensor([logL.size], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt)
-    nmax = int(max(int(c.item()) for c in cnts))
-    rec = torch.full((nmax, 2), float("nan"), dtype=torch.float64, device=dev)
+    ks = [int(c.item()) for c in cnts]
+    nmax = max(ks)
+    rec = torch.zeros((nmax, 2), dtype=torch.float64, device=dev)
     rec[:logL.size, 0] = torch.from_numpy(np.ascontiguousarray(logL)).to(dev)
     rec[:logL.size, 1] = torch.from_numpy(np.ascontiguousarray(birth)).to(dev)
     recs = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(recs, rec)                            # RCCL all-gather over xGMI
-    allL, allB = [], []
-    for c, r in zip(cnts, recs):
-        k = int(c.item())
-        a = r[:k].cpu().numpy()
-        allL.append(a[:, 0]); allB.append(a[:, 1])
-    lz, var = evidence_replay(np.concatenate(allL), np.concatenate(allB))
-    return {"n_runs": world, "logZ": lz, "logZerr": float(np.sqrt(abs(var))), "records": int(sum(int(c.item()) for c in cnts))}
+    allL = torch.cat([r[:k, 0] for k, r in zip(ks, recs)])
+    allB = torch.cat([r[:k, 1] for k, r in zip(ks, recs)])
+    lz, var = evidence_replay_torch(torch, allL, allB)
+    return {"n_runs": world, "logZ": lz, "logZerr": float(np.sqrt(abs(var))), "records": int(sum(ks))}
