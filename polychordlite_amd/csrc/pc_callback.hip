@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
             for (int d = 0; d < D; ++d) { x0[d] = pc[d]; row[d] = pc[d]; row[S.p0 + d] = c.ok_theta ? ev_theta[(size_t)chain * D + d] : 0.0; }
             for (int e = 0; e < S.nDer; ++e) row[S.d0 + e] = c.ok_theta ? ev_phi[(size_t)chain * S.nDer + e] : 0.0;
             row[S.b0] = c.contour; row[S.l0] = c.lnew;
-            S.baby_logL[(size_t)chain * nr + c.s] = c.lnew;
+            S.baby_logL[(size_t)chain * nr + c.s] = c.lnew; S.baby_logL_T[(size_t)c.s * S.B + chain] = c.lnew;
             c.s++; c.phase = CB_NEW_SLICE;
         }
         if (c.phase == CB_DONE) break;

@@ -818,22 +818,37 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
     }
     if (tid == 0) bad = 0;
     __syncthreads();
-    for (int i = 0; i < D; ++i) {
-        if (tid == 0) {
-            double s = 0.0;
-            for (int k = 0; k < i; ++k) s += L[i * D + k] * L[i * D + k];
-            const double dii = A[i * D + i] - s;
-            if (dii <= 0.0) bad = 1; else L[i * D + i] = sqrt(dii);
+    // calc_cholesky by ONE wavefront, lane = row: column i needs, for every row j >= i, the dot product
+    // sum_{k<i} L(i,k) L(j,k) in ascending k (the reference's order); row i's own value gives the
+    // diagonal.  No workgroup barrier inside the column loop, only wave-level LDS ordering.
+    if (tid < 64) {
+        for (int i = 0; i < D; ++i) {
+            double tj[4] = {0.0, 0.0, 0.0, 0.0};           // D <= 256: at most 4 rows per lane
+            #pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = m * 64 + tid;
+                if (j >= i && j < D) {
+                    double t = 0.0;
+                    for (int k = 0; k < i; ++k) t += L[i * D + k] * L[j * D + k];
+                    tj[m] = t;
+                }
+            }
+            double ti = 0.0;                                // row i's own dot product
+            #pragma unroll
+            for (int m = 0; m < 4; ++m) { const double v = __shfl(tj[m], i & 63); if ((i >> 6) == m) ti = v; }
+            const double dii = A[i * D + i] - ti;
+            if (dii <= 0.0) { if (tid == 0) bad = 1; break; }
+            const double lii = sqrt(dii);
+            #pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = m * 64 + tid;
+                if (j > i && j < D) L[j * D + i] = (A[i * D + j] - tj[m]) / lii;
+            }
+            if (tid == 0) L[i * D + i] = lii;
+            __threadfence_block();
         }
-        __syncthreads();
-        if (bad) break;
-        for (int j = i + 1 + tid; j < D; j += PC_CHOL_NT) {
-            double t = 0.0;
-            for (int k = 0; k < i; ++k) t += L[i * D + k] * L[j * D + k];
-            L[j * D + i] = (A[i * D + j] - t) / L[i * D + i];
-        }
-        __syncthreads();
     }
+    __syncthreads();
     if (bad) {   // no Cholesky factor: scaled identity (utils.F90:633-638)
         double tr = 0.0;
         for (int k = 0; k < D; ++k) tr += A[k * D + k];

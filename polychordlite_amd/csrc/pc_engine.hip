@@ -278,7 +278,7 @@ struct Engine {
         S.dead = dalloc<double>((size_t)S.Dcap * nT); S.dead_logw = dalloc<double>(S.Dcap);
         S.dead_postX = dalloc<double>(S.Dcap); S.dead_postZ = dalloc<double>(S.Dcap); S.dead_cuid = dalloc<unsigned>(S.Dcap);
         S.dead_entry = dalloc<double>(S.Dcap);
-        S.babies = dalloc<double>((size_t)B * nr * nT); S.baby_logL = dalloc<double>((size_t)B * nr);
+        S.babies = dalloc<double>((size_t)B * nr * nT); S.baby_logL = dalloc<double>((size_t)B * nr); S.baby_logL_T = dalloc<double>((size_t)B * nr);
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
@@ -716,8 +716,7 @@ struct Engine {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0;
                 if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }
-                rc2 = rc2 || pc_launch_consume_par(&S, st);
-                pc_launch_ph_prepare(&S, st);
+                rc2 = rc2 || pc_launch_consume_par(&S, st);      // also lays out the phantoms
             }
             else if (use_fast) { sort_valid = false; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else { sort_valid = false; rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st); }
@@ -798,7 +797,7 @@ struct Engine {
     {
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
-                          &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL,
+                          &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,
                           &S.ch_contour, &S.nhat, &S.nhat_w, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);

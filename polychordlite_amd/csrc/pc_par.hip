@@ -53,33 +53,59 @@ __device__ __forceinline__ void ls_comb(double &m, double &s, double m2, double 
 }
 __device__ __forceinline__ double ls_val(double m, double s) { return s > 0.0 ? m + log(s) : NEGBIG; }
 
-// inclusive block-wide prefix of two independent pair sequences (their exp chains overlap).
-// nact = number of leading threads that carry data (the rest hold the neutral element).
-__device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &bm, double &bs, int lane, int wv, int nact, double *wtot)
+// Inclusive block-wide prefix of two independent pair sequences (their exp chains overlap), work
+// efficient: 256 threads own four consecutive elements each (O(n) combines; a Hillis-Steele scan over
+// 1024 threads costs O(n log n) exps and is bound by the fp64 rate of the one CU this kernel runs on).
+// In-wave levels move data with DPP only (row_shr 1/2/4/8, then row_bcast15 / row_bcast31).
+// Elements at and after nact hold the neutral element.  X0..X3: [1024] doubles of scratch each.
+#define PAR_SCAN_LEVEL(AM, AS, BM, BS, CTRL, PRED) { \
+        const double oam = dpp_f64<CTRL>(AM), oas = dpp_f64<CTRL>(AS), obm = dpp_f64<CTRL>(BM), obs = dpp_f64<CTRL>(BS); \
+        double nam = AM, nas = AS, nbm = BM, nbs = BS; \
+        ls_comb(nam, nas, oam, oas); ls_comb(nbm, nbs, obm, obs); \
+        if (PRED) { AM = nam; AS = nas; BM = nbm; BS = nbs; } }
+__device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &bm, double &bs, int tid, int nact,
+                                               double *X0, double *X1, double *X2, double *X3, double *wtot)
 {
-    if (wv * 64 < nact) {
-        for (int k = 1; k < 64; k <<= 1) {
-            const double oam = __shfl_up(am, k), oas = __shfl_up(as, k), obm = __shfl_up(bm, k), obs = __shfl_up(bs, k);
-            double nam = am, nas = as, nbm = bm, nbs = bs;
-            ls_comb(nam, nas, oam, oas); ls_comb(nbm, nbs, obm, obs);
-            if (lane >= k) { am = nam; as = nas; bm = nbm; bs = nbs; }
-        }
-    }
-    if (lane == 63) { wtot[wv] = am; wtot[PAR_W + wv] = as; wtot[2 * PAR_W + wv] = bm; wtot[3 * PAR_W + wv] = bs; }
+    const int lane = tid & 63, wv = tid >> 6;
+    X0[tid] = am; X1[tid] = as; X2[tid] = bm; X3[tid] = bs;
     __syncthreads();
-    const int nw = (nact + 63) >> 6;
-    if (wv > 0 && wv < nw) {
-        // every wave reduces the totals of the waves before it (<= 15 pairs, 4 levels)
-        const int l16 = lane & 15;
-        const bool on = l16 < wv;
-        double tam = on ? wtot[l16] : NEGBIG, tas = on ? wtot[PAR_W + l16] : 0.0;
-        double tbm = on ? wtot[2 * PAR_W + l16] : NEGBIG, tbs = on ? wtot[3 * PAR_W + l16] : 0.0;
-        for (int k = 1; k < PAR_W; k <<= 1) {
-            const double oam = __shfl_xor(tam, k), oas = __shfl_xor(tas, k), obm = __shfl_xor(tbm, k), obs = __shfl_xor(tbs, k);
-            ls_comb(tam, tas, oam, oas); ls_comb(tbm, tbs, obm, obs);
+    double a_m[4], a_s[4], b_m[4], b_s[4];
+    double tam = NEGBIG, tas = 0.0, tbm = NEGBIG, tbs = 0.0;
+    const bool has = tid * 4 < nact;
+    if (wv < 4) {
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a_m[u] = has ? X0[4 * tid + u] : NEGBIG; a_s[u] = has ? X1[4 * tid + u] : 0.0;
+            b_m[u] = has ? X2[4 * tid + u] : NEGBIG; b_s[u] = has ? X3[4 * tid + u] : 0.0;
         }
-        ls_comb(am, as, tam, tas); ls_comb(bm, bs, tbm, tbs);
+        #pragma unroll
+        for (int u = 1; u < 4; ++u) { ls_comb(a_m[u], a_s[u], a_m[u - 1], a_s[u - 1]); ls_comb(b_m[u], b_s[u], b_m[u - 1], b_s[u - 1]); }
+        tam = a_m[3]; tas = a_s[3]; tbm = b_m[3]; tbs = b_s[3];
+        const int lr = lane & 15;
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x111, lr >= 1)
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x112, lr >= 2)
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x114, lr >= 4)
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x118, lr >= 8)
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x142, (lane >> 4) & 1)      // row_bcast15: lane 15 of the previous row
+        PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x143, lane >= 32)           // row_bcast31: lane 31
+        if (lane == 63) { wtot[wv] = tam; wtot[4 + wv] = tas; wtot[8 + wv] = tbm; wtot[12 + wv] = tbs; }
     }
+    __syncthreads();
+    if (wv < 4) {
+        // exclusive prefix of my segment: the previous lane's inclusive value, then the waves before mine
+        double eam = __shfl_up(tam, 1), eas = __shfl_up(tas, 1), ebm = __shfl_up(tbm, 1), ebs = __shfl_up(tbs, 1);
+        if (lane == 0) { eam = NEGBIG; eas = 0.0; ebm = NEGBIG; ebs = 0.0; }
+        for (int x = 0; x < wv; ++x) { ls_comb(eam, eas, wtot[x], wtot[4 + x]); ls_comb(ebm, ebs, wtot[8 + x], wtot[12 + x]); }
+        if (has) {
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ls_comb(a_m[u], a_s[u], eam, eas); ls_comb(b_m[u], b_s[u], ebm, ebs);
+                X0[4 * tid + u] = a_m[u]; X1[4 * tid + u] = a_s[u]; X2[4 * tid + u] = b_m[u]; X3[4 * tid + u] = b_s[u];
+            }
+        }
+    }
+    __syncthreads();
+    am = X0[tid]; as = X1[tid]; bm = X2[tid]; bs = X3[tid];
     __syncthreads();
 }
 
@@ -123,10 +149,12 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     int *parA = slotA + PAR_NT;              // [1024]
     int *accStep = parA + PAR_NT;            // [1024] step of the j-th acceptance
     int *ish = accStep + PAR_NT;             // [16]
+    int *hist = ish + 16;                    // [NS + 64] candidates per snapshot gap, then gap offsets
     double *sLse = (double *)Gm;
 
     const int epoch = ctl->admin_epoch;
-    const int ndead0 = ctl->ndead, fail0 = ctl->failures;
+    const int ndead0 = ctl->ndead, fail0 = ctl->failures, nph0 = ctl->nphantom;
+    const long long nlike0 = ctl->nlike, niter0 = ctl->niter;
     const double logZ0 = ctl->logZ, logZ20 = ctl->logZ2;
     const double Xp0 = S.logXp[0], Zp0 = S.logZp[0], ZXp0 = S.logZXp[0], Zp20 = S.logZp2[0], ZpXp0 = S.logZpXp[0], XX0 = S.XpXq[0];
     const double lseRef0 = S.lse_ref[0], lseSum0 = S.lse_sum[0];
@@ -141,8 +169,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const bool inT = tid < T;
     const int w = T - 1 - tid;
     u64 ck = KEY_HUGE; bool valid = false; int nl = 0;
-    if (inT) { ck = d2key(S.baby_logL[(size_t)w * nr + nr - 1]); valid = S.ch_epoch[w] == epoch; nl = S.ch_nlike[w]; }
-    cK[tid] = ck; srtK[tid] = ck; srtT[tid] = tid;
+    if (inT) { ck = d2key(S.baby_logL_T[(size_t)(nr - 1) * S.B + w]); valid = S.ch_epoch[w] == epoch; nl = S.ch_nlike[w]; }
+    cK[tid] = ck;
+    for (int i = tid; i < NS + 64; i += PAR_NT) hist[i] = 0;
     {
         const u64 vm = __ballot(valid);
         if (lane == 0) { vmask[wv] = vm; accR[wv] = 0ull; amask[wv] = 0ull; }
@@ -161,21 +190,40 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     rlo[tid] = rl;
 
     cyc[ncy++] = clock64();
-    // ---- phase 2: rank of every candidate (bitonic sort of (key, step); equal keys: earlier step = larger)
-    for (int k = 2; k <= PAR_NT; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int l = tid ^ j;
-            if (l > tid) {
-                const bool up = (tid & k) == 0;
-                const u64 a = srtK[tid], b = srtK[l]; const int ta = srtT[tid], tb = srtT[l];
-                const bool gt = (a > b) || (a == b && ta < tb);
-                if (gt == up) { srtK[tid] = b; srtK[l] = a; srtT[tid] = tb; srtT[l] = ta; }
-            }
-            __syncthreads();
-        }
-    rnk[srtT[tid]] = tid;
+    // ---- phase 2: rank of every candidate among the candidates (equal keys: earlier step = larger).
+    //      Candidates are already bucketed by the snapshot gap they fall in (rl): rank = candidates in
+    //      lower gaps + candidates of the same gap that compare lower.
+    int myoff = 0;
+    if (inT) myoff = atomicAdd(&hist[rl], 1);            // arrival order inside a gap: placement only
     __syncthreads();
-    const int rho = rnk[tid];
+    {
+        const int nb = n + 2;                             // gaps 0..n, plus one sentinel that receives T
+        const int per = (nb + PAR_NT - 1) / PAR_NT, b0 = tid * per;
+        int sum = 0;
+        for (int x = 0; x < per; ++x) if (b0 + x < nb) sum += hist[b0 + x];
+        int inc = sum;
+        for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(inc, k); if (lane >= k) inc += o; }
+        if (lane == 63) accStep[wv] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int x = 0; x < wv; ++x) run += accStep[x];
+        for (int x = 0; x < per; ++x) if (b0 + x < nb) { const int cnt = hist[b0 + x]; hist[b0 + x] = run; run += cnt; }
+    }
+    __syncthreads();
+    if (inT) srtT[hist[rl] + myoff] = tid;
+    __syncthreads();
+    int rho = tid;
+    if (inT) {
+        const int g0 = hist[rl], g1 = hist[rl + 1];
+        int below = 0;
+        for (int x = g0; x < g1; ++x) {
+            const int o = srtT[x];
+            const u64 ko = cK[o];
+            below += (ko < ck) || (ko == ck && o > tid);
+        }
+        rho = g0 + below;
+    }
+    rnk[tid] = rho;
 
     cyc[ncy++] = clock64();
     // ---- phase 3: acceptance.  In-chunk dependency masks by every wave, then wave 0 resolves the
@@ -192,20 +240,20 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     __syncthreads();
     if (wv == 0) {
         const int nch = (T + 63) >> 6;
-        volatile u64 *vacc = accR;
+        int *cum = accStep;                               // [16] accepted candidates in the bitmap words before x
+        if (lane < PAR_W) cum[lane] = 0;
+        __threadfence_block();
+        int rho_t = rnk[lane], r = rlo[lane], tot = 0;
+        u64 Gt = Gm[lane];
         for (int c = 0; c < nch; ++c) {
-            const int t = c * 64 + lane;
-            const int rho_t = rnk[t], r = rlo[t];
-            const u64 Gt = Gm[t];
+            // operands of the next chunk travel while this one is resolved
+            const int tn = (c + 1 < nch) ? (c + 1) * 64 + lane : lane;
+            const int nrho = rnk[tn], nr2 = rlo[tn];
+            const u64 nG = Gm[tn];
             const bool v = (vmask[c] >> lane) & 1ull;
             const int wq = rho_t >> 6, bq = rho_t & 63;
-            int P = 0;                                    // accepted in earlier chunks with a larger rank
-            #pragma unroll
-            for (int x = 0; x < PAR_W; ++x) {
-                const u64 word = vacc[x];
-                const u64 m = (x > wq) ? ~0ull : ((x == wq) ? ((~0ull << bq) << 1) : 0ull);
-                P += __popcll(word & m);
-            }
+            // accepted in earlier chunks with a larger rank = all of them minus those at or below my rank
+            const int P = tot - cum[wq] - __popcll(accR[wq] & (((1ull << bq) << 1) - 1ull));
             u64 am = __ballot(v && r > P);
             for (int it = 0; it < 66; ++it) {
                 const bool a = v && r > P + __popcll(Gt & am);
@@ -215,7 +263,15 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             }
             if ((am >> lane) & 1ull) atomicOr(&accR[wq], 1ull << bq);
             if (lane == 0) amask[c] = am;
+            tot += __popcll(am);
             __threadfence_block();
+            {   // refresh the per-word offsets
+                int cw = (lane < PAR_W) ? __popcll(accR[lane]) : 0, inc = cw;
+                for (int k = 1; k < PAR_W; k <<= 1) { const int o = __shfl_up(inc, k); if (lane >= k) inc += o; }
+                if (lane < PAR_W) cum[lane] = inc - cw;
+            }
+            __threadfence_block();
+            rho_t = nrho; r = nr2; Gt = nG;
         }
     }
     __syncthreads();
@@ -263,6 +319,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
 
     cyc[ncy++] = clock64();
+#ifdef PAR_DBG_EVID
+    long long ecy[9]; ecy[0] = clock64();
+#endif
     // ---- phase 7: evidence of the K deaths (thread j = j-th death), update_evidence (run_time_info.f90:211-296)
     const bool isd = tid < K;
     double L = NEGBIG, Ladd = NEGBIG;
@@ -270,10 +329,17 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const double jd = (double)tid;
     const double Xb = Xp0 + jd * d01, XXb = XX0 + jd * d02;           // volumes before my death
     const double Sd = (jd + 1.0) * d01;
+#ifdef PAR_DBG_EVID
+    ecy[1] = clock64();
+#endif
     // increments of logZ and of <Z X> (decay factored out) as pairs
     double tM = isd ? Xb + L - l1 : NEGBIG, tS = isd ? 1.0 : 0.0;
     double vM = isd ? (XXb + L + l0 - l1 - l2) - Sd : NEGBIG, vS = tS;
-    block_scan_ls2(tM, tS, vM, vS, lane, wv, K, wtot);
+    double *X0 = (double *)srtK, *X1 = (double *)Gm, *X2 = sZi, *X3 = (double *)rnk;   // scratch until the end of this phase
+    block_scan_ls2(tM, tS, vM, vS, tid, K, X0, X1, X2, X3, wtot);
+#ifdef PAR_DBG_EVID
+    ecy[2] = clock64();
+#endif
     double ziM = tM, ziS = tS;
     ls_comb(ziM, ziS, logZ0, 1.0);
     const double Zi = ls_val(ziM, ziS);                                // logZ after my death
@@ -287,12 +353,18 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         pzpxM = wv ? wtot[2 * PAR_W + wv - 1] : ZpXp0; pzpxS = wv ? wtot[3 * PAR_W + wv - 1] : 1.0;
     }
     __syncthreads();
+#ifdef PAR_DBG_EVID
+    ecy[3] = clock64();
+#endif
     const double cz = log2v + XXb + 2 * L - l1 - l2;
     const double cw = log2v + L - l1 + jd * d01;                        // + <Z X> before my death
     double wM = isd ? cw + pzxM : NEGBIG, wS = isd ? pzxS : 0.0;
     double wpM = isd ? cw + pzpxM : NEGBIG, wpS = isd ? pzpxS : 0.0;
     if (isd) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
-    block_scan_ls2(wM, wS, wpM, wpS, lane, wv, K, wtot);
+    block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot);
+#ifdef PAR_DBG_EVID
+    ecy[4] = clock64();
+#endif
     // live log-sum-exp after every death (run_time_info.f90:683-709), one reference for the launch
     double refp;
     {
@@ -303,11 +375,20 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         for (int x = 0; x < PAR_W; ++x) refp = fmax(refp, wtot[x]);
         __syncthreads();
     }
+#ifdef PAR_DBG_EVID
+    ecy[5] = clock64();
+#endif
     const double lse0 = lseSum0 * exp(lseRef0 - refp);
     const double de = isd ? exp(Ladd - refp) - exp(L - refp) : 0.0;
     const double lsei = lse0 + block_scan_add(de, lane, wv, wtot);
+#ifdef PAR_DBG_EVID
+    ecy[6] = clock64();
+#endif
     sZi[tid] = Zi; sLse[tid] = lsei;
     __syncthreads();
+#ifdef PAR_DBG_EVID
+    ecy[7] = clock64();
+#endif
 
     cyc[ncy++] = clock64();
     // ---- phase 8: the first step at which the reference's loop would have stopped
@@ -322,16 +403,14 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             while (Xp0 + (double)kupd * d01 > tx) kupd++;
         }
     }
-    auto check = [&](int t) __attribute__((always_inline)) {
-        const int kb = prefix_bits(amask, t), vb = prefix_bits(vmask, t);
+    // last accepted step before my wave's first step, dead records before every step
+    int tlw = -1;
+    for (int x = wv - 1; x >= 0; --x) { const u64 word = amask[x]; if (word) { tlw = x * 64 + 63 - __clzll((long long)word); break; } }
+    parA[tid] = vp;
+    __syncthreads();
+    auto check = [&](int t, int kb, int vb, int tl) __attribute__((always_inline)) {
         const int ndead_b = ndead0 + vb;
-        int tl = -1;                                      // last accepted step before t
-        for (int x = PAR_W - 1; x >= 0; --x) {
-            u64 word = amask[x];
-            if (x > (t >> 6)) word = 0ull; else if (x == (t >> 6)) word &= (1ull << (t & 63)) - 1ull;
-            if (word) { tl = x * 64 + 63 - __clzll((long long)word); break; }
-        }
-        const int fb = (tl >= 0) ? vb - prefix_bits(vmask, tl) - 1 : fail0 + vb;
+        const int fb = (tl >= 0) ? vb - parA[tl] - 1 : fail0 + vb;      // consecutive failed spawns before t
         bool more = true;                                 // more_samples_needed (nested_sampling.F90:514-543)
         if (S.max_ndead == 0) more = false;
         else if (S.max_ndead > 0 && ndead_b >= S.max_ndead) more = false;
@@ -346,14 +425,23 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         else if (tv && ndead_b >= S.Dcap) code = (t << 2) | 2;
         else if (ta && kb + 1 == kupd) code = ((t + 1) << 2) | 0;
         if (code != 0x7fffffff) atomicMin(&ish[0], code);
-        return fb;
     };
-    if (tid <= T) check(tid);
-    if (T == PAR_NT && tid == 0) check(PAR_NT);
+    {
+        const u64 mw = amask[wv] & ((1ull << lane) - 1ull);
+        const int tl = mw ? wv * 64 + 63 - __clzll((long long)mw) : tlw;
+        if (tid < T) check(tid, kt, vp, tl);
+        if (tid == T - 1) {                               // the state after the last step of the nursery
+            const int tl2 = acc ? tid : tl;
+            check(T, kt + (acc ? 1 : 0), vp + (valid ? 1 : 0), tl2);
+        }
+    }
     __syncthreads();
 
     cyc[ncy++] = clock64();
     // ---- phase 9: truncate at the trigger and publish
+#ifdef PAR_DBG_PUBLISH
+    long long pcy[8]; pcy[0] = clock64();
+#endif
     const int code = ish[0];
     const int ts = code >> 2, pri = code & 3;
     const int Kp = prefix_bits(amask, ts), vps = prefix_bits(vmask, ts);
@@ -365,11 +453,15 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ls_comb(wM, wS, logZ20, 1.0); ls_comb(wpM, wpS, Zp20, 1.0);
         fin[4] = ls_val(wM, wS); fin[5] = ls_val(wpM, wpS); fin[6] = lsei; fin[7] = L;
     }
+    {
+        int nls = (inT && tid < ts) ? nl : 0;
+        for (int k = 32; k > 0; k >>= 1) nls += __shfl_xor(nls, k);
+        if (lane == 0 && nls) atomicAdd(&ish[1], nls);
+    }
     if (inT && tid < ts) {
-        atomicAdd(&ish[1], nl);
         PcPlan *pw = S.plan + w;
         const double Lg = key2d(gk);
-        pw->ph_cuid = cuid; pw->ph_count = -1; pw->ph_base = 0;
+        pw->ph_cuid = cuid;
         pw->contour = valid ? Lg : PC_HUGE;               // chains of an old epoch get no phantoms
         pw->dead_idx = valid ? ndead0 + vp : -1;
         if (acc) {
@@ -380,9 +472,49 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             pw->dead_src = -(1 + w); pw->logw = S.logzero; pw->postX = 0.0; pw->postZ = 0.0; pw->dead_cuid = 0xFFFFFFFFu;
         }
     }
+#ifdef PAR_DBG_PUBLISH
+    pcy[1] = clock64();
+#endif
+    // phantoms of the consumed chains (run_time_info.f90:747-757): the babies above the contour their
+    // chain was consumed at; masks, counts and row offsets in consumption order (deterministic layout)
+    int phc = 0;
+    if (inT && tid < ts) {
+        // slice-major copy of the babies' logL: lane = chain, every load of the wave is one contiguous run
+        PcPlan *pw = S.plan + w;
+        const double Lg = valid ? key2d(gk) : PC_HUGE;
+        const double *bl = S.baby_logL_T + w;
+        for (int mw = 0; mw < (nr + 62) / 64; ++mw) {
+            unsigned long long mask = 0ull;
+            const int i1 = min(nr - 1, mw * 64 + 64);
+            for (int i0 = mw * 64; i0 < i1; i0 += 8) {    // eight independent loads in flight
+                double v8[8];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) v8[u] = (i0 + u < i1) ? bl[(size_t)(i0 + u) * S.B] : -PC_HUGE;
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) if (v8[u] > Lg) mask |= 1ull << ((i0 + u) & 63);
+            }
+            pw->ph_mask[mw] = mask;
+            phc += __popcll(mask);
+        }
+    }
+#ifdef PAR_DBG_PUBLISH
+    pcy[2] = clock64();
+#endif
+    int phi = phc;                                        // inclusive prefix over the steps
+    for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(phi, k); if (lane >= k) phi += o; }
+    if (lane == 63) accStep[wv] = phi;
     for (int s = tid; s < Ncap; s += PAR_NT) S.slot_src[s] = -1;
     if (lane == 0) accR[wv] = 0ull;
     __syncthreads();
+    {
+        int pbase = nph0;
+        for (int x = 0; x < wv; ++x) pbase += accStep[x];
+        if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = pbase + phi - phc; pw->ph_count = phc; }
+        if (tid == PAR_NT - 1) ish[2] = pbase + phi;     // rows in use after this launch
+    }
+#ifdef PAR_DBG_PUBLISH
+    pcy[3] = clock64();
+#endif
     const bool accT = acc && tid < ts;
     if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));
     __syncthreads();
@@ -394,6 +526,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         S.live_logL[sl] = key2d(ck); S.slot_src[sl] = w;
         S.sort_key[pos2 - Kp] = ck; S.sort_slot[pos2 - Kp] = sl;
     }
+#ifdef PAR_DBG_PUBLISH
+    pcy[4] = clock64();
+#endif
     // the sorted order of the new live set: the survivors merged into what is left of the snapshot
     for (int idx = tid; idx < n; idx += PAR_NT) {
         const u64 sk = sSortK[idx];
@@ -402,6 +537,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         const int p2 = idx + lo;
         if (p2 >= Kp) { S.sort_key[p2 - Kp] = sk; S.sort_slot[p2 - Kp] = sSort[idx]; }
     }
+#ifdef PAR_DBG_PUBLISH
+    pcy[5] = clock64();
+#endif
     if (tid == 0) {
         const double Xp = Xp0 + (double)Kp * d01, XX = XX0 + (double)Kp * d02;
         const double lse_e = Kp ? fin[6] : lse0;
@@ -420,19 +558,26 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ctl->failures = (tl >= 0) ? vps - prefix_bits(vmask, tl) - 1 : fail0 + vps;
         ctl->status = status; ctl->error = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
         ctl->i_nursery = T - ts; ctl->ndead = ndead0 + vps; ctl->seg_hi = T - 1; ctl->seg_lo = T - ts; ctl->cluster_deleted = 0;
-        ctl->nlike += ish[1]; ctl->niter += ts;
+        ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2];
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
         if (S.use_prec) ctl->live_logZ = refp + log(lse_e) - l0 + Xp;
         cyc[ncy++] = clock64();
+#ifdef PAR_DBG_EVID
+        for (int x = 0; x < 7; ++x) ctl->dbg[x] += ecy[x + 1] - ecy[x];
+#elif defined(PAR_DBG_PUBLISH)
+        pcy[6] = clock64();
+        for (int x = 0; x < 6; ++x) ctl->dbg[x] += pcy[x + 1] - pcy[x];
+#else
         for (int x = 0; x + 1 < ncy && x < 8; ++x) ctl->dbg[x] += cyc[x + 1] - cyc[x];
+#endif
     }
 }
 
 static size_t par_lds(const PcState *S)
 {
     const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
-    return 8 * (NS + 4 * PAR_NT + 64 + 3 * PAR_W + PAR_NT + 64 + 16) + 4 * (NS + 7 * PAR_NT + 64 + 16) + 64;
+    return 8 * (NS + 4 * PAR_NT + 64 + 3 * PAR_W + PAR_NT + 64 + 16) + 4 * (2 * NS + 7 * PAR_NT + 2 * 64 + 16) + 64;
 }
 
 extern "C" int pc_par_fits(const PcState *S) { return par_lds(S) <= 160 * 1024 && S->B <= PAR_NT; }

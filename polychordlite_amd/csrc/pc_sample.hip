@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch)
             for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
             row[S.b0] = contour;                    // nested_sampling.F90:260
             row[S.l0] = lnew;
-            S.baby_logL[(size_t)chain * nr + s] = lnew;
+            S.baby_logL[(size_t)chain * nr + s] = lnew; S.baby_logL_T[(size_t)s * S.B + chain] = lnew;
         }
     }
     if (lane == 0) S.ch_nlike[chain] = C.nlike;

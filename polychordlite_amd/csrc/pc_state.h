@@ -87,6 +87,7 @@ struct PcState {
     // ---- nursery (one synchronous batch of B chains)
     double *babies;              // [B][nr][nT]
     double *baby_logL;           // [B][nr]
+    double *baby_logL_T;         // [nr][B] the same values, slice-major (read by the parallel contraction, lane = chain)
     int *ch_cluster, *ch_epoch, *ch_nlike, *ch_seed_slot;
     double *ch_contour;          // [B] contour each chain sampled under
     double *nhat;                // [B][nr][D] whitened, normalised directions (generation order)
