@@ -859,6 +859,86 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
 }
 
 // ------------------------------------------------------------------------------------------
+// initial values of the per-cluster state and of the control block (initialise_run_time_info,
+// run_time_info.f90:164-206): one launch instead of a dozen small host copies
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_state(PcState S, double logzero)
+{
+    const int tid = threadIdx.x, maxc = S.maxc, D = S.D;
+    for (int m = tid; m < maxc; m += 256) {
+        S.logZp[m] = logzero; S.logZXp[m] = logzero; S.logZp2[m] = logzero; S.logZpXp[m] = logzero; S.logLp[m] = logzero;
+        S.logXp[m] = 0.0; S.lse_ref[m] = 0.0; S.lse_sum[m] = 0.0; S.death_thr[m] = -PC_HUGE;
+        S.cl_n[m] = 0; S.cl_uid[m] = 0u; S.imin_slot[m] = 0;
+    }
+    for (int e = tid; e < maxc * maxc; e += 256) S.XpXq[e] = 0.0;
+    for (size_t e = tid; e < (size_t)maxc * D * D; e += 256) {
+        const int r = (int)(e % ((size_t)D * D));
+        const double v = (r / D == r % D) ? 1.0 : 0.0;
+        S.chol[e] = v; S.cov[e] = v;
+    }
+    if (tid == 0) {
+        PcCtl c0{};
+        c0.status = PC_ST_RUNNING; c0.ncluster = 1; c0.logZ = logzero; c0.logZ2 = logzero;
+        c0.logX_last_update = 0.0; c0.next_cluster_uid = 1; c0.live_logZ = logzero;
+        *S.ctl = c0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// posterior moments of theta from the dead points: weights exp(logw + logL - max), fixed-order sums
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_max(PcState S, int nd, double *pmax)
+{
+    __shared__ double red[256];
+    double m = -PC_HUGE;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nd; i += gridDim.x * 256) {
+        const double lw = S.dead_logw[i];
+        if (lw > S.logzero) m = fmax(m, lw + S.dead[(size_t)i * S.nT + S.l0]);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]); __syncthreads(); }
+    if (threadIdx.x == 0) pmax[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const double *pmax, double *part /* [grid][2D+1] */)
+{
+    // thread = (row group g, coordinate d); group g takes rows blockIdx*G+g, +gridDim*G, ... in order
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    const int tid = threadIdx.x, D = S.D;
+    const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
+    double m = -PC_HUGE;
+    for (int b = 0; b < (int)gridDim.x; ++b) m = fmax(m, pmax[b]);
+    for (int d0 = 0; d0 < D; d0 += DPc) {
+        const int d = d0 + tid % DPc;
+        double s1 = 0.0, s2 = 0.0, sw = 0.0;
+        for (int i = blockIdx.x * G + g; i < nd; i += gridDim.x * G) {
+            const double lw = S.dead_logw[i];
+            if (!(lw > S.logzero)) continue;
+            const double *row = S.dead + (size_t)i * S.nT;
+            const double wgt = exp(lw + row[S.l0] - m);
+            sw += wgt;
+            if (d < D) { const double th = row[S.p0 + d]; s1 += wgt * th; s2 += wgt * th * th; }
+        }
+        red[tid] = s1; red2[tid] = s2;
+        __syncthreads();
+        if (tid < DPc && d < D) {
+            double a = 0.0, b2 = 0.0;
+            for (int gg = 0; gg < G; ++gg) { a += red[gg * DPc + tid]; b2 += red2[gg * DPc + tid]; }
+            part[(size_t)blockIdx.x * (2 * D + 1) + d] = a; part[(size_t)blockIdx.x * (2 * D + 1) + D + d] = b2;
+        }
+        __syncthreads();
+        if (d0 == 0) {
+            red[tid] = (tid % DPc == 0) ? sw : 0.0;
+            __syncthreads();
+            if (tid == 0) { double a = 0.0; for (int gg = 0; gg < G; ++gg) a += red[gg * DPc]; part[(size_t)blockIdx.x * (2 * D + 1) + 2 * D] = a; }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static size_t consume_lds(const PcState *S, int NT, int xrows)
@@ -944,4 +1024,17 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
     hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nchunk, pcov, count);
     return 0;
+}
+
+extern "C" void pc_launch_init_state(const PcState *S, double logzero, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(256), 0, st, *S, logzero);
+}
+
+#define PC_POST_BLOCKS 128
+extern "C" int pc_post_blocks(void) { return PC_POST_BLOCKS; }
+extern "C" void pc_launch_post_moments(const PcState *S, int nd, double *pmax, double *part, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_post_max, dim3(PC_POST_BLOCKS), dim3(256), 0, st, *S, nd, pmax);
+    hipLaunchKernelGGL(k_post_moments, dim3(PC_POST_BLOCKS), dim3(256), 0, st, *S, nd, pmax, part);
 }

@@ -43,6 +43,9 @@ void pc_launch_ph_rehome(const PcState *, int, int, const unsigned *, int, int *
 void pc_launch_slice_tick(const PcState *, unsigned, int, void *, double *, int *, double *, const double *, const double *,
                           const double *, int, int *, int *, hipStream_t);
 size_t pc_chain_state_size(void);
+void pc_launch_init_state(const PcState *, double, hipStream_t);
+int pc_post_blocks(void);
+void pc_launch_post_moments(const PcState *, int, double *, double *, hipStream_t);
 int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
 }
 
@@ -117,6 +120,36 @@ template <class T> void dfree(T *&p) { if (p) dcache().put((void *)p); p = nullp
 template <class T> T *halloc(size_t n) { return (T *)hcache().get(sizeof(T) * (n ? n : 1)); }
 void hfree(void *p) { if (p && !hcache().put(p)) std::free(p); }
 
+// streams and events are pooled for the same reason (creation / destruction synchronise with the driver)
+struct HandlePool {
+    std::mutex m;
+    std::vector<std::pair<int, hipStream_t>> streams;
+    std::vector<std::pair<int, hipEvent_t>> events;
+    hipStream_t get_stream()
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < streams.size(); ++i)
+                if (streams[i].first == dev) { hipStream_t s = streams[i].second; streams.erase(streams.begin() + i); return s; }
+        }
+        hipStream_t s; HIPCHK(hipStreamCreate(&s)); return s;
+    }
+    void put_stream(hipStream_t s) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); streams.push_back({dev, s}); }
+    hipEvent_t get_event()
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = events.size(); i-- > 0;)
+                if (events[i].first == dev) { hipEvent_t e = events[i].second; events.erase(events.begin() + i); return e; }
+        }
+        hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;
+    }
+    void put_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); events.push_back({dev, e}); }
+};
+HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
+
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
 
 // HIP-event stopwatch per kernel class, on the engine's own stream (bench.py's roofline numbers)
@@ -128,7 +161,7 @@ struct KTimer {
     struct Span { int k; hipEvent_t a, b; };
     std::vector<Span> open;
     double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
-    hipEvent_t get() { if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); } return pool[used++]; }
+    hipEvent_t get() { if (used == pool.size()) pool.push_back(hpool().get_event()); return pool[used++]; }
     hipEvent_t begin() { if (!on) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
     void end(int k, hipEvent_t a) { if (!on) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
     void collect() {   // call after a stream synchronisation
@@ -136,7 +169,7 @@ struct KTimer {
         for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
         open.clear(); used = 0;
     }
-    void destroy() { for (auto e : pool) hipEventDestroy(e); pool.clear(); }
+    void destroy() { for (auto e : pool) hpool().put_event(e); pool.clear(); }
 };
 
 // host copy of the device's counter RNG (pc_dev.h), used when the host evaluates the likelihood
@@ -172,6 +205,8 @@ struct Engine {
     std::vector<double> h_lo, h_hi;
     PcState S{};
     hipStream_t st = nullptr;
+    hipStream_t st_copy = nullptr;            // dead rows leave for the host while the run goes on
+    double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
     PcCtl *h_ctl = nullptr;       // pinned mirror
     // alternate phantom buffers + scratch for the update step
     double *ph2 = nullptr, *phL2 = nullptr; unsigned *phC2 = nullptr; unsigned long long *phU2 = nullptr;
@@ -204,7 +239,7 @@ struct Engine {
             std::abort();
         }
         HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
-        HIPCHK(hipStreamCreate(&st));
+        st = hpool().get_stream(); st_copy = hpool().get_stream();
         kt.on = c.profile != 0; kt.st = st;
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
@@ -293,29 +328,11 @@ struct Engine {
             HIPCHK(hipMemset(d_cs, 0, pc_chain_state_size() * B));
         }
         h_ctl = halloc<PcCtl>(1);
-        // per-cluster initial values (initialise_run_time_info, run_time_info.f90:164-206)
-        std::vector<double> lz(maxc, c.logzero), zero(maxc, 0.0), hugeneg(maxc, -PC_HUGE);
-        std::vector<double> xq((size_t)maxc * maxc, 0.0), eye((size_t)maxc * D * D, 0.0);
-        for (int m = 0; m < maxc; ++m) for (int d = 0; d < D; ++d) eye[(size_t)m * D * D + d * D + d] = 1.0;
-        HIPCHK(hipMemcpy(S.logZp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.logZXp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.logZp2, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.logZpXp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.logLp, lz.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.logXp, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.lse_ref, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.lse_sum, zero.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.death_thr, hugeneg.data(), sizeof(double) * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.XpXq, xq.data(), sizeof(double) * maxc * maxc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.chol, eye.data(), sizeof(double) * maxc * D * D, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(S.cov, eye.data(), sizeof(double) * maxc * D * D, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(S.cl_n, 0, sizeof(int) * maxc));
-        HIPCHK(hipMemset(S.cl_uid, 0, sizeof(unsigned) * maxc));
-        HIPCHK(hipMemset(S.imin_slot, 0, sizeof(int) * maxc));
+        // per-cluster initial values and the control block (initialise_run_time_info, run_time_info.f90:164-206)
+        pc_launch_init_state(&S, c.logzero, st);
         PcCtl c0{};
         c0.status = PC_ST_RUNNING; c0.ncluster = 1; c0.logZ = c.logzero; c0.logZ2 = c.logzero;
         c0.logX_last_update = 0.0; c0.next_cluster_uid = 1; c0.live_logZ = c.logzero;
-        HIPCHK(hipMemcpy(S.ctl, &c0, sizeof(PcCtl), hipMemcpyHostToDevice));
         *h_ctl = c0;
     }
 
@@ -330,6 +347,7 @@ struct Engine {
     {   // the next batch may append B*nr phantoms and B dead points
         if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) {
             const int nd = S.Dcap * 2;
+            HIPCHK(hipStreamSynchronize(st_copy));        // rows still travelling from the old array
             auto grow = [&](auto *&p, size_t per) {
                 using T = std::remove_reference_t<decltype(*p)>;
                 T *q = dalloc<T>((size_t)nd * per);
@@ -681,10 +699,22 @@ struct Engine {
         }
     }
 
+    // Dead rows are append-only: everything below ctl.ndead is final once the round's kernels have been
+    // synchronised, so it can travel to the pinned result buffer on a second stream during the run.
+    void stream_dead()
+    {
+        const size_t nd = (size_t)h_ctl->ndead;
+        if (!h_dead || nd > h_dead_cap || nd <= h_dead_copied) return;
+        HIPCHK(hipMemcpyAsync(h_dead + h_dead_copied * S.nT, S.dead + h_dead_copied * S.nT,
+                              sizeof(double) * (nd - h_dead_copied) * S.nT, hipMemcpyDeviceToHost, st_copy));
+        h_dead_copied = nd;
+    }
+
     int run(pchip_result *out)
     {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
+        h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
         if (callback_mode) generate_live_callback(); else generate_live();
         if (g_stop_requested) return 5;
         auto t1 = clk::now();
@@ -726,6 +756,7 @@ struct Engine {
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             read_ctl();
+            stream_dead();
             tm.rounds++;
             if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; }
         }
@@ -757,12 +788,16 @@ struct Engine {
         if (cfg.feedback >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3]);
         if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg par: stage+search %lld rank-sort %lld accept %lld merge+slots %lld evidence %lld triggers %lld publish %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4], h_ctl->dbg[5], h_ctl->dbg[6]);
         if (cfg.feedback == 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) accept-steps %lld (%lld) ins-rescan %lld (%lld) reject-steps cycles %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
-        out->dead = halloc<double>((size_t)std::max(1, h_ctl->ndead) * nT);
+        if ((size_t)h_ctl->ndead > h_dead_cap) {          // the dead array grew beyond the first estimate
+            HIPCHK(hipStreamSynchronize(st_copy));
+            hfree(h_dead); h_dead_cap = (size_t)h_ctl->ndead; h_dead = halloc<double>(h_dead_cap * nT); h_dead_copied = 0;
+        }
+        stream_dead();
+        out->dead = h_dead; h_dead = nullptr;
         out->logweights = halloc<double>(std::max(1, h_ctl->ndead));
-        HIPCHK(hipMemcpy(out->dead, S.dead, sizeof(double) * (size_t)h_ctl->ndead * nT, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(out->logweights, S.dead_logw, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(out->logweights, S.dead_logw, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost, st_copy));
         out->entry = halloc<double>(std::max(1, h_ctl->ndead));
-        HIPCHK(hipMemcpy(out->entry, S.dead_entry, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(out->entry, S.dead_entry, sizeof(double) * h_ctl->ndead, hipMemcpyDeviceToHost, st_copy));
         int nl = 0;
         for (int s = 0; s < S.Ncap; ++s) nl += hcl[s] >= 0;
         out->nlive_final = nl;
@@ -776,20 +811,21 @@ struct Engine {
         HIPCHK(hipMemcpy(zp.data(), S.logZp_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(zp2.data(), S.logZp2_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
         for (int i = 0; i < ncd; ++i) { out->logZp[i] = 2 * zp[i] - 0.5 * zp2[i]; out->varlogZp[i] = zp2[i] - 2 * zp[i]; }
-        // posterior moments of theta from the dead points
-        const int D = S.D;
+        // posterior moments of theta from the dead points (device reduction, fixed order)
+        const int D = S.D, nb = pc_post_blocks(), pw = 2 * D + 1;
         out->post_mean = (double *)std::calloc(D, sizeof(double)); out->post_var = (double *)std::calloc(D, sizeof(double));
-        double m = -PC_HUGE;
-        for (long i = 0; i < out->ndead; ++i)
-            if (out->logweights[i] > cfg.logzero) m = std::max(m, out->logweights[i] + out->dead[(size_t)i * nT + S.l0]);
+        double *d_pmax = dalloc<double>(nb), *d_part = dalloc<double>((size_t)nb * pw), *h_part = halloc<double>((size_t)nb * pw);
+        pc_launch_post_moments(&S, h_ctl->ndead, d_pmax, d_part, st);
+        HIPCHK(hipMemcpyAsync(h_part, d_part, sizeof(double) * nb * pw, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         double sw = 0.0;
-        for (long i = 0; i < out->ndead; ++i) {
-            if (!(out->logweights[i] > cfg.logzero)) continue;
-            const double wgt = std::exp(out->logweights[i] + out->dead[(size_t)i * nT + S.l0] - m);
-            sw += wgt;
-            for (int d = 0; d < D; ++d) { const double th = out->dead[(size_t)i * nT + S.p0 + d]; out->post_mean[d] += wgt * th; out->post_var[d] += wgt * th * th; }
+        for (int b = 0; b < nb; ++b) {
+            sw += h_part[(size_t)b * pw + 2 * D];
+            for (int d = 0; d < D; ++d) { out->post_mean[d] += h_part[(size_t)b * pw + d]; out->post_var[d] += h_part[(size_t)b * pw + D + d]; }
         }
         for (int d = 0; d < D; ++d) { out->post_mean[d] /= sw; out->post_var[d] = out->post_var[d] / sw - out->post_mean[d] * out->post_mean[d]; }
+        dfree(d_pmax); dfree(d_part); hfree(h_part);
+        HIPCHK(hipStreamSynchronize(st_copy));
         return 0;
     }
 
@@ -808,8 +844,10 @@ struct Engine {
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
         kt.destroy();
+        if (h_dead) { hfree(h_dead); h_dead = nullptr; }
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
-        if (st) hipStreamDestroy(st); st = nullptr;
+        if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
+        if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
     }
 };
 
