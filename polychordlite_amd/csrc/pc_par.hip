@@ -563,7 +563,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (pri == 0) ctl->logX_last_update = Xp;
         if (S.use_prec) ctl->live_logZ = refp + log(lse_e) - l0 + Xp;
         cyc[ncy++] = clock64();
-#ifdef PAR_DBG_EVID
+#ifdef PAR_NO_DBG
+#elif defined(PAR_DBG_EVID)
         for (int x = 0; x < 7; ++x) ctl->dbg[x] += ecy[x + 1] - ecy[x];
 #elif defined(PAR_DBG_PUBLISH)
         pcy[6] = clock64();

@@ -148,6 +148,16 @@ __global__ __launch_bounds__(64) void k_generate_live(PcState S, int attempt0, d
 __device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, int chain, int &sel, int &slot)
 {   // GenerateSeed, generate.F90:42-53; random_integer_P random_utils.F90:548-576
     const int nc = S.ctl->ncluster;
+    if (nc == 1) {       // one cluster: the volume-weighted draw (generate.F90:36-41) can only return it
+        sel = 0;
+        const double u2s = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+        const int ns = S.cl_n[0];
+        int is = (int)ceil(u2s * ns);
+        is = is < 1 ? 1 : (is > ns ? ns : is);
+        slot = S.cl_list[is - 1];
+        if (S.seed_override) slot = chain;
+        return;
+    }
     double m = S.logXp[0];
     for (int c = 1; c < nc; ++c) m = fmax(m, S.logXp[c]);
     double sum = 0.0;
@@ -173,8 +183,11 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = S.D, nr = S.nr;
     double *G = (double *)smem;          // [D*D] deviates, vector-major
-    double *Q = G + (size_t)D * D;       // [D] broadcast of the finished vector
-    int *sh = (int *)(Q + D);            // [2] chosen cluster, seed slot
+    double *Q = G + (size_t)(D + 8) * (D + 8);   // [2][DMAX] broadcast of the current vector (double buffered)
+    int *sh = (int *)(Q + 2 * DMAX);     // [2] chosen cluster, seed slot
+#ifdef NHATS_DBG
+    long long ncyc[8]; ncyc[0] = clock64();
+#endif
     const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
     if (tid == 0) {
         int sel, slot;
@@ -187,6 +200,9 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
             if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
         }
     }
+#ifdef NHATS_DBG
+    ncyc[1] = clock64();
+#endif
     // gaussian deviates: index (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT
     const uint32_t e0 = (uint32_t)basis * D * D, e1 = e0 + (uint32_t)D * D;
     for (uint32_t call = (e0 >> 1) + tid; call <= ((e1 - 1) >> 1); call += NT) {
@@ -197,64 +213,128 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
     }
     __syncthreads();
+#ifdef NHATS_DBG
+    ncyc[2] = clock64();
+#endif
     const int i = tid;
     const bool active = i < D;
     double v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? G[(size_t)i * D + d] : 0.0;
+    // dot products run on four partial sums: a dependent fp64 add costs ~32 cycles, a 20-term serial dot 640
+#define PC_DOT4(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
+        _Pragma("unroll") for (int d = 0; d < DMAX; d += 4) { \
+            p0_ += (A)[d] * (B)[d]; p1_ += (A)[d + 1] * (B)[d + 1]; p2_ += (A)[d + 2] * (B)[d + 2]; p3_ += (A)[d + 3] * (B)[d + 3]; } \
+        RES = (p0_ + p1_) + (p2_ + p3_); }
+    // (register vectors are zero padded up to DMAX, LDS rows up to D + 8: no per-element bounds tests, which
+    //  cost a scalar compare-and-branch each)
     // random_direction (random_utils.F90:276-298): normalise the raw deviates
     {
-        double n2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
+        double n2;
+        PC_DOT4(n2, v, v)
         const double inrm = 1.0 / sqrt(n2);
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] * inrm;
+        for (int d = 0; d < DMAX; ++d) v[d] = v[d] * inrm;
     }
-    // Gram-Schmidt, row oriented: once vector j is final it is removed from every later vector.
-    // Per vector this is the same sequence of projections as random_utils.F90:391-399.
-    for (int j = 0; j < D; ++j) {
-        if (i == j) {
-            double n2 = 0.0;
+#ifdef NHATS_DBG
+    ncyc[3] = clock64();
+#endif
+    // Gram-Schmidt, row oriented (the projections of random_utils.F90:391-399 in the same order): at step j
+    // the vector v_j -- already orthogonal to its predecessors, not yet normalised -- is broadcast
+    // through LDS; every later vector removes its component along it, (v.q / q.q) q, while thread j
+    // normalises.  One barrier per step; q.q is recomputed by everybody instead of being broadcast.
+    double *Qb = Q;                                   // [2][QS] double buffer
+    const int QS = DMAX;
+    if (i == 0) {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) n2 += v[d] * v[d];
-            const double inrm = 1.0 / sqrt(n2);
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) { v[d] = v[d] * inrm; Q[d] = v[d]; }
-        }
-        __syncthreads();
-        if (active && i > j) {
-            double dot = 0.0;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) dot += v[d] * Q[d];
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) v[d] = v[d] - dot * Q[d];
-        }
-        __syncthreads();
-    }
-    // whitening  w = L.n  (chordal_sampling.f90:73).  The finished vectors go back to LDS
-    // (the deviate buffer is free now) so that the triangular product can index them.
-    const int col = basis * D + i;
-    if (active) {
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) if (d < D) G[(size_t)i * D + d] = v[d];
+        for (int d = 0; d < DMAX; ++d) Qb[d] = v[d];
     }
     __syncthreads();
-    if (active && col < nr) {
-        const double *Lc = S.chol + (size_t)sh[0] * D * D;
-        double *mine = G + (size_t)i * D;
-        double n2 = 0.0;
-        for (int a = D - 1; a >= 0; --a) {          // in place: row a only needs n[0..a]
-            double t = 0.0;
-            for (int b = 0; b <= a; ++b) t += Lc[(size_t)a * D + b] * mine[b];
-            mine[a] = t;
+#define PC_GS_STEP(QV) { \
+        double qq, dv; \
+        PC_DOT4(qq, QV, QV) \
+        PC_DOT4(dv, QV, v) \
+        if (i == j) { \
+            const double inrm = 1.0 / sqrt(qq); \
+            _Pragma("unroll") for (int d = 0; d < DMAX; ++d) v[d] = v[d] * inrm; \
+        } else if (active && i > j) { \
+            const double cproj = dv / qq; \
+            _Pragma("unroll") for (int d = 0; d < DMAX; ++d) v[d] = v[d] - cproj * (QV)[d]; \
+            if (i == j + 1) { \
+                double *qn = Qb + (size_t)((j + 1) & 1) * QS; \
+                _Pragma("unroll") for (int d = 0; d < DMAX; ++d) qn[d] = v[d]; \
+            } \
+        } }
+    for (int j = 0; j < D; ++j) {
+        const double *q = Qb + (size_t)(j & 1) * QS;
+        if constexpr (DMAX <= 32) {
+            double qv[DMAX];                          // registers: one LDS pass per step
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) qv[d] = q[d];
+            PC_GS_STEP(qv)
+        } else {
+            PC_GS_STEP(q)                             // large nDims: stream q from LDS, v alone fills the registers
         }
-        for (int d = 0; d < D; ++d) n2 += mine[d] * mine[d];
-        const double w = sqrt(n2), iw = 1.0 / w;           // chordal_sampling.f90:80-82
-        double *out = S.nhat + ((size_t)chain * nr + col) * D;
-        for (int d = 0; d < D; ++d) out[d] = mine[d] * iw;
-        S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+        __syncthreads();
     }
+#undef PC_GS_STEP
+#ifdef NHATS_DBG
+    ncyc[4] = clock64();
+#endif
+    // whitening  w = L.n  (chordal_sampling.f90:73)
+    const int col = basis * D + i;
+    if constexpr (DMAX <= 32) {
+        // the deviate buffer is free: it receives the Cholesky factor, every thread multiplies its own
+        // vector from registers; the D row sums are independent chains (row a adds b = 0..a in order)
+        const double *Lg = S.chol + (size_t)sh[0] * D * D;
+        for (int e = tid; e < D * D; e += NT) G[e] = Lg[e];
+        __syncthreads();
+        if (active && col < nr) {
+            double t[DMAX];
+#pragma unroll
+            for (int a = 0; a < DMAX; ++a) t[a] = 0.0;
+#pragma unroll
+            for (int b = 0; b < DMAX; ++b)
+#pragma unroll
+                for (int a = b; a < DMAX; ++a) t[a] += G[(size_t)a * D + b] * v[b];
+#pragma unroll
+            for (int a = 0; a < DMAX; ++a) if (a >= D) t[a] = 0.0;     // rows past D read padding
+            double n2;
+            PC_DOT4(n2, t, t)
+            const double w = sqrt(n2), iw = 1.0 / w;           // chordal_sampling.f90:80-82
+            double *out = S.nhat + ((size_t)chain * nr + col) * D;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) out[d] = t[d] * iw;
+            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+        }
+    } else {
+        // large nDims: the finished vectors go back to LDS so that the triangular product can index them
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) G[(size_t)i * D + d] = v[d];
+        }
+        __syncthreads();
+        if (active && col < nr) {
+            const double *Lc = S.chol + (size_t)sh[0] * D * D;
+            double *mine = G + (size_t)i * D;
+            double n2 = 0.0;
+            for (int a = D - 1; a >= 0; --a) {          // in place: row a only needs n[0..a]
+                double t = 0.0;
+                for (int b = 0; b <= a; ++b) t += Lc[(size_t)a * D + b] * mine[b];
+                mine[a] = t;
+            }
+            for (int d = 0; d < D; ++d) n2 += mine[d] * mine[d];
+            const double w = sqrt(n2), iw = 1.0 / w;           // chordal_sampling.f90:80-82
+            double *out = S.nhat + ((size_t)chain * nr + col) * D;
+            for (int d = 0; d < D; ++d) out[d] = mine[d] * iw;
+            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+        }
+    }
+#ifdef NHATS_DBG
+    ncyc[5] = clock64();
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += ncyc[x + 1] - ncyc[x];
+#endif
+#undef PC_DOT4
 }
 
 // ------------------------------------------------------------------------------------------
@@ -449,7 +529,7 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
 extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
     const int D = S->D, nb = (S->nr + D - 1) / D;
-    const size_t sh = sizeof(double) * ((size_t)D * D + D) + 16;
+    const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * (D + 8)) + 16;
     dim3 grid(nb, nchains);
     if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64>), grid, dim3(64), sh, st, *S, batch);
