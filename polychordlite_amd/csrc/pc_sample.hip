@@ -372,13 +372,64 @@ __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double 
     return logL;
 }
 
+// Two independent trial points at once (the two ends of the initial bracket): the per-point work is a
+// dependent chain (FMA -> compare -> reduction), so the second evaluation rides in the shadow of the first.
+// Straight-line code: both likelihoods are computed unconditionally and masked afterwards.
 template <int DPL, int NROWS>
-__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch)
+__device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double (&x0)[DPL], const double (&nh)[DPL],
+                                          double tA, double tB, double &lA, double &lB)
+{
+    const PcLike &L = C.S.like;
+    if (L.kind == PC_LIKE_CORR_GAUSSIAN) {          // uses the per-wave LDS scratch: one after the other
+        double cube[DPL], th[DPL];
+        lA = eval_at<DPL, NROWS>(C, x0, nh, tA, cube, th);
+        lB = eval_at<DPL, NROWS>(C, x0, nh, tB, cube, th);
+        return;
+    }
+    bool outA = false, outB = false;
+    double sA = 0.0, sB = 0.0, s2A = 0.0, s2B = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        const double cA = x0[k] + tA * nh[k], cB = x0[k] + tB * nh[k];
+        if (C.ld.on[k]) { outA |= (cA < 0.0) | (cA > 1.0); outB |= (cB < 0.0) | (cB > 1.0); }
+        const double thA = C.ld.lo[k] + C.ld.span[k] * cA, thB = C.ld.lo[k] + C.ld.span[k] * cB;
+        if (C.ld.on[k]) {
+            if (L.kind == PC_LIKE_GAUSSIAN) {
+                const double zA = (thA - L.mu) * L.inv_sigma, zB = (thB - L.mu) * L.inv_sigma;
+                sA += zA * zA; sB += zB * zB;
+            } else if (L.kind == PC_LIKE_RASTRIGIN) {
+                sA += 8.515435146961291 + thA * thA - 10.0 * cos(PC_TWO_PI * thA);
+                sB += 8.515435146961291 + thB * thB - 10.0 * cos(PC_TWO_PI * thB);
+            } else {
+                const int dim = C.lane + 64 * k;
+                const double m1 = dim < 2 ? -0.5 : 0.0, m2 = dim < 2 ? 0.5 : 0.0;
+                const double a1 = (thA - m1) * L.inv_sigma, a2 = (thA - m2) * L.inv_sigma;
+                const double b1 = (thB - m1) * L.inv_sigma, b2 = (thB - m2) * L.inv_sigma;
+                sA += a1 * a1; s2A += a2 * a2; sB += b1 * b1; s2B += b2 * b2;
+            }
+        }
+    }
+    const bool oa = __ballot(outA) != 0ull, ob = __ballot(outB) != 0ull;
+    sA = wsum<DPL, NROWS>(sA); sB = wsum<DPL, NROWS>(sB);
+    if (L.kind == PC_LIKE_GAUSSIAN) { lA = L.norm - sA / 2.0; lB = L.norm - sB / 2.0; }
+    else if (L.kind == PC_LIKE_RASTRIGIN) { lA = -sA; lB = -sB; }
+    else {
+        s2A = wsum<DPL, NROWS>(s2A); s2B = wsum<DPL, NROWS>(s2B);
+        lA = pc_logaddexp(L.norm - sA / 2.0, L.norm - s2A / 2.0) - 0.6931471805599453;
+        lB = pc_logaddexp(L.norm - sB / 2.0, L.norm - s2B / 2.0) - 0.6931471805599453;
+    }
+    if (oa) lA = C.S.logzero; else if (lA > C.S.logzero) C.nlike++;     // calculate.f90:36-38
+    if (ob) lB = C.S.logzero; else if (lB > C.S.logzero) C.nlike++;
+}
+
+template <int DPL, int NROWS>
+__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *ybuf = (double *)smem;                 // [D] (corr gaussian only)
     int *sdeck = (int *)(ybuf + S.D);              // [nr] deck, only used when nr > 64
     int *sj = sdeck + S.nr;                        // [nr]
+    double *tbuf = ybuf + S.D + S.nr;              // [nr][D+1] theta of every baby (when it fits: phi_lds)
     const int lane = threadIdx.x, chain = blockIdx.x;
     const int D = S.D, nr = S.nr, nT = S.nT;
     const double logzero = S.logzero;
@@ -473,8 +524,8 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch)
         // initial bracket (chordal_sampling.f90:213-219)
         const double u0 = next_u();
         double tR = (1 - u0) * w, tL = -(u0 * w);
-        double lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th);
-        double lL = eval_at<DPL, NROWS>(C, x0, nh, tL, cube, th);
+        double lR, lL;
+        eval_pair<DPL, NROWS>(C, x0, nh, tR, tL, lR, lL);
         // stepping out (:223-236)
         int istep = 0;
         while (lR >= contour && lR > logzero) { istep++; tR = w * istep; lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th); }
@@ -492,24 +543,54 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch)
         }
         if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
         // the baby becomes the next start point (chordal_sampling.f90:85-88)
-        double phi0, phi1;
-        like_phi<DPL, NROWS>(S, th, ld, lane, phi0, phi1);
         double *row = S.babies + ((size_t)chain * nr + s) * nT;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             x0[k] = cube[k];
             if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[S.p0 + lane + 64 * k] = th[k]; }
         }
+        if (phi_lds) {
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) if (ld.on[k]) tbuf[(size_t)s * (D + 1) + lane + 64 * k] = th[k];
+        } else if (S.nDer > 0) {
+            double phi0, phi1;
+            like_phi<DPL, NROWS>(S, th, ld, lane, phi0, phi1);
+            if (lane == 0) {
+                row[S.d0] = phi0;
+                if (S.nDer >= 2) row[S.d0 + 1] = phi1;
+                for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
+            }
+        }
         if (lane == 0) {
-            if (S.nDer >= 1) row[S.d0] = phi0;
-            if (S.nDer >= 2) row[S.d0 + 1] = phi1;
-            for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
             row[S.b0] = contour;                    // nested_sampling.F90:260
             row[S.l0] = lnew;
             S.baby_logL[(size_t)chain * nr + s] = lnew; S.baby_logL_T[(size_t)s * S.B + chain] = lnew;
         }
     }
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
+    // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
+    // one sqrt / log per chain instead of one per slice on the chain's critical path
+    if (S.nDer > 0 && phi_lds) {
+        __syncthreads();                            // one wave per workgroup: orders the LDS writes above
+        for (int s0 = 0; s0 < nr; s0 += 64) {
+            const int s = s0 + lane;
+            if (s >= nr) continue;
+            double *row = S.babies + ((size_t)chain * nr + s) * nT;
+            const double *tt = tbuf + (size_t)s * (D + 1);
+            double phi0 = 0.0, phi1 = 0.0;
+            if (S.like.kind == PC_LIKE_GAUSSIAN) {
+                double r2 = 0.0;
+                for (int d = 0; d < D; ++d) { const double z = tt[d] - S.like.mu; r2 += z * z; }
+                phi0 = sqrt(r2);
+                if (S.nDer >= 2) phi1 = pc_log_ball(phi0, D, S.like.log_vn);
+            } else if (S.like.kind == PC_LIKE_TWIN_GAUSSIAN) {
+                phi0 = (tt[0] > 0.5) ? 1.0 : -1.0;
+            }
+            row[S.d0] = phi0;
+            if (S.nDer >= 2) row[S.d0 + 1] = phi1;
+            for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -543,13 +624,17 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
 
 extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
-    const size_t sh = sizeof(double) * S->D + sizeof(int) * 2 * (size_t)S->nr + 16;
+    // theta of every baby stays in LDS (derived parameters at the end of the chain) when it fits
+    const size_t sh0 = sizeof(double) * ((size_t)S->D + S->nr) + 16;     // ybuf + two int decks
+    const size_t tb = sizeof(double) * (size_t)S->nr * (S->D + 1);
+    const int phi_lds = (S->nDer > 0 && sh0 + tb <= 48 * 1024) ? 1 : 0;
+    const size_t sh = sh0 + (phi_lds ? tb : 0);
     const int D = S->D;
-    if (D <= 16) hipLaunchKernelGGL((k_slice<1, 1>), dim3(nchains), dim3(64), sh, st, *S, batch);
-    else if (D <= 32) hipLaunchKernelGGL((k_slice<1, 2>), dim3(nchains), dim3(64), sh, st, *S, batch);
-    else if (D <= 64) hipLaunchKernelGGL((k_slice<1, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
-    else if (D <= 128) hipLaunchKernelGGL((k_slice<2, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
-    else if (D <= 256) hipLaunchKernelGGL((k_slice<4, 4>), dim3(nchains), dim3(64), sh, st, *S, batch);
+    if (D <= 16) hipLaunchKernelGGL((k_slice<1, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
+    else if (D <= 32) hipLaunchKernelGGL((k_slice<1, 2>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
+    else if (D <= 64) hipLaunchKernelGGL((k_slice<1, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
+    else if (D <= 128) hipLaunchKernelGGL((k_slice<2, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
+    else if (D <= 256) hipLaunchKernelGGL((k_slice<4, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
     else return 1;
     return 0;
 }
