@@ -347,6 +347,9 @@ struct ChainCtx {
     int lane;
     double *ybuf;
     int nlike;
+    // gaussian likelihood + uniform prior: along a slice z_d(t) = gA_d + t gB_d (set once per slice), so an
+    // evaluation is fma -> square -> reduction instead of fma -> fma -> sub -> mul -> square -> reduction
+    double gA[DPL], gB[DPL];
 };
 
 // calculate_point (calculate.f90:6-50) at x0 + t*nh; leaves cube/theta of the trial in registers
@@ -355,6 +358,25 @@ __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double 
                                           double t, double (&cube)[DPL], double (&th)[DPL])
 {
     bool outside = false;
+    if (C.S.like.kind == PC_LIKE_GAUSSIAN) {
+        // straight line: the cube test and theta run beside the likelihood chain, the result is masked
+        double sg = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            cube[k] = x0[k] + t * nh[k];
+            const double z = C.gA[k] + t * C.gB[k];
+            if (C.ld.on[k]) { outside |= (cube[k] < 0.0) | (cube[k] > 1.0); sg += z * z; }
+            th[k] = C.ld.lo[k] + C.ld.span[k] * cube[k];
+        }
+        sg = wsum<DPL, NROWS>(sg);
+        double lg = C.S.like.norm - sg / 2.0;
+        if (__ballot(outside) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) th[k] = 0.0;
+            lg = C.S.logzero;                   // calculate.f90:36-38
+        } else if (lg > C.S.logzero) C.nlike++;
+        return lg;
+    }
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         cube[k] = x0[k] + t * nh[k];
@@ -395,7 +417,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
         const double thA = C.ld.lo[k] + C.ld.span[k] * cA, thB = C.ld.lo[k] + C.ld.span[k] * cB;
         if (C.ld.on[k]) {
             if (L.kind == PC_LIKE_GAUSSIAN) {
-                const double zA = (thA - L.mu) * L.inv_sigma, zB = (thB - L.mu) * L.inv_sigma;
+                const double zA = C.gA[k] + tA * C.gB[k], zB = C.gA[k] + tB * C.gB[k];
                 sA += zA * zA; sB += zB * zB;
             } else if (L.kind == PC_LIKE_RASTRIGIN) {
                 sA += 8.515435146961291 + thA * thA - 10.0 * cos(PC_TWO_PI * thA);
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             x0[k] = ld.on[k] ? seed[dim] : 0.5;
         }
     }
-    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0};
+    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, {}, {}};
 
     // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
     //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
@@ -494,16 +516,30 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
         w_next = S.nhat_w[(size_t)chain * nr + v0];
     }
 
-    for (int s = 0; s < nr; ++s) {
-        const double w = w_next;
+#ifdef SLICE_DBG
+    long long scy[6] = {0, 0, 0, 0, 0, 0}; long long nev = 0;
+#endif
+    double w = w_next;
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) nh[k] = nh_next[k];
+    for (int k = 0; k < DPL; ++k) nh[k] = nh_next[k];
+    // loop-invariant addresses (the per-slice address arithmetic was a third of the slice's instructions)
+    const double *nh_base = S.nhat + (size_t)chain * nr * D + lane;
+    const double *nw_base = S.nhat_w + (size_t)chain * nr;
+    double *row = S.babies + (size_t)chain * nr * nT;
+    double *bl_row = S.baby_logL + (size_t)chain * nr;
+    double *bl_col = S.baby_logL_T + chain;
+    double *tb_row = tbuf + lane;
+    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
+    for (int s = 0; s < nr; ++s, row += nT, bl_col += Bstride, tb_row += D + 1) {
+#ifdef SLICE_DBG
+        const long long c0 = clock64();
+#endif
         if (s + 1 < nr) {                           // prefetch the next direction (hidden under this slice)
             const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
-            const double *p = S.nhat + ((size_t)chain * nr + v1) * D;
+            const double *p = nh_base + v1 * D;
 #pragma unroll
-            for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[lane + 64 * k] : 0.0;
-            w_next = S.nhat_w[(size_t)chain * nr + v1];
+            for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[64 * k] : 0.0;
+            w_next = nw_base[v1];
         }
         if ((s & 3) == 0) {                         // one Philox call per lane covers 4 slices x 32 uniforms
             const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
@@ -520,17 +556,33 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             return pc_uniform(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain, (uint32_t)s * PC_SLICE_STRIDE + k);
         };
 
+#ifdef SLICE_DBG
+        const long long c1 = clock64();
+#endif
         double cube[DPL], th[DPL];
+        if (S.like.kind == PC_LIKE_GAUSSIAN) {
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) {
+                C.gA[k] = ((ld.lo[k] + ld.span[k] * x0[k]) - S.like.mu) * S.like.inv_sigma;
+                C.gB[k] = (ld.span[k] * nh[k]) * S.like.inv_sigma;
+            }
+        }
         // initial bracket (chordal_sampling.f90:213-219)
         const double u0 = next_u();
         double tR = (1 - u0) * w, tL = -(u0 * w);
         double lR, lL;
         eval_pair<DPL, NROWS>(C, x0, nh, tR, tL, lR, lL);
+#ifdef SLICE_DBG
+        const long long c2 = clock64();
+#endif
         // stepping out (:223-236)
         int istep = 0;
         while (lR >= contour && lR > logzero) { istep++; tR = w * istep; lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th); }
         istep = 0;
         while (lL >= contour && lL > logzero) { istep++; tL = -(w * istep); lL = eval_at<DPL, NROWS>(C, x0, nh, tL, cube, th); }
+#ifdef SLICE_DBG
+        const long long c3 = clock64();
+#endif
         // shrinkage (:240-271)
         double lnew = logzero;
         bool ok = false;
@@ -538,35 +590,54 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             const double dl = fabs(tL), dr = fabs(tR);
             const double t = next_u() * (dr + dl) - dl;
             lnew = eval_at<DPL, NROWS>(C, x0, nh, t, cube, th);
+#ifdef SLICE_DBG
+            nev++;
+#endif
             if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
             else { ok = true; break; }
         }
         if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
+#ifdef SLICE_DBG
+        const long long c4 = clock64();
+#endif
         // the baby becomes the next start point (chordal_sampling.f90:85-88)
-        double *row = S.babies + ((size_t)chain * nr + s) * nT;
+        // The prefetched direction is taken over BEFORE this slice's stores are issued: its loads were
+        // issued a whole slice ago, whereas a wait placed after the stores (vmcnt counts them too on
+        // gfx9) would stall every slice for a full store round trip.
+        w = w_next;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) { nh[k] = nh_next[k]; asm volatile("" : "+v"(nh[k])); }
+        asm volatile("" : "+v"(w));
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             x0[k] = cube[k];
-            if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[S.p0 + lane + 64 * k] = th[k]; }
+            if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[o_p0 + lane + 64 * k] = th[k]; }
         }
         if (phi_lds) {
 #pragma unroll
-            for (int k = 0; k < DPL; ++k) if (ld.on[k]) tbuf[(size_t)s * (D + 1) + lane + 64 * k] = th[k];
-        } else if (S.nDer > 0) {
+            for (int k = 0; k < DPL; ++k) if (ld.on[k]) tb_row[64 * k] = th[k];
+        } else if (nDer > 0) {
             double phi0, phi1;
             like_phi<DPL, NROWS>(S, th, ld, lane, phi0, phi1);
             if (lane == 0) {
-                row[S.d0] = phi0;
-                if (S.nDer >= 2) row[S.d0 + 1] = phi1;
-                for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
+                row[o_d0] = phi0;
+                if (nDer >= 2) row[o_d0 + 1] = phi1;
+                for (int e = 2; e < nDer; ++e) row[o_d0 + e] = 0.0;
             }
         }
         if (lane == 0) {
-            row[S.b0] = contour;                    // nested_sampling.F90:260
-            row[S.l0] = lnew;
-            S.baby_logL[(size_t)chain * nr + s] = lnew; S.baby_logL_T[(size_t)s * S.B + chain] = lnew;
+            row[o_b0] = contour;                    // nested_sampling.F90:260
+            row[o_l0] = lnew;
+            bl_row[s] = lnew; *bl_col = lnew;
         }
+#ifdef SLICE_DBG
+        const long long c5 = clock64();
+        scy[0] += c1 - c0; scy[1] += c2 - c1; scy[2] += c3 - c2; scy[3] += c4 - c3; scy[4] += c5 - c4;
+#endif
     }
+#ifdef SLICE_DBG
+    if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; }
+#endif
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
     // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
     // one sqrt / log per chain instead of one per slice on the chain's critical path
