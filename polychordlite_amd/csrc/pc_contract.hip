@@ -503,6 +503,31 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
 // apply the plan: dead rows + phantoms (reads live[] before k_apply_live overwrites slots)
 // one wave per consumed chain
 // ------------------------------------------------------------------------------------------
+// Copy the rows selected by a wave-uniform bit mask (row of bit b = src0 + b*nT) to consecutive rows at dst.
+// Eight rows travel together: their loads are independent, so a batch costs one memory round trip
+// instead of eight (rows written by other XCDs come from HBM / Infinity Cache, ~1 us each).
+__device__ __forceinline__ int wave_copy_masked(const double *src0, unsigned long long mask, double *dst, int nT, int lane)
+{
+    int n = 0;
+    while (mask) {
+        int idx[8], cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            idx[u] = 0;
+            if (mask) { idx[u] = __ffsll((long long)mask) - 1; mask &= mask - 1; cnt = u + 1; }
+        }
+        for (int e = lane; e < nT; e += 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < cnt) v[u] = src0[(size_t)idx[u] * nT + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < cnt) dst[(size_t)(n + u) * nT + e] = v[u];
+        }
+        n += cnt;
+    }
+    return n;
+}
+
 __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
 {
     const PcCtl *ctl = S.ctl;
@@ -525,20 +550,14 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
     int base = S.plan[w].ph_base;
     const unsigned cuid = S.plan[w].ph_cuid;
     for (int m = 0; m < (nr + 62) / 64; ++m) {
-        unsigned long long mask = S.plan[w].ph_mask[m];
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int i = m * 64 + b;
-            const double *row = S.babies + ((size_t)w * nr + i) * nT;
-            double *dst = S.phantom + (size_t)base * nT;
-            for (int e = lane; e < nT; e += 64) dst[e] = row[e];
-            if (lane == 0) {
-                S.ph_logL[base] = row[S.l0]; S.ph_cuid[base] = cuid;
-                S.ph_uid[base] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
-            }
-            base++;
+        const unsigned long long mask = S.plan[w].ph_mask[m];
+        // side arrays: lane b owns baby m*64+b, its row offset is the number of selected babies before it
+        if ((mask >> lane) & 1ull) {
+            const int i = m * 64 + lane, dsti = base + __popcll(mask & ((1ull << lane) - 1ull));
+            S.ph_logL[dsti] = S.baby_logL[(size_t)w * nr + i]; S.ph_cuid[dsti] = cuid;
+            S.ph_uid[dsti] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
         }
+        base += wave_copy_masked(S.babies + ((size_t)w * nr + m * 64) * nT, mask, S.phantom + (size_t)base * nT, nT, lane);
     }
 }
 
@@ -657,16 +676,14 @@ __global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const
     __shared__ int wcnt[4];
     if (lane == 0) wcnt[wid] = __popcll(m);
     __syncthreads();
-    int off = blk_off[blockIdx.x];
-    for (int i = 0; i < wid; ++i) off += wcnt[i];
-    off += __popcll(m & ((1ull << lane) - 1ull));
+    int woff = blk_off[blockIdx.x];
+    for (int i = 0; i < wid; ++i) woff += wcnt[i];
+    const int off = woff + __popcll(m & ((1ull << lane) - 1ull));
     if (dst_index && j < nph) dst_index[j] = k ? off : -1;
-    if (k) {
-        phL2[off] = S.ph_logL[j]; phC2[off] = S.ph_cuid[j]; phU2[off] = S.ph_uid[j];
-        const double *row = S.phantom + (size_t)j * S.nT;
-        double *dst = ph2 + (size_t)off * S.nT;
-        for (int e = 0; e < S.nT; ++e) dst[e] = row[e];
-    }
+    if (k) { phL2[off] = S.ph_logL[j]; phC2[off] = S.ph_cuid[j]; phU2[off] = S.ph_uid[j]; }
+    // rows: the wave copies its surviving rows cooperatively (coalesced, eight rows in flight)
+    const int j0 = blockIdx.x * 256 + wid * 64;
+    wave_copy_masked(S.phantom + (size_t)j0 * S.nT, m, ph2 + (size_t)woff * S.nT, S.nT, lane);
 }
 
 __global__ void k_reset_thresholds(PcState S) { if (threadIdx.x < S.maxc) S.death_thr[threadIdx.x] = -PC_HUGE; }
@@ -746,7 +763,15 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     }
     for (int d = tid % DPc; d < D; d += DPc) {
         double s = 0.0;
-        for (int k = g; k < nchunk; k += G) s += psum[((size_t)k * nc + c) * D + d];
+        int k = g;
+        for (; k + 7 * G < nchunk; k += 8 * G) {          // eight independent loads in flight, added in order
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = psum[((size_t)(k + u * G) * nc + c) * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t8[u];
+        }
+        for (; k < nchunk; k += G) s += psum[((size_t)k * nc + c) * D + d];
         if (G > 1) red[tid] = s; else mu[d] = s;
     }
     __syncthreads();
@@ -805,7 +830,17 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
         const int p = p0 + tid % DDp;
         double s = 0.0;
         if (p < DD && g < G)
-            for (int k = g; k < nchunk; k += G) s += pcov[((size_t)k * nc + c) * DD + p];
+        {
+            int k = g;
+            for (; k + 7 * G < nchunk; k += 8 * G) {      // eight independent loads in flight, added in order
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t8[u] = pcov[((size_t)(k + u * G) * nc + c) * DD + p];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t8[u];
+            }
+            for (; k < nchunk; k += G) s += pcov[((size_t)k * nc + c) * DD + p];
+        }
         red[tid] = s;
         __syncthreads();
         if (tid < DDp && p < DD) {
