@@ -87,7 +87,9 @@ typedef struct {
     int batch;          /* chains per synchronous nursery (the reference's nprocs-1); 0 = auto */
     int device;         /* HIP device ordinal, -1 = current/0 */
     int feedback;
-    int profile;        /* 1: HIP-event stopwatch around every kernel class (bench.py) */
+    int profile;        /* 0: off; 1: HIP-event stopwatch around every kernel class; otherwise a bit mask,
+                           bit k+1 = time kernel class k (0 nhats, 1 slice, 2 consume, 3 apply, 4 clean, 5 covmats):
+                           a few hundred event records per run instead of a few thousand */
     int force_general;  /* 1: always use the general contraction kernel (tests) */
     int ablate;         /* developer timing hook: bit mask of contraction sub-steps to skip; 0 = product */
 } pchip_settings;

@@ -111,13 +111,43 @@ def make_problem(kind, nDims, nDerived=0, lo=None, hi=None, mu=0.5, sigma=0.1, i
     return L, P, keep
 
 
+class _Owner:
+    """Keeps a pchip_result alive for the numpy views handed out by run(); frees it when the last view dies."""
+
+    def __init__(self, lib, res):
+        self.lib, self.res = lib, res
+
+    def __del__(self):
+        try:
+            self.lib.pchip_result_free(C.byref(self.res))
+        except Exception:
+            pass
+
+
+class _View:
+    """array-interface shim: numpy keeps this object (and through it the owner) as the array's base"""
+
+    def __init__(self, owner, ptr, shape):
+        self.owner = owner
+        addr = C.cast(ptr, C.c_void_p).value or 0
+        self.__array_interface__ = {"data": (addr, False), "shape": tuple(shape), "typestr": "<f8", "version": 3}
+
+
+def _view(owner, ptr, shape):
+    if int(np.prod(shape)) == 0:
+        return np.zeros(shape)
+    return np.asarray(_View(owner, ptr, shape))
+
+
 def run(settings, like, prior):
-    """pchip_run -> dict of numpy copies (the C result is freed)."""
+    """pchip_run -> dict; the big arrays (dead points, weights, live points) are zero-copy views of the
+    engine's pinned result buffers, released when the last view is garbage collected."""
     lib = load()
     r = Result()
     rc = lib.pchip_run(C.byref(settings), C.byref(like), C.byref(prior), C.byref(r))
     if rc != 0:
         raise RuntimeError(f"pchip_run failed with code {rc}")
+    own = _Owner(lib, r)
     nT, nd, D = r.nTotal, r.ndead, settings.nDims
     out = dict(logZ=r.logZ, logZerr=float(np.sqrt(abs(r.varlogZ))), varlogZ=r.varlogZ, ndead=nd, nlike=r.nlike,
                niter=r.niter, nbatches=r.nbatches, nrounds=r.nrounds, nupdates=r.nupdates, ncluster=r.ncluster,
@@ -125,12 +155,11 @@ def run(settings, like, prior):
                t_final=r.t_final, t_total=r.t_total, t_setup=r.t_setup, t_results=r.t_results, t_teardown=r.t_teardown,
                kernel_time={n: {"total_s": r.k_time_s[i], "launches": r.k_launches[i]}
                             for i, n in enumerate(KERNEL_CLASSES) if r.k_launches[i] > 0},
-               dead=np.ctypeslib.as_array(r.dead, shape=(nd, nT)).copy(),
-               logweights=np.ctypeslib.as_array(r.logweights, shape=(nd,)).copy(),
-               entry=np.ctypeslib.as_array(r.entry, shape=(nd,)).copy(),
-               live=np.ctypeslib.as_array(r.live, shape=(max(r.nlive_final, 1), nT))[:r.nlive_final].copy(),
+               dead=_view(own, r.dead, (nd, nT)),
+               logweights=_view(own, r.logweights, (nd,)),
+               entry=_view(own, r.entry, (nd,)),
+               live=_view(own, r.live, (r.nlive_final, nT)),
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy())
-    lib.pchip_result_free(C.byref(r))
     return out

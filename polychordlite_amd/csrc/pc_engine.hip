@@ -156,14 +156,15 @@ struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rou
 enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_N };
 struct KTimer {
     bool on = false;
+    unsigned mask = 0xFFFFFFFFu;            // kernel classes that are timed
     hipStream_t st = nullptr;
     std::vector<hipEvent_t> pool; size_t used = 0;
     struct Span { int k; hipEvent_t a, b; };
     std::vector<Span> open;
     double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
     hipEvent_t get() { if (used == pool.size()) pool.push_back(hpool().get_event()); return pool[used++]; }
-    hipEvent_t begin() { if (!on) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
-    void end(int k, hipEvent_t a) { if (!on) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
+    hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u)) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
+    void end(int k, hipEvent_t a) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
     void collect() {   // call after a stream synchronisation
         if (!on) return;
         for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
@@ -241,6 +242,7 @@ struct Engine {
         HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
         st = hpool().get_stream(); st_copy = hpool().get_stream();
         kt.on = c.profile != 0; kt.st = st;
+        kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : ((unsigned)c.profile >> 1);   // 1: every class; else bit k+1 = class k
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
         S.p0 = D; S.d0 = 2 * D; S.b0 = 2 * D + nDer; S.l0 = S.b0 + 1;
@@ -413,7 +415,7 @@ struct Engine {
         tm.updates++;
         call_dumper();
         const int nph = h_ctl->nphantom, nc = h_ctl->ncluster;
-        hipEvent_t e0 = kt.begin();
+        hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
         int total = 0;
@@ -424,7 +426,7 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(&S.ctl->nphantom, &h_ctl->nphantom, sizeof(int), hipMemcpyHostToDevice, st));
         pc_launch_reset_thresholds(&S, st);
         if (cfg.do_clustering) { HIPCHK(hipStreamSynchronize(st)); do_clustering(); }
-        hipEvent_t e1 = kt.begin();
+        hipEvent_t e1 = kt.begin(KT_COV);
         covmats(total, h_ctl->ncluster);
         kt.end(KT_COV, e1);
     }
@@ -730,16 +732,16 @@ struct Engine {
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
             if (h_ctl->i_nursery == 0) {
                 ensure_capacity();
-                hipEvent_t e0 = kt.begin();
+                hipEvent_t e0 = kt.begin(KT_NHATS);
                 if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_NHATS, e0);
-                hipEvent_t e1 = kt.begin();
+                hipEvent_t e1 = kt.begin(KT_SLICE);
                 if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
                 else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
                 batch++; tm.batches++;
             }
-            hipEvent_t e2 = kt.begin();
+            hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
             if (use_fast && par_ok) {
@@ -752,7 +754,7 @@ struct Engine {
             else { sort_valid = false; rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st); }
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
-            hipEvent_t e3 = kt.begin();
+            hipEvent_t e3 = kt.begin(KT_APPLY);
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             read_ctl();

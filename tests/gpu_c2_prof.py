@@ -13,7 +13,7 @@ D, nDer = 20, 1
 lib = api.load()
 for it in range(nruns):
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
-    s.nlive = 2000; s.num_repeats = 40; s.seed = 7 + it; s.batch = 1000; s.profile = 1
+    s.nlive = 2000; s.num_repeats = 40; s.seed = 7 + it; s.batch = 1000; s.profile = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     s.feedback = fb if it == nruns - 1 else 0
     L, P, keep = api.make_problem("gaussian", D, nDer)
     t0 = time.perf_counter()
