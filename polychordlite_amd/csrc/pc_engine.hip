@@ -29,6 +29,7 @@ int pc_fast_fits(const PcState *);
 int pc_par_fits(const PcState *);
 int pc_launch_sort_live(const PcState *, hipStream_t);
 int pc_launch_consume_par(const PcState *, hipStream_t);
+int pc_launch_final_par(const PcState *, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
@@ -769,7 +770,10 @@ struct Engine {
         HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
         const int nc_end = h_ctl->ncluster;
-        if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
+        if (par_ok && h_ctl->ncluster == 1) {
+            if (!sort_valid) (void)pc_launch_sort_live(&S, st);
+            (void)pc_launch_final_par(&S, st);
+        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
         call_dumper();
         auto t3 = clk::now();

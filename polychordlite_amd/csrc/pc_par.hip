@@ -575,6 +575,93 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Kill-off (nested_sampling.F90:381-384): every remaining live point dies, lowest first.  Death i of
+// the sorted live set leaves n-i points behind, so volumes are prefix sums of log((n-i)/(n-i+1)) and the
+// evidence is the same pair scan as above, 1024 deaths per pass with the state carried between passes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S)
+{
+    __shared__ __attribute__((aligned(16))) double X0[PAR_NT], X1[PAR_NT], X2[PAR_NT], X3[PAR_NT];
+    __shared__ double wtot[64];
+    __shared__ double carry[12];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    PcCtl *ctl = S.ctl;
+    const int n0 = S.cl_n[0], nT = S.nT, ndead0 = ctl->ndead;
+    const unsigned cuid = S.cl_uid[0];
+    const double log2v = 0.6931471805599453;
+    if (ndead0 + n0 > S.Dcap) { if (tid == 0) { ctl->status = PC_ST_ERROR; ctl->error = PC_ERR_DEAD_CAP; } return; }
+    if (tid == 0) {
+        carry[0] = ctl->logZ; carry[1] = ctl->logZ2; carry[2] = S.logXp[0]; carry[3] = S.XpXq[0]; carry[4] = S.logZp[0];
+        carry[5] = S.logZXp[0]; carry[6] = S.logZp2[0]; carry[7] = S.logZpXp[0]; carry[8] = S.death_thr[0];
+    }
+    __syncthreads();
+    for (int base = 0; base < n0; base += PAR_NT) {
+        const int m = min(PAR_NT, n0 - base), i = base + tid;
+        const bool on = tid < m;
+        const double logZ0 = carry[0], logZ20 = carry[1], Xp0 = carry[2], XX0 = carry[3], Zp0 = carry[4], ZXp0 = carry[5],
+                     Zp20 = carry[6], ZpXp0 = carry[7];
+        const int slot = on ? S.sort_slot[i] : 0;
+        const double L = on ? key2d(S.sort_key[i]) : NEGBIG;
+        const int myn = n0 - i;                                   // live points before my death
+        const double a0 = on ? log((double)myn) : 0.0, a1 = on ? log((double)myn + 1.0) : 0.0, a2 = on ? log((double)myn + 2.0) : 0.0;
+        const double e01 = a0 - a1, e02 = a0 - a2;
+        const double sx = block_scan_add(e01, lane, wv, wtot), sxx = block_scan_add(e02, lane, wv, wtot);   // inclusive
+        const double Xb = Xp0 + (sx - e01), XXb = XX0 + (sxx - e02), Sd = sx;
+        double tM = on ? Xb + L - a1 : NEGBIG, tS = on ? 1.0 : 0.0;
+        double vM = on ? (XXb + L + a0 - a1 - a2) - Sd : NEGBIG, vS = tS;
+        block_scan_ls2(tM, tS, vM, vS, tid, m, X0, X1, X2, X3, wtot);
+        double ziM = tM, ziS = tS;
+        ls_comb(ziM, ziS, logZ0, 1.0);
+        const double Zi = ls_val(ziM, ziS);
+        double zxM = vM, zxS = vS, zpxM = vM, zpxS = vS;
+        ls_comb(zxM, zxS, ZXp0, 1.0); ls_comb(zpxM, zpxS, ZpXp0, 1.0);
+        // <Z X> before my death: the previous death's value (its own decay prefix), the carry for the first
+        X0[tid] = zxM; X1[tid] = zxS; X2[tid] = zpxM; X3[tid] = zpxS;
+        __syncthreads();
+        const double SdPrev = Sd - e01;
+        double pzxM = tid ? X0[tid - 1] : ZXp0, pzxS = tid ? X1[tid - 1] : 1.0;
+        double pzpxM = tid ? X2[tid - 1] : ZpXp0, pzpxS = tid ? X3[tid - 1] : 1.0;
+        __syncthreads();
+        const double cz = log2v + XXb + 2 * L - a1 - a2;
+        const double cw = log2v + L - a1 + SdPrev;
+        double wM = on ? cw + pzxM : NEGBIG, wS = on ? pzxS : 0.0;
+        double wpM = on ? cw + pzpxM : NEGBIG, wpS = on ? pzpxS : 0.0;
+        if (on) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
+        block_scan_ls2(wM, wS, wpM, wpS, tid, m, X0, X1, X2, X3, wtot);
+        if (on) {
+            const int di = ndead0 + i;
+            S.dead_logw[di] = Xb - a1; S.dead_postX[di] = Xb + e01; S.dead_postZ[di] = Zi;
+            S.dead_cuid[di] = cuid; S.dead_entry[di] = S.live_entry[slot];
+            S.live_logL[slot] = PC_HUGE; S.live_cluster[slot] = -1; S.slot_src[slot] = -1;
+        }
+        __syncthreads();                                          // everybody has read the carry
+        if (tid == m - 1) {
+            double a = tM, b = tS;
+            ls_comb(a, b, Zp0, 1.0);
+            ls_comb(wM, wS, logZ20, 1.0); ls_comb(wpM, wpS, Zp20, 1.0);
+            carry[0] = Zi; carry[1] = ls_val(wM, wS); carry[2] = Xp0 + sx; carry[3] = XX0 + sxx; carry[4] = ls_val(a, b);
+            carry[5] = Sd + ls_val(zxM, zxS); carry[6] = ls_val(wpM, wpS); carry[7] = Sd + ls_val(zpxM, zpxS); carry[8] = L;
+        }
+        __syncthreads();
+        // rows: one wave per row, 16 rows at a time
+        for (int r = wv; r < m; r += PAR_NT / 64) {
+            const int sl = S.sort_slot[base + r];
+            const double *row = S.live + (size_t)sl * nT;
+            double *dst = S.dead + (size_t)(ndead0 + base + r) * nT;
+            for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+        }
+    }
+    if (tid == 0) {
+        const int ncd = ctl->ncluster_dead;
+        if (ncd < S.maxc_dead) { S.logZp_dead[ncd] = carry[4]; S.logZp2_dead[ncd] = carry[6]; }
+        S.logLp[0] = PC_HUGE; S.imin_slot[0] = -1; S.logXp[0] = carry[2]; S.XpXq[0] = carry[3]; S.logZp[0] = carry[4];
+        S.logZXp[0] = carry[5]; S.logZp2[0] = carry[6]; S.logZpXp[0] = carry[7]; S.death_thr[0] = carry[8]; S.cl_n[0] = 0;
+        ctl->status = PC_ST_DONE; ctl->error = PC_ERR_NONE; ctl->ndead = ndead0 + n0; ctl->ncluster = 0; ctl->ncluster_dead = ncd + 1;
+        ctl->logZ = carry[0]; ctl->logZ2 = carry[1]; ctl->cluster_deleted = 0;
+    }
+}
+
 static size_t par_lds(const PcState *S)
 {
     const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
@@ -590,5 +677,11 @@ extern "C" int pc_launch_consume_par(const PcState *S, hipStream_t st)
     static size_t d = 0;
     if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
     hipLaunchKernelGGL(k_consume_par, dim3(1), dim3(PAR_NT), sh, st, *S);
+    return 0;
+}
+
+extern "C" int pc_launch_final_par(const PcState *S, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_final_par, dim3(1), dim3(PAR_NT), 0, st, *S);
     return 0;
 }
