@@ -122,12 +122,32 @@ typedef struct {
                                       (== birth column when batch = 1); used by the multi-run merge */
     double *live; int nlive_final; /* live set at termination, before the final kill-off */
     double *logZp, *varlogZp; int nZp;
-    double *post_mean, *post_var;  /* [nDims] weighted posterior moments of theta */
+    double *post_mean, *post_var;  /* [nDims + nDerived] weighted posterior moments of theta, phi */
 } pchip_result;
+
+/* snapshot handed to the update hook: what the reference's file writers see at every update
+   (nested_sampling.F90:323-340, read_write.F90) -- host memory owned by the engine, valid during the call */
+typedef struct {
+    int final_call;                 /* 1: the call after the kill-off (nested_sampling.F90:386-398) */
+    long ndead; int nlive, npars;   /* npars = nDims + nDerived + 2 */
+    const double *dead;             /* [ndead][npars]  theta, phi, birth contour, logL -- in death order */
+    const double *logpost;          /* [ndead] logweight + logL; failed spawns carry logzero + logL */
+    const double *live;             /* [nlive][npars], ordered by cluster, then position in the cluster's list */
+    const int *live_cluster;        /* [nlive] 0-based cluster of each live row */
+    double logZ, logZerr;
+    long nlike;
+    int ncluster, ncluster_dead;
+    const int *nlive_p;             /* [ncluster] */
+    const double *logZp, *logZperr;            /* [ncluster] clusters still active */
+    const double *logZp_dead, *logZperr_dead;  /* [ncluster_dead] */
+} pchip_update;
+typedef void (*pchip_update_fn)(void *user, const pchip_update *u);
 
 /* optional host hooks of a run */
 typedef struct {
     polychord_dumper_fn dumper;   /* called at every update and at the end, like nested_sampling.F90:335,392 */
+    pchip_update_fn on_update;    /* same moments; may be NULL */
+    void *user;
 } pchip_hooks;
 
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);

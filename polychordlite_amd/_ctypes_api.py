@@ -160,6 +160,6 @@ def run(settings, like, prior):
                entry=_view(own, r.entry, (nd,)),
                live=_view(own, r.live, (r.nlive_final, nT)),
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
-               post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),
-               post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy())
+               post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
+               post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy())
     return out

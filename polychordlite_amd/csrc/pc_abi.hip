@@ -16,6 +16,8 @@
 #include <sys/stat.h>
 #include <chrono>
 
+extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
+
 namespace {
 
 struct Builtins {
@@ -54,53 +56,137 @@ std::string fmt_e24(double v)
     return out;
 }
 
-void write_rows(const std::string &path, const pchip_result &r, int nDims, int nDer, bool birth, bool live)
-{
-    FILE *f = std::fopen(path.c_str(), "w");
-    if (!f) halt_program(("polychord_hip: cannot open " + path).c_str());
-    const int nT = r.nTotal, p0 = nDims, l0 = nT - 1, b0 = nT - 2;
-    const long n = live ? 0 : r.ndead;       // every live point has been killed when the run ends
-    for (long i = 0; i < n; ++i) {
-        const double *row = r.dead + (size_t)i * nT;
-        std::string line;
-        if (birth || live) {                 // read_write.F90:707-716: theta, phi, logL, birth
-            for (int k = 0; k < nDims + nDer; ++k) line += fmt_e24(row[p0 + k]);
-            line += fmt_e24(row[l0]);
-            if (birth) line += fmt_e24(row[b0]);
-        } else {                              // read_write.F90:698-703: logL, theta, phi
-            line += fmt_e24(row[l0]);
-            for (int k = 0; k < nDims + nDer; ++k) line += fmt_e24(row[p0 + k]);
-        }
-        std::fprintf(f, "%s\n", line.c_str());
-    }
-    std::fclose(f);
-}
+// Files of a run (read_write.F90:479-910, names :1022-1224), written from the engine's update hook:
+//   <root>_dead.txt / _dead-birth.txt   appended as points die (the reference rewrites them in full at
+//                                       every update -- most of its wall time at small nlive)
+//   <root>_phys_live.txt / -birth.txt   rewritten at every update
+//   <root>.stats                        rewritten at every update ("Still Active" clusters listed first)
+//   <root>.txt / _equal_weights.txt     weighted / equally weighted posterior from the dead points, at the end
+struct FileSink {
+    std::string base, root;
+    int nDims = 0, nDer = 0;
+    bool write_stats = false, write_live = false, write_dead = false, posteriors = false, equals = false;
+    unsigned seed = 0; double logzero = -1e30, compression = 0.36787944117144233; int num_repeats = 1;
+    long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
+    std::vector<double> mu, sig;
 
-void write_stats(const std::string &path, const pchip_result &r, int nposterior, int nequals)
-{   // read_write.F90:842-889
-    FILE *f = std::fopen(path.c_str(), "w");
-    if (!f) halt_program(("polychord_hip: cannot open " + path).c_str());
-    std::fprintf(f, "Evidence estimates:\n===================\n");
-    std::fprintf(f, "  - The evidence Z is a log-normally distributed, with location and scale parameters mu and sigma.\n");
-    std::fprintf(f, "  - We denote this as log(Z) = mu +/- sigma.\n\nGlobal evidence:\n----------------\n\n");
-    std::fprintf(f, "log(Z)       = %s +/- %s\n\n\n", fmt_e24(r.logZ).c_str(), fmt_e24(std::sqrt(std::fabs(r.varlogZ))).c_str());
-    std::fprintf(f, "Local evidences:\n----------------\n\n");
-    for (int p = 0; p < r.nZp; ++p) {
-        const int idx = p + 1 + 0;                        // no cluster is still active at the end
-        char lab[32];
-        std::snprintf(lab, sizeof lab, "log(Z_%d)", idx);
-        std::fprintf(f, "%-13s= %s +/- %s\n", lab, fmt_e24(r.logZp[p]).c_str(), fmt_e24(std::sqrt(std::fabs(r.varlogZp[p]))).c_str());
+    std::string path(const char *suffix) const { return base + "/" + root + suffix; }
+    static FILE *open(const std::string &p, const char *mode)
+    {
+        FILE *f = std::fopen(p.c_str(), mode);
+        if (!f) halt_program(("polychord_hip: cannot open " + p).c_str());
+        return f;
     }
-    std::fprintf(f, "\n\nRun-time information:\n---------------------\n\n");
-    std::fprintf(f, " ncluster:   %8d /%8d\n", 0, r.ncluster_dead);
-    std::fprintf(f, " nposterior: %8d\n", nposterior);
-    std::fprintf(f, " nequals:    %8d\n", nequals);
-    std::fprintf(f, " ndead:      %8ld\n", r.ndead);
-    std::fprintf(f, " nlive:      %8d\n", 0);
-    std::fprintf(f, " nlike:      %8ld\n", r.nlike);
-    std::fprintf(f, " <nlike>:    %8.2f   (%8.2f per slice )\n", 0.0, 0.0);
-    std::fclose(f);
-}
+    void rows(FILE *f, const double *rows_, long i0, long i1, int npars, bool logl_first, bool birth) const
+    {
+        const int np = nDims + nDer;
+        std::string line;
+        for (long i = i0; i < i1; ++i) {
+            const double *r = rows_ + (size_t)i * npars;
+            line.clear();
+            if (logl_first) {                     // read_write.F90:698-703: logL, theta, phi
+                line += fmt_e24(r[np + 1]);
+                for (int k = 0; k < np; ++k) line += fmt_e24(r[k]);
+            } else {                              // read_write.F90:707-716: theta, phi, logL[, birth]
+                for (int k = 0; k < np; ++k) line += fmt_e24(r[k]);
+                line += fmt_e24(r[np + 1]);
+                if (birth) line += fmt_e24(r[np]);
+            }
+            line += '\n';
+            std::fwrite(line.data(), 1, line.size(), f);
+        }
+    }
+    void stats(const pchip_update &u) const
+    {   // read_write.F90:809-910
+        FILE *f = open(path(".stats"), "w");
+        std::fprintf(f, "Evidence estimates:\n===================\n");
+        std::fprintf(f, "  - The evidence Z is a log-normally distributed, with location and scale parameters mu and sigma.\n");
+        std::fprintf(f, "  - We denote this as log(Z) = mu +/- sigma.\n\nGlobal evidence:\n----------------\n\n");
+        std::fprintf(f, "log(Z)       = %s +/- %s\n\n\n", fmt_e24(u.logZ).c_str(), fmt_e24(u.logZerr).c_str());
+        std::fprintf(f, "Local evidences:\n----------------\n\n");
+        char lab[32];
+        for (int p = 0; p < u.ncluster; ++p) {
+            std::snprintf(lab, sizeof lab, "log(Z_%d)", p + 1);
+            std::fprintf(f, "%-13s= %s +/- %s (Still Active)\n", lab, fmt_e24(u.logZp[p]).c_str(), fmt_e24(u.logZperr[p]).c_str());
+        }
+        for (int p = 0; p < u.ncluster_dead; ++p) {
+            std::snprintf(lab, sizeof lab, "log(Z_%d)", p + 1 + u.ncluster);
+            std::fprintf(f, "%-13s= %s +/- %s\n", lab, fmt_e24(u.logZp_dead[p]).c_str(), fmt_e24(u.logZperr_dead[p]).c_str());
+        }
+        std::fprintf(f, "\n\nRun-time information:\n---------------------\n\n");
+        std::fprintf(f, " ncluster:   %8d /%8d\n", u.ncluster, u.ncluster + u.ncluster_dead);
+        std::fprintf(f, " nposterior: %8d\n", nposterior);
+        std::fprintf(f, " nequals:    %8d\n", nequals);
+        std::fprintf(f, " ndead:      %8ld\n", u.ndead);
+        std::fprintf(f, " nlive:      %8d\n", u.nlive);
+        std::fprintf(f, " nlike:      %8ld\n", u.nlike);
+        double per_it = 0.0, per_slice = 0.0;
+        if (u.nlive > 0) {                        // likelihood calls per iteration since the last update
+            const double upd = -(double)u.nlive * std::log(compression);
+            per_it = (double)(u.nlike - nlike_last) / upd; per_slice = per_it / (double)num_repeats;
+        }
+        std::fprintf(f, " <nlike>:    %8.2f   (%8.2f per slice )\n", per_it, per_slice);
+        if (posteriors && !mu.empty()) {
+            std::fprintf(f, "\n\nDim No.       Mean        Sigma\n");
+            for (int k = 0; k < nDims + nDer; ++k) {
+                if (k == nDims) std::fprintf(f, "-------------------------------\n");
+                std::fprintf(f, "%3d%s +/- %s\n", k + 1, fmt_e24(mu[k]).c_str(), fmt_e24(sig[k]).c_str());
+            }
+            if (nDer == 0) std::fprintf(f, "-------------------------------\n");
+        }
+        std::fclose(f);
+    }
+    // weighted / equally weighted posteriors from the dead points (update_posteriors, run_time_info.f90:955-1066;
+    // write_posterior_file, read_write.F90:479-617).  A dead point is an equal-weight sample with probability
+    // weight / max weight; the uniform is keyed by its index so the thinning is reproducible.
+    void posterior_files(const pchip_update &u)
+    {
+        const int np = nDims + nDer, npars = u.npars;
+        double mx = -1.7e308;
+        for (long i = 0; i < u.ndead; ++i) if (u.logpost[i] > -1e29) mx = std::max(mx, u.logpost[i]);
+        FILE *fp = posteriors ? open(path(".txt"), "w") : nullptr;
+        FILE *fe = equals ? open(path("_equal_weights.txt"), "w") : nullptr;
+        mu.assign(np, 0.0); sig.assign(np, 0.0);
+        double sw = 0.0;
+        nposterior = 0; nequals = 0;
+        std::string tail;
+        for (long i = 0; i < u.ndead; ++i) {
+            if (!(u.logpost[i] > -1e29)) continue;        // failed spawns carry no weight
+            const double *row = u.dead + (size_t)i * npars;
+            const double wgt = std::exp(u.logpost[i] - mx);
+            sw += wgt;
+            for (int k = 0; k < np; ++k) { mu[k] += wgt * row[k]; sig[k] += wgt * row[k] * row[k]; }
+            if (!fp && !fe) continue;
+            tail = fmt_e24(-2 * row[np + 1]);
+            for (int k = 0; k < np; ++k) tail += fmt_e24(row[k]);
+            if (fp && wgt > 0.0) { std::fprintf(fp, "%s%s\n", fmt_e24(wgt).c_str(), tail.c_str()); nposterior++; }
+            if (fe && polychord_hip_keyed_uniform(seed, 6u, 0u, 0u, (unsigned)i) < wgt) { std::fprintf(fe, "%s%s\n", fmt_e24(1.0).c_str(), tail.c_str()); nequals++; }
+        }
+        for (int k = 0; k < np; ++k) { mu[k] /= sw; sig[k] = std::sqrt(std::fabs(sig[k] / sw - mu[k] * mu[k])); }
+        if (fp) std::fclose(fp);
+        if (fe) std::fclose(fe);
+    }
+    void update(const pchip_update &u)
+    {
+        if (write_dead && (u.ndead > dead_written || dead_written == 0)) {
+            FILE *f1 = open(path("_dead.txt"), dead_written ? "a" : "w"), *f2 = open(path("_dead-birth.txt"), dead_written ? "a" : "w");
+            rows(f1, u.dead, dead_written, u.ndead, u.npars, true, false);
+            rows(f2, u.dead, dead_written, u.ndead, u.npars, false, true);
+            std::fclose(f1); std::fclose(f2);
+            dead_written = u.ndead;
+        }
+        if (write_live) {
+            FILE *f1 = open(path("_phys_live.txt"), "w"), *f2 = open(path("_phys_live-birth.txt"), "w");
+            rows(f1, u.live, 0, u.nlive, u.npars, false, false);
+            rows(f2, u.live, 0, u.nlive, u.npars, false, true);
+            std::fclose(f1); std::fclose(f2);
+        }
+        if (u.final_call && (posteriors || equals)) posterior_files(u);
+        if (write_stats) stats(u);
+        nlike_last = u.nlike;
+    }
+    static void hook(void *user, const pchip_update *u) { ((FileSink *)user)->update(*u); }
+};
 
 }  // namespace
 
@@ -144,7 +230,6 @@ double polychord_hip_corr_gaussian(double *th, int D, double *, int)
     }
     return -((double)D * LOG_TWO_PI + G.cg_logdet) / 2.0 - q / 2.0;
 }
-extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
 void polychord_hip_set_gaussian(double mu, double sigma) { G.g_mu = mu; G.g_sigma = sigma; }
 void polychord_hip_set_corr_gaussian(int D, const double *invcov, const double *mean, double logdet)
 {
@@ -212,45 +297,19 @@ void polychord_c_interface(
         // a user prior with a built-in likelihood: evaluate both on the host (the device still proposes)
         L.kind = PCHIP_LIKE_CALLBACK; L.fn = loglikelihood;
     }
+    FileSink sink;
+    sink.base = base; sink.root = root; sink.nDims = nDims; sink.nDer = nDerived;
+    sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
+    sink.posteriors = posteriors; sink.equals = equals; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
+    sink.compression = compression_factor; sink.num_repeats = num_repeats;
+    if ((posteriors || equals) && boost_posterior != 0.0 && feedback >= 1)
+        std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");
+    const bool files = write_stats_f || write_dead || write_live || posteriors || equals;
     pchip_result r;
-    pchip_hooks hooks{dumper};
+    pchip_hooks hooks{dumper, files ? FileSink::hook : nullptr, &sink};
     const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);
     if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
     if (rc != 0) halt_program("polychord_hip: engine failure");
-    // weighted / equally weighted posteriors from the dead points (update_posteriors,
-    // run_time_info.f90:955-1066; write_posterior_file, read_write.F90:479-617).  A dead point is an
-    // equal-weight sample with probability weight/max weight; the uniform is keyed by its index so
-    // the thinning is reproducible.  Phantom-derived rows need boost_posterior > 0 (not built yet).
-    int nposterior = 0, nequals = 0;
-    if (posteriors || equals) {
-        if (boost_posterior != 0.0 && feedback >= 1)
-            std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");
-        const int nT = r.nTotal, np = nDims + nDerived;
-        double mx = -1.7e308;
-        for (long i = 0; i < r.ndead; ++i) if (r.logweights[i] > logzero) mx = std::max(mx, r.logweights[i] + r.dead[(size_t)i * nT + nT - 1]);
-        FILE *fp = posteriors ? std::fopen((base + "/" + root + ".txt").c_str(), "w") : nullptr;
-        FILE *fe = equals ? std::fopen((base + "/" + root + "_equal_weights.txt").c_str(), "w") : nullptr;
-        for (long i = 0; i < r.ndead; ++i) {
-            if (!(r.logweights[i] > logzero)) continue;
-            const double *row = r.dead + (size_t)i * nT;
-            const double wgt = std::exp(r.logweights[i] + row[nT - 1] - mx);
-            std::string tail = fmt_e24(-2 * row[nT - 1]);
-            for (int k = 0; k < np; ++k) tail += fmt_e24(row[nDims + k]);
-            if (fp && wgt > 0.0) { std::fprintf(fp, "%s%s\n", fmt_e24(wgt).c_str(), tail.c_str()); nposterior++; }
-            if (fe && polychord_hip_keyed_uniform((unsigned)s.seed, 6u, 0u, 0u, (unsigned)i) < wgt) { std::fprintf(fe, "%s%s\n", fmt_e24(1.0).c_str(), tail.c_str()); nequals++; }
-        }
-        if (fp) std::fclose(fp);
-        if (fe) std::fclose(fe);
-    }
-    if (write_stats_f) write_stats(base + "/" + root + ".stats", r, nposterior, nequals);
-    if (write_dead) {
-        write_rows(base + "/" + root + "_dead.txt", r, nDims, nDerived, false, false);
-        write_rows(base + "/" + root + "_dead-birth.txt", r, nDims, nDerived, true, false);
-    }
-    if (write_live) {
-        write_rows(base + "/" + root + "_phys_live.txt", r, nDims, nDerived, false, true);
-        write_rows(base + "/" + root + "_phys_live-birth.txt", r, nDims, nDerived, true, true);
-    }
     if (feedback >= 1) {
         std::printf("polychord_hip: log(Z) = %.6f +/- %.6f  ndead = %ld  nlike = %ld  (%.3f s, batch %d)\n",
                     r.logZ, std::sqrt(std::fabs(r.varlogZ)), r.ndead, r.nlike, r.t_total, r.batch);

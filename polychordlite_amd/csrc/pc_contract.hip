@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const d
     // thread = (row group g, coordinate d); group g takes rows blockIdx*G+g, +gridDim*G, ... in order
     __shared__ double red[256];
     __shared__ double red2[256];
-    const int tid = threadIdx.x, D = S.D;
+    const int tid = threadIdx.x, D = S.D + S.nDer;          // theta then phi, contiguous from p0
     const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
     double m = -PC_HUGE;
     for (int b = 0; b < (int)gridDim.x; ++b) m = fmax(m, pmax[b]);

@@ -203,6 +203,7 @@ struct Engine {
     long long cb_evals = 0; long cb_ticks = 0;
     // host mirror of the dead points for the dumper hook (nested_sampling.F90:546-590)
     polychord_dumper_fn dumper = nullptr;
+    pchip_update_fn on_update = nullptr; void *hook_user = nullptr;
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<double> h_lo, h_hi;
     PcState S{};
@@ -369,9 +370,9 @@ struct Engine {
 
     // dump (nested_sampling.F90:546-590): live and dead points as [theta, phi, birth, logL] rows,
     // posterior log-weights normalised to logsumexp 0
-    void call_dumper()
+    void call_dumper(bool final_call = false)
     {
-        if (!dumper) return;
+        if (!dumper && !on_update) return;
         const int nT = S.nT, D = S.D, nDer = S.nDer, npars = D + nDer + 2, nd = h_ctl->ndead;
         HIPCHK(hipStreamSynchronize(st));
         if (nd > hm_ndead) {
@@ -407,7 +408,26 @@ struct Engine {
         }
         const double lz = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2), var = h_ctl->logZ2 - 2 * h_ctl->logZ;
         double dummy = 0.0;
-        dumper(nd, (int)ord.size(), npars, live.data(), nd > 0 ? hm_dead.data() : &dummy, nd > 0 ? lwn.data() : &dummy, lz, std::sqrt(std::fabs(var)));
+        if (dumper) dumper(nd, (int)ord.size(), npars, live.data(), nd > 0 ? hm_dead.data() : &dummy, nd > 0 ? lwn.data() : &dummy, lz, std::sqrt(std::fabs(var)));
+        if (on_update) {
+            const int nc = h_ctl->ncluster, ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead);
+            std::vector<int> lcl(std::max<size_t>(1, ord.size()));
+            for (size_t k = 0; k < ord.size(); ++k) lcl[k] = lc[ord[k].second];
+            auto zp = dl(S.logZp, std::max(1, nc)), zp2 = dl(S.logZp2, std::max(1, nc));
+            auto zd = dl(S.logZp_dead, std::max(1, ncd)), zd2 = dl(S.logZp2_dead, std::max(1, ncd));
+            auto cn = dl(S.cl_n, std::max(1, nc));
+            std::vector<double> e1(std::max(1, nc)), s1(std::max(1, nc)), e2(std::max(1, ncd)), s2(std::max(1, ncd));
+            for (int i = 0; i < nc; ++i) { e1[i] = 2 * zp[i] - 0.5 * zp2[i]; s1[i] = std::sqrt(std::fabs(zp2[i] - 2 * zp[i])); }   // run_time_info.f90:652-678
+            for (int i = 0; i < ncd; ++i) { e2[i] = 2 * zd[i] - 0.5 * zd2[i]; s2[i] = std::sqrt(std::fabs(zd2[i] - 2 * zd[i])); }
+            pchip_update u{};
+            u.final_call = final_call ? 1 : 0; u.ndead = nd; u.nlive = (int)ord.size(); u.npars = npars;
+            u.dead = nd > 0 ? hm_dead.data() : &dummy; u.logpost = nd > 0 ? hm_logw.data() : &dummy;
+            u.live = live.data(); u.live_cluster = lcl.data();
+            u.logZ = lz; u.logZerr = std::sqrt(std::fabs(var)); u.nlike = h_ctl->nlike;
+            u.ncluster = nc; u.ncluster_dead = ncd; u.nlive_p = cn.data();
+            u.logZp = e1.data(); u.logZperr = s1.data(); u.logZp_dead = e2.data(); u.logZperr_dead = s2.data();
+            on_update(hook_user, &u);
+        }
     }
 
     // clean_phantoms + calculate_covmats (nested_sampling.F90:326-368 minus file output / clustering)
@@ -775,7 +795,7 @@ struct Engine {
             (void)pc_launch_final_par(&S, st);
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
-        call_dumper();
+        call_dumper(true);
         auto t3 = clk::now();
         tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
         tm.t_loop = std::chrono::duration<double>(t2 - t1).count();
@@ -818,7 +838,7 @@ struct Engine {
         HIPCHK(hipMemcpy(zp2.data(), S.logZp2_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
         for (int i = 0; i < ncd; ++i) { out->logZp[i] = 2 * zp[i] - 0.5 * zp2[i]; out->varlogZp[i] = zp2[i] - 2 * zp[i]; }
         // posterior moments of theta from the dead points (device reduction, fixed order)
-        const int D = S.D, nb = pc_post_blocks(), pw = 2 * D + 1;
+        const int D = S.D + S.nDer, nb = pc_post_blocks(), pw = 2 * D + 1;   // theta and phi columns are contiguous in a row
         out->post_mean = (double *)std::calloc(D, sizeof(double)); out->post_var = (double *)std::calloc(D, sizeof(double));
         double *d_pmax = dalloc<double>(nb), *d_part = dalloc<double>((size_t)nb * pw), *h_part = halloc<double>((size_t)nb * pw);
         pc_launch_post_moments(&S, h_ctl->ndead, d_pmax, d_part, st);
@@ -897,7 +917,7 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
     auto t0 = clk::now();
     g_stop_requested = 0;
     Engine E;
-    if (hooks) E.dumper = hooks->dumper;
+    if (hooks) { E.dumper = hooks->dumper; E.on_update = hooks->on_update; E.hook_user = hooks->user; }
     E.setup(*s, *like, *prior);
     auto t1 = clk::now();
     std::memset(out, 0, sizeof(*out));

@@ -104,7 +104,8 @@ def test_full_run_matches_oracle(engine, kind, D, nDer, nlive, nr, B, general, c
     ok = o["logweights"] > -1e29
     assert np.array_equal(ok, g["logweights"] > -1e29)
     assert np.abs(g["logweights"][ok] - o["logweights"][ok]).max() < 1e-9
-    assert np.allclose(g["post_mean"], o["post_mean"], atol=1e-8)
+    nD = o["post_mean"].size                     # the engine also reports the derived parameters' moments
+    assert np.allclose(g["post_mean"][:nD], o["post_mean"], atol=1e-8)
 
 
 def test_analytic_evidence_and_reference_numbers(engine, golden):
@@ -119,7 +120,7 @@ def test_analytic_evidence_and_reference_numbers(engine, golden):
         g = api.run(s, L, P)
         assert abs(g["logZ"]) < 3 * g["logZerr"]
         assert abs(g["logZerr"] - ref[0]["logZerr"]) < 0.02
-        assert np.all(np.abs(g["post_mean"] - 0.5) < 0.02) and np.all(np.abs(np.sqrt(g["post_var"]) - 0.1) < 0.02)
+        assert np.all(np.abs(g["post_mean"][:20] - 0.5) < 0.02) and np.all(np.abs(np.sqrt(g["post_var"][:20]) - 0.1) < 0.02)
         zs.append(g["logZ"]); nds.append(g["ndead"])
     sig = ref[0]["logZerr"]
     assert abs(np.mean(zs) - np.mean([c["logZ"] for c in ref])) < 3 * sig * np.sqrt(1 / 6 + 1 / 8)

@@ -159,3 +159,59 @@ def test_ini_front_end_and_cli(engine, tmp_path):
     bad = tmp_path / "bad.ini"; bad.write_text("num_repeats = 4\nP : a | a | 1 | uniform | 1 | 0 1\n")
     out = subprocess.run([cli, str(bad), "gaussian"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 1 and "nlive" in out.stderr
+
+
+@pytest.mark.gpu
+def test_files_written_at_every_update(engine, tmp_path):
+    """read_write.F90: dead files grow as points die, live/stats files are refreshed at every update;
+    the final files agree with the run's own record (row counts, evidence, posterior table)."""
+    import ctypes as C
+    import os
+    api = engine
+    lib = api.load()
+    base = str(tmp_path / "chains"); os.makedirs(base)
+    seen = []
+
+    DUMPER = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                         C.POINTER(C.c_double), C.c_double, C.c_double)
+
+    def dumper(ndead, nlive, npars, live, dead, logw, logZ, logZerr):
+        # what is on disk when the dumper runs is the previous update's state or newer
+        p = os.path.join(base, "t_dead-birth.txt")
+        rows = sum(1 for _ in open(p)) if os.path.exists(p) else 0
+        stats = open(os.path.join(base, "t.stats")).read() if os.path.exists(os.path.join(base, "t.stats")) else ""
+        seen.append((ndead, nlive, rows, "(Still Active)" in stats))
+
+    cb = DUMPER(dumper)
+    lib.polychord_c_interface.restype = None
+    nD, nDer = 4, 1
+    gauss = C.cast(lib.polychord_hip_gaussian, C.c_void_p)
+    prior = C.cast(lib.polychord_hip_uniform_prior, C.c_void_p)
+    lib.polychord_hip_set_gaussian(C.c_double(0.5), C.c_double(0.1))
+    comm = C.c_int(0)
+    args = [gauss, prior, C.cast(cb, C.c_void_p), C.c_int(200), C.c_int(8), C.c_int(-1), C.c_int(-1), C.c_bool(False), C.c_int(0),
+            C.c_double(1e-3), C.c_double(-1e30), C.c_int(-1), C.c_double(0.0), C.c_bool(True), C.c_bool(True), C.c_bool(False),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False), C.c_bool(True), C.c_bool(True), C.c_bool(True), C.c_bool(False),
+            C.c_bool(False), C.c_double(np.exp(-1)), C.c_bool(True), C.c_int(nD), C.c_int(nDer), C.c_char_p(base.encode()),
+            C.c_char_p(b"t"), C.c_int(1), (C.c_double * 1)(1.0), (C.c_int * 1)(nD), C.c_int(0), None, None, C.c_int(3), C.byref(comm)]
+    lib.polychord_c_interface(*args)
+    assert len(seen) >= 3
+    # dead rows on disk never exceed the dumper's count and grow monotonically; active cluster while running
+    assert all(r <= nd for nd, _, r, _ in seen) and [r for *_, r, _ in seen] == sorted(r for *_, r, _ in seen)
+    assert seen[1][2] > 0 and seen[1][3]
+    ndead = seen[-1][0]
+    db = np.loadtxt(os.path.join(base, "t_dead-birth.txt")); d = np.loadtxt(os.path.join(base, "t_dead.txt"))
+    assert db.shape == (ndead, nD + nDer + 2) and d.shape == (ndead, nD + nDer + 1)
+    assert np.allclose(db[:, nD + nDer], d[:, 0])                      # logL column in both layouts
+    assert np.all(db[:, -1] <= db[:, -2] + 1e-12)                      # birth contour below logL
+    stats = open(os.path.join(base, "t.stats")).read().splitlines()
+    logZ, err = [float(x) for x in stats[8].split("=")[1].split("+/-")]
+    assert abs(logZ) < 4 * err
+    assert not any("(Still Active)" in l for l in stats)
+    assert any(l.startswith(" ndead:") and int(l.split()[1]) == ndead for l in stats)
+    k = stats.index("Dim No.       Mean        Sigma")
+    mean1, sig1 = [float(x) for x in stats[k + 1][3:].split("+/-")]
+    assert abs(mean1 - 0.5) < 0.03 and abs(sig1 - 0.1) < 0.03
+    post = np.loadtxt(os.path.join(base, "t.txt"))
+    assert post.shape[1] == 2 + nD + nDer and abs(post[:, 0].max() - 1.0) < 1e-12
+    assert os.path.getsize(os.path.join(base, "t_phys_live.txt")) == 0   # every live point has been killed
