@@ -70,6 +70,9 @@ void polychord_hip_set_uniform_prior(int nDims, const double *lo, const double *
 /* asks a running engine to stop at the next host callback boundary (used by language bindings when a
  * user callback raised: the reference throws through the Fortran frames, _pypolychord.cpp:219-224) */
 void polychord_hip_request_stop(void);
+/* .resume files (reference grammar) without a run: parse `in`, optionally write it back to `out`;
+ * counts[0..5] = nDims, nDerived, ndead, ncluster, ncluster_dead, total live points.  0 on success. */
+int polychord_hip_resume_copy(const char *in, const char *out, int *counts);
 /* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
 void polychord_hip_set_option(const char *name, double value);
 
@@ -92,6 +95,10 @@ typedef struct {
                            a few hundred event records per run instead of a few thousand */
     int force_general;  /* 1: always use the general contraction kernel (tests) */
     int ablate;         /* developer timing hook: bit mask of contraction sub-steps to skip; 0 = product */
+    const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
+                                  update and at the end; NULL = off */
+    const char *resume_read;   /* start from this .resume file if it exists (read_write.F90:384-476; also the file
+                                  pypolychord writes for `cube_samples`); NULL = off */
 } pchip_settings;
 
 typedef struct {
@@ -128,7 +135,9 @@ typedef struct {
 /* snapshot handed to the update hook: what the reference's file writers see at every update
    (nested_sampling.F90:323-340, read_write.F90) -- host memory owned by the engine, valid during the call */
 typedef struct {
-    int final_call;                 /* 1: the call after the kill-off (nested_sampling.F90:386-398) */
+    int final_call;                 /* 0: an update; 1: the call after the kill-off (nested_sampling.F90:386-398);
+                                       2: the initial live points, before any death (write_prior_file, :197) */
+    long ndiscarded;                /* prior samples rejected while the live points were generated */
     long ndead; int nlive, npars;   /* npars = nDims + nDerived + 2 */
     const double *dead;             /* [ndead][npars]  theta, phi, birth contour, logL -- in death order */
     const double *logpost;          /* [ndead] logweight + logL; failed spawns carry logzero + logL */

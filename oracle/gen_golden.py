@@ -83,6 +83,12 @@ def main():
     json.dump({"stats": j, "logL": logL, "birth": birth}, open(os.path.join(GOLD, "ref_replay.json"), "w"))
     print("replay rows", len(rows))
 
+    # resume grammar: the .resume file of the reference in the middle of a clustered run (4 live clusters,
+    # 4 dead ones, phantoms, posterior stacks) -- data written by the reference's write_resume_file
+    import shutil
+    sh(f"rm -rf {TMP}/rs && {nat} rastrigin 2 0 40 6 3 1 {TMP}/rs r 0 300")
+    shutil.copy(f"{TMP}/rs/r.resume_mid", os.path.join(GOLD, "ref_rastrigin2d_mid.resume"))
+
 
 if __name__ == "__main__":
     main()

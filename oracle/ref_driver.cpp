@@ -6,7 +6,7 @@
  * in this container and (b) as bench.py's cpu_baseline kind="reference" on the GPU box.
  * Test infrastructure only.
  *
- * usage: ref_driver <like> <nDims> <nDerived> <nlive> <nrepeats> <seed> <clustering> <base_dir> <root> [write_dead]
+ * usage: ref_driver <like> <nDims> <nDerived> <nlive> <nrepeats> <seed> <clustering> <base_dir> <root> [write_dead [resume_snapshot_after_ndead]]
  * prints one JSON line: {"logZ":..,"logZerr":..,"ndead":..,"nlike":..,"wall":..}
  */
 #include <cstdio>
@@ -63,7 +63,19 @@ static double twin(double *th, int D, double *phi, int nDer)
     return la - std::log(2.0);
 }
 static void prior(double *cube, double *theta, int D) { for (int d = 0; d < D; ++d) theta[d] = g_lo + (g_hi - g_lo) * cube[d]; }
-static void dumper(int, int, int, double *, double *, double *, double, double) {}
+// with write_resume the dumper keeps a copy of the first .resume file written after `g_snap_after` deaths:
+// the file at the end of a run holds no live points any more (golden fixture for the resume grammar)
+static std::string g_resume_path; static int g_snap_after = -1; static bool g_snapped = false;
+static void dumper(int ndead, int, int, double *, double *, double *, double, double)
+{
+    if (g_snap_after < 0 || g_snapped || ndead < g_snap_after) return;
+    FILE *in = std::fopen(g_resume_path.c_str(), "r");
+    if (!in) return;
+    FILE *out = std::fopen((g_resume_path + "_mid").c_str(), "w");
+    char buf[1 << 16]; size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, in)) > 0) std::fwrite(buf, 1, n, out);
+    std::fclose(in); std::fclose(out); g_snapped = true;
+}
 
 int main(int argc, char **argv)
 {
@@ -74,6 +86,8 @@ int main(int argc, char **argv)
     bool clustering = atoi(argv[7]) != 0;
     std::string base = argv[8], root = argv[9];
     bool write_dead = argc > 10 && atoi(argv[10]) != 0;
+    bool write_resume = argc > 11 && atoi(argv[11]) >= 0;
+    if (write_resume) { g_snap_after = atoi(argv[11]); g_resume_path = base + "/" + root + ".resume"; }
     mkdir(base.c_str(), 0755); mkdir((base + "/clusters").c_str(), 0755);
     double (*fn)(double *, int, double *, int) = gaussian;
     if (like == "rastrigin") { fn = rastrigin; g_lo = -5.12; g_hi = 5.12; }
@@ -84,7 +98,7 @@ int main(int argc, char **argv)
     if (pc_shim_reset) pc_shim_reset((unsigned)seed);
     auto t0 = std::chrono::steady_clock::now();
     polychord_c_interface(fn, prior, dumper, nlive, nrep, -1, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
-                          false, false, false, false, false, false, true, false, write_dead, false, false,
+                          false, false, false, write_resume, false, false, true, false, write_dead, false, false,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
                           1, grade_frac, grade_dims, 0, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -30,7 +30,8 @@ class Settings(C.Structure):
                 ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
-                ("force_general", C.c_int), ("ablate", C.c_int)]
+                ("force_general", C.c_int), ("ablate", C.c_int),
+                ("resume_write", C.c_char_p), ("resume_read", C.c_char_p)]
 
 
 class Like(C.Structure):

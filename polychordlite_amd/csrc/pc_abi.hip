@@ -7,6 +7,7 @@
 //   <root>_phys_live.txt / -birth (:621-676), <root>.paramnames is written by the Python layer.
 // Fatal conditions follow abort.F90:19-29: message on stderr, exit status 1.
 #include "../../include/polychord_hip.h"
+#include "pc_resume.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,7 +66,7 @@ std::string fmt_e24(double v)
 struct FileSink {
     std::string base, root;
     int nDims = 0, nDer = 0;
-    bool write_stats = false, write_live = false, write_dead = false, posteriors = false, equals = false;
+    bool write_stats = false, write_live = false, write_dead = false, posteriors = false, equals = false, write_prior = false;
     unsigned seed = 0; double logzero = -1e30, compression = 0.36787944117144233; int num_repeats = 1;
     long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
     std::vector<double> mu, sig;
@@ -168,6 +169,23 @@ struct FileSink {
     }
     void update(const pchip_update &u)
     {
+        if (u.final_call == 2) {                  // write_prior_file (read_write.F90:721-752) + generate.F90:274-279
+            if (!write_prior) return;
+            const int np = nDims + nDer;
+            FILE *f = open(path("_prior.txt"), "w");
+            std::string line;
+            for (int i = 0; i < u.nlive; ++i) {
+                const double *r = u.live + (size_t)i * u.npars;
+                line = fmt_e24(1.0) + fmt_e24(-2 * r[np + 1]);
+                for (int k = 0; k < np; ++k) line += fmt_e24(r[k]);
+                std::fprintf(f, "%s\n", line.c_str());
+            }
+            std::fclose(f);
+            f = open(path(".prior_info"), "w");
+            std::fprintf(f, "nprior = %12d\nndiscarded = %12ld\n", u.nlive, u.ndiscarded);
+            std::fclose(f);
+            return;
+        }
         if (write_dead && (u.ndead > dead_written || dead_written == 0)) {
             FILE *f1 = open(path("_dead.txt"), dead_written ? "a" : "w"), *f2 = open(path("_dead-birth.txt"), dead_written ? "a" : "w");
             rows(f1, u.dead, dead_written, u.ndead, u.npars, true, false);
@@ -181,7 +199,7 @@ struct FileSink {
             rows(f2, u.live, 0, u.nlive, u.npars, false, true);
             std::fclose(f1); std::fclose(f2);
         }
-        if (u.final_call && (posteriors || equals)) posterior_files(u);
+        if (u.final_call == 1 && (posteriors || equals)) posterior_files(u);
         if (write_stats) stats(u);
         nlike_last = u.nlike;
     }
@@ -253,6 +271,21 @@ void polychord_hip_set_option(const char *name, double value)
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }
 
+// .resume files without a run: parse `in` and write it back to `out` (NULL: only parse).  counts[0..5] =
+// nDims, nDerived, ndead, ncluster, ncluster_dead, live points in total.  Returns 0 on success.
+int polychord_hip_resume_copy(const char *in, const char *out, int *counts)
+{
+    PcResume r; std::string err;
+    if (!pc_resume_read(in, r, err)) { std::fprintf(stderr, "polychord_hip: %s\n", err.c_str()); return 1; }
+    if (counts) {
+        int nl = 0;
+        for (int v : r.nlive) nl += v;
+        counts[0] = r.nDims; counts[1] = r.nDerived; counts[2] = r.ndead; counts[3] = r.ncluster; counts[4] = r.ncluster_dead; counts[5] = nl;
+    }
+    if (out && !pc_resume_write(out, r, -1e30, err)) { std::fprintf(stderr, "polychord_hip: %s\n", err.c_str()); return 2; }
+    return 0;
+}
+
 void polychord_c_interface(
     polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
     int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
@@ -263,7 +296,7 @@ void polychord_c_interface(
     char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
     double *loglikes, int *nlives, int seed, int *comm)
 {
-    (void)write_resume; (void)write_paramnames; (void)read_resume; (void)write_prior; (void)maximise;
+    (void)write_paramnames; (void)maximise;
     (void)synchronous; (void)comm; (void)grade_frac;
     if (num_repeats < 1) halt_program("You need to set num_repeats. Suggestion: 5*nDims");     // settings.f90:216
     if (nGrade > 1 || (nGrade == 1 && grade_dims && grade_dims[0] != nDims))
@@ -276,6 +309,9 @@ void polychord_c_interface(
     s.compression_factor = compression_factor; s.n_nlives = n_nlives; s.loglikes = loglikes; s.nlives = nlives;
     s.seed = seed >= 0 ? seed : (int)(std::chrono::system_clock::now().time_since_epoch().count() & 0x7fffffff); // random_utils.F90:62-79
     s.batch = G.batch; s.device = G.device;
+    const std::string resume_path = std::string(base_dir ? base_dir : "chains") + "/" + (file_root ? file_root : "test") + ".resume";   // read_write.F90:1040-1062
+    if (write_resume) s.resume_write = resume_path.c_str();
+    if (read_resume) s.resume_read = resume_path.c_str();
     pchip_like L{}; pchip_prior P{};
     if (loglikelihood == polychord_hip_gaussian) { L.kind = PCHIP_LIKE_GAUSSIAN; L.mu = G.g_mu; L.sigma = G.g_sigma; }
     else if (loglikelihood == polychord_hip_rastrigin) L.kind = PCHIP_LIKE_RASTRIGIN;
@@ -289,7 +325,7 @@ void polychord_c_interface(
         if (G.up_D == nDims) { P.lo = G.up_lo.data(); P.hi = G.up_hi.data(); }
     } else { P.kind = 0; P.fn = prior; }
     const std::string base = base_dir ? base_dir : "chains", root = file_root ? file_root : "test";
-    if (write_stats_f || write_dead || write_live || posteriors || equals) {
+    if (write_stats_f || write_dead || write_live || posteriors || equals || write_prior || write_resume) {
         struct stat sb;
         if (stat(base.c_str(), &sb) != 0) halt_program(("PolyChord Error: " + base + " does not exist").c_str()); // read_write.F90:28-38
     }
@@ -300,11 +336,11 @@ void polychord_c_interface(
     FileSink sink;
     sink.base = base; sink.root = root; sink.nDims = nDims; sink.nDer = nDerived;
     sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
-    sink.posteriors = posteriors; sink.equals = equals; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
+    sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
     sink.compression = compression_factor; sink.num_repeats = num_repeats;
     if ((posteriors || equals) && boost_posterior != 0.0 && feedback >= 1)
         std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");
-    const bool files = write_stats_f || write_dead || write_live || posteriors || equals;
+    const bool files = write_stats_f || write_dead || write_live || posteriors || equals || write_prior;
     pchip_result r;
     pchip_hooks hooks{dumper, files ? FileSink::hook : nullptr, &sink};
     const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);

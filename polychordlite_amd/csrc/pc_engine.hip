@@ -6,6 +6,7 @@
 // on the device.  One round = [K0 directions | K1 slice chains] (when the nursery is empty)
 // + [K2 consume | K3 apply] + (on an update) [clean phantoms | covariance + Cholesky].
 #include "pc_state.h"
+#include "pc_resume.h"
 #include "../../include/polychord_hip.h"
 #include <cstdio>
 #include <cstdlib>
@@ -204,6 +205,8 @@ struct Engine {
     // host mirror of the dead points for the dumper hook (nested_sampling.F90:546-590)
     polychord_dumper_fn dumper = nullptr;
     pchip_update_fn on_update = nullptr; void *hook_user = nullptr;
+    long ndiscarded = 0;                        // prior samples rejected while generating the live points
+    bool resume_static = true; unsigned resume_batch0 = 0;
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<double> h_lo, h_hi;
     PcState S{};
@@ -347,21 +350,23 @@ struct Engine {
         kt.collect();
     }
 
+    void grow_dead(int nd)
+    {
+        HIPCHK(hipStreamSynchronize(st_copy));        // rows still travelling from the old array
+        auto grow = [&](auto *&p, size_t per) {
+            using T = std::remove_reference_t<decltype(*p)>;
+            T *q = dalloc<T>((size_t)nd * per);
+            HIPCHK(hipMemcpyAsync(q, p, sizeof(T) * (size_t)h_ctl->ndead * per, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            dfree(p); p = q;
+        };
+        grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1); grow(S.dead_entry, 1);
+        S.Dcap = nd;
+    }
+
     void ensure_capacity()
     {   // the next batch may append B*nr phantoms and B dead points
-        if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) {
-            const int nd = S.Dcap * 2;
-            HIPCHK(hipStreamSynchronize(st_copy));        // rows still travelling from the old array
-            auto grow = [&](auto *&p, size_t per) {
-                using T = std::remove_reference_t<decltype(*p)>;
-                T *q = dalloc<T>((size_t)nd * per);
-                HIPCHK(hipMemcpyAsync(q, p, sizeof(T) * (size_t)h_ctl->ndead * per, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipStreamSynchronize(st));
-                dfree(p); p = q;
-            };
-            grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1); grow(S.dead_entry, 1);
-            S.Dcap = nd;
-        }
+        if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) grow_dead(S.Dcap * 2);
         if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) {
             std::fprintf(stderr, "polychord_hip: phantom capacity exceeded (%d + %d*%d > %d)\n", h_ctl->nphantom, B, S.nr, S.Pcap);
             std::abort();
@@ -370,9 +375,10 @@ struct Engine {
 
     // dump (nested_sampling.F90:546-590): live and dead points as [theta, phi, birth, logL] rows,
     // posterior log-weights normalised to logsumexp 0
-    void call_dumper(bool final_call = false)
+    // stage 0: update, 1: after the kill-off, 2: the initial live points before any death (prior files)
+    void call_dumper(int stage = 0)
     {
-        if (!dumper && !on_update) return;
+        if (!(dumper && stage != 2) && !on_update) return;
         const int nT = S.nT, D = S.D, nDer = S.nDer, npars = D + nDer + 2, nd = h_ctl->ndead;
         HIPCHK(hipStreamSynchronize(st));
         if (nd > hm_ndead) {
@@ -408,7 +414,7 @@ struct Engine {
         }
         const double lz = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2), var = h_ctl->logZ2 - 2 * h_ctl->logZ;
         double dummy = 0.0;
-        if (dumper) dumper(nd, (int)ord.size(), npars, live.data(), nd > 0 ? hm_dead.data() : &dummy, nd > 0 ? lwn.data() : &dummy, lz, std::sqrt(std::fabs(var)));
+        if (dumper && stage != 2) dumper(nd, (int)ord.size(), npars, live.data(), nd > 0 ? hm_dead.data() : &dummy, nd > 0 ? lwn.data() : &dummy, lz, std::sqrt(std::fabs(var)));
         if (on_update) {
             const int nc = h_ctl->ncluster, ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead);
             std::vector<int> lcl(std::max<size_t>(1, ord.size()));
@@ -420,7 +426,7 @@ struct Engine {
             for (int i = 0; i < nc; ++i) { e1[i] = 2 * zp[i] - 0.5 * zp2[i]; s1[i] = std::sqrt(std::fabs(zp2[i] - 2 * zp[i])); }   // run_time_info.f90:652-678
             for (int i = 0; i < ncd; ++i) { e2[i] = 2 * zd[i] - 0.5 * zd2[i]; s2[i] = std::sqrt(std::fabs(zd2[i] - 2 * zd[i])); }
             pchip_update u{};
-            u.final_call = final_call ? 1 : 0; u.ndead = nd; u.nlive = (int)ord.size(); u.npars = npars;
+            u.final_call = stage; u.ndiscarded = ndiscarded; u.ndead = nd; u.nlive = (int)ord.size(); u.npars = npars;
             u.dead = nd > 0 ? hm_dead.data() : &dummy; u.logpost = nd > 0 ? hm_logw.data() : &dummy;
             u.live = live.data(); u.live_cluster = lcl.data();
             u.logZ = lz; u.logZerr = std::sqrt(std::fabs(var)); u.nlike = h_ctl->nlike;
@@ -450,6 +456,7 @@ struct Engine {
         hipEvent_t e1 = kt.begin(KT_COV);
         covmats(total, h_ctl->ncluster);
         kt.end(KT_COV, e1);
+        write_resume();                               // nested_sampling.F90:337
     }
 
     // ---- kNN clustering (clustering.f90:253-324); heavy parts on the device (pc_cluster.hip)
@@ -509,7 +516,7 @@ struct Engine {
         HIPCHK(hipMemcpy(v.data(), p, sizeof(T) * n, hipMemcpyDeviceToHost));
         return v;
     }
-    template <class T> void ul(T *p, const std::vector<T> &v) { HIPCHK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice)); }
+    template <class T> void ul(T *p, const std::vector<T> &v) { if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice)); }
 
     // add_cluster (run_time_info.f90:303-505): cluster p splits into nnew clusters appended at the end
     void add_cluster(int p, const std::vector<int> &labels, int nnew)
@@ -661,6 +668,8 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(&S.ctl->nlike, &h_ctl->nlike, sizeof(long long), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
         dfree(drows);
+        ndiscarded = (long)attempt - nprior;
+        call_dumper(2);
         if (nprior > cfg.nlive) { pc_launch_consume(&S, 2, 0, st); read_ctl(); }
     }
 
@@ -708,6 +717,7 @@ struct Engine {
             HIPCHK(hipMemcpy(hrows.data(), rows, sizeof(double) * (size_t)nprior * nT, hipMemcpyDeviceToHost));
             for (int i = 0; i < nprior && have < nprior; ++i)
                 if (hl[i] > cfg.logzero) { keep_rows.insert(keep_rows.end(), hrows.begin() + (size_t)i * nT, hrows.begin() + (size_t)(i + 1) * nT); have++; nlike++; }
+                else ndiscarded++;
             attempt0 += nprior;
         }
         if (!direct) HIPCHK(hipMemcpy(rows, keep_rows.data(), sizeof(double) * (size_t)nprior * nT, hipMemcpyHostToDevice));
@@ -716,6 +726,7 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(&S.ctl->nlike, &h_ctl->nlike, sizeof(long long), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
         dfree(rows); dfree(rl);
+        call_dumper(2);                // write_prior_file, nested_sampling.F90:197
         if (nprior > cfg.nlive) {      // nested_sampling.F90:201-205
             pc_launch_consume(&S, 2, 0, st);
             read_ctl();
@@ -733,20 +744,163 @@ struct Engine {
         h_dead_copied = nd;
     }
 
+    // ---- .resume (pc_resume.h): the sampler state at an update boundary, in the reference's own grammar
+    void export_resume(PcResume &r)
+    {
+        HIPCHK(hipStreamSynchronize(st));
+        const int D = S.D, nT = S.nT, nc = h_ctl->ncluster, ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead), maxc = S.maxc;
+        r = PcResume{};
+        r.nDims = D; r.nDerived = S.nDer; r.ndead = h_ctl->ndead; r.ncluster = nc; r.ncluster_dead = ncd;
+        r.grade_dims = {D}; r.num_repeats = {S.nr}; r.nlike = {h_ctl->nlike};
+        r.logZ = h_ctl->logZ; r.logZ2 = h_ctl->logZ2; r.thin_posterior = cfg.boost_posterior; r.logX_last_update = h_ctl->logX_last_update;
+        auto take = [&](const double *p) { auto v = dl(p, std::max(1, nc)); v.resize(nc); return v; };
+        r.logLp = take(S.logLp); r.logXp = take(S.logXp); r.logZXp = take(S.logZXp); r.logZp = take(S.logZp);
+        r.logZp2 = take(S.logZp2); r.logZpXp = take(S.logZpXp);
+        auto xq = dl(S.XpXq, (size_t)maxc * maxc);
+        r.logXpXq.assign((size_t)nc * nc, 0.0);
+        for (int q = 0; q < nc; ++q) for (int p = 0; p < nc; ++p) r.logXpXq[(size_t)q * nc + p] = xq[(size_t)p * maxc + q];
+        r.logZp_dead = dl(S.logZp_dead, std::max(1, ncd)); r.logZp_dead.resize(ncd);
+        r.logZp2_dead = dl(S.logZp2_dead, std::max(1, ncd)); r.logZp2_dead.resize(ncd);
+        auto cov = dl(S.cov, (size_t)std::max(1, nc) * D * D), ch = dl(S.chol, (size_t)std::max(1, nc) * D * D);
+        r.covmat.assign((size_t)nc * D * D, 0.0); r.cholesky.assign((size_t)nc * D * D, 0.0);
+        for (int c = 0; c < nc; ++c) for (int j = 0; j < D; ++j) for (int a = 0; a < D; ++a) {     // file line j = column j
+            r.covmat[((size_t)c * D + j) * D + a] = cov[((size_t)c * D + a) * D + j];
+            r.cholesky[((size_t)c * D + j) * D + a] = ch[((size_t)c * D + a) * D + j];
+        }
+        auto cn = dl(S.cl_n, std::max(1, nc)); auto cl = dl(S.cl_list, (size_t)maxc * S.Ncap);
+        auto rows = dl(S.live, (size_t)S.Ncap * nT); auto uid = dl(S.cl_uid, std::max(1, nc));
+        r.nlive.assign(nc, 0); r.imin.assign(nc, 1); r.live.assign(nc, {}); r.nphantom.assign(nc, 0); r.phantom.assign(nc, {});
+        for (int c = 0; c < nc; ++c) {
+            r.nlive[c] = cn[c];
+            double lo = PC_HUGE;
+            for (int k = 0; k < cn[c]; ++k) {
+                const double *row = rows.data() + (size_t)cl[(size_t)c * S.Ncap + k] * nT;
+                r.live[c].insert(r.live[c].end(), row, row + nT);
+                if (row[S.l0] < lo) { lo = row[S.l0]; r.imin[c] = k + 1; }
+            }
+        }
+        const int nph = h_ctl->nphantom;
+        auto ph = dl(S.phantom, (size_t)std::max(1, nph) * nT); auto pc = dl(S.ph_cuid, std::max(1, nph));
+        for (int j = 0; j < nph; ++j)
+            for (int c = 0; c < nc; ++c)
+                if (uid[c] == pc[j]) { r.phantom[c].insert(r.phantom[c].end(), ph.begin() + (size_t)j * nT, ph.begin() + (size_t)(j + 1) * nT); r.nphantom[c]++; break; }
+        r.dead = dl(S.dead, (size_t)std::max(1, r.ndead) * nT); r.dead.resize((size_t)r.ndead * nT);
+        r.logweights = dl(S.dead_logw, std::max(1, r.ndead)); r.logweights.resize(r.ndead);
+    }
+
+    void write_resume()
+    {
+        if (!cfg.resume_write) return;
+        PcResume r;
+        export_resume(r);
+        std::string err;
+        if (!pc_resume_write(cfg.resume_write, r, cfg.logzero, err)) { std::fprintf(stderr, "polychord_hip: %s\n", err.c_str()); std::exit(1); }
+    }
+
+    // upload a .resume state; the run continues with the counter RNG streams of batch `ndead` onwards
+    // (the reference does not store its generator state either: a resumed run is a valid, different trajectory)
+    bool import_resume(const PcResume &r, std::string &err)
+    {
+        const int D = S.D, nT = S.nT, nc = r.ncluster, maxc = S.maxc, Ncap = S.Ncap;
+        if (r.nDims != D || r.nDerived != S.nDer) { err = "resume file has different nDims / nDerived"; return false; }
+        int ntot = 0, nph = 0;
+        for (int c = 0; c < nc; ++c) { ntot += r.nlive[c]; nph += r.nphantom[c]; }
+        // ncluster = 0: the file of a finished run (every live point killed): nothing left to sample, the run
+        // returns what the file holds, as the reference does
+        if (nc > maxc || ntot > Ncap || (nc >= 1 && ntot < 1)) { err = "resume file: cluster / live point counts do not fit this run's settings"; return false; }
+        if (nph + (long long)B * S.nr > S.Pcap) { err = "resume file: too many phantom points"; return false; }
+        if ((long long)r.ndead + B + Ncap + 16 > S.Dcap) { h_ctl->ndead = 0; grow_dead(2 * (r.ndead + B + Ncap + 16)); }
+        std::vector<double> rows((size_t)Ncap * nT, 0.0), lL(Ncap, PC_HUGE), entry(Ncap, cfg.logzero);
+        std::vector<int> lc(Ncap, -1), lp(Ncap, 0), cl((size_t)maxc * Ncap, 0), cn(maxc, 0), imin(maxc, 0);
+        std::vector<unsigned> uid(maxc, 0u);
+        std::vector<double> logLp(maxc, cfg.logzero), lref(maxc, 0.0), lsum(maxc, 0.0);
+        int slot = 0;
+        for (int c = 0; c < nc; ++c) {
+            cn[c] = r.nlive[c]; uid[c] = (unsigned)(c + 1);
+            double lo = PC_HUGE, hi = -PC_HUGE;
+            for (int k = 0; k < r.nlive[c]; ++k, ++slot) {
+                const double *row = r.live[c].data() + (size_t)k * nT;
+                std::memcpy(rows.data() + (size_t)slot * nT, row, sizeof(double) * nT);
+                lL[slot] = row[S.l0]; lc[slot] = c; lp[slot] = k; entry[slot] = row[S.b0]; cl[(size_t)c * Ncap + k] = slot;
+                if (row[S.l0] < lo) { lo = row[S.l0]; imin[c] = slot; }
+                hi = std::max(hi, row[S.l0]);
+            }
+            logLp[c] = r.nlive[c] ? lo : cfg.logzero;
+            lref[c] = r.nlive[c] ? hi : 0.0;
+            for (int k = 0; k < r.nlive[c]; ++k) lsum[c] += std::exp(r.live[c][(size_t)k * nT + S.l0] - lref[c]);
+        }
+        ul(S.live, rows); ul(S.live_logL, lL); ul(S.live_entry, entry); ul(S.live_cluster, lc); ul(S.live_pos, lp);
+        ul(S.cl_list, cl); ul(S.cl_n, cn); ul(S.cl_uid, uid); ul(S.imin_slot, imin); ul(S.logLp, logLp); ul(S.lse_ref, lref); ul(S.lse_sum, lsum);
+        auto put = [&](double *dst, const std::vector<double> &v) { std::vector<double> t(maxc, cfg.logzero); std::copy(v.begin(), v.end(), t.begin()); ul(dst, t); };
+        put(S.logZp, r.logZp); put(S.logZXp, r.logZXp); put(S.logZp2, r.logZp2); put(S.logZpXp, r.logZpXp);
+        { std::vector<double> t(maxc, 0.0); std::copy(r.logXp.begin(), r.logXp.end(), t.begin()); ul(S.logXp, t); }
+        std::vector<double> xq((size_t)maxc * maxc, 0.0);
+        for (int q = 0; q < nc; ++q) for (int p = 0; p < nc; ++p) xq[(size_t)p * maxc + q] = r.logXpXq[(size_t)q * nc + p];
+        ul(S.XpXq, xq);
+        std::vector<double> cov((size_t)maxc * D * D, 0.0), ch((size_t)maxc * D * D, 0.0);
+        for (int c = 0; c < maxc; ++c) for (int a = 0; a < D; ++a) { cov[((size_t)c * D + a) * D + a] = 1.0; ch[((size_t)c * D + a) * D + a] = 1.0; }
+        for (int c = 0; c < nc; ++c) for (int j = 0; j < D; ++j) for (int a = 0; a < D; ++a) {
+            cov[((size_t)c * D + a) * D + j] = r.covmat[((size_t)c * D + j) * D + a];
+            ch[((size_t)c * D + a) * D + j] = r.cholesky[((size_t)c * D + j) * D + a];
+        }
+        ul(S.cov, cov); ul(S.chol, ch);
+        const int ncd = std::min(r.ncluster_dead, S.maxc_dead);
+        { std::vector<double> a(r.logZp_dead.begin(), r.logZp_dead.begin() + ncd), b(r.logZp2_dead.begin(), r.logZp2_dead.begin() + ncd); ul(S.logZp_dead, a); ul(S.logZp2_dead, b); }
+        // phantoms, cluster by cluster
+        std::vector<double> ph((size_t)std::max(1, nph) * nT), phL(std::max(1, nph));
+        std::vector<unsigned> phC(std::max(1, nph)); std::vector<unsigned long long> phU(std::max(1, nph));
+        int j = 0;
+        for (int c = 0; c < nc; ++c)
+            for (int k = 0; k < r.nphantom[c]; ++k, ++j) {
+                std::memcpy(ph.data() + (size_t)j * nT, r.phantom[c].data() + (size_t)k * nT, sizeof(double) * nT);
+                phL[j] = ph[(size_t)j * nT + S.l0]; phC[j] = uid[c]; phU[j] = 0xFFFFFFFF00000000ull | (unsigned)j;
+            }
+        if (nph) { ul(S.phantom, ph); ul(S.ph_logL, phL); ul(S.ph_cuid, phC); ul(S.ph_uid, phU); }
+        // dead points
+        if (r.ndead) {
+            ul(S.dead, r.dead); ul(S.dead_logw, r.logweights);
+            std::vector<double> z(r.ndead, 0.0), en(r.ndead);
+            for (int i = 0; i < r.ndead; ++i) en[i] = r.dead[(size_t)i * nT + S.b0];
+            ul(S.dead_postX, z); ul(S.dead_postZ, z); ul(S.dead_entry, en);
+            std::vector<unsigned> du(r.ndead, 0u); ul(S.dead_cuid, du);
+        }
+        PcCtl c0 = *h_ctl;
+        c0.status = nc >= 1 ? PC_ST_RUNNING : PC_ST_DONE; c0.ncluster = nc; c0.ncluster_dead = ncd; c0.ndead = r.ndead; c0.nphantom = nph;
+        c0.logZ = r.logZ; c0.logZ2 = r.logZ2; c0.logX_last_update = r.logX_last_update; c0.next_cluster_uid = (unsigned)nc + 1;
+        c0.nlike = r.nlike.empty() ? 0 : r.nlike[0]; c0.nlike_device = c0.nlike; c0.i_nursery = 0; c0.failures = 0;
+        HIPCHK(hipMemcpy(S.ctl, &c0, sizeof(PcCtl), hipMemcpyHostToDevice));
+        *h_ctl = c0;
+        return true;
+    }
+
     int run(pchip_result *out)
     {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
         h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
-        if (callback_mode) generate_live_callback(); else generate_live();
+        bool resumed = false;
+        if (cfg.resume_read) {                         // read_write.F90:384-476; a missing file means a fresh start
+            if (FILE *probe = std::fopen(cfg.resume_read, "r")) {
+                std::fclose(probe);
+                PcResume rs; std::string err;
+                if (!pc_resume_read(cfg.resume_read, rs, err) || !import_resume(rs, err)) { std::fprintf(stderr, "polychord_hip: %s\n", err.c_str()); return 6; }
+                resumed = true;
+                int ntot = 0;
+                for (int v : rs.nlive) ntot += v;
+                if (ntot > cfg.nlive && rs.ncluster == 1) { pc_launch_consume(&S, 2, 0, st); read_ctl(); ntot = cfg.nlive; }   // nested_sampling.F90:201-205
+                resume_static = (ntot == cfg.nlive);
+                resume_batch0 = (unsigned)rs.ndead;
+            }
+        }
+        if (!resumed) { if (callback_mode) generate_live_callback(); else generate_live(); }
         if (g_stop_requested) return 5;
         auto t1 = clk::now();
-        unsigned batch = 0;
+        unsigned batch = resume_batch0;               // fresh counter-RNG streams after a resume
         bool sort_valid = false;
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
-        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && cfg.force_general != 1 && pc_fast_fits(&S);
+        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && resume_static && cfg.force_general != 1 && pc_fast_fits(&S);
         const bool par_ok = fast_ok && cfg.force_general == 0 && pc_par_fits(&S);
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
@@ -790,12 +944,15 @@ struct Engine {
         HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
         const int nc_end = h_ctl->ncluster;
-        if (par_ok && h_ctl->ncluster == 1) {
+        if (h_ctl->ncluster == 0) {
+            // a finished run read back from its .resume file: nothing to kill
+        } else if (par_ok && h_ctl->ncluster == 1) {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
-        call_dumper(true);
+        call_dumper(1);
+        write_resume();
         auto t3 = clk::now();
         tm.t_gen = std::chrono::duration<double>(t1 - t0).count();
         tm.t_loop = std::chrono::duration<double>(t2 - t1).count();

@@ -75,11 +75,86 @@ class _Output:
         return f"log(Z) = {self.logZ} +/- {self.logZerr}"
 
 
+def _e24(v):
+    """Fortran E24.15E3 (src/polychord/utils.F90:19-21)"""
+    v = float(v)
+    if v == 0.0:
+        return "   0.000000000000000E+000"
+    m, e = ("%.14E" % abs(v)).split("E")
+    ex = int(e) + 1
+    return ("%s0.%sE%s%03d" % ("-" if v < 0 else "", m.replace(".", ""), "-" if ex < 0 else "+", abs(ex))).rjust(24)
+
+
+def _make_resume_file(loglikelihood, **kwargs):
+    """A .resume file whose live points are the user's `cube_samples` (polychord.py:650-789 of the reference):
+    one cluster, nothing dead yet, identity covariance; the run then starts with read_resume."""
+    cubes = np.asarray(kwargs["cube_samples"], dtype=float)
+    lives = []
+    for cube in cubes:
+        theta = np.asarray(kwargs["prior"](cube), dtype=float)
+        logL = loglikelihood(theta)
+        try:
+            logL, derived = logL
+        except TypeError:
+            derived = []
+        lives.append(np.concatenate([cube, theta, np.asarray(derived, dtype=float), [kwargs["logzero"], float(logL)]]))
+    lives = np.array(lives)
+    nDims, nDerived = cubes.shape[1], lives.shape[1] - 2 * cubes.shape[1] - 2
+    lz, ident = kwargs["logzero"], np.identity(nDims)
+    sep = "---------------------------------------"
+
+    def ints(v):
+        return "".join("%12d" % int(x) for x in np.atleast_1d(v))
+
+    def reals(v):
+        return "".join(_e24(x) for x in np.atleast_1d(v))
+
+    body = [
+        ("Number of dimensions", [ints(nDims)]), ("Number of derived parameters", [ints(nDerived)]),
+        ("Number of dead points/iterations", [ints(0)]), ("Number of clusters", [ints(1)]), ("Number of dead clusters", [ints(0)]),
+        ("Number of global weighted posterior points", [ints(0)]), ("Number of global equally weighted posterior points", [ints(0)]),
+        ("Number of grades", [ints(len(kwargs["grade_dims"]))]), ("positions of grades", [ints(kwargs["grade_dims"])]),
+        ("Number of repeats", [ints(kwargs["num_repeats"])]), ("Number of likelihood calls", [ints(len(lives))]),
+        ("Number of live points in each cluster", [ints(len(lives))]), ("Number of phantom points in each cluster", [ints(0)]),
+        ("Number of weighted posterior points in each cluster", [ints(0)]),
+        ("Number of equally weighted posterior points in each cluster", [ints(0)]),
+        ("Minimum loglikelihood positions", [ints(np.argmin(lives[:, -1]) + 1)]),
+        ("Number of weighted posterior points in each dead cluster", []),
+        ("Number of equally weighted posterior points in each dead cluster", []),
+        ("global evidence -- log(<Z>)", [reals(lz)]), ("global evidence^2 -- log(<Z^2>)", [reals(lz)]),
+        ("posterior thin factor", [reals(kwargs["boost_posterior"])]), ("local loglikelihood bounds", [reals(lives[:, -1].min())]),
+        ("local volume -- log(<X_p>)", [reals(0.0)]), ("last update volume", [reals(0.0)]),
+        ("global evidence volume cross correlation -- log(<ZX_p>)", [reals(lz)]), ("local evidence -- log(<Z_p>)", [reals(lz)]),
+        ("local evidence^2 -- log(<Z_p^2>)", [reals(lz)]), ("local evidence volume cross correlation -- log(<Z_pX_p>)", [reals(lz)]),
+        ("local volume cross correlation -- log(<X_pX_q>)", [reals(0.0)]), ("maximum log weights -- log(w_p)", [reals(lz)]),
+        ("local dead evidence -- log(<Z_p>)", []), ("local dead evidence^2 -- log(<Z_p^2>)", []),
+        ("maximum dead log weights -- log(w_p)", []),
+        ("covariance matrices", [sep] + [reals(x) for x in ident]), ("cholesky decompositions", [sep] + [reals(x) for x in ident]),
+        ("live points", [sep] + [reals(x) for x in lives]), ("dead points", []), ("logweights of dead points", []),
+        ("phantom points", [sep]), ("weighted posterior points", [sep]), ("dead weighted posterior points", []),
+        ("global weighted posterior points", []), ("equally weighted posterior points", [sep]),
+        ("dead equally weighted posterior points", []), ("global equally weighted posterior points", []),
+    ]
+    path = Path(kwargs["base_dir"]) / (kwargs["file_root"] + ".resume")
+    with open(path, "w") as f:
+        for name, lines in body:
+            f.write("=== %s ===\n" % name)
+            for l in lines:
+                f.write(l + "\n")
+
+
+def _legacy_make_resume_file(settings, loglikelihood, prior):
+    kwargs = dict(settings.__dict__)
+    kwargs["prior"] = prior
+    _make_resume_file(loglikelihood, **kwargs)
+
+
 def run_polychord(loglikelihood, nDims, nDerived, settings, prior=default_prior, dumper=default_dumper):
     """legacy interface (polychord.py:16-215)"""
     Path(settings.cluster_dir).mkdir(parents=True, exist_ok=True)
-    if settings.cube_samples is not None:
-        raise NotImplementedError("cube_samples needs the resume-file reader, which this engine does not have yet")
+    if settings.cube_samples is not None:                      # polychord.py:170-173 of the reference
+        _legacy_make_resume_file(settings, loglikelihood, prior)
+        settings.read_resume = True
     wl, wp = _wrap(loglikelihood, prior)
     settings.grade_dims = [int(d) for d in settings.grade_dims]
     settings.nlives = {float(logL): int(nlive) for logL, nlive in settings.nlives.items()}
@@ -103,7 +178,7 @@ def run(loglikelihood, nDims, **kwargs):
         "write_resume": True, "write_paramnames": False, "read_resume": True, "write_stats": True, "write_live": True,
         "write_dead": True, "write_prior": True, "maximise": False, "compression_factor": np.exp(-1), "synchronous": True,
         "base_dir": "chains", "file_root": "test", "cluster_dir": "clusters", "grade_dims": [nDims], "nlives": {},
-        "seed": -1,
+        "seed": -1, "cube_samples": None,
     }
     default_kwargs["grade_frac"] = ([1.0] * len(default_kwargs["grade_dims"]) if "grade_dims" not in kwargs
                                     else [1.0] * len(kwargs["grade_dims"]))
@@ -119,6 +194,9 @@ def run(loglikelihood, nDims, **kwargs):
     if sum(kwargs["grade_dims"]) != nDims:
         raise ValueError(f"grade_dims ({sum(kwargs['grade_dims'])}) must sum to nDims ({nDims})")
     kwargs["nlives"] = {float(logL): int(nlive) for logL, nlive in kwargs["nlives"].items()}
+    if kwargs["cube_samples"] is not None:                     # polychord.py:596-598 of the reference
+        _make_resume_file(loglikelihood, **kwargs)
+        kwargs["read_resume"] = True
     _pypolychord.run(wl, wp, kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
                      kwargs["nprior"], kwargs["nfail"], kwargs["do_clustering"], kwargs["feedback"],
                      kwargs["precision_criterion"], kwargs["logzero"], kwargs["max_ndead"], kwargs["boost_posterior"],

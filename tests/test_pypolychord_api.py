@@ -215,3 +215,52 @@ def test_files_written_at_every_update(engine, tmp_path):
     post = np.loadtxt(os.path.join(base, "t.txt"))
     assert post.shape[1] == 2 + nD + nDer and abs(post[:, 0].max() - 1.0) < 1e-12
     assert os.path.getsize(os.path.join(base, "t_phys_live.txt")) == 0   # every live point has been killed
+
+
+@pytest.mark.gpu
+def test_resume_and_cube_samples(engine, tmp_path):
+    """write_resume / read_resume (read_write.F90:219-288, 384-476): a run restarted from the .resume file of an
+    earlier update keeps the dead points of the first run and finishes with a consistent evidence; a finished
+    run's file gives its result back; cube_samples start a run from user supplied live points."""
+    import shutil
+    from polychordlite_amd import pypolychord as pc
+    from polychordlite_amd.pypolychord.device_likelihoods import Gaussian
+    nD = 4
+    base1, base2 = tmp_path / "a", tmp_path / "b"
+    snap = {}
+
+    def dumper(live, dead, logw, logZ, logZerr):
+        f = base1 / "r.resume"
+        if "n" not in snap and f.exists() and len(dead) > 400:
+            (base2 / "clusters").mkdir(parents=True, exist_ok=True)
+            shutil.copy(f, base2 / "r.resume")
+            snap["n"] = int(open(f).read().splitlines()[5])        # dead points in that file
+    kw = dict(nDerived=1, nlive=100, num_repeats=8, do_clustering=False, feedback=0, seed=5, file_root="r",
+              write_resume=True, read_resume=True, posteriors=False, equals=False, write_live=False, write_prior=False)
+    pc.run(Gaussian(mu=0.5, sigma=0.1), nD, base_dir=str(base1), dumper=dumper, **kw)
+    assert "n" in snap and snap["n"] > 0
+    full = np.loadtxt(base1 / "r_dead-birth.txt")
+    # restart from the copied mid-run file
+    pc.run(Gaussian(mu=0.5, sigma=0.1), nD, base_dir=str(base2), **kw)
+    cont = np.loadtxt(base2 / "r_dead-birth.txt")
+    assert cont.shape[0] > snap["n"] + 100
+    assert np.array_equal(cont[:snap["n"]], full[:snap["n"]])       # the first run's dead points, as written
+    st = open(base2 / "r.stats").read().splitlines()
+    logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
+    assert abs(logZ) < 4 * err and 0.1 < err < 0.6                   # truth: logZ = 0
+    # the file a finished run leaves behind (no live point): the same result comes back without sampling
+    st1 = open(base1 / "r.stats").read().splitlines()
+    nlike1 = [l for l in st1 if l.startswith(" nlike:")][0]
+    pc.run(Gaussian(mu=0.5, sigma=0.1), nD, base_dir=str(base1), **kw)
+    st1b = open(base1 / "r.stats").read().splitlines()
+    va, vb = ([float(x) for x in l[8].split("=")[1].split("+/-")] for l in (st1, st1b))
+    assert np.allclose(va, vb, rtol=0, atol=1e-12)                   # the file stores 15 significant digits
+    assert [l for l in st1b if l.startswith(" nlike:")][0] == nlike1
+    # cube_samples: user supplied live points (python callbacks, host evaluation)
+    base3 = tmp_path / "c"
+    cubes = np.random.default_rng(1).random((60, 2))
+    pc.run(lambda th: -0.5 * float(np.sum(((th - 0.5) / 0.1) ** 2)), 2, cube_samples=cubes, base_dir=str(base3), file_root="cs",
+           nlive=60, num_repeats=6, do_clustering=False, feedback=0, seed=2, write_resume=False, posteriors=False, equals=False)
+    st3 = open(base3 / "cs.stats").read().splitlines()
+    logZ3, err3 = [float(x) for x in st3[8].split("=")[1].split("+/-")]
+    assert abs(logZ3 - np.log(2 * np.pi * 0.01)) < 4 * err3          # Z = integral of exp(-r^2/(2 s^2)) over the unit square
