@@ -296,7 +296,7 @@ void polychord_c_interface(
     char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
     double *loglikes, int *nlives, int seed, int *comm)
 {
-    (void)write_paramnames; (void)maximise;
+    (void)maximise;
     (void)synchronous; (void)comm; (void)grade_frac;
     if (num_repeats < 1) halt_program("You need to set num_repeats. Suggestion: 5*nDims");     // settings.f90:216
     if (nGrade > 1 || (nGrade == 1 && grade_dims && grade_dims[0] != nDims))
@@ -328,6 +328,16 @@ void polychord_c_interface(
     if (write_stats_f || write_dead || write_live || posteriors || equals || write_prior || write_resume) {
         struct stat sb;
         if (stat(base.c_str(), &sb) != 0) halt_program(("PolyChord Error: " + base + " does not exist").c_str()); // read_write.F90:28-38
+    }
+    if (write_paramnames) {
+        // interfaces.F90:424-428 + ini.f90:98-121: theta<i> / phi<i> with LaTeX labels; read_write.F90:964-1014
+        FILE *f = std::fopen((base + "/" + root + ".paramnames").c_str(), "w");
+        if (!f) halt_program(("PolyChord Error: " + base + " does not exist").c_str());
+        for (int i = 1; i <= nDims; ++i) std::fprintf(f, "theta%d      \\theta_{%d}\n", i, i);
+        for (int i = 1; i <= nDerived; ++i) std::fprintf(f, "phi%d      \\phi_{%d}\n", i, i);
+        std::fclose(f);
+        f = std::fopen((base + "/" + root + ".properties.ini").c_str(), "w");
+        if (f) { std::fprintf(f, "sampler=nested\nlabel=%s\n", root.c_str()); std::fclose(f); }
     }
     if (P.kind == 0 && L.kind != PCHIP_LIKE_CALLBACK) {
         // a user prior with a built-in likelihood: evaluate both on the host (the device still proposes)

@@ -165,12 +165,14 @@ extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, vo
             for (auto &d : ini.derived) std::fprintf(f, "%s*     %s\n", d.first.c_str(), d.second.c_str());
             std::fclose(f);
         }
+        f = std::fopen((base + "/" + root + ".properties.ini").c_str(), "w");      // read_write.F90:996-1014
+        if (f) { std::fprintf(f, "sampler=nested\nlabel=%s\n", root.c_str()); std::fclose(f); }
     }
     polychord_c_interface(loglikelihood, prior, nullptr, ini.integer_required("nlive"), ini.integer_required("num_repeats"),
                           ini.integer("nprior", -1), ini.integer("nfail", -1), ini.logical("do_clustering", false), ini.integer("feedback", 1),
                           ini.dbl("precision_criterion", 1e-3), ini.dbl("logzero", -1e30), ini.integer("max_ndead", -1),
                           ini.dbl("boost_posterior", 0.0), ini.logical("posteriors", false), ini.logical("equals", false),
-                          ini.logical("cluster_posteriors", false), ini.logical("write_resume", false), ini.logical("write_paramnames", false),
+                          ini.logical("cluster_posteriors", false), ini.logical("write_resume", false), false /* written above with the ini names */,
                           ini.logical("read_resume", false), ini.logical("write_stats", true), ini.logical("write_live", false),
                           ini.logical("write_dead", true), ini.logical("write_prior", false), ini.logical("maximise", false),
                           ini.dbl("compression_factor", std::exp(-1.0)), ini.logical("synchronous", true), nDims, nDerived,
