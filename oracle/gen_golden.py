@@ -56,6 +56,14 @@ def main():
         j.pop("wall", None)
         injected.append(j)
         print("injected", j)
+    # dynamic nlive + nprior > nlive (environment of ref_driver: REF_NPRIOR, REF_NLIVES)
+    for c, nprior, nlv in ((("gaussian", 4, 1, 100, 8, 9, 0), 160, "-20:60,0:150"), (("gaussian", 4, 1, 100, 8, 4, 0), -1, "-10:200")):
+        env = f"REF_NLIVES={nlv} " + (f"REF_NPRIOR={nprior} " if nprior > 0 else "")
+        j = last_json(sh(f"{env}{inj} {c[0]} {c[1]} {c[2]} {c[3]} {c[4]} {c[5]} {c[6]} {TMP}/chains inj 0"))
+        j.update(nDerived=c[2], clustering=c[6], nprior=nprior, nlives=nlv)
+        j.pop("wall", None)
+        injected.append(j)
+        print("injected", j)
     json.dump(injected, open(os.path.join(GOLD, "ref_injected.json"), "w"), indent=1)
 
     native = []

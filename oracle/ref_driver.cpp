@@ -93,14 +93,26 @@ int main(int argc, char **argv)
     if (like == "rastrigin") { fn = rastrigin; g_lo = -5.12; g_hi = 5.12; }
     else if (like == "twin_gaussian") { fn = twin; g_lo = -1.0; g_hi = 1.0; }
     double grade_frac[1] = { 1.0 }; int grade_dims[1] = { nDims };
-    double loglikes[1] = { 0 }; int nlives[1] = { 0 };
+    // optional: REF_NPRIOR=<n>, REF_NLIVES="logL:n,logL:n" (dynamic nlive, run_time_info.f90:766-779)
+    double loglikes[8] = { 0 }; int nlives[8] = { 0 }; int n_nlives = 0, nprior = -1;
+    if (const char *e = std::getenv("REF_NPRIOR")) nprior = atoi(e);
+    if (const char *e = std::getenv("REF_NLIVES")) {
+        std::string t = e; size_t pos = 0;
+        while (pos < t.size() && n_nlives < 8) {
+            size_t c = t.find(':', pos), k = t.find(',', pos);
+            if (c == std::string::npos) break;
+            if (k == std::string::npos) k = t.size();
+            loglikes[n_nlives] = atof(t.substr(pos, c - pos).c_str()); nlives[n_nlives] = atoi(t.substr(c + 1, k - c - 1).c_str());
+            n_nlives++; pos = k + 1;
+        }
+    }
     int comm = 0;
     if (pc_shim_reset) pc_shim_reset((unsigned)seed);
     auto t0 = std::chrono::steady_clock::now();
-    polychord_c_interface(fn, prior, dumper, nlive, nrep, -1, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
+    polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
                           false, false, false, write_resume, false, false, true, false, write_dead, false, false,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
-                          1, grade_frac, grade_dims, 0, loglikes, nlives, seed, comm);
+                          1, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // parse <base>/<root>.stats (read_write.F90:842-889)
     std::string fn_stats = base + "/" + root + ".stats";

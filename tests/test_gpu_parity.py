@@ -176,3 +176,26 @@ def test_edge_cases(engine):
     Lo1, Po1, k3 = orc.make_problem("gaussian", 1)
     o = orc.run(so, Lo1, Po1)
     assert g["ndead"] == o["ndead"] and g["nlike"] == o["nlike"] and abs(g["logZ"] - o["logZ"]) < 1e-8
+
+
+@pytest.mark.parametrize("B", [1, 24])
+def test_dynamic_nlive_and_nprior_match_oracle(engine, B):
+    """nlives/loglikes (run_time_info.f90:766-779: the number of live points follows the contour) and
+    nprior > nlive (nested_sampling.F90:201-205): same trajectory as the oracle."""
+    api = engine
+    D, nDer = 4, 1
+    ll = np.array([-20.0, 0.0]); nl = np.array([60, 150], dtype=np.int32)
+    kw = dict(nlive=100, num_repeats=8, seed=9, batch=B, nprior=160, n_nlives=2)
+    s = _settings(api, D, nDer, **kw)
+    s.loglikes = ll.ctypes.data_as(C.POINTER(C.c_double)); s.nlives = nl.ctypes.data_as(C.POINTER(C.c_int))
+    L, P, keep = api.make_problem("gaussian", D, nDer)
+    g = api.run(s, L, P)
+    so = orc.settings(D, nDer, **kw)
+    so.loglikes = ll.ctypes.data_as(C.POINTER(C.c_double)); so.nlives = nl.ctypes.data_as(C.POINTER(C.c_int))
+    Lo, Po, keep2 = orc.make_problem("gaussian", D)
+    o = orc.run(so, Lo, Po)
+    for k in ("ndead", "nlike", "niter"):
+        assert g[k] == o[k], (k, g[k], o[k])
+    assert abs(g["logZ"] - o["logZ"]) < 1e-8
+    assert np.abs(g["dead"] - o["dead"]).max() < 1e-7
+    assert abs(g["logZ"]) < 4 * g["logZerr"]            # truth 0

@@ -19,7 +19,14 @@ def test_oracle_reproduces_injected_reference(golden):
     for c in cases:
         lo, hi = BOX[c["like"]]
         s = orc.settings(c["nDims"], c["nDerived"], nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"],
-                         batch=1, sequential_rng=1, time_speeds_draw=1, do_clustering=c["clustering"])
+                         batch=1, sequential_rng=1, time_speeds_draw=1, do_clustering=c["clustering"], nprior=c.get("nprior", -1))
+        if "nlives" in c:                                # dynamic nlive: "logL:n,logL:n" (run_time_info.f90:766-779)
+            import ctypes as C
+            import numpy as np
+            pairs = [p.split(":") for p in c["nlives"].split(",")]
+            ll = np.array([float(a) for a, _ in pairs]); nl = np.array([int(b) for _, b in pairs], dtype=np.int32)
+            s.n_nlives = len(pairs)
+            s.loglikes = ll.ctypes.data_as(C.POINTER(C.c_double)); s.nlives = nl.ctypes.data_as(C.POINTER(C.c_int))
         L, P, keep = orc.make_problem(c["like"], c["nDims"], lo, hi)
         o = orc.run(s, L, P)
         assert o["ndead"] == c["ndead"], c
