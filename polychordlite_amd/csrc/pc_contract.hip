@@ -819,7 +819,9 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
     // one workgroup per cluster: fixed-order sum of the partials, then calc_cholesky (utils.F90:621-649)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D, tid = threadIdx.x;
-    double *A = (double *)smem, *L = A + DD, *red = L + DD;   // red [PC_CHOL_NT]
+    // red [PC_CHOL_NT]: scratch of the reduction; it borrows L (zeroed afterwards) when the two matrices
+    // alone fill the LDS (nDims = 100: 2 x 80 KB)
+    double *A = (double *)smem, *L = A + DD, *red = (DD >= PC_CHOL_NT) ? L : L + DD;
     __shared__ int bad;
     const double n = (double)count[c];
     // G groups of DDp threads; group g adds chunks g, g+G, ... in order, then the groups are added in order
@@ -846,11 +848,12 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
         if (tid < DDp && p < DD) {
             double t = 0.0;
             for (int gg = 0; gg < G; ++gg) t += red[gg * DDp + tid];
-            A[p] = t / n; L[p] = 0.0;
+            A[p] = t / n;
             S.cov[(size_t)c * DD + p] = A[p];
         }
         __syncthreads();
     }
+    for (int p = tid; p < DD; p += PC_CHOL_NT) L[p] = 0.0;
     if (tid == 0) bad = 0;
     __syncthreads();
     // calc_cholesky by ONE wavefront, lane = row: column i needs, for every row j >= i, the dot product
@@ -1054,7 +1057,8 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     static size_t donep = 0;
     if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
     hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nchunk, psum, pcnt, mean, count, pcov, CR);
-    const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + PC_CHOL_NT);
+    const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
+    if (sh2 > 160 * 1024) return 1;
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
     hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nchunk, pcov, count);

@@ -347,6 +347,7 @@ struct Engine {
     {
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
         kt.collect();
     }
 

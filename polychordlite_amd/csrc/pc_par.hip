@@ -365,25 +365,21 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
 #endif
-    // live log-sum-exp after every death (run_time_info.f90:683-709), one reference for the launch
-    double refp;
+    // live log-sum-exp after every death (run_time_info.f90:683-709) as a (max, sum) pair: a death removes
+    // exp(L), the newcomer adds exp(Ladd).  A single reference for the whole launch underflows when the
+    // newcomers are hundreds of nats above the points they replace (early in a run, narrow posteriors).
+    double lsM = NEGBIG, lsS = 0.0;
+    if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
     {
-        const double mx = wave_max(Ladd);
-        if (lane == 0) wtot[wv] = mx;
-        __syncthreads();
-        refp = lseRef0;
-        for (int x = 0; x < PAR_W; ++x) refp = fmax(refp, wtot[x]);
-        __syncthreads();
+        double dM = NEGBIG, dS = 0.0;                 // idle partner of the two-sequence scan
+        block_scan_ls2(lsM, lsS, dM, dS, tid, K, X0, X1, X2, X3, wtot);
     }
+    ls_comb(lsM, lsS, lseRef0, lseSum0);              // + the live set before the launch
 #ifdef PAR_DBG_EVID
-    ecy[5] = clock64();
+    ecy[5] = clock64(); ecy[6] = ecy[5];
 #endif
-    const double lse0 = lseSum0 * exp(lseRef0 - refp);
-    const double de = isd ? exp(Ladd - refp) - exp(L - refp) : 0.0;
-    const double lsei = lse0 + block_scan_add(de, lane, wv, wtot);
-#ifdef PAR_DBG_EVID
-    ecy[6] = clock64();
-#endif
+    const double lse_log0 = lseRef0 + log(lseSum0);
+    const double lsei = lsM + log(lsS);
     sZi[tid] = Zi; sLse[tid] = lsei;
     __syncthreads();
 #ifdef PAR_DBG_EVID
@@ -415,8 +411,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (S.max_ndead == 0) more = false;
         else if (S.max_ndead > 0 && ndead_b >= S.max_ndead) more = false;
         else if (S.use_prec) {
-            const double lse_b = kb ? sLse[kb - 1] : lse0, Zb = kb ? sZi[kb - 1] : logZ0;
-            const double live = refp + log(lse_b) - l0 + Xp0 + (double)kb * d01;
+            const double lse_b = kb ? sLse[kb - 1] : lse_log0, Zb = kb ? sZi[kb - 1] : logZ0;     // log of the sum
+            const double live = lse_b - l0 + Xp0 + (double)kb * d01;
             more = !(live < S.log_prec + Zb);
         }
         int code = 0x7fffffff;
@@ -451,7 +447,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ls_comb(m, q, Zp0, 1.0);
         fin[0] = Zi; fin[1] = ls_val(m, q); fin[2] = Sd + ls_val(zxM, zxS); fin[3] = Sd + ls_val(zpxM, zpxS);
         ls_comb(wM, wS, logZ20, 1.0); ls_comb(wpM, wpS, Zp20, 1.0);
-        fin[4] = ls_val(wM, wS); fin[5] = ls_val(wpM, wpS); fin[6] = lsei; fin[7] = L;
+        fin[4] = ls_val(wM, wS); fin[5] = ls_val(wpM, wpS); fin[6] = lsM; fin[7] = L; fin[8] = lsS;
     }
     {
         int nls = (inT && tid < ts) ? nl : 0;
@@ -542,12 +538,12 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #endif
     if (tid == 0) {
         const double Xp = Xp0 + (double)Kp * d01, XX = XX0 + (double)Kp * d02;
-        const double lse_e = Kp ? fin[6] : lse0;
+        const double lse_m = Kp ? fin[6] : lseRef0, lse_s = Kp ? fin[8] : lseSum0;
         const int usrc = uSrc[Kp];
         S.logLp[0] = key2d(uKey[Kp]); S.imin_slot[0] = (usrc >= 0) ? usrc : slotA[-usrc - 1];
         S.logXp[0] = Xp; S.XpXq[0] = XX;
         if (Kp) { S.logZp[0] = fin[1]; S.logZXp[0] = fin[2]; S.logZpXp[0] = fin[3]; S.logZp2[0] = fin[5]; S.death_thr[0] = fin[7]; }
-        S.lse_ref[0] = refp; S.lse_sum[0] = lse_e;
+        S.lse_ref[0] = lse_m; S.lse_sum[0] = lse_s;
         // consecutive failed spawns at the end of the launch
         int tl = -1;
         for (int x = PAR_W - 1; x >= 0; --x) {
@@ -561,7 +557,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2];
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
-        if (S.use_prec) ctl->live_logZ = refp + log(lse_e) - l0 + Xp;
+        if (S.use_prec) ctl->live_logZ = lse_m + log(lse_s) - l0 + Xp;
         cyc[ncy++] = clock64();
 #ifdef PAR_NO_DBG
 #elif defined(PAR_DBG_EVID)

@@ -681,7 +681,8 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
 extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
     const int D = S->D, nb = (S->nr + D - 1) / D;
-    const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * (D + 8)) + 16;
+    // deviates / Cholesky factor with padded rows, then the double-buffered pivot (2 x DMAX <= 2 x 128)
+    const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
     dim3 grid(nb, nchains);
     if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64>), grid, dim3(64), sh, st, *S, batch);

@@ -199,3 +199,26 @@ def test_dynamic_nlive_and_nprior_match_oracle(engine, B):
     assert abs(g["logZ"] - o["logZ"]) < 1e-8
     assert np.abs(g["dead"] - o["dead"]).max() < 1e-7
     assert abs(g["logZ"]) < 4 * g["logZerr"]            # truth 0
+
+
+@pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24)])
+def test_correlated_gaussian_high_dim_matches_oracle(engine, D, nlive, nr, B):
+    """random_gaussian.f90 in 100 (and 40) dimensions: the wide-nDims kernel variants, and live sets whose logL
+    spans ~1e5 nats inside one nursery (the live log-sum-exp must not lose the old points to underflow)."""
+    api = engine; olib = orc.load()
+    ic = np.zeros((D, D)); ld = C.c_double()
+    olib.pc_random_invcov(12345, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
+    mean = np.full(D, 0.5)
+    kw = dict(nlive=nlive, num_repeats=nr, seed=3, batch=B, max_ndead=6 * nlive)
+    s = _settings(api, D, 0, **kw)
+    L, P, keep = api.make_problem("corr_gaussian", D, 0, invcov=ic, mean=mean, logdet=ld.value)
+    g = api.run(s, L, P)
+    so = orc.settings(D, 0, **kw)
+    Lo, Po, k2 = orc.make_problem("corr_gaussian", D, invcov=ic, mean=mean, logdet=ld.value)
+    o = orc.run(so, Lo, Po)
+    for k in ("ndead", "nlike", "niter"):
+        assert g[k] == o[k], (k, g[k], o[k])
+    assert g["ndead"] > 5 * nlive
+    assert abs(g["logZ"] - o["logZ"]) < 1e-6 * max(1.0, abs(o["logZ"]))
+    rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
+    assert rel.max() < 1e-7
