@@ -79,6 +79,9 @@ RUNS = [  # kind D nDer nlive nr B general clustering
     # kNN clustering on the device: cluster splits, deaths, phantom re-homing, evidence splitting
     ("rastrigin", 2, 0, 300, 6, 1, 0, 1), ("rastrigin", 2, 0, 300, 6, 40, 0, 1), ("twin_gaussian", 6, 1, 150, 12, 30, 0, 1),
     ("rastrigin", 4, 0, 200, 12, 50, 0, 1), ("gaussian", 20, 2, 200, 40, 16, 0, 1),
+    # other kernel variants: nDims in (32, 64], num_repeats > 64 (deck in LDS), no derived parameters, serial fast kernel (general=2)
+    ("gaussian", 40, 0, 120, 40, 32, 0, 0), ("gaussian", 12, 2, 150, 70, 32, 0, 0), ("gaussian", 6, 1, 300, 12, 150, 2, 0),
+    ("rastrigin", 3, 0, 120, 9, 60, 2, 0),
 ]
 
 
@@ -222,3 +225,21 @@ def test_correlated_gaussian_high_dim_matches_oracle(engine, D, nlive, nr, B):
     assert abs(g["logZ"] - o["logZ"]) < 1e-6 * max(1.0, abs(o["logZ"]))
     rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
     assert rel.max() < 1e-7
+
+
+@pytest.mark.parametrize("kw", [dict(max_ndead=777), dict(nfail=3, precision_criterion=1e-9, max_ndead=5000), dict(precision_criterion=0.2)])
+def test_termination_triggers_match_oracle(engine, kw):
+    """max_ndead, nfail and the precision criterion (nested_sampling.F90:514-543, :315-319) stop the run at the same
+    step as the oracle, inside a nursery."""
+    api = engine
+    base = dict(nlive=150, num_repeats=10, seed=21, batch=64)
+    base.update(kw)
+    s = _settings(api, 5, 1, **base)
+    L, P, keep = api.make_problem("gaussian", 5, 1)
+    g = api.run(s, L, P)
+    so = orc.settings(5, 1, **base)
+    Lo, Po, keep2 = orc.make_problem("gaussian", 5)
+    o = orc.run(so, Lo, Po)
+    for k in ("ndead", "nlike", "niter"):
+        assert g[k] == o[k], (k, g[k], o[k], kw)
+    assert abs(g["logZ"] - o["logZ"]) < 1e-8
