@@ -971,6 +971,7 @@ struct Engine {
         (void)nlike_dev;
         if (cfg.feedback >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3]);
         if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg par: stage+search %lld rank-sort %lld accept %lld merge+slots %lld evidence %lld triggers %lld publish %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4], h_ctl->dbg[5], h_ctl->dbg[6]);
+        if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg7 %lld\n", h_ctl->dbg[7]);
         if (cfg.feedback == 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) accept-steps %lld (%lld) ins-rescan %lld (%lld) reject-steps cycles %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
         if ((size_t)h_ctl->ndead > h_dead_cap) {          // the dead array grew beyond the first estimate
             HIPCHK(hipStreamSynchronize(st_copy));

@@ -347,9 +347,14 @@ struct ChainCtx {
     int lane;
     double *ybuf;
     int nlike;
-    // gaussian likelihood + uniform prior: along a slice z_d(t) = gA_d + t gB_d (set once per slice), so an
-    // evaluation is fma -> square -> reduction instead of fma -> fma -> sub -> mul -> square -> reduction
-    double gA[DPL], gB[DPL];
+    // Quadratic-form likelihoods (gaussian.f90, random_gaussian.f90) under a uniform prior: along a chord
+    // theta(t) = theta0 + t s the exponent is  q(t) = qa + 2 qb t + qc t^2  with
+    //   qa = y.M.y,  qb = s.M.y,  qc = s.M.s   (y = theta0 - mu; M = 1/sigma^2 or the inverse covariance),
+    // all three reduced once per slice.  A trial is then a handful of scalar operations instead of a
+    // wave reduction (or a D x D matrix-vector product) per likelihood call.  Every trial still counts as
+    // one evaluation (calculate.f90:44).
+    bool quad;
+    double qa, qb, qc, qnorm;
 };
 
 // calculate_point (calculate.f90:6-50) at x0 + t*nh; leaves cube/theta of the trial in registers
@@ -358,18 +363,14 @@ __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double 
                                           double t, double (&cube)[DPL], double (&th)[DPL])
 {
     bool outside = false;
-    if (C.S.like.kind == PC_LIKE_GAUSSIAN) {
-        // straight line: the cube test and theta run beside the likelihood chain, the result is masked
-        double sg = 0.0;
+    if (C.quad) {
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             cube[k] = x0[k] + t * nh[k];
-            const double z = C.gA[k] + t * C.gB[k];
-            if (C.ld.on[k]) { outside |= (cube[k] < 0.0) | (cube[k] > 1.0); sg += z * z; }
+            if (C.ld.on[k]) outside |= (cube[k] < 0.0) | (cube[k] > 1.0);
             th[k] = C.ld.lo[k] + C.ld.span[k] * cube[k];
         }
-        sg = wsum<DPL, NROWS>(sg);
-        double lg = C.S.like.norm - sg / 2.0;
+        double lg = C.qnorm - (C.qa + t * (2.0 * C.qb + t * C.qc)) / 2.0;
         if (__ballot(outside) != 0ull) {
 #pragma unroll
             for (int k = 0; k < DPL; ++k) th[k] = 0.0;
@@ -402,10 +403,17 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
                                           double tA, double tB, double &lA, double &lB)
 {
     const PcLike &L = C.S.like;
-    if (L.kind == PC_LIKE_CORR_GAUSSIAN) {          // uses the per-wave LDS scratch: one after the other
-        double cube[DPL], th[DPL];
-        lA = eval_at<DPL, NROWS>(C, x0, nh, tA, cube, th);
-        lB = eval_at<DPL, NROWS>(C, x0, nh, tB, cube, th);
+    if (C.quad) {
+        bool oA = false, oB = false;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const double cA = x0[k] + tA * nh[k], cB = x0[k] + tB * nh[k];
+            if (C.ld.on[k]) { oA |= (cA < 0.0) | (cA > 1.0); oB |= (cB < 0.0) | (cB > 1.0); }
+        }
+        lA = C.qnorm - (C.qa + tA * (2.0 * C.qb + tA * C.qc)) / 2.0;
+        lB = C.qnorm - (C.qa + tB * (2.0 * C.qb + tB * C.qc)) / 2.0;
+        if (__ballot(oA) != 0ull) lA = C.S.logzero; else if (lA > C.S.logzero) C.nlike++;     // calculate.f90:36-38
+        if (__ballot(oB) != 0ull) lB = C.S.logzero; else if (lB > C.S.logzero) C.nlike++;
         return;
     }
     bool outA = false, outB = false;
@@ -416,10 +424,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
         if (C.ld.on[k]) { outA |= (cA < 0.0) | (cA > 1.0); outB |= (cB < 0.0) | (cB > 1.0); }
         const double thA = C.ld.lo[k] + C.ld.span[k] * cA, thB = C.ld.lo[k] + C.ld.span[k] * cB;
         if (C.ld.on[k]) {
-            if (L.kind == PC_LIKE_GAUSSIAN) {
-                const double zA = C.gA[k] + tA * C.gB[k], zB = C.gA[k] + tB * C.gB[k];
-                sA += zA * zA; sB += zB * zB;
-            } else if (L.kind == PC_LIKE_RASTRIGIN) {
+            if (L.kind == PC_LIKE_RASTRIGIN) {
                 sA += 8.515435146961291 + thA * thA - 10.0 * cos(PC_TWO_PI * thA);
                 sB += 8.515435146961291 + thB * thB - 10.0 * cos(PC_TWO_PI * thB);
             } else {
@@ -433,8 +438,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
     }
     const bool oa = __ballot(outA) != 0ull, ob = __ballot(outB) != 0ull;
     sA = wsum<DPL, NROWS>(sA); sB = wsum<DPL, NROWS>(sB);
-    if (L.kind == PC_LIKE_GAUSSIAN) { lA = L.norm - sA / 2.0; lB = L.norm - sB / 2.0; }
-    else if (L.kind == PC_LIKE_RASTRIGIN) { lA = -sA; lB = -sB; }
+    if (L.kind == PC_LIKE_RASTRIGIN) { lA = -sA; lB = -sB; }
     else {
         s2A = wsum<DPL, NROWS>(s2A); s2B = wsum<DPL, NROWS>(s2B);
         lA = pc_logaddexp(L.norm - sA / 2.0, L.norm - s2A / 2.0) - 0.6931471805599453;
@@ -445,13 +449,14 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 }
 
 template <int DPL, int NROWS>
-__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi_lds)
+__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *ybuf = (double *)smem;                 // [D] (corr gaussian only)
     int *sdeck = (int *)(ybuf + S.D);              // [nr] deck, only used when nr > 64
     int *sj = sdeck + S.nr;                        // [nr]
     double *tbuf = ybuf + S.D + S.nr;              // [nr][D+1] theta of every baby (when it fits: phi_lds)
+    double *Mlds = tbuf + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0);   // [D][D] inverse covariance, transposed (mat_lds)
     const int lane = threadIdx.x, chain = blockIdx.x;
     const int D = S.D, nr = S.nr, nT = S.nT;
     const double logzero = S.logzero;
@@ -473,7 +478,50 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             x0[k] = ld.on[k] ? seed[dim] : 0.5;
         }
     }
-    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, {}, {}};
+    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, false, 0.0, 0.0, 0.0, 0.0};
+    const bool corr = S.like.kind == PC_LIKE_CORR_GAUSSIAN;
+    C.quad = corr || S.like.kind == PC_LIKE_GAUSSIAN;
+    C.qnorm = corr ? -((double)D * PC_LOG_TWO_PI + S.like.logdetcov) / 2.0 : S.like.norm;
+    // correlated Gaussian: y = theta - mean and M.y travel with the chain (updated, not recomputed, at every
+    // accepted point); the matrix is read from LDS when it fits
+    const double *Mt = S.like.invcov;             // transposed: Mt[b*D + a] = M(a,b), lanes read consecutive a
+    double yv[DPL], My[DPL], sv[DPL], Ms[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) { yv[k] = 0.0; My[k] = 0.0; sv[k] = 0.0; Ms[k] = 0.0; }
+    auto matvec = [&](const double (&vec)[DPL], double (&out)[DPL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) if (ld.on[k]) ybuf[lane + 64 * k] = vec[k];
+        __syncthreads();                             // one wave per workgroup
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int a = lane + 64 * k;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            if (ld.on[k]) {
+                int b = 0;
+                for (; b + 3 < D; b += 4) {
+                    t0 += Mt[(size_t)b * D + a] * ybuf[b]; t1 += Mt[(size_t)(b + 1) * D + a] * ybuf[b + 1];
+                    t2 += Mt[(size_t)(b + 2) * D + a] * ybuf[b + 2]; t3 += Mt[(size_t)(b + 3) * D + a] * ybuf[b + 3];
+                }
+                for (; b < D; ++b) t0 += Mt[(size_t)b * D + a] * ybuf[b];
+            }
+            out[k] = (t0 + t1) + (t2 + t3);
+        }
+        __syncthreads();
+    };
+    if (corr) {
+        if (mat_lds) {
+            for (int e = lane; e < D * D; e += 64) Mlds[e] = S.like.invcov[e];
+            __syncthreads();
+            Mt = Mlds;
+        }
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) yv[k] = ld.on[k] ? (ld.lo[k] + ld.span[k] * x0[k]) - ld.mean[k] : 0.0;
+        matvec(yv, My);
+        double pa = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) pa += yv[k] * My[k];
+        C.qa = wsum<DPL, NROWS>(pa);
+    }
 
     // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
     //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
@@ -517,7 +565,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     }
 
 #ifdef SLICE_DBG
-    long long scy[6] = {0, 0, 0, 0, 0, 0}; long long nev = 0;
+    long long scy[6] = {0, 0, 0, 0, 0, 0}; long long nev = 0, ev2 = 0;
 #endif
     double w = w_next;
 #pragma unroll
@@ -560,12 +608,24 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
         const long long c1 = clock64();
 #endif
         double cube[DPL], th[DPL];
-        if (S.like.kind == PC_LIKE_GAUSSIAN) {
+        if (C.quad) {
+            double pa = 0.0, pb = 0.0, pc = 0.0;
+            if (!corr) {
 #pragma unroll
-            for (int k = 0; k < DPL; ++k) {
-                C.gA[k] = ((ld.lo[k] + ld.span[k] * x0[k]) - S.like.mu) * S.like.inv_sigma;
-                C.gB[k] = (ld.span[k] * nh[k]) * S.like.inv_sigma;
+                for (int k = 0; k < DPL; ++k) {
+                    const double zA = ((ld.lo[k] + ld.span[k] * x0[k]) - S.like.mu) * S.like.inv_sigma;
+                    const double zB = (ld.span[k] * nh[k]) * S.like.inv_sigma;
+                    if (ld.on[k]) { pa += zA * zA; pb += zA * zB; pc += zB * zB; }
+                }
+                C.qa = wsum<DPL, NROWS>(pa);
+            } else {
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) sv[k] = ld.on[k] ? ld.span[k] * nh[k] : 0.0;
+                matvec(sv, Ms);
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) { pb += sv[k] * My[k]; pc += sv[k] * Ms[k]; }
             }
+            C.qb = wsum<DPL, NROWS>(pb); C.qc = wsum<DPL, NROWS>(pc);
         }
         // initial bracket (chordal_sampling.f90:213-219)
         const double u0 = next_u();
@@ -584,19 +644,41 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
         const long long c3 = clock64();
 #endif
         // shrinkage (:240-271)
-        double lnew = logzero;
+        double lnew = logzero, t_last = 0.0;
         bool ok = false;
         for (int it = 0; it <= 100; ++it) {
             const double dl = fabs(tL), dr = fabs(tR);
+#ifdef SLICE_DBG
+            const long long e0 = clock64();
+#endif
             const double t = next_u() * (dr + dl) - dl;
+            t_last = t;
+#ifdef SLICE_DBG
+            asm volatile("" :: "v"(t));
+            const long long e1 = clock64();
+#endif
             lnew = eval_at<DPL, NROWS>(C, x0, nh, t, cube, th);
 #ifdef SLICE_DBG
-            nev++;
+            asm volatile("" :: "v"(lnew));
+            const long long e2 = clock64();
+            nev++; scy[5] += e1 - e0; ev2 += e2 - e1;
 #endif
             if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
             else { ok = true; break; }
         }
         if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
+        if (corr) {                                 // the next start point: y and M.y move along the chord
+            C.qa = C.qa + t_last * (2.0 * C.qb + t_last * C.qc);
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) { yv[k] += t_last * sv[k]; My[k] += t_last * Ms[k]; }
+            if ((s & 15) == 15) {                    // resynchronise the carried products now and then
+                matvec(yv, My);
+                double pa = 0.0;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) pa += yv[k] * My[k];
+                C.qa = wsum<DPL, NROWS>(pa);
+            }
+        }
 #ifdef SLICE_DBG
         const long long c4 = clock64();
 #endif
@@ -636,7 +718,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
 #endif
     }
 #ifdef SLICE_DBG
-    if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; }
+    if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; S.ctl->dbg[6] += scy[5]; S.ctl->dbg[7] += ev2; }
 #endif
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
     // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
@@ -696,17 +778,25 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
 
 extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
-    // theta of every baby stays in LDS (derived parameters at the end of the chain) when it fits
+    // theta of every baby stays in LDS (derived parameters at the end of the chain) when it fits; so does the
+    // inverse covariance of the correlated Gaussian
     const size_t sh0 = sizeof(double) * ((size_t)S->D + S->nr) + 16;     // ybuf + two int decks
     const size_t tb = sizeof(double) * (size_t)S->nr * (S->D + 1);
     const int phi_lds = (S->nDer > 0 && sh0 + tb <= 48 * 1024) ? 1 : 0;
-    const size_t sh = sh0 + (phi_lds ? tb : 0);
+    size_t sh = sh0 + (phi_lds ? tb : 0);
+    const size_t mb = sizeof(double) * (size_t)S->D * S->D;
+    const int mat_lds = (S->like.kind == PC_LIKE_CORR_GAUSSIAN && sh + mb <= 150 * 1024) ? 1 : 0;
+    if (mat_lds) sh += mb;
     const int D = S->D;
-    if (D <= 16) hipLaunchKernelGGL((k_slice<1, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
-    else if (D <= 32) hipLaunchKernelGGL((k_slice<1, 2>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
-    else if (D <= 64) hipLaunchKernelGGL((k_slice<1, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
-    else if (D <= 128) hipLaunchKernelGGL((k_slice<2, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
-    else if (D <= 256) hipLaunchKernelGGL((k_slice<4, 4>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds);
+#define PC_SLICE_LAUNCH(DPL, NROWS) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<DPL, NROWS>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
+    if (D <= 16) PC_SLICE_LAUNCH(1, 1)
+    else if (D <= 32) PC_SLICE_LAUNCH(1, 2)
+    else if (D <= 64) PC_SLICE_LAUNCH(1, 4)
+    else if (D <= 128) PC_SLICE_LAUNCH(2, 4)
+    else if (D <= 256) PC_SLICE_LAUNCH(4, 4)
     else return 1;
+#undef PC_SLICE_LAUNCH
     return 0;
 }
