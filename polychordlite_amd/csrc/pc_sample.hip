@@ -209,10 +209,85 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         double ua, ub;
         pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
         const uint32_t ia = 2 * call, ib = 2 * call + 1;
-        if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
-        if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+        if constexpr (DMAX > 64) {                 // wide bases live in LDS rows of odd stride (see below)
+            const uint32_t DSw = (uint32_t)((D + 3) & ~3) + 1u;
+            if (ia >= e0 && ia < e1) G[((ia - e0) / D) * DSw + (ia - e0) % D] = pc_inv_normal_cdf(ua);
+            if (ib >= e0 && ib < e1) G[((ib - e0) / D) * DSw + (ib - e0) % D] = pc_inv_normal_cdf(ub);
+        } else {
+            if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
+            if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+        }
     }
     __syncthreads();
+    if constexpr (DMAX > 64) {
+        // ---- wide nDims (65..128): a vector does not fit the register file (128 fp64 = every VGPR, the compiler
+        // spilled 437 of them), so the basis stays in LDS: thread i owns row i (stride D4+1: conflict free), the
+        // pivot is broadcast through a double buffer, dots run on four partial sums over zero-padded rows.
+        const int i = tid, D4 = (D + 3) & ~3, DS = D4 + 1, TR = 12;
+        const bool active = i < D;
+        double *v = G + (size_t)i * DS;
+        double *Qb = Q;                                // [2][D4]
+        double *Lt = G + (size_t)D * DS;               // [TR][D] tile of the Cholesky factor
+        auto dot4 = [&](const double *a, const double *b) __attribute__((always_inline)) {
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+            for (int d = 0; d < D4; d += 4) { p0 += a[d] * b[d]; p1 += a[d + 1] * b[d + 1]; p2 += a[d + 2] * b[d + 2]; p3 += a[d + 3] * b[d + 3]; }
+            return (p0 + p1) + (p2 + p3);
+        };
+        if (active) {
+            for (int d = D; d < D4; ++d) v[d] = 0.0;
+            const double inrm = 1.0 / sqrt(dot4(v, v));        // random_direction (random_utils.F90:276-298)
+            for (int d = 0; d < D; ++d) v[d] *= inrm;
+        }
+        if (i == 0) for (int d = 0; d < D4; ++d) Qb[d] = v[d];
+        __syncthreads();
+        for (int j = 0; j < D; ++j) {
+            const double *q = Qb + (size_t)(j & 1) * D4;
+            if (active && i >= j) {
+                const double qq = dot4(q, q);
+                if (i == j) {
+                    const double inrm = 1.0 / sqrt(qq);
+                    for (int d = 0; d < D; ++d) v[d] *= inrm;
+                } else {
+                    const double cproj = dot4(q, v) / qq;
+                    for (int d = 0; d < D; ++d) v[d] -= cproj * q[d];
+                    if (i == j + 1) { double *qn = Qb + (size_t)((j + 1) & 1) * D4; for (int d = 0; d < D4; ++d) qn[d] = v[d]; }
+                }
+            }
+            __syncthreads();
+        }
+        // whitening  w = L.n  (chordal_sampling.f90:73), in place, the factor streaming through a row tile
+        const int col = basis * D + i;
+        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        for (int a_hi = D - 1; a_hi >= 0; a_hi -= TR) {
+            const int a_lo = max(0, a_hi - TR + 1), nrow = a_hi - a_lo + 1;
+            __syncthreads();
+            for (int e = tid; e < nrow * D; e += NT) Lt[e] = Lc[(size_t)a_lo * D + e];
+            __syncthreads();
+            if (active && col < nr) {
+                for (int a = a_hi; a >= a_lo; --a) {
+                    const double *Lr = Lt + (size_t)(a - a_lo) * D;
+                    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+                    int bb = 0;
+                    for (; bb + 3 <= a; bb += 4) { t0 += Lr[bb] * v[bb]; t1 += Lr[bb + 1] * v[bb + 1]; t2 += Lr[bb + 2] * v[bb + 2]; t3 += Lr[bb + 3] * v[bb + 3]; }
+                    for (; bb <= a; ++bb) t0 += Lr[bb] * v[bb];
+                    v[a] = (t0 + t1) + (t2 + t3);
+                }
+            }
+        }
+        __syncthreads();
+        if (active && col < nr) {
+            const double w = sqrt(dot4(v, v));                 // chordal_sampling.f90:80-82 (padding is zero)
+            Qb[i] = 1.0 / w;
+            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+        }
+        __syncthreads();
+        for (int r = 0; r < D && basis * D + r < nr; ++r) {      // rows leave coalesced
+            double *out = S.nhat + ((size_t)chain * nr + basis * D + r) * D;
+            const double iw = Qb[r];
+            for (int d = tid; d < D; d += NT) out[d] = G[(size_t)r * DS + d] * iw;
+        }
+        return;
+    }
 #ifdef NHATS_DBG
     ncyc[2] = clock64();
 #endif
@@ -308,26 +383,51 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
             S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
         }
     } else {
-        // large nDims: the finished vectors go back to LDS so that the triangular product can index them
+        // large nDims: the finished vectors go back to LDS (odd row stride: no bank conflicts when every thread
+        // walks its own row) and the Cholesky factor streams through a tile of rows in the padding of the buffer,
+        // loaded cooperatively -- the product used to read every L(a,b) from global memory inside a dependent loop
+        const int DS = D + 1, TR = 12;
+        double *Lt = G + (size_t)D * DS;             // [TR][D]
+        __syncthreads();
         if (active) {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) G[(size_t)i * D + d] = v[d];
+            for (int d = 0; d < DMAX; ++d) if (d < D) G[(size_t)i * DS + d] = v[d];
+        }
+        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        double *mine = G + (size_t)i * DS;
+        for (int a_hi = D - 1; a_hi >= 0; a_hi -= TR) {     // in place: row a only needs n[0..a], rows go downwards
+            const int a_lo = max(0, a_hi - TR + 1), nrow = a_hi - a_lo + 1;
+            __syncthreads();
+            for (int e = tid; e < nrow * D; e += NT) Lt[e] = Lc[(size_t)a_lo * D + e];
+            __syncthreads();
+            if (active && col < nr) {
+                for (int a = a_hi; a >= a_lo; --a) {
+                    const double *Lr = Lt + (size_t)(a - a_lo) * D;
+                    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+                    int bb = 0;
+                    for (; bb + 3 <= a; bb += 4) {
+                        t0 += Lr[bb] * mine[bb]; t1 += Lr[bb + 1] * mine[bb + 1]; t2 += Lr[bb + 2] * mine[bb + 2]; t3 += Lr[bb + 3] * mine[bb + 3];
+                    }
+                    for (; bb <= a; ++bb) t0 += Lr[bb] * mine[bb];
+                    mine[a] = (t0 + t1) + (t2 + t3);
+                }
+            }
+        }
+        if (active && col < nr) {
+            double n0 = 0.0, n1 = 0.0;
+            int d = 0;
+            for (; d + 1 < D; d += 2) { n0 += mine[d] * mine[d]; n1 += mine[d + 1] * mine[d + 1]; }
+            if (d < D) n0 += mine[d] * mine[d];
+            const double w = sqrt(n0 + n1);                   // chordal_sampling.f90:80-82
+            Q[i] = 1.0 / w;
+            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
         }
         __syncthreads();
-        if (active && col < nr) {
-            const double *Lc = S.chol + (size_t)sh[0] * D * D;
-            double *mine = G + (size_t)i * D;
-            double n2 = 0.0;
-            for (int a = D - 1; a >= 0; --a) {          // in place: row a only needs n[0..a]
-                double t = 0.0;
-                for (int b = 0; b <= a; ++b) t += Lc[(size_t)a * D + b] * mine[b];
-                mine[a] = t;
-            }
-            for (int d = 0; d < D; ++d) n2 += mine[d] * mine[d];
-            const double w = sqrt(n2), iw = 1.0 / w;           // chordal_sampling.f90:80-82
-            double *out = S.nhat + ((size_t)chain * nr + col) * D;
-            for (int d = 0; d < D; ++d) out[d] = mine[d] * iw;
-            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
+        // rows leave coalesced
+        for (int r = 0; r < D && basis * D + r < nr; ++r) {
+            double *out = S.nhat + ((size_t)chain * nr + basis * D + r) * D;
+            const double iw = Q[r];
+            for (int d = tid; d < D; d += NT) out[d] = G[(size_t)r * DS + d] * iw;
         }
     }
 #ifdef NHATS_DBG
