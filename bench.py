@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=4,
+                    help="after the timed steps: R independent runs driven concurrently from R host threads on this GPU "
+                         "(reported separately, never part of `value`); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +127,26 @@ def main():
         t = torch.tensor([dt, nlike], dtype=torch.float64, device=f"cuda:{local_rank}")
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); tmax = float(tm[0])
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1])
+    # one run keeps a small part of the chip busy (B chains = B wavefronts, the contraction one CU): independent
+    # runs on separate streams overlap.  Reported next to the headline, not in it.
+    conc = None
+    if args.concurrent > 1 and args.steps > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        R = args.concurrent
+        s_c = [api.Settings() for _ in range(R)]
+        for j, sj in enumerate(s_c):
+            C.memmove(C.byref(sj), C.byref(s), C.sizeof(s)); sj.profile = 0; sj.seed = 500000 + j + 100003 * rank
+
+        def one_c(j):
+            return api.run(s_c[j], L, P)["nlike"]
+        with ThreadPoolExecutor(R) as ex:
+            list(ex.map(one_c, range(R)))                       # block cache for R engines
+            tc0 = time.perf_counter()
+            nl = sum(ex.map(one_c, range(R)))
+            tc = time.perf_counter() - tc0
+        conc = {"runs": R, "wall_ms": tc * 1e3, "value": nl / tc, "unit": "likelihood evals/s",
+                "note": "R independent runs of the same workload in flight on one GPU (one host thread + HIP stream each)"}
+        sync()
     if rank == 0:
         value = nlike / tmax
         k = runs[-1]["kernel_time"]
@@ -150,7 +173,7 @@ def main():
                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world},
                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
                "logZ_truth": 0.0, "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
-               "merged": merged, "step_ms": step_ms, "merge_ms": merge_ms, "roofline": roof,
+               "merged": merged, "step_ms": step_ms, "merge_ms": merge_ms, "concurrent": conc, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
