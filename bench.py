@@ -157,12 +157,20 @@ def main():
             kl = sum(r["kernel_time"][dom]["launches"] for r in runs)
             evals = float(sum(r["nlike"] for r in runs))
             achieved = evals * BYTES_PER_EVAL / kt / 1e9
+            # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE in separate runs of this command; FETCH_SIZE doubled on gfx950)
+            traffic, pmc_src = None, os.path.join(ROOT, "profiles", "r01_pmc.json")
+            if os.path.exists(pmc_src):
+                pk = json.load(open(pmc_src))["kernels"]
+                hit = [v for k, v in pk.items() if k.startswith(dom if dom != "k_consume" else "k_consume_par")]
+                if hit:
+                    traffic = hit[0]["hbm_bytes_per_launch"]
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": kt / max(kl, 1) * 1e6, "launches": kl,
                     "bytes_per_launch": evals * BYTES_PER_EVAL / max(kl, 1),
-                    "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; "
-                            "algorithmic bytes = 258 B per likelihood evaluation"}
+                    "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; algorithmic bytes = "
+                            "258 B per likelihood evaluation x evaluations of one nursery; traffic = PMC bytes of this kernel alone"}
         out = {"metric": "likelihood evals/sec, 20D Gaussian nlive=%d" % args.nlive, "value": value,
                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
