@@ -741,15 +741,16 @@ __global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, 
 }
 
 __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int nchunk, const double *psum, const int *pcnt,
-                                                    double *mean /* [nc][D] */, int *count /* [nc] */, double *pcov, int CR)
+                                                    double *mean /* [nc][D] */, int *count /* [nc] */, double *pcov, int CR,
+                                                    int TS /* tile row stride */, int use_mfma)
 {
     // grid (nchunk, nc).  Every workgroup first reduces the chunk sums to the cluster mean (fixed order,
     // identical in every workgroup), then accumulates the centred outer products of its own rows.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
-    double *tile = (double *)smem;               // [rows][D+1]
-    double *mu = tile + (size_t)CR * (D + 1);    // [D]
+    double *tile = (double *)smem;               // [rows][TS], TS = D+1 or (D rounded up to 16)+1, zero padded
+    double *mu = tile + (size_t)CR * TS;         // [D]
     double *red = mu + D;                        // [256]
     int *rc = (int *)(red + 256);                // [CR] member rows, in row order
     __shared__ int wcnt[4];
@@ -800,16 +801,73 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (member) rc[base + __popcll(bm & ((1ull << lane) - 1ull))] = r0 + tid;
     __syncthreads();
-    for (int e = tid; e < n * D; e += 256) {
-        const int i = e / D, d = e % D;
-        tile[(size_t)i * (D + 1) + d] = cov_ptr(S, rc[i])[d] - mu[d];
+    if (!use_mfma) {
+        for (int e = tid; e < n * D; e += 256) {
+            const int i = e / D, d = e % D;
+            tile[(size_t)i * TS + d] = cov_ptr(S, rc[i])[d] - mu[d];
+        }
+        __syncthreads();
+        for (int p = tid; p < D * D; p += 256) {
+            const int a = p / D, b = p % D;
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += tile[(size_t)i * TS + a] * tile[(size_t)i * TS + b];
+            pcov[((size_t)chunk * nc + c) * D * D + p] = s;
+        }
+        return;
+    }
+    // ---- wide nDims: X^T X on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), one 16x16 tile of the result per
+    // wave at a time, upper triangle only.  Operand maps (cdna_hip_programming.md): A[i=lane&15][k=lane>>4],
+    // B[k=lane>>4][j=lane&15], D col = lane&15, row = (lane>>4) + 4*reg.  Rows are consumed four at a time in row
+    // order: a fixed summation order.
+    const int nP = (n + 3) & ~3, W = TS - 1;                      // rows / columns of the zero padded tile
+    for (int e = tid; e < nP * W; e += 256) {
+        const int i = e / W, d = e % W;
+        tile[(size_t)i * TS + d] = (i < n && d < D) ? cov_ptr(S, rc[i])[d] - mu[d] : 0.0;
     }
     __syncthreads();
-    for (int p = tid; p < D * D; p += 256) {
-        const int a = p / D, b = p % D;
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int nt = W / 16, ntile = nt * (nt + 1) / 2;
+    for (int t = wv; t < ntile; t += 4) {
+        int ti = 0, rem = t;
+        while (rem >= nt - ti) { rem -= nt - ti; ti++; }
+        const int tj = ti + rem;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const double *pa = tile + (size_t)(lane >> 4) * TS + ti * 16 + (lane & 15);
+        const double *pb = tile + (size_t)(lane >> 4) * TS + tj * 16 + (lane & 15);
+        for (int r0 = 0; r0 < nP; r0 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)r0 * TS], pb[(size_t)r0 * TS], acc, 0, 0, 0);
+        double *out = pcov + ((size_t)chunk * nc + c) * D * D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + (lane >> 4) + 4 * r, col = tj * 16 + (lane & 15);
+            if (row < D && col < D) { out[(size_t)row * D + col] = acc[r]; if (ti != tj) out[(size_t)col * D + row] = acc[r]; }
+        }
+    }
+}
+
+// Fold the per-chunk partial sums of a cluster into the first R chunk slots (slot r = chunks r, r+R, ... added in
+// that order; slot r is only ever read by workgroup r, so the fold is in place).  A 100-D run has ~800 chunks
+// of 80 KB each: one workgroup reading all of them for the final sum took 3 ms per update.
+__global__ __launch_bounds__(256) void k_fold_partials(double *buf, int *cnt, int nchunk, int nc, int per)
+{
+    const int r = blockIdx.x, R = gridDim.x, c = blockIdx.y, tid = threadIdx.x;
+    for (int p = tid; p < per; p += 256) {
         double s = 0.0;
-        for (int i = 0; i < n; ++i) s += tile[(size_t)i * (D + 1) + a] * tile[(size_t)i * (D + 1) + b];
-        pcov[((size_t)chunk * nc + c) * D * D + p] = s;
+        int k = r;
+        for (; k + 7 * R < nchunk; k += 8 * R) {
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = buf[((size_t)(k + u * R) * nc + c) * per + p];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t8[u];
+        }
+        for (; k < nchunk; k += R) s += buf[((size_t)k * nc + c) * per + p];
+        buf[((size_t)r * nc + c) * per + p] = s;
+    }
+    if (cnt && tid == 0) {
+        int n = 0;
+        for (int k = r; k < nchunk; k += R) n += cnt[(size_t)k * nc + c];
+        cnt[(size_t)r * nc + c] = n;
     }
 }
 
@@ -1038,10 +1096,12 @@ extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
     hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
 }
 
+static int cov_use_mfma(const PcState *S) { return S->D >= 32; }
+static int cov_tile_stride(const PcState *S) { return cov_use_mfma(S) ? ((S->D + 15) & ~15) + 1 : S->D + 1; }
 static int cov_rows(const PcState *S)
-{   // rows per chunk: the centred tile [rows][D+1] must fit in LDS
+{   // rows per chunk: the centred tile [rows][stride] must fit in LDS
     int r = PC_COV_ROWS;
-    while (r > 8 && sizeof(double) * (size_t)r * (S->D + 1) + sizeof(int) * r > 120 * 1024) r >>= 1;
+    while (r > 8 && sizeof(double) * (size_t)r * cov_tile_stride(S) + sizeof(int) * r > 120 * 1024) r >>= 1;
     return r;
 }
 extern "C" int pc_cov_nchunk(const PcState *S, int nph) { const int r = cov_rows(S); return (S->Ncap + nph + r - 1) / r; }
@@ -1052,16 +1112,24 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     const int CR = cov_rows(S);
     const int nrows = S->Ncap + nph, nchunk = (nrows + CR - 1) / CR, D = S->D;
     hipLaunchKernelGGL(k_cov_mean_partial, dim3(nchunk, nc), dim3(256), 0, st, *S, nrows, nph, psum, pcnt, CR);
-    const size_t sh = sizeof(double) * ((size_t)CR * (D + 1) + D + 256) + sizeof(int) * CR;
+    const int NFOLD = 64;
+    int nred = nchunk;                                           // partial sums the later stages read
+    if (nchunk > 2 * NFOLD) {
+        hipLaunchKernelGGL(k_fold_partials, dim3(NFOLD, nc), dim3(256), 0, st, psum, pcnt, nchunk, nc, D);
+        nred = NFOLD;
+    }
+    const int TS = cov_tile_stride(S);
+    const size_t sh = sizeof(double) * ((size_t)CR * TS + D + 256) + sizeof(int) * CR;
     if (sh > 160 * 1024) return 1;
     static size_t donep = 0;
     if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
-    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nchunk, psum, pcnt, mean, count, pcov, CR);
+    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nred, psum, pcnt, mean, count, pcov, CR, TS, cov_use_mfma(S));
+    if (nchunk > 2 * NFOLD) hipLaunchKernelGGL(k_fold_partials, dim3(NFOLD, nc), dim3(256), 0, st, pcov, (int *)nullptr, nchunk, nc, D * D);
     const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
     if (sh2 > 160 * 1024) return 1;
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nchunk, pcov, count);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nred, pcov, count);
     return 0;
 }
 
