@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned
     if (threadIdx.x == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 
-__global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total)
+__global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total, int *total2)
 {   // exclusive scan, single workgroup, fixed order
     __shared__ int carry;
     __shared__ int tmp[256];
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, i
         if (threadIdx.x == 255) carry += tmp[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) { *total = carry; if (total2) *total2 = carry; }   // total2: the control block's phantom count
 }
 
 __global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const unsigned char *keep, const int *blk_off,
@@ -716,6 +716,7 @@ __global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, 
     // grid (nchunk, nc); thread = (row group g, coordinate d): group g sums rows r0+g, r0+g+G, ... of
     // cluster c in that order, the groups are added in order: a fixed summation tree
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x;
+    nrows = min(nrows, S.Ncap + S.ctl->nphantom);   // the grid may have been sized before the phantoms were cleaned
     const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
     const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
     __shared__ int rc[PC_COV_ROWS];
@@ -748,7 +749,8 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     // identical in every workgroup), then accumulates the centred outer products of its own rows.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r0 = chunk * CR, r1 = min(nrows, r0 + CR);
+    nrows = min(nrows, S.Ncap + S.ctl->nphantom);
+    const int r0 = chunk * CR, r1 = max(r0, min(nrows, r0 + CR));
     double *tile = (double *)smem;               // [rows][TS], TS = D+1 or (D rounded up to 16)+1, zero padded
     double *mu = tile + (size_t)CR * TS;         // [D]
     double *red = mu + D;                        // [256]
@@ -1084,10 +1086,11 @@ extern "C" void pc_launch_clean(const PcState *S, int nph, unsigned char *keep, 
     const int nblk = (nph + 255) / 256;
     if (nblk > 0) {
         hipLaunchKernelGGL(k_clean_flag, dim3(nblk), dim3(256), 0, st, *S, nph, keep, blk);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, blk, nblk, d_total);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, blk, nblk, d_total, &S->ctl->nphantom);
         hipLaunchKernelGGL(k_clean_scatter, dim3(nblk), dim3(256), 0, st, *S, nph, keep, blk, ph2, phL2, phC2, phU2, dst_index);
     } else {
         hipMemsetAsync(d_total, 0, sizeof(int), st);
+        hipMemsetAsync(&S->ctl->nphantom, 0, sizeof(int), st);
     }
 }
 

@@ -207,6 +207,7 @@ struct Engine {
     pchip_update_fn on_update = nullptr; void *hook_user = nullptr;
     long ndiscarded = 0;                        // prior samples rejected while generating the live points
     bool resume_static = true; unsigned resume_batch0 = 0;
+    bool nph_stale = false;                     // h_ctl->nphantom is the count before the last clean (an upper bound)
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<double> h_lo, h_hi;
     PcState S{};
@@ -348,6 +349,7 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
+        nph_stale = false;
         kt.collect();
     }
 
@@ -368,6 +370,7 @@ struct Engine {
     void ensure_capacity()
     {   // the next batch may append B*nr phantoms and B dead points
         if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) grow_dead(S.Dcap * 2);
+        if (nph_stale && (long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) read_ctl();   // pre-clean count: refresh
         if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) {
             std::fprintf(stderr, "polychord_hip: phantom capacity exceeded (%d + %d*%d > %d)\n", h_ctl->nphantom, B, S.nr, S.Pcap);
             std::abort();
@@ -446,12 +449,17 @@ struct Engine {
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
-        int total = 0;
-        HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        // The surviving count is written to the control block on the device.  Without clustering / resume files
+        // nothing on the host needs it before the next round's read-back, so the update costs no extra sync: the
+        // covariance grid is sized with the pre-clean count and the kernels clamp to the device value.
+        const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update;
+        int total = nph;
+        if (need_count) {
+            HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h_ctl->nphantom = total;
+        } else nph_stale = true;
         std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
-        h_ctl->nphantom = total;
-        HIPCHK(hipMemcpyAsync(&S.ctl->nphantom, &h_ctl->nphantom, sizeof(int), hipMemcpyHostToDevice, st));
         pc_launch_reset_thresholds(&S, st);
         if (cfg.do_clustering) { HIPCHK(hipStreamSynchronize(st)); do_clustering(); }
         hipEvent_t e1 = kt.begin(KT_COV);
