@@ -165,8 +165,13 @@ def main():
                 hit = [v for k, v in pk.items() if k.startswith(dom if dom != "k_consume" else "k_consume_par")]
                 if hit:
                     traffic = hit[0]["hbm_bytes_per_launch"]
+            # the kernel's own algorithmic I/O per launch, to read `traffic` against
+            nT, B_, N_ = 2 * nDims + nDer + 2, runs[-1]["batch"], args.nlive
+            own = {"k_slice": B_ * (8 * nT * (1 + nr) + 8 * nr * (nDims + 1) + 16 * nr),
+                   "k_consume": 8 * (2 * N_ + 3 * B_) + 120 * B_,
+                   "k_nhats": B_ * 8 * nr * (nDims + 1)}.get(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_own_bytes_per_launch": own,
                     "avg_launch_us": kt / max(kl, 1) * 1e6, "launches": kl,
                     "bytes_per_launch": evals * BYTES_PER_EVAL / max(kl, 1),
                     "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; algorithmic bytes = "
