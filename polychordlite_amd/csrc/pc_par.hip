@@ -63,25 +63,35 @@ __device__ __forceinline__ double ls_val(double m, double s) { return s > 0.0 ? 
         double nam = AM, nas = AS, nbm = BM, nbs = BS; \
         ls_comb(nam, nas, oam, oas); ls_comb(nbm, nbs, obm, obs); \
         if (PRED) { AM = nam; AS = nas; BM = nbm; BS = nbs; } }
-__device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &bm, double &bs, int tid, int nact,
-                                               double *X0, double *X1, double *X2, double *X3, double *wtot)
+// Three sequences per pass: waves 0-3 scan the pair (a, b), waves 4-7 scan c at the same time (the other waves
+// only park and fetch).  Xc / Xcs: scratch of the third sequence; pass nullptr to scan two sequences only.
+#define PAR_SCAN_LEVEL1(AM, AS, CTRL, PRED) { \
+        const double oam = dpp_f64<CTRL>(AM), oas = dpp_f64<CTRL>(AS); \
+        double nam = AM, nas = AS; \
+        ls_comb(nam, nas, oam, oas); \
+        if (PRED) { AM = nam; AS = nas; } }
+__device__ __forceinline__ void block_scan_ls3(double &am, double &as, double &bm, double &bs, double &cm, double &cs, int tid, int nact,
+                                               double *X0, double *X1, double *X2, double *X3, double *Xc, double *Xcs, double *wtot)
 {
     const int lane = tid & 63, wv = tid >> 6;
+    const bool three = Xc != nullptr;
     X0[tid] = am; X1[tid] = as; X2[tid] = bm; X3[tid] = bs;
+    if (three) { Xc[tid] = cm; Xcs[tid] = cs; }
     __syncthreads();
     double a_m[4], a_s[4], b_m[4], b_s[4];
     double tam = NEGBIG, tas = 0.0, tbm = NEGBIG, tbs = 0.0;
-    const bool has = tid * 4 < nact;
+    const int t4 = (tid & 255) * 4;                          // my four elements (waves 4-7 mirror waves 0-3)
+    const bool has = t4 < nact;
+    const int lr = lane & 15;
     if (wv < 4) {
         #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a_m[u] = has ? X0[4 * tid + u] : NEGBIG; a_s[u] = has ? X1[4 * tid + u] : 0.0;
-            b_m[u] = has ? X2[4 * tid + u] : NEGBIG; b_s[u] = has ? X3[4 * tid + u] : 0.0;
+            a_m[u] = has ? X0[t4 + u] : NEGBIG; a_s[u] = has ? X1[t4 + u] : 0.0;
+            b_m[u] = has ? X2[t4 + u] : NEGBIG; b_s[u] = has ? X3[t4 + u] : 0.0;
         }
         #pragma unroll
         for (int u = 1; u < 4; ++u) { ls_comb(a_m[u], a_s[u], a_m[u - 1], a_s[u - 1]); ls_comb(b_m[u], b_s[u], b_m[u - 1], b_s[u - 1]); }
         tam = a_m[3]; tas = a_s[3]; tbm = b_m[3]; tbs = b_s[3];
-        const int lr = lane & 15;
         PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x111, lr >= 1)
         PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x112, lr >= 2)
         PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x114, lr >= 4)
@@ -89,6 +99,19 @@ __device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &b
         PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x142, (lane >> 4) & 1)      // row_bcast15: lane 15 of the previous row
         PAR_SCAN_LEVEL(tam, tas, tbm, tbs, 0x143, lane >= 32)           // row_bcast31: lane 31
         if (lane == 63) { wtot[wv] = tam; wtot[4 + wv] = tas; wtot[8 + wv] = tbm; wtot[12 + wv] = tbs; }
+    } else if (three && wv < 8) {
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) { a_m[u] = has ? Xc[t4 + u] : NEGBIG; a_s[u] = has ? Xcs[t4 + u] : 0.0; }
+        #pragma unroll
+        for (int u = 1; u < 4; ++u) ls_comb(a_m[u], a_s[u], a_m[u - 1], a_s[u - 1]);
+        tam = a_m[3]; tas = a_s[3];
+        PAR_SCAN_LEVEL1(tam, tas, 0x111, lr >= 1)
+        PAR_SCAN_LEVEL1(tam, tas, 0x112, lr >= 2)
+        PAR_SCAN_LEVEL1(tam, tas, 0x114, lr >= 4)
+        PAR_SCAN_LEVEL1(tam, tas, 0x118, lr >= 8)
+        PAR_SCAN_LEVEL1(tam, tas, 0x142, (lane >> 4) & 1)
+        PAR_SCAN_LEVEL1(tam, tas, 0x143, lane >= 32)
+        if (lane == 63) { wtot[16 + wv - 4] = tam; wtot[20 + wv - 4] = tas; }
     }
     __syncthreads();
     if (wv < 4) {
@@ -100,13 +123,28 @@ __device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &b
             #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 ls_comb(a_m[u], a_s[u], eam, eas); ls_comb(b_m[u], b_s[u], ebm, ebs);
-                X0[4 * tid + u] = a_m[u]; X1[4 * tid + u] = a_s[u]; X2[4 * tid + u] = b_m[u]; X3[4 * tid + u] = b_s[u];
+                X0[t4 + u] = a_m[u]; X1[t4 + u] = a_s[u]; X2[t4 + u] = b_m[u]; X3[t4 + u] = b_s[u];
             }
+        }
+    } else if (three && wv < 8) {
+        double eam = __shfl_up(tam, 1), eas = __shfl_up(tas, 1);
+        if (lane == 0) { eam = NEGBIG; eas = 0.0; }
+        for (int x = 0; x < wv - 4; ++x) ls_comb(eam, eas, wtot[16 + x], wtot[20 + x]);
+        if (has) {
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) { ls_comb(a_m[u], a_s[u], eam, eas); Xc[t4 + u] = a_m[u]; Xcs[t4 + u] = a_s[u]; }
         }
     }
     __syncthreads();
     am = X0[tid]; as = X1[tid]; bm = X2[tid]; bs = X3[tid];
+    if (three) { cm = Xc[tid]; cs = Xcs[tid]; }
     __syncthreads();
+}
+__device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &bm, double &bs, int tid, int nact,
+                                               double *X0, double *X1, double *X2, double *X3, double *wtot)
+{
+    double cm = NEGBIG, cs = 0.0;
+    block_scan_ls3(am, as, bm, bs, cm, cs, tid, nact, X0, X1, X2, X3, nullptr, nullptr, wtot);
 }
 
 __device__ __forceinline__ double block_scan_add(double v, int lane, int wv, double *wtot)
@@ -150,6 +188,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     int *accStep = parA + PAR_NT;            // [1024] step of the j-th acceptance
     int *ish = accStep + PAR_NT;             // [16]
     int *hist = ish + 16;                    // [NS + 64] candidates per snapshot gap, then gap offsets
+    double *X5 = (double *)(hist + NS + 64); // [1024] scan scratch (third sequence)
     double *sLse = (double *)Gm;
 
     const int epoch = ctl->admin_epoch;
@@ -336,7 +375,14 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     double tM = isd ? Xb + L - l1 : NEGBIG, tS = isd ? 1.0 : 0.0;
     double vM = isd ? (XXb + L + l0 - l1 - l2) - Sd : NEGBIG, vS = tS;
     double *X0 = (double *)srtK, *X1 = (double *)Gm, *X2 = sZi, *X3 = (double *)rnk;   // scratch until the end of this phase
-    block_scan_ls2(tM, tS, vM, vS, tid, K, X0, X1, X2, X3, wtot);
+    // live log-sum-exp after every death (run_time_info.f90:683-709) as a (max, sum) pair: a death removes
+    // exp(L), the newcomer adds exp(Ladd).  A single reference for the whole launch underflows when the
+    // newcomers are hundreds of nats above the points they replace (early in a run, narrow posteriors).
+    // It rides in the same pass as the two evidence sequences, on waves 4-7.
+    double lsM = NEGBIG, lsS = 0.0;
+    if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
+    __syncthreads();                                  // every thread has read its candidate key: cK becomes scratch
+    block_scan_ls3(tM, tS, vM, vS, lsM, lsS, tid, K, X0, X1, X2, X3, (double *)cK, X5, wtot);
 #ifdef PAR_DBG_EVID
     ecy[2] = clock64();
 #endif
@@ -365,15 +411,6 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
 #endif
-    // live log-sum-exp after every death (run_time_info.f90:683-709) as a (max, sum) pair: a death removes
-    // exp(L), the newcomer adds exp(Ladd).  A single reference for the whole launch underflows when the
-    // newcomers are hundreds of nats above the points they replace (early in a run, narrow posteriors).
-    double lsM = NEGBIG, lsS = 0.0;
-    if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
-    {
-        double dM = NEGBIG, dS = 0.0;                 // idle partner of the two-sequence scan
-        block_scan_ls2(lsM, lsS, dM, dS, tid, K, X0, X1, X2, X3, wtot);
-    }
     ls_comb(lsM, lsS, lseRef0, lseSum0);              // + the live set before the launch
 #ifdef PAR_DBG_EVID
     ecy[5] = clock64(); ecy[6] = ecy[5];
@@ -661,7 +698,7 @@ __global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S)
 static size_t par_lds(const PcState *S)
 {
     const size_t NS = ((size_t)S->Ncap + 63) & ~(size_t)63;
-    return 8 * (NS + 4 * PAR_NT + 64 + 3 * PAR_W + PAR_NT + 64 + 16) + 4 * (2 * NS + 7 * PAR_NT + 2 * 64 + 16) + 64;
+    return 8 * (NS + 4 * PAR_NT + 64 + 3 * PAR_W + PAR_NT + 64 + 16 + PAR_NT) + 4 * (2 * NS + 7 * PAR_NT + 2 * 64 + 16) + 64;
 }
 
 extern "C" int pc_par_fits(const PcState *S) { return par_lds(S) <= 160 * 1024 && S->B <= PAR_NT; }
