@@ -264,3 +264,42 @@ def test_resume_and_cube_samples(engine, tmp_path):
     st3 = open(base3 / "cs.stats").read().splitlines()
     logZ3, err3 = [float(x) for x in st3[8].split("=")[1].split("+/-")]
     assert abs(logZ3 - np.log(2 * np.pi * 0.01)) < 4 * err3          # Z = integral of exp(-r^2/(2 s^2)) over the unit square
+
+
+@pytest.mark.gpu
+def test_resume_with_clusters_and_large_nlive(engine, tmp_path):
+    """a restart from a .resume file written while several clusters were alive (per-cluster live points, phantoms,
+    evidences, covariances); and a run whose live set does not fit the LDS-resident parallel contraction"""
+    import shutil
+    from polychordlite_amd import pypolychord as pc
+    from polychordlite_amd.pypolychord.device_likelihoods import Rastrigin, Gaussian, UniformPrior
+    base1, base2 = tmp_path / "a", tmp_path / "b"
+    snap = {}
+
+    def dumper(live, dead, logw, logZ, logZerr):
+        f = base1 / "r.resume"
+        if "nc" not in snap and f.exists():
+            lines = open(f).read().splitlines()
+            if int(lines[7]) >= 3:                                     # "=== Number of clusters ===" value
+                (base2 / "clusters").mkdir(parents=True, exist_ok=True)
+                shutil.copy(f, base2 / "r.resume")
+                snap["nc"], snap["nd"] = int(lines[7]), int(lines[5])
+    kw = dict(nDerived=0, nlive=300, num_repeats=6, do_clustering=True, feedback=0, seed=2, file_root="r",
+              prior=UniformPrior(-5.12, 5.12), write_resume=True, read_resume=True, posteriors=False, equals=False,
+              write_live=False, write_prior=False)
+    pc.run(Rastrigin(), 2, base_dir=str(base1), dumper=dumper, **kw)
+    assert snap.get("nc", 0) >= 3
+    pc.run(Rastrigin(), 2, base_dir=str(base2), **kw)
+    st = open(base2 / "r.stats").read().splitlines()
+    logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
+    assert abs(logZ + 4.6526) < 4 * err + 0.05                          # truth -2 ln 10.24
+    assert sum(1 for l in st if l.startswith("log(Z_")) >= snap["nc"]
+    assert np.loadtxt(base2 / "r_dead-birth.txt").shape[0] > snap["nd"] + 200
+    # nlive = 6000: serial single-wave contraction and kill-off (the parallel kernel's LDS budget is exceeded)
+    base3 = tmp_path / "c"
+    pc.run(Gaussian(mu=0.5, sigma=0.1), 3, base_dir=str(base3), file_root="big", nlive=6000, num_repeats=6, do_clustering=False,
+           feedback=0, seed=4, write_resume=False, read_resume=False, posteriors=False, equals=False, write_live=False,
+           write_prior=False, write_dead=False)
+    st3 = open(base3 / "big.stats").read().splitlines()
+    logZ3, err3 = [float(x) for x in st3[8].split("=")[1].split("+/-")]
+    assert abs(logZ3) < 4 * err3 and err3 < 0.06
