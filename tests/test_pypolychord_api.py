@@ -303,3 +303,29 @@ def test_resume_with_clusters_and_large_nlive(engine, tmp_path):
     st3 = open(base3 / "big.stats").read().splitlines()
     logZ3, err3 = [float(x) for x in st3[8].split("=")[1].split("+/-")]
     assert abs(logZ3) < 4 * err3 and err3 < 0.06
+
+
+@pytest.mark.gpu
+def test_fortran_binding(engine, tmp_path):
+    """bindings/fortran: a Fortran program (ISO_C_BINDING) drives the engine through polychord_c_interface, with the
+    device likelihood and with a likelihood written in Fortran (the reference's Fortran callers, interfaces.F90:10-12)"""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("amdflang") is None:
+        pytest.skip("no Fortran compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "bindings", "fortran")
+    lib = os.path.join(root, "polychordlite_amd")
+    subprocess.check_call(["amdflang", "-c", os.path.join(src, "polychord_hip.f90"), "-o", "ph.o"], cwd=tmp_path)
+    subprocess.check_call(["amdflang", os.path.join(src, "example_gaussian.f90"), "ph.o", "-L" + lib, "-lpolychord_hip",
+                           "-Wl,-rpath," + lib, "-o", "ex"], cwd=tmp_path)
+    (tmp_path / "chains").mkdir()
+    out = subprocess.run(["./ex"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for rootname in ("f_device", "f_host"):
+        st = (tmp_path / "chains" / (rootname + ".stats")).read_text().splitlines()
+        logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
+        assert abs(logZ) < 4 * err and err < 0.5, (rootname, logZ, err)       # truth 0
+        rows = np.loadtxt(tmp_path / "chains" / (rootname + "_dead-birth.txt"))
+        assert rows.shape[1] == 4 + 1 + 2
