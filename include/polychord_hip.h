@@ -149,6 +149,13 @@ typedef struct {
     const int *nlive_p;             /* [ncluster] */
     const double *logZp, *logZperr;            /* [ncluster] clusters still active */
     const double *logZp_dead, *logZperr_dead;  /* [ncluster_dead] */
+    /* cluster bookkeeping for the per-cluster posterior files (run_time_info.f90:303-505: a split hands every
+       child a copy of the parent's posterior points, weights scaled by the evidence fraction it received) */
+    const unsigned *dead_cluster;              /* [ndead] id of the cluster each point died in (failed spawns: 0xFFFFFFFF) */
+    const unsigned *cluster_uid, *cluster_uid_dead;   /* ids of the active / dead clusters, same order as logZp* */
+    int nsplit;                                /* children created by splits so far */
+    const unsigned *split_child, *split_parent;
+    const double *split_logfrac;               /* log(evidence of child / evidence of parent) at the split */
 } pchip_update;
 typedef void (*pchip_update_fn)(void *user, const pchip_update *u);
 

@@ -14,6 +14,8 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include <sys/stat.h>
 #include <chrono>
 
@@ -66,7 +68,8 @@ std::string fmt_e24(double v)
 struct FileSink {
     std::string base, root;
     int nDims = 0, nDer = 0;
-    bool write_stats = false, write_live = false, write_dead = false, posteriors = false, equals = false, write_prior = false;
+    bool write_stats = false, write_live = false, write_dead = false, posteriors = false, equals = false, write_prior = false,
+         cluster_posteriors = false;
     unsigned seed = 0; double logzero = -1e30, compression = 0.36787944117144233; int num_repeats = 1;
     long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
     std::vector<double> mu, sig;
@@ -167,6 +170,52 @@ struct FileSink {
         if (fp) std::fclose(fp);
         if (fe) std::fclose(fe);
     }
+    // Per-cluster posteriors (write_posterior_file, read_write.F90:521-592; files clusters/<root>_<rank>.txt, rank 1 =
+    // largest evidence).  A cluster's posterior = the points that died in it + the points of every ancestor, scaled
+    // by the evidence fractions of the splits in between (add_cluster, run_time_info.f90:432-436,499-502); the
+    // largest weight of file k is Z_k / Z.
+    void cluster_files(const pchip_update &u)
+    {
+        const int np = nDims + nDer, K = u.ncluster + u.ncluster_dead;
+        std::vector<double> lz(K); std::vector<unsigned> uid(K);
+        for (int k = 0; k < u.ncluster; ++k) { lz[k] = u.logZp[k]; uid[k] = u.cluster_uid[k]; }
+        for (int k = 0; k < u.ncluster_dead; ++k) { lz[u.ncluster + k] = u.logZp_dead[k]; uid[u.ncluster + k] = u.cluster_uid_dead[k]; }
+        std::vector<int> order(K);
+        for (int k = 0; k < K; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lz[a] > lz[b]; });
+        std::map<unsigned, std::vector<long>> pts;
+        for (long i = 0; i < u.ndead; ++i) if (u.logpost[i] > -1e29) pts[u.dead_cluster[i]].push_back(i);
+        std::map<unsigned, std::pair<unsigned, double>> parent;
+        for (int j = 0; j < u.nsplit; ++j) parent[u.split_child[j]] = {u.split_parent[j], u.split_logfrac[j]};
+        std::string tail;
+        for (int r = 0; r < K; ++r) {
+            const int k = order[r];
+            std::vector<std::pair<unsigned, double>> chain;        // (cluster id, log scale of its points), youngest first
+            unsigned cur = uid[k]; double cum = 0.0;
+            chain.push_back({cur, 0.0});
+            for (auto it = parent.find(cur); it != parent.end(); it = parent.find(cur)) { cum += it->second.second; cur = it->second.first; chain.push_back({cur, cum}); }
+            double mx = -1.7e308;
+            for (auto &c : chain) for (long i : pts[c.first]) mx = std::max(mx, u.logpost[i] + c.second);
+            char num[32]; std::snprintf(num, sizeof num, "%d", r + 1);
+            const std::string stem = base + "/clusters/" + root + "_" + num;
+            FILE *fp = posteriors ? std::fopen((stem + ".txt").c_str(), "w") : nullptr;
+            FILE *fe = equals ? std::fopen((stem + "_equal_weights.txt").c_str(), "w") : nullptr;
+            if ((posteriors && !fp) || (equals && !fe)) halt_program(("polychord_hip: cannot write " + stem + " (does " + base + "/clusters exist?)").c_str());
+            const double frac = std::exp(lz[k] - u.logZ);
+            for (auto c = chain.rbegin(); c != chain.rend(); ++c)      // ancestors first, as the copies were made
+                for (long i : pts[c->first]) {
+                    const double *row = u.dead + (size_t)i * u.npars;
+                    const double rel = std::exp(u.logpost[i] + c->second - mx);
+                    if (!(rel > 0.0)) continue;
+                    tail = fmt_e24(-2 * row[np + 1]);
+                    for (int q = 0; q < np; ++q) tail += fmt_e24(row[q]);
+                    if (fp) std::fprintf(fp, "%s%s\n", fmt_e24(rel * frac).c_str(), tail.c_str());
+                    if (fe && polychord_hip_keyed_uniform(seed, 7u, (unsigned)r, 0u, (unsigned)i) < rel) std::fprintf(fe, "%s%s\n", fmt_e24(frac).c_str(), tail.c_str());
+                }
+            if (fp) std::fclose(fp);
+            if (fe) std::fclose(fe);
+        }
+    }
     void update(const pchip_update &u)
     {
         if (u.final_call == 2) {                  // write_prior_file (read_write.F90:721-752) + generate.F90:274-279
@@ -199,7 +248,7 @@ struct FileSink {
             rows(f2, u.live, 0, u.nlive, u.npars, false, true);
             std::fclose(f1); std::fclose(f2);
         }
-        if (u.final_call == 1 && (posteriors || equals)) posterior_files(u);
+        if (u.final_call == 1 && (posteriors || equals)) { posterior_files(u); if (cluster_posteriors) cluster_files(u); }
         if (write_stats) stats(u);
         nlike_last = u.nlike;
     }
@@ -346,7 +395,7 @@ void polychord_c_interface(
     FileSink sink;
     sink.base = base; sink.root = root; sink.nDims = nDims; sink.nDer = nDerived;
     sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
-    sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
+    sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.cluster_posteriors = cluster_posteriors; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
     sink.compression = compression_factor; sink.num_repeats = num_repeats;
     if ((posteriors || equals) && boost_posterior != 0.0 && feedback >= 1)
         std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         __syncthreads();
         if (tid == 0) {
             if (nc_dead < S.maxc_dead) {
-                S.logZp_dead[nc_dead] = H.cLogZp[p]; S.logZp2_dead[nc_dead] = H.cLogZp2[p];
+                S.logZp_dead[nc_dead] = H.cLogZp[p]; S.logZp2_dead[nc_dead] = H.cLogZp2[p]; S.cl_uid_dead[nc_dead] = H.cUid[p];
             }
         }
         nc_dead++;

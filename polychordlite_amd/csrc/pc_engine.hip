@@ -209,6 +209,9 @@ struct Engine {
     bool resume_static = true; unsigned resume_batch0 = 0;
     bool nph_stale = false;                     // h_ctl->nphantom is the count before the last clean (an upper bound)
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
+    std::vector<unsigned> hm_cuid;              // cluster uid every dead point died in
+    // cluster genealogy: child uid, parent uid, log of the evidence fraction the child received (add_cluster)
+    std::vector<unsigned> split_child, split_parent; std::vector<double> split_logfrac;
     std::vector<double> h_lo, h_hi;
     PcState S{};
     hipStream_t st = nullptr;
@@ -314,7 +317,7 @@ struct Engine {
         S.lse_ref = dalloc<double>(maxc); S.lse_sum = dalloc<double>(maxc); S.death_thr = dalloc<double>(maxc);
         S.cl_uid = dalloc<unsigned>(maxc);
         S.chol = dalloc<double>((size_t)maxc * D * D); S.cov = dalloc<double>((size_t)maxc * D * D);
-        S.logZp_dead = dalloc<double>(S.maxc_dead); S.logZp2_dead = dalloc<double>(S.maxc_dead);
+        S.logZp_dead = dalloc<double>(S.maxc_dead); S.logZp2_dead = dalloc<double>(S.maxc_dead); S.cl_uid_dead = dalloc<unsigned>(S.maxc_dead);
         S.phantom = dalloc<double>((size_t)S.Pcap * nT); S.ph_logL = dalloc<double>(S.Pcap);
         S.ph_cuid = dalloc<unsigned>(S.Pcap); S.ph_uid = dalloc<unsigned long long>(S.Pcap);
         alloc_phantom_side(S.Pcap);
@@ -387,6 +390,8 @@ struct Engine {
         HIPCHK(hipStreamSynchronize(st));
         if (nd > hm_ndead) {
             std::vector<double> rows((size_t)(nd - hm_ndead) * nT), lw(nd - hm_ndead);
+            hm_cuid.resize(nd);
+            HIPCHK(hipMemcpy(hm_cuid.data() + hm_ndead, S.dead_cuid + hm_ndead, sizeof(unsigned) * (nd - hm_ndead), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(rows.data(), S.dead + (size_t)hm_ndead * nT, sizeof(double) * rows.size(), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(lw.data(), S.dead_logw + hm_ndead, sizeof(double) * lw.size(), hipMemcpyDeviceToHost));
             hm_dead.resize((size_t)nd * npars); hm_logw.resize(nd);
@@ -436,6 +441,11 @@ struct Engine {
             u.logZ = lz; u.logZerr = std::sqrt(std::fabs(var)); u.nlike = h_ctl->nlike;
             u.ncluster = nc; u.ncluster_dead = ncd; u.nlive_p = cn.data();
             u.logZp = e1.data(); u.logZperr = s1.data(); u.logZp_dead = e2.data(); u.logZperr_dead = s2.data();
+            auto ua = dl(S.cl_uid, std::max(1, nc)); auto ud = dl(S.cl_uid_dead, std::max(1, ncd));
+            unsigned dummy_u = 0u;
+            u.dead_cluster = nd > 0 ? hm_cuid.data() : &dummy_u; u.cluster_uid = ua.data(); u.cluster_uid_dead = ud.data();
+            u.nsplit = (int)split_child.size(); u.split_child = split_child.data(); u.split_parent = split_parent.data();
+            u.split_logfrac = split_logfrac.data();
             on_update(hook_user, &u);
         }
     }
@@ -581,6 +591,7 @@ struct Engine {
         for (int k = 0; k < nnew; ++k) sm += std::exp(logni[k] - mx);
         const double logn = mx + std::log(sm);
         const double logn1 = logn > 0.0 ? logn + std::log(std::exp(0.0 - logn) + 1.0) : 0.0 + std::log(std::exp(logn - 0.0) + 1.0);
+        for (int k = 0; k < nnew; ++k) { split_child.push_back(uid[nold + k]); split_parent.push_back(olduid[p]); split_logfrac.push_back(logni[k] - logn); }
         for (int k = 0; k < nnew; ++k) {
             const int c = nold + k;
             Xp[c] = logXp + logni[k] - logn; ZXp[c] = logZXp + logni[k] - logn; Zp[c] = logZp + logni[k] - logn;
@@ -1033,7 +1044,7 @@ struct Engine {
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
                        &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
-        unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2 };
+        unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
         kt.destroy();

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         if (status == PC_ST_RUNNING) {
             for (int s = lane; s < NS; s += 64) sL[s] = PC_HUGE;
             n = 0;
-            if (lane == 0 && nc_dead < S.maxc_dead) { S.logZp_dead[nc_dead] = Zp; S.logZp2_dead[nc_dead] = Zp2; }
+            if (lane == 0 && nc_dead < S.maxc_dead) { S.logZp_dead[nc_dead] = Zp; S.logZp2_dead[nc_dead] = Zp2; S.cl_uid_dead[nc_dead] = cuid; }
             nc_dead++; nc = 0;
             status = PC_ST_DONE;
         }

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S)
     }
     if (tid == 0) {
         const int ncd = ctl->ncluster_dead;
-        if (ncd < S.maxc_dead) { S.logZp_dead[ncd] = carry[4]; S.logZp2_dead[ncd] = carry[6]; }
+        if (ncd < S.maxc_dead) { S.logZp_dead[ncd] = carry[4]; S.logZp2_dead[ncd] = carry[6]; S.cl_uid_dead[ncd] = cuid; }
         S.logLp[0] = PC_HUGE; S.imin_slot[0] = -1; S.logXp[0] = carry[2]; S.XpXq[0] = carry[3]; S.logZp[0] = carry[4];
         S.logZXp[0] = carry[5]; S.logZp2[0] = carry[6]; S.logZpXp[0] = carry[7]; S.death_thr[0] = carry[8]; S.cl_n[0] = 0;
         ctl->status = PC_ST_DONE; ctl->error = PC_ERR_NONE; ctl->ndead = ndead0 + n0; ctl->ncluster = 0; ctl->ncluster_dead = ncd + 1;

@@ -72,6 +72,7 @@ struct PcState {
     unsigned *cl_uid;            // [maxc] stable ids (phantoms carry these)
     double *chol, *cov;          // [maxc][D*D] row-major lower Cholesky / covariance
     double *logZp_dead, *logZp2_dead;   // [maxc_dead]
+    unsigned *cl_uid_dead;              // [maxc_dead] uid of every dead cluster (cluster posterior files)
     int maxc_dead;
     // ---- phantoms (append-only between cleans)
     double *phantom;             // [Pcap][nT]

@@ -329,3 +329,40 @@ def test_fortran_binding(engine, tmp_path):
         assert abs(logZ) < 4 * err and err < 0.5, (rootname, logZ, err)       # truth 0
         rows = np.loadtxt(tmp_path / "chains" / (rootname + "_dead-birth.txt"))
         assert rows.shape[1] == 4 + 1 + 2
+
+
+@pytest.mark.gpu
+def test_cluster_posterior_files(engine, tmp_path):
+    """clusters/<root>_<rank>.txt (read_write.F90:521-592): one file per cluster, ranked by evidence; the largest
+    weight of file k is Z_k / Z; every cluster sits on one Rastrigin mode; the mixture of the cluster posteriors
+    with weights Z_k / Z is the global posterior (points inherited through splits carry the evidence fractions)."""
+    from polychordlite_amd import pypolychord as pc
+    from polychordlite_amd.pypolychord.device_likelihoods import Rastrigin, UniformPrior
+    base = tmp_path / "ch"
+    pc.run(Rastrigin(), 2, base_dir=str(base), file_root="r", nlive=400, num_repeats=6, do_clustering=True, feedback=0, seed=7,
+           prior=UniformPrior(-5.12, 5.12), posteriors=True, equals=True, cluster_posteriors=True, write_resume=False,
+           read_resume=False, write_live=False, write_prior=False)
+    st = open(base / "r.stats").read().splitlines()
+    logZ = float(st[8].split("=")[1].split("+/-")[0])
+    zk = sorted((float(l.split("=")[1].split("+/-")[0]) for l in st if l.startswith("log(Z_")), reverse=True)
+    files = sorted((base / "clusters").glob("r_[0-9]*.txt"), key=lambda p: int(p.stem.split("_")[1]))
+    files = [f for f in files if "equal" not in f.name]
+    assert len(files) == len(zk) >= 10
+    glob_post = np.loadtxt(base / "r.txt")
+    gmean = (glob_post[:, 0:1] * glob_post[:, 2:4]).sum(0) / glob_post[:, 0].sum()
+    mix = np.zeros(2); ftot = 0.0
+    for k, f in enumerate(files):
+        a = np.atleast_2d(np.loadtxt(f))
+        if a.size == 0:
+            continue
+        frac = np.exp(zk[k] - logZ)
+        assert abs(a[:, 0].max() - frac) < 1e-9 * max(1.0, frac)              # normalisation and ranking
+        m = (a[:, 0:1] * a[:, 2:4]).sum(0) / a[:, 0].sum()
+        if k < 8:                                                              # the heavy clusters: one mode each
+            sd = np.sqrt((a[:, 0:1] * (a[:, 2:4] - m) ** 2).sum(0) / a[:, 0].sum())
+            assert np.all(np.abs(m - np.round(m)) < 0.2) and np.all(sd < 0.45), (k, m, sd)
+        mix += frac * m; ftot += frac
+        eq = base / "clusters" / (f.stem + "_equal_weights.txt")
+        assert eq.exists()
+    assert abs(ftot - 1.0) < 0.1
+    assert np.all(np.abs(mix / ftot - gmean) < 0.15)
