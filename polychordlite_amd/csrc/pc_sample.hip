@@ -209,85 +209,10 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         double ua, ub;
         pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
         const uint32_t ia = 2 * call, ib = 2 * call + 1;
-        if constexpr (DMAX > 64) {                 // wide bases live in LDS rows of odd stride (see below)
-            const uint32_t DSw = (uint32_t)((D + 3) & ~3) + 1u;
-            if (ia >= e0 && ia < e1) G[((ia - e0) / D) * DSw + (ia - e0) % D] = pc_inv_normal_cdf(ua);
-            if (ib >= e0 && ib < e1) G[((ib - e0) / D) * DSw + (ib - e0) % D] = pc_inv_normal_cdf(ub);
-        } else {
-            if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
-            if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
-        }
+        if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
+        if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
     }
     __syncthreads();
-    if constexpr (DMAX > 64) {
-        // ---- wide nDims (65..128): a vector does not fit the register file (128 fp64 = every VGPR, the compiler
-        // spilled 437 of them), so the basis stays in LDS: thread i owns row i (stride D4+1: conflict free), the
-        // pivot is broadcast through a double buffer, dots run on four partial sums over zero-padded rows.
-        const int i = tid, D4 = (D + 3) & ~3, DS = D4 + 1, TR = 12;
-        const bool active = i < D;
-        double *v = G + (size_t)i * DS;
-        double *Qb = Q;                                // [2][D4]
-        double *Lt = G + (size_t)D * DS;               // [TR][D] tile of the Cholesky factor
-        auto dot4 = [&](const double *a, const double *b) __attribute__((always_inline)) {
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-            for (int d = 0; d < D4; d += 4) { p0 += a[d] * b[d]; p1 += a[d + 1] * b[d + 1]; p2 += a[d + 2] * b[d + 2]; p3 += a[d + 3] * b[d + 3]; }
-            return (p0 + p1) + (p2 + p3);
-        };
-        if (active) {
-            for (int d = D; d < D4; ++d) v[d] = 0.0;
-            const double inrm = 1.0 / sqrt(dot4(v, v));        // random_direction (random_utils.F90:276-298)
-            for (int d = 0; d < D; ++d) v[d] *= inrm;
-        }
-        if (i == 0) for (int d = 0; d < D4; ++d) Qb[d] = v[d];
-        __syncthreads();
-        for (int j = 0; j < D; ++j) {
-            const double *q = Qb + (size_t)(j & 1) * D4;
-            if (active && i >= j) {
-                const double qq = dot4(q, q);
-                if (i == j) {
-                    const double inrm = 1.0 / sqrt(qq);
-                    for (int d = 0; d < D; ++d) v[d] *= inrm;
-                } else {
-                    const double cproj = dot4(q, v) / qq;
-                    for (int d = 0; d < D; ++d) v[d] -= cproj * q[d];
-                    if (i == j + 1) { double *qn = Qb + (size_t)((j + 1) & 1) * D4; for (int d = 0; d < D4; ++d) qn[d] = v[d]; }
-                }
-            }
-            __syncthreads();
-        }
-        // whitening  w = L.n  (chordal_sampling.f90:73), in place, the factor streaming through a row tile
-        const int col = basis * D + i;
-        const double *Lc = S.chol + (size_t)sh[0] * D * D;
-        for (int a_hi = D - 1; a_hi >= 0; a_hi -= TR) {
-            const int a_lo = max(0, a_hi - TR + 1), nrow = a_hi - a_lo + 1;
-            __syncthreads();
-            for (int e = tid; e < nrow * D; e += NT) Lt[e] = Lc[(size_t)a_lo * D + e];
-            __syncthreads();
-            if (active && col < nr) {
-                for (int a = a_hi; a >= a_lo; --a) {
-                    const double *Lr = Lt + (size_t)(a - a_lo) * D;
-                    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-                    int bb = 0;
-                    for (; bb + 3 <= a; bb += 4) { t0 += Lr[bb] * v[bb]; t1 += Lr[bb + 1] * v[bb + 1]; t2 += Lr[bb + 2] * v[bb + 2]; t3 += Lr[bb + 3] * v[bb + 3]; }
-                    for (; bb <= a; ++bb) t0 += Lr[bb] * v[bb];
-                    v[a] = (t0 + t1) + (t2 + t3);
-                }
-            }
-        }
-        __syncthreads();
-        if (active && col < nr) {
-            const double w = sqrt(dot4(v, v));                 // chordal_sampling.f90:80-82 (padding is zero)
-            Qb[i] = 1.0 / w;
-            S.nhat_w[(size_t)chain * nr + col] = w * 3.0;
-        }
-        __syncthreads();
-        for (int r = 0; r < D && basis * D + r < nr; ++r) {      // rows leave coalesced
-            double *out = S.nhat + ((size_t)chain * nr + basis * D + r) * D;
-            const double iw = Qb[r];
-            for (int d = tid; d < D; d += NT) out[d] = G[(size_t)r * DS + d] * iw;
-        }
-        return;
-    }
 #ifdef NHATS_DBG
     ncyc[2] = clock64();
 #endif
@@ -435,6 +360,138 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += ncyc[x + 1] - ncyc[x];
 #endif
 #undef PC_DOT4
+}
+
+// ------------------------------------------------------------------------------------------
+// K0 for 64 < nDims <= 128: FOUR threads per basis vector (32 coordinates each, all in registers), 512 threads per
+// basis.  Dot products are 8 deep instead of 32, the four partial sums meet through DPP quad permutes, the pivot
+// travels through 2 KB of LDS, and the whitening streams the Cholesky factor through 32-row LDS tiles whose rows
+// line up with the four coordinate blocks.  (One thread per vector needed 128 fp64 registers and spilled; vectors
+// kept in LDS made every Gram-Schmidt step an LDS round trip per coordinate: 1.5 ms per launch at nDims = 100.)
+// ------------------------------------------------------------------------------------------
+#define PC_WIDE_NT 512
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += dpp_f64<PC_DPP_XOR1>(v);
+    v += dpp_f64<PC_DPP_XOR2>(v);
+    return v;
+}
+__global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned batch)
+{
+    __shared__ __attribute__((aligned(16))) double Qb[2][128];        // pivot, double buffered
+    __shared__ __attribute__((aligned(16))) double Lt[32][128];       // 32 rows of the Cholesky factor
+    __shared__ int sh[2];
+    const int D = S.D, nr = S.nr;
+    const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
+    const int i = tid >> 2, h = tid & 3, d0 = 32 * h;                 // my vector, my coordinate block
+    const bool active = i < D;
+    if (tid == 0) {
+        int sel, slot;
+        select_seed(S, batch, chain, sel, slot);
+        sh[0] = sel; sh[1] = slot;
+        if (basis == 0) {
+            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
+            S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
+            S.ch_epoch[chain] = S.ctl->admin_epoch;
+            if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
+        }
+    }
+    // gaussian deviates of my 32 coordinates: element (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT,
+    // two per Philox call
+    double v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = 0.0;
+    if (active) {
+        const uint32_t e0 = ((uint32_t)basis * D + i) * D + d0;
+        const int cnt = min(32, D - d0);                              // coordinates of this block that exist
+        if (cnt > 0) {
+            const uint32_t c0 = e0 >> 1, c1 = (e0 + cnt - 1) >> 1;
+#pragma unroll
+            for (int cc = 0; cc < 17; ++cc) {
+                const uint32_t call = c0 + cc;
+                if (call <= c1) {
+                    double ua, ub;
+                    pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+                    const int ea = (int)(2 * call) - (int)e0, eb = ea + 1;     // -1 .. 32
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        if (e == ea && e < cnt) v[e] = pc_inv_normal_cdf(ua);
+                        if (e == eb && e < cnt) v[e] = pc_inv_normal_cdf(ub);
+                    }
+                }
+            }
+        }
+    }
+#define PC_DOT32(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
+        _Pragma("unroll") for (int e = 0; e < 32; e += 4) { \
+            p0_ += (A)[e] * (B)[e]; p1_ += (A)[e + 1] * (B)[e + 1]; p2_ += (A)[e + 2] * (B)[e + 2]; p3_ += (A)[e + 3] * (B)[e + 3]; } \
+        RES = quad_sum((p0_ + p1_) + (p2_ + p3_)); }
+    {   // random_direction (random_utils.F90:276-298)
+        double n2;
+        PC_DOT32(n2, v, v)
+        const double inrm = active ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) v[e] *= inrm;
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) Qb[0][d0 + e] = v[e];
+    }
+    __syncthreads();
+    // Gram-Schmidt (random_utils.F90:391-399): same projections as k_nhats, pivot unnormalised
+    for (int j = 0; j < D; ++j) {
+        double q[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) q[e] = Qb[j & 1][d0 + e];
+        double qq, dv;
+        PC_DOT32(qq, q, q)
+        PC_DOT32(dv, q, v)
+        if (i == j) {
+            const double inrm = 1.0 / sqrt(qq);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] *= inrm;
+        } else if (active && i > j) {
+            const double cproj = dv / qq;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] -= cproj * q[e];
+            if (i == j + 1) {
+#pragma unroll
+                for (int e = 0; e < 32; ++e) Qb[(j + 1) & 1][d0 + e] = v[e];
+            }
+        }
+        __syncthreads();
+    }
+    // whitening  w = L.n  (chordal_sampling.f90:73): tile k holds rows 32k..32k+31 of L, i.e. exactly the output
+    // coordinates of block h = k
+    const int col = basis * D + i;
+    const double *Lc = S.chol + (size_t)sh[0] * D * D;
+    double w[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) w[e] = 0.0;
+    for (int k = 0; k * 32 < D; ++k) {
+        __syncthreads();
+        for (int x = tid; x < 32 * 128; x += PC_WIDE_NT) {
+            const int r = x >> 7, b = x & 127, a = 32 * k + r;
+            Lt[r][b] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            double t;
+            PC_DOT32(t, (&Lt[r][d0]), v)
+            if (h == k) w[r] = t;
+        }
+    }
+    if (active && col < nr) {
+        double n2;
+        PC_DOT32(n2, w, w)
+        const double wn = sqrt(n2), iw = 1.0 / wn;              // chordal_sampling.f90:80-82
+        double *out = S.nhat + ((size_t)chain * nr + col) * D + d0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) if (d0 + e < D) out[e] = w[e] * iw;
+        if (h == 0) S.nhat_w[(size_t)chain * nr + col] = wn * 3.0;
+    }
+#undef PC_DOT32
 }
 
 // ------------------------------------------------------------------------------------------
@@ -871,7 +928,7 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
     else if (D <= 24) hipLaunchKernelGGL((k_nhats<24, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 64) hipLaunchKernelGGL((k_nhats<64, 64>), grid, dim3(64), sh, st, *S, batch);
-    else if (D <= 128) hipLaunchKernelGGL((k_nhats<128, 128>), grid, dim3(128), sh, st, *S, batch);
+    else if (D <= 128) hipLaunchKernelGGL(k_nhats_wide, grid, dim3(PC_WIDE_NT), 0, st, *S, batch);
     else return 1;
     return 0;
 }
