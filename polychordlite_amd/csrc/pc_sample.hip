@@ -14,6 +14,7 @@
 //                SliceSampling / slice_sample (chordal_sampling.f90:7-92, 163-273) and
 //                calculate_point (calculate.f90:6-50); likelihood sums are DPP butterflies.
 #include "pc_state.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
 // likelihood on a wave: lane owns DPL coordinates (dim = lane + 64*k)
@@ -369,21 +370,23 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 // line up with the four coordinate blocks.  (One thread per vector needed 128 fp64 registers and spilled; vectors
 // kept in LDS made every Gram-Schmidt step an LDS round trip per coordinate: 1.5 ms per launch at nDims = 100.)
 // ------------------------------------------------------------------------------------------
-#define PC_WIDE_NT 512
 __device__ __forceinline__ double quad_sum(double v)
 {
     v += dpp_f64<PC_DPP_XOR1>(v);
     v += dpp_f64<PC_DPP_XOR2>(v);
     return v;
 }
-__global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned batch)
+// HV = coordinates per thread: 8 (nDims <= 32), 16 (<= 64), 32 (<= 128); 4*HV vectors of 4*HV padded coordinates
+template <int HV>
+__global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
-    __shared__ __attribute__((aligned(16))) double Qb[2][128];        // pivot, double buffered
-    __shared__ __attribute__((aligned(16))) double Lt[32][128];       // 32 rows of the Cholesky factor
+    constexpr int DP = 4 * HV, NTQ = 16 * HV;
+    __shared__ __attribute__((aligned(16))) double Qb[2][DP];         // pivot, double buffered
+    __shared__ __attribute__((aligned(16))) double Lt[HV][DP];        // HV rows of the Cholesky factor
     __shared__ int sh[2];
     const int D = S.D, nr = S.nr;
     const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
-    const int i = tid >> 2, h = tid & 3, d0 = 32 * h;                 // my vector, my coordinate block
+    const int i = tid >> 2, h = tid & 3, d0 = HV * h;                 // my vector, my coordinate block
     const bool active = i < D;
     if (tid == 0) {
         int sel, slot;
@@ -398,32 +401,33 @@ __global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned b
     }
     // gaussian deviates of my 32 coordinates: element (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT,
     // two per Philox call
-    double v[32];
+    double v[HV];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] = 0.0;
+    for (int e = 0; e < HV; ++e) v[e] = 0.0;
     if (active) {
         const uint32_t e0 = ((uint32_t)basis * D + i) * D + d0;
-        const int cnt = min(32, D - d0);                              // coordinates of this block that exist
+        const int cnt = min(HV, D - d0);                              // coordinates of this block that exist
         if (cnt > 0) {
             const uint32_t c0 = e0 >> 1, c1 = (e0 + cnt - 1) >> 1;
 #pragma unroll
-            for (int cc = 0; cc < 17; ++cc) {
+            for (int cc = 0; cc < HV / 2 + 1; ++cc) {
                 const uint32_t call = c0 + cc;
                 if (call <= c1) {
                     double ua, ub;
                     pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
-                    const int ea = (int)(2 * call) - (int)e0, eb = ea + 1;     // -1 .. 32
+                    const int ea = (int)(2 * call) - (int)e0, eb = ea + 1;     // -1 .. HV
+                    const double ga = pc_inv_normal_cdf(ua), gb = pc_inv_normal_cdf(ub);
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) {
-                        if (e == ea && e < cnt) v[e] = pc_inv_normal_cdf(ua);
-                        if (e == eb && e < cnt) v[e] = pc_inv_normal_cdf(ub);
+                    for (int e = 0; e < HV; ++e) {
+                        if (e == ea && e < cnt) v[e] = ga;
+                        if (e == eb && e < cnt) v[e] = gb;
                     }
                 }
             }
         }
     }
 #define PC_DOT32(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
-        _Pragma("unroll") for (int e = 0; e < 32; e += 4) { \
+        _Pragma("unroll") for (int e = 0; e < HV; e += 4) { \
             p0_ += (A)[e] * (B)[e]; p1_ += (A)[e + 1] * (B)[e + 1]; p2_ += (A)[e + 2] * (B)[e + 2]; p3_ += (A)[e + 3] * (B)[e + 3]; } \
         RES = quad_sum((p0_ + p1_) + (p2_ + p3_)); }
     {   // random_direction (random_utils.F90:276-298)
@@ -431,32 +435,42 @@ __global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned b
         PC_DOT32(n2, v, v)
         const double inrm = active ? 1.0 / sqrt(n2) : 0.0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) v[e] *= inrm;
+        for (int e = 0; e < HV; ++e) v[e] *= inrm;
     }
     if (i == 0) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) Qb[0][d0 + e] = v[e];
+        for (int e = 0; e < HV; ++e) Qb[0][d0 + e] = v[e];
     }
     __syncthreads();
-    // Gram-Schmidt (random_utils.F90:391-399): same projections as k_nhats, pivot unnormalised
-    for (int j = 0; j < D; ++j) {
-        double q[32];
+    // first tile of the Cholesky factor: requested now, consumed after the loop
+    double lpre[(HV * DP + NTQ - 1) / NTQ];
+    {
+        const double *Lc0 = S.chol + (size_t)sh[0] * D * D;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) q[e] = Qb[j & 1][d0 + e];
+        for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) {
+            const int y = tid + x * NTQ, r = y / DP, b = y % DP;
+            lpre[x] = (y < HV * DP && r < D && b < D) ? Lc0[(size_t)r * D + b] : 0.0;
+        }
+    }
+    // Gram-Schmidt (random_utils.F90:391-399): same projections as before, pivot unnormalised
+    for (int j = 0; j < D; ++j) {
+        double q[HV];
+#pragma unroll
+        for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][d0 + e];
         double qq, dv;
         PC_DOT32(qq, q, q)
         PC_DOT32(dv, q, v)
         if (i == j) {
             const double inrm = 1.0 / sqrt(qq);
 #pragma unroll
-            for (int e = 0; e < 32; ++e) v[e] *= inrm;
+            for (int e = 0; e < HV; ++e) v[e] *= inrm;
         } else if (active && i > j) {
             const double cproj = dv / qq;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) v[e] -= cproj * q[e];
+            for (int e = 0; e < HV; ++e) v[e] -= cproj * q[e];
             if (i == j + 1) {
 #pragma unroll
-                for (int e = 0; e < 32; ++e) Qb[(j + 1) & 1][d0 + e] = v[e];
+                for (int e = 0; e < HV; ++e) Qb[(j + 1) & 1][d0 + e] = v[e];
             }
         }
         __syncthreads();
@@ -465,18 +479,24 @@ __global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned b
     // coordinates of block h = k
     const int col = basis * D + i;
     const double *Lc = S.chol + (size_t)sh[0] * D * D;
-    double w[32];
+    double w[HV];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) w[e] = 0.0;
-    for (int k = 0; k * 32 < D; ++k) {
+    for (int e = 0; e < HV; ++e) w[e] = 0.0;
+    for (int k = 0; k * HV < D; ++k) {
         __syncthreads();
-        for (int x = tid; x < 32 * 128; x += PC_WIDE_NT) {
-            const int r = x >> 7, b = x & 127, a = 32 * k + r;
-            Lt[r][b] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
+        if (k == 0) {
+            // the first tile was requested before the Gram-Schmidt loop (registers lpre): its latency is hidden
+#pragma unroll
+            for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) { const int y = tid + x * NTQ; if (y < HV * DP) Lt[y / DP][y % DP] = lpre[x]; }
+        } else {
+            for (int x = tid; x < HV * DP; x += NTQ) {
+                const int r = x / DP, b = x % DP, a = HV * k + r;
+                Lt[r][b] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
+        for (int r = 0; r < HV; ++r) {
             double t;
             PC_DOT32(t, (&Lt[r][d0]), v)
             if (h == k) w[r] = t;
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(PC_WIDE_NT) void k_nhats_wide(PcState S, unsigned b
         const double wn = sqrt(n2), iw = 1.0 / wn;              // chordal_sampling.f90:80-82
         double *out = S.nhat + ((size_t)chain * nr + col) * D + d0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) if (d0 + e < D) out[e] = w[e] * iw;
+        for (int e = 0; e < HV; ++e) if (d0 + e < D) out[e] = w[e] * iw;
         if (h == 0) S.nhat_w[(size_t)chain * nr + col] = wn * 3.0;
     }
 #undef PC_DOT32
@@ -920,15 +940,23 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
 extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
     const int D = S->D, nb = (S->nr + D - 1) / D;
+    dim3 grid(nb, nchains);
+    static int quad_min = -1;                       // smallest nDims that takes the four-threads-per-vector kernel
+    if (quad_min < 0) { const char *e = std::getenv("PC_NHATS_QUAD_MIN"); quad_min = e ? std::atoi(e) : 25; }   // measured: 20-D 52 vs 39 us (old kernel better), 28-D 43 vs 47, 40-D 95 vs 133, 64-D 129 vs 240
+    if (D >= quad_min) {
+        if (D <= 32) hipLaunchKernelGGL((k_nhats_q<8>), grid, dim3(128), 0, st, *S, batch);
+        else if (D <= 64) hipLaunchKernelGGL((k_nhats_q<16>), grid, dim3(256), 0, st, *S, batch);
+        else if (D <= 128) hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), 0, st, *S, batch);
+        else return 1;
+        return 0;
+    }
     // deviates / Cholesky factor with padded rows, then the double-buffered pivot (2 x DMAX <= 2 x 128)
     const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
-    dim3 grid(nb, nchains);
     if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 24) hipLaunchKernelGGL((k_nhats<24, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 64) hipLaunchKernelGGL((k_nhats<64, 64>), grid, dim3(64), sh, st, *S, batch);
-    else if (D <= 128) hipLaunchKernelGGL(k_nhats_wide, grid, dim3(PC_WIDE_NT), 0, st, *S, batch);
     else return 1;
     return 0;
 }
