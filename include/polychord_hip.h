@@ -97,6 +97,9 @@ typedef struct {
     int ablate;         /* developer timing hook: bit mask of contraction sub-steps to skip; 0 = product */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
+    int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the
+                           general contraction kernel with the reference's list rule): with the generator shim of
+                           oracle/ref_rng_shim.c the reference binary then produces the same run, draw for draw */
     const char *resume_read;   /* start from this .resume file if it exists (read_write.F90:384-476; also the file
                                   pypolychord writes for `cube_samples`); NULL = off */
 } pchip_settings;

@@ -31,7 +31,7 @@ class Settings(C.Structure):
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
                 ("force_general", C.c_int), ("ablate", C.c_int),
-                ("resume_write", C.c_char_p), ("resume_read", C.c_char_p)]
+                ("resume_write", C.c_char_p), ("sequential_rng", C.c_int), ("resume_read", C.c_char_p)]
 
 
 class Like(C.Structure):

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                     __syncthreads();
                     // engine rule (oracle keyed mode): a point that replaces a death of its own cluster
                     // takes the dead point's list position instead of being appended
-                    if (replaced && last_cd == ca && last_pos_del < H.cN[ca] - 1) {
+                    if (!S.seq_mode && replaced && last_cd == ca && last_pos_del < H.cN[ca] - 1) {
                         const int pos_new = H.cN[ca] - 1;
                         for (int s = tid; s < Ncap; s += NT)
                             if (s != free_slot && H.sC[s] == ca && H.sP[s] == last_pos_del) H.sP[s] = pos_new;

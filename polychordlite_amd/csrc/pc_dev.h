@@ -13,7 +13,7 @@
 #define PC_WAVE 64
 #define PC_SLICE_STRIDE 128
 enum { PC_DOM_LIVEGEN = 0, PC_DOM_SEED = 1, PC_DOM_NHAT = 2, PC_DOM_SHUFFLE = 3, PC_DOM_SLICE = 4,
-       PC_DOM_PHANTOM = 5, PC_DOM_POST = 6 };
+       PC_DOM_PHANTOM = 5, PC_DOM_POST = 6, PC_DOM_SEQ = 0xFFFF };
 enum { PC_LIKE_CALLBACK = 0, PC_LIKE_GAUSSIAN = 1, PC_LIKE_RASTRIGIN = 2, PC_LIKE_TWIN_GAUSSIAN = 3,
        PC_LIKE_CORR_GAUSSIAN = 4 };
 

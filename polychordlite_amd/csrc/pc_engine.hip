@@ -260,6 +260,7 @@ struct Engine {
         const int nprior = c.nprior <= 0 ? c.nlive : c.nprior;
         S.Ncap = std::max(nmax, nprior);
         B = c.batch > 0 ? c.batch : std::max(1, std::min(1024, c.nlive / 2));
+        if (c.sequential_rng) B = 1;
         if (c.batch <= 0 && (like.kind == PC_LIKE_CALLBACK || prior.kind != 1)) B = std::max(1, std::min(64, c.nlive / 4));
         S.B = B;
         S.maxc = c.do_clustering ? 128 : 4;
@@ -271,7 +272,8 @@ struct Engine {
         S.log_prec = S.use_prec ? std::log(c.precision_criterion) : 0.0;
         S.log_cf = std::log(c.compression_factor);
         S.max_ndead = c.max_ndead; S.nfail = c.nfail <= 0 ? c.nlive : c.nfail;
-        S.seed_override = 0; S.ablate = c.ablate;
+        S.seed_override = 0; S.ablate = c.ablate; S.seq_mode = c.sequential_rng ? 1 : 0;
+        if (S.seq_mode) { cfg.batch = 1; cfg.force_general = 1; }
         // dynamic nlive tables
         S.n_nlives = c.n_nlives;
         if (c.n_nlives > 0) {
@@ -723,7 +725,7 @@ struct Engine {
         double *rows = dalloc<double>((size_t)nprior * nT), *rl = dalloc<double>(nprior);
         std::vector<double> keep_rows; keep_rows.reserve((size_t)nprior * nT);
         std::vector<double> hrows((size_t)nprior * nT), hl(nprior);
-        int have = 0, attempt0 = 0;
+        int have = 0, attempt0 = 0, last_attempt = -1;
         long long nlike = 0;
         bool direct = true;
         while (have < nprior) {
@@ -732,11 +734,11 @@ struct Engine {
             HIPCHK(hipStreamSynchronize(st));
             int nvalid = 0;
             for (int i = 0; i < nprior; ++i) nvalid += hl[i] > cfg.logzero;
-            if (nvalid == nprior && have == 0) { have = nprior; nlike = nprior; break; }   // common case: all valid
+            if (nvalid == nprior && have == 0) { have = nprior; nlike = nprior; last_attempt = nprior - 1; break; }   // common case: all valid
             direct = false;
             HIPCHK(hipMemcpy(hrows.data(), rows, sizeof(double) * (size_t)nprior * nT, hipMemcpyDeviceToHost));
             for (int i = 0; i < nprior && have < nprior; ++i)
-                if (hl[i] > cfg.logzero) { keep_rows.insert(keep_rows.end(), hrows.begin() + (size_t)i * nT, hrows.begin() + (size_t)(i + 1) * nT); have++; nlike++; }
+                if (hl[i] > cfg.logzero) { keep_rows.insert(keep_rows.end(), hrows.begin() + (size_t)i * nT, hrows.begin() + (size_t)(i + 1) * nT); have++; nlike++; last_attempt = attempt0 + i; }
                 else ndiscarded++;
             attempt0 += nprior;
         }
@@ -745,6 +747,20 @@ struct Engine {
         h_ctl->nlike = nlike; h_ctl->nlike_device = nlike;
         HIPCHK(hipMemcpyAsync(&S.ctl->nlike, &h_ctl->nlike, sizeof(long long), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (S.seq_mode) {
+            // the reference draws and evaluates one more prior sample while it times the likelihood
+            // (time_speeds, generate.F90:388-393); the stream position after it is where the sampling starts
+            int a = last_attempt + 1;
+            for (;; ++a) {
+                double l1 = 0.0;
+                (void)pc_launch_generate_live(&S, a, 1, rows, rl, st);
+                HIPCHK(hipMemcpyAsync(&l1, rl, sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (l1 > cfg.logzero) break;
+            }
+            h_ctl->seq = (unsigned long long)(a + 1) * S.D;
+            HIPCHK(hipMemcpy(&S.ctl->seq, &h_ctl->seq, sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
         dfree(rows); dfree(rl);
         call_dumper(2);                // write_prior_file, nested_sampling.F90:197
         if (nprior > cfg.nlive) {      // nested_sampling.F90:201-205

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void k_generate_live(PcState S, int attempt0, d
         const double hi = (ld.on[k] && S.prior.hi) ? S.prior.hi[dim] : 1.0;
         ld.lo[k] = lo; ld.span[k] = hi - lo;
         ld.mean[k] = (ld.on[k] && S.like.mean) ? S.like.mean[dim] : 0.0;
-        cube[k] = ld.on[k] ? pc_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, (uint32_t)attempt, (uint32_t)dim) : 0.5;
+        cube[k] = !ld.on[k] ? 0.5 : (S.seq_mode ? pc_seq_uniform(S, (unsigned long long)attempt * D + dim)
+                                                 : pc_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, (uint32_t)attempt, (uint32_t)dim));
         th[k] = ld.lo[k] + ld.span[k] * cube[k];
     }
     const double logL = like_eval<DPL, 4>(S, th, ld, lane, ybuf);
@@ -151,7 +152,7 @@ __device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, in
     const int nc = S.ctl->ncluster;
     if (nc == 1) {       // one cluster: the volume-weighted draw (generate.F90:36-41) can only return it
         sel = 0;
-        const double u2s = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+        const double u2s = S.seq_mode ? pc_seq_uniform(S, S.ctl->seq + 1) : pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
         const int ns = S.cl_n[0];
         int is = (int)ceil(u2s * ns);
         is = is < 1 ? 1 : (is > ns ? ns : is);
@@ -166,11 +167,11 @@ __device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, in
     const double lse = m + log(sum);
     double norm = 0.0;
     for (int c = 0; c < nc; ++c) norm += exp(S.logXp[c] - lse);
-    const double u = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 0u);
+    const double u = S.seq_mode ? pc_seq_uniform(S, S.ctl->seq) : pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 0u);
     double cdf = 0.0;
     sel = nc - 1;
     for (int c = 0; c < nc; ++c) { cdf += exp(S.logXp[c] - lse) / norm; if (u < cdf) { sel = c; break; } }
-    const double u2 = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+    const double u2 = S.seq_mode ? pc_seq_uniform(S, S.ctl->seq + 1) : pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
     const int n = S.cl_n[sel];
     int idx = (int)ceil(u2 * n);
     idx = idx < 1 ? 1 : (idx > n ? n : idx);
@@ -205,10 +206,13 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
     ncyc[1] = clock64();
 #endif
     // gaussian deviates: index (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT
-    const uint32_t e0 = (uint32_t)basis * D * D, e1 = e0 + (uint32_t)D * D;
+    // (seq_mode: after the two seed draws, basis after basis: generate_nhats inside SliceSampling)
+    const uint32_t eoff = S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u;
+    const uint32_t e0 = eoff + (uint32_t)basis * D * D, e1 = e0 + (uint32_t)D * D;
     for (uint32_t call = (e0 >> 1) + tid; call <= ((e1 - 1) >> 1); call += NT) {
         double ua, ub;
-        pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+        if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
+        else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
         const uint32_t ia = 2 * call, ib = 2 * call + 1;
         if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
         if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #pragma unroll
     for (int e = 0; e < HV; ++e) v[e] = 0.0;
     if (active) {
-        const uint32_t e0 = ((uint32_t)basis * D + i) * D + d0;
+        const uint32_t e0 = (S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + ((uint32_t)basis * D + i) * D + d0;
         const int cnt = min(HV, D - d0);                              // coordinates of this block that exist
         if (cnt > 0) {
             const uint32_t c0 = e0 >> 1, c1 = (e0 + cnt - 1) >> 1;
@@ -414,7 +418,8 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
                 const uint32_t call = c0 + cc;
                 if (call <= c1) {
                     double ua, ub;
-                    pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+                    if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
+                    else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
                     const int ea = (int)(2 * call) - (int)e0, eb = ea + 1;     // -1 .. HV
                     const double ga = pc_inv_normal_cdf(ua), gb = pc_inv_normal_cdf(ub);
 #pragma unroll
@@ -702,12 +707,16 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
 
     // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
     //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
+    // seq_mode: stream positions of the shuffle draws (after the seed draws and every basis) and of the slice draws
+    const unsigned long long seq_g0 = S.seq_mode ? S.ctl->seq + 2ull + (unsigned long long)((nr + D - 1) / D) * D * D : 0ull;
+    unsigned long long seq_run = seq_g0 + (unsigned long long)(nr - 1);
     int deck = lane;
     const bool deck_in_regs = nr <= 64;
     if (deck_in_regs) {
         int jv = 0;
         if (lane >= 1 && lane < nr) {
-            const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
+            const double u = S.seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - lane))
+                                        : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
             int j = (int)ceil(u * lane);
             jv = j < 1 ? 1 : (j > lane ? lane : j);
         }
@@ -720,7 +729,8 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
         for (int i = lane; i < nr; i += 64) {
             sdeck[i] = i;
             if (i >= 1) {
-                const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
+                const double u = S.seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - i))
+                                            : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
                 int j = (int)ceil(u * i);
                 sj[i] = j < 1 ? 1 : (j > i ? i : j);
             }
@@ -766,13 +776,14 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[64 * k] : 0.0;
             w_next = nw_base[v1];
         }
-        if ((s & 3) == 0) {                         // one Philox call per lane covers 4 slices x 32 uniforms
+        if ((s & 3) == 0 && !S.seq_mode) {          // one Philox call per lane covers 4 slices x 32 uniforms
             const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
             pc_uniform2(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain,
                         (sl * PC_SLICE_STRIDE) / 2 + (uint32_t)(lane & 15), ua, ub);
         }
         uint32_t kdraw = 0;
         auto next_u = [&]() -> double {
+            if (S.seq_mode) return pc_seq_uniform(S, seq_run++);
             const uint32_t k = kdraw++;
             if (k < 32u) {
                 const int src = ((s & 3) << 4) + (int)(k >> 1);
@@ -898,6 +909,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; S.ctl->dbg[6] += scy[5]; S.ctl->dbg[7] += ev2; }
 #endif
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
+    if (S.seq_mode && lane == 0 && chain == 0) S.ctl->seq = seq_run;
     // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
     // one sqrt / log per chain instead of one per slice on the chain's critical path
     if (S.nDer > 0 && phi_lds) {

@@ -33,6 +33,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     double logZ, logZ2;          // run_time_info.f90:165-166 (log <Z>, log <Z^2>)
     double logX_last_update;
     double live_logZ;            // last evaluated termination estimate
+    unsigned long long seq;      // seq_mode: uniforms consumed so far
     long long dbg[8];            // developer cycle counters of the contraction kernel
 };
 
@@ -99,6 +100,14 @@ struct PcState {
     unsigned long long *sort_key; // [NS] sortable logL keys (pc_keys.h) in the same order
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
     int ablate;                  // dev timing hook (bit mask), 0 in production
+    int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
+                                 // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     PcCtl *ctl;
 };
+
+// uniform number n of the single sequential stream (tests: the order the reference program consumes its generator)
+__device__ __forceinline__ double pc_seq_uniform(const PcState &S, unsigned long long n)
+{
+    return pc_uniform(S.k0, S.k1, PC_DOM_SEQ, (uint32_t)(n >> 32), 0u, (uint32_t)n);
+}

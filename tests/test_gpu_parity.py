@@ -243,3 +243,34 @@ def test_termination_triggers_match_oracle(engine, kw):
     for k in ("ndead", "nlike", "niter"):
         assert g[k] == o[k], (k, g[k], o[k], kw)
     assert abs(g["logZ"] - o["logZ"]) < 1e-8
+
+
+def test_engine_reproduces_the_reference_binary(engine, golden):
+    """The closing link: with ONE Philox stream consumed in the reference's program order (sequential_rng: batch 1,
+    reference list rule) the HIP engine walks the same trajectory as the REFERENCE BINARY whose `random_number` was fed
+    that stream (tests/golden/ref_injected.json, made by oracle/gen_golden.py with oracle/ref_rng_shim.c): identical
+    ndead and nlike, logZ to round-off -- Gaussian, Rastrigin and twin Gaussian, with and without clustering,
+    dynamic nlive, nprior > nlive."""
+    api = engine
+    done = 0
+    for c in golden["ref_injected"]:
+        if c["nlike"] > 1300000:
+            continue
+        lo, hi = BOX[c["like"]]
+        kw = dict(nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"], do_clustering=c["clustering"],
+                  nprior=c.get("nprior", -1), sequential_rng=1)
+        s = _settings(api, c["nDims"], c["nDerived"], **kw)
+        keep_arrays = None
+        if "nlives" in c:
+            pairs = [p.split(":") for p in c["nlives"].split(",")]
+            ll = np.array([float(a) for a, _ in pairs]); nl = np.array([int(b) for _, b in pairs], dtype=np.int32)
+            s.n_nlives = len(pairs)
+            s.loglikes = ll.ctypes.data_as(C.POINTER(C.c_double)); s.nlives = nl.ctypes.data_as(C.POINTER(C.c_int))
+            keep_arrays = (ll, nl)
+        L, P, keep = api.make_problem(c["like"], c["nDims"], c["nDerived"], lo, hi)
+        g = api.run(s, L, P)
+        assert g["ndead"] == c["ndead"], (c, g["ndead"])
+        assert g["nlike"] == c["nlike"], (c, g["nlike"])
+        assert abs(g["logZ"] - c["logZ"]) < 1e-8 and abs(g["logZerr"] - c["logZerr"]) < 1e-8, (c, g["logZ"], g["logZerr"])
+        done += 1
+    assert done >= 8
