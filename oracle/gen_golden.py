@@ -48,6 +48,9 @@ def main():
         ("gaussian", 20, 2, 200, 40, 3, 1),
         ("rastrigin", 2, 0, 1000, 6, 7, 1), ("rastrigin", 2, 0, 300, 6, 2, 1), ("rastrigin", 4, 0, 200, 12, 5, 1),
         ("twin_gaussian", 10, 1, 200, 20, 3, 1), ("twin_gaussian", 6, 1, 150, 12, 4, 1),
+        # other kernel variants of the engine: nDims > 32, num_repeats > 64, small clustered problems
+        ("gaussian", 33, 0, 60, 40, 5, 0), ("gaussian", 6, 2, 80, 70, 6, 0), ("rastrigin", 3, 0, 150, 9, 8, 1),
+        ("twin_gaussian", 4, 1, 120, 8, 9, 1),
     ]
     injected = []
     for c in cases:
