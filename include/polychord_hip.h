@@ -159,6 +159,8 @@ typedef struct {
     int nsplit;                                /* children created by splits so far */
     const unsigned *split_child, *split_parent;
     const double *split_logfrac;               /* log(evidence of child / evidence of parent) at the split */
+    /* boost_posterior: phantom points kept as posterior samples (run_time_info.f90:845-870), same row layout */
+    int n_extra; const double *extra, *extra_logpost; const unsigned *extra_cluster;
 } pchip_update;
 typedef void (*pchip_update_fn)(void *user, const pchip_update *u);
 

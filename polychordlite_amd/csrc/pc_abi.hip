@@ -146,18 +146,21 @@ struct FileSink {
     void posterior_files(const pchip_update &u)
     {
         const int np = nDims + nDer, npars = u.npars;
+        const long ntot = u.ndead + u.n_extra;                 // dead points, then phantoms kept by boost_posterior
+        auto lp = [&](long i) { return i < u.ndead ? u.logpost[i] : u.extra_logpost[i - u.ndead]; };
+        auto rowp = [&](long i) { return i < u.ndead ? u.dead + (size_t)i * npars : u.extra + (size_t)(i - u.ndead) * npars; };
         double mx = -1.7e308;
-        for (long i = 0; i < u.ndead; ++i) if (u.logpost[i] > -1e29) mx = std::max(mx, u.logpost[i]);
+        for (long i = 0; i < ntot; ++i) if (lp(i) > -1e29) mx = std::max(mx, lp(i));
         FILE *fp = posteriors ? open(path(".txt"), "w") : nullptr;
         FILE *fe = equals ? open(path("_equal_weights.txt"), "w") : nullptr;
         mu.assign(np, 0.0); sig.assign(np, 0.0);
         double sw = 0.0;
         nposterior = 0; nequals = 0;
         std::string tail;
-        for (long i = 0; i < u.ndead; ++i) {
-            if (!(u.logpost[i] > -1e29)) continue;        // failed spawns carry no weight
-            const double *row = u.dead + (size_t)i * npars;
-            const double wgt = std::exp(u.logpost[i] - mx);
+        for (long i = 0; i < ntot; ++i) {
+            if (!(lp(i) > -1e29)) continue;               // failed spawns carry no weight
+            const double *row = rowp(i);
+            const double wgt = std::exp(lp(i) - mx);
             sw += wgt;
             for (int k = 0; k < np; ++k) { mu[k] += wgt * row[k]; sig[k] += wgt * row[k] * row[k]; }
             if (!fp && !fe) continue;
@@ -183,8 +186,11 @@ struct FileSink {
         std::vector<int> order(K);
         for (int k = 0; k < K; ++k) order[k] = k;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lz[a] > lz[b]; });
+        const long ntot = u.ndead + u.n_extra;
+        auto lp = [&](long i) { return i < u.ndead ? u.logpost[i] : u.extra_logpost[i - u.ndead]; };
+        auto rowp = [&](long i) { return i < u.ndead ? u.dead + (size_t)i * u.npars : u.extra + (size_t)(i - u.ndead) * u.npars; };
         std::map<unsigned, std::vector<long>> pts;
-        for (long i = 0; i < u.ndead; ++i) if (u.logpost[i] > -1e29) pts[u.dead_cluster[i]].push_back(i);
+        for (long i = 0; i < ntot; ++i) if (lp(i) > -1e29) pts[i < u.ndead ? u.dead_cluster[i] : u.extra_cluster[i - u.ndead]].push_back(i);
         std::map<unsigned, std::pair<unsigned, double>> parent;
         for (int j = 0; j < u.nsplit; ++j) parent[u.split_child[j]] = {u.split_parent[j], u.split_logfrac[j]};
         std::string tail;
@@ -195,7 +201,7 @@ struct FileSink {
             chain.push_back({cur, 0.0});
             for (auto it = parent.find(cur); it != parent.end(); it = parent.find(cur)) { cum += it->second.second; cur = it->second.first; chain.push_back({cur, cum}); }
             double mx = -1.7e308;
-            for (auto &c : chain) for (long i : pts[c.first]) mx = std::max(mx, u.logpost[i] + c.second);
+            for (auto &c : chain) for (long i : pts[c.first]) mx = std::max(mx, lp(i) + c.second);
             char num[32]; std::snprintf(num, sizeof num, "%d", r + 1);
             const std::string stem = base + "/clusters/" + root + "_" + num;
             FILE *fp = posteriors ? std::fopen((stem + ".txt").c_str(), "w") : nullptr;
@@ -204,8 +210,8 @@ struct FileSink {
             const double frac = std::exp(lz[k] - u.logZ);
             for (auto c = chain.rbegin(); c != chain.rend(); ++c)      // ancestors first, as the copies were made
                 for (long i : pts[c->first]) {
-                    const double *row = u.dead + (size_t)i * u.npars;
-                    const double rel = std::exp(u.logpost[i] + c->second - mx);
+                    const double *row = rowp(i);
+                    const double rel = std::exp(lp(i) + c->second - mx);
                     if (!(rel > 0.0)) continue;
                     tail = fmt_e24(-2 * row[np + 1]);
                     for (int q = 0; q < np; ++q) tail += fmt_e24(row[q]);
@@ -397,8 +403,6 @@ void polychord_c_interface(
     sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
     sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.cluster_posteriors = cluster_posteriors; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
     sink.compression = compression_factor; sink.num_repeats = num_repeats;
-    if ((posteriors || equals) && boost_posterior != 0.0 && feedback >= 1)
-        std::fprintf(stderr, "polychord_hip: boost_posterior > 0 (posterior samples from phantom points) is not built; using dead points only\n");
     const bool files = write_stats_f || write_dead || write_live || posteriors || equals || write_prior;
     pchip_result r;
     pchip_hooks hooks{dumper, files ? FileSink::hook : nullptr, &sink};

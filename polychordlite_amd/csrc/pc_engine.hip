@@ -56,6 +56,7 @@ int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int 
     std::abort(); } } while (0)
 
 static volatile int g_stop_requested = 0;
+extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
 
 namespace {
 
@@ -210,6 +211,8 @@ struct Engine {
     bool nph_stale = false;                     // h_ctl->nphantom is the count before the last clean (an upper bound)
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<unsigned> hm_cuid;              // cluster uid every dead point died in
+    // boost_posterior: phantoms removed by a clean that were kept as posterior samples (run_time_info.f90:857-870)
+    std::vector<double> pp_rows, pp_logpost; std::vector<unsigned> pp_cuid; int nd_last_update = 0;
     // cluster genealogy: child uid, parent uid, log of the evidence fraction the child received (add_cluster)
     std::vector<unsigned> split_child, split_parent; std::vector<double> split_logfrac;
     std::vector<double> h_lo, h_hi;
@@ -448,11 +451,55 @@ struct Engine {
             u.dead_cluster = nd > 0 ? hm_cuid.data() : &dummy_u; u.cluster_uid = ua.data(); u.cluster_uid_dead = ud.data();
             u.nsplit = (int)split_child.size(); u.split_child = split_child.data(); u.split_parent = split_parent.data();
             u.split_logfrac = split_logfrac.data();
+            u.n_extra = (int)pp_logpost.size(); u.extra = pp_rows.data(); u.extra_logpost = pp_logpost.data(); u.extra_cluster = pp_cuid.data();
             on_update(hook_user, &u);
         }
     }
 
     // clean_phantoms + calculate_covmats (nested_sampling.F90:326-368 minus file output / clustering)
+    // clean_phantoms also feeds the posterior (run_time_info.f90:845-870): a phantom that falls below the contour is
+    // kept with probability thin_posterior = boost_posterior / num_repeats (generate.F90:311-316) and carries the
+    // weight of the first point of its cluster that died since the last update with a larger logL.  Host side: the
+    // feature is off by default and touches each phantom once per update.
+    void collect_phantom_posteriors(int nph)
+    {
+        const double thin = cfg.boost_posterior < 0.0 ? 1.0 : cfg.boost_posterior / (double)S.nr;
+        const int nd0 = nd_last_update, nd = h_ctl->ndead, nT = S.nT, np = S.D + S.nDer;
+        nd_last_update = nd;
+        if (!(thin > 0.0) || nph <= 0 || nd <= nd0) return;
+        HIPCHK(hipStreamSynchronize(st));
+        auto kp = dl(keep, nph); auto phL = dl(S.ph_logL, nph); auto phC = dl(S.ph_cuid, nph); auto phU = dl(S.ph_uid, nph);
+        const int m = nd - nd0;
+        std::vector<double> dL(m), dW = dl(S.dead_logw + nd0, m); auto dC = dl(S.dead_cuid + nd0, m);
+        HIPCHK(hipMemcpy2D(dL.data(), sizeof(double), S.dead + (size_t)nd0 * nT + S.l0, sizeof(double) * nT, sizeof(double), m, hipMemcpyDeviceToHost));
+        std::map<unsigned, std::vector<std::pair<double, double>>> stack;      // per cluster: (logL, logweight), death order
+        for (int i = 0; i < m; ++i) if (dW[i] > cfg.logzero) stack[dC[i]].push_back({dL[i], dW[i]});
+        std::vector<int> pick; std::vector<double> pickw;
+        for (int j = 0; j < nph; ++j) {
+            if (kp[j]) continue;
+            const unsigned long long uid = phU[j];
+            if (!(polychord_hip_keyed_uniform((unsigned)cfg.seed, PC_DOM_PHANTOM, (unsigned)(uid >> 32), (unsigned)uid, 0u) < thin)) continue;
+            auto it = stack.find(phC[j]);
+            if (it == stack.end()) continue;
+            const auto &v = it->second;
+            // deaths of one cluster arrive in ascending logL: first entry above the phantom
+            size_t lo = 0, hi = v.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (v[mid].first > phL[j]) hi = mid; else lo = mid + 1; }
+            if (lo == v.size()) continue;
+            pick.push_back(j); pickw.push_back(v[lo].second);
+        }
+        if (pick.empty()) return;
+        std::vector<double> row(nT);
+        for (size_t k = 0; k < pick.size(); ++k) {
+            HIPCHK(hipMemcpy(row.data(), S.phantom + (size_t)pick[k] * nT, sizeof(double) * nT, hipMemcpyDeviceToHost));
+            const size_t o = pp_rows.size();
+            pp_rows.resize(o + np + 2);
+            std::memcpy(pp_rows.data() + o, row.data() + S.p0, sizeof(double) * np);
+            pp_rows[o + np] = row[S.b0]; pp_rows[o + np + 1] = row[S.l0];
+            pp_logpost.push_back(pickw[k] + row[S.l0]); pp_cuid.push_back(phC[pick[k]]);
+        }
+    }
+
     void do_update()
     {
         tm.updates++;
@@ -461,10 +508,11 @@ struct Engine {
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
+        if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals)) collect_phantom_posteriors(nph);
         // The surviving count is written to the control block on the device.  Without clustering / resume files
         // nothing on the host needs it before the next round's read-back, so the update costs no extra sync: the
         // covariance grid is sized with the pre-clean count and the kernels clamp to the device value.
-        const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update;
+        const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update || cfg.boost_posterior != 0.0;
         int total = nph;
         if (need_count) {
             HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -987,6 +1035,11 @@ struct Engine {
             (void)pc_launch_final_par(&S, st);
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
+        if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals) && h_ctl->nphantom > 0) {
+            // the last update_posteriors (nested_sampling.F90:386-390): every remaining phantom is below the last death
+            pc_launch_clean(&S, h_ctl->nphantom, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
+            collect_phantom_posteriors(h_ctl->nphantom);
+        }
         call_dumper(1);
         write_resume();
         auto t3 = clk::now();

@@ -366,3 +366,28 @@ def test_cluster_posterior_files(engine, tmp_path):
         assert eq.exists()
     assert abs(ftot - 1.0) < 0.1
     assert np.all(np.abs(mix / ftot - gmean) < 0.15)
+
+
+@pytest.mark.gpu
+def test_boost_posterior(engine, tmp_path):
+    """boost_posterior (run_time_info.f90:845-870): phantoms that fall below the contour are kept as posterior samples
+    with probability boost/num_repeats and the weight of the death that overtook them: more samples, same posterior."""
+    from polychordlite_amd import pypolychord as pc
+    from polychordlite_amd.pypolychord.device_likelihoods import Gaussian
+    out = {}
+    for boost in (0.0, 4.0):
+        base = tmp_path / ("b%d" % int(boost))
+        pc.run(Gaussian(mu=0.5, sigma=0.1), 4, base_dir=str(base), file_root="g", nDerived=1, nlive=200, num_repeats=8,
+               do_clustering=False, feedback=0, seed=11, boost_posterior=boost, posteriors=True, equals=True,
+               write_resume=False, read_resume=False, write_live=False, write_prior=False)
+        post = np.loadtxt(base / "g.txt")
+        w = post[:, 0]
+        mean = (w[:, None] * post[:, 2:6]).sum(0) / w.sum()
+        sd = np.sqrt((w[:, None] * (post[:, 2:6] - mean) ** 2).sum(0) / w.sum())
+        ess = w.sum() ** 2 / (w ** 2).sum()
+        out[boost] = (post.shape[0], mean, sd, ess)
+        assert abs(w.max() - 1.0) < 1e-12
+        assert np.all(np.abs(mean - 0.5) < 0.03) and np.all(np.abs(sd - 0.1) < 0.03), (boost, mean, sd)
+    n0, n4 = out[0.0][0], out[4.0][0]
+    assert n4 > 2.0 * n0                      # ~ (1 + boost) times the dead points
+    assert out[4.0][3] > 1.5 * out[0.0][3]    # and the effective sample size grows with it
