@@ -34,8 +34,40 @@ def last_json(out):
     return json.loads(lines[-1])
 
 
+GRADE_CASES = [  # like nDims nDerived nlive seed clustering grade_dims grade_repeats
+    ("gaussian", 4, 1, 100, 2, 0, [2, 2], [8, 4]), ("gaussian", 20, 2, 100, 3, 0, [8, 12], [20, 24]),
+    ("gaussian", 6, 0, 80, 5, 0, [2, 2, 2], [6, 4, 5]), ("rastrigin", 4, 0, 200, 6, 1, [1, 3], [4, 9]),
+    ("twin_gaussian", 6, 1, 150, 7, 1, [3, 3], [6, 7]), ("gaussian", 33, 0, 60, 8, 0, [30, 3], [33, 8]),
+]
+
+
+def grade_cases(inj):
+    """fast/slow parameter grades with explicit repeats per grade (every grade_frac > 1: generate.F90:303-309);
+    REF_GRADES of ref_driver.  nlike_grades = RTI%nlike per grade as printed in .stats"""
+    out = []
+    for like, D, nDer, nlive, seed, clus, dims, reps in GRADE_CASES:
+        env = "REF_GRADES='" + ",".join(map(str, dims)) + ";" + ",".join(map(str, reps)) + "' "
+        j = last_json(sh(f"{env}{inj} {like} {D} {nDer} {nlive} {sum(reps)} {seed} {clus} {TMP}/chains inj 0"))
+        j.update(nDerived=nDer, clustering=clus, grade_dims=dims, grade_repeats=reps,
+                 nlike_grades=[int(x) for x in j["nlike_grades"].split()])
+        j.pop("wall", None)
+        out.append(j)
+        print("injected", j)
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "grades":     # refresh only the grade cases of ref_injected.json
+        os.makedirs(TMP + "/chains/clusters", exist_ok=True)
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        path = os.path.join(GOLD, "ref_injected.json")
+        injected = [c for c in json.load(open(path)) if "grade_dims" not in c]
+        for c in injected:
+            c.pop("nlike_grades", None)
+        injected += grade_cases(os.path.join(HERE, "_ref", "ref_driver_inject"))
+        json.dump(injected, open(path, "w"), indent=1)
+        return
     os.makedirs(TMP, exist_ok=True)
     subprocess.check_call(["make", "-C", HERE, "ref", "_ref/ref_units"])
     units = json.loads(subprocess.check_output([os.path.join(HERE, "_ref", "ref_units")], text=True))
@@ -56,7 +88,7 @@ def main():
     for c in cases:
         j = last_json(sh(f"{inj} {c[0]} {c[1]} {c[2]} {c[3]} {c[4]} {c[5]} {c[6]} {TMP}/chains inj 0"))
         j.update(nDerived=c[2], clustering=c[6])
-        j.pop("wall", None)
+        j.pop("wall", None); j.pop("nlike_grades", None)
         injected.append(j)
         print("injected", j)
     # dynamic nlive + nprior > nlive (environment of ref_driver: REF_NPRIOR, REF_NLIVES)
@@ -64,9 +96,10 @@ def main():
         env = f"REF_NLIVES={nlv} " + (f"REF_NPRIOR={nprior} " if nprior > 0 else "")
         j = last_json(sh(f"{env}{inj} {c[0]} {c[1]} {c[2]} {c[3]} {c[4]} {c[5]} {c[6]} {TMP}/chains inj 0"))
         j.update(nDerived=c[2], clustering=c[6], nprior=nprior, nlives=nlv)
-        j.pop("wall", None)
+        j.pop("wall", None); j.pop("nlike_grades", None)
         injected.append(j)
         print("injected", j)
+    injected += grade_cases(inj)
     json.dump(injected, open(os.path.join(GOLD, "ref_injected.json"), "w"), indent=1)
 
     native = []

@@ -409,6 +409,9 @@ typedef struct {
 
 typedef struct {
     const pc_settings *s; const pc_like *like; const pc_prior *prior; pc_rng rng;
+    pc_settings s_local;                     /* settings with num_repeats = total over the grades */
+    int ngrade, g_off[8], g_nr[8];           /* grades: first parameter and repeats of each (chordal_sampling.f90:119-130) */
+    long nlike_g[8];
     int D, nDer, nTotal, npost, np;
     int h0, p0, d0, b0, l0;                 /* 0-based offsets (settings.f90:163-182) */
     int pos_X, pos_l, pos_w, pos_Z, pos_p0; /* posterior layout (settings.f90:186-203) */
@@ -909,40 +912,46 @@ static void calculate_point(rti_t *R, double *pt, long *nlike)
 }
 
 /* ---- directions ------------------------------------------------------------ */
-static void generate_nhats(rti_t *R, uint32_t batch, uint32_t chain, double *nh /* [nr][D] */)
+static void generate_nhats(rti_t *R, uint32_t batch, uint32_t chain, double *nh /* [nr][D] */, int *speeds /* [nr] grade of each */)
 {   /* chordal_sampling.f90:94-145 (single grade) + random_utils.F90:381-437, 276-298, 505-532 */
     int D = R->D, nr = R->s->num_repeats;
-    int nbases = (nr + D - 1) / D;
     double *basis = (double *)malloc(sizeof(double) * (size_t)D * D);
-    double *raw = (double *)malloc(sizeof(double) * (size_t)nr * D);
-    for (int b = 0; b < nbases; ++b) {
-        for (int i = 0; i < D; ++i) {
-            double *v = basis + (size_t)i * D, n2 = 0.0;
-            do {    /* random_direction: gaussian deviates by inverse CDF, retry while |v|=0 */
-                n2 = 0.0;
-                for (int d = 0; d < D; ++d) {
-                    v[d] = pc_inv_normal_cdf(pc_rng_u(&R->rng, PC_DOM_NHAT, batch, chain,
-                                                      (uint32_t)(((size_t)b * D + i) * D + d)));
-                    n2 += v[d] * v[d];
+    double *raw = (double *)calloc((size_t)nr * D, sizeof(double));
+    uint32_t e = 0;                 /* running index inside the (batch, chain) stream of PC_DOM_NHAT */
+    int col0 = 0;
+    for (int g = 0; g < R->ngrade; ++g) {
+        /* grade g moves the parameters from its first one to the last: an orthonormal basis of that subspace */
+        const int off = R->g_off[g], Dg = D - off, nrg = R->g_nr[g];
+        const int nbases = (nrg + Dg - 1) / Dg;
+        for (int b = 0; b < nbases; ++b) {
+            for (int i = 0; i < Dg; ++i) {
+                double *v = basis + (size_t)i * Dg, n2 = 0.0;
+                do {    /* random_direction: gaussian deviates by inverse CDF, retry while |v|=0 */
+                    n2 = 0.0;
+                    for (int d = 0; d < Dg; ++d) {
+                        v[d] = pc_inv_normal_cdf(pc_rng_u(&R->rng, PC_DOM_NHAT, batch, chain, e++));
+                        n2 += v[d] * v[d];
+                    }
+                } while (n2 <= 0.0);
+                double nrm = sqrt(n2);
+                for (int d = 0; d < Dg; ++d) v[d] = v[d] / nrm;
+                for (int j = 0; j < i; ++j) {   /* Gram-Schmidt against the finished vectors, in order */
+                    const double *q = basis + (size_t)j * Dg;
+                    double dot = 0.0;
+                    for (int d = 0; d < Dg; ++d) dot += v[d] * q[d];
+                    for (int d = 0; d < Dg; ++d) v[d] = v[d] - dot * q[d];
                 }
-            } while (n2 <= 0.0);
-            double nrm = sqrt(n2);
-            for (int d = 0; d < D; ++d) v[d] = v[d] / nrm;
-            for (int j = 0; j < i; ++j) {   /* Gram-Schmidt against the finished vectors, in order */
-                const double *q = basis + (size_t)j * D;
-                double dot = 0.0;
-                for (int d = 0; d < D; ++d) dot += v[d] * q[d];
-                for (int d = 0; d < D; ++d) v[d] = v[d] - dot * q[d];
+                n2 = 0.0;
+                for (int d = 0; d < Dg; ++d) n2 += v[d] * v[d];
+                nrm = sqrt(n2);
+                for (int d = 0; d < Dg; ++d) v[d] = v[d] / nrm;
             }
-            n2 = 0.0;
-            for (int d = 0; d < D; ++d) n2 += v[d] * v[d];
-            nrm = sqrt(n2);
-            for (int d = 0; d < D; ++d) v[d] = v[d] / nrm;
+            for (int i = 0; i < Dg; ++i) {
+                int col = b * Dg + i;
+                if (col < nrg) memcpy(raw + (size_t)(col0 + col) * D + off, basis + (size_t)i * Dg, sizeof(double) * Dg);
+            }
         }
-        for (int i = 0; i < D; ++i) {
-            int col = b * D + i;
-            if (col < nr) memcpy(raw + (size_t)col * D, basis + (size_t)i * D, sizeof(double) * D);
-        }
+        col0 += nrg;
     }
     /* deck = 1..nr, first stays, the rest Fisher-Yates shuffled from the top */
     int *deck = (int *)malloc(sizeof(int) * nr);
@@ -955,7 +964,10 @@ static void generate_nhats(rti_t *R, uint32_t batch, uint32_t chain, double *nh 
         if (j > i) j = i;
         int t = deck[i]; deck[i] = deck[j]; deck[j] = t;   /* deck(2:)(i) <-> deck(2:)(j) */
     }
-    for (int i = 0; i < nr; ++i) memcpy(nh + (size_t)i * D, raw + (size_t)deck[i] * D, sizeof(double) * D);
+    for (int i = 0; i < nr; ++i) {
+        memcpy(nh + (size_t)i * D, raw + (size_t)deck[i] * D, sizeof(double) * D);
+        if (speeds) { int g = 0, c = R->g_nr[0]; while (deck[i] >= c) c += R->g_nr[++g]; speeds[i] = g; }
+    }
     free(basis); free(raw); free(deck);
 }
 
@@ -1007,7 +1019,7 @@ static void slice_sample(rti_t *R, uint32_t batch, uint32_t chain, int islice, d
 }
 
 static long slice_sampling(rti_t *R, uint32_t batch, uint32_t chain, const double *seed_point,
-                           const double *chol, double logLb, double *babies, double *nhats_out)
+                           const double *chol, double logLb, double *babies, double *nhats_out, long *nlike_g)
 {   /* chordal_sampling.f90:7-92 */
     int D = R->D, nr = R->s->num_repeats, nT = R->nTotal;
     long nlike = 0;
@@ -1015,8 +1027,10 @@ static long slice_sampling(rti_t *R, uint32_t batch, uint32_t chain, const doubl
     double *v = (double *)malloc(sizeof(double) * D);
     double *prev = (double *)malloc(sizeof(double) * nT);
     memcpy(prev, seed_point, sizeof(double) * nT);
-    generate_nhats(R, batch, chain, nh);
+    int *speeds = (int *)malloc(sizeof(int) * nr);
+    generate_nhats(R, batch, chain, nh, speeds);
     for (int i = 0; i < nr; ++i) {
+        const long nl0 = nlike;
         /* nhat = L . nhat_i  (matmul(cholesky,nhats), chordal_sampling.f90:73) */
         for (int a = 0; a < D; ++a) {
             double t = 0.0;
@@ -1031,7 +1045,9 @@ static long slice_sampling(rti_t *R, uint32_t batch, uint32_t chain, const doubl
         w = w * 3.0;
         slice_sample(R, batch, chain, i, logLb, v, prev, w, &nlike, babies + (size_t)i * nT);
         memcpy(prev, babies + (size_t)i * nT, sizeof(double) * nT);
+        if (nlike_g) nlike_g[speeds[i]] += nlike - nl0;     /* chordal_sampling.f90:84 */
     }
+    free(speeds);
     for (int i = 0; i < nr; ++i) babies[(size_t)i * nT + R->b0] = logLb;   /* nested_sampling.F90:260 */
     free(nh); free(v); free(prev);
     return nlike;
@@ -1040,7 +1056,16 @@ static long slice_sampling(rti_t *R, uint32_t batch, uint32_t chain, const doubl
 static void rti_setup(rti_t *R, const pc_settings *s, const pc_like *like, const pc_prior *prior)
 {
     memset(R, 0, sizeof(*R));
-    R->s = s; R->like = like; R->prior = prior;
+    R->s_local = *s; R->s = &R->s_local; R->like = like; R->prior = prior;
+    /* grades (generate.F90:303-309, deterministic branch: repeats = int(grade_frac)) */
+    R->ngrade = 1; R->g_off[0] = 0; R->g_nr[0] = s->num_repeats;
+    if (s->nGrade > 1) {
+        R->ngrade = s->nGrade > 8 ? 8 : s->nGrade;
+        int off = 0, tot = 0;
+        for (int g = 0; g < R->ngrade; ++g) { R->g_off[g] = off; off += s->grade_dims[g]; R->g_nr[g] = (int)s->grade_frac[g]; tot += R->g_nr[g]; }
+        R->s_local.num_repeats = tot;
+    }
+    s = R->s;
     R->D = s->nDims; R->nDer = s->nDerived;
     R->h0 = 0; R->p0 = R->D; R->d0 = 2 * R->D; R->b0 = 2 * R->D + R->nDer; R->l0 = R->b0 + 1;
     R->nTotal = R->l0 + 1;
@@ -1066,7 +1091,7 @@ long pc_slice_chain(const pc_settings *s, const pc_like *like, const pc_prior *p
     rti_t R;
     rti_setup(&R, s, like, prior);
     R.rng = *rng;
-    long n = slice_sampling(&R, batch, chain, seed_point, chol, logL, babies, nhats_out);
+    long n = slice_sampling(&R, batch, chain, seed_point, chol, logL, babies, nhats_out, NULL);
     *rng = R.rng;
     cluster_free(&R.cl[0]); free(R.cl); free(R.XpXq);
     return n;
@@ -1104,6 +1129,7 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
 {
     rti_t Rs, *R = &Rs;
     rti_setup(R, s, like, prior);
+    s = R->s;                                   /* num_repeats is the total over the grades from here on */
     int D = R->D, nT = R->nTotal, nr = s->num_repeats;
     int B = s->batch > 1 ? s->batch : 1;
     memset(out, 0, sizeof(*out));
@@ -1138,7 +1164,7 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
     double *nursery = (double *)malloc(sizeof(double) * (size_t)B * nr * nT);
     uint64_t *uids = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)B * nr);
     int *wcluster = (int *)malloc(sizeof(int) * B), *wepoch = (int *)malloc(sizeof(int) * B);
-    long *wnlike = (long *)malloc(sizeof(long) * B);
+    long *wnlike = (long *)malloc(sizeof(long) * B), *wnlike_g = (long *)calloc((size_t)B * 8, sizeof(long));
     int i_nursery = 0, admin_epoch = 0;
     uint32_t batch = 0;
     long niter = 0;
@@ -1152,14 +1178,16 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
             for (int w = 0; w < B; ++w) {
                 if (!(R->rng.sequential && B == 1)) generate_seed(R, batch, (uint32_t)w, &cluster_id, &seedpt);
                 wcluster[w] = cluster_id; wepoch[w] = admin_epoch;
+                for (int g = 0; g < 8; ++g) wnlike_g[(size_t)w * 8 + g] = 0;
                 wnlike[w] = slice_sampling(R, batch, (uint32_t)w, seedpt, R->cl[cluster_id].chol,
-                                           R->cl[cluster_id].logLp, nursery + (size_t)w * nr * nT, NULL);
+                                           R->cl[cluster_id].logLp, nursery + (size_t)w * nr * nT, NULL, wnlike_g + (size_t)w * 8);
                 for (int i = 0; i < nr; ++i) uids[(size_t)w * nr + i] = ((uint64_t)batch << 32) | (uint32_t)(w * nr + i);
             }
             i_nursery = B; batch++; out->nbatches++;
         }
         int w = i_nursery - 1; i_nursery--;
         R->nlike += wnlike[w];
+        for (int g = 0; g < 8; ++g) R->nlike_g[g] += wnlike_g[(size_t)w * 8 + g];
         niter++;
         if (wepoch[w] == admin_epoch) {
             if (replace_point(R, nursery + (size_t)w * nr * nT, uids + (size_t)w * nr, nr, wcluster[w])) failures = 0;
@@ -1194,6 +1222,9 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
     if (out->logZ < -HUGE_D) out->logZ = -HUGE_D;
     out->varlogZ = R->logZ2 - 2 * R->logZ;
     out->ndead = R->dead.n; out->nlike = R->nlike; out->ncluster = ncluster_at_end;
+    for (int g = 0; g < 8; ++g) out->nlike_grade[g] = R->nlike_g[g];
+    if (R->ngrade == 1) out->nlike_grade[0] = R->nlike;       /* the prior samples belong to grade 1 (generate.F90:294) */
+    else out->nlike_grade[0] += nprior;
     out->ncluster_dead = R->ncluster_dead; out->niter = niter; out->nTotal = nT;
     out->dead = R->dead.a; out->logweights = R->logweights;
     out->nZp = R->ncluster_dead;

@@ -101,6 +101,10 @@ typedef struct {
     int batch;          /* B: chains per synchronous nursery (reference nprocs-1); <=1 => linear mode */
     int sequential_rng; /* 1: one running stream consumed in the reference's program order */
     int time_speeds_draw; /* 1: mimic generate.F90:388-393 extra prior draw (sequential pinning) */
+    /* fast/slow parameter grades (chordal_sampling.f90:94-145): nGrade <= 1 means one grade of nDims parameters.
+     * Only the deterministic branch of generate.F90:303-309 is restated: every grade_frac > 1 is the number of
+     * repeats of that grade (the other branch times the likelihood with the wall clock). */
+    int nGrade; const int *grade_dims; const double *grade_frac;
 } pc_settings;
 
 typedef struct {
@@ -119,6 +123,7 @@ typedef struct {
     /* weighted posterior mean of theta (from dead points + logweights) */
     double *post_mean; double *post_var;
     long nposterior_global, nequals_global;
+    long nlike_grade[8];       /* likelihood calls per grade (RTI%nlike) */
 } pc_result;
 
 void pc_settings_default(pc_settings *s, int nDims, int nDerived);

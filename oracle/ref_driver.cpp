@@ -92,7 +92,17 @@ int main(int argc, char **argv)
     double (*fn)(double *, int, double *, int) = gaussian;
     if (like == "rastrigin") { fn = rastrigin; g_lo = -5.12; g_hi = 5.12; }
     else if (like == "twin_gaussian") { fn = twin; g_lo = -1.0; g_hi = 1.0; }
-    double grade_frac[1] = { 1.0 }; int grade_dims[1] = { nDims };
+    // optional: REF_GRADES="dims,dims;repeats,repeats" -- explicit repeats per grade (every grade_frac > 1:
+    // the deterministic branch of generate.F90:303-309)
+    double grade_frac[8] = { 1.0 }; int grade_dims[8] = { nDims }; int nGrade = 1;
+    if (const char *e = std::getenv("REF_GRADES")) {
+        std::string t = e; const size_t semi = t.find(';');
+        std::string a = t.substr(0, semi), b = t.substr(semi + 1);
+        nGrade = 0;
+        for (size_t pos = 0; pos <= a.size() && nGrade < 8;) { size_t k = a.find(',', pos); if (k == std::string::npos) k = a.size(); grade_dims[nGrade++] = atoi(a.substr(pos, k - pos).c_str()); pos = k + 1; }
+        int m = 0;
+        for (size_t pos = 0; pos <= b.size() && m < 8;) { size_t k = b.find(',', pos); if (k == std::string::npos) k = b.size(); grade_frac[m++] = atof(b.substr(pos, k - pos).c_str()); pos = k + 1; }
+    }
     // optional: REF_NPRIOR=<n>, REF_NLIVES="logL:n,logL:n" (dynamic nlive, run_time_info.f90:766-779)
     double loglikes[8] = { 0 }; int nlives[8] = { 0 }; int n_nlives = 0, nprior = -1;
     if (const char *e = std::getenv("REF_NPRIOR")) nprior = atoi(e);
@@ -112,24 +122,24 @@ int main(int argc, char **argv)
     polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
                           false, false, false, write_resume, false, false, true, false, write_dead, false, false,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
-                          1, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
+                          nGrade, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // parse <base>/<root>.stats (read_write.F90:842-889)
     std::string fn_stats = base + "/" + root + ".stats";
     FILE *f = std::fopen(fn_stats.c_str(), "r");
-    double logZ = 0, err = 0; long ndead = 0, nlike = 0; int ncl = 0; char line[512];
+    double logZ = 0, err = 0; long ndead = 0, nlike = 0; int ncl = 0; char line[512]; char nlike_line[256] = "";
     while (f && std::fgets(line, sizeof line, f)) {
         if (std::strncmp(line, "log(Z)", 6) == 0 && std::strstr(line, "+/-")) {
             const char *eq = std::strchr(line, '='); if (eq) std::sscanf(eq + 1, "%lf +/- %lf", &logZ, &err);
         }
         if (std::strstr(line, "ndead:")) std::sscanf(std::strstr(line, "ndead:") + 6, "%ld", &ndead);
-        if (std::strstr(line, "nlike:")) std::sscanf(std::strstr(line, "nlike:") + 6, "%ld", &nlike);
+        if (std::strstr(line, " nlike:")) { std::sscanf(std::strstr(line, "nlike:") + 6, "%ld", &nlike); std::snprintf(nlike_line, sizeof nlike_line, "%s", std::strstr(line, "nlike:") + 6); for (char *q = nlike_line; *q; ++q) if (*q == '\n') *q = 0; }
         if (std::strstr(line, "ncluster:")) std::sscanf(std::strstr(line, "ncluster:") + 9, "%d", &ncl);
     }
     if (f) std::fclose(f);
     std::printf("{\"like\":\"%s\",\"nDims\":%d,\"nlive\":%d,\"num_repeats\":%d,\"seed\":%d,\"logZ\":%.15g,\"logZerr\":%.15g,"
-                "\"ndead\":%ld,\"nlike\":%ld,\"ncluster\":%d,\"calls\":%ld,\"rng_consumed\":%lu,\"wall\":%.4f}\n",
+                "\"ndead\":%ld,\"nlike\":%ld,\"ncluster\":%d,\"calls\":%ld,\"rng_consumed\":%lu,\"wall\":%.4f,\"nlike_grades\":\"%s\"}\n",
                 like.c_str(), nDims, nlive, nrep, seed, logZ, err, ndead, nlike, ncl, g_calls,
-                pc_shim_consumed ? pc_shim_consumed() : 0ul, wall);
+                pc_shim_consumed ? pc_shim_consumed() : 0ul, wall, nlike_line);
     return 0;
 }

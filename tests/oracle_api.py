@@ -34,7 +34,8 @@ class Settings(C.Structure):
                 ("boost_posterior", C.c_double), ("posteriors", C.c_int), ("equals", C.c_int),
                 ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
-                ("batch", C.c_int), ("sequential_rng", C.c_int), ("time_speeds_draw", C.c_int)]
+                ("batch", C.c_int), ("sequential_rng", C.c_int), ("time_speeds_draw", C.c_int),
+                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_frac", C.POINTER(C.c_double))]
 
 
 class Result(C.Structure):
@@ -43,7 +44,8 @@ class Result(C.Structure):
                 ("nTotal", C.c_int), ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)),
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int), ("logZp", C.POINTER(C.c_double)),
                 ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int), ("post_mean", C.POINTER(C.c_double)),
-                ("post_var", C.POINTER(C.c_double)), ("nposterior_global", C.c_long), ("nequals_global", C.c_long)]
+                ("post_var", C.POINTER(C.c_double)), ("nposterior_global", C.c_long), ("nequals_global", C.c_long),
+                ("nlike_grade", C.c_long * 8)]
 
 
 _lib = None
@@ -113,6 +115,13 @@ def settings(nDims, nDerived=0, **kw):
     return s
 
 
+def set_grades(s, dims, repeats):
+    """fast/slow grades with explicit repeats (chordal_sampling.f90:94-145); returns the arrays to keep alive"""
+    gd = np.array(dims, dtype=np.int32); gf = np.array(repeats, dtype=np.float64)
+    s.nGrade = len(dims); s.grade_dims = gd.ctypes.data_as(C.POINTER(C.c_int)); s.grade_frac = dptr(gf)
+    return gd, gf
+
+
 def run(s, like, prior):
     lib = load()
     r = Result()
@@ -126,7 +135,8 @@ def run(s, like, prior):
                live=np.ctypeslib.as_array(r.live, shape=(max(r.nlive_final, 1), nT))[:r.nlive_final].copy(),
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),
-               post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy())
+               post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy(),
+               nlike_grade=[int(v) for v in r.nlike_grade])
     lib.pc_result_free(C.byref(r))
     return out
 
