@@ -102,6 +102,11 @@ typedef struct {
                            oracle/ref_rng_shim.c the reference binary then produces the same run, draw for draw */
     const char *resume_read;   /* start from this .resume file if it exists (read_write.F90:384-476; also the file
                                   pypolychord writes for `cube_samples`); NULL = off */
+    /* fast/slow parameter grades (chordal_sampling.f90:94-145, generate.F90:303-309): nGrade <= 1 = one grade of nDims
+       parameters with num_repeats repeats.  Otherwise grade g owns grade_dims[g] parameters (sum = nDims) and
+       grade_repeats[g] directions per chain, drawn in the subspace of its own and all faster parameters;
+       num_repeats is then ignored (the total is the sum).  At most 8 grades. */
+    int nGrade; const int *grade_dims; const int *grade_repeats;
 } pchip_settings;
 
 typedef struct {
@@ -133,6 +138,7 @@ typedef struct {
     double *live; int nlive_final; /* live set at termination, before the final kill-off */
     double *logZp, *varlogZp; int nZp;
     double *post_mean, *post_var;  /* [nDims + nDerived] weighted posterior moments of theta, phi */
+    long nlike_grade[8];           /* likelihood evaluations per grade (RTI%nlike; the prior samples count for grade 1) */
 } pchip_result;
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
@@ -148,6 +154,7 @@ typedef struct {
     const int *live_cluster;        /* [nlive] 0-based cluster of each live row */
     double logZ, logZerr;
     long nlike;
+    int ngrade; const long *nlike_grade; const int *grade_dims, *grade_repeats;   /* [ngrade] RTI%nlike / num_repeats per grade */
     int ncluster, ncluster_dead;
     const int *nlive_p;             /* [ncluster] */
     const double *logZp, *logZperr;            /* [ncluster] clusters still active */

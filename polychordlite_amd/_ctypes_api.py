@@ -31,7 +31,8 @@ class Settings(C.Structure):
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
                 ("force_general", C.c_int), ("ablate", C.c_int),
-                ("resume_write", C.c_char_p), ("sequential_rng", C.c_int), ("resume_read", C.c_char_p)]
+                ("resume_write", C.c_char_p), ("sequential_rng", C.c_int), ("resume_read", C.c_char_p),
+                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_repeats", C.POINTER(C.c_int))]
 
 
 class Like(C.Structure):
@@ -53,7 +54,8 @@ class Result(C.Structure):
                 ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("entry", C.POINTER(C.c_double)),
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
-                ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double))]
+                ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
+                ("nlike_grade", C.c_long * 8)]
 
 
 _lib = None
@@ -112,6 +114,16 @@ def make_problem(kind, nDims, nDerived=0, lo=None, hi=None, mu=0.5, sigma=0.1, i
     return L, P, keep
 
 
+def set_grades(settings, dims, repeats):
+    """fast/slow parameter grades with explicit repeats per grade; returns the arrays to keep alive"""
+    gd = np.array(dims, dtype=np.int32)
+    gr = np.array(repeats, dtype=np.int32)
+    settings.nGrade = len(dims)
+    settings.grade_dims = gd.ctypes.data_as(C.POINTER(C.c_int))
+    settings.grade_repeats = gr.ctypes.data_as(C.POINTER(C.c_int))
+    return gd, gr
+
+
 class _Owner:
     """Keeps a pchip_result alive for the numpy views handed out by run(); frees it when the last view dies."""
 
@@ -162,5 +174,6 @@ def run(settings, like, prior):
                live=_view(own, r.live, (r.nlive_final, nT)),
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
-               post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy())
+               post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
+               nlike_grade=[int(v) for v in r.nlike_grade])
     return out

@@ -72,6 +72,7 @@ struct FileSink {
          cluster_posteriors = false;
     unsigned seed = 0; double logzero = -1e30, compression = 0.36787944117144233; int num_repeats = 1;
     long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
+    std::vector<long> nlike_last_g;
     std::vector<double> mu, sig;
 
     std::string path(const char *suffix) const { return base + "/" + root + suffix; }
@@ -123,13 +124,24 @@ struct FileSink {
         std::fprintf(f, " nequals:    %8d\n", nequals);
         std::fprintf(f, " ndead:      %8ld\n", u.ndead);
         std::fprintf(f, " nlive:      %8d\n", u.nlive);
-        std::fprintf(f, " nlike:      %8ld\n", u.nlike);
-        double per_it = 0.0, per_slice = 0.0;
+        // one column per grade (read_write.F90:880-889)
+        const int ng = u.ngrade > 0 ? u.ngrade : 1;
+        auto last_g = [&](int g) { return g < (int)nlike_last_g.size() ? nlike_last_g[g] : 0L; };
+        std::fprintf(f, " nlike:      ");
+        for (int g = 0; g < ng; ++g) std::fprintf(f, "%8ld", u.nlike_grade ? u.nlike_grade[g] : u.nlike);
+        std::fprintf(f, "\n <nlike>:    ");
+        std::vector<double> per_it(ng, 0.0), per_slice(ng, 0.0);
         if (u.nlive > 0) {                        // likelihood calls per iteration since the last update
             const double upd = -(double)u.nlive * std::log(compression);
-            per_it = (double)(u.nlike - nlike_last) / upd; per_slice = per_it / (double)num_repeats;
+            for (int g = 0; g < ng; ++g) {
+                per_it[g] = (double)((u.nlike_grade ? u.nlike_grade[g] : u.nlike) - last_g(g)) / upd;
+                per_slice[g] = per_it[g] / (double)(u.grade_repeats ? u.grade_repeats[g] : num_repeats);
+            }
         }
-        std::fprintf(f, " <nlike>:    %8.2f   (%8.2f per slice )\n", per_it, per_slice);
+        for (int g = 0; g < ng; ++g) std::fprintf(f, "%8.2f", per_it[g]);
+        std::fprintf(f, "   (");
+        for (int g = 0; g < ng; ++g) std::fprintf(f, "%8.2f", per_slice[g]);
+        std::fprintf(f, " per slice )\n");
         if (posteriors && !mu.empty()) {
             std::fprintf(f, "\n\nDim No.       Mean        Sigma\n");
             for (int k = 0; k < nDims + nDer; ++k) {
@@ -257,6 +269,8 @@ struct FileSink {
         if (u.final_call == 1 && (posteriors || equals)) { posterior_files(u); if (cluster_posteriors) cluster_files(u); }
         if (write_stats) stats(u);
         nlike_last = u.nlike;
+        nlike_last_g.assign((size_t)(u.ngrade > 0 ? u.ngrade : 1), 0L);
+        for (int g = 0; g < (int)nlike_last_g.size(); ++g) nlike_last_g[g] = u.nlike_grade ? u.nlike_grade[g] : u.nlike;
     }
     static void hook(void *user, const pchip_update *u) { ((FileSink *)user)->update(*u); }
 };
@@ -341,6 +355,46 @@ int polychord_hip_resume_copy(const char *in, const char *out, int *counts)
     return 0;
 }
 
+// time_speeds (generate.F90:330-455) for this engine: seconds per likelihood call of every grade.  The likelihoods that
+// run inside the slice kernel cost the same whichever parameters moved (speed ratio 1).  A host callback is timed:
+// grade 1 = a call after all parameters changed, grade g = a call after only the parameters of grades >= g changed
+// (callers that cache on the slow parameters, e.g. cobaya, return faster then).
+static std::vector<double> time_speeds_host(polychord_loglike_fn like, polychord_prior_fn prior, int D, int nDer, int nGrade,
+                                            const int *grade_dims, double logzero, unsigned seed, int feedback)
+{
+    std::vector<double> speed(nGrade, 1.0);
+    const bool device_like = like == polychord_hip_gaussian || like == polychord_hip_rastrigin ||
+                             like == polychord_hip_twin_gaussian || like == polychord_hip_corr_gaussian;
+    if (device_like) return speed;
+    std::vector<double> cube(D), theta(D), phi(std::max(1, nDer));
+    unsigned long long n = 0;
+    auto draw = [&](int from) { for (int d = from; d < D; ++d) cube[d] = polychord_hip_keyed_uniform(seed, 8u /* timing stream */, 0u, 0u, (unsigned)(n++)); };
+    auto eval = [&]() {
+        if (prior && prior != polychord_hip_uniform_prior) prior(cube.data(), theta.data(), D); else polychord_hip_uniform_prior(cube.data(), theta.data(), D);
+        return like(theta.data(), D, phi.data(), nDer);
+    };
+    using clk = std::chrono::steady_clock;
+    auto timed = [&](int from, int ncalls) {
+        double tot = 0.0; int ok = 0;
+        for (int tries = 0; ok < ncalls && tries < 50 * ncalls; ++tries) {
+            draw(from);
+            const auto t0 = clk::now();
+            const double l = eval();
+            const double dt = std::chrono::duration<double>(clk::now() - t0).count();
+            if (l > logzero) { tot += dt; ok++; } else if (from > 0) draw(0);
+        }
+        return ok > 0 ? tot / ok : 1.0;
+    };
+    draw(0);
+    speed[0] = std::max(1e-9, timed(0, 8));
+    for (int g = 1, off = 0; g < nGrade; ++g) {
+        off += grade_dims[g - 1];
+        speed[g] = std::max(1e-9, timed(off, 16));
+        if (feedback >= 1) std::printf("Speed %2d = %10.3E seconds\n", g + 1, speed[g]);
+    }
+    return speed;
+}
+
 void polychord_c_interface(
     polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
     int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
@@ -352,12 +406,30 @@ void polychord_c_interface(
     double *loglikes, int *nlives, int seed, int *comm)
 {
     (void)maximise;
-    (void)synchronous; (void)comm; (void)grade_frac;
+    (void)synchronous; (void)comm;
     if (num_repeats < 1) halt_program("You need to set num_repeats. Suggestion: 5*nDims");     // settings.f90:216
-    if (nGrade > 1 || (nGrade == 1 && grade_dims && grade_dims[0] != nDims))
-        halt_program("polychord_hip: fast/slow parameter grades are not supported by the HIP engine yet");
     pchip_settings s;
     pchip_settings_default(&s, nDims, nDerived);
+    // fast/slow parameter grades.  generate.F90:303-309: if every grade_frac exceeds 1 they ARE the repeats per grade;
+    // otherwise the first grade keeps num_repeats and grade g gets nint(frac_g / frac_1 * num_repeats * speed_1 / speed_g),
+    // the speeds being wall-clock times per likelihood call (time_speeds, generate.F90:330-455).
+    std::vector<int> g_reps;
+    if (nGrade > 1 && grade_dims && grade_frac) {
+        if (nGrade > 8) halt_program("polychord_hip: at most 8 parameter grades");
+        int tot = 0;
+        for (int g = 0; g < nGrade; ++g) { if (grade_dims[g] < 1) halt_program("polychord_hip: every grade needs at least one parameter"); tot += grade_dims[g]; }
+        if (tot != nDims) halt_program("polychord_hip: grade_dims must sum to nDims");
+        bool explicit_reps = true;
+        for (int g = 0; g < nGrade; ++g) explicit_reps = explicit_reps && grade_frac[g] > 1.0;
+        g_reps.assign(nGrade, num_repeats);
+        if (explicit_reps) for (int g = 0; g < nGrade; ++g) g_reps[g] = (int)grade_frac[g];
+        else {
+            std::vector<double> speed = time_speeds_host(loglikelihood, prior, nDims, nDerived, nGrade, grade_dims, logzero, (unsigned)(seed >= 0 ? seed : 1), feedback);
+            for (int g = 1; g < nGrade; ++g)
+                g_reps[g] = std::max(1, (int)std::lround(grade_frac[g] / grade_frac[0] * num_repeats * speed[0] / speed[g]));
+        }
+        s.nGrade = nGrade; s.grade_dims = grade_dims; s.grade_repeats = g_reps.data();
+    } else if (nGrade == 1 && grade_dims && grade_dims[0] != nDims) halt_program("polychord_hip: grade_dims must sum to nDims");
     s.nlive = nlive; s.num_repeats = num_repeats; s.nprior = nprior; s.nfail = nfail; s.do_clustering = do_clustering;
     s.feedback = feedback; s.precision_criterion = precision_criterion; s.logzero = logzero; s.max_ndead = max_ndead;
     s.boost_posterior = boost_posterior; s.posteriors = posteriors; s.equals = equals; s.cluster_posteriors = cluster_posteriors;

@@ -41,12 +41,16 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
             const int t = deck[i]; deck[i] = deck[j]; deck[j] = t;
         }
         c.phase = CB_NEW_SLICE; c.s = 0; c.nlike = 0; c.need = 0; c.contour = S.ch_contour[chain]; c.ok_theta = 0;
+        if (S.ngrade > 1) for (int g = 0; g < PC_MAX_GRADE; ++g) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + g] = 0;
     }
     double logL = 0.0;
     bool have = false;
     if (c.need) {                                        // the host answered the parked proposal
         logL = ev_logL[chain];
-        if (logL > S.logzero) c.nlike++;
+        if (logL > S.logzero) {
+            c.nlike++;
+            if (S.ngrade > 1) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + pc_grade_of(S, deck[c.s])]++;   // chordal_sampling.f90:84
+        }
         c.need = 0; have = true; c.ok_theta = 1;
     }
     const double *nh = S.nhat + ((size_t)chain * nr + deck[c.s < nr ? c.s : 0]) * D;

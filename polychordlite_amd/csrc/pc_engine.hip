@@ -236,6 +236,8 @@ struct Engine {
     KTimer kt;
     int B = 0;
     bool fast_ok = false;
+    long long nlike_g[PC_MAX_GRADE] = {0};      // RTI%nlike per grade (grade 1 includes the prior samples)
+    std::vector<int> h_nlike_g;                 // [B][PC_MAX_GRADE] of the batch in the nursery
 
     void alloc_phantom_side(int Pcap)
     {
@@ -257,6 +259,29 @@ struct Engine {
         kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : ((unsigned)c.profile >> 1);   // 1: every class; else bit k+1 = class k
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
+        // grades (chordal_sampling.f90:119-130): bases per grade, first direction and first deviate of each
+        S.ngrade = 1; S.g_off[0] = 0; S.g_nr[0] = c.num_repeats;
+        for (int g = 1; g < PC_MAX_GRADE; ++g) { S.g_off[g] = 0; S.g_nr[g] = 0; }
+        if (c.nGrade > 1 && c.grade_dims && c.grade_repeats) {
+            if (c.nGrade > PC_MAX_GRADE) { std::fprintf(stderr, "polychord_hip: at most %d parameter grades\n", PC_MAX_GRADE); std::abort(); }
+            S.ngrade = c.nGrade;
+            int off = 0, tot = 0;
+            for (int g = 0; g < c.nGrade; ++g) {
+                if (c.grade_dims[g] < 1 || c.grade_repeats[g] < 1) { std::fprintf(stderr, "polychord_hip: every grade needs at least one parameter and one repeat\n"); std::abort(); }
+                S.g_off[g] = off; off += c.grade_dims[g]; S.g_nr[g] = c.grade_repeats[g]; tot += c.grade_repeats[g];
+            }
+            if (off != D) { std::fprintf(stderr, "polychord_hip: grade_dims must sum to nDims\n"); std::abort(); }
+            S.nr = tot; cfg.num_repeats = tot;
+        }
+        S.nb_total = 0; S.n_dev = 0;
+        for (int g = 0, col = 0; g < PC_MAX_GRADE; ++g) {
+            const int Dg = D - S.g_off[g];
+            S.g_nb[g] = g < S.ngrade ? (S.g_nr[g] + Dg - 1) / Dg : 0;
+            S.g_col0[g] = col; S.g_e0[g] = (int)S.n_dev;
+            col += S.g_nr[g]; S.nb_total += S.g_nb[g]; S.n_dev += (unsigned)S.g_nb[g] * Dg * Dg;
+        }
+        S.ch_nlike_g = nullptr;
+        std::memset(nlike_g, 0, sizeof(nlike_g));
         S.p0 = D; S.d0 = 2 * D; S.b0 = 2 * D + nDer; S.l0 = S.b0 + 1;
         int nmax = c.nlive;
         for (int i = 0; i < c.n_nlives; ++i) nmax = std::max(nmax, c.nlives[i]);
@@ -332,6 +357,7 @@ struct Engine {
         S.babies = dalloc<double>((size_t)B * nr * nT); S.baby_logL = dalloc<double>((size_t)B * nr); S.baby_logL_T = dalloc<double>((size_t)B * nr);
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
+        if (S.ngrade > 1) { S.ch_nlike_g = dalloc<int>((size_t)B * PC_MAX_GRADE); h_nlike_g.assign((size_t)B * PC_MAX_GRADE, 0); }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
@@ -350,6 +376,23 @@ struct Engine {
         c0.status = PC_ST_RUNNING; c0.ncluster = 1; c0.logZ = c.logzero; c0.logZ2 = c.logzero;
         c0.logX_last_update = 0.0; c0.next_cluster_uid = 1; c0.live_logZ = c.logzero;
         *h_ctl = c0;
+    }
+
+    void grade_counts(long *o)
+    {   // grade 1 carries the prior samples (generate.F90:294); with one grade it is simply nlike
+        for (int g = 0; g < PC_MAX_GRADE; ++g) o[g] = 0;
+        if (S.ngrade <= 1) { o[0] = (long)h_ctl->nlike; return; }
+        long rest = 0;
+        for (int g = 1; g < S.ngrade; ++g) { o[g] = (long)nlike_g[g]; rest += o[g]; }
+        o[0] = (long)h_ctl->nlike - rest;
+    }
+
+    // per-grade likelihood counts (RTI%nlike, nested_sampling.F90:307): the chains the last segment consumed
+    void tally_grades()
+    {
+        if (S.ngrade <= 1) return;
+        for (int w = h_ctl->seg_lo; w <= h_ctl->seg_hi; ++w)
+            for (int g = 0; g < PC_MAX_GRADE; ++g) nlike_g[g] += h_nlike_g[(size_t)w * PC_MAX_GRADE + g];
     }
 
     void read_ctl()
@@ -444,6 +487,10 @@ struct Engine {
             u.dead = nd > 0 ? hm_dead.data() : &dummy; u.logpost = nd > 0 ? hm_logw.data() : &dummy;
             u.live = live.data(); u.live_cluster = lcl.data();
             u.logZ = lz; u.logZerr = std::sqrt(std::fabs(var)); u.nlike = h_ctl->nlike;
+            long ng[PC_MAX_GRADE]; int gdims[PC_MAX_GRADE];
+            grade_counts(ng);
+            for (int g = 0; g < S.ngrade; ++g) gdims[g] = (g + 1 < S.ngrade ? S.g_off[g + 1] : D) - S.g_off[g];
+            u.ngrade = S.ngrade; u.nlike_grade = ng; u.grade_dims = gdims; u.grade_repeats = S.g_nr;
             u.ncluster = nc; u.ncluster_dead = ncd; u.nlive_p = cn.data();
             u.logZp = e1.data(); u.logZperr = s1.data(); u.logZp_dead = e2.data(); u.logZperr_dead = s2.data();
             auto ua = dl(S.cl_uid, std::max(1, nc)); auto ud = dl(S.cl_uid_dead, std::max(1, ncd));
@@ -797,16 +844,17 @@ struct Engine {
         HIPCHK(hipStreamSynchronize(st));
         if (S.seq_mode) {
             // the reference draws and evaluates one more prior sample while it times the likelihood
-            // (time_speeds, generate.F90:388-393); the stream position after it is where the sampling starts
+            // (time_speeds, generate.F90:388-393); the stream position after it is where the sampling starts.
+            // With explicit repeats for every grade it does not (generate.F90:285-287).
             int a = last_attempt + 1;
-            for (;; ++a) {
+            for (; S.ngrade <= 1; ++a) {
                 double l1 = 0.0;
                 (void)pc_launch_generate_live(&S, a, 1, rows, rl, st);
                 HIPCHK(hipMemcpyAsync(&l1, rl, sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (l1 > cfg.logzero) break;
             }
-            h_ctl->seq = (unsigned long long)(a + 1) * S.D;
+            h_ctl->seq = (unsigned long long)(a + (S.ngrade <= 1 ? 1 : 0)) * S.D;
             HIPCHK(hipMemcpy(&S.ctl->seq, &h_ctl->seq, sizeof(unsigned long long), hipMemcpyHostToDevice));
         }
         dfree(rows); dfree(rl);
@@ -835,7 +883,15 @@ struct Engine {
         const int D = S.D, nT = S.nT, nc = h_ctl->ncluster, ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead), maxc = S.maxc;
         r = PcResume{};
         r.nDims = D; r.nDerived = S.nDer; r.ndead = h_ctl->ndead; r.ncluster = nc; r.ncluster_dead = ncd;
-        r.grade_dims = {D}; r.num_repeats = {S.nr}; r.nlike = {h_ctl->nlike};
+        {
+            long ng[PC_MAX_GRADE];
+            grade_counts(ng);
+            r.grade_dims.clear(); r.num_repeats.clear(); r.nlike.clear();
+            for (int g = 0; g < S.ngrade; ++g) {
+                r.grade_dims.push_back((g + 1 < S.ngrade ? S.g_off[g + 1] : D) - S.g_off[g]);
+                r.num_repeats.push_back(S.g_nr[g]); r.nlike.push_back(ng[g]);
+            }
+        }
         r.logZ = h_ctl->logZ; r.logZ2 = h_ctl->logZ2; r.thin_posterior = cfg.boost_posterior; r.logX_last_update = h_ctl->logX_last_update;
         auto take = [&](const double *p) { auto v = dl(p, std::max(1, nc)); v.resize(nc); return v; };
         r.logLp = take(S.logLp); r.logXp = take(S.logXp); r.logZXp = take(S.logZXp); r.logZp = take(S.logZp);
@@ -951,7 +1007,9 @@ struct Engine {
         PcCtl c0 = *h_ctl;
         c0.status = nc >= 1 ? PC_ST_RUNNING : PC_ST_DONE; c0.ncluster = nc; c0.ncluster_dead = ncd; c0.ndead = r.ndead; c0.nphantom = nph;
         c0.logZ = r.logZ; c0.logZ2 = r.logZ2; c0.logX_last_update = r.logX_last_update; c0.next_cluster_uid = (unsigned)nc + 1;
-        c0.nlike = r.nlike.empty() ? 0 : r.nlike[0]; c0.nlike_device = c0.nlike; c0.i_nursery = 0; c0.failures = 0;
+        c0.nlike = 0;                                  // the engine's counter is the total over the grades
+        for (size_t g = 0; g < r.nlike.size(); ++g) { c0.nlike += r.nlike[g]; if (g >= 1 && g < PC_MAX_GRADE) nlike_g[g] = r.nlike[g]; }
+        c0.nlike_device = c0.nlike; c0.i_nursery = 0; c0.failures = 0;
         HIPCHK(hipMemcpy(S.ctl, &c0, sizeof(PcCtl), hipMemcpyHostToDevice));
         *h_ctl = c0;
         return true;
@@ -998,6 +1056,7 @@ struct Engine {
                 if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
                 else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
+                if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
                 batch++; tm.batches++;
             }
             hipEvent_t e2 = kt.begin(KT_CONSUME);
@@ -1017,6 +1076,7 @@ struct Engine {
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             read_ctl();
+            tally_grades();
             stream_dead();
             tm.rounds++;
             if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; }
@@ -1052,6 +1112,7 @@ struct Engine {
         out->logZ = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2);
         out->varlogZ = h_ctl->logZ2 - 2 * h_ctl->logZ;
         out->ndead = h_ctl->ndead; out->nlike = h_ctl->nlike; out->niter = h_ctl->niter;
+        grade_counts(out->nlike_grade);
         out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
         out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
@@ -1113,6 +1174,7 @@ struct Engine {
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
                        &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
+        dfree(S.ch_nlike_g);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);

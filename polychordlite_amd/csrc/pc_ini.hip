@@ -107,8 +107,12 @@ double inv_normal_cdf_host(double p)
     return q < 0 ? -v : v;
 }
 
-void ini_prior(double *cube, double *theta, int nDims)
+std::vector<int> g_hyper;   // hypercube index of physical parameter i: parameters are ordered by speed in the cube (priors.f90:708-737)
+
+void ini_prior(double *cube_h, double *theta, int nDims)
 {   // hypercube_to_physical (priors.f90:494-556) for the supported separable / sorted blocks
+    std::vector<double> cube(nDims);
+    for (int k = 0; k < nDims; ++k) cube[k] = cube_h[g_hyper[k]];
     int i = 0;
     while (i < nDims) {
         const Param &p = g_params[i];
@@ -140,7 +144,25 @@ extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, vo
     if (nDims == 0) halt_program("ini error: no 'P :' parameter lines");
     if (setup_loglikelihood) setup_loglikelihood();            // interfaces.F90:273
     // uniform-only priors run on the device (when the likelihood is a built-in); anything else is a host prior
-    bool all_uniform = true;
+    // grades from the speed column (priors.f90:708-737): speeds relabelled 1,2,3.. in increasing order, the hypercube
+    // lists the parameters grade by grade (file order within a grade), grade_dims = parameters per grade
+    std::vector<int> speeds(nDims), grade_dims;
+    {
+        std::vector<int> distinct;
+        for (auto &p : ini.params) distinct.push_back(p.speed);
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        g_hyper.assign(nDims, 0);
+        int h = 0;
+        for (size_t g = 0; g < distinct.size(); ++g) {
+            int cnt = 0;
+            for (int i = 0; i < nDims; ++i) if (ini.params[i].speed == distinct[g]) { g_hyper[i] = h++; cnt++; }
+            grade_dims.push_back(cnt);
+        }
+    }
+    bool identity = true;
+    for (int i = 0; i < nDims; ++i) identity = identity && g_hyper[i] == i;
+    bool all_uniform = identity;               // the device prior maps cube coordinate i to parameter i
     std::vector<double> lo(nDims), hi(nDims);
     for (int i = 0; i < nDims; ++i) {
         all_uniform &= ini.params[i].prior == "uniform";
@@ -151,8 +173,10 @@ extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, vo
     if (all_uniform) { polychord_hip_set_uniform_prior(nDims, lo.data(), hi.data()); prior = polychord_hip_uniform_prior; }
     std::vector<double> grade_frac = ini.dbls("grade_frac");
     if (grade_frac.empty()) grade_frac = {1.0};
-    std::vector<int> grade_dims = {nDims};
-    if (grade_frac.size() > 1) halt_program("polychord_hip: fast/slow parameter grades are not supported by the HIP engine yet");
+    if (grade_frac.size() != grade_dims.size()) {
+        if (grade_dims.size() == 1) grade_frac.resize(1);
+        else halt_program("ini error: grade_frac needs one entry per parameter speed");
+    }
     std::vector<double> loglikes = ini.dbls("loglikes"), nl = ini.dbls("nlives");
     std::vector<int> nlives(nl.begin(), nl.end());
     const int n_nlives = (int)std::min(loglikes.size(), nlives.size());
@@ -176,6 +200,6 @@ extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, vo
                           ini.logical("read_resume", false), ini.logical("write_stats", true), ini.logical("write_live", false),
                           ini.logical("write_dead", true), ini.logical("write_prior", false), ini.logical("maximise", false),
                           ini.dbl("compression_factor", std::exp(-1.0)), ini.logical("synchronous", true), nDims, nDerived,
-                          (char *)base.c_str(), (char *)root.c_str(), 1, grade_frac.data(), grade_dims.data(), n_nlives,
+                          (char *)base.c_str(), (char *)root.c_str(), (int)grade_dims.size(), grade_frac.data(), grade_dims.data(), n_nlives,
                           loglikes.empty() ? nullptr : loglikes.data(), nlives.empty() ? nullptr : nlives.data(), ini.integer("seed", -1), comm);
 }

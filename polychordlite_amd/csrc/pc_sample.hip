@@ -190,12 +190,17 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #ifdef NHATS_DBG
     long long ncyc[8]; ncyc[0] = clock64();
 #endif
-    const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
+    const int tid = threadIdx.x, chain = blockIdx.y;
+    // grade of this block and its basis within the grade (chordal_sampling.f90:119-130): the basis spans the
+    // parameters off..D-1, its vectors carry zeros in front; one grade: off = 0, Dg = D
+    int grade, basis;
+    pc_grade_of_basis(S, blockIdx.x, grade, basis);
+    const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
     if (tid == 0) {
         int sel, slot;
         select_seed(S, batch, chain, sel, slot);
         sh[0] = sel; sh[1] = slot;
-        if (basis == 0) {
+        if (blockIdx.x == 0) {
             S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
             S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
             S.ch_epoch[chain] = S.ctl->admin_epoch;
@@ -205,24 +210,29 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #ifdef NHATS_DBG
     ncyc[1] = clock64();
 #endif
-    // gaussian deviates: index (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT
-    // (seq_mode: after the two seed draws, basis after basis: generate_nhats inside SliceSampling)
+    // gaussian deviates: running index of stream (batch, chain) in PC_DOM_NHAT, grade after grade, basis after basis,
+    // vector after vector (seq_mode: after the two seed draws: generate_nhats inside SliceSampling)
     const uint32_t eoff = S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u;
-    const uint32_t e0 = eoff + (uint32_t)basis * D * D, e1 = e0 + (uint32_t)D * D;
+    const uint32_t e0 = eoff + (uint32_t)pc_sel(S.g_e0, grade) + (uint32_t)basis * Dg * Dg, e1 = e0 + (uint32_t)Dg * Dg;
+    if (off > 0) {
+        for (int e = tid; e < Dg * D; e += NT) G[e] = 0.0;
+        __syncthreads();
+    }
     for (uint32_t call = (e0 >> 1) + tid; call <= ((e1 - 1) >> 1); call += NT) {
         double ua, ub;
         if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
         else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
         const uint32_t ia = 2 * call, ib = 2 * call + 1;
-        if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
-        if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+        // element x of the basis = coordinate off + x % Dg of vector x / Dg
+        if (ia >= e0 && ia < e1) { const uint32_t x = ia - e0; G[off == 0 ? x : (x / Dg) * D + off + x % Dg] = pc_inv_normal_cdf(ua); }
+        if (ib >= e0 && ib < e1) { const uint32_t x = ib - e0; G[off == 0 ? x : (x / Dg) * D + off + x % Dg] = pc_inv_normal_cdf(ub); }
     }
     __syncthreads();
 #ifdef NHATS_DBG
     ncyc[2] = clock64();
 #endif
     const int i = tid;
-    const bool active = i < D;
+    const bool active = i < Dg;
     double v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? G[(size_t)i * D + d] : 0.0;
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
                 _Pragma("unroll") for (int d = 0; d < DMAX; ++d) qn[d] = v[d]; \
             } \
         } }
-    for (int j = 0; j < D; ++j) {
+    for (int j = 0; j < Dg; ++j) {
         const double *q = Qb + (size_t)(j & 1) * QS;
         if constexpr (DMAX <= 32) {
             double qv[DMAX];                          // registers: one LDS pass per step
@@ -287,14 +297,15 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
     ncyc[4] = clock64();
 #endif
     // whitening  w = L.n  (chordal_sampling.f90:73)
-    const int col = basis * D + i;
+    const int col = col0 + basis * Dg + i;
+    const bool wanted = basis * Dg + i < nrg;         // the last basis of a grade is truncated
     if constexpr (DMAX <= 32) {
         // the deviate buffer is free: it receives the Cholesky factor, every thread multiplies its own
         // vector from registers; the D row sums are independent chains (row a adds b = 0..a in order)
         const double *Lg = S.chol + (size_t)sh[0] * D * D;
         for (int e = tid; e < D * D; e += NT) G[e] = Lg[e];
         __syncthreads();
-        if (active && col < nr) {
+        if (active && wanted) {
             double t[DMAX];
 #pragma unroll
             for (int a = 0; a < DMAX; ++a) t[a] = 0.0;
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
             __syncthreads();
             for (int e = tid; e < nrow * D; e += NT) Lt[e] = Lc[(size_t)a_lo * D + e];
             __syncthreads();
-            if (active && col < nr) {
+            if (active && wanted) {
                 for (int a = a_hi; a >= a_lo; --a) {
                     const double *Lr = Lt + (size_t)(a - a_lo) * D;
                     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
                 }
             }
         }
-        if (active && col < nr) {
+        if (active && wanted) {
             double n0 = 0.0, n1 = 0.0;
             int d = 0;
             for (; d + 1 < D; d += 2) { n0 += mine[d] * mine[d]; n1 += mine[d + 1] * mine[d + 1]; }
@@ -354,8 +365,8 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         }
         __syncthreads();
         // rows leave coalesced
-        for (int r = 0; r < D && basis * D + r < nr; ++r) {
-            double *out = S.nhat + ((size_t)chain * nr + basis * D + r) * D;
+        for (int r = 0; r < Dg && basis * Dg + r < nrg; ++r) {
+            double *out = S.nhat + ((size_t)chain * nr + col0 + basis * Dg + r) * D;
             const double iw = Q[r];
             for (int d = tid; d < D; d += NT) out[d] = G[(size_t)r * DS + d] * iw;
         }
@@ -389,14 +400,17 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     __shared__ __attribute__((aligned(16))) double Lt[HV][DP];        // HV rows of the Cholesky factor
     __shared__ int sh[2];
     const int D = S.D, nr = S.nr;
-    const int tid = threadIdx.x, basis = blockIdx.x, chain = blockIdx.y;
+    const int tid = threadIdx.x, chain = blockIdx.y;
     const int i = tid >> 2, h = tid & 3, d0 = HV * h;                 // my vector, my coordinate block
-    const bool active = i < D;
+    int grade, basis;                                                 // chordal_sampling.f90:119-130, see k_nhats
+    pc_grade_of_basis(S, blockIdx.x, grade, basis);
+    const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
+    const bool active = i < Dg;
     if (tid == 0) {
         int sel, slot;
         select_seed(S, batch, chain, sel, slot);
         sh[0] = sel; sh[1] = slot;
-        if (basis == 0) {
+        if (blockIdx.x == 0) {
             S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
             S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
             S.ch_epoch[chain] = S.ctl->admin_epoch;
@@ -409,10 +423,12 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #pragma unroll
     for (int e = 0; e < HV; ++e) v[e] = 0.0;
     if (active) {
-        const uint32_t e0 = (S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + ((uint32_t)basis * D + i) * D + d0;
-        const int cnt = min(HV, D - d0);                              // coordinates of this block that exist
-        if (cnt > 0) {
-            const uint32_t c0 = e0 >> 1, c1 = (e0 + cnt - 1) >> 1;
+        // stream element of my register 0 (coordinate d0); registers [r_lo, r_hi) hold coordinates that exist and move
+        const long long e0 = (long long)(S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + pc_sel(S.g_e0, grade)
+                             + ((long long)basis * Dg + i) * Dg + (d0 - off);
+        const int r_lo = max(0, off - d0), r_hi = min(HV, D - d0);
+        if (r_hi > r_lo) {
+            const uint32_t c0 = (uint32_t)((e0 + r_lo) >> 1), c1 = (uint32_t)((e0 + r_hi - 1) >> 1);
 #pragma unroll
             for (int cc = 0; cc < HV / 2 + 1; ++cc) {
                 const uint32_t call = c0 + cc;
@@ -420,12 +436,12 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
                     double ua, ub;
                     if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
                     else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
-                    const int ea = (int)(2 * call) - (int)e0, eb = ea + 1;     // -1 .. HV
+                    const int ea = (int)(2ll * call - e0), eb = ea + 1;     // -1 .. HV
                     const double ga = pc_inv_normal_cdf(ua), gb = pc_inv_normal_cdf(ub);
 #pragma unroll
                     for (int e = 0; e < HV; ++e) {
-                        if (e == ea && e < cnt) v[e] = ga;
-                        if (e == eb && e < cnt) v[e] = gb;
+                        if (e == ea && e >= r_lo && e < r_hi) v[e] = ga;
+                        if (e == eb && e >= r_lo && e < r_hi) v[e] = gb;
                     }
                 }
             }
@@ -458,7 +474,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
         }
     }
     // Gram-Schmidt (random_utils.F90:391-399): same projections as before, pivot unnormalised
-    for (int j = 0; j < D; ++j) {
+    for (int j = 0; j < Dg; ++j) {
         double q[HV];
 #pragma unroll
         for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][d0 + e];
@@ -482,7 +498,8 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     }
     // whitening  w = L.n  (chordal_sampling.f90:73): tile k holds rows 32k..32k+31 of L, i.e. exactly the output
     // coordinates of block h = k
-    const int col = basis * D + i;
+    const int col = col0 + basis * Dg + i;
+    const bool wanted = basis * Dg + i < nrg;
     const double *Lc = S.chol + (size_t)sh[0] * D * D;
     double w[HV];
 #pragma unroll
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             if (h == k) w[r] = t;
         }
     }
-    if (active && col < nr) {
+    if (active && wanted) {
         double n2;
         PC_DOT32(n2, w, w)
         const double wn = sqrt(n2), iw = 1.0 / wn;              // chordal_sampling.f90:80-82
@@ -630,7 +647,10 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
     if (ob) lB = C.S.logzero; else if (lB > C.S.logzero) C.nlike++;
 }
 
-template <int DPL, int NROWS>
+// SPECIAL = false is the production kernel.  SPECIAL = true adds the two rare modes, both decided at run time:
+// more than one parameter grade (the evaluations of a slice are booked to the grade of its direction) and the
+// sequential-stream test mode (every draw taken from ONE running stream in the reference's program order).
+template <int DPL, int NROWS, bool SPECIAL>
 __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -642,6 +662,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     const int lane = threadIdx.x, chain = blockIdx.x;
     const int D = S.D, nr = S.nr, nT = S.nT;
     const double logzero = S.logzero;
+    const bool seq_mode = SPECIAL && S.seq_mode != 0, graded = SPECIAL && S.ngrade > 1;
 
     LaneDims<DPL> ld;
     const int slot = S.ch_seed_slot[chain];
@@ -708,14 +729,14 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
     //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
     // seq_mode: stream positions of the shuffle draws (after the seed draws and every basis) and of the slice draws
-    const unsigned long long seq_g0 = S.seq_mode ? S.ctl->seq + 2ull + (unsigned long long)((nr + D - 1) / D) * D * D : 0ull;
+    const unsigned long long seq_g0 = seq_mode ? S.ctl->seq + 2ull + (unsigned long long)S.n_dev : 0ull;
     unsigned long long seq_run = seq_g0 + (unsigned long long)(nr - 1);
     int deck = lane;
     const bool deck_in_regs = nr <= 64;
     if (deck_in_regs) {
         int jv = 0;
         if (lane >= 1 && lane < nr) {
-            const double u = S.seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - lane))
+            const double u = seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - lane))
                                         : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
             int j = (int)ceil(u * lane);
             jv = j < 1 ? 1 : (j > lane ? lane : j);
@@ -729,7 +750,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
         for (int i = lane; i < nr; i += 64) {
             sdeck[i] = i;
             if (i >= 1) {
-                const double u = S.seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - i))
+                const double u = seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - i))
                                             : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
                 int j = (int)ceil(u * i);
                 sj[i] = j < 1 ? 1 : (j > i ? i : j);
@@ -765,10 +786,16 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     double *bl_col = S.baby_logL_T + chain;
     double *tb_row = tbuf + lane;
     const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
+    int nl_grade[PC_MAX_GRADE];                    // evaluations per grade (chordal_sampling.f90:84), static indices only
+#pragma unroll
+    for (int g = 0; g < PC_MAX_GRADE; ++g) nl_grade[g] = 0;
     for (int s = 0; s < nr; ++s, row += nT, bl_col += Bstride, tb_row += D + 1) {
 #ifdef SLICE_DBG
         const long long c0 = clock64();
 #endif
+        const int nl_before = C.nlike;
+        int my_grade = 0;
+        if (graded) my_grade = pc_grade_of(S, deck_in_regs ? __builtin_amdgcn_readlane(deck, s) : sdeck[s]);
         if (s + 1 < nr) {                           // prefetch the next direction (hidden under this slice)
             const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
             const double *p = nh_base + v1 * D;
@@ -776,14 +803,14 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[64 * k] : 0.0;
             w_next = nw_base[v1];
         }
-        if ((s & 3) == 0 && !S.seq_mode) {          // one Philox call per lane covers 4 slices x 32 uniforms
+        if ((s & 3) == 0 && !seq_mode) {          // one Philox call per lane covers 4 slices x 32 uniforms
             const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
             pc_uniform2(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain,
                         (sl * PC_SLICE_STRIDE) / 2 + (uint32_t)(lane & 15), ua, ub);
         }
         uint32_t kdraw = 0;
         auto next_u = [&]() -> double {
-            if (S.seq_mode) return pc_seq_uniform(S, seq_run++);
+            if (seq_mode) return pc_seq_uniform(S, seq_run++);
             const uint32_t k = kdraw++;
             if (k < 32u) {
                 const int src = ((s & 3) << 4) + (int)(k >> 1);
@@ -900,6 +927,10 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
             row[o_l0] = lnew;
             bl_row[s] = lnew; *bl_col = lnew;
         }
+        if (graded) {
+#pragma unroll
+            for (int g = 0; g < PC_MAX_GRADE; ++g) nl_grade[g] += (my_grade == g) ? C.nlike - nl_before : 0;
+        }
 #ifdef SLICE_DBG
         const long long c5 = clock64();
         scy[0] += c1 - c0; scy[1] += c2 - c1; scy[2] += c3 - c2; scy[3] += c4 - c3; scy[4] += c5 - c4;
@@ -909,7 +940,13 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; S.ctl->dbg[6] += scy[5]; S.ctl->dbg[7] += ev2; }
 #endif
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
-    if (S.seq_mode && lane == 0 && chain == 0) S.ctl->seq = seq_run;
+    if (graded) {
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < PC_MAX_GRADE; ++g) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + g] = nl_grade[g];
+        }
+    }
+    if (seq_mode && lane == 0 && chain == 0) S.ctl->seq = seq_run;
     // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
     // one sqrt / log per chain instead of one per slice on the chain's critical path
     if (S.nDer > 0 && phi_lds) {
@@ -951,7 +988,7 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
 
 extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
-    const int D = S->D, nb = (S->nr + D - 1) / D;
+    const int D = S->D, nb = S->nb_total;
     dim3 grid(nb, nchains);
     static int quad_min = -1;                       // smallest nDims that takes the four-threads-per-vector kernel
     if (quad_min < 0) { const char *e = std::getenv("PC_NHATS_QUAD_MIN"); quad_min = e ? std::atoi(e) : 25; }   // measured: 20-D 52 vs 39 us (old kernel better), 28-D 43 vs 47, 40-D 95 vs 133, 64-D 129 vs 240
@@ -985,9 +1022,10 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     const int mat_lds = (S->like.kind == PC_LIKE_CORR_GAUSSIAN && sh + mb <= 150 * 1024) ? 1 : 0;
     if (mat_lds) sh += mb;
     const int D = S->D;
-#define PC_SLICE_LAUNCH(DPL, NROWS) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_slice<DPL, NROWS>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
+#define PC_SLICE_LAUNCH1(DPL, NROWS, GR) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<DPL, NROWS, GR>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
+#define PC_SLICE_LAUNCH(DPL, NROWS) { if (S->ngrade > 1 || S->seq_mode) PC_SLICE_LAUNCH1(DPL, NROWS, true) else PC_SLICE_LAUNCH1(DPL, NROWS, false) }
     if (D <= 16) PC_SLICE_LAUNCH(1, 1)
     else if (D <= 32) PC_SLICE_LAUNCH(1, 2)
     else if (D <= 64) PC_SLICE_LAUNCH(1, 4)
@@ -995,5 +1033,6 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     else if (D <= 256) PC_SLICE_LAUNCH(4, 4)
     else return 1;
 #undef PC_SLICE_LAUNCH
+#undef PC_SLICE_LAUNCH1
     return 0;
 }

@@ -37,6 +37,8 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     long long dbg[8];            // developer cycle counters of the contraction kernel
 };
 
+#define PC_MAX_GRADE 8
+
 struct PcPlan {                  // one record per nursery chain, written by the consume kernel
     int dead_idx;                // index in dead[] or -1
     int dead_src;                // >=0: live slot; <0: -(1+chain) whose last baby is the row
@@ -99,12 +101,43 @@ struct PcState {
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
     unsigned long long *sort_key; // [NS] sortable logL keys (pc_keys.h) in the same order
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
+    // ---- fast/slow parameter grades (chordal_sampling.f90:94-145): grade g moves the parameters from g_off[g] to the
+    //      last one with g_nr[g] directions taken from g_nb[g] orthonormal bases of that subspace; nr = sum g_nr.
+    //      One grade: g_off = 0, g_nr = nr.  g_col0 = first direction of the grade in generation order, g_e0 = first
+    //      deviate of the grade in the chain's PC_DOM_NHAT stream, n_dev = deviates per chain.
+    int ngrade, nb_total; unsigned n_dev;
+    int g_off[PC_MAX_GRADE], g_nr[PC_MAX_GRADE], g_nb[PC_MAX_GRADE], g_col0[PC_MAX_GRADE], g_e0[PC_MAX_GRADE];
+    int *ch_nlike_g;             // [B][PC_MAX_GRADE] evaluations per grade of each chain (only when ngrade > 1)
     int ablate;                  // dev timing hook (bit mask), 0 in production
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     PcCtl *ctl;
 };
+
+// element g of a small settings array without dynamic indexing of the kernel argument block
+__device__ __forceinline__ int pc_sel(const int (&a)[PC_MAX_GRADE], int g)
+{
+    int r = a[0];
+#pragma unroll
+    for (int k = 1; k < PC_MAX_GRADE; ++k) r = (g == k) ? a[k] : r;
+    return r;
+}
+// grade of direction `col` (generation order): speeds(), chordal_sampling.f90:128
+__device__ __forceinline__ int pc_grade_of(const PcState &S, int col)
+{
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < PC_MAX_GRADE; ++k) if (k < S.ngrade && col >= S.g_col0[k]) g = k;
+    return g;
+}
+// block -> (grade, basis within the grade)
+__device__ __forceinline__ void pc_grade_of_basis(const PcState &S, int block, int &g, int &b)
+{
+    g = 0; b = block;
+#pragma unroll
+    for (int k = 0; k + 1 < PC_MAX_GRADE; ++k) if (g == k && k + 1 < S.ngrade && b >= S.g_nb[k]) { b -= S.g_nb[k]; g = k + 1; }
+}
 
 // uniform number n of the single sequential stream (tests: the order the reference program consumes its generator)
 __device__ __forceinline__ double pc_seq_uniform(const PcState &S, unsigned long long n)
