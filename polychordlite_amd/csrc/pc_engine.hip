@@ -1042,8 +1042,10 @@ struct Engine {
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
-        fast_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && resume_static && cfg.force_general != 1 && pc_fast_fits(&S);
-        const bool par_ok = fast_ok && cfg.force_general == 0 && pc_par_fits(&S);
+        // the one-cluster kernels assume a static number of live points; each has its own LDS budget
+        const bool static_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && resume_static && cfg.force_general != 1;
+        fast_ok = static_ok && pc_fast_fits(&S);
+        const bool par_ok = static_ok && cfg.force_general == 0 && pc_par_fits(&S);
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
@@ -1062,7 +1064,7 @@ struct Engine {
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
-            if (use_fast && par_ok) {
+            if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0;
                 if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }

@@ -82,6 +82,8 @@ RUNS = [  # kind D nDer nlive nr B general clustering
     # other kernel variants: nDims in (32, 64], num_repeats > 64 (deck in LDS), no derived parameters, serial fast kernel (general=2)
     ("gaussian", 40, 0, 120, 40, 32, 0, 0), ("gaussian", 12, 2, 150, 70, 32, 0, 0), ("gaussian", 6, 1, 300, 12, 150, 2, 0),
     ("rastrigin", 3, 0, 120, 9, 60, 2, 0),
+    # BASELINE configs[4] live-set size: the parallel contraction at nlive = 5000 with 1024 chains per nursery
+    ("gaussian", 3, 0, 5000, 3, 1024, 0, 0),
 ]
 
 

@@ -391,3 +391,42 @@ def test_boost_posterior(engine, tmp_path):
     n0, n4 = out[0.0][0], out[4.0][0]
     assert n4 > 2.0 * n0                      # ~ (1 + boost) times the dead points
     assert out[4.0][3] > 1.5 * out[0.0][3]    # and the effective sample size grows with it
+
+
+@pytest.mark.gpu
+def test_grades_through_the_python_surface(engine, tmp_path):
+    """grade_dims / grade_frac as pypolychord passes them (polychord.py:593-634): explicit repeats per grade
+    (every grade_frac > 1) are deterministic -- a host callback reproduces the device run -- and .stats lists the
+    likelihood calls per grade (read_write.F90:880-889); fractions <= 1 go through the speed timing
+    (generate.F90:303-309, time_speeds)."""
+    D = 6
+    kw = dict(nlive=80, num_repeats=12, seed=5, do_clustering=False, read_resume=False, write_resume=False,
+              base_dir=str(tmp_path), feedback=0, grade_dims=[2, 4], grade_frac=[6.0, 9.0])
+    s = pypolychord.PolyChordSettings(D, 0, file_root="gdev", **kw)
+    out_dev = pypolychord.run_polychord(dl.Gaussian(0.5, 0.1), D, 0, s, dl.UniformPrior(0.0, 1.0))
+    s.file_root = "gcb"
+    lib = engine.load(); lib.polychord_hip_set_option(b"batch", 40.0)
+    def host_gauss(theta):
+        return float(-D * (np.log(0.1) + 0.5 * np.log(2 * np.pi)) - 0.5 * np.sum(((theta - 0.5) / 0.1) ** 2))
+    out_cb = pypolychord.run_polychord(host_gauss, D, 0, s, lambda c: c.copy())
+    lib.polychord_hip_set_option(b"batch", 0.0)
+    assert out_dev.ndead == out_cb.ndead and abs(out_dev.logZ - out_cb.logZ) < 1e-9
+    assert abs(out_dev.logZ) < 4 * out_dev.logZerr
+    for root in ("gdev", "gcb"):
+        line = [l for l in (tmp_path / (root + ".stats")).read_text().splitlines() if l.startswith(" nlike:")][0]
+        counts = [int(x) for x in line.split(":")[1].split()]
+        assert len(counts) == 2 and all(c > 0 for c in counts)
+    a = [l for l in (tmp_path / "gdev.stats").read_text().splitlines() if l.startswith(" nlike:")][0]
+    b = [l for l in (tmp_path / "gcb.stats").read_text().splitlines() if l.startswith(" nlike:")][0]
+    assert a == b
+    # fractions: device likelihoods have equal speeds, so grade 2 gets nint(frac_2 / frac_1 * num_repeats) repeats
+    s2 = pypolychord.PolyChordSettings(D, 0, file_root="gfrac", **dict(kw, grade_frac=[1.0, 0.5]))
+    out = pypolychord.run_polychord(dl.Gaussian(0.5, 0.1), D, 0, s2, dl.UniformPrior(0.0, 1.0))
+    assert abs(out.logZ) < 4 * out.logZerr
+    line = [l for l in (tmp_path / "gfrac.stats").read_text().splitlines() if l.startswith(" nlike:")][0]
+    c = [int(x) for x in line.split(":")[1].split()]
+    assert len(c) == 2 and 0.3 < c[1] / c[0] < 0.8        # 12 repeats in 6-D vs 6 repeats in the 4-D fast subspace
+    # a Python likelihood with fractions: the speeds are timed on the host, the run completes
+    s3 = pypolychord.PolyChordSettings(D, 0, file_root="gtime", **dict(kw, grade_frac=[1.0, 1.0]))
+    out = pypolychord.run_polychord(host_gauss, D, 0, s3, lambda c: c.copy())
+    assert abs(out.logZ) < 4 * out.logZerr
