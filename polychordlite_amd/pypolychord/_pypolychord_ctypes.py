@@ -1,6 +1,8 @@
 """`_pypolychord.run` -- the 37-positional-argument entry of the reference's CPython extension
 (pypolychord/_pypolychord.cpp:119-228, parse format "OOOiiiiiiiiddidiiiiiiiiiiidissO!O!O!i"),
-implemented over the C ABI of libpolychord_hip.so with ctypes.
+implemented over the C ABI of libpolychord_hip.so with ctypes.  The package prefers the compiled module
+`_pypolychord` (pypolychord/_pypolychord_module.cpp, same surface); this one is the binding of choice when no C++
+compiler / Python headers are around, and the cross-check of the compiled one in tests.
 
 Callbacks follow _pypolychord.cpp:29-115: `loglikelihood(theta, phi) -> float` gets numpy views of
 engine-owned buffers (theta read-only, phi written in place), must return a Python float;

@@ -5,7 +5,10 @@ from pathlib import Path
 
 import numpy as np
 
-from . import _pypolychord
+try:                                    # compiled CPython extension (pypolychord/_pypolychord_module.cpp)
+    from . import _pypolychord
+except ImportError:                     # not built: the ctypes binding of the same C entry point
+    from . import _pypolychord_ctypes as _pypolychord
 from .settings import PolyChordSettings  # noqa: F401
 
 

@@ -47,6 +47,31 @@ def test_run_rejects_bad_arguments(tmp_path):
     assert (tmp_path / "clusters").is_dir()              # polychord.py:566-568
 
 
+def test_compiled_extension_surface():
+    """the package runs on the compiled CPython module `_pypolychord` (reference pypolychord/_pypolychord.cpp:119-228):
+    one function `run`, 34 positional arguments in the reference's parse format, the reference's argument checks --
+    all of them made before the engine is entered, so they hold without a GPU"""
+    from polychordlite_amd.pypolychord import polychord as pc
+    m = pc._pypolychord
+    assert m.__file__.endswith(".so") and [n for n in dir(m) if not n.startswith("_")] == ["backend", "run"]
+    base = [lambda t, p: 0.0, lambda c, t: None, lambda *a: None, 4, 0, 10, 4, -1, -1, 0, 0, 1e-3, -1e30, -1, 0.0,
+            0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.36, 1, "chains", "t"]
+    with pytest.raises(ValueError, match="sum to nDims"):            # _pypolychord.cpp:201-204
+        m.run(*base, [1.0], [3], {}, 1)
+    with pytest.raises(ValueError, match="same size"):               # :196-200
+        m.run(*base, [1.0, 2.0], [4], {}, 1)
+    with pytest.raises(TypeError):                                   # "O!" wants a list
+        m.run(*base, (1.0,), [4], {}, 1)
+    with pytest.raises(TypeError, match="list of integers"):         # :190-194
+        m.run(*base, [1.0], [4.5], {}, 1)
+    with pytest.raises(TypeError, match="dict mapping"):             # :205-209
+        m.run(*base, [1.0], [4], {"a": 3}, 1)
+    with pytest.raises(TypeError, match="callable"):
+        m.run(*([3] + base[1:]), [1.0], [4], {}, 1)
+    with pytest.raises(TypeError):                                   # wrong number of positional arguments
+        m.run(*base)
+
+
 def test_builtin_functors_are_plain_callables():
     g = dl.Gaussian(mu=0.5, sigma=0.1, nDerived=2)
     logL, phi = g(np.full(20, 0.5))
@@ -430,3 +455,51 @@ def test_grades_through_the_python_surface(engine, tmp_path):
     s3 = pypolychord.PolyChordSettings(D, 0, file_root="gtime", **dict(kw, grade_frac=[1.0, 1.0]))
     out = pypolychord.run_polychord(host_gauss, D, 0, s3, lambda c: c.copy())
     assert abs(out.logZ) < 4 * out.logZerr
+
+
+@pytest.mark.gpu
+def test_compiled_and_ctypes_bindings_agree(engine, tmp_path):
+    """the compiled `_pypolychord` and the ctypes binding drive the same C entry point: identical dumps, files and
+    exceptions -- Python likelihood with a derived parameter, Python prior, dynamic nlive dict, device functors"""
+    from polychordlite_amd.pypolychord import _pypolychord as comp, _pypolychord_ctypes as ct
+    def like(theta, phi):
+        logL, p = gaussian_likelihood(theta)
+        phi[0] = p[0]
+        return logL
+    def prior(cube, theta):
+        theta[:] = -1.0 + 2.0 * cube
+    res = {}
+    for name, mod in (("comp", comp), ("ct", ct)):
+        got = []
+        mod.run(like, prior, lambda live, dead, w, z, e: got.append((dead.copy(), w.copy(), z, e)), nDims, 1, nlive, 8, -1, -1,
+                False, 0, 1e-3, -1e30, -1, 0.0, True, True, False, False, False, False, True, False, True, False, False,
+                0.36787944117144233, True, str(tmp_path), name, [1.0], [nDims], {-5.0: 40}, 11)
+        res[name] = got
+    assert len(res["comp"]) == len(res["ct"]) >= 3
+    for a, b in zip(res["comp"], res["ct"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert (tmp_path / "comp.stats").read_text() == (tmp_path / "ct.stats").read_text()
+    assert (tmp_path / "comp_dead-birth.txt").read_text() == (tmp_path / "ct_dead-birth.txt").read_text()
+    # read-only views, float check and exception transport (_pypolychord.cpp:35,47-51,219-224)
+    def nosy(theta, phi):
+        assert not theta.flags.writeable and phi.flags.writeable
+        return 1                                                     # not a float
+    with pytest.raises(TypeError, match="must be a float"):
+        comp.run(nosy, prior, lambda *a: None, 3, 0, 20, 3, -1, -1, False, 0, 1e-3, -1e30, -1, 0.0, False, False, False, False,
+                 False, False, False, False, False, False, False, 0.36787944117144233, True, str(tmp_path), "bad", [1.0], [3], {}, 1)
+    class Boom(Exception):
+        pass
+    def bad(theta, phi):
+        raise Boom("boom")
+    with pytest.raises(Boom):
+        comp.run(bad, prior, lambda *a: None, 3, 0, 20, 3, -1, -1, False, 0, 1e-3, -1e30, -1, 0.0, False, False, False, False,
+                 False, False, False, False, False, False, False, 0.36787944117144233, True, str(tmp_path), "bad", [1.0], [3], {}, 1)
+    # device functors resolve to the library's own symbols in both bindings: same run as above tests use
+    outs = []
+    for mod, root in ((comp, "dcomp"), (ct, "dct")):
+        got = []
+        mod.run(dl.Gaussian(0.5, 0.1), dl.UniformPrior(0.0, 1.0), lambda live, dead, w, z, e: got.append(z), 6, 0, 80, 12, -1, -1,
+                False, 0, 1e-3, -1e30, -1, 0.0, False, False, False, False, False, False, True, False, False, False, False,
+                0.36787944117144233, True, str(tmp_path), root, [1.0], [6], {}, 5)
+        outs.append(got[-1])
+    assert outs[0] == outs[1] and abs(outs[0]) < 1.5
