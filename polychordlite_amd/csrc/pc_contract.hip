@@ -42,6 +42,7 @@ struct ConsumeShared {
     int xrows;
     double *gd2; int *gkey; int *ids;                   // [IDG][IDP] partial minima; [nr] cluster of each baby
     int *misc;                                          // small scratch
+    int *sO, *sCS;                                      // nn_slot_owner [Ncap], nn_chain_slot [B] (only when S.nn_valid)
 };
 
 // identify_cluster (run_time_info.f90:913-949) for ALL babies of a chain at once: the cluster of the
@@ -51,14 +52,20 @@ struct ConsumeShared {
 // from the LDS cache H.sX when it fits (updated on every insertion), else from HBM.
 #define PC_IDG 32
 template <int NT>
-__device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int w, const double *blog, double Lg, int nc)
+__device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int w, const double *blog, double Lg, int nc,
+                                   bool only_unresolved = false)
 {
     const int tid = threadIdx.x, D = S.D, nr = S.nr, nT = S.nT;
     constexpr int IDG = (NT >= 1024) ? PC_IDG : 4, IDP = NT / IDG;
-    for (int i = tid; i < nr; i += NT) H.ids[i] = -1;
+    if (!only_unresolved) for (int i = tid; i < nr; i += NT) H.ids[i] = -1;
     if (nc == 1) { __syncthreads(); for (int i = tid; i < nr; i += NT) H.ids[i] = 0; __syncthreads(); return; }
     for (int g0 = 0; g0 < nr; g0 += IDG) {
         __syncthreads();
+        if (only_unresolved) {                          // skip groups that the candidate lists settled completely
+            bool need = false;
+            for (int g = 0; g < IDG && g0 + g < nr; ++g) need = need || (H.ids[g0 + g] == -2);
+            if (!need) continue;
+        }
         for (int e = tid; e < IDG * D; e += NT) {
             const int g = e / D, d = e % D, i = g0 + g;
             H.xbuf[e] = (i < nr) ? S.babies[((size_t)w * nr + i) * nT + d] : 0.0;
@@ -66,7 +73,7 @@ __device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int
         __syncthreads();
         const int g = tid / IDP, p = tid % IDP, i = g0 + g;
         double bd = PC_HUGE; int bk = 0x7fffffff;
-        const bool mine = i < nr && blog[i] > Lg;
+        const bool mine = i < nr && blog[i] > Lg && (!only_unresolved || H.ids[i] == -2);
         const double *x = H.xbuf + (size_t)g * D;
         if (H.xrows >= S.Ncap) {                       // every live coordinate is resident in LDS
             if (mine)
@@ -102,7 +109,7 @@ __device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int
         }
         H.gd2[tid] = bd; H.gkey[tid] = bk;
         __syncthreads();
-        if (tid < IDG && g0 + tid < nr) {
+        if (tid < IDG && g0 + tid < nr && (!only_unresolved || H.ids[g0 + tid] == -2)) {
             double md = PC_HUGE; int mk = 0x7fffffff;
             for (int q = 0; q < IDP; ++q) {
                 const double v = H.gd2[tid * IDP + q]; const int k = H.gkey[tid * IDP + q];
@@ -112,6 +119,133 @@ __device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int
         }
     }
     __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_nn_lists: the nearest-cluster search of a whole nursery, done once by the whole chip.
+//
+// identify_cluster (run_time_info.f90:913-949) asks, for every baby, for the nearest live point AT THE MOMENT ITS
+// CHAIN IS CONSUMED; between the consumption of two chains the live set changes by one point, so the reference's
+// answer is a property of an evolving set and the serial contraction used to recompute N x D distances per baby on one
+// CU.  But every point that can be alive then is known now (T0): the live points of T0 and the last babies of the
+// chains consumed before this one (reverse nursery order: chains w' > w).  One workgroup per unconsumed chain ranks
+// that superset for each of its babies and keeps the PC_NN_K nearest, ascending; the contraction then only walks the
+// list for the first entry that is still / already alive (exact: everything nearer is dead), and falls back to the
+// full search when a list is exhausted.
+//   256 threads = 32 babies x 8 partial scanners; points are staged through an LDS tile.
+// ------------------------------------------------------------------------------------------
+#define NNL_G 32
+#define NNL_P 8
+__global__ __launch_bounds__(256) void k_nn_lists(PcState S, int nleft, int tile_pts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, D = S.D, nr = S.nr, nT = S.nT, Ncap = S.Ncap;
+    const int w = blockIdx.x;                         // chain, w < nleft = entries still in the nursery
+    double *xb = (double *)smem;                      // [NNL_G][D] babies of the group
+    double *pts = xb + (size_t)NNL_G * D;             // [tile_pts][D]
+    double *md = pts + (size_t)tile_pts * D;          // [256][PC_NN_K] merge buffer
+    int *mc = (int *)(md + 256 * PC_NN_K);            // [256][PC_NN_K]
+    int *pcode = mc + 256 * PC_NN_K;                  // [tile_pts] code of each staged point, PC_NN_NONE = skip
+    if (w == 0) {                                     // liveness bookkeeping starts now
+        for (int s = tid; s < Ncap; s += 256) S.nn_slot_owner[s] = -1;
+        for (int c = tid; c < S.B; c += 256) S.nn_chain_slot[c] = -1;
+    }
+    const int nc = S.ctl->ncluster;
+    double Lg0 = S.logLp[0];
+    for (int c = 1; c < nc; ++c) Lg0 = fmin(Lg0, S.logLp[c]);
+    const double *blog = S.baby_logL + (size_t)w * nr;
+    const int ncand = nleft - 1 - w;                  // chains w+1 .. nleft-1 are consumed before w
+    const int npts = Ncap + ncand;
+    const int g = tid / NNL_P, p = tid % NNL_P;
+    for (int g0 = 0; g0 < nr; g0 += NNL_G) {
+        __syncthreads();
+        for (int e = tid; e < NNL_G * D; e += 256) {
+            const int gg = e / D, d = e % D, i = g0 + gg;
+            xb[e] = (i < nr) ? S.babies[((size_t)w * nr + i) * nT + d] : 0.0;
+        }
+        const int i = g0 + g;
+        const bool mine = i < nr && blog[i] > Lg0;    // the contour only rises: others never need a cluster
+        double bd[PC_NN_K]; int bc[PC_NN_K];
+#pragma unroll
+        for (int k = 0; k < PC_NN_K; ++k) { bd[k] = PC_HUGE; bc[k] = PC_NN_NONE; }
+        for (int t0 = 0; t0 < npts; t0 += tile_pts) {
+            const int tn = min(tile_pts, npts - t0);
+            __syncthreads();
+            for (int q = tid; q < tn; q += 256) {
+                const int gi = t0 + q;
+                int code = PC_NN_NONE;
+                if (gi < Ncap) { if (S.live_cluster[gi] >= 0) code = gi; }
+                else code = -(1 + (w + 1 + (gi - Ncap)));
+                pcode[q] = code;
+            }
+            __syncthreads();
+            for (int e = tid; e < tn * D; e += 256) {
+                const int q = e / D, d = e % D, code = pcode[q];
+                double v = 0.0;
+                if (code >= 0) { const int src = S.slot_src[code]; v = (src >= 0) ? S.babies[((size_t)src * nr + (nr - 1)) * nT + d] : S.live[(size_t)code * nT + d]; }
+                else if (code != PC_NN_NONE) v = S.babies[((size_t)(-(1 + code)) * nr + (nr - 1)) * nT + d];
+                pts[e] = v;
+            }
+            __syncthreads();
+            if (mine) {
+                const double *x = xb + (size_t)g * D;
+                for (int q = p; q < tn; q += NNL_P) {
+                    const int code = pcode[q];
+                    if (code == PC_NN_NONE) continue;
+                    const double *y = pts + (size_t)q * D;
+                    double d2 = 0.0;
+                    for (int d = 0; d < D; ++d) { const double t = x[d] - y[d]; d2 += t * t; }
+                    if (d2 < bd[PC_NN_K - 1]) {       // sorted insertion, registers only
+                        double cd = d2; int cc = code;
+#pragma unroll
+                        for (int k = 0; k < PC_NN_K; ++k) {
+                            const bool sw = cd < bd[k];
+                            const double td = sw ? bd[k] : cd; const int tc = sw ? bc[k] : cc;
+                            bd[k] = sw ? cd : bd[k]; bc[k] = sw ? cc : bc[k];
+                            cd = td; cc = tc;
+                        }
+                    }
+                }
+            }
+        }
+        // merge the NNL_P partial lists of a baby: each is sorted, NNL_P-way pick by the first scanner
+#pragma unroll
+        for (int k = 0; k < PC_NN_K; ++k) { md[tid * PC_NN_K + k] = bd[k]; mc[tid * PC_NN_K + k] = bc[k]; }
+        __syncthreads();
+        if (p == 0 && i < nr) {
+            int head[NNL_P];
+#pragma unroll
+            for (int q = 0; q < NNL_P; ++q) head[q] = 0;
+            int out[PC_NN_K];
+#pragma unroll
+            for (int k = 0; k < PC_NN_K; ++k) {
+                double best = PC_HUGE; int bq = -1;
+#pragma unroll
+                for (int q = 0; q < NNL_P; ++q) {
+                    const double v = (head[q] < PC_NN_K) ? md[(g * NNL_P + q) * PC_NN_K + head[q]] : PC_HUGE;
+                    if (v < best) { best = v; bq = q; }
+                }
+                int code = PC_NN_NONE;
+#pragma unroll
+                for (int q = 0; q < NNL_P; ++q) if (q == bq) { code = mc[(g * NNL_P + q) * PC_NN_K + head[q]]; head[q]++; }
+                out[k] = mine ? code : PC_NN_NONE;
+            }
+            int4 *dst = (int4 *)(S.nn_list + ((size_t)w * nr + i) * PC_NN_K);
+            dst[0] = make_int4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_int4(out[4], out[5], out[6], out[7]);
+        }
+    }
+}
+
+extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, hipStream_t st)
+{
+    if (nleft <= 0) return;
+    int tile = (int)(24576 / (sizeof(double) * S->D));            // ~24 KB of coordinates per tile
+    tile = tile < 16 ? 16 : (tile > 512 ? 512 : tile);
+    const size_t sh = sizeof(double) * ((size_t)NNL_G * S->D + (size_t)tile * S->D + 256 * PC_NN_K) + sizeof(int) * (256 * PC_NN_K + tile) + 64;
+    static size_t done = 0;
+    if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    hipLaunchKernelGGL(k_nn_lists, dim3(nleft), dim3(256), sh, st, *S, nleft, tile);
 }
 
 // dynamic nlive target (run_time_info.f90:766-771)
@@ -147,12 +281,19 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         H.cUid = (unsigned *)p; p += sizeof(unsigned) * maxc;
         H.misc = (int *)p; p += sizeof(int) * 8;
         H.gkey = (int *)p; p += sizeof(int) * NT;
-        H.ids = (int *)p;
+        H.ids = (int *)p; p += sizeof(int) * nr;
+        H.sO = (int *)p; p += sizeof(int) * Ncap;
+        H.sCS = (int *)p;
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
     for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
     if (H.xrows >= Ncap) for (int e = tid; e < Ncap * S.D; e += NT) H.sX[e] = S.live[(size_t)(e / S.D) * nT + e % S.D];
+    const bool nn = S.nn_valid != 0 && !final_mode;
+    if (nn) {
+        for (int s = tid; s < Ncap; s += NT) H.sO[s] = S.nn_slot_owner[s];
+        for (int c = tid; c < S.B; c += NT) H.sCS[c] = S.nn_chain_slot[c];
+    }
     int nc = ctl->ncluster;
     for (int c = tid; c < maxc; c += NT) {
         H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
@@ -170,16 +311,36 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     double live_logZ_val = S.logzero;
     const double log2v = log(2.0);
     __syncthreads();
+    // Reductions over the clusters, one cluster per lane.  Every wave computes them for itself from LDS: no barrier,
+    // no broadcast (a serial loop over ~40 clusters with an exp each cost more than the rest of an iteration).
+    auto lse_logXp = [&]() -> double {                 // log sum_p X_p
+        if (nc == 1) return H.cLogXp[0];
+        double m = -PC_HUGE;
+        for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; m = fmax(m, c < nc ? H.cLogXp[c] : -PC_HUGE); }
+        m = wave_max(m);
+        double sum = 0.0;
+        for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; sum += (c < nc) ? exp(H.cLogXp[c] - m) : 0.0; }
+        return m + log(wave_sum<4>(sum));
+    };
+    auto lowest_contour = [&]() -> vk_t {              // (min_p logL_p, first cluster that has it): minpos
+        if (nc == 1) return vk_t{H.cLogLp[0], 0};
+        vk_t b{PC_HUGE, 0x7fffffff};
+        for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; if (c < nc) b = vk_min(b, vk_t{H.cLogLp[c], c}); }
+        return wave_argmin(b);
+    };
 
     // ================================================================================
     // one death: delete_outermost_point (run_time_info.f90:789-817) without the row copy
     // ================================================================================
     int last_cd = -1, last_pos_del = -1;
+    double lx_now = 0.0; bool lx_known = false;        // log sum_p X_p: only a death changes it
+    int n_total = 0;                                   // live points over all clusters
+    for (int c = 0; c < nc; ++c) n_total += H.cN[c];
     auto kill_lowest = [&](int plan_w) {
         // cluster with the lowest contour (minpos: first minimum)
-        int cd = 0;
-        for (int c = 1; c < nc; ++c) if (H.cLogLp[c] < H.cLogLp[cd]) cd = c;
+        const int cd = lowest_contour().k;
         const int n = H.cN[cd];
+        n_total--;
         const double L = H.cLogLp[cd];
         const int slot_del = H.cMinSlot[cd];
         const int pos_del = H.sP[slot_del];
@@ -221,6 +382,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             H.cThr[cd] = L;
             H.cN[cd] = n - 1;
             H.sC[slot_del] = -1;
+            if (nn) H.sO[slot_del] = -2;
         }
         for (int q = tid; q < nc; q += NT) {
             if (q == cd) { if (true) S.XpXq[(size_t)cd * maxc + cd] = XX + l0 - l2; }
@@ -251,11 +413,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         } else if (tid == 0) { H.cMinSlot[cd] = -1; H.cLogLp[cd] = PC_HUGE; }
         __syncthreads();
         // posterior-stack columns (calculate.f90:53-79): volume after the update, logZ after the update
-        double mX = H.cLogXp[0];
-        for (int c = 1; c < nc; ++c) mX = fmax(mX, H.cLogXp[c]);
-        double sX = 0.0;
-        for (int c = 0; c < nc; ++c) sX += exp(H.cLogXp[c] - mX);
-        const double lseX = (nc == 1) ? H.cLogXp[0] : mX + log(sX);
+        const double lseX = lse_logXp();
+        lx_now = lseX; lx_known = true;
         if (ndead >= S.Dcap) { error = PC_ERR_DEAD_CAP; status = PC_ST_ERROR; }
         if (status != PC_ST_ERROR) {
             if (plan_w >= 0) {
@@ -336,7 +495,19 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // ================================================================================
     // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
     // ================================================================================
-    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0;
+    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0, cyF = 0;
+    if (!final_mode && nc > 1) {
+        // The nursery's records were written by other XCDs: a first touch costs 1-2 us, and the loop below would pay
+        // that once per chain and array, serially.  Touch everything it will read now, in bulk, so that the loop's
+        // loads hit this XCD's L2 (a few hundred KB at most).
+        auto touch = [&](const void *base, size_t bytes) {
+            const char *b = (const char *)base;
+            for (size_t o = (size_t)tid * 64; o < bytes; o += (size_t)NT * 64) { const int v = *(const volatile int *)(b + o); asm volatile("" :: "v"(v)); }
+        };
+        touch(S.baby_logL, sizeof(double) * (size_t)i_nursery * nr);
+        touch(S.ch_nlike, sizeof(int) * (size_t)i_nursery); touch(S.ch_epoch, sizeof(int) * (size_t)i_nursery); touch(S.ch_cluster, sizeof(int) * (size_t)i_nursery);
+        if (nn) touch(S.nn_list, sizeof(int) * (size_t)i_nursery * nr * PC_NN_K);
+    }
     while (!final_mode && status == PC_ST_RUNNING) {
         const long long q0 = clock64();
         // ---- more_samples_needed (nested_sampling.F90:514-543) + failures guard (:239)
@@ -346,21 +517,18 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         else if (S.use_prec) {
             // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally.
             // One cluster per lane, log-sum-exp over the wave; the other waves pick the result up from LDS.
-            if (tid < 64) {
+            {   // every wave for itself (the state it reads was published before the last barrier of the iteration)
                 double mxv = -PC_HUGE, acc = 0.0;
                 for (int c0 = 0; c0 < nc; c0 += 64) {
-                    const int c = c0 + tid;
-                    const double term = (c < nc && H.cN[c] > 0) ? H.cLseRef[c] + log(H.cLseSum[c]) - log((double)H.cN[c] + 0.0) + H.cLogXp[c] : -PC_HUGE;
+                    const int c = c0 + lane;
+                    const double term = (c < nc && H.cN[c] > 0) ? H.cLseRef[c] + log(H.cLseSum[c] / ((double)H.cN[c] + 0.0)) + H.cLogXp[c] : -PC_HUGE;
                     const double m2 = fmax(mxv, wave_max(term));
                     acc = acc * exp(mxv - m2) + wave_sum<4>(term > -PC_HUGE ? exp(term - m2) : 0.0);
                     mxv = m2;
                 }
                 const double v = (acc > 0.0) ? mxv + log(acc) : S.logzero;
-                if (tid == 0) H.jobres[0] = pc_logaddexp(S.logzero, v);
+                live_logZ_val = pc_logaddexp(S.logzero, v);
             }
-            __syncthreads();
-            live_logZ_val = H.jobres[0];
-            __syncthreads();
             if (live_logZ_val < S.log_prec + logZ) more = false;
         }
         if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
@@ -369,16 +537,15 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         const long long q1 = clock64(); cyT += q1 - q0;
         const int w = i_nursery - 1;
         i_nursery--;
-        nlike += S.ch_nlike[w];
+        const int w_nlike = S.ch_nlike[w], w_epoch = S.ch_epoch[w], ca = S.ch_cluster[w];
+        nlike += w_nlike;
         niter++;
         if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_count = 0; S.plan[w].contour = S.logzero; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
         __syncthreads();
-        if (S.ch_epoch[w] != epoch) continue;           // nested_sampling.F90:313 epoch guard
+        if (w_epoch != epoch) continue;                 // nested_sampling.F90:313 epoch guard
 
-        const int ca = S.ch_cluster[w];
         // ---- replace_point (run_time_info.f90:716-787)
-        double Lg = H.cLogLp[0];
-        for (int c = 1; c < nc; ++c) Lg = fmin(Lg, H.cLogLp[c]);
+        const double Lg = lowest_contour().v;
         const double *blog = S.baby_logL + (size_t)w * nr;
         if (tid == 0) S.plan[w].contour = Lg;
         // phantoms: babies 1..nr-1 that beat the global contour and fall in the seed cluster's cell
@@ -396,12 +563,42 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
             }
         } else {
-            block_identify_all<NT>(S, H, w, blog, Lg, nc);
-            for (int i = 0; i < nr - 1; ++i)
-                if (blog[i] > Lg && H.ids[i] == ca) {
-                    if (tid == 0) S.plan[w].ph_mask[(i >> 6)] |= (1ull << (i & 63));
-                    nph_add++;
+            if (nn) {
+                // identify_cluster from the candidate lists: the first entry that is alive NOW is the nearest live
+                // point (everything nearer in the superset is dead or not yet born); one baby per thread
+                int unresolved = 0;
+                for (int i = tid; i < nr; i += NT) {
+                    int res = -1;
+                    if (blog[i] > Lg) {
+                        res = -2;
+                        const int4 *L4 = (const int4 *)(S.nn_list + ((size_t)w * nr + i) * PC_NN_K);
+                        const int4 a = L4[0], b = L4[1];
+                        const int codes[PC_NN_K] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+                        for (int k = 0; k < PC_NN_K; ++k) {
+                            const int code = codes[k];
+                            if (res != -2 || code == PC_NN_NONE) continue;
+                            const int s = code >= 0 ? code : H.sCS[-(1 + code)];
+                            const bool alive = code >= 0 ? (H.sO[s] == -1) : (s >= 0 && H.sO[s] == -(1 + code));
+                            if (alive) res = H.sC[s];
+                        }
+                        if (res == -2) unresolved = 1;
+                    }
+                    H.ids[i] = res;
                 }
+                if (__syncthreads_or(unresolved)) { cyF++; block_identify_all<NT>(S, H, w, blog, Lg, nc, true); }
+            } else block_identify_all<NT>(S, H, w, blog, Lg, nc);
+            for (int base = 0; base < nr - 1; base += NT) {
+                const int i = base + tid;
+                const bool f = (i < nr - 1) && (blog[i] > Lg) && (H.ids[i] == ca);
+                const unsigned long long m = __ballot(f);
+                if (lane == 0 && m) S.plan[w].ph_mask[(base >> 6) + (tid >> 6)] = m;
+                if (NT == 64) nph_add += __popcll(m);
+            }
+            if (NT > 64) {   // count after the masks are visible
+                __syncthreads();
+                for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
+            }
         }
         const long long q2 = clock64(); cyI += q2 - q1;
         if (nph + nph_add > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
@@ -414,8 +611,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             const int id = (nc == 1) ? 0 : H.ids[nr - 1];
             if (id == ca) {
                 const int nl = nlive_target(S, Lg);
-                int tot = 0;
-                for (int c = 0; c < nc; ++c) tot += H.cN[c];
+                int tot = n_total;
                 int free_slot = -1;
                 if (tot >= (nl > 1 ? nl : 1)) { free_slot = kill_lowest(w); replaced = true; tot--; }
                 if (status == PC_ST_ERROR) break;
@@ -439,7 +635,9 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                         else if (Llast > H.cLseRef[ca]) { H.cLseSum[ca] = H.cLseSum[ca] * exp(H.cLseRef[ca] - Llast) + 1.0; H.cLseRef[ca] = Llast; }
                         else H.cLseSum[ca] += exp(Llast - H.cLseRef[ca]);
                         S.slot_src[free_slot] = w;
+                        if (nn) { H.sO[free_slot] = w; H.sCS[w] = free_slot; }
                     }
+                    n_total++;
                     if (H.xrows >= Ncap) for (int d = tid; d < S.D; d += NT) H.sX[(size_t)free_slot * S.D + d] = S.babies[((size_t)w * nr + nr - 1) * nT + d];
                     __syncthreads();
                     // engine rule (oracle keyed mode): a point that replaces a death of its own cluster
@@ -467,11 +665,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         const long long q3 = clock64(); cyK += q3 - q2;
 
         // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
-        double mX = H.cLogXp[0];
-        for (int c = 1; c < nc; ++c) mX = fmax(mX, H.cLogXp[c]);
-        double sX = 0.0;
-        for (int c = 0; c < nc; ++c) sX += exp(H.cLogXp[c] - mX);
-        const double lx = (nc == 1) ? H.cLogXp[0] : mX + log(sX);
+        if (!lx_known) { lx_now = lse_logXp(); lx_known = true; }
+        const double lx = lx_now;
         const bool update = lx <= lx_last + S.log_cf;
         if (update) lx_last = lx;
         if (drop_empty_cluster()) epoch++;
@@ -484,6 +679,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     __syncthreads();
     for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
     for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
+    if (nn) {
+        for (int s = tid; s < Ncap; s += NT) S.nn_slot_owner[s] = H.sO[s];
+        for (int c = tid; c < S.B; c += NT) S.nn_chain_slot[c] = H.sCS[c];
+    }
     for (int c = tid; c < maxc; c += NT) {
         S.logLp[c] = H.cLogLp[c]; S.logXp[c] = H.cLogXp[c]; S.logZp[c] = H.cLogZp[c]; S.logZXp[c] = H.cLogZXp[c];
         S.logZp2[c] = H.cLogZp2[c]; S.logZpXp[c] = H.cLogZpXp[c]; S.lse_ref[c] = H.cLseRef[c]; S.lse_sum[c] = H.cLseSum[c];
@@ -495,7 +694,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
-        ctl->dbg[0] += cyT; ctl->dbg[1] += cyI; ctl->dbg[2] += cyK; ctl->dbg[3] += cyE;
+        ctl->dbg[0] += cyT; ctl->dbg[1] += cyI; ctl->dbg[2] += cyK; ctl->dbg[3] += cyE; ctl->dbg[4] += cyF;
     }
 }
 
@@ -1042,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const d
 static size_t consume_lds(const PcState *S, int NT, int xrows)
 {
     return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + 2 * NT + (size_t)S->D * PC_IDG + (size_t)xrows * S->D) +
-           sizeof(vk_t) * 16 + sizeof(int) * (2 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8 + NT + S->nr) + 64;
+           sizeof(vk_t) * 16 + sizeof(int) * (3 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8 + NT + S->nr + (size_t)S->B) + 64;
 }
 
 extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hipStream_t st)

@@ -25,6 +25,7 @@ int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipSt
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
+void pc_launch_nn_lists(const PcState *, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
 int pc_fast_fits(const PcState *);
 int pc_par_fits(const PcState *);
@@ -358,6 +359,10 @@ struct Engine {
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         if (S.ngrade > 1) { S.ch_nlike_g = dalloc<int>((size_t)B * PC_MAX_GRADE); h_nlike_g.assign((size_t)B * PC_MAX_GRADE, 0); }
+        S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_valid = 0;
+        if (c.do_clustering) {      // candidate lists of the nearest-cluster search (k_nn_lists)
+            S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
+        }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
@@ -1039,6 +1044,7 @@ struct Engine {
         auto t1 = clk::now();
         unsigned batch = resume_batch0;               // fresh counter-RNG streams after a resume
         bool sort_valid = false;
+        int nursery_left = 0;
         const int wide = 0;
         long long nlike_dev = h_ctl->nlike;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
@@ -1060,24 +1066,36 @@ struct Engine {
                 kt.end(KT_SLICE, e1);
                 if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
                 batch++; tm.batches++;
+                S.nn_valid = 0; nursery_left = B;
             }
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
             if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
-                rc2 = 0;
+                rc2 = 0; S.nn_valid = 0;                     // (the one-cluster kernels do not keep the list bookkeeping)
                 if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }
                 rc2 = rc2 || pc_launch_consume_par(&S, st);      // also lays out the phantoms
             }
-            else if (use_fast) { sort_valid = false; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
-            else { sort_valid = false; rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st); }
+            else if (use_fast) { sort_valid = false; S.nn_valid = 0; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
+            else {
+                sort_valid = false;
+                // several clusters: rank the possible nearest neighbours of every baby still in the nursery once, on
+                // the whole chip; the serial contraction then walks short lists instead of searching the live set
+                static const bool nn_off = std::getenv("PC_NN_LISTS_OFF") != nullptr;
+                if (h_ctl->ncluster > 1 && S.nn_list && !S.nn_valid && !nn_off && !S.seq_mode && nursery_left > 1) {
+                    pc_launch_nn_lists(&S, nursery_left, st);
+                    S.nn_valid = 1;
+                }
+                rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
+            }
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
             kt.end(KT_CONSUME, e2);
             hipEvent_t e3 = kt.begin(KT_APPLY);
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             read_ctl();
+            nursery_left = h_ctl->i_nursery;
             tally_grades();
             stream_dead();
             tm.rounds++;
@@ -1120,7 +1138,7 @@ struct Engine {
         out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
         for (int k = 0; k < KT_N; ++k) { out->k_time_s[k] = kt.total_ms[k] * 1e-3; out->k_launches[k] = kt.launches[k]; }
         (void)nlike_dev;
-        if (cfg.feedback >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3]);
+        if (cfg.feedback >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles, %lld list fallbacks\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4]);
         if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg par: stage+search %lld rank-sort %lld accept %lld merge+slots %lld evidence %lld triggers %lld publish %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4], h_ctl->dbg[5], h_ctl->dbg[6]);
         if (cfg.feedback == 4) std::fprintf(stderr, "polychord_hip dbg7 %lld\n", h_ctl->dbg[7]);
         if (cfg.feedback == 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) accept-steps %lld (%lld) ins-rescan %lld (%lld) reject-steps cycles %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
@@ -1176,7 +1194,7 @@ struct Engine {
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
                        &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
-        dfree(S.ch_nlike_g);
+        dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);

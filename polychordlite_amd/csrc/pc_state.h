@@ -38,6 +38,8 @@ struct PcCtl {                   // written by the consume kernel, read by the h
 };
 
 #define PC_MAX_GRADE 8
+#define PC_NN_K 8
+#define PC_NN_NONE (-2147483647 - 1)
 
 struct PcPlan {                  // one record per nursery chain, written by the consume kernel
     int dead_idx;                // index in dead[] or -1
@@ -108,6 +110,14 @@ struct PcState {
     int ngrade, nb_total; unsigned n_dev;
     int g_off[PC_MAX_GRADE], g_nr[PC_MAX_GRADE], g_nb[PC_MAX_GRADE], g_col0[PC_MAX_GRADE], g_e0[PC_MAX_GRADE];
     int *ch_nlike_g;             // [B][PC_MAX_GRADE] evaluations per grade of each chain (only when ngrade > 1)
+    // ---- nearest-neighbour candidate lists for identify_cluster (run_time_info.f90:913-949), built once per nursery by
+    //      the whole chip (k_nn_lists) at a moment T0: for every baby of every unconsumed chain the PC_NN_K nearest points
+    //      among the live set at T0 and the last babies of the chains consumed before its own, ascending.  Entry >= 0:
+    //      live slot as occupied at T0; entry < 0: -(1 + chain) whose last baby may have entered since; PC_NN_NONE: end.
+    int *nn_list;                // [B][nr][PC_NN_K]
+    int *nn_slot_owner;          // [Ncap] -1: occupant of T0 still there; -2: emptied since; w >= 0: last baby of chain w
+    int *nn_chain_slot;          // [B] slot the chain's last baby went to since T0, or -1
+    int nn_valid;                // set by the host for the launches after T0 of the same nursery
     int ablate;                  // dev timing hook (bit mask), 0 in production
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
