@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // ================================================================================
     // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
     // ================================================================================
-    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0, cyF = 0;
+    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0, cyF = 0, cyW = 0;
     if (!final_mode && nc > 1) {
         // The nursery's records were written by other XCDs: a first touch costs 1-2 us, and the loop below would pay
         // that once per chain and array, serially.  Touch everything it will read now, in bulk, so that the loop's
@@ -586,18 +586,34 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                     }
                     H.ids[i] = res;
                 }
+                cyW++;
                 if (__syncthreads_or(unresolved)) { cyF++; block_identify_all<NT>(S, H, w, blog, Lg, nc, true); }
             } else block_identify_all<NT>(S, H, w, blog, Lg, nc);
-            for (int base = 0; base < nr - 1; base += NT) {
-                const int i = base + tid;
-                const bool f = (i < nr - 1) && (blog[i] > Lg) && (H.ids[i] == ca);
+            if (NT > 64 && nr <= NT) {
+                // the masks of the 16 waves meet in LDS (scratch of the search); a store to the plan followed by a
+                // load of the same words would cost a global round trip per chain
+                const bool f = (tid < nr - 1) && (blog[tid] > Lg) && (H.ids[tid] == ca);
                 const unsigned long long m = __ballot(f);
-                if (lane == 0 && m) S.plan[w].ph_mask[(base >> 6) + (tid >> 6)] = m;
-                if (NT == 64) nph_add += __popcll(m);
-            }
-            if (NT > 64) {   // count after the masks are visible
+                if (lane == 0) { H.gkey[2 * (tid >> 6)] = (int)(unsigned)m; H.gkey[2 * (tid >> 6) + 1] = (int)(unsigned)(m >> 32); }
                 __syncthreads();
-                for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
+                for (int q = 0; q < (nr + 62) / 64; ++q) nph_add += __popc((unsigned)H.gkey[2 * q]) + __popc((unsigned)H.gkey[2 * q + 1]);
+                if (tid < PC_MASK_WORDS && tid < (nr + 62) / 64) {
+                    const unsigned long long mm = ((unsigned long long)(unsigned)H.gkey[2 * tid + 1] << 32) | (unsigned)H.gkey[2 * tid];
+                    if (mm) S.plan[w].ph_mask[tid] = mm;
+                }
+                __syncthreads();                       // gkey is reused by the next search
+            } else {
+                for (int base = 0; base < nr - 1; base += NT) {
+                    const int i = base + tid;
+                    const bool f = (i < nr - 1) && (blog[i] > Lg) && (H.ids[i] == ca);
+                    const unsigned long long m = __ballot(f);
+                    if (lane == 0 && m) S.plan[w].ph_mask[(base >> 6) + (tid >> 6)] = m;
+                    if (NT == 64) nph_add += __popcll(m);
+                }
+                if (NT > 64) {   // count after the masks are visible
+                    __syncthreads();
+                    for (int m = 0; m < (nr + 62) / 64; ++m) nph_add += __popcll(S.plan[w].ph_mask[m]);
+                }
             }
         }
         const long long q2 = clock64(); cyI += q2 - q1;
@@ -694,7 +710,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
-        ctl->dbg[0] += cyT; ctl->dbg[1] += cyI; ctl->dbg[2] += cyK; ctl->dbg[3] += cyE; ctl->dbg[4] += cyF;
+        ctl->gen_cyc[0] += cyT; ctl->gen_cyc[1] += cyI; ctl->gen_cyc[2] += cyK; ctl->gen_cyc[3] += cyE; ctl->nn_walks += cyW; ctl->nn_fallbacks += cyF;
     }
 }
 

@@ -35,6 +35,8 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     double live_logZ;            // last evaluated termination estimate
     unsigned long long seq;      // seq_mode: uniforms consumed so far
     long long dbg[8];            // developer cycle counters of the contraction kernel
+    long long gen_cyc[4];        // general contraction kernel: cycles in termination test / identify / kill+add / tail
+    long long nn_walks, nn_fallbacks;   // chains identified from the candidate lists / of those, chains that needed the full search
 };
 
 #define PC_MAX_GRADE 8
