@@ -650,16 +650,20 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 // SPECIAL = false is the production kernel.  SPECIAL = true adds the two rare modes, both decided at run time:
 // more than one parameter grade (the evaluations of a slice are booked to the grade of its direction) and the
 // sequential-stream test mode (every draw taken from ONE running stream in the reference's program order).
-template <int DPL, int NROWS, bool SPECIAL>
-__global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
+// WPB = chains (wavefronts) per workgroup.  One, except for the correlated Gaussian with its inverse covariance in LDS:
+// an 80 KB matrix per chain left one wave per CU; WPB chains share one copy (every barrier below is executed the same
+// number of times by every chain: per slice, never per likelihood evaluation).
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *ybuf = (double *)smem;                 // [D] (corr gaussian only)
+    const int lane = threadIdx.x & 63, wv = (WPB > 1) ? (int)(threadIdx.x >> 6) : 0, chain = blockIdx.x * WPB + wv;
+    const size_t per_wave = ((size_t)S.D + S.nr + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0) + 1) & ~(size_t)1;   // doubles
+    double *ybuf = (double *)smem + (size_t)wv * per_wave;   // [D] (corr gaussian only)
     int *sdeck = (int *)(ybuf + S.D);              // [nr] deck, only used when nr > 64
     int *sj = sdeck + S.nr;                        // [nr]
     double *tbuf = ybuf + S.D + S.nr;              // [nr][D+1] theta of every baby (when it fits: phi_lds)
-    double *Mlds = tbuf + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0);   // [D][D] inverse covariance, transposed (mat_lds)
-    const int lane = threadIdx.x, chain = blockIdx.x;
+    double *Mlds = (double *)smem + (size_t)WPB * per_wave;  // [D][D] inverse covariance, transposed (mat_lds), shared
     const int D = S.D, nr = S.nr, nT = S.nT;
     const double logzero = S.logzero;
     const bool seq_mode = SPECIAL && S.seq_mode != 0, graded = SPECIAL && S.ngrade > 1;
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(64) void k_slice(PcState S, unsigned batch, int phi
     };
     if (corr) {
         if (mat_lds) {
-            for (int e = lane; e < D * D; e += 64) Mlds[e] = S.like.invcov[e];
+            for (int e = threadIdx.x; e < D * D; e += 64 * WPB) Mlds[e] = S.like.invcov[e];
             __syncthreads();
             Mt = Mlds;
         }
@@ -1020,8 +1024,16 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     size_t sh = sh0 + (phi_lds ? tb : 0);
     const size_t mb = sizeof(double) * (size_t)S->D * S->D;
     const int mat_lds = (S->like.kind == PC_LIKE_CORR_GAUSSIAN && sh + mb <= 150 * 1024) ? 1 : 0;
-    if (mat_lds) sh += mb;
     const int D = S->D;
+    // four chains per workgroup around one LDS copy of the inverse covariance (65 <= nDims <= 128)
+    static const bool wpb_off = std::getenv("PC_SLICE_WPB_OFF") != nullptr;
+    if (mat_lds && D > 64 && D <= 128 && nchains % 4 == 0 && S->ngrade <= 1 && !S->seq_mode && !wpb_off && 4 * sh + mb <= 150 * 1024) {
+        const size_t sh4 = 4 * sh + mb;
+        if (sh4 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<2, 4, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+        hipLaunchKernelGGL((k_slice<2, 4, false, 4>), dim3(nchains / 4), dim3(256), sh4, st, *S, batch, phi_lds, mat_lds);
+        return 0;
+    }
+    if (mat_lds) sh += mb;
 #define PC_SLICE_LAUNCH1(DPL, NROWS, GR) { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, GR>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
