@@ -396,16 +396,22 @@ template <int HV>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
     constexpr int DP = 4 * HV, NTQ = 16 * HV;
-    __shared__ __attribute__((aligned(16))) double Qb[2][DP];         // pivot, double buffered
-    __shared__ __attribute__((aligned(16))) double Lt[HV][DP];        // HV rows of the Cholesky factor
+    // LDS rows are stored as four coordinate blocks of HV + 2 doubles: the four threads of a vector read their blocks
+    // at the same time, and blocks exactly HV doubles (a multiple of 256 B) apart would all start in the same bank
+    constexpr int HP = HV + 2, DPP = 4 * HP;
+    __shared__ __attribute__((aligned(16))) double Qb[2][DPP];        // pivot, double buffered
+    __shared__ __attribute__((aligned(16))) double Lt[HV][DPP];       // HV rows of the Cholesky factor
     __shared__ int sh[2];
     const int D = S.D, nr = S.nr;
     const int tid = threadIdx.x, chain = blockIdx.y;
-    const int i = tid >> 2, h = tid & 3, d0 = HV * h;                 // my vector, my coordinate block
+    const int i = tid >> 2, h = tid & 3, d0 = HV * h, p0 = HP * h;    // my vector, my coordinate block (p0: in LDS rows)
     int grade, basis;                                                 // chordal_sampling.f90:119-130, see k_nhats
     pc_grade_of_basis(S, blockIdx.x, grade, basis);
     const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
     const bool active = i < Dg;
+#ifdef NHATSQ_DBG
+    long long qc[6]; qc[0] = clock64();
+#endif
     if (tid == 0) {
         int sel, slot;
         select_seed(S, batch, chain, sel, slot);
@@ -447,6 +453,9 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             }
         }
     }
+#ifdef NHATSQ_DBG
+    qc[1] = clock64();
+#endif
 #define PC_DOT32(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
         _Pragma("unroll") for (int e = 0; e < HV; e += 4) { \
             p0_ += (A)[e] * (B)[e]; p1_ += (A)[e + 1] * (B)[e + 1]; p2_ += (A)[e + 2] * (B)[e + 2]; p3_ += (A)[e + 3] * (B)[e + 3]; } \
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     }
     if (i == 0) {
 #pragma unroll
-        for (int e = 0; e < HV; ++e) Qb[0][d0 + e] = v[e];
+        for (int e = 0; e < HV; ++e) Qb[0][p0 + e] = v[e];
     }
     __syncthreads();
     // first tile of the Cholesky factor: requested now, consumed after the loop
@@ -473,11 +482,14 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             lpre[x] = (y < HV * DP && r < D && b < D) ? Lc0[(size_t)r * D + b] : 0.0;
         }
     }
+#ifdef NHATSQ_DBG
+    qc[2] = clock64();
+#endif
     // Gram-Schmidt (random_utils.F90:391-399): same projections as before, pivot unnormalised
     for (int j = 0; j < Dg; ++j) {
         double q[HV];
 #pragma unroll
-        for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][d0 + e];
+        for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][p0 + e];
         double qq, dv;
         PC_DOT32(qq, q, q)
         PC_DOT32(dv, q, v)
@@ -491,11 +503,14 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             for (int e = 0; e < HV; ++e) v[e] -= cproj * q[e];
             if (i == j + 1) {
 #pragma unroll
-                for (int e = 0; e < HV; ++e) Qb[(j + 1) & 1][d0 + e] = v[e];
+                for (int e = 0; e < HV; ++e) Qb[(j + 1) & 1][p0 + e] = v[e];
             }
         }
         __syncthreads();
     }
+#ifdef NHATSQ_DBG
+    qc[3] = clock64();
+#endif
     // whitening  w = L.n  (chordal_sampling.f90:73): tile k holds rows 32k..32k+31 of L, i.e. exactly the output
     // coordinates of block h = k
     const int col = col0 + basis * Dg + i;
@@ -509,18 +524,18 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
         if (k == 0) {
             // the first tile was requested before the Gram-Schmidt loop (registers lpre): its latency is hidden
 #pragma unroll
-            for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) { const int y = tid + x * NTQ; if (y < HV * DP) Lt[y / DP][y % DP] = lpre[x]; }
+            for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) { const int y = tid + x * NTQ, b = y % DP; if (y < HV * DP) Lt[y / DP][(b / HV) * HP + b % HV] = lpre[x]; }
         } else {
             for (int x = tid; x < HV * DP; x += NTQ) {
                 const int r = x / DP, b = x % DP, a = HV * k + r;
-                Lt[r][b] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
+                Lt[r][(b / HV) * HP + b % HV] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < HV; ++r) {
             double t;
-            PC_DOT32(t, (&Lt[r][d0]), v)
+            PC_DOT32(t, (&Lt[r][p0]), v)
             if (h == k) w[r] = t;
         }
     }
@@ -534,6 +549,10 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
         if (h == 0) S.nhat_w[(size_t)chain * nr + col] = wn * 3.0;
     }
 #undef PC_DOT32
+#ifdef NHATSQ_DBG
+    qc[4] = clock64();
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int x = 0; x < 4; ++x) S.ctl->gen_cyc[x] += qc[x + 1] - qc[x];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

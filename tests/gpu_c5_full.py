@@ -14,6 +14,7 @@ olib.pc_random_invcov(12345, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
 mean = np.full(D, 0.5)
 s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, 0)
 s.nlive, s.num_repeats, s.seed, s.batch, s.profile = nlive, nr, 3, B, 1
+s.feedback = int(__import__("os").environ.get("PC_FB", "0"))
 L, P, keep = api.make_problem("corr_gaussian", D, 0, invcov=ic, mean=mean, logdet=ld.value)
 t0 = time.time(); g = api.run(s, L, P); dt = time.time() - t0
 print(f"C5 D={D} nlive={nlive} nr={nr} B={g['batch']}: logZ {g['logZ']:.4f} +- {g['logZerr']:.4f} (truth ~0 up to prior truncation) ndead {g['ndead']} nlike {g['nlike']} "
