@@ -180,6 +180,19 @@ def test_ini_front_end_and_cli(engine, tmp_path):
     assert abs(logZ + 4.6526) < 4 * err + 0.05
     nclusters = sum(1 for l in stats if l.startswith("log(Z_"))
     assert nclusters >= 10                                            # the reference finds ~40 modes
+    # parameter speeds in the ini file (priors.f90:708-737): two grades with explicit repeats; .stats has one likelihood
+    # count per grade.  In the second file the fast parameters are listed first: the hypercube is ordered by speed, the
+    # prior then runs on the host (the device prior maps cube coordinate i to parameter i)
+    for name in ("gaussian_grades", "gaussian_grades_permuted"):
+        out = subprocess.run([cli, os.path.join(root, "configs", name + ".ini"), "gaussian"], cwd=tmp_path, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        stats = (tmp_path / "chains" / (name + ".stats")).read_text().splitlines()
+        logZ, err = [float(x) for x in stats[8].split("=")[1].split("+/-")]
+        assert abs(logZ) < 4 * err
+        counts = [int(x) for x in [l for l in stats if l.startswith(" nlike:")][0].split(":")[1].split()]
+        assert len(counts) == 2 and min(counts) > 1000
+        rows = np.loadtxt(tmp_path / "chains" / (name + "_dead-birth.txt"))
+        assert rows.shape[1] == 6 + 2 and abs(np.average(rows[-300:, :6]) - 0.5) < 0.05
     # a missing mandatory key is a fatal error with exit status 1 (abort.F90:19-29)
     bad = tmp_path / "bad.ini"; bad.write_text("num_repeats = 4\nP : a | a | 1 | uniform | 1 | 0 1\n")
     out = subprocess.run([cli, str(bad), "gaussian"], cwd=tmp_path, capture_output=True, text=True)
