@@ -31,6 +31,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_EVAL = 258.0
+# BASELINE.json configs through this harness: kind, nDims, nDerived, nlive, num_repeats, clustering, box, analytic logZ
+WORKLOADS = {
+    "c2": dict(kind="gaussian", D=20, nDer=2, nlive=2000, nr=40, clustering=0, box=None, truth=0.0,
+               name="BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, num_repeats=40"),
+    "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.26,
+               name="BASELINE configs[2]: 10-D Rastrigin, U(-5.12,5.12)^10, nlive=%d, num_repeats=30 (= 3 nDims, the ini's ratio), kNN clustering"),
+    "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.79,
+               name="BASELINE configs[3]: 30-D twin Gaussian (sigma=0.1), U(-1,1)^30, nlive=%d, num_repeats=40, kNN clustering"),
+    "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=None,
+               name="BASELINE configs[4]: 100-D correlated Gaussian (random eigenbasis, eigen-sigma 0.1 .. 0.001), U(0,1)^100, nlive=%d, num_repeats=200"),
+}
+
+
+def algorithmic_bytes_per_iteration(D, nDer, nr, N):
+    """chain I/O + covariance pass + phantom compaction + contour scan, per nested-sampling iteration
+    (phi = nr + 1 phantoms per live point in steady state)"""
+    nT, phi = 2 * D + nDer + 2, nr + 1
+    return 8.0 * nT * (1 + nr) + 8.0 * (1 + phi) * D + 8.0 * phi * nT + 8.0 * N
+
+
+def random_correlated_gaussian(D, seed=12345, sigma0=0.1):
+    """random_gaussian.f90 / random_utils.F90:581-614: random orthonormal eigenbasis, eigen-sigma_j = sigma0 (1e-2)^(j/(D-1))"""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    sig = sigma0 * (1e-2) ** (np.arange(D) / max(D - 1, 1))
+    return Q @ np.diag(sig ** -2) @ Q.T, np.full(D, 0.5), float(2.0 * np.log(sig).sum())
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -66,6 +92,9 @@ def main():
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE configs[1], the metric configuration (default, what the driver runs); c3 / c4 / c5 = "
+                         "BASELINE configs[2..4] through the same harness (their lines are kept under profiles/)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="after the timed steps: R independent runs driven concurrently from R host threads on this GPU "
                          "(reported separately, never part of `value`); 0 = skip")
@@ -88,13 +117,22 @@ def main():
     if lib.pchip_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
 
-    nDims, nDer, nr = 20, 2, 40
+    wl = WORKLOADS[args.workload]
+    if args.workload != "c2" and args.nlive == 2000:
+        args.nlive = wl["nlive"]
+    nDims, nDer, nr = wl["D"], wl["nDer"], wl["nr"]
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
     s.nlive = args.nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
+    s.do_clustering = wl["clustering"]
     # HIP-event stopwatch on the two heaviest kernel classes only (slice sampling = the likelihood evaluations,
     # contraction); timing all six classes costs ~4 ms of event records per 28 ms run
     s.profile = (1 << (1 + 1)) | (1 << (2 + 1))
-    L, P, keep = api.make_problem("gaussian", nDims, nDer)
+    if wl["kind"] == "corr_gaussian":
+        ic, mean, logdet = random_correlated_gaussian(nDims)
+        L, P, keep = api.make_problem("corr_gaussian", nDims, nDer, invcov=ic, mean=mean, logdet=logdet)
+    else:
+        lo, hi = wl["box"] if wl["box"] else (None, None)
+        L, P, keep = api.make_problem(wl["kind"], nDims, nDer, lo, hi)
 
     def one(i):
         s.seed = 1000 + i + 100003 * rank
@@ -156,11 +194,13 @@ def main():
             kt = sum(r["kernel_time"][dom]["total_s"] for r in runs)
             kl = sum(r["kernel_time"][dom]["launches"] for r in runs)
             evals = float(sum(r["nlike"] for r in runs))
-            achieved = evals * BYTES_PER_EVAL / kt / 1e9
+            niter = float(sum(r["niter"] for r in runs))
+            bpe = BYTES_PER_EVAL if args.workload == "c2" else algorithmic_bytes_per_iteration(nDims, nDer, nr, args.nlive) * niter / evals
+            achieved = evals * bpe / kt / 1e9
             # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE in separate runs of this command; FETCH_SIZE doubled on gfx950)
             traffic, pmc_src = None, os.path.join(ROOT, "profiles", "r01_pmc.json")
-            if os.path.exists(pmc_src):
+            if os.path.exists(pmc_src) and args.workload == "c2":
                 pk = json.load(open(pmc_src))["kernels"]
                 hit = [v for k, v in pk.items() if k.startswith(dom if dom != "k_consume" else "k_consume_par")]
                 if hit:
@@ -173,25 +213,26 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_own_bytes_per_launch": own,
                     "avg_launch_us": kt / max(kl, 1) * 1e6, "launches": kl,
-                    "bytes_per_launch": evals * BYTES_PER_EVAL / max(kl, 1),
+                    "bytes_per_launch": evals * bpe / max(kl, 1), "bytes_per_eval": bpe,
                     "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; algorithmic bytes = "
-                            "258 B per likelihood evaluation x evaluations of one nursery; traffic = PMC bytes of this kernel alone"}
-        out = {"metric": "likelihood evals/sec, 20D Gaussian nlive=%d" % args.nlive, "value": value,
+                            "SURVEY 8(d) bytes per likelihood evaluation (258 B at the metric config) x evaluations of one nursery; "
+                            "traffic = PMC bytes of this kernel alone"}
+        metric_name = {"c2": "likelihood evals/sec, 20D Gaussian nlive=%d", "c3": "likelihood evals/sec, 10D Rastrigin nlive=%d",
+                       "c4": "likelihood evals/sec, 30D twin Gaussian nlive=%d", "c5": "likelihood evals/sec, 100D correlated Gaussian nlive=%d"}
+        out = {"metric": metric_name[args.workload] % args.nlive, "value": value,
                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, "
-                                      "num_repeats=40, precision_criterion=1e-3, one full nested-sampling run per step"
-                                      % args.nlive,
+               "config": {"workload": wl["name"] % args.nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world},
                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
-               "logZ_truth": 0.0, "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
+               "logZ_truth": wl["truth"], "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
                "merged": merged, "step_ms": step_ms, "merge_ms": merge_ms, "concurrent": conc, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                "reference_cpu_evals_per_s_survey_container": 357e3}
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and args.workload == "c2":
             out["cpu_baseline"] = cpu_baseline(nDims, nDer, nr)
         else:
             out["cpu_baseline"] = None
