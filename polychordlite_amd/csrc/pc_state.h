@@ -11,7 +11,7 @@
 enum { PC_ST_RUNNING = 0, PC_ST_DONE = 1, PC_ST_UPDATE = 2, PC_ST_ERROR = 4 };
 enum { PC_ERR_NONE = 0, PC_ERR_PHANTOM_CAP = 1, PC_ERR_DEAD_CAP = 2, PC_ERR_CLUSTER_CAP = 3, PC_ERR_NOSLOT = 4 };
 
-#define PC_MASK_WORDS 8          /* phantom mask words per chain: num_repeats <= 512 */
+#define PC_MASK_WORDS 16         /* phantom mask words per chain: num_repeats <= 1024 */
 
 struct PcCtl {                   // written by the consume kernel, read by the host after each round
     int status;                  // PC_ST_*

@@ -84,6 +84,8 @@ RUNS = [  # kind D nDer nlive nr B general clustering
     ("rastrigin", 3, 0, 120, 9, 60, 2, 0),
     # BASELINE configs[4] live-set size: the parallel contraction at nlive = 5000 with 1024 chains per nursery
     ("gaussian", 3, 0, 5000, 3, 1024, 0, 0),
+    # num_repeats beyond 512 (5 nDims at nDims > 102): sixteen phantom mask words per chain
+    ("gaussian", 6, 1, 60, 600, 16, 0, 0), ("gaussian", 5, 0, 50, 1000, 8, 1, 0),
 ]
 
 
