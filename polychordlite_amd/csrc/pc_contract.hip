@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, 
 
 __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int nchunk, const double *psum, const int *pcnt,
                                                     double *mean /* [nc][D] */, int *count /* [nc] */, double *pcov, int CR,
-                                                    int TS /* tile row stride */, int use_mfma)
+                                                    int TS /* tile row stride */, int use_mfma, int nchunk_rows)
 {
     // grid (nchunk, nc).  Every workgroup first reduces the chunk sums to the cluster mean (fixed order,
     // identical in every workgroup), then accumulates the centred outer products of its own rows.
@@ -1007,10 +1007,25 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
         if (chunk == 0) mean[(size_t)c * D + d] = m;
     }
     if (chunk == 0 && tid == 0) count[c] = ntot;
+    // ---- wide nDims: X^T X on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), upper triangle only, one 16x16 tile of
+    // the result per wave at a time.  Operand maps (cdna_hip_programming.md): A[i=lane&15][k=lane>>4],
+    // B[k=lane>>4][j=lane&15], D col = lane&15, row = (lane>>4) + 4*reg.  The workgroup is persistent: it takes the chunks
+    // chunk, chunk + gridDim.x, ... and keeps its accumulators in registers across them, so that ONE partial matrix
+    // per workgroup goes to memory (a 100-D update used to write and re-read one 80 KB partial per 128 rows: 1.3 GB).
+    // Rows are consumed four at a time in row order, chunks in order: a fixed summation order.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int MAXT = 9;                                       // tiles per wave: nDims <= 128 -> 36 tiles / 4 waves
+    v4d acc[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) acc[k] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int W = TS - 1, nt = W / 16, ntile = nt * (nt + 1) / 2;
+    for (int ch = chunk; ch == chunk || (use_mfma && ch < nchunk_rows); ch += gridDim.x) {
+    const int r0 = ch * CR, r1 = max(r0, min(nrows, r0 + CR));
     // ---- member rows of this chunk, in row order (CR <= 256: one row per thread)
     bool member = false;
     { const int r = r0 + tid; int cc = -1; if (tid < CR && r < r1) cov_row(S, r, S.Ncap, nc, cc); member = (tid < CR && r < r1 && cc == c); }
     const unsigned long long bm = __ballot(member);
+    __syncthreads();                                              // the previous chunk's tile and rc are no longer read
     if (lane == 0) wcnt[wv] = __popcll(bm);
     __syncthreads();
     int base = 0;
@@ -1032,32 +1047,41 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
         }
         return;
     }
-    // ---- wide nDims: X^T X on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), one 16x16 tile of the result per
-    // wave at a time, upper triangle only.  Operand maps (cdna_hip_programming.md): A[i=lane&15][k=lane>>4],
-    // B[k=lane>>4][j=lane&15], D col = lane&15, row = (lane>>4) + 4*reg.  Rows are consumed four at a time in row
-    // order: a fixed summation order.
-    const int nP = (n + 3) & ~3, W = TS - 1;                      // rows / columns of the zero padded tile
+    const int nP = (n + 3) & ~3;                                  // rows of the zero padded tile
     for (int e = tid; e < nP * W; e += 256) {
         const int i = e / W, d = e % W;
         tile[(size_t)i * TS + d] = (i < n && d < D) ? cov_ptr(S, rc[i])[d] - mu[d] : 0.0;
     }
     __syncthreads();
-    typedef double v4d __attribute__((ext_vector_type(4)));
-    const int nt = W / 16, ntile = nt * (nt + 1) / 2;
-    for (int t = wv; t < ntile; t += 4) {
-        int ti = 0, rem = t;
-        while (rem >= nt - ti) { rem -= nt - ti; ti++; }
-        const int tj = ti + rem;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        const double *pa = tile + (size_t)(lane >> 4) * TS + ti * 16 + (lane & 15);
-        const double *pb = tile + (size_t)(lane >> 4) * TS + tj * 16 + (lane & 15);
-        for (int r0 = 0; r0 < nP; r0 += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)r0 * TS], pb[(size_t)r0 * TS], acc, 0, 0, 0);
-        double *out = pcov + ((size_t)chunk * nc + c) * D * D;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + (lane >> 4) + 4 * r, col = tj * 16 + (lane & 15);
-            if (row < D && col < D) { out[(size_t)row * D + col] = acc[r]; if (ti != tj) out[(size_t)col * D + row] = acc[r]; }
+    for (int k = 0; k < MAXT; ++k) {
+        const int t = wv + 4 * k;
+        if (t < ntile) {
+            int ti = 0, rem = t;
+            while (rem >= nt - ti) { rem -= nt - ti; ti++; }
+            const int tj = ti + rem;
+            const double *pa = tile + (size_t)(lane >> 4) * TS + ti * 16 + (lane & 15);
+            const double *pb = tile + (size_t)(lane >> 4) * TS + tj * 16 + (lane & 15);
+            v4d a4 = acc[k];
+            for (int q0 = 0; q0 < nP; q0 += 4)
+                a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)q0 * TS], pb[(size_t)q0 * TS], a4, 0, 0, 0);
+            acc[k] = a4;
+        }
+    }
+    }   // chunks of this workgroup
+    double *out = pcov + ((size_t)chunk * nc + c) * D * D;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+        const int t = wv + 4 * k;
+        if (t < ntile) {
+            int ti = 0, rem = t;
+            while (rem >= nt - ti) { rem -= nt - ti; ti++; }
+            const int tj = ti + rem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + (lane >> 4) + 4 * r, col = tj * 16 + (lane & 15);
+                if (row < D && col < D) { out[(size_t)row * D + col] = acc[k][r]; if (ti != tj) out[(size_t)col * D + row] = acc[k][r]; }
+            }
         }
     }
 }
@@ -1341,13 +1365,21 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     if (sh > 160 * 1024) return 1;
     static size_t donep = 0;
     if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
-    hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nred, psum, pcnt, mean, count, pcov, CR, TS, cov_use_mfma(S));
-    if (nchunk > 2 * NFOLD) hipLaunchKernelGGL(k_fold_partials, dim3(NFOLD, nc), dim3(256), 0, st, pcov, (int *)nullptr, nchunk, nc, D * D);
+    int ncov = nred;                                             // partial matrices the Cholesky kernel adds up
+    if (cov_use_mfma(S)) {
+        // persistent workgroups (one per CU at nDims = 100), each walks its share of the chunks and writes one partial matrix
+        const int G = nchunk < 256 ? nchunk : 256;
+        hipLaunchKernelGGL(k_cov_partial, dim3(G, nc), dim3(256), sh, st, *S, nrows, nred, psum, pcnt, mean, count, pcov, CR, TS, 1, nchunk);
+        ncov = G;
+    } else {
+        hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nred, psum, pcnt, mean, count, pcov, CR, TS, 0, nchunk);
+        if (nchunk > 2 * NFOLD) hipLaunchKernelGGL(k_fold_partials, dim3(NFOLD, nc), dim3(256), 0, st, pcov, (int *)nullptr, nchunk, nc, D * D);
+    }
     const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
     if (sh2 > 160 * 1024) return 1;
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, nred, pcov, count);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count);
     return 0;
 }
 
