@@ -399,8 +399,9 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     // LDS rows are stored as four coordinate blocks of HV + 2 doubles: the four threads of a vector read their blocks
     // at the same time, and blocks exactly HV doubles (a multiple of 256 B) apart would all start in the same bank
     constexpr int HP = HV + 2, DPP = 4 * HP;
-    __shared__ __attribute__((aligned(16))) double Qb[2][DPP];        // pivot, double buffered
-    __shared__ __attribute__((aligned(16))) double Lt[HV][DPP];       // HV rows of the Cholesky factor
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];
+    double (*Qb)[DPP] = (double (*)[DPP])smem_q;                      // [2][DPP] pivot, double buffered
+    double (*Lt)[DPP] = (double (*)[DPP])(smem_q + sizeof(double) * 2 * DPP);   // [HV][DPP] HV rows of the Cholesky factor (HV < 32)
     __shared__ int sh[2];
     const int D = S.D, nr = S.nr;
     const int tid = threadIdx.x, chain = blockIdx.y;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     __syncthreads();
     // first tile of the Cholesky factor: requested now, consumed after the loop
     double lpre[(HV * DP + NTQ - 1) / NTQ];
-    {
+    if constexpr (HV < 32) {
         const double *Lc0 = S.chol + (size_t)sh[0] * D * D;
 #pragma unroll
         for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) {
@@ -516,6 +517,71 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     const int col = col0 + basis * Dg + i;
     const bool wanted = basis * Dg + i < nrg;
     const double *Lc = S.chol + (size_t)sh[0] * D * D;
+    if constexpr (HV == 32) {
+        // nDims 65..128: W = L.N on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  The basis goes to LDS (row = vector,
+        // odd row stride), L passes through LDS sixteen rows at a time (lower triangle only), wave tj owns the sixteen
+        // output columns (vectors) 16 tj ..: it keeps their tiles in registers, normalises, and writes whole rows.
+        // Operand maps as in k_cov_partial: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D row = (lane>>4)+4 reg.
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        constexpr int NS = 129;
+        const int nt = (D + 15) >> 4, NR = nt * 16;
+        double *Nl = (double *)smem_q + 2 * DPP;                       // [NR][NS]
+        double *L16 = Nl + (size_t)NR * NS;                            // [16][NS]
+        if (i < NR) {
+#pragma unroll
+            for (int e = 0; e < HV; ++e) Nl[(size_t)i * NS + d0 + e] = v[e];    // zero beyond nDims and beyond the basis
+        }
+        const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+        v4d acc[8];
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) acc[ti] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+            if (ti < nt) {
+                __syncthreads();                                       // basis complete / previous rows of L consumed
+                const int kmax = min(NR, 16 * (ti + 1));               // L(a, b) = 0 for b > a
+                for (int x = tid; x < 16 * kmax; x += NTQ) {
+                    const int r = x / kmax, bcol = x % kmax, arow = 16 * ti + r;
+                    L16[(size_t)r * NS + bcol] = (arow < D && bcol < D) ? Lc[(size_t)arow * D + bcol] : 0.0;
+                }
+                __syncthreads();
+                if (wv < nt) {
+                    const double *pa = L16 + (size_t)li * NS + lk;
+                    const double *pb = Nl + (size_t)(16 * wv + li) * NS + lk;
+                    v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
+                    for (int k0 = 0; k0 < kmax; k0 += 4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], a4, 0, 0, 0);
+                    acc[ti] = a4;
+                }
+            }
+        }
+        if (wv < nt) {
+            // |w| of my column (chordal_sampling.f90:80-82): my four row groups, then the other three lane groups
+            double n2 = 0.0;
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) n2 += acc[ti][r] * acc[ti][r];
+            n2 += __shfl_xor(n2, 16); n2 += __shfl_xor(n2, 32);
+            const double wn = sqrt(n2), iw = 1.0 / wn;
+            const int ivec = 16 * wv + li;                             // vector of this basis = column
+            double *mine = Nl + (size_t)ivec * NS;                     // the basis rows of this wave are no longer read
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ti < nt) mine[16 * ti + lk + 4 * r] = acc[ti][r] * iw;
+            if (lk == 0 && ivec < Dg && basis * Dg + ivec < nrg) S.nhat_w[(size_t)chain * nr + col0 + basis * Dg + ivec] = wn * 3.0;
+            // rows leave coalesced
+            for (int cc = 0; cc < 16; ++cc) {
+                const int iv = 16 * wv + cc;
+                if (iv < Dg && basis * Dg + iv < nrg) {
+                    double *out = S.nhat + ((size_t)chain * nr + col0 + basis * Dg + iv) * D;
+                    const double *src = Nl + (size_t)iv * NS;
+                    for (int a2 = lane; a2 < D; a2 += 64) out[a2] = src[a2];
+                }
+            }
+        }
+        return;
+    }
     double w[HV];
 #pragma unroll
     for (int e = 0; e < HV; ++e) w[e] = 0.0;
@@ -1016,9 +1082,16 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
     static int quad_min = -1;                       // smallest nDims that takes the four-threads-per-vector kernel
     if (quad_min < 0) { const char *e = std::getenv("PC_NHATS_QUAD_MIN"); quad_min = e ? std::atoi(e) : 25; }   // measured: 20-D 52 vs 39 us (old kernel better), 28-D 43 vs 47, 40-D 95 vs 133, 64-D 129 vs 240
     if (D >= quad_min) {
-        if (D <= 32) hipLaunchKernelGGL((k_nhats_q<8>), grid, dim3(128), 0, st, *S, batch);
-        else if (D <= 64) hipLaunchKernelGGL((k_nhats_q<16>), grid, dim3(256), 0, st, *S, batch);
-        else if (D <= 128) hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), 0, st, *S, batch);
+        // dynamic LDS: pivot buffer + Cholesky tile (HV rows of 4 (HV + 2) doubles), or basis + sixteen rows of L (HV = 32)
+        auto lds_q = [](int HV) { return sizeof(double) * (size_t)(2 + HV) * 4 * (HV + 2); };
+        if (D <= 32) hipLaunchKernelGGL((k_nhats_q<8>), grid, dim3(128), lds_q(8), st, *S, batch);
+        else if (D <= 64) hipLaunchKernelGGL((k_nhats_q<16>), grid, dim3(256), lds_q(16), st, *S, batch);
+        else if (D <= 128) {
+            const size_t shq = sizeof(double) * (2 * 4 * 34 + (size_t)(((D + 15) / 16) * 16 + 16) * 129);
+            static size_t doneq = 0;
+            if (shq > doneq) { (void)hipFuncSetAttribute((const void *)k_nhats_q<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); doneq = shq; }
+            hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), shq, st, *S, batch);
+        }
         else return 1;
         return 0;
     }
