@@ -435,23 +435,26 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
                              + ((long long)basis * Dg + i) * Dg + (d0 - off);
         const int r_lo = max(0, off - d0), r_hi = min(HV, D - d0);
         if (r_hi > r_lo) {
-            const uint32_t c0 = (uint32_t)((e0 + r_lo) >> 1), c1 = (uint32_t)((e0 + r_hi - 1) >> 1);
+            // Philox call number cbase + cc holds stream elements 2 (cbase + cc) and + 1, i.e. my registers 2 cc - par and
+            // 2 cc - par + 1 with par = parity of e0: every call lands in one of two fixed register pairs
+            const long long cbase = e0 >> 1;
+            const bool par = (e0 & 1ll) != 0;
 #pragma unroll
             for (int cc = 0; cc < HV / 2 + 1; ++cc) {
-                const uint32_t call = c0 + cc;
-                if (call <= c1) {
+                const int ea = 2 * cc - (par ? 1 : 0), eb = ea + 1;
+                if (eb >= r_lo && ea < r_hi) {
+                    const uint32_t call = (uint32_t)(cbase + cc);
                     double ua, ub;
                     if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
                     else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
-                    const int ea = (int)(2ll * call - e0), eb = ea + 1;     // -1 .. HV
                     const double ga = pc_inv_normal_cdf(ua), gb = pc_inv_normal_cdf(ub);
-#pragma unroll
-                    for (int e = 0; e < HV; ++e) {
-                        if (e == ea && e >= r_lo && e < r_hi) v[e] = ga;
-                        if (e == eb && e >= r_lo && e < r_hi) v[e] = gb;
-                    }
+                    if (2 * cc - 1 >= 0 && 2 * cc - 1 < HV) v[(2 * cc - 1 >= 0 && 2 * cc - 1 < HV) ? 2 * cc - 1 : 0] = par ? ga : v[(2 * cc - 1 >= 0 && 2 * cc - 1 < HV) ? 2 * cc - 1 : 0];
+                    if (2 * cc < HV) v[2 * cc < HV ? 2 * cc : 0] = par ? gb : ga;
+                    if (2 * cc + 1 < HV) v[2 * cc + 1 < HV ? 2 * cc + 1 : 0] = par ? v[2 * cc + 1 < HV ? 2 * cc + 1 : 0] : gb;
                 }
             }
+#pragma unroll
+            for (int e = 0; e < HV; ++e) v[e] = (e >= r_lo && e < r_hi) ? v[e] : 0.0;   // coordinates that do not exist / do not move
         }
     }
 #ifdef NHATSQ_DBG
