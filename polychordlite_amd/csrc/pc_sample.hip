@@ -491,6 +491,8 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #endif
     // Gram-Schmidt (random_utils.F90:391-399): same projections as before, pivot unnormalised
     for (int j = 0; j < Dg; ++j) {
+        // a wave whose sixteen vectors are all finished (i < j) only keeps the barrier company
+        if ((((tid >> 6) + 1) << 4) <= j) { __syncthreads(); continue; }
         double q[HV];
 #pragma unroll
         for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][p0 + e];
