@@ -507,6 +507,13 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         touch(S.baby_logL, sizeof(double) * (size_t)i_nursery * nr);
         touch(S.ch_nlike, sizeof(int) * (size_t)i_nursery); touch(S.ch_epoch, sizeof(int) * (size_t)i_nursery); touch(S.ch_cluster, sizeof(int) * (size_t)i_nursery);
         if (nn) touch(S.nn_list, sizeof(int) * (size_t)i_nursery * nr * PC_NN_K);
+        touch(S.slot_src, sizeof(int) * (size_t)Ncap);
+        for (int c = 0; c < nc; ++c) touch(S.XpXq + (size_t)c * maxc, sizeof(double) * (size_t)nc);
+        // cube coordinates of every chain's last baby (they enter the LDS copy of the live set when the chain is accepted)
+        for (int w2 = tid; w2 < i_nursery; w2 += NT) {
+            const char *b = (const char *)(S.babies + ((size_t)w2 * nr + (nr - 1)) * nT);
+            for (size_t o = 0; o < sizeof(double) * (size_t)S.D; o += 64) { const int v = *(const volatile int *)(b + o); asm volatile("" :: "v"(v)); }
+        }
     }
     while (!final_mode && status == PC_ST_RUNNING) {
         const long long q0 = clock64();
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                     mxv = m2;
                 }
                 const double v = (acc > 0.0) ? mxv + log(acc) : S.logzero;
-                live_logZ_val = pc_logaddexp(S.logzero, v);
+                live_logZ_val = (v > S.logzero + 800.0) ? v : pc_logaddexp(S.logzero, v);   // exp(logzero - v) underflows to 0
             }
             if (live_logZ_val < S.log_prec + logZ) more = false;
         }
