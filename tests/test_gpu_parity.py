@@ -318,3 +318,56 @@ def test_graded_runs_match_oracle(engine, kind, D, nDer, nlive, B, clustering, d
     assert rel.max() < 1e-7
     if kind == "gaussian":
         assert abs(g["logZ"]) < 4 * g["logZerr"]                # truth 0
+
+
+def _random_cases(n, seed=2024):
+    """small random configurations: every front-door knob of the path at once"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        kind = ["gaussian", "rastrigin", "twin_gaussian"][int(rng.integers(0, 3))]
+        D = int(rng.integers(2 if kind == "twin_gaussian" else 1, 13))
+        nDer = 0 if kind == "rastrigin" else int(rng.integers(0, 3 if kind == "gaussian" else 2))
+        nlive = int(rng.integers(25, 220))
+        nr = int(rng.integers(1, 4 * D + 3))
+        B = int([1, 2, 7, 16, 33, 64, 128][int(rng.integers(0, 7))])
+        clustering = int(rng.integers(0, 2)) if D <= 6 else 0
+        general = int(rng.integers(0, 3)) if not clustering else 0
+        grades = None
+        if D >= 2 and rng.random() < 0.35:
+            cut = int(rng.integers(1, D))
+            grades = ([cut, D - cut], [int(rng.integers(2, 2 * D + 2)), int(rng.integers(2, 2 * D + 2))])
+        extra = {}
+        r = rng.random()
+        if r < 0.15:
+            extra["max_ndead"] = int(rng.integers(nlive, 6 * nlive))
+        elif r < 0.3:
+            extra["precision_criterion"] = float(10 ** rng.uniform(-4, -0.5))
+        elif r < 0.4:
+            extra["nprior"] = nlive + int(rng.integers(1, nlive))
+        out.append((k, kind, D, nDer, nlive, nr, B, general, clustering, grades, extra))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(24) + _random_cases(24, seed=77), ids=lambda c: f"rnd{c[0]}-{c[1]}-D{c[2]}-N{c[4]}-nr{c[5]}-B{c[6]}-g{c[7]}c{c[8]}")
+def test_random_configurations_match_oracle(engine, case):
+    """48 seeded random configurations (likelihood, nDims, derived parameters, nlive, num_repeats, chains per nursery,
+    contraction kernel, clustering, parameter grades, termination knobs, nprior): same trajectory as the oracle"""
+    k, kind, D, nDer, nlive, nr, B, general, clustering, grades, extra = case
+    api = engine
+    lo, hi = BOX[kind]
+    kw = dict(nlive=nlive, num_repeats=nr if grades is None else sum(grades[1]), seed=300 + k, batch=B, do_clustering=clustering)
+    kw.update(extra)
+    s = _settings(api, D, nDer, force_general=general, **kw)
+    so = orc.settings(D, nDer, **kw)
+    keep = (api.set_grades(s, *grades), orc.set_grades(so, *grades)) if grades else None
+    L, P, k1 = api.make_problem(kind, D, nDer, lo, hi)
+    Lo, Po, k2 = orc.make_problem(kind, D, lo, hi)
+    g = api.run(s, L, P)
+    o = orc.run(so, Lo, Po)
+    for key in ("ndead", "nlike", "niter", "nbatches", "ncluster", "ncluster_dead"):
+        assert g[key] == o[key], (key, g[key], o[key], case)
+    assert g["nlike_grade"] == o["nlike_grade"]
+    assert abs(g["logZ"] - o["logZ"]) < 1e-8 * max(1.0, abs(o["logZ"])) and abs(g["logZerr"] - o["logZerr"]) < 1e-8
+    rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
+    assert rel.max() < 1e-7
