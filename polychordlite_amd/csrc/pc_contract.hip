@@ -12,6 +12,7 @@
 //               threshold test + deterministic stream compaction, calculate_covmats (:601-641) as a
 //               two-pass mean / centred SYRK with fixed-order reduction, calc_cholesky (utils.F90:621-649).
 #include "pc_state.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
 // block-level helpers (NT threads; NT == 64 needs no barrier traffic)
@@ -1293,6 +1294,24 @@ static size_t consume_lds(const PcState *S, int NT, int xrows)
 
 extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hipStream_t st)
 {
+    // With the candidate lists the heavy parallel part (the nearest-cluster search) is gone and what is left is barriers
+    // and short scans: 256 threads (4 waves) run it 1.4x faster than 1024 (16 waves, 128-VGPR cap).  PC_CONSUME_NT overrides.
+    static const int wide_nt = std::getenv("PC_CONSUME_NT") ? std::atoi(std::getenv("PC_CONSUME_NT")) : 256;
+    if (wide && S->nn_valid && wide_nt != 1024) {
+#define PC_CONSUME_LAUNCH(NTV) { \
+            int cache_x = S->Ncap; \
+            while (cache_x > 32 && consume_lds(S, NTV, cache_x) > 158 * 1024) cache_x = (cache_x + 1) / 2; \
+            const size_t sh = consume_lds(S, NTV, cache_x); \
+            if (sh > 160 * 1024) return 1; \
+            static size_t done_ = 0; \
+            if (sh > done_) { hipFuncSetAttribute((const void *)k_consume<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_ = sh; } \
+            hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x); \
+            return 0; }
+        if (wide_nt == 128) PC_CONSUME_LAUNCH(128)
+        if (wide_nt == 512) PC_CONSUME_LAUNCH(512)
+        PC_CONSUME_LAUNCH(256)
+#undef PC_CONSUME_LAUNCH
+    }
     if (wide) {
         // all live coordinates in LDS when they fit, else the largest tile that does
         int cache_x = S->Ncap;
