@@ -442,8 +442,11 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
 
     // delete_cluster (run_time_info.f90:507-598): drop the first empty cluster, keep the others' order
     auto drop_empty_cluster = [&]() -> bool {
-        int p = -1;
-        for (int c = 0; c < nc; ++c) if (H.cN[c] == 0) { p = c; break; }
+        int p = -1;                                    // first empty cluster: one cluster per lane, every wave for itself
+        for (int c0 = 0; c0 < nc && p < 0; c0 += 64) {
+            const unsigned long long m = __ballot(c0 + lane < nc && H.cN[c0 + lane] == 0);
+            if (m) p = c0 + __ffsll((long long)m) - 1;
+        }
         if (p < 0) return false;
         __syncthreads();
         if (tid == 0) {
