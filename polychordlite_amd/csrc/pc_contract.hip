@@ -44,6 +44,7 @@ struct ConsumeShared {
     double *gd2; int *gkey; int *ids;                   // [IDG][IDP] partial minima; [nr] cluster of each baby
     int *misc;                                          // small scratch
     int *sO, *sCS;                                      // nn_slot_owner [Ncap], nn_chain_slot [B] (only when S.nn_valid)
+    double *xq; int xq_ld;                              // log <X_p X_q>: LDS copy [xq_ld][xq_ld] when the clusters fit, else S.XpXq [maxc][maxc]
 };
 
 // identify_cluster (run_time_info.f90:913-949) for ALL babies of a chain at once: the cluster of the
@@ -259,7 +260,7 @@ __device__ __forceinline__ int nlive_target(const PcState &S, double logL)
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int cache_x)
+__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int cache_x, int xq_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         H.gkey = (int *)p; p += sizeof(int) * NT;
         H.ids = (int *)p; p += sizeof(int) * nr;
         H.sO = (int *)p; p += sizeof(int) * Ncap;
-        H.sCS = (int *)p;
+        H.sCS = (int *)p; p += sizeof(int) * S.B;
+        p = (char *)(((size_t)p + 15) & ~(size_t)15);
+        H.xq = (double *)p; H.xq_ld = xq_n;
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
@@ -296,6 +299,12 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         for (int c = tid; c < S.B; c += NT) H.sCS[c] = S.nn_chain_slot[c];
     }
     int nc = ctl->ncluster;
+    // the cross-volume matrix: every death reads and rewrites a row and a column of it; in global memory that is a
+    // store -> load round trip per death (and 2 nc^2 of them, serially, when a cluster is deleted)
+    const bool xq_lds = nc <= xq_n;                    // clusters only appear between launches
+    if (xq_lds) { for (int e = tid; e < nc * nc; e += NT) H.xq[(size_t)(e / nc) * xq_n + e % nc] = S.XpXq[(size_t)(e / nc) * maxc + e % nc]; }
+    else { H.xq = S.XpXq; H.xq_ld = maxc; }
+    const int nc_at_launch = nc;
     for (int c = tid; c < maxc; c += NT) {
         H.cLogLp[c] = S.logLp[c]; H.cLogXp[c] = S.logXp[c]; H.cLogZp[c] = S.logZp[c]; H.cLogZXp[c] = S.logZXp[c];
         H.cLogZp2[c] = S.logZp2[c]; H.cLogZpXp[c] = S.logZpXp[c]; H.cLseRef[c] = S.lse_ref[c]; H.cLseSum[c] = S.lse_sum[c];
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         // ---- update_evidence (run_time_info.f90:211-296): every log-space accumulation reads only
         //      pre-update values, so they are independent jobs: one lane each.
         const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
-        const double Xp = H.cLogXp[cd], XX = S.XpXq[(size_t)cd * maxc + cd];
+        const double Xp = H.cLogXp[cd], XX = H.xq[(size_t)cd * H.xq_ld + cd];
         const double logweight = Xp - l1;
         {
             double a = 0.0, b = 0.0, c3 = 0.0; bool has = false, has3 = false;
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             else if (tid == 6) { a = exp(L - H.cLseRef[cd]); }                       // live logsumexp bookkeeping
             else if (tid >= 8 && tid - 8 < nc && tid - 8 != cd && tid - 8 < NT - 8) {
                 const int q = tid - 8;
-                a = H.cLogZXp[q]; b = S.XpXq[(size_t)cd * maxc + q] + L - l1; has = true;
+                a = H.cLogZXp[q]; b = H.xq[(size_t)cd * H.xq_ld + q] + L - l1; has = true;
             }
             double r = a;
             if (has) r = pc_logaddexp(a, b);
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         __syncthreads();
         // clusters beyond the lane budget (nc > NT-8): serial tail, rare
         for (int q = NT - 8 + tid; q < nc; q += NT)
-            if (q != cd) H.cLogZXp[q] = pc_logaddexp(H.cLogZXp[q], S.XpXq[(size_t)cd * maxc + q] + L - l1);
+            if (q != cd) H.cLogZXp[q] = pc_logaddexp(H.cLogZXp[q], H.xq[(size_t)cd * H.xq_ld + q] + L - l1);
         logZ = H.jobres[0]; logZ2 = H.jobres[2];
         const double nZp = H.jobres[1], nZXp = H.jobres[3], nZp2 = H.jobres[4], nZpXp = H.jobres[5], edel = H.jobres[6];
         __syncthreads();
@@ -386,11 +395,11 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             if (nn) H.sO[slot_del] = -2;
         }
         for (int q = tid; q < nc; q += NT) {
-            if (q == cd) { if (true) S.XpXq[(size_t)cd * maxc + cd] = XX + l0 - l2; }
+            if (q == cd) { if (true) H.xq[(size_t)cd * H.xq_ld + cd] = XX + l0 - l2; }
             else {
                 if (q < NT - 8) H.cLogZXp[q] = H.jobres[8 + q];
-                const double v = S.XpXq[(size_t)cd * maxc + q] + l0 - l1;
-                S.XpXq[(size_t)cd * maxc + q] = v; S.XpXq[(size_t)q * maxc + cd] = v;
+                const double v = H.xq[(size_t)cd * H.xq_ld + q] + l0 - l1;
+                H.xq[(size_t)cd * H.xq_ld + q] = v; H.xq[(size_t)q * H.xq_ld + cd] = v;
             }
         }
         __syncthreads();
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         if (tid == 0) {
             for (int a = 0, na = 0; a < nc; ++a) {
                 if (a == p) continue;
-                for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; S.XpXq[(size_t)na * maxc + nb] = S.XpXq[(size_t)a * maxc + b]; nb++; }
+                for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; H.xq[(size_t)na * H.xq_ld + nb] = H.xq[(size_t)a * H.xq_ld + b]; nb++; }
                 na++;
             }
             for (int c = p; c < nc - 1; ++c) {
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         touch(S.ch_nlike, sizeof(int) * (size_t)i_nursery); touch(S.ch_epoch, sizeof(int) * (size_t)i_nursery); touch(S.ch_cluster, sizeof(int) * (size_t)i_nursery);
         if (nn) touch(S.nn_list, sizeof(int) * (size_t)i_nursery * nr * PC_NN_K);
         touch(S.slot_src, sizeof(int) * (size_t)Ncap);
-        for (int c = 0; c < nc; ++c) touch(S.XpXq + (size_t)c * maxc, sizeof(double) * (size_t)nc);
+        if (!xq_lds) for (int c = 0; c < nc; ++c) touch(S.XpXq + (size_t)c * maxc, sizeof(double) * (size_t)nc);
         // cube coordinates of every chain's last baby (they enter the LDS copy of the live set when the chain is accepted)
         for (int w2 = tid; w2 < i_nursery; w2 += NT) {
             const char *b = (const char *)(S.babies + ((size_t)w2 * nr + (nr - 1)) * nT);
@@ -706,6 +715,9 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     __syncthreads();
     for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
     for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
+    if (xq_lds) {                                      // (a deleted cluster leaves stale entries beyond nc: never read)
+        for (int e = tid; e < nc_at_launch * nc_at_launch; e += NT) S.XpXq[(size_t)(e / nc_at_launch) * maxc + e % nc_at_launch] = H.xq[(size_t)(e / nc_at_launch) * xq_n + e % nc_at_launch];
+    }
     if (nn) {
         for (int s = tid; s < Ncap; s += NT) S.nn_slot_owner[s] = H.sO[s];
         for (int c = tid; c < S.B; c += NT) S.nn_chain_slot[c] = H.sCS[c];
@@ -1289,8 +1301,9 @@ __global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-static size_t consume_lds(const PcState *S, int NT, int xrows)
+static size_t consume_lds(const PcState *S, int NT, int xrows, int xq_n = 0)
 {
+    if (xq_n > 0) return consume_lds(S, NT, xrows, 0) + sizeof(double) * (size_t)xq_n * xq_n + 16;
     return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + 2 * NT + (size_t)S->D * PC_IDG + (size_t)xrows * S->D) +
            sizeof(vk_t) * 16 + sizeof(int) * (3 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8 + NT + S->nr + (size_t)S->B) + 64;
 }
@@ -1302,13 +1315,14 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
     static const int wide_nt = std::getenv("PC_CONSUME_NT") ? std::atoi(std::getenv("PC_CONSUME_NT")) : 256;
     if (wide && S->nn_valid && wide_nt != 1024) {
 #define PC_CONSUME_LAUNCH(NTV) { \
-            int cache_x = S->Ncap; \
-            while (cache_x > 32 && consume_lds(S, NTV, cache_x) > 158 * 1024) cache_x = (cache_x + 1) / 2; \
-            const size_t sh = consume_lds(S, NTV, cache_x); \
+            /* the lists make the coordinate cache a fallback: a tile is enough, the LDS goes to the cross-volume matrix */ \
+            int cache_x = S->Ncap < 64 ? S->Ncap : 64, xq_n = S->maxc; \
+            while (xq_n > 8 && consume_lds(S, NTV, cache_x, xq_n) > 158 * 1024) xq_n -= 8; \
+            const size_t sh = consume_lds(S, NTV, cache_x, xq_n); \
             if (sh > 160 * 1024) return 1; \
             static size_t done_ = 0; \
             if (sh > done_) { hipFuncSetAttribute((const void *)k_consume<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_ = sh; } \
-            hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x); \
+            hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x, xq_n); \
             return 0; }
         if (wide_nt == 128) PC_CONSUME_LAUNCH(128)
         if (wide_nt == 512) PC_CONSUME_LAUNCH(512)
@@ -1323,7 +1337,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         if (sh > 160 * 1024) return 1;
         static size_t done1024 = 0;
         if (sh > done1024) { hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1024 = sh; }
-        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x);
+        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x, 0);
     } else {
         int xr = S->Ncap;
         while (xr > 32 && consume_lds(S, 64, xr) > 158 * 1024) xr = (xr + 1) / 2;
@@ -1331,7 +1345,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         if (sh > 160 * 1024) return 1;
         static size_t done64 = 0;
         if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
-        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr);
+        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr, 0);
     }
     return 0;
 }
