@@ -318,19 +318,21 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     unsigned next_uid = ctl->next_cluster_uid;
     int status = PC_ST_RUNNING, error = PC_ERR_NONE, cluster_deleted = 0;
     const int seg_hi = i_nursery - 1;
-    double live_logZ_val = S.logzero;
+    double live_logZ_val = S.logzero, ll_m = -PC_HUGE, ll_s = 0.0;   // termination estimate, as value and as (max, sum) pair
     const double log2v = log(2.0);
     __syncthreads();
     // Reductions over the clusters, one cluster per lane.  Every wave computes them for itself from LDS: no barrier,
     // no broadcast (a serial loop over ~40 clusters with an exp each cost more than the rest of an iteration).
-    auto lse_logXp = [&]() -> double {                 // log sum_p X_p
-        if (nc == 1) return H.cLogXp[0];
+    // log sum_p X_p as a pair (m, s): the value is m + log s.  A fp64 log costs ~2000 cycles of latency on this serial
+    // path; the update trigger compares in linear space and the posterior-stack column gets its log on the apply side.
+    auto lse_logXp = [&](double &m_out, double &s_out) {
+        if (nc == 1) { m_out = H.cLogXp[0]; s_out = 1.0; return; }
         double m = -PC_HUGE;
         for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; m = fmax(m, c < nc ? H.cLogXp[c] : -PC_HUGE); }
         m = wave_max(m);
         double sum = 0.0;
         for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; sum += (c < nc) ? exp(H.cLogXp[c] - m) : 0.0; }
-        return m + log(wave_sum<4>(sum));
+        m_out = m; s_out = wave_sum<4>(sum);
     };
     auto lowest_contour = [&]() -> vk_t {              // (min_p logL_p, first cluster that has it): minpos
         if (nc == 1) return vk_t{H.cLogLp[0], 0};
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // one death: delete_outermost_point (run_time_info.f90:789-817) without the row copy
     // ================================================================================
     int last_cd = -1, last_pos_del = -1;
-    double lx_now = 0.0; bool lx_known = false;        // log sum_p X_p: only a death changes it
+    double lx_m = 0.0, lx_s = 1.0; bool lx_known = false;   // log sum_p X_p = lx_m + log lx_s: only a death changes it
     int n_total = 0;                                   // live points over all clusters
     for (int c = 0; c < nc; ++c) n_total += H.cN[c];
     auto kill_lowest = [&](int plan_w) {
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         last_cd = cd; last_pos_del = pos_del;
         // ---- update_evidence (run_time_info.f90:211-296): every log-space accumulation reads only
         //      pre-update values, so they are independent jobs: one lane each.
-        const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0);
+        const double l0 = S.logn[n], l1 = S.logn[n + 1], l2 = S.logn[n + 2];
         const double Xp = H.cLogXp[cd], XX = H.xq[(size_t)cd * H.xq_ld + cd];
         const double logweight = Xp - l1;
         {
@@ -374,8 +376,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 a = H.cLogZXp[q]; b = H.xq[(size_t)cd * H.xq_ld + q] + L - l1; has = true;
             }
             double r = a;
-            if (has) r = pc_logaddexp(a, b);
-            if (has3) r = pc_logaddexp(r, c3);
+            if (has3) {                                 // one log instead of two nested logaddexp's
+                const double m3 = fmax(a, fmax(b, c3));
+                r = m3 + log(exp(a - m3) + exp(b - m3) + exp(c3 - m3));
+            } else if (has) r = pc_logaddexp(a, b);
             H.jobres[tid] = r;
         }
         __syncthreads();
@@ -423,8 +427,9 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         } else if (tid == 0) { H.cMinSlot[cd] = -1; H.cLogLp[cd] = PC_HUGE; }
         __syncthreads();
         // posterior-stack columns (calculate.f90:53-79): volume after the update, logZ after the update
-        const double lseX = lse_logXp();
-        lx_now = lseX; lx_known = true;
+        double lxm, lxs;
+        lse_logXp(lxm, lxs);
+        lx_m = lxm; lx_s = lxs; lx_known = true;
         if (ndead >= S.Dcap) { error = PC_ERR_DEAD_CAP; status = PC_ST_ERROR; }
         if (status != PC_ST_ERROR) {
             if (plan_w >= 0) {
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                     const int src = S.slot_src[slot_del];
                     S.plan[plan_w].dead_idx = ndead;
                     S.plan[plan_w].dead_src = (src >= 0) ? -(1 + src) : slot_del;
-                    S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lseX; S.plan[plan_w].postZ = logZ;
+                    S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lxm; S.plan[plan_w].postXs = lxs; S.plan[plan_w].postZ = logZ;
                     S.plan[plan_w].dead_cuid = H.cUid[cd];
                 }
             } else {   // kill-off / trimming: rows are current in live[], copy immediately
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 double *dst = S.dead + (size_t)ndead * nT;
                 for (int e = tid; e < nT; e += NT) dst[e] = row[e];
                 if (tid == 0) {
-                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lseX; S.dead_postZ[ndead] = logZ;
+                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lxm + log(lxs); S.dead_postZ[ndead] = logZ;
                     S.dead_cuid[ndead] = H.cUid[cd]; S.dead_entry[ndead] = S.live_entry[slot_del];
                 }
             }
@@ -537,19 +542,25 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         else if (S.use_prec) {
             // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally.
             // One cluster per lane, log-sum-exp over the wave; the other waves pick the result up from LDS.
-            {   // every wave for itself (the state it reads was published before the last barrier of the iteration)
-                double mxv = -PC_HUGE, acc = 0.0;
+            {   // every wave for itself (the state it reads was published before the last barrier of the iteration).
+                // live_logZ = log sum_p exp(lse_p - log n_p + logX_p) with lse_p = ref_p + log(sum_p): kept as a pair
+                // (mxv, acc), acc = sum_p (sum_p / n_p) exp(ref_p + logX_p - mxv) -- no log on the critical path
+                double mxv = -PC_HUGE;
                 for (int c0 = 0; c0 < nc; c0 += 64) {
                     const int c = c0 + lane;
-                    const double term = (c < nc && H.cN[c] > 0) ? H.cLseRef[c] + log(H.cLseSum[c] / ((double)H.cN[c] + 0.0)) + H.cLogXp[c] : -PC_HUGE;
-                    const double m2 = fmax(mxv, wave_max(term));
-                    acc = acc * exp(mxv - m2) + wave_sum<4>(term > -PC_HUGE ? exp(term - m2) : 0.0);
-                    mxv = m2;
+                    mxv = fmax(mxv, (c < nc && H.cN[c] > 0) ? H.cLseRef[c] + H.cLogXp[c] : -PC_HUGE);
                 }
-                const double v = (acc > 0.0) ? mxv + log(acc) : S.logzero;
-                live_logZ_val = (v > S.logzero + 800.0) ? v : pc_logaddexp(S.logzero, v);   // exp(logzero - v) underflows to 0
+                mxv = wave_max(mxv);
+                double acc = 0.0;
+                for (int c0 = 0; c0 < nc; c0 += 64) {
+                    const int c = c0 + lane;
+                    if (c < nc && H.cN[c] > 0) acc += (H.cLseSum[c] / ((double)H.cN[c] + 0.0)) * exp(H.cLseRef[c] + H.cLogXp[c] - mxv);
+                }
+                acc = wave_sum<4>(acc);
+                ll_m = mxv; ll_s = acc;
             }
-            if (live_logZ_val < S.log_prec + logZ) more = false;
+            // more_samples_needed: live_logZ < log(precision) + logZ   <=>   acc < exp(log(precision) + logZ - mxv)
+            if (!(ll_s > 0.0) || ll_s < exp(S.log_prec + logZ - ll_m)) more = false;
         }
         if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
         if (i_nursery == 0) break;                      // batch exhausted: host launches the next one
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             if (ndead >= S.Dcap) { status = PC_ST_ERROR; error = PC_ERR_DEAD_CAP; break; }
             if (tid == 0) {
                 S.plan[w].dead_idx = ndead; S.plan[w].dead_src = -(1 + w);
-                S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
+                S.plan[w].logw = S.logzero; S.plan[w].postX = 0.0; S.plan[w].postXs = 1.0; S.plan[w].postZ = 0.0; S.plan[w].dead_cuid = 0xFFFFFFFFu;
             }
             ndead++;
         }
@@ -701,10 +712,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         const long long q3 = clock64(); cyK += q3 - q2;
 
         // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
-        if (!lx_known) { lx_now = lse_logXp(); lx_known = true; }
-        const double lx = lx_now;
-        const bool update = lx <= lx_last + S.log_cf;
-        if (update) lx_last = lx;
+        if (!lx_known) { lse_logXp(lx_m, lx_s); lx_known = true; }
+        // nested_sampling.F90:321  logsumexp(logXp) <= logX_last_update + log(compression_factor), in linear space
+        const bool update = lx_s <= exp(lx_last + S.log_cf - lx_m);
+        if (update) lx_last = lx_m + log(lx_s);
         if (drop_empty_cluster()) epoch++;
         cyE += clock64() - q3;
         if (nc == 0) { status = PC_ST_DONE; break; }
@@ -732,6 +743,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         ctl->failures = failures; ctl->ncluster = nc; ctl->ncluster_dead = nc_dead; ctl->ndead = ndead;
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
         ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
+        if (ll_s > 0.0) { const double v = ll_m + log(ll_s); live_logZ_val = (v > S.logzero + 800.0) ? v : pc_logaddexp(S.logzero, v); }
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
         ctl->gen_cyc[0] += cyT; ctl->gen_cyc[1] += cyI; ctl->gen_cyc[2] += cyK; ctl->gen_cyc[3] += cyE; ctl->nn_walks += cyW; ctl->nn_fallbacks += cyF;
     }
@@ -780,7 +792,7 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
         double *dst = S.dead + (size_t)di * nT;
         for (int e = lane; e < nT; e += 64) dst[e] = row[e];
         if (lane == 0) {
-            S.dead_logw[di] = S.plan[w].logw; S.dead_postX[di] = S.plan[w].postX; S.dead_postZ[di] = S.plan[w].postZ;
+            S.dead_logw[di] = S.plan[w].logw; S.dead_postX[di] = S.plan[w].postX + log(S.plan[w].postXs); S.dead_postZ[di] = S.plan[w].postZ;
             S.dead_cuid[di] = S.plan[w].dead_cuid;
             S.dead_entry[di] = (src >= 0) ? S.live_entry[src] : S.plan[-src - 1].contour;
         }

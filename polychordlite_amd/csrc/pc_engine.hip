@@ -228,7 +228,7 @@ struct Engine {
     double *psum = nullptr, *mean = nullptr, *pcov = nullptr; int *pcnt = nullptr, *count = nullptr;
     size_t cov_chunks_cap = 0;
     double *d_lo = nullptr, *d_hi = nullptr, *d_invcovT = nullptr, *d_mean = nullptr;
-    double *d_dynL = nullptr; int *d_dynN = nullptr;
+    double *d_dynL = nullptr; int *d_dynN = nullptr; double *d_logn = nullptr;
     // clustering scratch (allocated on first use)
     double *c_Sm = nullptr; int *c_pts = nullptr, *c_gidx = nullptr, *c_knn = nullptr, *c_lab = nullptr, *c_out = nullptr, *c_cnt = nullptr;
     unsigned *c_olduid = nullptr; int c_cap = 0;
@@ -359,6 +359,14 @@ struct Engine {
         S.ch_cluster = dalloc<int>(B); S.ch_epoch = dalloc<int>(B); S.ch_nlike = dalloc<int>(B); S.ch_seed_slot = dalloc<int>(B);
         S.ch_contour = dalloc<double>(B);
         if (S.ngrade > 1) { S.ch_nlike_g = dalloc<int>((size_t)B * PC_MAX_GRADE); h_nlike_g.assign((size_t)B * PC_MAX_GRADE, 0); }
+        {   // log k for the evidence update of the serial kernel
+            std::vector<double> ln((size_t)Ncap + 4);
+            ln[0] = -PC_HUGE;
+            for (int k = 1; k < Ncap + 4; ++k) ln[k] = std::log((double)k);
+            d_logn = dalloc<double>(ln.size());
+            HIPCHK(hipMemcpy(d_logn, ln.data(), sizeof(double) * ln.size(), hipMemcpyHostToDevice));
+            S.logn = d_logn;
+        }
         S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_valid = 0;
         if (c.do_clustering) {      // candidate lists of the nearest-cluster search (k_nn_lists)
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
@@ -1194,7 +1202,7 @@ struct Engine {
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
                        &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
-        dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
+        dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);

@@ -272,9 +272,9 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
             pw->contour = (kind == 0) ? PC_HUGE : Lg;                       // dropped chains get no phantoms
             pw->dead_idx = (kind >= 1) ? didx : -1;
             if (kind == 2) {
-                pw->dead_src = rSrc[lane]; pw->logw = Xb - l1; pw->postX = Xb + d01; pw->postZ = Zi; pw->dead_cuid = cuid;
+                pw->dead_src = rSrc[lane]; pw->logw = Xb - l1; pw->postX = Xb + d01; pw->postXs = 1.0; pw->postZ = Zi; pw->dead_cuid = cuid;
             } else if (kind == 1) {
-                pw->dead_src = -(1 + w); pw->logw = S.logzero; pw->postX = 0.0; pw->postZ = 0.0; pw->dead_cuid = 0xFFFFFFFFu;
+                pw->dead_src = -(1 + w); pw->logw = S.logzero; pw->postX = 0.0; pw->postXs = 1.0; pw->postZ = 0.0; pw->dead_cuid = 0xFFFFFFFFu;
             }
         }
         ndead0 += __popcll(dm);

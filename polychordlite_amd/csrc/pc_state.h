@@ -50,6 +50,7 @@ struct PcPlan {                  // one record per nursery chain, written by the
     unsigned dead_cuid, ph_cuid;
     int ph_count;                // -1: the apply side derives mask/count/base from `contour` (one cluster)
     double logw, postX, postZ;
+    double postXs;               // the volume column is postX + log(postXs): the serial kernel leaves the log to the apply side
     double contour;              // global contour when the chain was consumed (phantom test, entry contour)
     unsigned long long ph_mask[PC_MASK_WORDS];
 };
@@ -116,6 +117,7 @@ struct PcState {
     //      the whole chip (k_nn_lists) at a moment T0: for every baby of every unconsumed chain the PC_NN_K nearest points
     //      among the live set at T0 and the last babies of the chains consumed before its own, ascending.  Entry >= 0:
     //      live slot as occupied at T0; entry < 0: -(1 + chain) whose last baby may have entered since; PC_NN_NONE: end.
+    const double *logn;          // [Ncap + 4] log(k), k = 0 .. Ncap + 3 (log 0 = -huge): the evidence update needs log n, log(n+1), log(n+2)
     int *nn_list;                // [B][nr][PC_NN_K]
     int *nn_slot_owner;          // [Ncap] -1: occupant of T0 still there; -2: emptied since; w >= 0: last baby of chain w
     int *nn_chain_slot;          // [B] slot the chain's last baby went to since T0, or -1
