@@ -983,6 +983,7 @@ struct Engine {
             for (int k = 0; k < r.nlive[c]; ++k) lsum[c] += std::exp(r.live[c][(size_t)k * nT + S.l0] - lref[c]);
         }
         ul(S.live, rows); ul(S.live_logL, lL); ul(S.live_entry, entry); ul(S.live_cluster, lc); ul(S.live_pos, lp);
+        { std::vector<int> none(Ncap, -1); ul(S.slot_src, none); }     // every live row is current (k_install_live does this in a fresh run)
         ul(S.cl_list, cl); ul(S.cl_n, cn); ul(S.cl_uid, uid); ul(S.imin_slot, imin); ul(S.logLp, logLp); ul(S.lse_ref, lref); ul(S.lse_sum, lsum);
         auto put = [&](double *dst, const std::vector<double> &v) { std::vector<double> t(maxc, cfg.logzero); std::copy(v.begin(), v.end(), t.begin()); ul(dst, t); };
         put(S.logZp, r.logZp); put(S.logZXp, r.logZXp); put(S.logZp2, r.logZp2); put(S.logZpXp, r.logZpXp);

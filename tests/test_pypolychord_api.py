@@ -283,6 +283,10 @@ def test_resume_and_cube_samples(engine, tmp_path):
     cont = np.loadtxt(base2 / "r_dead-birth.txt")
     assert cont.shape[0] > snap["n"] + 100
     assert np.array_equal(cont[:snap["n"]], full[:snap["n"]])       # the first run's dead points, as written
+    # every row written after the restart is a real point: logL column = likelihood of its theta columns (the points
+    # that were alive in the resume file die now; their rows must come from the restored live set)
+    gl = -nD * (np.log(0.1) + 0.5 * np.log(2 * np.pi)) - 0.5 * np.sum(((cont[:, :nD] - 0.5) / 0.1) ** 2, axis=1)
+    assert np.allclose(cont[:, nD + 1], gl, rtol=0, atol=1e-9)
     st = open(base2 / "r.stats").read().splitlines()
     logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
     assert abs(logZ) < 4 * err and 0.1 < err < 0.6                   # truth: logZ = 0
@@ -332,7 +336,13 @@ def test_resume_with_clusters_and_large_nlive(engine, tmp_path):
     logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
     assert abs(logZ + 4.6526) < 4 * err + 0.05                          # truth -2 ln 10.24
     assert sum(1 for l in st if l.startswith("log(Z_")) >= snap["nc"]
-    assert np.loadtxt(base2 / "r_dead-birth.txt").shape[0] > snap["nd"] + 200
+    rows2 = np.loadtxt(base2 / "r_dead-birth.txt")
+    assert rows2.shape[0] > snap["nd"] + 200
+    # every dead row is a real point: its logL column is the likelihood of its theta columns (the points that were alive
+    # in the resume file die after the restart; their rows must come from the restored live set)
+    th = rows2[:, :2]
+    assert np.allclose(rows2[:, 2], -np.sum(np.log(4991.21750) + th ** 2 - 10.0 * np.cos(2 * np.pi * th), axis=1), rtol=0, atol=1e-9)
+    assert np.all(rows2[:, 3] < rows2[:, 2])                            # born below where they died
     # nlive = 6000: serial single-wave contraction and kill-off (the parallel kernel's LDS budget is exceeded)
     base3 = tmp_path / "c"
     pc.run(Gaussian(mu=0.5, sigma=0.1), 3, base_dir=str(base3), file_root="big", nlive=6000, num_repeats=6, do_clustering=False,
