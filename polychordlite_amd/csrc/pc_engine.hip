@@ -119,7 +119,16 @@ struct BlockCache {
 BlockCache &dcache() { static BlockCache *c = new BlockCache(false, (size_t)48 << 30); return *c; }
 BlockCache &hcache() { static BlockCache *c = new BlockCache(true, (size_t)4 << 30); return *c; }
 
-template <class T> T *dalloc(size_t n) { return (T *)dcache().get(sizeof(T) * (n ? n : 1)); }
+// PC_POISON=1 (tests): every device block is filled with 0x5A bytes when it is handed out -- ints become 1515870810,
+// doubles 2.6e127 -- so that a buffer some path forgets to initialise fails loudly instead of working by the luck of
+// what the previous run left in it
+template <class T> T *dalloc(size_t n)
+{
+    static const bool poison = std::getenv("PC_POISON") != nullptr;
+    T *p = (T *)dcache().get(sizeof(T) * (n ? n : 1));
+    if (poison) { (void)hipMemset((void *)p, 0x5A, sizeof(T) * (n ? n : 1)); (void)hipDeviceSynchronize(); }
+    return p;
+}
 template <class T> void dfree(T *&p) { if (p) dcache().put((void *)p); p = nullptr; }
 template <class T> T *halloc(size_t n) { return (T *)hcache().get(sizeof(T) * (n ? n : 1)); }
 void hfree(void *p) { if (p && !hcache().put(p)) std::free(p); }

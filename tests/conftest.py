@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the engine recycles device blocks between runs; in the tests every block it hands out is first filled with a
+# garbage pattern (pc_engine.hip dalloc), so that a buffer a code path forgets to initialise cannot pass by luck
+os.environ.setdefault("PC_POISON", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
