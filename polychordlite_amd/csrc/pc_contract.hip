@@ -1148,14 +1148,16 @@ __global__ __launch_bounds__(256) void k_fold_partials(double *buf, int *cnt, in
 }
 
 #define PC_CHOL_NT 1024
-__global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count)
+__global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count, int a_global)
 {
     // one workgroup per cluster: fixed-order sum of the partials, then calc_cholesky (utils.F90:621-649)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D, tid = threadIdx.x;
     // red [PC_CHOL_NT]: scratch of the reduction; it borrows L (zeroed afterwards) when the two matrices
     // alone fill the LDS (nDims = 100: 2 x 80 KB)
-    double *A = (double *)smem, *L = A + DD, *red = (DD >= PC_CHOL_NT) ? L : L + DD;
+    // a_global (nDims > 101: two matrices exceed the LDS): the covariance is read back from S.cov, only L lives in LDS
+    double *A = a_global ? S.cov + (size_t)c * DD : (double *)smem;
+    double *L = a_global ? (double *)smem : A + DD, *red = (DD >= PC_CHOL_NT) ? L : L + DD;
     __shared__ int bad;
     const double n = (double)count[c];
     // G groups of DDp threads; group g adds chunks g, g+G, ... in order, then the groups are added in order
@@ -1182,8 +1184,9 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
         if (tid < DDp && p < DD) {
             double t = 0.0;
             for (int gg = 0; gg < G; ++gg) t += red[gg * DDp + tid];
-            A[p] = t / n;
-            S.cov[(size_t)c * DD + p] = A[p];
+            const double av = t / n;
+            if (!a_global) A[p] = av;
+            S.cov[(size_t)c * DD + p] = av;
         }
         __syncthreads();
     }
@@ -1430,11 +1433,13 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
         hipLaunchKernelGGL(k_cov_partial, dim3(nchunk, nc), dim3(256), sh, st, *S, nrows, nred, psum, pcnt, mean, count, pcov, CR, TS, 0, nchunk);
         if (nchunk > 2 * NFOLD) hipLaunchKernelGGL(k_fold_partials, dim3(NFOLD, nc), dim3(256), 0, st, pcov, (int *)nullptr, nchunk, nc, D * D);
     }
-    const size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
+    size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
+    int a_global = 0;
+    if (sh2 > 160 * 1024) { a_global = 1; sh2 = sizeof(double) * ((size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT)); }
     if (sh2 > 160 * 1024) return 1;
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count, a_global);
     return 0;
 }
 

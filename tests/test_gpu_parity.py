@@ -208,7 +208,7 @@ def test_dynamic_nlive_and_nprior_match_oracle(engine, B):
     assert abs(g["logZ"]) < 4 * g["logZerr"]            # truth 0
 
 
-@pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24)])
+@pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24), (128, 50, 8, 16), (113, 40, 6, 8)])
 def test_correlated_gaussian_high_dim_matches_oracle(engine, D, nlive, nr, B):
     """random_gaussian.f90 in 100 (and 40) dimensions: the wide-nDims kernel variants, and live sets whose logL
     spans ~1e5 nats inside one nursery (the live log-sum-exp must not lose the old points to underflow)."""
