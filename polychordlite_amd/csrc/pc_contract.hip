@@ -976,7 +976,15 @@ __global__ __launch_bounds__(256) void k_cov_mean_partial(PcState S, int nrows, 
     const int cnt = __syncthreads_count(mine);
     for (int d = tid % DPc; d < D; d += DPc) {
         double s = 0.0;
-        for (int r = r0 + g; r < r1; r += G)
+        int r = r0 + g;
+        for (; r + 7 * G < r1; r += 8 * G) {              // eight independent loads in flight, added in row order
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = (rc[r + u * G - r0] == c) ? cov_ptr(S, r + u * G)[d] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t8[u];
+        }
+        for (; r < r1; r += G)
             if (rc[r - r0] == c) s += cov_ptr(S, r)[d];
         if (G > 1) red[tid] = s; else psum[((size_t)chunk * nc + c) * D + d] = s;
     }
@@ -1069,16 +1077,31 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     if (member) rc[base + __popcll(bm & ((1ull << lane) - 1ull))] = r0 + tid;
     __syncthreads();
     if (!use_mfma) {
-        for (int e = tid; e < n * D; e += 256) {
-            const int i = e / D, d = e % D;
-            tile[(size_t)i * TS + d] = cov_ptr(S, rc[i])[d] - mu[d];
+        {
+            int e = tid;
+            for (; e + 7 * 256 < n * D; e += 8 * 256) {   // eight independent row reads in flight
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int ee = e + u * 256; t8[u] = cov_ptr(S, rc[ee / D])[ee % D]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int ee = e + u * 256, i = ee / D, d = ee % D; tile[(size_t)i * TS + d] = t8[u] - mu[d]; }
+            }
+            for (; e < n * D; e += 256) { const int i = e / D, d = e % D; tile[(size_t)i * TS + d] = cov_ptr(S, rc[i])[d] - mu[d]; }
         }
         __syncthreads();
         for (int p = tid; p < D * D; p += 256) {
             const int a = p / D, b = p % D;
-            double s = 0.0;
-            for (int i = 0; i < n; ++i) s += tile[(size_t)i * TS + a] * tile[(size_t)i * TS + b];
-            pcov[((size_t)chunk * nc + c) * D * D + p] = s;
+            // rows i, i+1, i+2, i+3 on four accumulators (a 256-deep dependent FMA chain costs ~32 cycles per row)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int i = 0;
+            for (; i + 3 < n; i += 4) {
+                s0 += tile[(size_t)i * TS + a] * tile[(size_t)i * TS + b];
+                s1 += tile[(size_t)(i + 1) * TS + a] * tile[(size_t)(i + 1) * TS + b];
+                s2 += tile[(size_t)(i + 2) * TS + a] * tile[(size_t)(i + 2) * TS + b];
+                s3 += tile[(size_t)(i + 3) * TS + a] * tile[(size_t)(i + 3) * TS + b];
+            }
+            for (; i < n; ++i) s0 += tile[(size_t)i * TS + a] * tile[(size_t)i * TS + b];
+            pcov[((size_t)chunk * nc + c) * D * D + p] = (s0 + s1) + (s2 + s3);
         }
         return;
     }
