@@ -12,6 +12,36 @@ except ImportError:                     # not built: the ctypes binding of the s
 from .settings import PolyChordSettings  # noqa: F401
 
 
+def _mpi_comm():
+    """COMM_WORLD when the script runs under mpirun with mpi4py (the reference's MPI farm: polychord.py:513-518,
+    nested_sampling.F90:262-301), else None.  The engine's parallelism is the GPU: rank 0 runs it, the other ranks wait
+    for it and return the same files' results -- they must not start duplicate runs into the same base_dir."""
+    try:
+        from mpi4py import MPI
+    except ImportError:
+        return None
+    comm = MPI.COMM_WORLD
+    return comm if comm.Get_size() > 1 else None
+
+
+def _engine_run(*args):
+    """_pypolychord.run on rank 0; every rank leaves together (a failure on rank 0 is re-raised there after the others
+    have been released)"""
+    comm = _mpi_comm()
+    if comm is None:
+        return _pypolychord.run(*args)
+    err = None
+    if comm.Get_rank() == 0:
+        try:
+            _pypolychord.run(*args)
+        except BaseException as e:      # noqa: BLE001 - re-raised below
+            err = e
+    comm.Barrier()
+    if err is not None:
+        raise err
+    return None
+
+
 def default_prior(cube):
     """identity prior on the unit hypercube (polychord.py:9-10)"""
     return cube.copy()
@@ -154,14 +184,18 @@ def _legacy_make_resume_file(settings, loglikelihood, prior):
 
 def run_polychord(loglikelihood, nDims, nDerived, settings, prior=default_prior, dumper=default_dumper):
     """legacy interface (polychord.py:16-215)"""
-    Path(settings.cluster_dir).mkdir(parents=True, exist_ok=True)
+    comm = _mpi_comm()
+    root = comm is None or comm.Get_rank() == 0
+    if root:
+        Path(settings.cluster_dir).mkdir(parents=True, exist_ok=True)
     if settings.cube_samples is not None:                      # polychord.py:170-173 of the reference
-        _legacy_make_resume_file(settings, loglikelihood, prior)
+        if root:
+            _legacy_make_resume_file(settings, loglikelihood, prior)
         settings.read_resume = True
     wl, wp = _wrap(loglikelihood, prior)
     settings.grade_dims = [int(d) for d in settings.grade_dims]
     settings.nlives = {float(logL): int(nlive) for logL, nlive in settings.nlives.items()}
-    _pypolychord.run(wl, wp, dumper, nDims, nDerived, settings.nlive, settings.num_repeats, settings.nprior, settings.nfail,
+    _engine_run(wl, wp, dumper, nDims, nDerived, settings.nlive, settings.num_repeats, settings.nprior, settings.nfail,
                      settings.do_clustering, settings.feedback, settings.precision_criterion, settings.logzero,
                      settings.max_ndead, settings.boost_posterior, settings.posteriors, settings.equals,
                      settings.cluster_posteriors, settings.write_resume, settings.write_paramnames, settings.read_resume,
@@ -189,18 +223,22 @@ def run(loglikelihood, nDims, **kwargs):
         raise TypeError(f"{__name__} got unknown keyword arguments: {kwargs.keys() - default_kwargs.keys()}")
     default_kwargs.update(kwargs)
     kwargs = default_kwargs
-    (Path(kwargs["base_dir"]) / kwargs["cluster_dir"]).mkdir(parents=True, exist_ok=True)
-    if paramnames is not None:
-        make_paramnames_file(paramnames, Path(kwargs["base_dir"]) / (kwargs["file_root"] + ".paramnames"))
+    comm = _mpi_comm()
+    root = comm is None or comm.Get_rank() == 0                # polychord.py:566-572 of the reference: rank 0 makes the directories
+    if root:
+        (Path(kwargs["base_dir"]) / kwargs["cluster_dir"]).mkdir(parents=True, exist_ok=True)
+        if paramnames is not None:
+            make_paramnames_file(paramnames, Path(kwargs["base_dir"]) / (kwargs["file_root"] + ".paramnames"))
     wl, wp = _wrap(loglikelihood, kwargs["prior"])
     kwargs["grade_dims"] = [int(d) for d in list(kwargs["grade_dims"])]
     if sum(kwargs["grade_dims"]) != nDims:
         raise ValueError(f"grade_dims ({sum(kwargs['grade_dims'])}) must sum to nDims ({nDims})")
     kwargs["nlives"] = {float(logL): int(nlive) for logL, nlive in kwargs["nlives"].items()}
     if kwargs["cube_samples"] is not None:                     # polychord.py:596-598 of the reference
-        _make_resume_file(loglikelihood, **kwargs)
+        if root:
+            _make_resume_file(loglikelihood, **kwargs)
         kwargs["read_resume"] = True
-    _pypolychord.run(wl, wp, kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
+    _engine_run(wl, wp, kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
                      kwargs["nprior"], kwargs["nfail"], kwargs["do_clustering"], kwargs["feedback"],
                      kwargs["precision_criterion"], kwargs["logzero"], kwargs["max_ndead"], kwargs["boost_posterior"],
                      kwargs["posteriors"], kwargs["equals"], kwargs["cluster_posteriors"], kwargs["write_resume"],

@@ -72,6 +72,35 @@ def test_compiled_extension_surface():
         m.run(*base)
 
 
+def test_under_mpirun_only_rank_0_runs_the_engine(tmp_path, monkeypatch):
+    """a script launched with mpirun (the reference's MPI farm, polychord.py:513-518): the GPU is the engine's
+    parallelism, so rank 0 runs it and the other ranks wait at a barrier -- they must not start duplicate runs into the
+    same base_dir.  mpi4py is simulated."""
+    import sys
+    import types
+    from polychordlite_amd.pypolychord import polychord as pc
+    calls, barriers = [], []
+
+    def fake_comm(rank):
+        comm = types.SimpleNamespace(Get_rank=lambda: rank, Get_size=lambda: 4, Barrier=lambda: barriers.append(rank))
+        return types.SimpleNamespace(MPI=types.SimpleNamespace(COMM_WORLD=comm))
+    monkeypatch.setattr(pc, "_pypolychord", types.SimpleNamespace(run=lambda *a: calls.append(a)))
+    for rank in (1, 0):
+        monkeypatch.setitem(sys.modules, "mpi4py", fake_comm(rank))
+        base = tmp_path / f"r{rank}"
+        pc.run(gaussian_likelihood, nDims, nDerived=1, base_dir=str(base), nlive=20, num_repeats=4, feedback=0)
+        assert (base / "clusters").is_dir() == (rank == 0)              # polychord.py:566-568: rank 0 makes the directories
+    assert len(calls) == 1 and barriers == [1, 0]
+    # a failure on rank 0 is raised after the barrier
+    def boom(*a):
+        raise RuntimeError("engine")
+    monkeypatch.setattr(pc, "_pypolychord", types.SimpleNamespace(run=boom))
+    monkeypatch.setitem(sys.modules, "mpi4py", fake_comm(0))
+    with pytest.raises(RuntimeError):
+        pc.run(gaussian_likelihood, nDims, nDerived=1, base_dir=str(tmp_path / "x"), nlive=20, num_repeats=4, feedback=0)
+    assert barriers[-1] == 0
+
+
 def test_builtin_functors_are_plain_callables():
     g = dl.Gaussian(mu=0.5, sigma=0.1, nDerived=2)
     logL, phi = g(np.full(20, 0.5))
