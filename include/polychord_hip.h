@@ -139,6 +139,7 @@ typedef struct {
     double *logZp, *varlogZp; int nZp;
     double *post_mean, *post_var;  /* [nDims + nDerived] weighted posterior moments of theta, phi */
     long nlike_grade[8];           /* likelihood evaluations per grade (RTI%nlike; the prior samples count for grade 1) */
+    int *live_cluster;             /* [nlive_final] 0-based cluster of each row of `live` */
 } pchip_result;
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
@@ -185,6 +186,11 @@ int  pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prio
 int  pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
                      const pchip_hooks *hooks, pchip_result *out);
 void pchip_result_free(pchip_result *r);
+/* `maximise = T` (maximiser.F90:32-224, nelder_mead.f90, write_max_file read_write.F90:754-807): Nelder-Mead polish of
+   the best live points of a finished run into the maximum-likelihood and maximum-posterior points, written to `path`
+   (<base_dir>/<file_root>.maximum).  Host code; live rows as in pchip_result.  0 on success. */
+int  pchip_maximise(polychord_loglike_fn loglikelihood, polychord_prior_fn prior, int nDims, int nDerived, double logzero,
+                    const double *live, const int *live_cluster, int nlive, const double *post_mean, const char *path);
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */
 int  pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
                         unsigned batch, int nchains, const double *seeds, const double *chol,

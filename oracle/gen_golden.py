@@ -56,8 +56,27 @@ def grade_cases(inj):
     return out
 
 
+def maximum_cases(inj):
+    """<root>.maximum of the reference (maximise = T, maximiser.F90 / nelder_mead.f90) for two injected runs"""
+    out = []
+    for like, D, nDer, nlive, nr, seed, clus in (("gaussian", 4, 1, 100, 20, 2, 0), ("rastrigin", 2, 0, 300, 6, 2, 1)):
+        j = last_json(sh(f"REF_MAXIMISE=1 {inj} {like} {D} {nDer} {nlive} {nr} {seed} {clus} {TMP}/chains mx 0"))
+        lines = open(f"{TMP}/chains/mx.maximum").read().splitlines()
+        num = lambda k: [float(x) for x in lines[k].split()]
+        out.append(dict(like=like, nDims=D, nDerived=nDer, nlive=nlive, num_repeats=nr, seed=seed, clustering=clus,
+                        ndead=j["ndead"], max_loglike=num(1)[0], max_point=num(3), max_posterior=num(6)[0],
+                        loglike_at_posterior=num(8)[0], posterior_point=num(10)))
+        print("maximum", out[-1])
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "maximum":
+        os.makedirs(TMP + "/chains/clusters", exist_ok=True)
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        json.dump(maximum_cases(os.path.join(HERE, "_ref", "ref_driver_inject")), open(os.path.join(GOLD, "ref_maximum.json"), "w"), indent=1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "grades":     # refresh only the grade cases of ref_injected.json
         os.makedirs(TMP + "/chains/clusters", exist_ok=True)
         subprocess.check_call(["make", "-C", HERE, "ref"])
@@ -101,6 +120,7 @@ def main():
         print("injected", j)
     injected += grade_cases(inj)
     json.dump(injected, open(os.path.join(GOLD, "ref_injected.json"), "w"), indent=1)
+    json.dump(maximum_cases(inj), open(os.path.join(GOLD, "ref_maximum.json"), "w"), indent=1)
 
     native = []
     for seed in range(1, 9):

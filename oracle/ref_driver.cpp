@@ -119,8 +119,9 @@ int main(int argc, char **argv)
     int comm = 0;
     if (pc_shim_reset) pc_shim_reset((unsigned)seed);
     auto t0 = std::chrono::steady_clock::now();
+    const bool maximise = std::getenv("REF_MAXIMISE") != nullptr;       // optional: <root>.maximum (maximiser.F90)
     polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
-                          false, false, false, write_resume, false, false, true, false, write_dead, false, false,
+                          false, false, false, write_resume, false, false, true, false, write_dead, false, maximise,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
                           nGrade, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

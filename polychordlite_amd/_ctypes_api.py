@@ -55,7 +55,7 @@ class Result(C.Structure):
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
-                ("nlike_grade", C.c_long * 8)]
+                ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int))]
 
 
 _lib = None

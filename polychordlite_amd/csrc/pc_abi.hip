@@ -405,7 +405,6 @@ void polychord_c_interface(
     char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
     double *loglikes, int *nlives, int seed, int *comm)
 {
-    (void)maximise;
     (void)synchronous; (void)comm;
     if (num_repeats < 1) halt_program("You need to set num_repeats. Suggestion: 5*nDims");     // settings.f90:216
     pchip_settings s;
@@ -481,6 +480,13 @@ void polychord_c_interface(
     const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);
     if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
     if (rc != 0) halt_program("polychord_hip: engine failure");
+    if (maximise && r.nlive_final > 0) {
+        // nested_sampling.F90:379: polish the best live points of the set at termination (host side, pc_maximise.hip)
+        const std::string mpath = base + "/" + root + ".maximum";
+        if (pchip_maximise(loglikelihood, prior, nDims, nDerived, logzero, r.live, r.live_cluster, r.nlive_final,
+                           posteriors ? r.post_mean : nullptr, mpath.c_str()) == 2)
+            halt_program(("PolyChord Error: " + base + " does not exist").c_str());
+    }
     if (feedback >= 1) {
         std::printf("polychord_hip: log(Z) = %.6f +/- %.6f  ndead = %ld  nlike = %ld  (%.3f s, batch %d)\n",
                     r.logZ, std::sqrt(std::fabs(r.varlogZ)), r.ndead, r.nlike, r.t_total, r.batch);

@@ -1174,7 +1174,8 @@ struct Engine {
         for (int s = 0; s < S.Ncap; ++s) nl += hcl[s] >= 0;
         out->nlive_final = nl;
         out->live = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, nl) * nT);
-        for (int s = 0, k = 0; s < S.Ncap; ++s) if (hcl[s] >= 0) { std::memcpy(out->live + (size_t)k * nT, hlive.data() + (size_t)s * nT, sizeof(double) * nT); k++; }
+        out->live_cluster = (int *)std::malloc(sizeof(int) * (size_t)std::max(1, nl));
+        for (int s = 0, k = 0; s < S.Ncap; ++s) if (hcl[s] >= 0) { std::memcpy(out->live + (size_t)k * nT, hlive.data() + (size_t)s * nT, sizeof(double) * nT); out->live_cluster[k] = hcl[s]; k++; }
         const int ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead);
         out->nZp = ncd;
         out->logZp = (double *)std::malloc(sizeof(double) * std::max(1, ncd));
@@ -1281,7 +1282,7 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
 void pchip_result_free(pchip_result *r)
 {
     hfree(r->dead); hfree(r->logweights); hfree(r->entry); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
-    std::free(r->post_mean); std::free(r->post_var);
+    std::free(r->post_mean); std::free(r->post_var); std::free(r->live_cluster);
     std::memset(r, 0, sizeof(*r));
 }
 

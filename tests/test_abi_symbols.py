@@ -48,3 +48,39 @@ def test_builtin_host_functions_evaluate():
     a = lib.polychord_hip_gaussian(api.dptr(th), 20, api.dptr(phi), 2)
     b = olib.pc_like_eval(C.byref(L), orc.dptr(th), 20, orc.dptr(phi2), 2)
     assert abs(a - b) < 1e-12 and np.allclose(phi, phi2, rtol=1e-13)
+
+
+def test_maximiser_on_the_host(tmp_path):
+    """pchip_maximise (maximise = T: maximiser.F90, nelder_mead.f90, write_max_file) is host code: from a live set around
+    the peak of the 4-D Gaussian it must climb to the peak and write <root>.maximum in the reference's layout"""
+    import ctypes as C
+    import numpy as np
+    from polychordlite_amd import _ctypes_api as api
+    lib = api.load()
+    D, nDer, n = 4, 1, 60
+    nT = 2 * D + nDer + 2
+    lib.polychord_hip_set_gaussian(0.5, 0.1)
+    lo, hi = np.zeros(D), np.ones(D)
+    lib.polychord_hip_set_uniform_prior(D, api.dptr(lo), api.dptr(hi))
+    like = C.cast(lib.polychord_hip_gaussian, C.c_void_p); prior = C.cast(lib.polychord_hip_uniform_prior, C.c_void_p)
+    rng = np.random.default_rng(5)
+    live = np.zeros((n, nT))
+    live[:, :D] = 0.5 + 0.03 * rng.standard_normal((n, D)); live[:, D:2 * D] = live[:, :D]
+    norm = -D * (np.log(0.1) + 0.5 * np.log(2 * np.pi))
+    live[:, -1] = norm - 0.5 * np.sum(((live[:, :D] - 0.5) / 0.1) ** 2, axis=1)
+    cl = np.zeros(n, dtype=np.int32)
+    mean = np.array([0.5, 0.5, 0.5, 0.5, 0.0])
+    f = lib.pchip_maximise
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
+                  C.POINTER(C.c_double), C.c_char_p]
+    path = tmp_path / "t.maximum"
+    assert f(like, prior, D, nDer, -1e30, api.dptr(live), cl.ctypes.data_as(C.POINTER(C.c_int)), n, api.dptr(mean), str(path).encode()) == 0
+    lines = path.read_text().splitlines()
+    assert lines[0] == "Maximum LogLikelihood:" and lines[2] == "Maximum Likelihood point:" and lines[5] == "Maximum Posterior:"
+    assert lines[7] == "Maximum Likelihood at posterior:" and lines[9] == "Maximum Posterior point:" and lines[12] == "LogLikelihood(mean):"
+    assert abs(float(lines[1]) - norm) < 1e-4                      # nelder_mead stops at a spread of 1e-5 (or a collapsed simplex)
+    pt = np.array([float(x) for x in lines[3].split()])
+    assert pt.size == D + nDer and np.all(np.abs(pt[:D] - 0.5) < 2e-3) and pt[D] < 3e-3      # phi = radius
+    assert abs(float(lines[6]) - float(lines[8])) < 1e-9          # uniform unit prior: dX/dtheta = 1
+    assert abs(float(lines[13]) - norm) < 1e-12 and len(lines[1]) == 24       # E24.15E3

@@ -555,3 +555,21 @@ def test_compiled_and_ctypes_bindings_agree(engine, tmp_path):
                 0.36787944117144233, True, str(tmp_path), root, [1.0], [6], {}, 5)
         outs.append(got[-1])
     assert outs[0] == outs[1] and abs(outs[0]) < 1.5
+
+
+@pytest.mark.gpu
+def test_maximise_writes_the_maximum_file(engine, tmp_path):
+    """maximise=True through pypolychord.run (polychord.py:397-400): <root>.maximum in the reference's layout
+    (read_write.F90:754-807), Python likelihood with a derived parameter and a Python prior on U(-1,1)^4"""
+    pypolychord.run(gaussian_likelihood, nDims, nDerived=1, prior=uniform_prior, nlive=nlive, num_repeats=8, seed=3,
+                    do_clustering=False, read_resume=False, write_resume=False, maximise=True, posteriors=True,
+                    base_dir=str(tmp_path), file_root="mx", feedback=0)
+    lines = (tmp_path / "mx.maximum").read_text().splitlines()
+    assert lines[0] == "Maximum LogLikelihood:" and lines[5] == "Maximum Posterior:" and lines[12] == "LogLikelihood(mean):"
+    peak = -np.log(2 * np.pi * 0.01) * nDims / 2.0
+    assert abs(float(lines[1]) - peak) < 1e-3
+    pt = np.array([float(x) for x in lines[3].split()])
+    assert pt.size == nDims + 1 and np.all(np.abs(pt[:nDims]) < 5e-3)
+    # U(-1,1)^4: dX/dtheta = 2^-4, the posterior density is the likelihood times it
+    assert abs(float(lines[6]) - (float(lines[8]) - nDims * np.log(2.0))) < 1e-6
+    assert abs(float(lines[13]) - peak) < 0.5                      # likelihood at the posterior mean
