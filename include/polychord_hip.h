@@ -73,6 +73,9 @@ void polychord_hip_request_stop(void);
 /* .resume files (reference grammar) without a run: parse `in`, optionally write it back to `out`;
  * counts[0..5] = nDims, nDerived, ndead, ncluster, ncluster_dead, total live points.  0 on success. */
 int polychord_hip_resume_copy(const char *in, const char *out, int *counts);
+/* the prior block of an ini file (ini.f90:354-458, priors.f90: uniform, log_uniform, power_uniform, gaussian,
+ * half_gaussian, exponential and their sorted_ variants) evaluated at one hypercube point; returns nDims, -1 if n < nDims */
+int polychord_hip_ini_prior(const char *inifile, const double *cube, double *theta, int n);
 /* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
 void polychord_hip_set_option(const char *name, double value);
 

@@ -88,9 +88,12 @@ def main():
         json.dump(injected, open(path, "w"), indent=1)
         return
     os.makedirs(TMP, exist_ok=True)
-    subprocess.check_call(["make", "-C", HERE, "ref", "_ref/ref_units"])
+    subprocess.check_call(["make", "-C", HERE, "ref", "_ref/ref_units", "_ref/ref_priors"])
     units = json.loads(subprocess.check_output([os.path.join(HERE, "_ref", "ref_units")], text=True))
     json.dump(units, open(os.path.join(GOLD, "ref_units.json"), "w"), indent=1)
+    # prior transforms of the reference's priors_module (oracle/ref_priors.f90)
+    priors = json.loads(subprocess.check_output([os.path.join(HERE, "_ref", "ref_priors")], text=True))
+    json.dump(priors, open(os.path.join(GOLD, "ref_priors.json"), "w"), indent=1)
 
     inj = os.path.join(HERE, "_ref", "ref_driver_inject")
     nat = os.path.join(HERE, "_ref", "ref_driver")

@@ -109,32 +109,85 @@ double inv_normal_cdf_host(double p)
 
 std::vector<int> g_hyper;   // hypercube index of physical parameter i: parameters are ordered by speed in the cube (priors.f90:708-737)
 
+// minimum number of prior parameters of a base type, or -1 if the type is not supported
+int base_prior_nparams(const std::string &t)
+{
+    if (t == "uniform" || t == "log_uniform" || t == "gaussian" || t == "half_gaussian") return 2;
+    if (t == "exponential") return 1;
+    if (t == "power_uniform") return 3;
+    return -1;
+}
+std::string base_of(const std::string &prior) { return prior.rfind("sorted_", 0) == 0 ? prior.substr(7) : prior; }
+
+// separable transforms of priors.f90:40-204 on one coordinate y in [0,1]
+double base_transform(const std::string &t, double y, const std::vector<double> &pp, const std::string &name)
+{
+    if (t == "uniform") return pp[0] + (pp[1] - pp[0]) * y;                                   // priors.f90:40-55
+    if (t == "log_uniform") return pp[0] * std::pow(pp[1] / pp[0], y);                       // :114-128
+    if (t == "gaussian") return pp[0] + pp[1] * inv_normal_cdf_host(y);                      // :73-88
+    if (t == "half_gaussian") return pp[0] + pp[1] * inv_normal_cdf_host(0.5 + 0.5 * y);    // :172-187
+    if (t == "exponential") return -std::log(1.0 - y) / pp[0];                               // :192-204
+    if (t == "power_uniform") {                                                               // :151-167
+        const double a = std::pow(pp[0], 1.0 / pp[2]), b = std::pow(pp[1], 1.0 / pp[2]);
+        return std::pow(a - y * std::fabs(a - b), pp[2]);
+    }
+    halt_program("get_priors error: Unknown prior type for parameter " + name);
+}
+
 void ini_prior(double *cube_h, double *theta, int nDims)
-{   // hypercube_to_physical (priors.f90:494-556) for the supported separable / sorted blocks
+{   // hypercube_to_physical (priors.f90:494-556): separable blocks, and sorted_* blocks = the order statistics of the
+    // block's coordinates (sort_hypercube, priors.f90:245-262) pushed through the separable transform
     std::vector<double> cube(nDims);
     for (int k = 0; k < nDims; ++k) cube[k] = cube_h[g_hyper[k]];
     int i = 0;
     while (i < nDims) {
         const Param &p = g_params[i];
-        if (p.prior == "sorted_uniform") {       // priors.f90:245-290: order statistics of a block of uniforms
+        const std::string base = base_of(p.prior);
+        if (p.prior != base) {                    // sorted block: consecutive parameters of the same type and block
             int j = i;
-            while (j < nDims && g_params[j].prior == "sorted_uniform" && g_params[j].block == p.block) ++j;
+            while (j < nDims && g_params[j].prior == p.prior && g_params[j].block == p.block) ++j;
             const int n = j - i;
-            const double lo = p.pp[0], hi = p.pp[1];
-            double prev = 1.0;                    // theta_n = x_n^(1/n); theta_{k} = theta_{k+1} x_k^(1/k)
-            for (int k = n; k >= 1; --k) { prev = prev * std::pow(cube[i + k - 1], 1.0 / k); theta[i + k - 1] = lo + (hi - lo) * prev; }
+            double prev = 1.0;                    // y_n = x_n^(1/n); y_k = y_{k+1} x_k^(1/k)
+            for (int k = n; k >= 1; --k) {
+                prev = prev * std::pow(cube[i + k - 1], 1.0 / k);
+                theta[i + k - 1] = base_transform(base, prev, g_params[i + k - 1].pp, g_params[i + k - 1].name);
+            }
             i = j;
             continue;
         }
-        if (p.prior == "uniform") theta[i] = p.pp[0] + (p.pp[1] - p.pp[0]) * cube[i];
-        else if (p.prior == "log_uniform") theta[i] = p.pp[0] * std::pow(p.pp[1] / p.pp[0], cube[i]);
-        else if (p.prior == "gaussian") theta[i] = p.pp[0] + p.pp[1] * inv_normal_cdf_host(cube[i]);
-        else halt_program("get_priors error: Unknown prior type for parameter " + p.name);
+        theta[i] = base_transform(base, cube[i], p.pp, p.name);
         ++i;
     }
 }
 
 }  // namespace
+
+// the prior block of an ini file evaluated at one hypercube point (tests; tools that want theta for a cube sample):
+// returns the number of parameters, or -1 when `n` is too small
+extern "C" int polychord_hip_ini_prior(const char *inifile, const double *cube, double *theta, int n)
+{
+    const Ini ini = read_ini(inifile ? inifile : "");
+    const int nDims = (int)ini.params.size();
+    if (nDims > n) return -1;
+    g_params = ini.params;
+    // hypercube order = parameters by speed (priors.f90:708-737), as in polychord_c_interface_ini
+    std::vector<int> distinct;
+    for (auto &p : ini.params) distinct.push_back(p.speed);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    g_hyper.assign(nDims, 0);
+    int h = 0;
+    for (size_t g = 0; g < distinct.size(); ++g)
+        for (int i = 0; i < nDims; ++i) if (ini.params[i].speed == distinct[g]) g_hyper[i] = h++;
+    for (int i = 0; i < nDims; ++i) {
+        const int need = base_prior_nparams(base_of(ini.params[i].prior));
+        if (need < 0) halt_program("get_priors error: Unknown prior type for parameter " + ini.params[i].name);
+        if ((int)ini.params[i].pp.size() < need) halt_program("ini error: parameter " + ini.params[i].name + " needs " + std::to_string(need) + " prior parameters");
+    }
+    std::vector<double> c(cube, cube + nDims);
+    ini_prior(c.data(), theta, nDims);
+    return nDims;
+}
 
 extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, void (*setup_loglikelihood)(void), char *inifile, int *comm)
 {
@@ -166,8 +219,10 @@ extern "C" void polychord_c_interface_ini(polychord_loglike_fn loglikelihood, vo
     std::vector<double> lo(nDims), hi(nDims);
     for (int i = 0; i < nDims; ++i) {
         all_uniform &= ini.params[i].prior == "uniform";
-        if (ini.params[i].pp.size() < 2) halt_program("ini error: parameter " + ini.params[i].name + " needs two prior parameters");
-        lo[i] = ini.params[i].pp[0]; hi[i] = ini.params[i].pp[1];
+        const int need = base_prior_nparams(base_of(ini.params[i].prior));
+        if (need < 0) halt_program("get_priors error: Unknown prior type for parameter " + ini.params[i].name);
+        if ((int)ini.params[i].pp.size() < need) halt_program("ini error: parameter " + ini.params[i].name + " needs " + std::to_string(need) + " prior parameters");
+        lo[i] = ini.params[i].pp[0]; hi[i] = ini.params[i].pp.size() > 1 ? ini.params[i].pp[1] : 0.0;
     }
     polychord_prior_fn prior = ini_prior;
     if (all_uniform) { polychord_hip_set_uniform_prior(nDims, lo.data(), hi.data()); prior = polychord_hip_uniform_prior; }

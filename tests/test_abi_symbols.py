@@ -84,3 +84,35 @@ def test_maximiser_on_the_host(tmp_path):
     assert pt.size == D + nDer and np.all(np.abs(pt[:D] - 0.5) < 2e-3) and pt[D] < 3e-3      # phi = radius
     assert abs(float(lines[6]) - float(lines[8])) < 1e-9          # uniform unit prior: dX/dtheta = 1
     assert abs(float(lines[13]) - norm) < 1e-12 and len(lines[1]) == 24       # E24.15E3
+
+
+def test_ini_priors_match_the_reference(golden, tmp_path):
+    """the prior blocks of the ini front end (pc_ini.hip) against the reference's priors_module evaluated on the same
+    hypercube point (tests/golden/ref_priors.json, written by oracle/ref_priors.f90 linked against the reference)"""
+    import ctypes as C
+    import numpy as np
+    from polychordlite_amd import _ctypes_api as api
+    lib = api.load()
+    f = lib.polychord_hip_ini_prior
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    g = golden["ref_priors"]
+    cube = np.array(g["cube"])
+    params = {  # prior type -> the three parameters' prior parameters (oracle/ref_priors.f90)
+        "uniform": [(-1, 2), (0, 5), (3, 4)], "log_uniform": [(1e-3, 1), (2, 50), (0.1, 0.2)], "gaussian": [(0, 1), (2, 0.5), (-3, 2)],
+        "half_gaussian": [(0, 1), (2, 0.5), (-3, 2)], "exponential": [(1,), (0.5,), (4,)], "power_uniform": [(1, 4, 2), (2, 9, -1.5), (0.5, 3, 3)],
+        "sorted_uniform": [(0, 10)] * 3, "sorted_gaussian": [(0, 1)] * 3, "sorted_half_gaussian": [(0, 2)] * 3, "sorted_exponential": [(2,)] * 3,
+    }
+    for kind, pp in params.items():
+        ini = tmp_path / (kind + ".ini")
+        ini.write_text("nlive = 10\nnum_repeats = 3\n" + "".join(
+            "P : p%d | p_{%d} | 1 | %s | 1 | %s\n" % (i + 1, i + 1, kind, " ".join(repr(float(v)) for v in pp[i])) for i in range(3)))
+        theta = np.zeros(3)
+        assert f(str(ini).encode(), api.dptr(cube), api.dptr(theta), 3) == 3
+        assert np.allclose(theta, g[kind], rtol=1e-13, atol=1e-15), (kind, theta, g[kind])
+    # the hypercube is ordered by speed (priors.f90:708-737): the fast parameter listed first takes the last coordinate
+    ini = tmp_path / "speeds.ini"
+    ini.write_text("nlive = 10\nnum_repeats = 3\nP : a | a | 2 | uniform | 1 | 0 1\nP : b | b | 1 | uniform | 2 | 10 20\nP : c | c | 1 | uniform | 2 | 100 200\n")
+    theta = np.zeros(3)
+    assert f(str(ini).encode(), api.dptr(cube), api.dptr(theta), 3) == 3
+    assert np.allclose(theta, [cube[2], 10 + 10 * cube[0], 100 + 100 * cube[1]])
