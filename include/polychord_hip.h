@@ -76,6 +76,8 @@ int polychord_hip_resume_copy(const char *in, const char *out, int *counts);
 /* the prior block of an ini file (ini.f90:354-458, priors.f90: uniform, log_uniform, power_uniform, gaussian,
  * half_gaussian, exponential and their sorted_ variants) evaluated at one hypercube point; returns nDims, -1 if n < nDims */
 int polychord_hip_ini_prior(const char *inifile, const double *cube, double *theta, int n);
+/* inverse normal CDF, AS241 PPND16 (utils.F90:806-966) */
+double polychord_hip_inv_normal_cdf(double p);
 /* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
 void polychord_hip_set_option(const char *name, double value);
 

@@ -162,6 +162,9 @@ void ini_prior(double *cube_h, double *theta, int nDims)
 
 }  // namespace
 
+// AS241 / PPND16 on the host (utils.F90:806-966), the inverse normal CDF every Gaussian prior uses
+extern "C" double polychord_hip_inv_normal_cdf(double p) { return inv_normal_cdf_host(p); }
+
 // the prior block of an ini file evaluated at one hypercube point (tests; tools that want theta for a cube sample):
 // returns the number of parameters, or -1 when `n` is too small
 extern "C" int polychord_hip_ini_prior(const char *inifile, const double *cube, double *theta, int n)

@@ -10,4 +10,6 @@ libpolychord_hip.so through the reference's C entry point `polychord_c_interface
 __version__ = "1.22.2+hip0.1"
 from .settings import PolyChordSettings
 from .polychord import run_polychord, run
+from .output import PolyChordOutput
+from . import priors
 from . import device_likelihoods

@@ -80,32 +80,7 @@ def _wrap(loglikelihood, prior):
     return wrap_loglikelihood, wrap_prior
 
 
-class _Output:
-    """minimal stand-in for PolyChordOutput (output.py:57-99): parses <root>.stats by line"""
-
-    def __init__(self, base_dir, file_root):
-        self.base_dir, self.file_root = base_dir, file_root
-        self.root = str(Path(base_dir) / file_root)
-        self.logZ = self.logZerr = None
-        self.logZs, self.logZerrs = [], []
-        try:
-            with open(self.root + ".stats") as f:
-                for line in f:
-                    if line.startswith("log(Z)") and "+/-" in line:
-                        a, b = line.split("=")[1].split("+/-")
-                        self.logZ, self.logZerr = float(a), float(b)
-                    elif line.startswith("log(Z_") and "+/-" in line:
-                        a, b = line.split("=")[1].replace("(Still Active)", "").split("+/-")
-                        self.logZs.append(float(a)); self.logZerrs.append(float(b))
-                    elif "ndead:" in line:
-                        self.ndead = int(line.split(":")[1])
-                    elif "nlike:" in line:
-                        self.nlike = int(line.split(":")[1].split()[0])
-        except OSError:
-            pass
-
-    def __repr__(self):
-        return f"log(Z) = {self.logZ} +/- {self.logZerr}"
+from .output import PolyChordOutput as _Output  # noqa: E402  (the class run_polychord returns)
 
 
 def _e24(v):

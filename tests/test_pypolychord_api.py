@@ -573,3 +573,69 @@ def test_maximise_writes_the_maximum_file(engine, tmp_path):
     # U(-1,1)^4: dX/dtheta = 2^-4, the posterior density is the likelihood times it
     assert abs(float(lines[6]) - (float(lines[8]) - nDims * np.log(2.0))) < 1e-6
     assert abs(float(lines[13]) - peak) < 0.5                      # likelihood at the posterior mean
+
+
+def test_priors_and_output_modules(tmp_path):
+    """pypolychord.priors and pypolychord.output with the reference's names (priors.py:5-47, output.py:20-235)"""
+    from polychordlite_amd.pypolychord import priors, PolyChordOutput
+    from polychordlite_amd.pypolychord.output import PolyChordOutput as PO2
+    assert PolyChordOutput is PO2
+    x = np.array([0.2, 0.7, 0.45])
+    assert np.allclose(priors.UniformPrior(-1, 2)(x), -1 + 3 * x)
+    assert np.allclose(priors.LogUniformPrior(1e-3, 1.0)(x), 1e-3 * 1e3 ** x)
+    g = priors.GaussianPrior(2.0, 0.5)(x)
+    assert np.allclose(g, [2 + 0.5 * -0.8416212335729143, 2 + 0.5 * 0.5244005127080407, 2 + 0.5 * -0.12566134685507402])
+    t = priors.forced_indentifiability_transform(x)
+    assert np.all(np.diff(t) > 0) and np.allclose(t, [0.12822809400794053, 0.6411404700397025, 0.7663094323935531])   # = reference's sort_hypercube
+    assert np.allclose(priors.SortedUniformPrior(0, 10)(x), 10 * t) and np.allclose(priors.LogSortedUniformPrior(1, 100)(x), 100 ** t)
+    # output object: the reference's .stats layout (read_write.F90:809-910), two clusters, two grades, posterior table
+    (tmp_path / "clusters").mkdir()
+    (tmp_path / "t.stats").write_text("""Evidence estimates:
+===================
+  - The evidence Z is a log-normally distributed, with location and scale parameters mu and sigma.
+  - We denote this as log(Z) = mu +/- sigma.
+
+Global evidence:
+----------------
+
+log(Z)       =  -0.334324000000000E+001 +/-   0.257810000000000E+000
+
+
+Local evidences:
+----------------
+
+log(Z_1)     =  -0.400000000000000E+001 +/-   0.300000000000000E+000 (Still Active)
+log(Z_2)     =  -0.410000000000000E+001 +/-   0.310000000000000E+000
+
+
+Run-time information:
+---------------------
+
+ ncluster:          1 /       2
+ nposterior:      321
+ nequals:          45
+ ndead:          1358
+ nlive:             0
+ nlike:        45080   22300
+ <nlike>:       12.00    3.00   (    1.50    0.75 per slice )
+
+
+Dim No.       Mean        Sigma
+  1  0.500000000000000E+000 +/-   0.100000000000000E+000
+  2  0.400000000000000E+000 +/-   0.200000000000000E+000
+-------------------------------
+  3  0.100000000000000E+001 +/-   0.300000000000000E+000
+""")
+    np.savetxt(tmp_path / "t_equal_weights.txt", np.array([[1.0, 2.0, 0.5, 0.4, 1.0], [1.0, 4.0, 0.6, 0.3, 1.1]]))
+    o = PolyChordOutput(str(tmp_path), "t")
+    assert (o.logZ, o.logZerr) == (-3.34324, 0.25781) and o.logZs == [-4.0, -4.1] and o.logZerrs == [0.3, 0.31]
+    assert (o.ncluster, o.nposterior, o.nequals, o.ndead, o.nlive, o.nlike) == (2, 321, 45, 1358, 0, 45080)
+    assert o.avnlike == [12.0, 3.0] and o.avnlikeslice == [1.5, 0.75]
+    assert o.means == [0.5, 0.4, 1.0] and o.sigmas == [0.1, 0.2, 0.3]
+    assert o.root == str(tmp_path / "t") and o.cluster_root(2).endswith("clusters/t_2") and o.paramnames_file.endswith("t.paramnames")
+    o.make_paramnames_files([("a", "a"), ("b", "b"), ("r*", "r")])
+    assert (tmp_path / "t.paramnames").read_text().splitlines() == ["a   a", "b   b", "r*   r"]
+    assert (tmp_path / "clusters" / "t_1.paramnames").exists()
+    if o.pandas:
+        assert list(o.samples.columns) == ["weight", "loglike", "a", "b", "r*"] and np.allclose(o.loglikes, [-1.0, -2.0])
+        assert "Global evidence" in str(o)
