@@ -639,3 +639,29 @@ Dim No.       Mean        Sigma
     if o.pandas:
         assert list(o.samples.columns) == ["weight", "loglike", "a", "b", "r*"] and np.allclose(o.loglikes, [-1.0, -2.0])
         assert "Global evidence" in str(o)
+
+
+@pytest.mark.gpu
+def test_cpp_facade(engine, tmp_path):
+    """include/polychord_hip.hpp: the reference's C++ `Settings` / `run_polychord` surface (interfaces.hpp:8-87, defaults of
+    c_interface.cpp:6-39) -- a driver in the style of src/drivers/polychord_CC.cpp, likelihood fused on the device and
+    likelihood written in C++; maximise defaults to true there, so <root>.maximum appears"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "polychordlite_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "bindings", "cpp", "example_gaussian.cpp"),
+                           "-L" + lib, "-lpolychord_hip", "-Wl,-rpath," + lib, "-o", "ex"], cwd=tmp_path)
+    (tmp_path / "chains" / "clusters").mkdir(parents=True)
+    out = subprocess.run(["./ex", "chains"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "final dump" in out.stdout
+    vals = {}
+    for rootname in ("cpp_device", "cpp_host"):
+        st = (tmp_path / "chains" / (rootname + ".stats")).read_text().splitlines()
+        logZ, err = [float(x) for x in st[8].split("=")[1].split("+/-")]
+        assert abs(logZ) < 4 * err and err < 0.5, (rootname, logZ, err)       # truth 0
+        mx = (tmp_path / "chains" / (rootname + ".maximum")).read_text().splitlines()
+        assert abs(float(mx[1]) - (-6 * (np.log(0.1) + 0.5 * np.log(2 * np.pi)))) < 1e-3
+        vals[rootname] = logZ
+    assert vals["cpp_device"] != vals["cpp_host"]     # different chains per nursery (device: nlive/2, callbacks: nlive/4)
