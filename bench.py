@@ -175,21 +175,17 @@ def main():
     # runs on separate streams overlap.  Reported next to the headline, not in it.
     conc = None
     if args.concurrent > 1 and args.steps > 0:
-        from concurrent.futures import ThreadPoolExecutor
+        from polychordlite_amd.repeats import run_repeats
         R = args.concurrent
-        s_c = [api.Settings() for _ in range(R)]
-        for j, sj in enumerate(s_c):
-            C.memmove(C.byref(sj), C.byref(s), C.sizeof(s)); sj.profile = 0; sj.seed = 500000 + j + 100003 * rank
-
-        def one_c(j):
-            return api.run(s_c[j], L, P)["nlike"]
-        with ThreadPoolExecutor(R) as ex:
-            list(ex.map(one_c, range(R)))                       # block cache for R engines
-            tc0 = time.perf_counter()
-            nl = sum(ex.map(one_c, range(R)))
-            tc = time.perf_counter() - tc0
-        conc = {"runs": R, "wall_ms": tc * 1e3, "value": nl / tc, "unit": "likelihood evals/s",
-                "note": "R independent runs of the same workload in flight on one GPU (one host thread + HIP stream each)"}
+        s_c = api.Settings(); C.memmove(C.byref(s_c), C.byref(s), C.sizeof(s)); s_c.profile = 0
+        run_repeats(s_c, L, P, [400000 + j + 100003 * rank for j in range(R)], max_in_flight=R)     # block cache for R engines
+        mc, _ = run_repeats(s_c, L, P, [500000 + j + 100003 * rank for j in range(R)], max_in_flight=R)
+        tc = mc["t_runs_s"]
+        nl = mc["nlike"]
+        conc = {"runs": R, "wall_ms": tc * 1e3, "value": nl / tc, "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3,
+                "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
+                "note": "R independent runs of the same workload in flight on one GPU (one host thread + HIP stream each, "
+                        "polychordlite_amd.repeats.run_repeats); wall_ms = the runs, merge_ms = evidence replay of their union on the host"}
         sync()
     if rank == 0:
         value = nlike / tmax
