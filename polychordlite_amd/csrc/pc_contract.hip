@@ -260,7 +260,9 @@ __device__ __forceinline__ int nlive_target(const PcState &S, double logL)
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int cache_x, int xq_n)
+// slots_global: the per-slot arrays (logL, cluster, list position, list owner) stay in HBM instead of LDS -- the way out
+// for live sets beyond ~8000 points (20 B of LDS per slot); slower, same code
+__global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int cache_x, int xq_n, int slots_global)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     ConsumeShared H;
     {
         char *p = smem;
-        H.sL = (double *)p; p += sizeof(double) * Ncap;
+        const bool sg0 = slots_global != 0;
+        H.sL = sg0 ? S.live_logL : (double *)p; if (!sg0) p += sizeof(double) * Ncap;
         double **cd[] = { &H.cLogLp, &H.cLogXp, &H.cLogZp, &H.cLogZXp, &H.cLogZp2, &H.cLogZpXp, &H.cLseRef, &H.cLseSum, &H.cThr };
         for (int i = 0; i < 9; ++i) { *cd[i] = (double *)p; p += sizeof(double) * maxc; }
         H.jobres = (double *)p; p += sizeof(double) * NT;
@@ -276,26 +279,27 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         H.gd2 = (double *)p; p += sizeof(double) * NT;
         H.sX = (double *)p; H.xrows = cache_x; p += sizeof(double) * (size_t)cache_x * S.D;
         H.red = (vk_t *)p; p += sizeof(vk_t) * 16;
-        H.sC = (int *)p; p += sizeof(int) * Ncap;
-        H.sP = (int *)p; p += sizeof(int) * Ncap;
+        H.sC = sg0 ? S.live_cluster : (int *)p; if (!sg0) p += sizeof(int) * Ncap;
+        H.sP = sg0 ? S.live_pos : (int *)p; if (!sg0) p += sizeof(int) * Ncap;
         H.cN = (int *)p; p += sizeof(int) * maxc;
         H.cMinSlot = (int *)p; p += sizeof(int) * maxc;
         H.cUid = (unsigned *)p; p += sizeof(unsigned) * maxc;
         H.misc = (int *)p; p += sizeof(int) * 8;
         H.gkey = (int *)p; p += sizeof(int) * NT;
         H.ids = (int *)p; p += sizeof(int) * nr;
-        H.sO = (int *)p; p += sizeof(int) * Ncap;
+        H.sO = sg0 ? S.nn_slot_owner : (int *)p; if (!sg0) p += sizeof(int) * Ncap;
         H.sCS = (int *)p; p += sizeof(int) * S.B;
         p = (char *)(((size_t)p + 15) & ~(size_t)15);
         H.xq = (double *)p; H.xq_ld = xq_n;
     }
     PcCtl *ctl = S.ctl;
     // ---- stage the state in LDS
-    for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
+    const bool sg = slots_global != 0;
+    if (!sg) for (int s = tid; s < Ncap; s += NT) { H.sL[s] = S.live_logL[s]; H.sC[s] = S.live_cluster[s]; H.sP[s] = S.live_pos[s]; }
     if (H.xrows >= Ncap) for (int e = tid; e < Ncap * S.D; e += NT) H.sX[e] = S.live[(size_t)(e / S.D) * nT + e % S.D];
     const bool nn = S.nn_valid != 0 && !final_mode;
     if (nn) {
-        for (int s = tid; s < Ncap; s += NT) H.sO[s] = S.nn_slot_owner[s];
+        if (!sg) for (int s = tid; s < Ncap; s += NT) H.sO[s] = S.nn_slot_owner[s];
         for (int c = tid; c < S.B; c += NT) H.sCS[c] = S.nn_chain_slot[c];
     }
     int nc = ctl->ncluster;
@@ -724,13 +728,13 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
 
     // ---- write the state back
     __syncthreads();
-    for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
+    if (!sg) for (int s = tid; s < Ncap; s += NT) { S.live_logL[s] = H.sL[s]; S.live_cluster[s] = H.sC[s]; S.live_pos[s] = H.sP[s]; }
     for (int s = tid; s < Ncap; s += NT) if (H.sC[s] >= 0) S.cl_list[(size_t)H.sC[s] * Ncap + H.sP[s]] = s;
     if (xq_lds) {                                      // (a deleted cluster leaves stale entries beyond nc: never read)
         for (int e = tid; e < nc_at_launch * nc_at_launch; e += NT) S.XpXq[(size_t)(e / nc_at_launch) * maxc + e % nc_at_launch] = H.xq[(size_t)(e / nc_at_launch) * xq_n + e % nc_at_launch];
     }
     if (nn) {
-        for (int s = tid; s < Ncap; s += NT) S.nn_slot_owner[s] = H.sO[s];
+        if (!sg) for (int s = tid; s < Ncap; s += NT) S.nn_slot_owner[s] = H.sO[s];
         for (int c = tid; c < S.B; c += NT) S.nn_chain_slot[c] = H.sCS[c];
     }
     for (int c = tid; c < maxc; c += NT) {
@@ -1339,12 +1343,15 @@ __global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-static size_t consume_lds(const PcState *S, int NT, int xrows, int xq_n = 0)
+static size_t consume_lds(const PcState *S, int NT, int xrows, int xq_n = 0, int slots_global = 0)
 {
-    if (xq_n > 0) return consume_lds(S, NT, xrows, 0) + sizeof(double) * (size_t)xq_n * xq_n + 16;
-    return sizeof(double) * ((size_t)S->Ncap + 9 * (size_t)S->maxc + 2 * NT + (size_t)S->D * PC_IDG + (size_t)xrows * S->D) +
-           sizeof(vk_t) * 16 + sizeof(int) * (3 * (size_t)S->Ncap + 3 * (size_t)S->maxc + 8 + NT + S->nr + (size_t)S->B) + 64;
+    if (xq_n > 0) return consume_lds(S, NT, xrows, 0, slots_global) + sizeof(double) * (size_t)xq_n * xq_n + 16;
+    const size_t nslot = slots_global ? 0 : (size_t)S->Ncap;
+    return sizeof(double) * (nslot + 9 * (size_t)S->maxc + 2 * NT + (size_t)S->D * PC_IDG + (size_t)xrows * S->D) +
+           sizeof(vk_t) * 16 + sizeof(int) * (3 * nslot + 3 * (size_t)S->maxc + 8 + NT + S->nr + (size_t)S->B) + 64;
 }
+// the per-slot arrays do not fit next to the smallest coordinate tile: keep them in HBM
+static int consume_slots_global(const PcState *S, int NT) { return consume_lds(S, NT, 32) > 150 * 1024; }
 
 extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hipStream_t st)
 {
@@ -1354,13 +1361,14 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
     if (wide && S->nn_valid && wide_nt != 1024) {
 #define PC_CONSUME_LAUNCH(NTV) { \
             /* the lists make the coordinate cache a fallback: a tile is enough, the LDS goes to the cross-volume matrix */ \
+            const int sgl = consume_slots_global(S, NTV); \
             int cache_x = S->Ncap < 64 ? S->Ncap : 64, xq_n = S->maxc; \
-            while (xq_n > 8 && consume_lds(S, NTV, cache_x, xq_n) > 158 * 1024) xq_n -= 8; \
-            const size_t sh = consume_lds(S, NTV, cache_x, xq_n); \
+            while (xq_n > 8 && consume_lds(S, NTV, cache_x, xq_n, sgl) > 158 * 1024) xq_n -= 8; \
+            const size_t sh = consume_lds(S, NTV, cache_x, xq_n, sgl); \
             if (sh > 160 * 1024) return 1; \
             static size_t done_ = 0; \
             if (sh > done_) { hipFuncSetAttribute((const void *)k_consume<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_ = sh; } \
-            hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x, xq_n); \
+            hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x, xq_n, sgl); \
             return 0; }
         if (wide_nt == 128) PC_CONSUME_LAUNCH(128)
         if (wide_nt == 512) PC_CONSUME_LAUNCH(512)
@@ -1369,21 +1377,23 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
     }
     if (wide) {
         // all live coordinates in LDS when they fit, else the largest tile that does
+        const int sgl = consume_slots_global(S, 1024);
         int cache_x = S->Ncap;
-        while (cache_x > 32 && consume_lds(S, 1024, cache_x) > 158 * 1024) cache_x = (cache_x + 1) / 2;
-        const size_t sh = consume_lds(S, 1024, cache_x);
+        while (cache_x > 32 && consume_lds(S, 1024, cache_x, 0, sgl) > 158 * 1024) cache_x = (cache_x + 1) / 2;
+        const size_t sh = consume_lds(S, 1024, cache_x, 0, sgl);
         if (sh > 160 * 1024) return 1;
         static size_t done1024 = 0;
         if (sh > done1024) { hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1024 = sh; }
-        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x, 0);
+        hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x, 0, sgl);
     } else {
+        const int sgl = consume_slots_global(S, 64);
         int xr = S->Ncap;
-        while (xr > 32 && consume_lds(S, 64, xr) > 158 * 1024) xr = (xr + 1) / 2;
-        const size_t sh = consume_lds(S, 64, xr);
+        while (xr > 32 && consume_lds(S, 64, xr, 0, sgl) > 158 * 1024) xr = (xr + 1) / 2;
+        const size_t sh = consume_lds(S, 64, xr, 0, sgl);
         if (sh > 160 * 1024) return 1;
         static size_t done64 = 0;
         if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
-        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr, 0);
+        hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr, 0, sgl);
     }
     return 0;
 }

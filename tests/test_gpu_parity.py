@@ -86,6 +86,8 @@ RUNS = [  # kind D nDer nlive nr B general clustering
     ("gaussian", 3, 0, 5000, 3, 1024, 0, 0),
     # num_repeats beyond 512 (5 nDims at nDims > 102): sixteen phantom mask words per chain
     ("gaussian", 6, 1, 60, 600, 16, 0, 0), ("gaussian", 5, 0, 50, 1000, 8, 1, 0),
+    # live sets beyond the LDS-resident kernels (20 B of LDS per slot): per-slot arrays in HBM, serial contraction
+    ("gaussian", 2, 0, 9000, 2, 512, 0, 0),
 ]
 
 
