@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // ================================================================================
     // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
     // ================================================================================
-    long long cyT = 0, cyI = 0, cyK = 0, cyA = 0, cyE = 0, cyF = 0, cyW = 0;
+    long long cyT = 0, cyI = 0, cyK = 0, cyE = 0, cyF = 0, cyW = 0;
     if (!final_mode && nc > 1) {
         // The nursery's records were written by other XCDs: a first touch costs 1-2 us, and the loop below would pay
         // that once per chain and array, serially.  Touch everything it will read now, in bulk, so that the loop's
@@ -1012,7 +1012,6 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int chunk = blockIdx.x, c = blockIdx.y, nc = gridDim.y, D = S.D, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     nrows = min(nrows, S.Ncap + S.ctl->nphantom);
-    const int r0 = chunk * CR, r1 = max(r0, min(nrows, r0 + CR));
     double *tile = (double *)smem;               // [rows][TS], TS = D+1 or (D rounded up to 16)+1, zero padded
     double *mu = tile + (size_t)CR * TS;         // [D]
     double *red = mu + D;                        // [256]

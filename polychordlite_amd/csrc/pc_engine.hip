@@ -573,7 +573,7 @@ struct Engine {
     {
         tm.updates++;
         call_dumper();
-        const int nph = h_ctl->nphantom, nc = h_ctl->ncluster;
+        const int nph = h_ctl->nphantom;
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
