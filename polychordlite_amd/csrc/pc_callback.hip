@@ -21,8 +21,9 @@ struct PcChain {
 __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, int nchains, PcChain *cs, double *x0s /* [B][D] */,
                                                   int *decks /* [B][nr] */, double *prop /* [B][D] */,
                                                   const double *ev_logL, const double *ev_theta, const double *ev_phi,
-                                                  int first, int *n_need, int *need_out)
-{
+                                                  int first, double *prop_host, int *need_host)
+{   // prop_host / need_host: pinned host memory; the proposals and the need flags are stored there directly (posted
+    // writes over PCIe), so that the host finds them after one stream synchronisation, without copies
     const int chain = blockIdx.x * 64 + threadIdx.x;
     if (chain >= nchains) return;
     const int D = S.D, nr = S.nr, nT = S.nT;
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
         bool outside = false;
         for (int d = 0; d < D; ++d) { const double v = x0[d] + t * nh[d]; pc[d] = v; outside |= (v < 0.0) | (v > 1.0); }
         if (outside) { logL = S.logzero; have = true; c.ok_theta = 0; return false; }   // calculate.f90:36-38
+        double *ph = prop_host + (size_t)chain * D;
+        for (int d = 0; d < D; ++d) ph[d] = pc[d];
         c.need = 1; have = false;
         return true;
     };
@@ -131,17 +134,16 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
         if (parked && c.need) break;       // a proposal waits for the host
     }
     if (c.phase == CB_DONE) S.ch_nlike[chain] = c.nlike;
-    if (c.need) atomicAdd(n_need, 1);
-    need_out[chain] = c.need;
+    need_host[chain] = c.need;
     cs[chain] = c;
 }
 
 extern "C" void pc_launch_slice_tick(const PcState *S, unsigned batch, int nchains, void *cs, double *x0s, int *decks, double *prop,
-                                     const double *ev_logL, const double *ev_theta, const double *ev_phi, int first, int *n_need,
-                                     int *need_out, hipStream_t st)
+                                     const double *ev_logL, const double *ev_theta, const double *ev_phi, int first, double *prop_host,
+                                     int *need_host, hipStream_t st)
 {
     hipLaunchKernelGGL(k_slice_tick, dim3((nchains + 63) / 64), dim3(64), 0, st, *S, batch, nchains, (PcChain *)cs, x0s, decks, prop,
-                       ev_logL, ev_theta, ev_phi, first, n_need, need_out);
+                       ev_logL, ev_theta, ev_phi, first, prop_host, need_host);
 }
 
 extern "C" size_t pc_chain_state_size(void) { return sizeof(PcChain); }

@@ -44,7 +44,7 @@ int pc_launch_knn_cluster(const double *, int, const int *, int, int *, int *, i
 void pc_launch_rebuild(const PcState *, int, hipStream_t);
 void pc_launch_ph_rehome(const PcState *, int, int, const unsigned *, int, int *, hipStream_t);
 void pc_launch_slice_tick(const PcState *, unsigned, int, void *, double *, int *, double *, const double *, const double *,
-                          const double *, int, int *, int *, hipStream_t);
+                          const double *, int, double *, int *, hipStream_t);
 size_t pc_chain_state_size(void);
 void pc_launch_init_state(const PcState *, double, hipStream_t);
 int pc_post_blocks(void);
@@ -209,9 +209,11 @@ struct Engine {
     // host-callback mode (device proposes, host evaluates): pc_callback.hip
     polychord_loglike_fn cb_like = nullptr; polychord_prior_fn cb_prior = nullptr;
     bool callback_mode = false;
-    void *d_cs = nullptr; double *d_x0s = nullptr, *d_prop = nullptr, *d_evL = nullptr, *d_evT = nullptr, *d_evP = nullptr;
-    int *d_decks = nullptr, *d_nneed = nullptr, *d_need = nullptr;
-    std::vector<double> h_prop, h_evL, h_evT, h_evP; std::vector<int> h_need;
+    void *d_cs = nullptr; double *d_x0s = nullptr, *d_prop = nullptr;
+    int *d_decks = nullptr;
+    // pinned host side of the propose / evaluate exchange: the kernel stores proposals and need flags here directly; the
+    // answers (logL | theta | phi of every chain, one block) go back in one copy
+    double *hp_prop = nullptr, *hp_ans = nullptr, *d_ans = nullptr; int *hp_need = nullptr;
     long long cb_evals = 0; long cb_ticks = 0;
     // host mirror of the dead points for the dumper hook (nested_sampling.F90:546-590)
     polychord_dumper_fn dumper = nullptr;
@@ -246,6 +248,7 @@ struct Engine {
     KTimer kt;
     int B = 0;
     bool fast_ok = false;
+    bool cb_auto_batch = false; int B_small = 1; double cb_eval_seconds = -1.0;   // host callbacks: chains per nursery chosen from the measured cost of a call
     long long nlike_g[PC_MAX_GRADE] = {0};      // RTI%nlike per grade (grade 1 includes the prior samples)
     std::vector<int> h_nlike_g;                 // [B][PC_MAX_GRADE] of the batch in the nursery
 
@@ -299,7 +302,12 @@ struct Engine {
         S.Ncap = std::max(nmax, nprior);
         B = c.batch > 0 ? c.batch : std::max(1, std::min(1024, c.nlive / 2));
         if (c.sequential_rng) B = 1;
-        if (c.batch <= 0 && (like.kind == PC_LIKE_CALLBACK || prior.kind != 1)) B = std::max(1, std::min(64, c.nlive / 4));
+        // Host callbacks: every chain of a nursery is seeded from one snapshot, so about B / (2 nlive) of the evaluations
+        // are spent on spawns that fail -- cheap for a compiled likelihood (then the round trips per nursery dominate and
+        // many chains per nursery pay: nlive / 2), dear for an expensive one (nlive / 4, at most 64).  Which one this is
+        // is measured while the live points are generated; buffers are sized for the larger choice.
+        cb_auto_batch = c.batch <= 0 && !c.sequential_rng && (like.kind == PC_LIKE_CALLBACK || prior.kind != 1);
+        if (cb_auto_batch) B_small = std::max(1, std::min(64, c.nlive / 4));
         S.B = B;
         S.maxc = c.do_clustering ? 128 : 4;
         S.maxc_dead = 4096;
@@ -386,9 +394,11 @@ struct Engine {
         d_total = dalloc<int>(1);
         if (callback_mode) {
             d_cs = (void *)dalloc<char>(pc_chain_state_size() * B); d_x0s = dalloc<double>((size_t)B * D); d_prop = dalloc<double>((size_t)B * D);
-            d_evL = dalloc<double>(B); d_evT = dalloc<double>((size_t)B * D); d_evP = dalloc<double>((size_t)B * std::max(1, nDer));
-            d_decks = dalloc<int>((size_t)B * nr); d_nneed = dalloc<int>(1); d_need = dalloc<int>(B);
-            h_prop.resize((size_t)B * D); h_evL.resize(B); h_evT.resize((size_t)B * D); h_evP.resize((size_t)B * std::max(1, nDer)); h_need.resize(B);
+            const size_t nans = (size_t)B * (1 + D + std::max(1, nDer));
+            d_ans = dalloc<double>(nans);
+            d_decks = dalloc<int>((size_t)B * nr);
+            hp_prop = halloc<double>((size_t)B * D); hp_ans = halloc<double>(nans); hp_need = halloc<int>(B);
+            std::memset(hp_ans, 0, sizeof(double) * nans); std::memset(hp_need, 0, sizeof(int) * B);
             HIPCHK(hipMemset(d_cs, 0, pc_chain_state_size() * B));
         }
         h_ctl = halloc<PcCtl>(1);
@@ -790,10 +800,13 @@ struct Engine {
         const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT, D = S.D;
         std::vector<double> rows((size_t)nprior * nT, 0.0);
         int have = 0; uint32_t attempt = 0; long long nlike = 0;
+        double t_eval = 0.0;
         while (have < nprior) {
             double *row = rows.data() + (size_t)have * nT;
             for (int d = 0; d < D; ++d) row[d] = h_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, attempt, (uint32_t)d);
+            const auto te0 = std::chrono::steady_clock::now();
             const double logL = host_eval(row, row + S.p0, row + S.d0);
+            t_eval += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
             row[S.b0] = cfg.logzero; row[S.l0] = logL;
             if (logL > cfg.logzero) { have++; nlike++; }
             attempt++;
@@ -808,6 +821,7 @@ struct Engine {
         HIPCHK(hipStreamSynchronize(st));
         dfree(drows);
         ndiscarded = (long)attempt - nprior;
+        cb_eval_seconds = attempt ? t_eval / attempt : -1.0;
         call_dumper(2);
         if (nprior > cfg.nlive) { pc_launch_consume(&S, 2, 0, st); read_ctl(); }
     }
@@ -818,21 +832,17 @@ struct Engine {
         const int D = S.D, nDer = S.nDer;
         int first = 1;
         while (true) {
-            HIPCHK(hipMemsetAsync(d_nneed, 0, sizeof(int), st));
-            pc_launch_slice_tick(&S, batch, B, d_cs, d_x0s, d_decks, d_prop, d_evL, d_evT, d_evP, first, d_nneed, d_need, st);
+            // answers of the host: [logL (B) | theta (B x D) | phi (B x nDerived)], device copy at d_ans (B = chains per nursery now)
+            pc_launch_slice_tick(&S, batch, B, d_cs, d_x0s, d_decks, d_prop, d_ans, d_ans + B, d_ans + B + (size_t)B * D, first, hp_prop, hp_need, st);
             first = 0; cb_ticks++;
-            int nneed = 0;
-            HIPCHK(hipMemcpyAsync(&nneed, d_nneed, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            if (nneed == 0) break;
-            HIPCHK(hipMemcpy(h_need.data(), d_need, sizeof(int) * B, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(h_prop.data(), d_prop, sizeof(double) * (size_t)B * D, hipMemcpyDeviceToHost));
             if (g_stop_requested) return;
+            double *evL = hp_ans, *evT = hp_ans + B, *evP = evT + (size_t)B * D;
+            int nneed = 0;
             for (int c = 0; c < B; ++c)
-                if (h_need[c]) h_evL[c] = host_eval(h_prop.data() + (size_t)c * D, h_evT.data() + (size_t)c * D, h_evP.data() + (size_t)c * std::max(1, nDer));
-            HIPCHK(hipMemcpyAsync(d_evL, h_evL.data(), sizeof(double) * B, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_evT, h_evT.data(), sizeof(double) * (size_t)B * D, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_evP, h_evP.data(), sizeof(double) * (size_t)B * std::max(1, nDer), hipMemcpyHostToDevice, st));
+                if (hp_need[c]) { nneed++; evL[c] = host_eval(hp_prop + (size_t)c * D, evT + (size_t)c * D, evP + (size_t)c * std::max(1, nDer)); }
+            if (nneed == 0) break;
+            HIPCHK(hipMemcpyAsync(d_ans, hp_ans, sizeof(double) * (size_t)B * (1 + D + std::max(1, nDer)), hipMemcpyHostToDevice, st));
         }
     }
 
@@ -1059,6 +1069,7 @@ struct Engine {
         }
         if (!resumed) { if (callback_mode) generate_live_callback(); else generate_live(); }
         if (g_stop_requested) return 5;
+        if (cb_auto_batch && !(cb_eval_seconds >= 0.0 && cb_eval_seconds < 2e-6)) { B = B_small; S.B = B; }   // expensive (or unmeasured) callback
         auto t1 = clk::now();
         unsigned batch = resume_batch0;               // fresh counter-RNG streams after a resume
         bool sort_valid = false;
@@ -1213,6 +1224,9 @@ struct Engine {
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
                        &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
+        { char *cs = (char *)d_cs; dfree(cs); d_cs = nullptr; }
+        dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);
+        if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
         dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);

@@ -664,4 +664,5 @@ def test_cpp_facade(engine, tmp_path):
         mx = (tmp_path / "chains" / (rootname + ".maximum")).read_text().splitlines()
         assert abs(float(mx[1]) - (-6 * (np.log(0.1) + 0.5 * np.log(2 * np.pi)))) < 1e-3
         vals[rootname] = logZ
-    assert vals["cpp_device"] != vals["cpp_host"]     # different chains per nursery (device: nlive/2, callbacks: nlive/4)
+    # a compiled callback this cheap gets the device's chains per nursery (nlive / 2): same draws, same decisions
+    assert abs(vals["cpp_device"] - vals["cpp_host"]) < 1e-9
