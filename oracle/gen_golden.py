@@ -70,8 +70,30 @@ def maximum_cases(inj):
     return out
 
 
+def file_cases(inj):
+    """output files of the reference itself (read_write.F90 writers) for two injected runs: data the engine's writers must
+    reproduce byte for byte in its sequential-RNG mode.  -> tests/golden/ref_files/"""
+    import shutil
+    dst = os.path.join(GOLD, "ref_files")
+    os.makedirs(dst, exist_ok=True)
+    meta = []
+    for name, like, D, nDer, nlive, nr, seed, clus in (("g3", "gaussian", 3, 1, 50, 6, 5, 0), ("r2", "rastrigin", 2, 0, 100, 6, 3, 1)):
+        sh(f"rm -f {TMP}/chains/{name}*")
+        j = last_json(sh(f"{inj} {like} {D} {nDer} {nlive} {nr} {seed} {clus} {TMP}/chains {name} 1"))
+        shutil.copy(f"{TMP}/chains/{name}.stats", os.path.join(dst, name + ".stats"))
+        shutil.copy(f"{TMP}/chains/{name}_dead-birth.txt", os.path.join(dst, name + "_dead-birth.txt"))
+        meta.append(dict(name=name, like=like, nDims=D, nDerived=nDer, nlive=nlive, num_repeats=nr, seed=seed, clustering=clus, ndead=j["ndead"]))
+        print("files", meta[-1])
+    json.dump(meta, open(os.path.join(GOLD, "ref_files.json"), "w"), indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "files":
+        os.makedirs(TMP + "/chains/clusters", exist_ok=True)
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        file_cases(os.path.join(HERE, "_ref", "ref_driver_inject"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "maximum":
         os.makedirs(TMP + "/chains/clusters", exist_ok=True)
         subprocess.check_call(["make", "-C", HERE, "ref"])
@@ -124,6 +146,7 @@ def main():
     injected += grade_cases(inj)
     json.dump(injected, open(os.path.join(GOLD, "ref_injected.json"), "w"), indent=1)
     json.dump(maximum_cases(inj), open(os.path.join(GOLD, "ref_maximum.json"), "w"), indent=1)
+    file_cases(inj)
 
     native = []
     for seed in range(1, 9):

@@ -435,6 +435,9 @@ void polychord_c_interface(
     s.compression_factor = compression_factor; s.n_nlives = n_nlives; s.loglikes = loglikes; s.nlives = nlives;
     s.seed = seed >= 0 ? seed : (int)(std::chrono::system_clock::now().time_since_epoch().count() & 0x7fffffff); // random_utils.F90:62-79
     s.batch = G.batch; s.device = G.device;
+    // tests: the engine's sequential-stream mode through the reference's entry point (draw order of the reference binary;
+    // with the RNG shim of oracle/ the two programs then write the same files)
+    if (const char *e = std::getenv("PC_SEQUENTIAL_RNG")) s.sequential_rng = std::atoi(e) != 0;
     const std::string resume_path = std::string(base_dir ? base_dir : "chains") + "/" + (file_root ? file_root : "test") + ".resume";   // read_write.F90:1040-1062
     if (write_resume) s.resume_write = resume_path.c_str();
     if (read_resume) s.resume_read = resume_path.c_str();

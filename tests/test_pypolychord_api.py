@@ -666,3 +666,39 @@ def test_cpp_facade(engine, tmp_path):
         vals[rootname] = logZ
     # a compiled callback this cheap gets the device's chains per nursery (nlive / 2): same draws, same decisions
     assert abs(vals["cpp_device"] - vals["cpp_host"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_output_files_equal_the_reference_binary(engine, golden, tmp_path, monkeypatch):
+    """The file writers (read_write.F90:479-910 restated in pc_abi.hip) against files the REFERENCE BINARY wrote
+    (tests/golden/ref_files/, oracle/gen_golden.py): in sequential-stream mode the engine walks the reference's run, so
+    <root>_dead-birth.txt must be the same rows in the same order and <root>.stats the same text, line for line
+    (evidences to the last printed digit or one unit of it)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("PC_SEQUENTIAL_RNG", "1")
+    likes = {"gaussian": (dl.Gaussian(0.5, 0.1, nDerived=1), dl.UniformPrior(0.0, 1.0)), "rastrigin": (dl.Rastrigin(), dl.UniformPrior(-5.12, 5.12))}
+    for c in golden["ref_files"]:
+        like, prior = likes[c["like"]]
+        s = pypolychord.PolyChordSettings(c["nDims"], c["nDerived"], nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"],
+                                          do_clustering=bool(c["clustering"]), read_resume=False, write_resume=False, write_dead=True,
+                                          write_stats=True, posteriors=False, equals=False, write_prior=False, write_live=False,
+                                          base_dir=str(tmp_path), file_root=c["name"], feedback=0)
+        pypolychord.run_polychord(like, c["nDims"], c["nDerived"], s, prior)
+        ref = np.loadtxt(os.path.join(root, "tests", "golden", "ref_files", c["name"] + "_dead-birth.txt"))
+        got = np.loadtxt(tmp_path / (c["name"] + "_dead-birth.txt"))
+        assert got.shape == ref.shape == (c["ndead"], c["nDims"] + c["nDerived"] + 2)
+        assert np.abs(got - ref).max() < 1e-9 * max(1.0, np.abs(ref[:, :-1]).max()), np.abs(got - ref).max()   # 15 printed digits; fp64 re-association
+        ref_lines = open(os.path.join(root, "tests", "golden", "ref_files", c["name"] + ".stats")).read().splitlines()
+        got_lines = (tmp_path / (c["name"] + ".stats")).read_text().splitlines()
+        assert len(got_lines) == len(ref_lines)
+        for a, b in zip(got_lines, ref_lines):
+            if a == b:
+                continue
+            fa, fb = a.replace("+/-", " ").replace("=", " ").split(), b.replace("+/-", " ").replace("=", " ").split()
+            assert len(fa) == len(fb), (a, b)
+            for x, y in zip(fa, fb):                     # same labels, numbers equal to round-off of the last digit
+                try:
+                    assert abs(float(x) - float(y)) <= 1e-9 * max(1.0, abs(float(y))), (a, b)
+                except ValueError:
+                    assert x == y, (a, b)
