@@ -90,7 +90,9 @@ RUNS = [  # kind D nDer nlive nr B general clustering
     ("gaussian", 2, 0, 9000, 2, 512, 0, 0),
     # degenerate sizes: two live points, one repeat, more chains per nursery than live points (one live point has no
     # covariance: the reference's directions are 0/0 there, and so are the oracle's and the engine's)
-    ("gaussian", 1, 0, 2, 1, 1, 0, 0), ("gaussian", 5, 0, 2, 2, 1, 0, 0), ("gaussian", 4, 0, 7, 5, 64, 0, 1),
+    # (fewer live points than nDims + 1 is left out: the covariance is singular in exact arithmetic, so whether the
+    #  Cholesky pivot comes out <= 0 -- the scaled-identity fallback of utils.F90:633-638 -- is decided by round-off)
+    ("gaussian", 1, 0, 2, 1, 1, 0, 0), ("gaussian", 4, 0, 7, 5, 64, 0, 1),
 ]
 
 
