@@ -67,6 +67,16 @@ void polychord_hip_set_corr_gaussian(int nDims, const double *invcov_rowmajor, c
 /* uniform box prior evaluated on the device; pass polychord_hip_uniform_prior as `prior` */
 void polychord_hip_uniform_prior(double *cube, double *theta, int nDims);
 void polychord_hip_set_uniform_prior(int nDims, const double *lo, const double *hi);
+/* Batched host evaluation.  In host-callback mode the engine parks the proposals of all chains of a nursery and hands them
+ * to the host together; with a batch callback registered it makes ONE call per round instead of one loglikelihood call
+ * per proposal: prior + likelihood for n hypercube points (row-major, host memory; logL[i] <= logzero marks an invalid
+ * point).  This is the hook for vectorised likelihoods, for likelihoods that run on an accelerator themselves, and for
+ * farming the evaluations out to MPI ranks (what the reference's MPI workers did, nested_sampling.F90:426-498).  The scalar
+ * callbacks passed to polychord_c_interface must still be valid (they serve the maximiser and single evaluations).
+ * Process-global like the other setters; NULL removes it. */
+typedef void (*polychord_batch_fn)(void *user, int n, int nDims, int nDerived, const double *cube, double *theta, double *phi,
+                                   double *logL);
+void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user);
 /* asks a running engine to stop at the next host callback boundary (used by language bindings when a
  * user callback raised: the reference throws through the Fortran frames, _pypolychord.cpp:219-224) */
 void polychord_hip_request_stop(void);

@@ -57,6 +57,8 @@ int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int 
     std::abort(); } } while (0)
 
 static volatile int g_stop_requested = 0;
+static polychord_batch_fn g_batch_fn = nullptr;     // polychord_hip_set_batch_callback
+static void *g_batch_user = nullptr;
 extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
 
 namespace {
@@ -215,6 +217,7 @@ struct Engine {
     // answers (logL | theta | phi of every chain, one block) go back in one copy
     double *hp_prop = nullptr, *hp_ans = nullptr, *d_ans = nullptr; int *hp_need = nullptr;
     long long cb_evals = 0; long cb_ticks = 0;
+    std::vector<int> cb_idx; std::vector<double> cb_c, cb_t, cb_p, cb_l;   // batch callback scratch
     // host mirror of the dead points for the dumper hook (nested_sampling.F90:546-590)
     polychord_dumper_fn dumper = nullptr;
     pchip_update_fn on_update = nullptr; void *hook_user = nullptr;
@@ -795,22 +798,43 @@ struct Engine {
         return cb_like(theta, D, phi, S.nDer);
     }
 
+    // prior + likelihood for n hypercube points at once: one call of the registered batch callback, else n scalar calls
+    void host_eval_batch(int n, const double *cubes, double *thetas, double *phis, double *logLs)
+    {
+        const int D = S.D, nDer = S.nDer, pd = std::max(1, nDer);
+        if (g_batch_fn) { g_batch_fn(g_batch_user, n, D, nDer, cubes, thetas, phis, logLs); cb_evals += n; return; }
+        for (int i = 0; i < n; ++i) logLs[i] = host_eval(cubes + (size_t)i * D, thetas + (size_t)i * D, phis + (size_t)i * pd);
+    }
+
     void generate_live_callback()
     {   // GenerateLivePoints with host evaluations; same Philox streams as k_generate_live
         const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT, D = S.D;
         std::vector<double> rows((size_t)nprior * nT, 0.0);
         int have = 0; uint32_t attempt = 0; long long nlike = 0;
         double t_eval = 0.0;
+        const int pd = std::max(1, S.nDer);
+        std::vector<double> bc, bt, bp, bl;
         while (have < nprior) {
-            double *row = rows.data() + (size_t)have * nT;
-            for (int d = 0; d < D; ++d) row[d] = h_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, attempt, (uint32_t)d);
+            // as many attempts as points are still missing (all of them valid is the common case); attempt numbers,
+            // and with them the Philox streams, are those of one-at-a-time generation
+            const int m = nprior - have;
+            bc.resize((size_t)m * D); bt.resize((size_t)m * D); bp.assign((size_t)m * pd, 0.0); bl.resize(m);
+            for (int i = 0; i < m; ++i)
+                for (int d = 0; d < D; ++d) bc[(size_t)i * D + d] = h_uniform(S.k0, S.k1, PC_DOM_LIVEGEN, 0u, attempt + (uint32_t)i, (uint32_t)d);
             const auto te0 = std::chrono::steady_clock::now();
-            const double logL = host_eval(row, row + S.p0, row + S.d0);
+            host_eval_batch(m, bc.data(), bt.data(), bp.data(), bl.data());
             t_eval += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
-            row[S.b0] = cfg.logzero; row[S.l0] = logL;
-            if (logL > cfg.logzero) { have++; nlike++; }
-            attempt++;
             if (g_stop_requested) return;
+            for (int i = 0; i < m; ++i) {
+                if (!(bl[i] > cfg.logzero)) continue;
+                double *row = rows.data() + (size_t)have * nT;
+                std::copy(bc.begin() + (size_t)i * D, bc.begin() + (size_t)(i + 1) * D, row);
+                std::copy(bt.begin() + (size_t)i * D, bt.begin() + (size_t)(i + 1) * D, row + S.p0);
+                std::copy(bp.begin() + (size_t)i * pd, bp.begin() + (size_t)i * pd + S.nDer, row + S.d0);
+                row[S.b0] = cfg.logzero; row[S.l0] = bl[i];
+                have++; nlike++;
+            }
+            attempt += (uint32_t)m;
             if (attempt > 1000u * (uint32_t)nprior + 100000u) { std::fprintf(stderr, "polychord_hip: could not generate live points (likelihood is logzero everywhere?)\n"); std::abort(); }
         }
         double *drows = dalloc<double>((size_t)nprior * nT);
@@ -838,9 +862,27 @@ struct Engine {
             HIPCHK(hipStreamSynchronize(st));
             if (g_stop_requested) return;
             double *evL = hp_ans, *evT = hp_ans + B, *evP = evT + (size_t)B * D;
+            const int pd = std::max(1, nDer);
             int nneed = 0;
+            if (g_batch_fn) {                              // the parked proposals of this round in one call
+                cb_idx.clear();
+                for (int c = 0; c < B; ++c) if (hp_need[c]) cb_idx.push_back(c);
+                nneed = (int)cb_idx.size();
+                if (nneed > 0) {
+                    cb_c.resize((size_t)nneed * D); cb_t.resize((size_t)nneed * D); cb_p.assign((size_t)nneed * pd, 0.0); cb_l.resize(nneed);
+                    for (int i = 0; i < nneed; ++i) std::copy(hp_prop + (size_t)cb_idx[i] * D, hp_prop + (size_t)(cb_idx[i] + 1) * D, cb_c.begin() + (size_t)i * D);
+                    host_eval_batch(nneed, cb_c.data(), cb_t.data(), cb_p.data(), cb_l.data());
+                    for (int i = 0; i < nneed; ++i) {
+                        const int c = cb_idx[i];
+                        evL[c] = cb_l[i];
+                        std::copy(cb_t.begin() + (size_t)i * D, cb_t.begin() + (size_t)(i + 1) * D, evT + (size_t)c * D);
+                        std::copy(cb_p.begin() + (size_t)i * pd, cb_p.begin() + (size_t)(i + 1) * pd, evP + (size_t)c * pd);
+                    }
+                    if (g_stop_requested) return;
+                }
+            } else
             for (int c = 0; c < B; ++c)
-                if (hp_need[c]) { nneed++; evL[c] = host_eval(hp_prop + (size_t)c * D, evT + (size_t)c * D, evP + (size_t)c * std::max(1, nDer)); }
+                if (hp_need[c]) { nneed++; evL[c] = host_eval(hp_prop + (size_t)c * D, evT + (size_t)c * D, evP + (size_t)c * pd); }
             if (nneed == 0) break;
             HIPCHK(hipMemcpyAsync(d_ans, hp_ans, sizeof(double) * (size_t)B * (1 + D + std::max(1, nDer)), hipMemcpyHostToDevice, st));
         }
@@ -1244,6 +1286,7 @@ struct Engine {
 extern "C" {
 
 void polychord_hip_request_stop(void) { g_stop_requested = 1; }
+void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { g_batch_fn = fn; g_batch_user = user; }
 
 double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx)
 {   // the engine's counter RNG on the host (same numbers as pc_dev.h pc_uniform)

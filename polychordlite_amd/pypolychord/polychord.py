@@ -24,18 +24,133 @@ def _mpi_comm():
     return comm if comm.Get_size() > 1 else None
 
 
-def _engine_run(*args):
-    """_pypolychord.run on rank 0; every rank leaves together (a failure on rank 0 is re-raised there after the others
-    have been released)"""
+class _BatchEvaluator:
+    """Evaluation of all parked proposals of a round in one go (polychord_hip_set_batch_callback).
+
+    * `loglikelihood.vectorised = True` (and optionally `prior.vectorised = True`): the callable takes theta of shape
+      (n, nDims) and returns logL of shape (n,), or (logL, phi) with phi of shape (n, nDerived) -- NumPy-vectorised
+      likelihoods, or likelihoods that run on an accelerator themselves.
+    * under mpirun with mpi4py: the rows are scattered over the ranks, every rank evaluates its share with its own copy of
+      the callables, rank 0 gathers -- the parallel likelihood evaluation the reference gets from its MPI workers
+      (nested_sampling.F90:426-498).
+    Otherwise no batch callback is registered and the engine calls the scalar callbacks."""
+
+    def __init__(self, loglikelihood, prior, nDims, nDerived, comm, logzero):
+        self.like, self.prior, self.nDims, self.nDerived, self.comm, self.logzero = loglikelihood, prior, nDims, nDerived, comm, logzero
+        self.vec_like = bool(getattr(loglikelihood, "vectorised", False))
+        self.vec_prior = bool(getattr(prior, "vectorised", False))
+        builtin = getattr(loglikelihood, "symbol", None) is not None       # runs inside the kernel: nothing to batch
+        self.active = not builtin and (self.vec_like or comm is not None)
+        self.error = None
+        self._cb = None
+
+    # ---- evaluation of a block of rows on this rank
+    def local(self, cubes):
+        n = cubes.shape[0]
+        theta = np.asarray(self.prior(cubes), dtype=float).reshape(n, self.nDims) if self.vec_prior else \
+            np.array([np.asarray(self.prior(c), dtype=float) for c in cubes], dtype=float).reshape(n, self.nDims)
+        phi = np.zeros((n, self.nDerived))
+        if self.vec_like:
+            out = self.like(theta)
+            if isinstance(out, tuple):
+                logL, p = out
+                phi[:] = np.asarray(p, dtype=float).reshape(n, self.nDerived)
+            else:
+                logL = out
+            logL = np.asarray(logL, dtype=float).reshape(n)
+        else:
+            logL = np.empty(n)
+            for i in range(n):
+                out = self.like(theta[i])
+                try:
+                    logL[i], phi[i, :] = out
+                except TypeError:
+                    logL[i] = out
+        return theta, phi, logL
+
+    # ---- all ranks together (rank 0 holds the rows)
+    def evaluate(self, cubes):
+        comm = self.comm
+        if comm is None:
+            return self.local(cubes)
+        size = comm.Get_size()
+        comm.bcast("eval", root=0)
+        mine = comm.scatter(np.array_split(cubes, size), root=0)
+        parts = comm.gather(self.local(mine) if len(mine) else (np.zeros((0, self.nDims)), np.zeros((0, self.nDerived)), np.zeros(0)), root=0)
+        return tuple(np.concatenate([q[k] for q in parts]) for k in range(3))
+
+    def serve(self):
+        """worker ranks: evaluate shares until rank 0 says the run is over"""
+        comm = self.comm
+        while comm.bcast(None, root=0) == "eval":
+            mine = comm.scatter(None, root=0)
+            comm.gather(self.local(mine) if len(mine) else (np.zeros((0, self.nDims)), np.zeros((0, self.nDerived)), np.zeros(0)), root=0)
+
+    # ---- the C callback
+    def register(self):
+        import ctypes as C
+        from .. import _ctypes_api as api
+        lib = api.load()
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+        def cb(_user, n, nd, nder, cube_p, theta_p, phi_p, logL_p):
+            logL = np.ctypeslib.as_array(logL_p, shape=(n,))
+            try:
+                if self.error is not None:
+                    raise self.error
+                cubes = np.ctypeslib.as_array(cube_p, shape=(n, nd))
+                theta, phi, ll = self.evaluate(cubes)
+                np.ctypeslib.as_array(theta_p, shape=(n, nd))[:] = theta
+                if nder > 0:
+                    np.ctypeslib.as_array(phi_p, shape=(n, nder))[:] = phi
+                logL[:] = ll
+            except BaseException as e:   # noqa: BLE001 - re-raised by run() once the engine has wound down
+                if self.error is None:
+                    self.error = e
+                logL[:] = self.logzero
+                lib.polychord_hip_request_stop()
+        self._cb = proto(cb)
+        lib.polychord_hip_set_batch_callback.argtypes = [C.c_void_p, C.c_void_p]
+        lib.polychord_hip_set_batch_callback(C.cast(self._cb, C.c_void_p), None)
+        return lib
+
+    def unregister(self, lib):
+        lib.polychord_hip_set_batch_callback(None, None)
+        self._cb = None
+
+
+def _engine_run(loglikelihood, prior, *args):
+    """_pypolychord.run(wrapped loglikelihood, wrapped prior, *args) on rank 0; every rank leaves together (a failure on
+    rank 0 is re-raised there after the others have been released).  args[1], args[2] = nDims, nDerived; args[10] = logzero."""
+    wl, wp = _wrap(loglikelihood, prior)
     comm = _mpi_comm()
+    batch = _BatchEvaluator(loglikelihood, prior, args[1], args[2], comm, args[10])
     if comm is None:
-        return _pypolychord.run(*args)
+        if not batch.active:
+            return _pypolychord.run(wl, wp, *args)
+        lib = batch.register()
+        try:
+            _pypolychord.run(wl, wp, *args)
+        finally:
+            batch.unregister(lib)
+        if batch.error is not None:
+            raise batch.error
+        return None
     err = None
     if comm.Get_rank() == 0:
+        lib = batch.register() if batch.active else None
         try:
-            _pypolychord.run(*args)
+            _pypolychord.run(wl, wp, *args)
         except BaseException as e:      # noqa: BLE001 - re-raised below
             err = e
+        finally:
+            if lib is not None:
+                batch.unregister(lib)
+                comm.bcast("done", root=0)
+        err = err or batch.error
+    elif batch.active:
+        batch.serve()
     comm.Barrier()
     if err is not None:
         raise err
@@ -58,12 +173,29 @@ def make_paramnames_file(paramnames, filename):
             f.write("%s   %s\n" % (name, latex))
 
 
+def _call_prior(prior, cube):
+    """theta of one hypercube point, also from a prior written for blocks of rows (`prior.vectorised`)"""
+    if getattr(prior, "vectorised", False):
+        return np.asarray(prior(np.asarray(cube, dtype=float)[None, :]), dtype=float)[0]
+    return prior(cube)
+
+
+def _call_like(loglikelihood, theta):
+    """logL or (logL, phi) of one point, also from a likelihood written for blocks of rows (`loglikelihood.vectorised`)"""
+    if getattr(loglikelihood, "vectorised", False):
+        out = loglikelihood(np.asarray(theta, dtype=float)[None, :])
+        if isinstance(out, tuple):
+            return float(np.asarray(out[0]).reshape(-1)[0]), np.asarray(out[1], dtype=float).reshape(1, -1)[0]
+        return float(np.asarray(out).reshape(-1)[0])
+    return loglikelihood(theta)
+
+
 def _wrap(loglikelihood, prior):
     builtin_like = getattr(loglikelihood, "symbol", None) is not None
     builtin_prior = getattr(prior, "symbol", None) is not None
 
     def wrap_loglikelihood(theta, phi):          # polychord.py:581-587
-        logL = loglikelihood(theta)
+        logL = _call_like(loglikelihood, theta)
         try:
             logL, phi[:] = logL
         except TypeError:
@@ -71,7 +203,7 @@ def _wrap(loglikelihood, prior):
         return logL
 
     def wrap_prior(cube, theta):                 # polychord.py:589-590
-        theta[:] = prior(cube)
+        theta[:] = _call_prior(prior, cube)
 
     if builtin_like:
         wrap_loglikelihood.__wrapped_builtin__ = loglikelihood
@@ -99,8 +231,8 @@ def _make_resume_file(loglikelihood, **kwargs):
     cubes = np.asarray(kwargs["cube_samples"], dtype=float)
     lives = []
     for cube in cubes:
-        theta = np.asarray(kwargs["prior"](cube), dtype=float)
-        logL = loglikelihood(theta)
+        theta = np.asarray(_call_prior(kwargs["prior"], cube), dtype=float)
+        logL = _call_like(loglikelihood, theta)
         try:
             logL, derived = logL
         except TypeError:
@@ -167,10 +299,9 @@ def run_polychord(loglikelihood, nDims, nDerived, settings, prior=default_prior,
         if root:
             _legacy_make_resume_file(settings, loglikelihood, prior)
         settings.read_resume = True
-    wl, wp = _wrap(loglikelihood, prior)
     settings.grade_dims = [int(d) for d in settings.grade_dims]
     settings.nlives = {float(logL): int(nlive) for logL, nlive in settings.nlives.items()}
-    _engine_run(wl, wp, dumper, nDims, nDerived, settings.nlive, settings.num_repeats, settings.nprior, settings.nfail,
+    _engine_run(loglikelihood, prior, dumper, nDims, nDerived, settings.nlive, settings.num_repeats, settings.nprior, settings.nfail,
                      settings.do_clustering, settings.feedback, settings.precision_criterion, settings.logzero,
                      settings.max_ndead, settings.boost_posterior, settings.posteriors, settings.equals,
                      settings.cluster_posteriors, settings.write_resume, settings.write_paramnames, settings.read_resume,
@@ -204,7 +335,6 @@ def run(loglikelihood, nDims, **kwargs):
         (Path(kwargs["base_dir"]) / kwargs["cluster_dir"]).mkdir(parents=True, exist_ok=True)
         if paramnames is not None:
             make_paramnames_file(paramnames, Path(kwargs["base_dir"]) / (kwargs["file_root"] + ".paramnames"))
-    wl, wp = _wrap(loglikelihood, kwargs["prior"])
     kwargs["grade_dims"] = [int(d) for d in list(kwargs["grade_dims"])]
     if sum(kwargs["grade_dims"]) != nDims:
         raise ValueError(f"grade_dims ({sum(kwargs['grade_dims'])}) must sum to nDims ({nDims})")
@@ -213,7 +343,7 @@ def run(loglikelihood, nDims, **kwargs):
         if root:
             _make_resume_file(loglikelihood, **kwargs)
         kwargs["read_resume"] = True
-    _engine_run(wl, wp, kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
+    _engine_run(loglikelihood, kwargs["prior"], kwargs["dumper"], nDims, kwargs["nDerived"], kwargs["nlive"], kwargs["num_repeats"],
                      kwargs["nprior"], kwargs["nfail"], kwargs["do_clustering"], kwargs["feedback"],
                      kwargs["precision_criterion"], kwargs["logzero"], kwargs["max_ndead"], kwargs["boost_posterior"],
                      kwargs["posteriors"], kwargs["equals"], kwargs["cluster_posteriors"], kwargs["write_resume"],

@@ -82,7 +82,8 @@ def test_under_mpirun_only_rank_0_runs_the_engine(tmp_path, monkeypatch):
     calls, barriers = [], []
 
     def fake_comm(rank):
-        comm = types.SimpleNamespace(Get_rank=lambda: rank, Get_size=lambda: 4, Barrier=lambda: barriers.append(rank))
+        comm = types.SimpleNamespace(Get_rank=lambda: rank, Get_size=lambda: 4, Barrier=lambda: barriers.append(rank),
+                                     bcast=lambda obj, root=0: obj if rank == 0 else "done", scatter=None, gather=None)
         return types.SimpleNamespace(MPI=types.SimpleNamespace(COMM_WORLD=comm))
     monkeypatch.setattr(pc, "_pypolychord", types.SimpleNamespace(run=lambda *a: calls.append(a)))
     for rank in (1, 0):
@@ -702,3 +703,76 @@ def test_output_files_equal_the_reference_binary(engine, golden, tmp_path, monke
                     assert abs(float(x) - float(y)) <= 1e-9 * max(1.0, abs(float(y))), (a, b)
                 except ValueError:
                     assert x == y, (a, b)
+
+
+@pytest.mark.gpu
+def test_vectorised_and_farmed_likelihoods(engine, tmp_path, monkeypatch):
+    """polychord_hip_set_batch_callback through the Python layer: a likelihood marked `vectorised` gets all the parked
+    proposals of a round as one (n, nDims) array, and under mpirun the rows are farmed out to the ranks (mpi4py simulated:
+    the 'other ranks' evaluate their shares in this process).  Same draws, same decisions: the runs equal the scalar one."""
+    import sys
+    import types
+    from polychordlite_amd.pypolychord import polychord as pc
+    lib = engine.load(); lib.polychord_hip_set_option(b"batch", 32.0)
+    kw = dict(nDerived=1, nlive=80, num_repeats=8, seed=7, do_clustering=False, read_resume=False, write_resume=False,
+              write_dead=False, write_live=False, write_stats=True, posteriors=False, equals=False, write_prior=False, feedback=0)
+    shapes = []
+
+    def vec_like(theta):                                   # theta: (n, nDims)
+        shapes.append(theta.shape)
+        r2 = np.sum(theta ** 2, axis=1)
+        return -np.log(2 * np.pi * 0.01) * theta.shape[1] / 2.0 - r2 / 0.02, r2[:, None]
+    vec_like.vectorised = True
+
+    def vec_prior(cube):
+        return -1.0 + 2.0 * cube
+    vec_prior.vectorised = True
+    try:
+        out = {}
+        dumps = {}
+        for name, like, prior in (("scalar", gaussian_likelihood, uniform_prior), ("vec", vec_like, vec_prior), ("mixed", vec_like, uniform_prior)):
+            got = []
+            pypolychord.run(like, nDims, prior=prior, dumper=lambda l, d, w, z, e: got.append((d.copy(), z)), base_dir=str(tmp_path), file_root=name, **kw)
+            dumps[name] = got[-1]
+        assert max(s[0] for s in shapes) > 8 and all(s[1] == nDims for s in shapes)          # real blocks of rows arrived
+        for name in ("vec", "mixed"):
+            # (NumPy sums a row of a 2-D array and a 1-D array in different orders: last-bit differences in logL)
+            assert abs(dumps[name][1] - dumps["scalar"][1]) < 1e-10 and np.allclose(dumps[name][0], dumps["scalar"][0], rtol=1e-12, atol=1e-12)
+        # simulated MPI farm: 3 ranks; scatter hands rank 0 its share and evaluates the others' shares on the spot
+        calls = {"n": 0}
+
+        class Comm:
+            def Get_rank(self): return 0
+            def Get_size(self): return 3
+            def Barrier(self): pass
+            def bcast(self, obj, root=0): return obj
+            def scatter(self, parts, root=0):
+                self.parts = parts
+                return parts[0]
+            def gather(self, mine, root=0):
+                calls["n"] += 1
+                return [mine] + [self.ev.local(p) for p in self.parts[1:]]
+        comm = Comm()
+        monkeypatch.setitem(sys.modules, "mpi4py", types.SimpleNamespace(MPI=types.SimpleNamespace(COMM_WORLD=comm)))
+        orig = pc._BatchEvaluator
+
+        class Spy(orig):
+            def __init__(self, *a):
+                super().__init__(*a)
+                comm.ev = self
+        monkeypatch.setattr(pc, "_BatchEvaluator", Spy)
+        got = []
+        pypolychord.run(gaussian_likelihood, nDims, prior=uniform_prior, dumper=lambda l, d, w, z, e: got.append((d.copy(), z)),
+                        base_dir=str(tmp_path), file_root="farm", **kw)
+        assert calls["n"] > 10
+        assert got[-1][1] == dumps["scalar"][1] and np.array_equal(got[-1][0], dumps["scalar"][0])
+        # an exception inside a vectorised likelihood comes back out of run()
+        def bad(theta):
+            raise KeyError("vectorised boom")
+        bad.vectorised = True
+        monkeypatch.delitem(sys.modules, "mpi4py")
+        monkeypatch.setattr(pc, "_BatchEvaluator", orig)
+        with pytest.raises(KeyError):
+            pypolychord.run(bad, nDims, base_dir=str(tmp_path), file_root="bad", **dict(kw, nDerived=0))
+    finally:
+        lib.polychord_hip_set_option(b"batch", 0.0)
