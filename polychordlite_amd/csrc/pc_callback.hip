@@ -18,13 +18,16 @@ struct PcChain {
     double t, tL, tR, lL, lR, w, contour, lnew;
 };
 
+// One wavefront per chain, lane = cube coordinate (d, d + 64, ...): a proposal, an acceptance or a row store touches all
+// coordinates in one round trip (one thread per chain walked them one global access at a time: 68 us per tick at 20-D).
+// Everything that steers the state machine is wave-uniform.
 __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, int nchains, PcChain *cs, double *x0s /* [B][D] */,
                                                   int *decks /* [B][nr] */, double *prop /* [B][D] */,
                                                   const double *ev_logL, const double *ev_theta, const double *ev_phi,
                                                   int first, double *prop_host, int *need_host)
 {   // prop_host / need_host: pinned host memory; the proposals and the need flags are stored there directly (posted
     // writes over PCIe), so that the host finds them after one stream synchronisation, without copies
-    const int chain = blockIdx.x * 64 + threadIdx.x;
+    const int chain = blockIdx.x, lane = threadIdx.x;
     if (chain >= nchains) return;
     const int D = S.D, nr = S.nr, nT = S.nT;
     PcChain c = cs[chain];
@@ -33,16 +36,20 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
     double *pc = prop + (size_t)chain * D;
     if (first) {
         const double *seed = S.live + (size_t)S.ch_seed_slot[chain] * nT;
-        for (int d = 0; d < D; ++d) x0[d] = seed[d];
-        for (int i = 0; i < nr; ++i) deck[i] = i;
-        for (int i = nr - 1; i >= 1; --i) {            // random_utils.F90:505-532 on deck(2:)
-            const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
-            int j = (int)ceil(u * i);
-            j = j < 1 ? 1 : (j > i ? i : j);
-            const int t = deck[i]; deck[i] = deck[j]; deck[j] = t;
-        }
+        for (int d = lane; d < D; d += 64) x0[d] = seed[d];
+        for (int i = lane; i < nr; i += 64) deck[i] = i;
+        __syncthreads();
+        if (lane == 0)
+            for (int i = nr - 1; i >= 1; --i) {            // random_utils.F90:505-532 on deck(2:)
+                const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
+                int j = (int)ceil(u * i);
+                j = j < 1 ? 1 : (j > i ? i : j);
+                const int t = deck[i]; deck[i] = deck[j]; deck[j] = t;
+            }
+        __syncthreads();
         c.phase = CB_NEW_SLICE; c.s = 0; c.nlike = 0; c.need = 0; c.contour = S.ch_contour[chain]; c.ok_theta = 0;
-        if (S.ngrade > 1) for (int g = 0; g < PC_MAX_GRADE; ++g) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + g] = 0;
+        if (S.ngrade > 1 && lane < PC_MAX_GRADE) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + lane] = 0;
+        __syncthreads();
     }
     double logL = 0.0;
     bool have = false;
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
         logL = ev_logL[chain];
         if (logL > S.logzero) {
             c.nlike++;
-            if (S.ngrade > 1) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + pc_grade_of(S, deck[c.s])]++;   // chordal_sampling.f90:84
+            if (S.ngrade > 1 && lane == 0) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + pc_grade_of(S, deck[c.s])]++;   // chordal_sampling.f90:84
         }
         c.need = 0; have = true; c.ok_theta = 1;
     }
@@ -60,10 +67,9 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
     auto propose = [&](double t) {
         c.t = t;
         bool outside = false;
-        for (int d = 0; d < D; ++d) { const double v = x0[d] + t * nh[d]; pc[d] = v; outside |= (v < 0.0) | (v > 1.0); }
-        if (outside) { logL = S.logzero; have = true; c.ok_theta = 0; return false; }   // calculate.f90:36-38
         double *ph = prop_host + (size_t)chain * D;
-        for (int d = 0; d < D; ++d) ph[d] = pc[d];
+        for (int d = lane; d < D; d += 64) { const double v = x0[d] + t * nh[d]; pc[d] = v; ph[d] = v; outside |= (v < 0.0) | (v > 1.0); }
+        if (__ballot(outside) != 0ull) { logL = S.logzero; have = true; c.ok_theta = 0; return false; }   // calculate.f90:36-38
         c.need = 1; have = false;
         return true;
     };
@@ -124,25 +130,33 @@ __global__ __launch_bounds__(64) void k_slice_tick(PcState S, unsigned batch, in
         }
         if (accept) {   // the baby becomes the next start point (chordal_sampling.f90:85-88)
             double *row = S.babies + ((size_t)chain * nr + c.s) * nT;
-            for (int d = 0; d < D; ++d) { x0[d] = pc[d]; row[d] = pc[d]; row[S.p0 + d] = c.ok_theta ? ev_theta[(size_t)chain * D + d] : 0.0; }
-            for (int e = 0; e < S.nDer; ++e) row[S.d0 + e] = c.ok_theta ? ev_phi[(size_t)chain * S.nDer + e] : 0.0;
-            row[S.b0] = c.contour; row[S.l0] = c.lnew;
-            S.baby_logL[(size_t)chain * nr + c.s] = c.lnew; S.baby_logL_T[(size_t)c.s * S.B + chain] = c.lnew;
+            for (int d = lane; d < D; d += 64) {
+                const double v = pc[d];
+                x0[d] = v; row[d] = v; row[S.p0 + d] = c.ok_theta ? ev_theta[(size_t)chain * D + d] : 0.0;
+            }
+            for (int e = lane; e < S.nDer; e += 64) row[S.d0 + e] = c.ok_theta ? ev_phi[(size_t)chain * S.nDer + e] : 0.0;
+            if (lane == 0) {
+                row[S.b0] = c.contour; row[S.l0] = c.lnew;
+                S.baby_logL[(size_t)chain * nr + c.s] = c.lnew; S.baby_logL_T[(size_t)c.s * S.B + chain] = c.lnew;
+            }
+            __syncthreads();                       // x0 of the next slice is read by other lanes than wrote it?  no: lane-private
             c.s++; c.phase = CB_NEW_SLICE;
         }
         if (c.phase == CB_DONE) break;
         if (parked && c.need) break;       // a proposal waits for the host
     }
-    if (c.phase == CB_DONE) S.ch_nlike[chain] = c.nlike;
-    need_host[chain] = c.need;
-    cs[chain] = c;
+    if (lane == 0) {
+        if (c.phase == CB_DONE) S.ch_nlike[chain] = c.nlike;
+        need_host[chain] = c.need;
+        cs[chain] = c;
+    }
 }
 
 extern "C" void pc_launch_slice_tick(const PcState *S, unsigned batch, int nchains, void *cs, double *x0s, int *decks, double *prop,
                                      const double *ev_logL, const double *ev_theta, const double *ev_phi, int first, double *prop_host,
                                      int *need_host, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slice_tick, dim3((nchains + 63) / 64), dim3(64), 0, st, *S, batch, nchains, (PcChain *)cs, x0s, decks, prop,
+    hipLaunchKernelGGL(k_slice_tick, dim3(nchains), dim3(64), 0, st, *S, batch, nchains, (PcChain *)cs, x0s, decks, prop,
                        ev_logL, ev_theta, ev_phi, first, prop_host, need_host);
 }
 
