@@ -124,9 +124,11 @@ def main():
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
     s.nlive = args.nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
     s.do_clustering = wl["clustering"]
-    # HIP-event stopwatch on the two heaviest kernel classes only (slice sampling = the likelihood evaluations,
-    # contraction); timing all six classes costs ~4 ms of event records per 28 ms run
-    s.profile = (1 << (1 + 1)) | (1 << (2 + 1))
+    # HIP-event stopwatch: the warm-up steps time the two heaviest kernel classes (slice sampling = the likelihood
+    # evaluations, contraction), the timed steps only the one that came out on top -- every timed launch costs two
+    # event records on the run's stream (all six classes: ~4 ms per 25 ms run, two classes: ~2.5 ms)
+    PROFILE_BOTH = (1 << (1 + 1)) | (1 << (2 + 1))
+    s.profile = PROFILE_BOTH
     if wl["kind"] == "corr_gaussian":
         ic, mean, logdet = random_correlated_gaussian(nDims)
         L, P, keep = api.make_problem("corr_gaussian", nDims, nDer, invcov=ic, mean=mean, logdet=logdet)
@@ -145,7 +147,15 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        merge_runs(one(-1 - i), dist, torch, local_rank)
+        w = one(-1 - i)
+        merge_runs(w, dist, torch, local_rank)
+        kw = w["kernel_time"]
+        if kw:
+            # (k_slice unless another class is clearly ahead: at the metric config the two are within a few per cent
+            #  of each other under the stopwatch, and the kernel trace in profiles/ has k_slice on top)
+            top = max(kw, key=lambda n: kw[n]["total_s"] * (1.2 if n == "k_slice" else 1.0))
+            s.profile = 1 << (api.KERNEL_CLASSES.index(top) + 1)
+        w = None
     sync()
     t0 = time.perf_counter()
     # Every step hands back its dead points in pinned host memory (zero-copy views).  Only the last step's arrays are

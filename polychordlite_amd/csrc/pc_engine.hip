@@ -23,6 +23,8 @@
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
+int pc_nhats_splittable(const PcState *);
+int pc_launch_nhats_part(const PcState *, unsigned, int, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
@@ -234,6 +236,9 @@ struct Engine {
     PcState S{};
     hipStream_t st = nullptr;
     hipStream_t st_copy = nullptr;            // dead rows leave for the host while the run goes on
+    hipStream_t st_side = nullptr;            // the orthonormal bases of the next nursery, while this one is consumed
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool pre_ready = false; unsigned pre_batch = 0; int pre_B = 0;
     double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
     PcCtl *h_ctl = nullptr;       // pinned mirror
     // alternate phantom buffers + scratch for the update step
@@ -392,6 +397,8 @@ struct Engine {
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
+        static const bool split_off = std::getenv("PC_NHATS_SPLIT_OFF") != nullptr;
+        S.nhat_raw = (D <= 24 && !S.seq_mode && !split_off) ? dalloc<double>((size_t)B * S.nb_total * D * D) : nullptr;
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
@@ -1129,12 +1136,28 @@ struct Engine {
             if (h_ctl->i_nursery == 0) {
                 ensure_capacity();
                 hipEvent_t e0 = kt.begin(KT_NHATS);
-                if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                const bool split = pc_nhats_splittable(&S) != 0;
+                if (split) {
+                    // the bases were drawn on the side stream while the last nursery was consumed (or are drawn now)
+                    if (pre_ready && pre_batch == batch && pre_B == B) HIPCHK(hipStreamWaitEvent(st, ev_side, 0));
+                    else (void)pc_launch_nhats_part(&S, batch, B, 1, st);
+                    pre_ready = false;
+                    (void)pc_launch_nhats_part(&S, batch, B, 2, st);
+                }
+                else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_NHATS, e0);
                 hipEvent_t e1 = kt.begin(KT_SLICE);
                 if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
                 else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
+                if (split) {
+                    if (!st_side) { st_side = hpool().get_stream(); ev_main = hpool().get_event(); ev_side = hpool().get_event(); }
+                    HIPCHK(hipEventRecord(ev_main, st));
+                    HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0));       // the raw bases of this nursery have been read
+                    (void)pc_launch_nhats_part(&S, batch + 1, B, 1, st_side);
+                    HIPCHK(hipEventRecord(ev_side, st_side));
+                    pre_ready = true; pre_batch = batch + 1; pre_B = B;
+                }
                 if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
                 batch++; tm.batches++;
                 S.nn_valid = 0; nursery_left = B;
@@ -1260,7 +1283,7 @@ struct Engine {
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,
-                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
+                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.nhat_raw, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
@@ -1278,6 +1301,8 @@ struct Engine {
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
         if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
         if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
+        if (st_side) { (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_main); hpool().put_event(ev_side); } st_side = nullptr; ev_main = ev_side = nullptr;
+        pre_ready = false;
     }
 };
 

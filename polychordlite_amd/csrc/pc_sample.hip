@@ -179,7 +179,10 @@ __device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, in
     if (S.seed_override) slot = chain;
 }
 
-template <int DMAX, int NT>
+// PART 0: the whole kernel.  PART 1 / 2: the two halves of a split launch -- the orthonormal bases depend on nothing
+// but the keys and the batch number (1: they go to S.nhat_raw, on a side stream while the previous nursery is being
+// consumed), seed selection and whitening need the live set and the covariance of the moment (2).
+template <int DMAX, int NT, int PART = 0>
 __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
     int grade, basis;
     pc_grade_of_basis(S, blockIdx.x, grade, basis);
     const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
-    if (tid == 0) {
+    if (PART != 1 && tid == 0) {
         int sel, slot;
         select_seed(S, batch, chain, sel, slot);
         sh[0] = sel; sh[1] = slot;
@@ -210,6 +213,15 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #ifdef NHATS_DBG
     ncyc[1] = clock64();
 #endif
+    const int i = tid;
+    const bool active = i < Dg;
+    double v[DMAX];
+    double *raw = S.nhat_raw + (((size_t)chain * gridDim.x + blockIdx.x) * D + (i < D ? i : 0)) * D;   // [chain][basis][vector][D]
+    if constexpr (PART == 2) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? raw[d] : 0.0;
+        __syncthreads();
+    } else {
     // gaussian deviates: running index of stream (batch, chain) in PC_DOM_NHAT, grade after grade, basis after basis,
     // vector after vector (seq_mode: after the two seed draws: generate_nhats inside SliceSampling)
     const uint32_t eoff = S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u;
@@ -231,9 +243,6 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #ifdef NHATS_DBG
     ncyc[2] = clock64();
 #endif
-    const int i = tid;
-    const bool active = i < Dg;
-    double v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? G[(size_t)i * D + d] : 0.0;
     // dot products run on four partial sums: a dependent fp64 add costs ~32 cycles, a 20-term serial dot 640
@@ -293,6 +302,14 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
         __syncthreads();
     }
 #undef PC_GS_STEP
+    if constexpr (PART == 1) {
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) raw[d] = v[d];
+        }
+        return;
+    }
+    }   // PART != 2
 #ifdef NHATS_DBG
     ncyc[4] = clock64();
 #endif
@@ -1077,6 +1094,30 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
     else if (S->D <= 128) hipLaunchKernelGGL((k_generate_live<2>), dim3(n), dim3(64), sh, st, *S, attempt0, rows, rows_logL);
     else if (S->D <= 256) hipLaunchKernelGGL((k_generate_live<4>), dim3(n), dim3(64), sh, st, *S, attempt0, rows, rows_logL);
     else return 1;
+    return 0;
+}
+
+// the split launch (see k_nhats): part 1 = bases, part 2 = seeds + whitening; returns 1 where only the whole kernel exists
+extern "C" int pc_nhats_splittable(const PcState *S)
+{
+    const char *e = std::getenv("PC_NHATS_QUAD_MIN");
+    return S->D <= 24 && S->D < (e ? std::atoi(e) : 25) && !S->seq_mode && S->nhat_raw != nullptr;
+}
+extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchains, int part, hipStream_t st)
+{
+    if (!pc_nhats_splittable(S)) return 1;
+    const int D = S->D;
+    dim3 grid(S->nb_total, nchains);
+    const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
+    if (part == 1) {
+        if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64, 1>), grid, dim3(64), sh, st, *S, batch);
+        else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64, 1>), grid, dim3(64), sh, st, *S, batch);
+        else hipLaunchKernelGGL((k_nhats<24, 64, 1>), grid, dim3(64), sh, st, *S, batch);
+    } else {
+        if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64, 2>), grid, dim3(64), sh, st, *S, batch);
+        else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64, 2>), grid, dim3(64), sh, st, *S, batch);
+        else hipLaunchKernelGGL((k_nhats<24, 64, 2>), grid, dim3(64), sh, st, *S, batch);
+    }
     return 0;
 }
 

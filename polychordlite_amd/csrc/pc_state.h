@@ -101,6 +101,7 @@ struct PcState {
     double *ch_contour;          // [B] contour each chain sampled under
     double *nhat;                // [B][nr][D] whitened, normalised directions (generation order)
     double *nhat_w;              // [B][nr] 3*|L n|
+    double *nhat_raw;            // [B][nb_total][D][D] orthonormal bases of the next nursery, before whitening (or null)
     // ---- plan written by the consume kernel for the apply kernels
     PcPlan *plan;                // [B]
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
