@@ -74,6 +74,47 @@ struct FileSink {
     long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
     std::vector<long> nlike_last_g;
     std::vector<double> mu, sig;
+    int feedback = 0, nlive_set = 1;
+
+    // progress block of an update, in the layout of feedback.f90:221-315 (the rows this engine keeps on the host:
+    // live points per cluster, counters, evidences -- per cluster in order of decreasing evidence)
+    void progress(const pchip_update &u) const
+    {
+        int wmax = 1;
+        for (int p = 0; p < u.ncluster; ++p) wmax = std::max(wmax, u.nlive_p[p]);
+        const int iw = std::max(1, (int)std::ceil(std::log10((double)wmax)));
+        std::string bar((size_t)(iw + 2) * (size_t)std::max(1, u.ncluster) + 11, '_');
+        std::printf("%s\nlives      |", bar.c_str());
+        for (int p = 0; p < u.ncluster; ++p) std::printf("%*d |", iw, u.nlive_p[p]);
+        std::printf("\n");
+        for (size_t i = 0; i < bar.size(); ++i) std::printf("\xE2\x80\xBE");
+        std::printf("\nncluster   =%8d /%8d\nndead      =%20ld\n", u.ncluster, u.ncluster + u.ncluster_dead, u.ndead);
+        const int ng = u.ngrade > 0 ? u.ngrade : 1;
+        std::printf("nlike      =");
+        for (int g = 0; g < ng; ++g) std::printf("%20ld", u.nlike_grade ? u.nlike_grade[g] : u.nlike);
+        std::printf("\n<nlike>    =");
+        std::vector<double> since((size_t)ng);
+        for (int g = 0; g < ng; ++g) since[g] = (double)((u.nlike_grade ? u.nlike_grade[g] : u.nlike) - (g < (int)nlike_last_g.size() ? nlike_last_g[g] : 0L));
+        for (int g = 0; g < ng; ++g) std::printf("%15.2f", since[g] / nlive_set);
+        std::printf("   (");
+        for (int g = 0; g < ng; ++g) std::printf("%15.2f", since[g] / ((double)(u.grade_repeats ? u.grade_repeats[g] : num_repeats) * nlive_set));
+        std::printf(" per slice )\n");
+        if (std::fabs(u.logZ) < 1e9) std::printf("log(Z)     = %15.2f +/- %5.2f\n", u.logZ, u.logZerr);
+        else std::printf("log(Z)     = ?\n");
+        std::vector<std::pair<double, int>> ord;
+        for (int p = 0; p < u.ncluster; ++p) ord.push_back({-u.logZp[p], p});
+        for (int p = 0; p < u.ncluster_dead; ++p) ord.push_back({-u.logZp_dead[p], u.ncluster + p});
+        std::stable_sort(ord.begin(), ord.end());
+        for (size_t k = 0; k < ord.size() && ord.size() > 1; ++k) {
+            const int p = ord[k].second;
+            const bool alive = p < u.ncluster;
+            const double z = alive ? u.logZp[p] : u.logZp_dead[p - u.ncluster], e = alive ? u.logZperr[p] : u.logZperr_dead[p - u.ncluster];
+            if (std::fabs(z) < 1e9) std::printf("log(Z_%zu)%*s= %15.2f +/- %5.2f%s\n", k + 1, k + 1 < 9 ? 3 : (k + 1 < 99 ? 2 : 1), "", z, e, alive ? " (still evaluating)" : "");
+            else std::printf("log(Z_%zu)%*s= ?%s\n", k + 1, k + 1 < 9 ? 3 : (k + 1 < 99 ? 2 : 1), "", alive ? " (still evaluating)" : "");
+        }
+        std::printf("\n\n\n");
+        std::fflush(stdout);
+    }
 
     std::string path(const char *suffix) const { return base + "/" + root + suffix; }
     static FILE *open(const std::string &p, const char *mode)
@@ -268,6 +309,7 @@ struct FileSink {
         }
         if (u.final_call == 1 && (posteriors || equals)) { posterior_files(u); if (cluster_posteriors) cluster_files(u); }
         if (write_stats) stats(u);
+        if (feedback >= 1 && u.final_call == 0) progress(u);
         nlike_last = u.nlike;
         nlike_last_g.assign((size_t)(u.ngrade > 0 ? u.ngrade : 1), 0L);
         for (int g = 0; g < (int)nlike_last_g.size(); ++g) nlike_last_g[g] = u.nlike_grade ? u.nlike_grade[g] : u.nlike;
@@ -477,9 +519,20 @@ void polychord_c_interface(
     sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
     sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.cluster_posteriors = cluster_posteriors; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
     sink.compression = compression_factor; sink.num_repeats = num_repeats;
+    sink.feedback = feedback; sink.nlive_set = nlive > 0 ? nlive : 1;
     const bool files = write_stats_f || write_dead || write_live || posteriors || equals || write_prior;
     pchip_result r;
-    pchip_hooks hooks{dumper, files ? FileSink::hook : nullptr, &sink};
+    pchip_hooks hooks{dumper, (files || feedback >= 1) ? FileSink::hook : nullptr, &sink};
+    if (feedback >= 1) {   // feedback.f90:19-63, 79-91, 189-218 in a few lines
+        std::printf("\nPolyChord interface on polychord_hip (MI355X engine)\n");
+        std::printf("nlive      : %8d\nnDims      : %8d\nnDerived   : %8d\n", nlive, nDims, nDerived);
+        if (do_clustering) std::printf("Doing Clustering\n");
+        if (write_resume || read_resume) std::printf("Resume file: %s/%s.resume\n", base.c_str(), root.c_str());
+        std::printf("\nnum_repeats:");
+        if (g_reps.size()) for (int v : g_reps) std::printf("%8d", v); else std::printf("%8d", num_repeats);
+        std::printf("\nstarted sampling\n\n");
+        std::fflush(stdout);
+    }
     const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);
     if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
     if (rc != 0) halt_program("polychord_hip: engine failure");
@@ -490,10 +543,16 @@ void polychord_c_interface(
                            posteriors ? r.post_mean : nullptr, mpath.c_str()) == 2)
             halt_program(("PolyChord Error: " + base + " does not exist").c_str());
     }
-    if (feedback >= 1) {
-        std::printf("polychord_hip: log(Z) = %.6f +/- %.6f  ndead = %ld  nlike = %ld  (%.3f s, batch %d)\n",
-                    r.logZ, std::sqrt(std::fabs(r.varlogZ)), r.ndead, r.nlike, r.t_total, r.batch);
+    if (feedback >= 0) {   // feedback.f90:320-339
+        std::printf(" ____________________________________________________ \n|                                                    |\n");
+        std::printf("| ndead  = %12ld                              |\n", r.ndead);
+        std::printf("| log(Z) = %18.5f +/- %18.5f |\n", r.logZ, std::sqrt(std::fabs(r.varlogZ)));
+        std::printf("|____________________________________________________|\n");
     }
+    if (feedback >= 1) {
+        std::printf("polychord_hip: nlike = %ld  (%.3f s on the device, %d chains per nursery)\n", r.nlike, r.t_total, r.batch);
+    }
+    std::fflush(stdout);
     pchip_result_free(&r);
 }
 

@@ -776,3 +776,28 @@ def test_vectorised_and_farmed_likelihoods(engine, tmp_path, monkeypatch):
             pypolychord.run(bad, nDims, base_dir=str(tmp_path), file_root="bad", **dict(kw, nDerived=0))
     finally:
         lib.polychord_hip_set_option(b"batch", 0.0)
+
+
+@pytest.mark.gpu
+def test_feedback_levels_print_like_the_reference(engine, tmp_path, capfd):
+    """feedback.f90: level 0 prints the final box, level 1 adds a progress block at every update (lives per
+    cluster, counters, evidence) -- and changes nothing about the run"""
+    D = 4
+    def run(fb, root):
+        s = pypolychord.PolyChordSettings(D, 0, nlive=60, num_repeats=8, seed=9, do_clustering=True, read_resume=False,
+                                          write_resume=False, base_dir=str(tmp_path), file_root=root, feedback=fb)
+        return pypolychord.run_polychord(dl.TwinGaussian(0.05), D, 0, s, dl.UniformPrior(-1.0, 1.0))
+    capfd.readouterr()
+    quiet = run(-1, "fbq")
+    assert capfd.readouterr().out.strip() == ""
+    box = run(0, "fb0")
+    out0 = capfd.readouterr().out
+    assert "| ndead  = %12d" % box.ndead in out0 and "| log(Z) =" in out0 and "lives      |" not in out0
+    loud = run(1, "fb1")
+    out1 = capfd.readouterr().out
+    assert "started sampling" in out1 and out1.count("lives      |") >= 3 and out1.count("log(Z)     =") >= 3
+    assert "ncluster   =" in out1 and "<nlike>    =" in out1 and "per slice )" in out1
+    # the last progress block reports the counters of the last update: below the final ones, above zero
+    nd = [int(l.split("=")[1]) for l in out1.splitlines() if l.startswith("ndead      =")]
+    assert nd == sorted(nd) and 0 < nd[-1] <= loud.ndead
+    assert (quiet.ndead, quiet.nlike, quiet.logZ) == (box.ndead, box.nlike, box.logZ) == (loud.ndead, loud.nlike, loud.logZ)

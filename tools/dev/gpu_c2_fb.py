@@ -1,4 +1,5 @@
 import ctypes as C, sys, os
+os.environ.setdefault("PC_DEBUG", os.environ.get("PC_FB", "3"))   # developer counters of the engine
 sys.path.insert(0, ".")
 from polychordlite_amd import _ctypes_api as api
 lib = api.load()

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("PC_DEBUG", "2")   # developer counters of the engine
 import ctypes as C, sys
 sys.path.insert(0, ".")
 from polychordlite_amd import _ctypes_api as api
