@@ -1182,8 +1182,10 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
     // red [PC_CHOL_NT]: scratch of the reduction; it borrows L (zeroed afterwards) when the two matrices
     // alone fill the LDS (nDims = 100: 2 x 80 KB)
     // a_global (nDims > 101: two matrices exceed the LDS): the covariance is read back from S.cov, only L lives in LDS
+    // a_global == 2 (nDims > 143: not even L fits): the factor is built in place in S.chol, the LDS holds the scratch only
     double *A = a_global ? S.cov + (size_t)c * DD : (double *)smem;
-    double *L = a_global ? (double *)smem : A + DD, *red = (DD >= PC_CHOL_NT) ? L : L + DD;
+    double *L = a_global == 2 ? S.chol + (size_t)c * DD : (a_global ? (double *)smem : A + DD);
+    double *red = a_global == 2 ? (double *)smem : ((DD >= PC_CHOL_NT) ? L : L + DD);
     __shared__ int bad;
     const double n = (double)count[c];
     // G groups of DDp threads; group g adds chunks g, g+G, ... in order, then the groups are added in order
@@ -1256,7 +1258,7 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
         for (int p = tid; p < DD; p += PC_CHOL_NT) L[p] = (p / D == p % D) ? sqrt(tr) : 0.0;
     }
     __syncthreads();
-    for (int p = tid; p < DD; p += PC_CHOL_NT) S.chol[(size_t)c * DD + p] = L[p];
+    if (a_global != 2) for (int p = tid; p < DD; p += PC_CHOL_NT) S.chol[(size_t)c * DD + p] = L[p];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1428,7 +1430,7 @@ extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
     hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
 }
 
-static int cov_use_mfma(const PcState *S) { return S->D >= 32; }
+static int cov_use_mfma(const PcState *S) { return S->D >= 32 && S->D <= 128; }   // wider: more result tiles than a wave's registers hold
 static int cov_tile_stride(const PcState *S) { return cov_use_mfma(S) ? ((S->D + 15) & ~15) + 1 : S->D + 1; }
 static int cov_rows(const PcState *S)
 {   // rows per chunk: the centred tile [rows][stride] must fit in LDS
@@ -1468,7 +1470,7 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
     int a_global = 0;
     if (sh2 > 160 * 1024) { a_global = 1; sh2 = sizeof(double) * ((size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT)); }
-    if (sh2 > 160 * 1024) return 1;
+    if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
     hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count, a_global);

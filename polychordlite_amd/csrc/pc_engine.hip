@@ -398,7 +398,8 @@ struct Engine {
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         static const bool split_off = std::getenv("PC_NHATS_SPLIT_OFF") != nullptr;
-        S.nhat_raw = (D <= 24 && !S.seq_mode && !split_off) ? dalloc<double>((size_t)B * S.nb_total * D * D) : nullptr;
+        S.nhat_raw = (D <= 24 && !S.seq_mode && !split_off) ? dalloc<double>((size_t)B * S.nb_total * D * D)
+                   : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);

@@ -396,6 +396,119 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 }
 
 // ------------------------------------------------------------------------------------------
+// K0 for 128 < nDims <= 256: a basis no longer fits in a CU's LDS (256 x 256 fp64 = 512 KB).  One workgroup of 256 threads per
+// (chain, basis), thread i owns vector i; the basis lives in a global scratch block, coordinate-major (V[d][i]: the
+// threads of a wave touch consecutive addresses, the pivot column is a broadcast read served by the L1/L2).  Same
+// arithmetic as k_nhats: row-oriented Gram-Schmidt against the not yet normalised pivot, dot products on four partial
+// sums, whitening in place from the last row upwards.  Correct rather than fast: ~5 nDims^2 memory operations per
+// thread; configurations this wide spend their time in the likelihood.
+// ------------------------------------------------------------------------------------------
+#define PC_BIG_NT 256
+__global__ __launch_bounds__(PC_BIG_NT) void k_nhats_big(PcState S, unsigned batch)
+{
+    __shared__ int sh[2];
+    __shared__ double iwv[PC_BIG_NT];
+    const int D = S.D, nr = S.nr, tid = threadIdx.x, chain = blockIdx.y, i = tid;
+    int grade, basis;
+    pc_grade_of_basis(S, blockIdx.x, grade, basis);
+    const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
+    if (tid == 0) {
+        int sel, slot;
+        select_seed(S, batch, chain, sel, slot);
+        sh[0] = sel; sh[1] = slot;
+        if (blockIdx.x == 0) {
+            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
+            S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
+            S.ch_epoch[chain] = S.ctl->admin_epoch;
+            if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
+        }
+    }
+    double *V = S.nhat_raw + ((size_t)chain * gridDim.x + blockIdx.x) * D * PC_BIG_NT;   // [D][256]
+    // vectors past the truncated end of a grade's last basis are never used and nothing depends on them
+    const int nvec = min(Dg, nrg - basis * Dg);
+    const bool active = i < nvec;
+    const uint32_t eoff = S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u;
+    const uint32_t e0 = eoff + (uint32_t)pc_sel(S.g_e0, grade) + (uint32_t)basis * Dg * Dg, e1 = e0 + (uint32_t)Dg * Dg;
+    for (int e = tid; e < off * PC_BIG_NT; e += PC_BIG_NT) V[e] = 0.0;
+    for (uint32_t call = (e0 >> 1) + tid; call <= ((e1 - 1) >> 1); call += PC_BIG_NT) {
+        double ua, ub;
+        if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
+        else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+        const uint32_t ia = 2 * call, ib = 2 * call + 1;
+        if (ia >= e0 && ia < e1) { const uint32_t x = ia - e0; V[(size_t)(off + x % Dg) * PC_BIG_NT + x / Dg] = pc_inv_normal_cdf(ua); }
+        if (ib >= e0 && ib < e1) { const uint32_t x = ib - e0; V[(size_t)(off + x % Dg) * PC_BIG_NT + x / Dg] = pc_inv_normal_cdf(ub); }
+    }
+    __syncthreads();
+    double *mine = V + i;
+    auto dot_own = [&](const double *q) {              // q . mine (q == mine: the squared norm), four partial sums
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int d = off;
+        for (; d + 3 < D; d += 4) {
+            p0 += q[(size_t)d * PC_BIG_NT] * mine[(size_t)d * PC_BIG_NT]; p1 += q[(size_t)(d + 1) * PC_BIG_NT] * mine[(size_t)(d + 1) * PC_BIG_NT];
+            p2 += q[(size_t)(d + 2) * PC_BIG_NT] * mine[(size_t)(d + 2) * PC_BIG_NT]; p3 += q[(size_t)(d + 3) * PC_BIG_NT] * mine[(size_t)(d + 3) * PC_BIG_NT];
+        }
+        for (; d < D; ++d) p0 += q[(size_t)d * PC_BIG_NT] * mine[(size_t)d * PC_BIG_NT];
+        return (p0 + p1) + (p2 + p3);
+    };
+    auto norm2 = [&](const double *q) {                // q . q in the same four-way order
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int d = off;
+        for (; d + 3 < D; d += 4) {
+            const double a = q[(size_t)d * PC_BIG_NT], b = q[(size_t)(d + 1) * PC_BIG_NT], c = q[(size_t)(d + 2) * PC_BIG_NT], e = q[(size_t)(d + 3) * PC_BIG_NT];
+            p0 += a * a; p1 += b * b; p2 += c * c; p3 += e * e;
+        }
+        for (; d < D; ++d) { const double a = q[(size_t)d * PC_BIG_NT]; p0 += a * a; }
+        return (p0 + p1) + (p2 + p3);
+    };
+    if (active) {                                      // random_direction (random_utils.F90:276-298)
+        const double inrm = 1.0 / sqrt(dot_own(mine));
+        for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] *= inrm;
+    }
+    __syncthreads();
+    // Gram-Schmidt (random_utils.F90:391-399): at step j every later vector removes its component along the pivot
+    // v_j, which is orthogonal to its predecessors already and is normalised by its owner after the loop
+    for (int j = 0; j + 1 < nvec; ++j) {
+        if (active && i > j) {
+            const double *q = V + j;
+            const double qq = norm2(q);
+            const double cproj = dot_own(q) / qq;
+            for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] -= cproj * q[(size_t)d * PC_BIG_NT];
+        }
+        __syncthreads();
+    }
+    if (active) {
+        const double inrm = 1.0 / sqrt(dot_own(mine));
+        for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] *= inrm;
+        // whitening  w = L.n  (chordal_sampling.f90:73), in place: row a only needs n[0..a], rows go downwards
+        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        for (int a = D - 1; a >= 0; --a) {
+            const double *Lr = Lc + (size_t)a * D;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            int b = 0;
+            for (; b + 3 <= a; b += 4) {
+                t0 += Lr[b] * mine[(size_t)b * PC_BIG_NT]; t1 += Lr[b + 1] * mine[(size_t)(b + 1) * PC_BIG_NT];
+                t2 += Lr[b + 2] * mine[(size_t)(b + 2) * PC_BIG_NT]; t3 += Lr[b + 3] * mine[(size_t)(b + 3) * PC_BIG_NT];
+            }
+            for (; b <= a; ++b) t0 += Lr[b] * mine[(size_t)b * PC_BIG_NT];
+            mine[(size_t)a * PC_BIG_NT] = (t0 + t1) + (t2 + t3);
+        }
+        double n0 = 0.0, n1 = 0.0;
+        int d = 0;
+        for (; d + 1 < D; d += 2) { const double a = mine[(size_t)d * PC_BIG_NT], b = mine[(size_t)(d + 1) * PC_BIG_NT]; n0 += a * a; n1 += b * b; }
+        if (d < D) { const double a = mine[(size_t)d * PC_BIG_NT]; n0 += a * a; }
+        const double w = sqrt(n0 + n1);                   // chordal_sampling.f90:80-82
+        iwv[i] = 1.0 / w;
+        S.nhat_w[(size_t)chain * nr + col0 + basis * Dg + i] = w * 3.0;
+    }
+    __syncthreads();
+    for (int r = 0; r < nvec; ++r) {
+        double *out = S.nhat + ((size_t)chain * nr + col0 + basis * Dg + r) * D;
+        const double iw = iwv[r];
+        for (int d = tid; d < D; d += PC_BIG_NT) out[d] = V[(size_t)d * PC_BIG_NT + r] * iw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K0 for 64 < nDims <= 128: FOUR threads per basis vector (32 coordinates each, all in registers), 512 threads per
 // basis.  Dot products are 8 deep instead of 32, the four partial sums meet through DPP quad permutes, the pivot
 // travels through 2 KB of LDS, and the whitening streams the Cholesky factor through 32-row LDS tiles whose rows
@@ -1138,6 +1251,7 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
             if (shq > doneq) { (void)hipFuncSetAttribute((const void *)k_nhats_q<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); doneq = shq; }
             hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), shq, st, *S, batch);
         }
+        else if (D <= 256 && S->nhat_raw) hipLaunchKernelGGL(k_nhats_big, grid, dim3(PC_BIG_NT), 0, st, *S, batch);
         else return 1;
         return 0;
     }

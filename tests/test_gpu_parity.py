@@ -215,20 +215,30 @@ def test_dynamic_nlive_and_nprior_match_oracle(engine, B):
     assert abs(g["logZ"]) < 4 * g["logZerr"]            # truth 0
 
 
-@pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24), (128, 50, 8, 16), (113, 40, 6, 8)])
+@pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24), (128, 50, 8, 16), (113, 40, 6, 8),
+                                          # beyond 128 dimensions: bases in HBM (k_nhats_big), Cholesky factor built in HBM
+                                          (150, 170, 6, 16), (200, 30, 210, 4), (256, 280, 4, 32), (131, 150, 140, 8),
+                                          # negative nDims: the spherical Gaussian of gaussian.f90 in that many dimensions
+                                          (-120, 140, 8, 8), (-140, 160, 8, 8)])
 def test_correlated_gaussian_high_dim_matches_oracle(engine, D, nlive, nr, B):
     """random_gaussian.f90 in 100 (and 40) dimensions: the wide-nDims kernel variants, and live sets whose logL
     spans ~1e5 nats inside one nursery (the live log-sum-exp must not lose the old points to underflow)."""
     api = engine; olib = orc.load()
+    spherical = D < 0
+    D = abs(D)
     ic = np.zeros((D, D)); ld = C.c_double()
     olib.pc_random_invcov(12345, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
     mean = np.full(D, 0.5)
+    # (a few live-set generations: in wide boxes round-off is amplified at every covariance update until a comparison
+    #  flips -- see test_graded_runs_match_oracle)
     kw = dict(nlive=nlive, num_repeats=nr, seed=3, batch=B, max_ndead=6 * nlive)
     s = _settings(api, D, 0, **kw)
-    L, P, keep = api.make_problem("corr_gaussian", D, 0, invcov=ic, mean=mean, logdet=ld.value)
+    if spherical: L, P, keep = api.make_problem("gaussian", D, 0)
+    else: L, P, keep = api.make_problem("corr_gaussian", D, 0, invcov=ic, mean=mean, logdet=ld.value)
     g = api.run(s, L, P)
     so = orc.settings(D, 0, **kw)
-    Lo, Po, k2 = orc.make_problem("corr_gaussian", D, invcov=ic, mean=mean, logdet=ld.value)
+    if spherical: Lo, Po, k2 = orc.make_problem("gaussian", D)
+    else: Lo, Po, k2 = orc.make_problem("corr_gaussian", D, invcov=ic, mean=mean, logdet=ld.value)
     o = orc.run(so, Lo, Po)
     for k in ("ndead", "nlike", "niter"):
         assert g[k] == o[k], (k, g[k], o[k])
@@ -298,6 +308,8 @@ GRADED = [  # kind D nDer nlive B clustering grade_dims grade_repeats
     ("gaussian", 6, 0, 80, 1, 0, [2, 2, 2], [6, 4, 5]), ("rastrigin", 4, 0, 200, 50, 1, [1, 3], [4, 9]),
     ("gaussian", 33, 0, 60, 16, 0, [30, 3], [33, 8]), ("gaussian", 40, 0, 80, 24, 0, [10, 30], [12, 70]),
     ("twin_gaussian", 6, 1, 150, 30, 1, [3, 3], [6, 7]),
+    ("gaussian", 140, 0, 160, 8, 0, [100, 40], [6, 45]),
+    ("gaussian", 120, 0, 140, 8, 0, [90, 30], [6, 35]),        # bases in HBM (nDims > 128), the fast grade's truncated
 ]
 
 
@@ -309,6 +321,11 @@ def test_graded_runs_match_oracle(engine, kind, D, nDer, nlive, B, clustering, d
     api = engine
     lo, hi = BOX[kind]
     kw = dict(nlive=nlive, num_repeats=sum(reps), seed=13, batch=B, do_clustering=clustering)
+    if D > 100:
+        # Wide boxes with few more live points than dimensions: round-off (1e-16 in a direction) is amplified at every
+        # covariance update -- 1e-10 in the live points after 2000 deaths, 1e-7 after 7000 at nDims = 120, then a
+        # comparison flips.  The oracle and the engine agree for as long as that takes; the test stops well before.
+        kw["max_ndead"] = 6 * nlive
     s = _settings(api, D, nDer, **kw)
     keep_g = api.set_grades(s, dims, reps)
     L, P, keep = api.make_problem(kind, D, nDer, lo, hi)
@@ -320,10 +337,11 @@ def test_graded_runs_match_oracle(engine, kind, D, nDer, nlive, B, clustering, d
     for k in ("ndead", "nlike", "niter", "nbatches", "ncluster", "ncluster_dead"):
         assert g[k] == o[k], (k, g[k], o[k])
     assert g["nlike_grade"] == o["nlike_grade"]
-    assert abs(g["logZ"] - o["logZ"]) < 1e-8 and abs(g["logZerr"] - o["logZerr"]) < 1e-8
+    tol = 1e-8 if D <= 100 else 1e-6
+    assert abs(g["logZ"] - o["logZ"]) < tol and abs(g["logZerr"] - o["logZerr"]) < tol
     rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
     assert rel.max() < 1e-7
-    if kind == "gaussian":
+    if kind == "gaussian" and D <= 100:
         assert abs(g["logZ"]) < 4 * g["logZerr"]                # truth 0
 
 
