@@ -9,11 +9,11 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/prof_c5_$tag
 rm -rf "$out"; mkdir -p "$out"
 CMD="python tools/dev/gpu_c5_full.py 5000 200"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- $CMD > "$out/stats.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- $CMD > "$out/stats.log" 2>&1
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "gpurun_out/${tag}_c5_kernel_stats.csv"
 tail -1 "$out/stats.log" > "gpurun_out/${tag}_c5_run.txt"
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > "$out/mfma_counters.txt"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d "$out/mfma" -o p -- $CMD > "$out/mfma.log" 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d "$out/mfma" -o p -- $CMD > "$out/mfma.log" 2>&1
 python - "$out/mfma" "gpurun_out/${tag}_c5_mfma.json" <<'PY'
 import csv, glob, json, os, sys
 acc = {}

@@ -9,13 +9,13 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out" profiles
 BENCH="python bench.py --no-cpu --steps 3 --warmup 1 --concurrent 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- $BENCH > "$out/stats.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- $BENCH > "$out/stats.log" 2>&1
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_kernel_stats.csv"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o p -- $BENCH > "$out/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o p -- $BENCH > "$out/write.log" 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o p -- $BENCH > "$out/fetch.log" 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o p -- $BENCH > "$out/write.log" 2>&1
 python tools/pmc_summary.py "$out/fetch" "$out/write" "profiles/${tag}_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $BENCH (one pass per counter)"
 cp "profiles/${tag}_pmc.json" "profiles/${tag}_kernel_stats.csv" gpurun_out/
 # the bench line itself (same command plus the CPU baseline and the concurrent-runs capacity figure), with the PMC file in place
-python bench.py > "profiles/${tag}_bench.json" 2> "$out/bench.log"
+timeout 400 python bench.py > "profiles/${tag}_bench.json" 2> "$out/bench.log"
 cp "profiles/${tag}_bench.json" gpurun_out/
 head -5 "profiles/${tag}_kernel_stats.csv"
