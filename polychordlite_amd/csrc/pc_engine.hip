@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <map>
 #include <unordered_map>
+#include <atomic>
 #include <mutex>
 
 extern "C" {
@@ -166,6 +167,7 @@ struct HandlePool {
     void put_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); events.push_back({dev, e}); }
 };
 HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
+std::atomic<int> g_active_runs{0};         // runs in flight in this process (polychordlite_amd.repeats: one thread each)
 
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
 
@@ -1100,6 +1102,7 @@ struct Engine {
 
     int run(pchip_result *out)
     {
+        struct ActiveRun { ActiveRun() { g_active_runs.fetch_add(1); } ~ActiveRun() { g_active_runs.fetch_sub(1); } } active_run;
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
         h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
@@ -1137,7 +1140,8 @@ struct Engine {
             if (h_ctl->i_nursery == 0) {
                 ensure_capacity();
                 hipEvent_t e0 = kt.begin(KT_NHATS);
-                const bool split = pc_nhats_splittable(&S) != 0;
+                // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
+                const bool split = pc_nhats_splittable(&S) != 0 && g_active_runs.load(std::memory_order_relaxed) == 1;
                 if (split) {
                     // the bases were drawn on the side stream while the last nursery was consumed (or are drawn now)
                     if (pre_ready && pre_batch == batch && pre_B == B) HIPCHK(hipStreamWaitEvent(st, ev_side, 0));
