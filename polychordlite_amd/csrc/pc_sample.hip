@@ -400,14 +400,16 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 // (chain, basis), thread i owns vector i; the basis lives in a global scratch block, coordinate-major (V[d][i]: the
 // threads of a wave touch consecutive addresses, the pivot column is a broadcast read served by the L1/L2).  Same
 // arithmetic as k_nhats: row-oriented Gram-Schmidt against the not yet normalised pivot, dot products on four partial
-// sums, whitening in place from the last row upwards.  Correct rather than fast: ~5 nDims^2 memory operations per
-// thread; configurations this wide spend their time in the likelihood.
+// sums, whitening in place from the last row upwards.
 // ------------------------------------------------------------------------------------------
 #define PC_BIG_NT 256
+#define PC_BIG_P 16
 __global__ __launch_bounds__(PC_BIG_NT) void k_nhats_big(PcState S, unsigned batch)
 {
     __shared__ int sh[2];
     __shared__ double iwv[PC_BIG_NT];
+    __shared__ double Pq[PC_BIG_P * PC_BIG_NT];        // pivot panel, [pivot][coordinate]
+    __shared__ double pqq[PC_BIG_P];
     const int D = S.D, nr = S.nr, tid = threadIdx.x, chain = blockIdx.y, i = tid;
     int grade, basis;
     pc_grade_of_basis(S, blockIdx.x, grade, basis);
@@ -465,22 +467,72 @@ __global__ __launch_bounds__(PC_BIG_NT) void k_nhats_big(PcState S, unsigned bat
         for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] *= inrm;
     }
     __syncthreads();
-    // Gram-Schmidt (random_utils.F90:391-399): at step j every later vector removes its component along the pivot
-    // v_j, which is orthogonal to its predecessors already and is normalised by its owner after the loop
-    for (int j = 0; j + 1 < nvec; ++j) {
-        if (active && i > j) {
-            const double *q = V + j;
-            const double qq = norm2(q);
-            const double cproj = dot_own(q) / qq;
-            for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] -= cproj * q[(size_t)d * PC_BIG_NT];
+    // Gram-Schmidt (random_utils.F90:391-399) in panels of sixteen pivots.  A panel is staged in LDS and orthogonalised
+    // there (modified Gram-Schmidt, one wave per later vector of the panel, lanes over the coordinates); every vector
+    // behind the panel then takes its sixteen projections in one pass over its coordinates and removes them in a
+    // second: three global accesses per coordinate and panel instead of five per coordinate and pivot.  (Within a
+    // panel the pivots are mutually orthogonal, so projecting on all of them at once differs from one after the other
+    // by round-off only.)  Pivots stay unnormalised: (v.q / q.q) q; every owner normalises after the loop.
+    {
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int j0 = 0; j0 < nvec; j0 += PC_BIG_P) {
+            const int np = min(PC_BIG_P, nvec - j0);
+            for (int e = tid; e < np * D; e += PC_BIG_NT) {           // vector index fastest: 128-B runs of the scratch
+                const int pp = e % np, d = e / np;
+                Pq[pp * PC_BIG_NT + d] = V[(size_t)d * PC_BIG_NT + j0 + pp];
+            }
+            for (int e = np * PC_BIG_NT + tid; e < PC_BIG_P * PC_BIG_NT; e += PC_BIG_NT) Pq[e] = 0.0;
+            __syncthreads();
+            for (int pp = 0; pp + 1 < np; ++pp) {
+                const double *qp = Pq + pp * PC_BIG_NT;
+                for (int q = pp + 1 + wv; q < np; q += 4) {
+                    double *vq = Pq + q * PC_BIG_NT;
+                    double dq = 0.0, dd = 0.0;
+                    for (int d = off + lane; d < D; d += 64) { const double a = qp[d], b2 = vq[d]; dq += a * b2; dd += a * a; }
+                    dq = wave_sum<4>(dq); dd = wave_sum<4>(dd);
+                    const double c = dq / dd;
+                    for (int d = off + lane; d < D; d += 64) vq[d] -= c * qp[d];
+                }
+                __syncthreads();
+            }
+            for (int pp = wv; pp < np; pp += 4) {
+                const double *qp = Pq + pp * PC_BIG_NT;
+                double dd = 0.0;
+                for (int d = off + lane; d < D; d += 64) dd += qp[d] * qp[d];
+                dd = wave_sum<4>(dd);
+                if (lane == 0) pqq[pp] = dd;
+            }
+            for (int e = tid; e < np * D; e += PC_BIG_NT) {
+                const int pp = e % np, d = e / np;
+                V[(size_t)d * PC_BIG_NT + j0 + pp] = Pq[pp * PC_BIG_NT + d];
+            }
+            __syncthreads();
+            if (active && i >= j0 + np) {
+                double c[PC_BIG_P];
+#pragma unroll
+                for (int pp = 0; pp < PC_BIG_P; ++pp) c[pp] = 0.0;
+                for (int d = off; d < D; ++d) {
+                    const double x = mine[(size_t)d * PC_BIG_NT];
+#pragma unroll
+                    for (int pp = 0; pp < PC_BIG_P; ++pp) c[pp] += x * Pq[pp * PC_BIG_NT + d];
+                }
+#pragma unroll
+                for (int pp = 0; pp < PC_BIG_P; ++pp) c[pp] = pp < np ? c[pp] / pqq[pp] : 0.0;
+                for (int d = off; d < D; ++d) {
+                    double x = mine[(size_t)d * PC_BIG_NT];
+#pragma unroll
+                    for (int pp = 0; pp < PC_BIG_P; ++pp) x -= c[pp] * Pq[pp * PC_BIG_NT + d];
+                    mine[(size_t)d * PC_BIG_NT] = x;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (active) {
         const double inrm = 1.0 / sqrt(dot_own(mine));
         for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] *= inrm;
         // whitening  w = L.n  (chordal_sampling.f90:73), in place: row a only needs n[0..a], rows go downwards
-        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        const double *Lc = S.chol + (size_t)__builtin_amdgcn_readfirstlane(sh[0]) * D * D;
         for (int a = D - 1; a >= 0; --a) {
             const double *Lr = Lc + (size_t)a * D;
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
