@@ -1062,9 +1062,12 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     typedef double v4d __attribute__((ext_vector_type(4)));
     constexpr int MAXT = 9;                                       // tiles per wave: nDims <= 128 -> 36 tiles / 4 waves
     v4d acc[MAXT];
+    const int W = TS - 1, nt = W / 16, ntile = nt * (nt + 1) / 2;
+    // beyond 128 dimensions there are more result tiles than a wave's registers hold (136 at nDims = 256): the
+    // workgroup walks its chunks once per group of 4 x MAXT tiles
+    for (int tile0 = 0; tile0 == 0 || (use_mfma && tile0 < ntile); tile0 += 4 * MAXT) {
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) acc[k] = v4d{0.0, 0.0, 0.0, 0.0};
-    const int W = TS - 1, nt = W / 16, ntile = nt * (nt + 1) / 2;
     for (int ch = chunk; ch == chunk || (use_mfma && ch < nchunk_rows); ch += gridDim.x) {
     const int r0 = ch * CR, r1 = max(r0, min(nrows, r0 + CR));
     // ---- member rows of this chunk, in row order (CR <= 256: one row per thread)
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-        const int t = wv + 4 * k;
+        const int t = tile0 + wv + 4 * k;
         if (t < ntile) {
             int ti = 0, rem = t;
             while (rem >= nt - ti) { rem -= nt - ti; ti++; }
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
     double *out = pcov + ((size_t)chunk * nc + c) * D * D;
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-        const int t = wv + 4 * k;
+        const int t = tile0 + wv + 4 * k;
         if (t < ntile) {
             int ti = 0, rem = t;
             while (rem >= nt - ti) { rem -= nt - ti; ti++; }
@@ -1145,6 +1148,7 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
             }
         }
     }
+    }   // groups of tiles
 }
 
 // Fold the per-chunk partial sums of a cluster into the first R chunk slots (slot r = chunks r, r+R, ... added in
@@ -1224,7 +1228,60 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
     // calc_cholesky by ONE wavefront, lane = row: column i needs, for every row j >= i, the dot product
     // sum_{k<i} L(i,k) L(j,k) in ascending k (the reference's order); row i's own value gives the
     // diagonal.  No workgroup barrier inside the column loop, only wave-level LDS ordering.
-    if (tid < 64) {
+    if (a_global == 2) {
+        // The factor is built TRANSPOSED in HBM (L(j,k) at [k][j]): lane = row, so a wave reads one contiguous stretch per
+        // k instead of 64 cache lines, the four rows a lane owns are four independent sums in the same ascending-k order,
+        // and a column is stored as one contiguous row.  Transposed in place at the end.
+        if (tid < 64) {
+            for (int i = 0; i < D; ++i) {
+                double tj[4] = {0.0, 0.0, 0.0, 0.0};
+                int jc[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) jc[m] = min(m * 64 + tid, D - 1);     // rows past D: a harmless duplicate
+                int k = 0;
+                for (; k + 8 <= i; k += 8) {                 // forty loads in flight, then the sums in ascending k
+                    double lik[8], l4[8][4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double *Lk = L + (size_t)(k + u) * D;
+                        lik[u] = Lk[i];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) l4[u][m] = Lk[jc[m]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) tj[m] += lik[u] * l4[u][m];
+                }
+                for (; k < i; ++k) {
+                    const double *Lk = L + (size_t)k * D;
+                    const double lik = Lk[i];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) tj[m] += lik * Lk[jc[m]];
+                }
+                double ti = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { const double v = __shfl(tj[m], i & 63); if ((i >> 6) == m) ti = v; }
+                const double dii = A[i * D + i] - ti;
+                if (dii <= 0.0) { if (tid == 0) bad = 1; break; }
+                const double lii = sqrt(dii);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = m * 64 + tid;
+                    if (j > i && j < D) L[(size_t)i * D + j] = (A[i * D + j] - tj[m]) / lii;
+                }
+                if (tid == 0) L[(size_t)i * D + i] = lii;
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        if (!bad)
+            for (int p = tid; p < DD; p += PC_CHOL_NT) {
+                const int a = p / D, b = p % D;
+                if (a < b) { const double x = L[p], y = L[(size_t)b * D + a]; L[p] = y; L[(size_t)b * D + a] = x; }
+            }
+    }
+    else if (tid < 64) {
         for (int i = 0; i < D; ++i) {
             double tj[4] = {0.0, 0.0, 0.0, 0.0};           // D <= 256: at most 4 rows per lane
             #pragma unroll
@@ -1430,7 +1487,7 @@ extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
     hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
 }
 
-static int cov_use_mfma(const PcState *S) { return S->D >= 32 && S->D <= 128; }   // wider: more result tiles than a wave's registers hold
+static int cov_use_mfma(const PcState *S) { return S->D >= 32; }
 static int cov_tile_stride(const PcState *S) { return cov_use_mfma(S) ? ((S->D + 15) & ~15) + 1 : S->D + 1; }
 static int cov_rows(const PcState *S)
 {   // rows per chunk: the centred tile [rows][stride] must fit in LDS
