@@ -531,19 +531,36 @@ __global__ __launch_bounds__(PC_BIG_NT) void k_nhats_big(PcState S, unsigned bat
     if (active) {
         const double inrm = 1.0 / sqrt(dot_own(mine));
         for (int d = off; d < D; ++d) mine[(size_t)d * PC_BIG_NT] *= inrm;
-        // whitening  w = L.n  (chordal_sampling.f90:73), in place: row a only needs n[0..a], rows go downwards
-        const double *Lc = S.chol + (size_t)__builtin_amdgcn_readfirstlane(sh[0]) * D * D;
-        for (int a = D - 1; a >= 0; --a) {
-            const double *Lr = Lc + (size_t)a * D;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            int b = 0;
-            for (; b + 3 <= a; b += 4) {
-                t0 += Lr[b] * mine[(size_t)b * PC_BIG_NT]; t1 += Lr[b + 1] * mine[(size_t)(b + 1) * PC_BIG_NT];
-                t2 += Lr[b + 2] * mine[(size_t)(b + 2) * PC_BIG_NT]; t3 += Lr[b + 3] * mine[(size_t)(b + 3) * PC_BIG_NT];
+    }
+    // whitening  w = L.n  (chordal_sampling.f90:73), in place, sixteen rows of L at a time from the last row upwards
+    // (row a only needs n[0..a]): the rows wait in LDS, a thread reads each of its coordinates once per tile and
+    // feeds sixteen independent sums in ascending column order (one row at a time re-read the vector nDims/2 times:
+    // 20 GB per launch at nDims = 200)
+    {
+        const double *Lc = S.chol + (size_t)sh[0] * D * D;
+        for (int a_hi = D - 1; a_hi >= 0; a_hi -= PC_BIG_P) {
+            const int a_lo = max(0, a_hi - PC_BIG_P + 1), nrow = a_hi - a_lo + 1;
+            __syncthreads();                              // the previous tile (or the last pivot panel) is no longer read
+            for (int e = tid; e < PC_BIG_P * PC_BIG_NT; e += PC_BIG_NT) {
+                const int r = e / PC_BIG_NT, b2 = e % PC_BIG_NT;
+                Pq[e] = (r < nrow && b2 <= a_hi) ? Lc[(size_t)(a_lo + r) * D + b2] : 0.0;
             }
-            for (; b <= a; ++b) t0 += Lr[b] * mine[(size_t)b * PC_BIG_NT];
-            mine[(size_t)a * PC_BIG_NT] = (t0 + t1) + (t2 + t3);
+            __syncthreads();
+            if (active) {
+                double acc[PC_BIG_P];
+#pragma unroll
+                for (int r = 0; r < PC_BIG_P; ++r) acc[r] = 0.0;
+                for (int b2 = 0; b2 <= a_hi; ++b2) {
+                    const double x = mine[(size_t)b2 * PC_BIG_NT];
+#pragma unroll
+                    for (int r = 0; r < PC_BIG_P; ++r) acc[r] += Pq[r * PC_BIG_NT + b2] * x;
+                }
+#pragma unroll
+                for (int r = 0; r < PC_BIG_P; ++r) if (r < nrow) mine[(size_t)(a_lo + r) * PC_BIG_NT] = acc[r];
+            }
         }
+    }
+    if (active) {
         double n0 = 0.0, n1 = 0.0;
         int d = 0;
         for (; d + 1 < D; d += 2) { const double a = mine[(size_t)d * PC_BIG_NT], b = mine[(size_t)(d + 1) * PC_BIG_NT]; n0 += a * a; n1 += b * b; }
