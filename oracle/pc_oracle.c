@@ -141,6 +141,7 @@ void pc_cholesky(const double *a, int n, double *L)
         for (int k = 0; k < i; ++k) s += L[i * n + k] * L[i * n + k];
         double dii = a[i * n + i] - s;
         if (dii <= 0.0) {
+            if (getenv("PC_ORACLE_TRACE_CHOL")) fprintf(stderr, "oracle chol fallback: n=%d column %d pivot %.3e\n", n, i, dii);
             double tr = 0.0;
             for (int k = 0; k < n; ++k) tr += a[k * n + k];
             memset(L, 0, sizeof(double) * n * n);

@@ -1309,6 +1309,7 @@ __global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nc
         }
     }
     __syncthreads();
+    if (bad && tid == 0 && (S.ablate & (1 << 30))) printf("engine chol fallback: cluster %d of %d, n = %d\n", c, nc, (int)n);   // developer trace
     if (bad) {   // no Cholesky factor: scaled identity (utils.F90:633-638)
         double tr = 0.0;
         for (int k = 0; k < D; ++k) tr += A[k * D + k];

@@ -1137,7 +1137,9 @@ struct Engine {
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
+            bool fresh_nursery = false;
             if (h_ctl->i_nursery == 0) {
+                fresh_nursery = true;
                 ensure_capacity();
                 hipEvent_t e0 = kt.begin(KT_NHATS);
                 // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
@@ -1194,6 +1196,10 @@ struct Engine {
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             read_ctl();
+            // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
+            // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery
+            // generated in between was never touched and does not count.
+            if (fresh_nursery && h_ctl->status == PC_ST_DONE && h_ctl->i_nursery == B) tm.batches--;
             nursery_left = h_ctl->i_nursery;
             tally_grades();
             stream_dead();
