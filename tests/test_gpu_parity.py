@@ -346,7 +346,7 @@ def test_graded_runs_match_oracle(engine, kind, D, nDer, nlive, B, clustering, d
         assert abs(g["logZ"]) < 4 * g["logZerr"]                # truth 0
 
 
-def _random_cases(n, seed=2024, dhi=13):
+def _random_cases(n, seed=2024, dhi=13, seq=False):
     """small random configurations: every front-door knob of the path at once"""
     rng = np.random.default_rng(seed)
     out = []
@@ -371,6 +371,9 @@ def _random_cases(n, seed=2024, dhi=13):
             extra["precision_criterion"] = float(10 ** rng.uniform(-4, -0.5))
         elif r < 0.4:
             extra["nprior"] = nlive + int(rng.integers(1, nlive))
+        if seq:   # the reference's own draw order and list rule, one chain at a time (the mode the reference binary pins)
+            B, general = 1, 0
+            extra["sequential_rng"] = 1
         if dhi > 13:
             # Round-off (1e-16: the engine sums in another order than the oracle) grows with every generation of live
             # points -- 1e-11 after 600 deaths, 1e-7 after 2600 for a 35-D Rastrigin at nlive 63 -- until a comparison
@@ -383,25 +386,32 @@ def _random_cases(n, seed=2024, dhi=13):
 # PC_FUZZ="seed:n" adds n more configurations from another seed (a one-off wider sweep on the GPU box)
 _FUZZ = [int(x) for x in os.environ.get("PC_FUZZ", "0:0").split(":")]
 _FUZZ_WIDE = [int(x) for x in os.environ.get("PC_FUZZ_WIDE", "0:0").split(":")]     # the same with nDims 13 ... 47
+_FUZZ_SEQ = [int(x) for x in os.environ.get("PC_FUZZ_SEQ", "0:0").split(":")]       # the same in sequential-stream mode
 
 
-@pytest.mark.parametrize("case", _random_cases(24) + _random_cases(24, seed=77) + _random_cases(16, seed=5, dhi=48) + _random_cases(_FUZZ[1], seed=_FUZZ[0]) + _random_cases(_FUZZ_WIDE[1], seed=_FUZZ_WIDE[0], dhi=48), ids=lambda c: f"rnd{c[0]}-{c[1]}-D{c[2]}-N{c[4]}-nr{c[5]}-B{c[6]}-g{c[7]}c{c[8]}")
+@pytest.mark.parametrize("case", _random_cases(24) + _random_cases(24, seed=77) + _random_cases(16, seed=5, dhi=48) + _random_cases(_FUZZ[1], seed=_FUZZ[0]) + _random_cases(_FUZZ_WIDE[1], seed=_FUZZ_WIDE[0], dhi=48) + _random_cases(8, seed=11, seq=True)
+                         + _random_cases(_FUZZ_SEQ[1], seed=_FUZZ_SEQ[0], seq=True), ids=lambda c: f"rnd{c[0]}-{c[1]}-D{c[2]}-N{c[4]}-nr{c[5]}-B{c[6]}-g{c[7]}c{c[8]}")
 def test_random_configurations_match_oracle(engine, case):
-    """48 + 16 (nDims 13 ... 47) seeded random configurations (likelihood, nDims, derived parameters, nlive, num_repeats, chains per nursery,
+    """48 + 16 (nDims 13 ... 47) + 8 (sequential-stream mode) seeded random configurations (likelihood, nDims, derived parameters, nlive, num_repeats, chains per nursery,
     contraction kernel, clustering, parameter grades, termination knobs, nprior): same trajectory as the oracle.
     A wider one-off sweep (PC_FUZZ=31337:300 and 4242:400 on the GPU box): 698 of 700 further configurations identical;
     the two that part ways are 6-D Rastrigin runs with clustering whose clusters hold fewer points than dimensions -- a
     Cholesky pivot of -1.7e-21 in the oracle (PC_ORACLE_TRACE_CHOL=1), a tiny positive one in the engine: the
     scaled-identity fallback of utils.F90:633-638 is decided by round-off there, in the reference as well.
     PC_FUZZ_WIDE=99:120 and 7:200: 320 of 320 configurations with nDims 13 ... 47 identical over their first eight
-    generations of live points (see _random_cases for why not longer)."""
+    generations of live points (see _random_cases for why not longer).  PC_FUZZ_SEQ=321:150: 150 of 150 in
+    sequential-stream mode (the reference's draw order and list rule -- the mode in which the reference binary itself
+    pins both sides)."""
     k, kind, D, nDer, nlive, nr, B, general, clustering, grades, extra = case
     api = engine
     lo, hi = BOX[kind]
     kw = dict(nlive=nlive, num_repeats=nr if grades is None else sum(grades[1]), seed=300 + k, batch=B, do_clustering=clustering)
     kw.update(extra)
     s = _settings(api, D, nDer, force_general=general, **kw)
-    so = orc.settings(D, nDer, **kw)
+    kwo = dict(kw)
+    if kw.get("sequential_rng"):   # one gaussian deviate goes to time_speeds unless the repeats per grade are given (generate.F90:285-287)
+        kwo["time_speeds_draw"] = 1 if grades is None else 0
+    so = orc.settings(D, nDer, **kwo)
     keep = (api.set_grades(s, *grades), orc.set_grades(so, *grades)) if grades else None
     L, P, k1 = api.make_problem(kind, D, nDer, lo, hi)
     Lo, Po, k2 = orc.make_problem(kind, D, lo, hi)
