@@ -88,8 +88,19 @@ int polychord_hip_resume_copy(const char *in, const char *out, int *counts);
 int polychord_hip_ini_prior(const char *inifile, const double *cube, double *theta, int n);
 /* inverse normal CDF, AS241 PPND16 (utils.F90:806-966) */
 double polychord_hip_inv_normal_cdf(double p);
-/* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal) */
+/* engine options by name: "batch" (chains per nursery), "device" (HIP device ordinal), "halt_returns" (1: a fatal
+ * condition inside polychord_c_interface -- which the reference answers with a message and `stop 1`, abort.F90:19-29,
+ * and so does this library by default -- returns to the caller instead, with the message kept for
+ * polychord_hip_last_error(): what a language binding needs to raise an exception rather than lose its interpreter),
+ * "inject_fault" (tests: the next run fails once -- 1: a device allocation, 2: cluster capacity at the next split,
+ * 3: growth of the phantom array) */
 void polychord_hip_set_option(const char *name, double value);
+/* message of the fatal condition that ended the last polychord_c_interface call in "halt_returns" mode, else NULL */
+const char *polychord_hip_last_error(void);
+void pchip_inject_fault(int kind);
+/* initial capacities of the per-cluster arrays (default 128) and of the phantom array (rows; 0 = estimate); both grow on
+   demand like the reference's reallocating arrays (run_time_info.f90:392-418), options "cluster_capacity" / "phantom_capacity" */
+void pchip_set_capacity(int clusters, int phantom_rows);
 
 typedef struct {
     int nDims, nDerived;
@@ -155,6 +166,9 @@ typedef struct {
     double *post_mean, *post_var;  /* [nDims + nDerived] weighted posterior moments of theta, phi */
     long nlike_grade[8];           /* likelihood evaluations per grade (RTI%nlike; the prior samples count for grade 1) */
     int *live_cluster;             /* [nlive_final] 0-based cluster of each row of `live` */
+    long nlike_failed;             /* of nlike: evaluations spent on chains whose spawn failed (their last point fell below the
+                                      contour that had risen since the nursery was seeded; batch = 1 has almost none) */
+    int ncluster_peak;             /* largest number of clusters alive at the same time */
 } pchip_result;
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
@@ -196,7 +210,9 @@ typedef struct {
 
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
 int  pchip_device_count(void);
-/* full run with a device likelihood + uniform prior; returns 0 on success */
+/* full run; returns 0 on success, else (message on stderr, nothing to free, the process goes on): 1 settings, 2 HIP /
+   device error, 3 nDims unsupported, 4 a working set beyond the LDS, 5 stopped on request, 6 resume file, 7 out of
+   memory, 8 a capacity limit */
 int  pchip_run(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, pchip_result *out);
 int  pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
                      const pchip_hooks *hooks, pchip_result *out);

@@ -87,8 +87,46 @@ def file_cases(inj):
     json.dump(meta, open(os.path.join(GOLD, "ref_files.json"), "w"), indent=1)
 
 
+def seed_runs(name, like, D, nDer, nlive, nr, seeds, comment, workdir=None, reuse=False):
+    """N runs of the untouched reference binary (own RNG) of one BASELINE configuration -> tests/golden/<name>.json:
+    logZ, logZerr, ndead, nlike and the number of clusters that died (local evidences listed in .stats), per seed.
+    The runs are independent: 6 at a time on the cores of this container (a 10-D Rastrigin run takes 140-270 s)."""
+    import concurrent.futures as cf
+    nat = os.path.join(HERE, "_ref", "ref_driver")
+    work = workdir or (TMP + "/" + name)
+    os.makedirs(work, exist_ok=True)
+
+    def one(seed):
+        d = f"{work}/d{seed}"
+        stats = f"{d}/r{seed}.stats"
+        if not (reuse and os.path.exists(stats) and os.path.getsize(f"{work}/out{seed}.json") > 0):
+            out = subprocess.run(["bash", "-c", f"ulimit -s unlimited; {nat} {like} {D} {nDer} {nlive} {nr} {seed} 1 {d} r{seed} 0"],
+                                 capture_output=True, text=True, cwd=work)
+            open(f"{work}/out{seed}.json", "w").write(out.stdout)
+        line = [l for l in open(f"{work}/out{seed}.json").read().splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        ncd = sum(1 for l in open(stats) if l.startswith("log(Z_"))
+        return dict(seed=seed, logZ=j["logZ"], logZerr=j["logZerr"], ndead=j["ndead"], nlike=j["nlike"], ncluster_dead=ncd)
+
+    with cf.ThreadPoolExecutor(6) as ex:
+        runs = list(ex.map(one, seeds))
+    json.dump({"_comment": comment, "config": dict(like=like, nDims=D, nDerived=nDer, nlive=nlive, num_repeats=nr, clustering=1),
+               "runs": runs}, open(os.path.join(GOLD, name + ".json"), "w"), indent=0)
+    for r in runs:
+        print(name, r)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "c3seeds":      # BASELINE configs[2]; `c3seeds <dir> reuse` collects finished runs
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        seed_runs("ref_c3_seeds", "rastrigin", 10, 0, 1000, 30, list(range(1, 13)),
+                  "BASELINE configs[2] (10-D Rastrigin, U(-5.12,5.12)^10, nlive 1000, num_repeats 30 = 3 nDims, kNN clustering) run by the "
+                  "REFERENCE BINARY with its own RNG, seeds 1..12: oracle/_ref/ref_driver rastrigin 10 0 1000 30 $s 1 <dir> r$s "
+                  "(oracle/Makefile builds the driver from /root/reference with amdflang; python oracle/gen_golden.py c3seeds); "
+                  "analytic logZ = -23.263; ncluster_dead = local evidences listed in <root>.stats",
+                  workdir=sys.argv[2] if len(sys.argv) > 2 else None, reuse=len(sys.argv) > 3)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "files":
         os.makedirs(TMP + "/chains/clusters", exist_ok=True)
         subprocess.check_call(["make", "-C", HERE, "ref"])

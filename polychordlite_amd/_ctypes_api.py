@@ -55,7 +55,8 @@ class Result(C.Structure):
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
-                ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int))]
+                ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int)),
+                ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int)]
 
 
 _lib = None
@@ -175,5 +176,6 @@ def run(settings, like, prior):
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
-               nlike_grade=[int(v) for v in r.nlike_grade])
+               nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak,
+               varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy())
     return out

@@ -28,13 +28,18 @@ struct Builtins {
     int cg_D = 0; std::vector<double> cg_invcov, cg_mean; double cg_logdet = 0.0;
     int up_D = 0; std::vector<double> up_lo, up_hi;
     int batch = 0, device = -1;
+    bool halt_returns = false;                        // fatal conditions return to the caller instead of `stop 1` (language bindings)
+    std::string last_error;
 } G;
 
 const double LOG_TWO_PI = 1.8378770664093453;
 
+struct HaltRequest { std::string msg; };
 [[noreturn]] void halt_program(const char *msg)
-{   // abort.F90:19-29
+{   // abort.F90:19-29: message + `stop 1`.  A language binding that must survive (polychord_hip_set_option
+    // "halt_returns") gets the message through polychord_hip_last_error() and the entry point returns instead.
     std::fprintf(stderr, "%s\n", msg);
+    if (G.halt_returns) throw HaltRequest{msg};
     std::exit(1);
 }
 
@@ -379,6 +384,10 @@ void polychord_hip_set_option(const char *name, double value)
 {
     if (!std::strcmp(name, "batch")) G.batch = (int)value;
     else if (!std::strcmp(name, "device")) G.device = (int)value;
+    else if (!std::strcmp(name, "inject_fault")) pchip_inject_fault((int)value);
+    else if (!std::strcmp(name, "cluster_capacity")) pchip_set_capacity((int)value, -1);
+    else if (!std::strcmp(name, "phantom_capacity")) pchip_set_capacity(-1, (int)value);
+    else if (!std::strcmp(name, "halt_returns")) G.halt_returns = value != 0.0;
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }
 
@@ -437,7 +446,39 @@ static std::vector<double> time_speeds_host(polychord_loglike_fn like, polychord
     return speed;
 }
 
+static void c_interface_impl(
+    polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
+    int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
+    double precision_criterion, double logzero, int max_ndead, double boost_posterior,
+    bool posteriors, bool equals, bool cluster_posteriors, bool write_resume, bool write_paramnames,
+    bool read_resume, bool write_stats_f, bool write_live, bool write_dead, bool write_prior,
+    bool maximise, double compression_factor, bool synchronous, int nDims, int nDerived,
+    char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
+    double *loglikes, int *nlives, int seed, int *comm);
+
+const char *polychord_hip_last_error(void) { return G.last_error.empty() ? nullptr : G.last_error.c_str(); }
+
 void polychord_c_interface(
+    polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
+    int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
+    double precision_criterion, double logzero, int max_ndead, double boost_posterior,
+    bool posteriors, bool equals, bool cluster_posteriors, bool write_resume, bool write_paramnames,
+    bool read_resume, bool write_stats_f, bool write_live, bool write_dead, bool write_prior,
+    bool maximise, double compression_factor, bool synchronous, int nDims, int nDerived,
+    char *base_dir, char *file_root, int nGrade, double *grade_frac, int *grade_dims, int n_nlives,
+    double *loglikes, int *nlives, int seed, int *comm)
+{
+    G.last_error.clear();
+    try {
+        c_interface_impl(loglikelihood, prior, dumper, nlive, num_repeats, nprior, nfail, do_clustering, feedback,
+                         precision_criterion, logzero, max_ndead, boost_posterior, posteriors, equals, cluster_posteriors,
+                         write_resume, write_paramnames, read_resume, write_stats_f, write_live, write_dead, write_prior,
+                         maximise, compression_factor, synchronous, nDims, nDerived, base_dir, file_root, nGrade, grade_frac,
+                         grade_dims, n_nlives, loglikes, nlives, seed, comm);
+    } catch (const HaltRequest &h) { G.last_error = h.msg; }      // only in "halt_returns" mode: halt_program exits otherwise
+}
+
+static void c_interface_impl(
     polychord_loglike_fn loglikelihood, polychord_prior_fn prior, polychord_dumper_fn dumper,
     int nlive, int num_repeats, int nprior, int nfail, bool do_clustering, int feedback,
     double precision_criterion, double logzero, int max_ndead, double boost_posterior,
@@ -535,7 +576,7 @@ void polychord_c_interface(
     }
     const int rc = pchip_run_hooks(&s, &L, &P, &hooks, &r);
     if (rc == 5) { pchip_result_free(&r); return; }           // stopped by a binding (callback raised)
-    if (rc != 0) halt_program("polychord_hip: engine failure");
+    if (rc != 0) { pchip_result_free(&r); halt_program(("polychord_hip: engine failure (code " + std::to_string(rc) + ", message above)").c_str()); }
     if (maximise && r.nlive_final > 0) {
         // nested_sampling.F90:379: polish the best live points of the set at termination (host side, pc_maximise.hip)
         const std::string mpath = base + "/" + root + ".maximum";

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // replicated scalars (every thread runs the same scalar code on the same inputs)
     int i_nursery = ctl->i_nursery, epoch = ctl->admin_epoch, failures = ctl->failures, ndead = ctl->ndead,
         nph = ctl->nphantom, nc_dead = ctl->ncluster_dead;
-    long long nlike = ctl->nlike, niter = ctl->niter;
+    long long nlike = ctl->nlike, niter = ctl->niter, nlike_failed = ctl->nlike_failed;
     double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
     unsigned next_uid = ctl->next_cluster_uid;
     int status = PC_ST_RUNNING, error = PC_ERR_NONE, cluster_deleted = 0;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         niter++;
         if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_count = 0; S.plan[w].contour = S.logzero; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
         __syncthreads();
-        if (w_epoch != epoch) continue;                 // nested_sampling.F90:313 epoch guard
+        if (w_epoch != epoch) { nlike_failed += w_nlike; continue; }   // nested_sampling.F90:313 epoch guard
 
         // ---- replace_point (run_time_info.f90:716-787)
         const double Lg = lowest_contour().v;
@@ -713,6 +713,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             ndead++;
         }
         failures = replaced ? 0 : failures + 1;
+        if (!replaced) nlike_failed += w_nlike;
         const long long q3 = clock64(); cyK += q3 - q2;
 
         // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->admin_epoch = epoch;
         ctl->failures = failures; ctl->ncluster = nc; ctl->ncluster_dead = nc_dead; ctl->ndead = ndead;
         ctl->nphantom = nph; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = cluster_deleted;
-        ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter;
+        ctl->next_cluster_uid = next_uid; ctl->nlike = nlike; ctl->niter = niter; ctl->nlike_failed = nlike_failed;
         if (ll_s > 0.0) { const double v = ll_m + log(ll_s); live_logZ_val = (v > S.logzero + 800.0) ? v : pc_logaddexp(S.logzero, v); }
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
         ctl->gen_cyc[0] += cyT; ctl->gen_cyc[1] += cyI; ctl->gen_cyc[2] += cyK; ctl->gen_cyc[3] += cyE; ctl->nn_walks += cyW; ctl->nn_fallbacks += cyF;

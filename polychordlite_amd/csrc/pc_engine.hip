@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdarg>
 #include <cmath>
 #include <vector>
 #include <string>
@@ -55,9 +56,25 @@ void pc_launch_post_moments(const PcState *, int, double *, double *, hipStream_
 int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
 }
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
-    std::fprintf(stderr, "polychord_hip: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
-    std::abort(); } } while (0)
+// Fatal conditions unwind to the C ABI entry points (pchip_run_hooks, pchip_slice_chains), which release the run's
+// resources, print the message and return the code: the reference's convention is message + `stop 1`
+// (abort.F90:19-29), and the process-level half of it belongs to the caller of the C ABI (polychord_c_interface exits;
+// a language binding raises) -- an engine inside somebody's interpreter must not take the process down itself.
+enum { PC_RC_SETTINGS = 1, PC_RC_DEVICE = 2, PC_RC_NDIMS = 3, PC_RC_LDS = 4, PC_RC_STOPPED = 5, PC_RC_RESUME = 6, PC_RC_MEMORY = 7, PC_RC_LIMIT = 8 };
+struct EngineError {
+    int code; std::string msg;
+};
+[[noreturn]] static void engine_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+[[noreturn]] static void engine_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); std::vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    throw EngineError{code, buf};
+}
+static std::atomic<int> g_cap_clusters{128}, g_cap_phantoms{0};   // initial capacities (both grow on demand); tests shrink them
+static std::atomic<int> g_inject_fault{0};           // polychord_hip_set_option("inject_fault", k): tests of the error paths, one-shot
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    engine_fail(PC_RC_DEVICE, "HIP error %s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 static volatile int g_stop_requested = 0;
 static polychord_batch_fn g_batch_fn = nullptr;     // polychord_hip_set_batch_callback
@@ -88,6 +105,7 @@ struct BlockCache {
         int dev = 0;
         if (!host) (void)hipGetDevice(&dev);
         const size_t sz = round_up(bytes ? bytes : 1);
+        if (!host && sz >= (256u << 10) && g_inject_fault.load() == 1) { g_inject_fault = 0; engine_fail(PC_RC_MEMORY, "out of device memory (%zu bytes): injected", sz); }
         {
             std::lock_guard<std::mutex> g(m);
             auto it = free_.find({dev, sz});
@@ -99,7 +117,7 @@ struct BlockCache {
             trim();
             e = host ? hipHostMalloc(&p, sz) : hipMalloc(&p, sz);
         }
-        if (e != hipSuccess) { std::fprintf(stderr, "polychord_hip: out of %s memory (%zu bytes): %s\n", host ? "pinned host" : "device", sz, hipGetErrorString(e)); std::abort(); }
+        if (e != hipSuccess) { (void)hipGetLastError(); engine_fail(PC_RC_MEMORY, "out of %s memory (%zu bytes): %s", host ? "pinned host" : "device", sz, hipGetErrorString(e)); }
         std::lock_guard<std::mutex> g(m);
         owner[p] = {dev, sz};
         return p;
@@ -253,7 +271,7 @@ struct Engine {
     // clustering scratch (allocated on first use)
     double *c_Sm = nullptr; int *c_pts = nullptr, *c_gidx = nullptr, *c_knn = nullptr, *c_lab = nullptr, *c_out = nullptr, *c_cnt = nullptr;
     unsigned *c_olduid = nullptr; int c_cap = 0;
-    long nsplits = 0;
+    long nsplits = 0; int ncluster_peak = 1;
     Timing tm;
     KTimer kt;
     int B = 0;
@@ -273,8 +291,7 @@ struct Engine {
         cfg = c;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-            std::fprintf(stderr, "polychord_hip: no HIP device available -- this engine has no CPU path\n");
-            std::abort();
+            engine_fail(PC_RC_DEVICE, "no HIP device available -- this engine has no CPU path");
         }
         HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
         st = hpool().get_stream(); st_copy = hpool().get_stream();
@@ -286,14 +303,14 @@ struct Engine {
         S.ngrade = 1; S.g_off[0] = 0; S.g_nr[0] = c.num_repeats;
         for (int g = 1; g < PC_MAX_GRADE; ++g) { S.g_off[g] = 0; S.g_nr[g] = 0; }
         if (c.nGrade > 1 && c.grade_dims && c.grade_repeats) {
-            if (c.nGrade > PC_MAX_GRADE) { std::fprintf(stderr, "polychord_hip: at most %d parameter grades\n", PC_MAX_GRADE); std::abort(); }
+            if (c.nGrade > PC_MAX_GRADE) engine_fail(PC_RC_SETTINGS, "at most %d parameter grades", PC_MAX_GRADE);
             S.ngrade = c.nGrade;
             int off = 0, tot = 0;
             for (int g = 0; g < c.nGrade; ++g) {
-                if (c.grade_dims[g] < 1 || c.grade_repeats[g] < 1) { std::fprintf(stderr, "polychord_hip: every grade needs at least one parameter and one repeat\n"); std::abort(); }
+                if (c.grade_dims[g] < 1 || c.grade_repeats[g] < 1) engine_fail(PC_RC_SETTINGS, "every grade needs at least one parameter and one repeat");
                 S.g_off[g] = off; off += c.grade_dims[g]; S.g_nr[g] = c.grade_repeats[g]; tot += c.grade_repeats[g];
             }
-            if (off != D) { std::fprintf(stderr, "polychord_hip: grade_dims must sum to nDims\n"); std::abort(); }
+            if (off != D) engine_fail(PC_RC_SETTINGS, "grade_dims must sum to nDims");
             S.nr = tot; cfg.num_repeats = tot;
         }
         S.nb_total = 0; S.n_dev = 0;
@@ -319,9 +336,10 @@ struct Engine {
         cb_auto_batch = c.batch <= 0 && !c.sequential_rng && (like.kind == PC_LIKE_CALLBACK || prior.kind != 1);
         if (cb_auto_batch) B_small = std::max(1, std::min(64, c.nlive / 4));
         S.B = B;
-        S.maxc = c.do_clustering ? 128 : 4;
+        S.maxc = c.do_clustering ? std::max(2, g_cap_clusters.load()) : 4;
         S.maxc_dead = 4096;
         S.Pcap = (int)std::min<long long>(2000000000LL / S.nT, 4LL * S.nr * S.Ncap + 4LL * B * S.nr + 1024);
+        if (g_cap_phantoms.load() > 0) S.Pcap = std::max(g_cap_phantoms.load(), B * S.nr + 16);
         S.Dcap = 64 * S.Ncap + 4 * B + 1024;
         S.k0 = (uint32_t)c.seed; S.k1 = 0x504F4C59u;
         S.logzero = c.logzero; S.use_prec = c.precision_criterion > 0;
@@ -355,7 +373,7 @@ struct Engine {
         callback_mode = (like.kind == PC_LIKE_CALLBACK) || (prior.kind != 1);
         if (callback_mode) {
             cb_like = like.fn; cb_prior = prior.fn;
-            if (!cb_like) { std::fprintf(stderr, "polychord_hip: callback mode needs a loglikelihood function pointer\n"); std::abort(); }
+            if (!cb_like) engine_fail(PC_RC_SETTINGS, "callback mode needs a loglikelihood function pointer");
         }
         S.prior.kind = prior.kind; S.prior.lo = nullptr; S.prior.hi = nullptr;
         if (prior.kind == 1 && prior.lo && prior.hi) {
@@ -463,14 +481,92 @@ struct Engine {
         S.Dcap = nd;
     }
 
+    // The reference reallocates its phantom arrays whenever they fill up (run_time_info.f90:747-757 via
+    // array_utils reallocate); phantoms are only cleaned at updates, i.e. every -nlive log(compression_factor) deaths,
+    // so a small compression_factor needs far more than the initial estimate.
+    void grow_phantoms(long long need)
+    {
+        const long long hard = 1LL << 30;             // rows; Pcap and the phantom counters are ints
+        if (need > hard) engine_fail(PC_RC_LIMIT, "more than %lld phantom points (%lld needed)", hard, need);
+        long long np = std::max<long long>(need, 2LL * S.Pcap);
+        np = std::min(np, hard);
+        if (g_inject_fault.load() == 3) { g_inject_fault = 0; engine_fail(PC_RC_MEMORY, "out of device memory growing the phantom array to %lld rows (injected)", np); }
+        const size_t used = (size_t)std::min<long long>(h_ctl->nphantom, S.Pcap);
+        HIPCHK(hipStreamSynchronize(st));
+        auto grow = [&](auto *&p, size_t per) {
+            using T = std::remove_reference_t<decltype(*p)>;
+            T *q = dalloc<T>((size_t)np * per);
+            if (used) HIPCHK(hipMemcpyAsync(q, p, sizeof(T) * used * per, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            dfree(p); p = q;
+        };
+        grow(S.phantom, S.nT); grow(S.ph_logL, 1); grow(S.ph_cuid, 1); grow(S.ph_uid, 1);
+        dfree(ph2); dfree(phL2); dfree(phC2); dfree(phU2); dfree(keep); dfree(blk);
+        alloc_phantom_side((int)np);
+        S.Pcap = (int)np;
+    }
+
     void ensure_capacity()
     {   // the next batch may append B*nr phantoms and B dead points
         if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) grow_dead(S.Dcap * 2);
         if (nph_stale && (long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) read_ctl();   // pre-clean count: refresh
-        if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) {
-            std::fprintf(stderr, "polychord_hip: phantom capacity exceeded (%d + %d*%d > %d)\n", h_ctl->nphantom, B, S.nr, S.Pcap);
-            std::abort();
+        if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) grow_phantoms((long long)h_ctl->nphantom + (long long)B * S.nr);
+        // dead clusters: a segment can retire at most the clusters that are active when it starts
+        if (h_ctl->ncluster_dead + h_ctl->ncluster + 8 > S.maxc_dead) grow_dead_clusters(2 * S.maxc_dead);
+    }
+
+    void grow_dead_clusters(int nd)
+    {
+        HIPCHK(hipStreamSynchronize(st));
+        const size_t used = (size_t)std::min(h_ctl->ncluster_dead, S.maxc_dead);
+        auto grow = [&](auto *&p) {
+            using T = std::remove_reference_t<decltype(*p)>;
+            T *q = dalloc<T>((size_t)nd);
+            if (used) HIPCHK(hipMemcpy(q, p, sizeof(T) * used, hipMemcpyDeviceToDevice));
+            dfree(p); p = q;
+        };
+        grow(S.logZp_dead); grow(S.logZp2_dead); grow(S.cl_uid_dead);
+        S.maxc_dead = nd;
+    }
+
+    // The reference has no limit on the number of clusters (add_cluster reallocates every per-cluster array,
+    // run_time_info.f90:392-418).  Here the per-cluster arrays are flat with a capacity: grow them the same way.
+    void grow_clusters(int need)
+    {
+        const int mo = S.maxc, mn = std::max(need, 2 * mo), Ncap = S.Ncap, DD = S.D * S.D;
+        if (mn > 16384) engine_fail(PC_RC_LIMIT, "more than 16384 clusters");
+        HIPCHK(hipStreamSynchronize(st));
+        auto grow_d = [&](double *&p, double fill) {
+            std::vector<double> v = dl(p, (size_t)mo); v.resize(mn, fill);
+            dfree(p); p = dalloc<double>(mn); ul(p, v);
+        };
+        grow_d(S.logZp, cfg.logzero); grow_d(S.logZXp, cfg.logzero); grow_d(S.logZp2, cfg.logzero); grow_d(S.logZpXp, cfg.logzero);
+        grow_d(S.logLp, cfg.logzero); grow_d(S.logXp, 0.0); grow_d(S.lse_ref, 0.0); grow_d(S.lse_sum, 0.0); grow_d(S.death_thr, -PC_HUGE);
+        { std::vector<int> v = dl(S.cl_n, (size_t)mo); v.resize(mn, 0); dfree(S.cl_n); S.cl_n = dalloc<int>(mn); ul(S.cl_n, v); }
+        { std::vector<int> v = dl(S.imin_slot, (size_t)mo); v.resize(mn, 0); dfree(S.imin_slot); S.imin_slot = dalloc<int>(mn); ul(S.imin_slot, v); }
+        { std::vector<unsigned> v = dl(S.cl_uid, (size_t)mo); v.resize(mn, 0u); dfree(S.cl_uid); S.cl_uid = dalloc<unsigned>(mn); ul(S.cl_uid, v); }
+        {   // the cross-volume matrix changes its leading dimension
+            std::vector<double> o = dl(S.XpXq, (size_t)mo * mo), v((size_t)mn * mn, 0.0);
+            for (int a = 0; a < mo; ++a) std::copy(o.begin() + (size_t)a * mo, o.begin() + (size_t)(a + 1) * mo, v.begin() + (size_t)a * mn);
+            dfree(S.XpXq); S.XpXq = dalloc<double>((size_t)mn * mn); ul(S.XpXq, v);
         }
+        {
+            int *q = dalloc<int>((size_t)mn * Ncap);
+            HIPCHK(hipMemcpy(q, S.cl_list, sizeof(int) * (size_t)mo * Ncap, hipMemcpyDeviceToDevice));
+            dfree(S.cl_list); S.cl_list = q;
+        }
+        auto grow_mat = [&](double *&p) {
+            double *q = dalloc<double>((size_t)mn * DD);
+            HIPCHK(hipMemcpy(q, p, sizeof(double) * (size_t)mo * DD, hipMemcpyDeviceToDevice));
+            std::vector<double> id((size_t)(mn - mo) * DD, 0.0);
+            for (int c = 0; c < mn - mo; ++c) for (int a = 0; a < S.D; ++a) id[(size_t)c * DD + (size_t)a * S.D + a] = 1.0;
+            HIPCHK(hipMemcpy(q + (size_t)mo * DD, id.data(), sizeof(double) * id.size(), hipMemcpyHostToDevice));
+            dfree(p); p = q;
+        };
+        grow_mat(S.chol); grow_mat(S.cov);
+        if (c_cnt) { dfree(c_cnt); dfree(c_olduid); c_cnt = dalloc<int>(mn); c_olduid = dalloc<unsigned>(mn); }
+        dfree(psum); dfree(pcnt); dfree(pcov); dfree(mean); dfree(count); cov_chunks_cap = 0;   // sized with maxc: covmats() reallocates
+        S.maxc = mn;
     }
 
     // dump (nested_sampling.F90:546-590): live and dead points as [theta, phi, birth, logL] rows,
@@ -642,7 +738,7 @@ struct Engine {
         labels.assign(m, 1);
         if (m <= 1) return 1;
         HIPCHK(hipMemcpyAsync(c_gidx, gidx.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
-        if (pc_launch_knn_cluster(c_Sm, nroot, c_gidx, m, c_knn, c_lab, c_out, st)) { std::fprintf(stderr, "polychord_hip: cluster too large for the LDS kNN sort\n"); std::abort(); }
+        if (pc_launch_knn_cluster(c_Sm, nroot, c_gidx, m, c_knn, c_lab, c_out, st)) engine_fail(PC_RC_LDS, "cluster of %d points too large for the LDS kNN sort", m);
         int num = 0;
         HIPCHK(hipMemcpyAsync(labels.data(), c_lab, sizeof(int) * m, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&num, c_out, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -682,8 +778,10 @@ struct Engine {
     // add_cluster (run_time_info.f90:303-505): cluster p splits into nnew clusters appended at the end
     void add_cluster(int p, const std::vector<int> &labels, int nnew)
     {
-        const int nc = h_ctl->ncluster, nold = nc - 1, ncn = nc + nnew - 1, maxc = S.maxc, Ncap = S.Ncap;
-        if (ncn > maxc) { std::fprintf(stderr, "polychord_hip: more than %d clusters\n", maxc); std::abort(); }
+        const int nc = h_ctl->ncluster, nold = nc - 1, ncn = nc + nnew - 1, Ncap = S.Ncap;
+        if (g_inject_fault.load() == 2) { g_inject_fault = 0; engine_fail(PC_RC_LIMIT, "more than %d clusters (injected)", nc); }
+        if (ncn > S.maxc) grow_clusters(ncn);
+        const int maxc = S.maxc;
         nsplits++;
         auto lc = dl(S.live_cluster, Ncap); auto lp = dl(S.live_pos, Ncap);
         // position of every split point inside its new cluster = rank among equal labels in list order
@@ -746,6 +844,7 @@ struct Engine {
                                                                      : logXp2 + logni[a] + logni[b] - logn - logn1;
         ul(S.logXp, Xp); ul(S.logZXp, ZXp); ul(S.logZp, Zp); ul(S.logZp2, Zp2); ul(S.logZpXp, ZpXp); ul(S.XpXq, XQ);
         h_ctl->ncluster = ncn;
+        ncluster_peak = std::max(ncluster_peak, ncn);
     }
 
     // do_clustering (clustering.f90:253-324)
@@ -788,7 +887,7 @@ struct Engine {
             mean = dalloc<double>((size_t)S.maxc * S.D); count = dalloc<int>(S.maxc);
         }
         if (pc_launch_covmats(&S, nph, nc, psum, pcnt, mean, count, pcov, st)) {
-            std::fprintf(stderr, "polychord_hip: covariance tile exceeds LDS (nDims too large)\n"); std::abort();
+            engine_fail(PC_RC_LDS, "covariance tile exceeds LDS (nDims too large)");
         }
     }
 
@@ -845,7 +944,7 @@ struct Engine {
                 have++; nlike++;
             }
             attempt += (uint32_t)m;
-            if (attempt > 1000u * (uint32_t)nprior + 100000u) { std::fprintf(stderr, "polychord_hip: could not generate live points (likelihood is logzero everywhere?)\n"); std::abort(); }
+            if (attempt > 1000u * (uint32_t)nprior + 100000u) engine_fail(PC_RC_SETTINGS, "could not generate live points (likelihood is logzero everywhere?)");
         }
         double *drows = dalloc<double>((size_t)nprior * nT);
         HIPCHK(hipMemcpy(drows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
@@ -908,7 +1007,7 @@ struct Engine {
         long long nlike = 0;
         bool direct = true;
         while (have < nprior) {
-            if (pc_launch_generate_live(&S, attempt0, nprior, rows, rl, st)) { std::fprintf(stderr, "polychord_hip: nDims > 256 unsupported\n"); std::abort(); }
+            if (pc_launch_generate_live(&S, attempt0, nprior, rows, rl, st)) engine_fail(PC_RC_NDIMS, "nDims > 256 unsupported");
             HIPCHK(hipMemcpyAsync(hl.data(), rl, sizeof(double) * nprior, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             int nvalid = 0;
@@ -1018,21 +1117,24 @@ struct Engine {
         PcResume r;
         export_resume(r);
         std::string err;
-        if (!pc_resume_write(cfg.resume_write, r, cfg.logzero, err)) { std::fprintf(stderr, "polychord_hip: %s\n", err.c_str()); std::exit(1); }
+        if (!pc_resume_write(cfg.resume_write, r, cfg.logzero, err)) engine_fail(PC_RC_RESUME, "%s", err.c_str());
     }
 
     // upload a .resume state; the run continues with the counter RNG streams of batch `ndead` onwards
     // (the reference does not store its generator state either: a resumed run is a valid, different trajectory)
     bool import_resume(const PcResume &r, std::string &err)
     {
-        const int D = S.D, nT = S.nT, nc = r.ncluster, maxc = S.maxc, Ncap = S.Ncap;
+        const int D = S.D, nT = S.nT, nc = r.ncluster, Ncap = S.Ncap;
         if (r.nDims != D || r.nDerived != S.nDer) { err = "resume file has different nDims / nDerived"; return false; }
+        if (nc > S.maxc) grow_clusters(nc);
+        if (r.ncluster_dead + nc + 8 > S.maxc_dead) grow_dead_clusters(2 * (r.ncluster_dead + nc + 8));
+        const int maxc = S.maxc;
         int ntot = 0, nph = 0;
         for (int c = 0; c < nc; ++c) { ntot += r.nlive[c]; nph += r.nphantom[c]; }
         // ncluster = 0: the file of a finished run (every live point killed): nothing left to sample, the run
         // returns what the file holds, as the reference does
-        if (nc > maxc || ntot > Ncap || (nc >= 1 && ntot < 1)) { err = "resume file: cluster / live point counts do not fit this run's settings"; return false; }
-        if (nph + (long long)B * S.nr > S.Pcap) { err = "resume file: too many phantom points"; return false; }
+        if (ntot > Ncap || (nc >= 1 && ntot < 1)) { err = "resume file: live point counts do not fit this run's settings"; return false; }
+        if (nph + (long long)B * S.nr > S.Pcap) { h_ctl->nphantom = 0; grow_phantoms(nph + (long long)B * S.nr); }
         if ((long long)r.ndead + B + Ncap + 16 > S.Dcap) { h_ctl->ndead = 0; grow_dead(2 * (r.ndead + B + Ncap + 16)); }
         std::vector<double> rows((size_t)Ncap * nT, 0.0), lL(Ncap, PC_HUGE), entry(Ncap, cfg.logzero);
         std::vector<int> lc(Ncap, -1), lp(Ncap, 0), cl((size_t)maxc * Ncap, 0), cn(maxc, 0), imin(maxc, 0);
@@ -1237,6 +1339,7 @@ struct Engine {
         out->logZ = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2);
         out->varlogZ = h_ctl->logZ2 - 2 * h_ctl->logZ;
         out->ndead = h_ctl->ndead; out->nlike = h_ctl->nlike; out->niter = h_ctl->niter;
+        out->nlike_failed = h_ctl->nlike_failed; out->ncluster_peak = ncluster_peak;
         grade_counts(out->nlike_grade);
         out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
@@ -1293,6 +1396,12 @@ struct Engine {
 
     void destroy()
     {
+        // work may still be in flight on any of the run's streams (early returns, the prefetched bases of a nursery
+        // that was never consumed): the blocks below go back to a process-wide cache and may be handed to another
+        // run's thread at once
+        if (st) (void)hipStreamSynchronize(st);
+        if (st_copy) (void)hipStreamSynchronize(st_copy);
+        if (st_side) (void)hipStreamSynchronize(st_side);
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,
@@ -1324,6 +1433,12 @@ struct Engine {
 extern "C" {
 
 void polychord_hip_request_stop(void) { g_stop_requested = 1; }
+// tests of the error paths: the next run fails once at the chosen point (1: a device allocation, 2: the cluster
+// capacity at the next split, 3: the phantom array at its next growth); 0 disarms
+void pchip_inject_fault(int kind) { g_inject_fault = kind; }
+// initial capacity of the per-cluster arrays (default 128) and of the phantom array in rows (0 = the engine's estimate);
+// both grow on demand, so these only matter to tests of the growth paths
+void pchip_set_capacity(int clusters, int phantom_rows) { if (clusters > 0) g_cap_clusters = clusters; if (phantom_rows >= 0) g_cap_phantoms = phantom_rows; }   // negative: leave as is
 void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { g_batch_fn = fn; g_batch_user = user; }
 
 double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx)
@@ -1358,19 +1473,40 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
     if (like->kind == PC_LIKE_CALLBACK && !like->fn) { std::fprintf(stderr, "polychord_hip: callback likelihood without a function pointer\n"); return 1; }
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    g_stop_requested = 0;
+    if (g_active_runs.load() == 0) g_stop_requested = 0;      // (a stop requested for a run in flight on another thread stays)
+    std::memset(out, 0, sizeof(*out));
     Engine E;
     if (hooks) { E.dumper = hooks->dumper; E.on_update = hooks->on_update; E.hook_user = hooks->user; }
-    E.setup(*s, *like, *prior);
-    auto t1 = clk::now();
-    std::memset(out, 0, sizeof(*out));
-    const int rc = E.run(out);
-    auto t2 = clk::now();
+    int rc;
+    auto t1 = t0, t2 = t0;
+    try {
+        E.setup(*s, *like, *prior);
+        t1 = clk::now();
+        rc = E.run(out);
+        t2 = clk::now();
+    } catch (const EngineError &e) {
+        std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str());
+        (void)hipGetLastError();
+        rc = e.code;
+        pchip_result_free(out);
+        t2 = clk::now();
+    } catch (const std::bad_alloc &) {
+        std::fprintf(stderr, "polychord_hip: out of host memory\n");
+        rc = PC_RC_MEMORY;
+        pchip_result_free(out);
+        t2 = clk::now();
+    } catch (...) {                       // thrown by a host hook (a binding's halt request): pass it on, resources released
+        pchip_result_free(out);
+        E.destroy();
+        throw;
+    }
     E.destroy();
     auto t3 = clk::now();
-    out->t_setup = std::chrono::duration<double>(t1 - t0).count();
-    out->t_teardown = std::chrono::duration<double>(t3 - t2).count();
-    out->t_results = std::chrono::duration<double>(t2 - t1).count() - out->t_total;
+    if (rc == 0) {
+        out->t_setup = std::chrono::duration<double>(t1 - t0).count();
+        out->t_teardown = std::chrono::duration<double>(t3 - t2).count();
+        out->t_results = std::chrono::duration<double>(t2 - t1).count() - out->t_total;
+    }
     return rc;
 }
 
@@ -1390,25 +1526,32 @@ int pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pc
     pchip_settings c = *s;
     c.nlive = nchains; c.nprior = nchains; c.batch = nchains; c.do_clustering = 0;
     Engine E;
-    E.setup(c, *like, *prior);
-    PcState &S = E.S;
-    const int nT = S.nT, D = S.D, nr = S.nr;
-    HIPCHK(hipMemcpy(S.live, seeds, sizeof(double) * (size_t)nchains * nT, hipMemcpyHostToDevice));
-    std::vector<double> ll(nchains); std::vector<int> idn(nchains), zero(nchains, 0);
-    for (int i = 0; i < nchains; ++i) { ll[i] = seeds[(size_t)i * nT + S.l0]; idn[i] = i; }
-    HIPCHK(hipMemcpy(S.live_logL, ll.data(), sizeof(double) * nchains, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.live_cluster, zero.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.live_pos, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.cl_list, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.cl_n, &nchains, sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.logLp, &contour, sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(S.chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice));
-    S.seed_override = 1;
-    int rc = pc_launch_nhats(&S, batch, nchains, E.st) || pc_launch_slice(&S, batch, nchains, E.st);
-    HIPCHK(hipStreamSynchronize(E.st));
-    HIPCHK(hipMemcpy(babies_out, S.babies, sizeof(double) * (size_t)nchains * nr * nT, hipMemcpyDeviceToHost));
-    if (nhats_out) HIPCHK(hipMemcpy(nhats_out, S.nhat, sizeof(double) * (size_t)nchains * nr * D, hipMemcpyDeviceToHost));
-    if (nlike_out) HIPCHK(hipMemcpy(nlike_out, S.ch_nlike, sizeof(int) * nchains, hipMemcpyDeviceToHost));
+    int rc;
+    try {
+        E.setup(c, *like, *prior);
+        PcState &S = E.S;
+        const int nT = S.nT, D = S.D, nr = S.nr;
+        HIPCHK(hipMemcpy(S.live, seeds, sizeof(double) * (size_t)nchains * nT, hipMemcpyHostToDevice));
+        std::vector<double> ll(nchains); std::vector<int> idn(nchains), zero(nchains, 0);
+        for (int i = 0; i < nchains; ++i) { ll[i] = seeds[(size_t)i * nT + S.l0]; idn[i] = i; }
+        HIPCHK(hipMemcpy(S.live_logL, ll.data(), sizeof(double) * nchains, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.live_cluster, zero.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.live_pos, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.cl_list, idn.data(), sizeof(int) * nchains, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.cl_n, &nchains, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.logLp, &contour, sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice));
+        S.seed_override = 1;
+        rc = pc_launch_nhats(&S, batch, nchains, E.st) || pc_launch_slice(&S, batch, nchains, E.st);
+        HIPCHK(hipStreamSynchronize(E.st));
+        HIPCHK(hipMemcpy(babies_out, S.babies, sizeof(double) * (size_t)nchains * nr * nT, hipMemcpyDeviceToHost));
+        if (nhats_out) HIPCHK(hipMemcpy(nhats_out, S.nhat, sizeof(double) * (size_t)nchains * nr * D, hipMemcpyDeviceToHost));
+        if (nlike_out) HIPCHK(hipMemcpy(nlike_out, S.ch_nlike, sizeof(int) * nchains, hipMemcpyDeviceToHost));
+    } catch (const EngineError &e) {
+        std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str());
+        (void)hipGetLastError();
+        rc = e.code;
+    }
     E.destroy();
     return rc;
 }

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
     int i_nursery = nchain, failures = ctl->failures, ndead = ctl->ndead;
     const int epoch = ctl->admin_epoch;
     int nc_dead = ctl->ncluster_dead, nc = ctl->ncluster;
-    long long nlike = ctl->nlike, niter = ctl->niter;
+    long long nlike = ctl->nlike, niter = ctl->niter, nlike_failed = ctl->nlike_failed;
     double logZ = ctl->logZ, logZ2 = ctl->logZ2, lx_last = ctl->logX_last_update;
     double Xp = S.logXp[0], Zp = S.logZp[0], ZXp = S.logZXp[0], Zp2 = S.logZp2[0], ZpXp = S.logZpXp[0], XX = S.XpXq[0];
     double lseRef = S.lse_ref[0], lseSum = S.lse_sum[0], thr = S.death_thr[0];
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         const int ep = __builtin_amdgcn_readfirstlane(cEpoch[w]);
         const unsigned long long LgK = snapK < insK ? snapK : insK;
         if (ep != epoch) {                             // nested_sampling.F90:313: only nlike is counted
+            nlike_failed += __builtin_amdgcn_readfirstlane(cNlike[w]);
             if (lane == 0) { rW[m] = w; rKind[m] = 0; rLgK[m] = LgK; }
             m++;
             if (m == 64) { __builtin_amdgcn_wave_barrier(); flush(); if (fastphase) eval_guard(); }
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
             // failed spawn (run_time_info.f90:781-785): the baby is recorded dead with zero weight
             if (lane == 0) { rW[m] = w; rKind[m] = 1; rLgK[m] = LgK; }
             ndead++; m++;
+            nlike_failed += __builtin_amdgcn_readfirstlane(cNlike[w]);
         }
         const bool upd = replaced && deaths_total == kupd;
         if (m == 64 || mdeaths == G || upd || (!fastphase && replaced)) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64) void k_consume_fast(PcState S, int final_mode)
         ctl->status = status; ctl->error = error; ctl->i_nursery = i_nursery; ctl->failures = failures;
         ctl->ndead = ndead; ctl->seg_hi = seg_hi; ctl->seg_lo = i_nursery; ctl->cluster_deleted = 0;
         ctl->ncluster = nc; ctl->ncluster_dead = nc_dead;
-        ctl->nlike = nlike; ctl->niter = niter; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
+        ctl->nlike = nlike; ctl->niter = niter; ctl->nlike_failed = nlike_failed; ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last;
         ctl->live_logZ = live_logZ_val;
         ctl->dbg[0] += cy1 - cy0; ctl->dbg[1] += cyB; ctl->dbg[2] += cyCommon; ctl->dbg[3] += nCommon; ctl->dbg[4] += nFlush;
         ctl->dbg[5] += cyIns; ctl->dbg[6] += nIns; ctl->dbg[7] += cyRej;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         const u64 vm = __ballot(valid);
         if (lane == 0) { vmask[wv] = vm; accR[wv] = 0ull; amask[wv] = 0ull; }
     }
-    if (tid == 0) { ish[0] = (T << 2) | 3; ish[1] = 0; }
+    if (tid == 0) { ish[0] = (T << 2) | 3; ish[1] = 0; ish[3] = 0; }
     __syncthreads();
 
     // ---- phase 1: snapshot points strictly below / not above the candidate
@@ -487,9 +487,10 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         fin[4] = ls_val(wM, wS); fin[5] = ls_val(wpM, wpS); fin[6] = lsM; fin[7] = L; fin[8] = lsS;
     }
     {
-        int nls = (inT && tid < ts) ? nl : 0;
-        for (int k = 32; k > 0; k >>= 1) nls += __shfl_xor(nls, k);
+        int nls = (inT && tid < ts) ? nl : 0, nlf = (inT && tid < ts && !acc) ? nl : 0;
+        for (int k = 32; k > 0; k >>= 1) { nls += __shfl_xor(nls, k); nlf += __shfl_xor(nlf, k); }
         if (lane == 0 && nls) atomicAdd(&ish[1], nls);
+        if (lane == 0 && nlf) atomicAdd(&ish[3], nlf);
     }
     if (inT && tid < ts) {
         PcPlan *pw = S.plan + w;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ctl->failures = (tl >= 0) ? vps - prefix_bits(vmask, tl) - 1 : fail0 + vps;
         ctl->status = status; ctl->error = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
         ctl->i_nursery = T - ts; ctl->ndead = ndead0 + vps; ctl->seg_hi = T - 1; ctl->seg_lo = T - ts; ctl->cluster_deleted = 0;
-        ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2];
+        ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2]; ctl->nlike_failed += ish[3];
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
         if (S.use_prec) ctl->live_logZ = lse_m + log(lse_s) - l0 + Xp;

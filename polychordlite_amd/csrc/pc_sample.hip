@@ -976,7 +976,7 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
     }
     ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, false, 0.0, 0.0, 0.0, 0.0};
     const bool corr = S.like.kind == PC_LIKE_CORR_GAUSSIAN;
-    C.quad = corr || S.like.kind == PC_LIKE_GAUSSIAN;
+    C.quad = (corr || S.like.kind == PC_LIKE_GAUSSIAN) && !(S.ablate & 1);
     C.qnorm = corr ? -((double)D * PC_LOG_TWO_PI + S.like.logdetcov) / 2.0 : S.like.norm;
     // correlated Gaussian: y = theta - mean and M.y travel with the chain (updated, not recomputed, at every
     // accepted point); the matrix is read from LDS when it fits

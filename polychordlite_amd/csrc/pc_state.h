@@ -30,6 +30,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     long long nlike;             // RTI%nlike(1)
     long long niter;             // consumed nursery entries
     long long nlike_device;      // evaluations executed on the device (incl. dropped nursery)
+    long long nlike_failed;      // of nlike: evaluations of chains whose spawn failed (the price of seeding a whole nursery from one snapshot)
     double logZ, logZ2;          // run_time_info.f90:165-166 (log <Z>, log <Z^2>)
     double logX_last_update;
     double live_logZ;            // last evaluated termination estimate
@@ -123,7 +124,9 @@ struct PcState {
     int *nn_slot_owner;          // [Ncap] -1: occupant of T0 still there; -2: emptied since; w >= 0: last baby of chain w
     int *nn_chain_slot;          // [B] slot the chain's last baby went to since T0, or -1
     int nn_valid;                // set by the host for the launches after T0 of the same nursery
-    int ablate;                  // dev timing hook (bit mask), 0 in production
+    int ablate;                  // developer / bench switches (bit mask), 0 in production: bit 0 = the built-in quadratic-form
+                                 // likelihoods are evaluated like any device functor (one reduction per trial) instead of in closed form
+                                 // along the chord; bit 30 = trace of Cholesky fallbacks
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed

@@ -93,6 +93,8 @@ def run(loglikelihood, prior, dumper, nDims, nDerived, nlive, num_repeats, nprio
     ll = (C.c_double * max(len(keys), 1))(*[float(k) for k in keys])
     nl = (C.c_int * max(len(keys), 1))(*[int(nlives[k]) for k in keys])
     comm = C.c_int(0)
+    lib.polychord_hip_set_option(b"halt_returns", 1.0)       # engine failures come back as exceptions, not as `stop 1`
+    lib.polychord_hip_last_error.restype = C.c_char_p
     f(like_ptr, prior_ptr, C.cast(cbd, C.c_void_p), int(nlive), int(num_repeats), int(nprior), int(nfail), bool(do_clustering),
       int(feedback), float(precision_criterion), float(logzero), int(max_ndead), float(boost_posterior), bool(posteriors),
       bool(equals), bool(cluster_posteriors), bool(write_resume), bool(write_paramnames), bool(read_resume),
@@ -101,4 +103,7 @@ def run(loglikelihood, prior, dumper, nDims, nDerived, nlive, num_repeats, nprio
       len(keys), ll, nl, int(seed), C.byref(comm))
     if errors:
         raise errors[0]
+    msg = lib.polychord_hip_last_error()
+    if msg:
+        raise RuntimeError(msg.decode())
     return None

@@ -199,6 +199,7 @@ PyObject *py_run(PyObject *, PyObject *args)
 
     std::string base = base_dir, root = file_root;
     int comm = 0;
+    polychord_hip_set_option("halt_returns", 1.0);
     // the GIL stays with this thread for the whole run: callbacks are made synchronously from it (_pypolychord.cpp:219)
     polychord_c_interface(dev_like ? (polychord_loglike_fn)dev_like : cb_loglike, dev_prior ? (polychord_prior_fn)dev_prior : cb_prior,
                           cb_dumper, nlive, num_repeats, nprior, nfail, do_clustering != 0, feedback, precision_criterion, logzero,
@@ -213,6 +214,9 @@ PyObject *py_run(PyObject *, PyObject *args)
         b.err_type = b.err_value = b.err_tb = nullptr;
         return nullptr;
     }
+    // a fatal condition of the engine (the reference prints and stops the process, abort.F90:19-29; inside an
+    // interpreter that is an exception)
+    if (const char *msg = polychord_hip_last_error()) { PyErr_SetString(PyExc_RuntimeError, msg); return nullptr; }
     Py_RETURN_NONE;
 }
 

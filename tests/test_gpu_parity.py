@@ -276,8 +276,6 @@ def test_engine_reproduces_the_reference_binary(engine, golden):
     api = engine
     done = 0
     for c in golden["ref_injected"]:
-        if c["nlike"] > 1300000:
-            continue
         lo, hi = BOX[c["like"]]
         kw = dict(nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"], do_clustering=c["clustering"],
                   nprior=c.get("nprior", -1), sequential_rng=1)
@@ -301,7 +299,7 @@ def test_engine_reproduces_the_reference_binary(engine, golden):
             assert g["nlike"] == c["nlike"], (c, g["nlike"])
         assert abs(g["logZ"] - c["logZ"]) < 1e-8 and abs(g["logZerr"] - c["logZerr"]) < 1e-8, (c, g["logZ"], g["logZerr"])
         done += 1
-    assert done >= 8
+    assert done == len(golden["ref_injected"])
 
 
 GRADED = [  # kind D nDer nlive B clustering grade_dims grade_repeats
