@@ -1,21 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- likelihood evaluations / second of the MI355X nested-sampling engine.
 
-Contract (see DESIGN.md "Measurement"):
-  * a STEP is one complete nested-sampling run of BASELINE.json configs[1]: 20-D Gaussian
-    (likelihoods/examples/gaussian.f90, ini/gaussian.ini priors), nlive = 2000, num_repeats = 40,
-    precision_criterion 1e-3, no clustering, fp64 throughout; step i uses seed = 1000 + i (+ rank*100003).
-  * metric  = likelihood evals/sec = sum of the reference's own counter RTI%nlike (calculate.f90:44)
-    over the timed steps / wall time (barrier + device sync on both sides, max over ranks).
-  * N > 1 GPUs: repeat-sharded: every rank runs independent runs with its own seeds; the
-    (logL, birth) records of all dead points are all-gathered over RCCL (torch.distributed "nccl") and
-    merged into one evidence by the replay recursion; scaling is "weak".
-  * roofline: the dominant kernel's algorithmic HBM bytes (258 B / evaluation at this
-    config) over its HIP-event time, against 8 TB/s.  This path is latency bound; the fraction says so.
-  * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by
-    oracle/Makefile) when the prebuilt binary is present, else the C restatement (oracle/liboracle.so),
-    on one host core (the reference is single threaded; its MPI farm does not speed this likelihood up,
-    BASELINE.md), on one full run of the same workload (about 10-25 s).
+Contract (DESIGN.md "Measurement"):
+  * a STEP is one complete nested-sampling run of the workload (default c2 = BASELINE.json configs[1]: 20-D Gaussian of
+    likelihoods/examples/gaussian.f90 with ini/gaussian.ini's priors, nlive = 2000, num_repeats = 40, precision_criterion
+    1e-3, no clustering, fp64 throughout); step i uses seed = 1000 + i (+ rank * 100003).
+  * metric = likelihood evals/sec = sum of the reference's own counter RTI%nlike (calculate.f90:44) over the timed steps
+    / wall time (barrier + device sync on both sides, max over ranks).  The exchange step is inside the timed region.
+  * N > 1 GPUs: repeat-sharded: every rank runs independent runs with its own seeds; the dead points of the
+    last step's runs -- full rows + entry contours -- are all-gathered over RCCL (torch.distributed "nccl", one padded
+    buffer per rank) and merged on every rank by the device merge of the library (evidence + posterior of the union);
+    scaling is "weak".  N = 1 goes through the same merge code.
+  * roofline: the kernel class with the largest HIP-event time (no thumb on the scale); `achieved` = SURVEY 8(d)'s
+    algorithmic bytes per evaluation x evaluations of one launch / its measured launch duration; `kernels` carries the
+    two heaviest classes each with its OWN algorithmic bytes; `whole_run_frac` = nlike x bytes / wall / peak.
+  * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by oracle/Makefile; else the C
+    restatement oracle/liboracle.so) on one host core, one full run of the same workload, and `all_cores`: one
+    independent run per host core at the same time (the reference's MPI farm does not speed this likelihood up,
+    BASELINE.md), aggregate evals/s, core count and CPU model stated.
 """
 import argparse
 import ctypes as C
@@ -31,17 +33,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_EVAL = 258.0
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # BASELINE.json configs through this harness: kind, nDims, nDerived, nlive, num_repeats, clustering, box, analytic logZ
 WORKLOADS = {
     "c2": dict(kind="gaussian", D=20, nDer=2, nlive=2000, nr=40, clustering=0, box=None, truth=0.0,
                name="BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, num_repeats=40"),
-    "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.26,
+    "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.263,
                name="BASELINE configs[2]: 10-D Rastrigin, U(-5.12,5.12)^10, nlive=%d, num_repeats=30 (= 3 nDims, the ini's ratio), kNN clustering"),
-    "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.79,
+    "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.794,
                name="BASELINE configs[3]: 30-D twin Gaussian (sigma=0.1), U(-1,1)^30, nlive=%d, num_repeats=40, kNN clustering"),
-    "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=None,
+    "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=0.0,
                name="BASELINE configs[4]: 100-D correlated Gaussian (random eigenbasis, eigen-sigma 0.1 .. 0.001), U(0,1)^100, nlive=%d, num_repeats=200"),
 }
+METRIC = {"c2": "likelihood evals/sec, 20D Gaussian nlive=%d", "c3": "likelihood evals/sec, 10D Rastrigin nlive=%d",
+          "c4": "likelihood evals/sec, 30D twin Gaussian nlive=%d", "c5": "likelihood evals/sec, 100D correlated Gaussian nlive=%d"}
 
 
 def algorithmic_bytes_per_iteration(D, nDer, nr, N):
@@ -51,35 +56,81 @@ def algorithmic_bytes_per_iteration(D, nDer, nr, N):
     return 8.0 * nT * (1 + nr) + 8.0 * (1 + phi) * D + 8.0 * phi * nT + 8.0 * N
 
 
+def own_bytes_per_launch(kernel, D, nDer, nr, N, B):
+    """a kernel class's OWN algorithmic HBM bytes per launch"""
+    nT = 2 * D + nDer + 2
+    return {"k_slice": B * (8 * nT * (1 + nr) + 8 * nr * (D + 1) + 16 * nr),    # seed row in, nr baby rows out, directions + widths in, logL twice
+            "k_consume": 8 * (2 * N + 3 * B) + 8 * nr * B + 184 * B,               # sorted keys + slots in and out, candidates, the babies' logL (phantom masks), plan records
+            "k_nhats": B * 8 * nr * (D + 1) * 2 + 8 * D * D,                       # raw bases in, whitened directions + widths out, the Cholesky factor
+            "k_apply": B * 8 * nT * (1 + nr) + 8 * nT * B}.get(kernel)
+
+
 def random_correlated_gaussian(D, seed=12345, sigma0=0.1):
     """random_gaussian.f90 / random_utils.F90:581-614: random orthonormal eigenbasis, eigen-sigma_j = sigma0 (1e-2)^(j/(D-1))"""
     rng = np.random.default_rng(seed)
     Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
     sig = sigma0 * (1e-2) ** (np.arange(D) / max(D - 1, 1))
     return Q @ np.diag(sig ** -2) @ Q.T, np.full(D, 0.5), float(2.0 * np.log(sig).sum())
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(nDims, nDer, nr):
-    """reference (preferred) or restatement on ONE host core, bounded sample"""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, nlive, all_cores=True):
+    """the reference (preferred) or the restatement on ONE host core, then one run per core at the same time"""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    sample = "the workload itself: 20-D Gaussian, nlive=2000, num_repeats=40, one full run, seed 7"
-    if os.path.exists(ref):
-        tmp = "/tmp/pc_ref_bench"
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = ncores
+    try:    # the cores this container may actually use (cgroup v2 quota), not the threads the host shows
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncores = max(1, min(ncores, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    ncores = min(ncores, 32)         # bounded sample: at most 32 runs at a time
+    sample = "the workload itself (%s), one full run per measurement, seed 7 (all_cores: seeds 7 .. 7 + cores - 1, one run per core in parallel)" % (wl["name"] % nlive)
+    kind, D, nDer, nr, clus = wl["kind"], wl["D"], wl["nDer"], wl["nr"], wl["clustering"]
+
+    def ref_run(seed, tag):
+        tmp = "/tmp/pc_ref_bench_%s" % tag
         os.makedirs(tmp, exist_ok=True)
-        cmd = f"ulimit -s unlimited; {ref} gaussian {nDims} {nDer} 2000 {nr} 7 0 {tmp} ref 0"
-        out = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, cwd=tmp)
-        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        if line:
-            j = json.loads(line[-1])
-            return {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
-                    "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off",
-                    "logZ": j["logZ"], "logZerr": j["logZerr"], "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"]}
+        cmd = f"ulimit -s unlimited; {ref} {kind} {D} {nDer} {nlive} {nr} {seed} {clus} {tmp} ref 0"
+        return subprocess.Popen(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=tmp)
+
+    def parse(p):
+        out = p.communicate()[0]
+        line = [l for l in out.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else None
+
+    if os.path.exists(ref) and kind != "corr_gaussian":
+        j = parse(ref_run(7, "one"))
+        if j:
+            res = {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
+                   "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off", "cpu_model": cpu_model(),
+                   "logZ": j["logZ"], "logZerr": j["logZerr"], "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"]}
+            if all_cores and ncores > 1:
+                t0 = time.time()
+                js = [parse(p) for p in [ref_run(7 + c, "c%d" % c) for c in range(ncores)]]
+                wall = time.time() - t0
+                js = [x for x in js if x]
+                res["all_cores"] = {"value": sum(x["nlike"] for x in js) / wall, "unit": "likelihood evals/s", "cores": ncores, "runs": len(js),
+                                    "wall_s": wall, "mean_run_wall_s": float(np.mean([x["wall"] for x in js])),
+                                    "hardware_threads_visible": visible,
+                                    "note": "independent runs, one per host core this container may use (cgroup cpu.max quota, at most 32), started together; aggregate nlike / wall of the slowest"}
+            return res
     from tests import oracle_api as orc
-    s = orc.settings(nDims, nDer, nlive=2000, num_repeats=nr, seed=7, batch=1)
-    L, P, keep = orc.make_problem("gaussian", nDims)
+    s = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=7, batch=1, do_clustering=clus)
+    lo, hi = wl["box"] if wl["box"] else (None, None)
+    L, P, keep = orc.make_problem(kind, D, lo, hi)
     t0 = time.time(); o = orc.run(s, L, P); dt = time.time() - t0
-    return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port",
+    return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": sample + "; oracle/liboracle.so (C restatement, gcc -O2)", "logZ": o["logZ"],
             "logZerr": o["logZerr"], "ndead": int(o["ndead"]), "nlike": int(o["nlike"]), "wall_s": dt}
 
@@ -89,15 +140,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nlive", type=int, default=2000)
+    ap.add_argument("--nlive", type=int, default=0, help="0 = the workload's own")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1], the metric configuration (default, what the driver runs); c3 / c4 / c5 = "
-                         "BASELINE configs[2..4] through the same harness (their lines are kept under profiles/)")
-    ap.add_argument("--concurrent", type=int, default=4,
-                    help="after the timed steps: R independent runs driven concurrently from R host threads on this GPU "
-                         "(reported separately, never part of `value`); 0 = skip")
+                         "BASELINE configs[2..4] through the same harness, also with --gpus N (their lines are kept under profiles/)")
+    ap.add_argument("--concurrent", default="4,8,16,32",
+                    help="after the timed steps (N = 1): R independent runs in flight on this GPU for each R of the list "
+                         "(polychordlite_amd.repeats.run_repeats; reported separately, never part of `value`); '' or 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip the figures after the timed region (general functor, concurrent sweep)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,17 +170,16 @@ def main():
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
 
     wl = WORKLOADS[args.workload]
-    if args.workload != "c2" and args.nlive == 2000:
-        args.nlive = wl["nlive"]
+    nlive = args.nlive if args.nlive > 0 else wl["nlive"]
     nDims, nDer, nr = wl["D"], wl["nDer"], wl["nr"]
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
-    s.nlive = args.nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
+    s.nlive = nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
     s.do_clustering = wl["clustering"]
-    # HIP-event stopwatch: the warm-up steps time the two heaviest kernel classes (slice sampling = the likelihood
-    # evaluations, contraction), the timed steps only the one that came out on top -- every timed launch costs two
-    # event records on the run's stream (all six classes: ~4 ms per 25 ms run, two classes: ~2.5 ms)
-    PROFILE_BOTH = (1 << (1 + 1)) | (1 << (2 + 1))
-    s.profile = PROFILE_BOTH
+    # HIP-event stopwatch on the run's own stream.  Warm-up: the four kernel classes a round consists of, every launch
+    # (picks the two heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream
+    # ~6 us, every launch of two classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
+    cls_bit = lambda name: 1 << (api.KERNEL_CLASSES.index(name) + 1)
+    s.profile = cls_bit("k_nhats") | cls_bit("k_slice") | cls_bit("k_consume") | cls_bit("k_apply")
     if wl["kind"] == "corr_gaussian":
         ic, mean, logdet = random_correlated_gaussian(nDims)
         L, P, keep = api.make_problem("corr_gaussian", nDims, nDer, invcov=ic, mean=mean, logdet=logdet)
@@ -146,16 +197,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    top2 = ["k_slice", "k_consume"]
     for i in range(args.warmup):
         w = one(-1 - i)
-        merge_runs(w, dist, torch, local_rank)
+        merge_runs(w, dist, torch, local_rank, nDims, nDer)
         kw = w["kernel_time"]
         if kw:
-            # (k_slice unless another class is clearly ahead: at the metric config the two are within a few per cent
-            #  of each other under the stopwatch, and the kernel trace in profiles/ has k_slice on top)
-            top = max(kw, key=lambda n: kw[n]["total_s"] * (1.2 if n == "k_slice" else 1.0))
-            s.profile = 1 << (api.KERNEL_CLASSES.index(top) + 1)
+            top2 = sorted(kw, key=lambda n: -kw[n]["total_s"])[:2]
         w = None
+    TIMED_STRIDE = 8
+    s.profile = sum(cls_bit(n) for n in top2) | (TIMED_STRIDE << 8)
     sync()
     t0 = time.perf_counter()
     # Every step hands back its dead points in pinned host memory (zero-copy views).  Only the last step's arrays are
@@ -169,83 +220,114 @@ def main():
         last = one(i)
         runs.append({k: v for k, v in last.items() if k not in BIG})
         step_ms.append((time.perf_counter() - ts0) * 1e3)
-    # repeat-sharded merge: all-gather (logL, entry contour) of every dead point of the last step's runs
+    # the exchange step: all-gather of the last step's dead points (rows + entry contours), merged on the device
     tm0 = time.perf_counter()
-    merged = merge_runs(last, dist, torch, local_rank) if args.steps > 0 else None
+    merged = merge_runs(last, dist, torch, local_rank, nDims, nDer) if args.steps > 0 else None
     merge_ms = (time.perf_counter() - tm0) * 1e3
     sync()
     dt = time.perf_counter() - t0
     tmax = dt
     nlike = float(sum(r["nlike"] for r in runs))
+    nfailed = float(sum(r["nlike_failed"] for r in runs))
     if dist is not None:
-        t = torch.tensor([dt, nlike], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt, nlike, nfailed], dtype=torch.float64, device=f"cuda:{local_rank}")
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); tmax = float(tm[0])
-        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1])
-    # one run keeps a small part of the chip busy (B chains = B wavefronts, the contraction one CU): independent
-    # runs on separate streams overlap.  Reported next to the headline, not in it.
+        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1]); nfailed = float(ts[2])
+
+    extras = rank == 0 and world == 1 and not args.no_extras and args.steps > 0
+    general = None
+    if extras and wl["kind"] in ("gaussian", "corr_gaussian") and args.workload != "c5":
+        # the same workload with the closed-form chord evaluation of the built-in quadratic likelihoods switched off: every
+        # trial point pays a wave reduction like any other device functor would (same trajectory up to round-off)
+        s.ablate = 1; s.profile = 0
+        one(-100)
+        tg0 = time.perf_counter()
+        gr = [one(-101 - k) for k in range(3)]
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg0
+        general = {"value": sum(r["nlike"] for r in gr) / tg, "unit": "likelihood evals/s", "ms_per_step": tg / 3 * 1e3,
+                   "logZ": [r["logZ"] for r in gr],
+                   "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
+        gr = None
+        s.ablate = 0
     conc = None
-    if args.concurrent > 1 and args.steps > 0:
+    Rs = [int(x) for x in args.concurrent.split(",") if x.strip() and int(x) > 1] if args.concurrent else []
+    if extras and Rs:
         from polychordlite_amd.repeats import run_repeats
-        R = args.concurrent
         s_c = api.Settings(); C.memmove(C.byref(s_c), C.byref(s), C.sizeof(s)); s_c.profile = 0
-        run_repeats(s_c, L, P, [400000 + j + 100003 * rank for j in range(R)], max_in_flight=R)     # block cache for R engines
-        mc, _ = run_repeats(s_c, L, P, [500000 + j + 100003 * rank for j in range(R)], max_in_flight=R)
-        tc = mc["t_runs_s"]
-        nl = mc["nlike"]
-        conc = {"runs": R, "wall_ms": tc * 1e3, "value": nl / tc, "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3,
-                "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
-                "note": "R independent runs of the same workload in flight on one GPU (one host thread + HIP stream each, "
-                        "polychordlite_amd.repeats.run_repeats); wall_ms = the runs, merge_ms = evidence replay of their union on the host"}
+        conc = []
+        for R in Rs:
+            if R * nlive * (4 * nr + 64) * (2 * nDims + nDer + 2) * 8 * 2 > 200e9:      # phantom buffers of R engines
+                continue
+            run_repeats(s_c, L, P, [400000 + j for j in range(R)], max_in_flight=R)      # block cache for R engines
+            mc, _ = run_repeats(s_c, L, P, [500000 + j for j in range(R)], max_in_flight=R)
+            conc.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": mc["nlike"] / mc["t_runs_s"], "unit": "likelihood evals/s",
+                         "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"]})
         sync()
     if rank == 0:
         value = nlike / tmax
-        k = runs[-1]["kernel_time"]
-        dom = max(k, key=lambda n: k[n]["total_s"]) if k else None
+        B_ = runs[-1]["batch"]
+        evals = float(sum(r["nlike"] for r in runs)); niter = float(sum(r["niter"] for r in runs))
+        nurseries = float(sum(r["nbatches"] for r in runs))
+        bpe = BYTES_PER_EVAL if args.workload == "c2" else algorithmic_bytes_per_iteration(nDims, nDer, nr, nlive) * niter / evals
+        pmc = {}
+        for name in ("r02_pmc.json", "r01_pmc.json"):
+            pth = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pth) and args.workload == "c2":
+                pmc = json.load(open(pth))["kernels"]; pmc_src = name
+                break
+        kern = []
+        k_last = runs[-1]["kernel_time"]
+        for name in sorted(k_last, key=lambda n: -sum(r["kernel_time"][n]["total_s"] for r in runs)):
+            kt = sum(r["kernel_time"][name]["total_s"] for r in runs); kl = sum(r["kernel_time"][name]["launches"] for r in runs)
+            if kl == 0:
+                continue
+            own = own_bytes_per_launch(name, nDims, nDer, nr, nlive, B_)
+            avg = kt / kl
+            hit = [v for k, v in pmc.items() if k.startswith(name if name != "k_consume" else "k_consume_par")]
+            kern.append({"kernel": name, "avg_launch_us": avg * 1e6, "launches_timed": kl, "timed_every": TIMED_STRIDE,
+                         "own_bytes_per_launch": own, "own_achieved_GBs": own / avg / 1e9 if own else None,
+                         "own_frac": own / avg / 1e9 / HBM_PEAK_GBS if own else None,
+                         "traffic": hit[0]["hbm_bytes_per_launch"] if hit else None})
         roof = None
-        if dom:
-            kt = sum(r["kernel_time"][dom]["total_s"] for r in runs)
-            kl = sum(r["kernel_time"][dom]["launches"] for r in runs)
-            evals = float(sum(r["nlike"] for r in runs))
-            niter = float(sum(r["niter"] for r in runs))
-            bpe = BYTES_PER_EVAL if args.workload == "c2" else algorithmic_bytes_per_iteration(nDims, nDer, nr, args.nlive) * niter / evals
-            achieved = evals * bpe / kt / 1e9
-            # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
-            # FETCH_SIZE / WRITE_SIZE in separate runs of this command; FETCH_SIZE doubled on gfx950)
-            traffic, pmc_src = None, os.path.join(ROOT, "profiles", "r01_pmc.json")
-            if os.path.exists(pmc_src) and args.workload == "c2":
-                pk = json.load(open(pmc_src))["kernels"]
-                hit = [v for k, v in pk.items() if k.startswith(dom if dom != "k_consume" else "k_consume_par")]
-                if hit:
-                    traffic = hit[0]["hbm_bytes_per_launch"]
-            # the kernel's own algorithmic I/O per launch, to read `traffic` against
-            nT, B_, N_ = 2 * nDims + nDer + 2, runs[-1]["batch"], args.nlive
-            own = {"k_slice": B_ * (8 * nT * (1 + nr) + 8 * nr * (nDims + 1) + 16 * nr),
-                   "k_consume": 8 * (2 * N_ + 3 * B_) + 120 * B_,
-                   "k_nhats": B_ * 8 * nr * (nDims + 1)}.get(dom)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_own_bytes_per_launch": own,
-                    "avg_launch_us": kt / max(kl, 1) * 1e6, "launches": kl,
-                    "bytes_per_launch": evals * bpe / max(kl, 1), "bytes_per_eval": bpe,
-                    "note": "latency/parallelism bound path (SURVEY 8d): <=B chains x nDims lanes are live; algorithmic bytes = "
-                            "SURVEY 8(d) bytes per likelihood evaluation (258 B at the metric config) x evaluations of one nursery; "
-                            "traffic = PMC bytes of this kernel alone"}
-        metric_name = {"c2": "likelihood evals/sec, 20D Gaussian nlive=%d", "c3": "likelihood evals/sec, 10D Rastrigin nlive=%d",
-                       "c4": "likelihood evals/sec, 30D twin Gaussian nlive=%d", "c5": "likelihood evals/sec, 100D correlated Gaussian nlive=%d"}
-        out = {"metric": metric_name[args.workload] % args.nlive, "value": value,
+        if kern:
+            # launches of the dominant class per run: nurseries (k_slice, k_nhats) or rounds (k_consume, k_apply)
+            dom = kern[0]
+            per_launch_evals = evals / (nurseries if dom["kernel"] in ("k_slice", "k_nhats") else float(sum(r["nrounds"] for r in runs)))
+            achieved = per_launch_evals * bpe / (dom["avg_launch_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
+                    "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe,
+                    "whole_run_frac": evals * bpe / dt / 1e9 / HBM_PEAK_GBS,
+                    "kernels": kern,
+                    "note": "latency/parallelism bound path (SURVEY 8d): <= B chains x nDims lanes are live.  achieved = SURVEY 8(d) algorithmic "
+                            "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
+                            "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
+                            "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
+        out = {"metric": METRIC[args.workload] % nlive, "value": value,
                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": wl["name"] % args.nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
-                          "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world},
+               "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
+                          "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world},
                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
                "logZ_truth": wl["truth"], "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
-               "merged": merged, "step_ms": step_ms, "merge_ms": merge_ms, "concurrent": conc, "roofline": roof,
+               # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
+               # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
+               "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
+               "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "records", "post_mean", "t_merge_s")} if merged else None,
+               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                "reference_cpu_evals_per_s_survey_container": 357e3}
-        if not args.no_cpu and world == 1 and args.workload == "c2":
-            out["cpu_baseline"] = cpu_baseline(nDims, nDer, nr)
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(wl, nlive)
+            out["cpu_baseline"] = cb
+            # wall clock of one run of the reference / of the engine: what a user waits for (the evals/s ratio also counts the
+            # engine's failed spawns as work)
+            out["speedup_wall_per_run"] = cb["wall_s"] / (tmax / max(args.steps, 1))
+            out["speedup_evals_per_s"] = value / cb["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -118,7 +118,8 @@ typedef struct {
     int feedback;
     int profile;        /* 0: off; 1: HIP-event stopwatch around every kernel class; otherwise a bit mask,
                            bit k+1 = time kernel class k (0 nhats, 1 slice, 2 consume, 3 apply, 4 clean, 5 covmats):
-                           a few hundred event records per run instead of a few thousand */
+                           a few hundred event records per run instead of a few thousand; bits 8..15 = n: only every
+                           n-th launch of a class is timed (k_launches then counts the timed ones) */
     int force_general;  /* 1: always use the general contraction kernel (tests) */
     int ablate;         /* developer timing hook: bit mask of contraction sub-steps to skip; 0 = product */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
@@ -222,6 +223,39 @@ void pchip_result_free(pchip_result *r);
    (<base_dir>/<file_root>.maximum).  Host code; live rows as in pchip_result.  0 on success. */
 int  pchip_maximise(polychord_loglike_fn loglikelihood, polychord_prior_fn prior, int nDims, int nDerived, double logzero,
                     const double *live, const int *live_cluster, int nlive, const double *post_mean, const char *path);
+/* ---- repeat-sharded runs: independent runs of one problem, merged ------------------------------------
+ * The reference's way to use more hardware is its MPI farm (nested_sampling.F90:262-301, mpi_utils.F90:376-463: workers'
+ * babies gathered into one run).  Here every GPU carries a complete run of its own; the dead points of all runs are
+ * gathered and their union -- a nested-sampling run with n(L) = sum of the runs' live points -- gives one evidence
+ * (error ~ 1/sqrt(runs)) and one posterior. */
+typedef struct {
+    double logZ, varlogZ;          /* evidence of the union (log-normal location and variance, run_time_info.f90:652-678) */
+    long n; int nTotal, nruns;     /* points that entered a live set, over all runs */
+    double *rows;                  /* [n][nTotal] merged dead points ascending in logL (host; only if asked for); the birth
+                                      column holds the contour at which the point ENTERED its live set */
+    double *logweights;            /* [n] log prior-volume weight logX_i - log(n_i + 1) of each merged point */
+    int *nlive;                    /* [n] live points over all runs just before each death */
+    double *post_mean, *post_var;  /* [nDims + nDerived] posterior moments of theta, phi */
+    double t_merge_s, t_runs_s;    /* wall clock of the merge / of the runs (pchip_run_repeats) */
+    long nlike, ndead_all;         /* totals over the runs (pchip_run_repeats) */
+} pchip_merged;
+/* Merge `nruns` runs on the device.  rows = the lived records (logweight > logzero) of run 0, then run 1, ...: counts[q]
+ * rows of nTotal doubles each, every run ascending in logL (the order in which they died); entry[i] = contour at which
+ * record i entered its live set (pchip_result.entry).  on_device: the two arrays are device pointers (e.g. the buffer an
+ * RCCL all-gather filled), else host memory that is uploaded first.  Returns 0, or a pchip_run code; no CPU path. */
+int  pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
+                         int on_device, int want_rows, pchip_merged *out);
+void pchip_merged_free(pchip_merged *m);
+/* <root>.stats (global evidence, counters, posterior means), <root>_dead-birth.txt and <root>.txt of a merged result in
+ * the reference's formats (read_write.F90:809-910, :707-716, :479-617), so that PolyChordOutput / anesthetic read the
+ * union like a single run.  0 on success. */
+int  pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const char *base_dir, const char *file_root);
+/* nseeds independent runs (settings `s` with seed = seeds[k]) spread over `devices` (ordinals of this process; NULL / 0 =
+ * the device of `s`), at most max_in_flight at a time per device, one host thread each; results[k] as from pchip_run
+ * (free each with pchip_result_free), merged (may be NULL) = their union with rows.  0 on success. */
+int  pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
+                       int ndevices, const int *devices, int max_in_flight, pchip_result *results, pchip_merged *merged);
+
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */
 int  pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
                         unsigned batch, int nchains, const double *seeds, const double *chol,

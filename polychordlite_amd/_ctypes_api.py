@@ -161,6 +161,12 @@ def run(settings, like, prior):
     rc = lib.pchip_run(C.byref(settings), C.byref(like), C.byref(prior), C.byref(r))
     if rc != 0:
         raise RuntimeError(f"pchip_run failed with code {rc}")
+    return result_dict(r, settings)
+
+
+def result_dict(r, settings):
+    """dict view of a filled pchip_result; takes ownership (the block is freed when the last array view dies)"""
+    lib = load()
     own = _Owner(lib, r)
     nT, nd, D = r.nTotal, r.ndead, settings.nDims
     out = dict(logZ=r.logZ, logZerr=float(np.sqrt(abs(r.varlogZ))), varlogZ=r.varlogZ, ndead=nd, nlike=r.nlike,

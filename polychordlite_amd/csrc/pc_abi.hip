@@ -391,6 +391,60 @@ void polychord_hip_set_option(const char *name, double value)
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }
 
+// Files of a merged result (pchip_merge_records / pchip_run_repeats) in the reference's formats: <root>.stats
+// (read_write.F90:809-910; no local evidences: the union has one volume), <root>_dead-birth.txt (theta, phi, logL, birth;
+// :707-716) and <root>.txt (weight, -2 logL, theta, phi; :479-617, weights relative to the largest).
+int pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const char *base_dir, const char *file_root)
+{
+    if (!m || !m->rows || m->n <= 0) { std::fprintf(stderr, "polychord_hip: merged result without rows\n"); return 1; }
+    const std::string stem = std::string(base_dir ? base_dir : "chains") + "/" + (file_root ? file_root : "test");
+    const int np = nDims + nDerived, nT = m->nTotal, p0 = nDims, b0 = 2 * nDims + nDerived, l0 = b0 + 1;
+    FILE *fd = std::fopen((stem + "_dead-birth.txt").c_str(), "w"), *fp = std::fopen((stem + ".txt").c_str(), "w");
+    FILE *fs = std::fopen((stem + ".stats").c_str(), "w");
+    if (!fd || !fp || !fs) { if (fd) std::fclose(fd); if (fp) std::fclose(fp); if (fs) std::fclose(fs); std::fprintf(stderr, "PolyChord Error: cannot write %s.*\n", stem.c_str()); return 2; }
+    double mx = -1.7e308;
+    for (long i = 0; i < m->n; ++i) mx = std::max(mx, m->logweights[i] + m->rows[(size_t)i * nT + l0]);
+    std::string line;
+    long nposterior = 0;
+    for (long i = 0; i < m->n; ++i) {
+        const double *r = m->rows + (size_t)i * nT;
+        line.clear();
+        for (int k = 0; k < np; ++k) line += fmt_e24(r[p0 + k]);
+        line += fmt_e24(r[l0]); line += fmt_e24(r[b0]); line += '\n';
+        std::fwrite(line.data(), 1, line.size(), fd);
+        const double w = std::exp(m->logweights[i] + r[l0] - mx);
+        if (w > 0.0) {
+            line = fmt_e24(w) + fmt_e24(-2 * r[l0]);
+            for (int k = 0; k < np; ++k) line += fmt_e24(r[p0 + k]);
+            line += '\n';
+            std::fwrite(line.data(), 1, line.size(), fp);
+            nposterior++;
+        }
+    }
+    std::fclose(fd); std::fclose(fp);
+    std::fprintf(fs, "Evidence estimates:\n===================\n");
+    std::fprintf(fs, "  - The evidence Z is a log-normally distributed, with location and scale parameters mu and sigma.\n");
+    std::fprintf(fs, "  - We denote this as log(Z) = mu +/- sigma.\n\nGlobal evidence:\n----------------\n\n");
+    std::fprintf(fs, "log(Z)       = %s +/- %s\n\n\n", fmt_e24(m->logZ).c_str(), fmt_e24(std::sqrt(std::fabs(m->varlogZ))).c_str());
+    std::fprintf(fs, "Local evidences:\n----------------\n\n");
+    std::fprintf(fs, "\n\nRun-time information:\n---------------------\n\n");
+    std::fprintf(fs, " ncluster:   %8d /%8d\n", 0, m->nruns);
+    std::fprintf(fs, " nposterior: %8ld\n", nposterior);
+    std::fprintf(fs, " nequals:    %8d\n", 0);
+    std::fprintf(fs, " ndead:      %8ld\n", m->n);
+    std::fprintf(fs, " nlive:      %8d\n", 0);
+    std::fprintf(fs, " nlike:      %8ld\n", m->nlike);
+    std::fprintf(fs, " <nlike>:    %8.2f   (%8.2f per slice )\n", 0.0, 0.0);
+    std::fprintf(fs, "\n\nDim No.       Mean        Sigma\n");
+    for (int k = 0; k < np; ++k) {
+        if (k == nDims) std::fprintf(fs, "-------------------------------\n");
+        std::fprintf(fs, "%3d%s +/- %s\n", k + 1, fmt_e24(m->post_mean[k]).c_str(), fmt_e24(std::sqrt(std::fabs(m->post_var[k]))).c_str());
+    }
+    if (nDerived == 0) std::fprintf(fs, "-------------------------------\n");
+    std::fclose(fs);
+    return 0;
+}
+
 // .resume files without a run: parse `in` and write it back to `out` (NULL: only parse).  counts[0..5] =
 // nDims, nDerived, ndead, ncluster, ncluster_dead, live points in total.  Returns 0 on success.
 int polychord_hip_resume_copy(const char *in, const char *out, int *counts)

@@ -752,6 +752,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->logX_last_update = lx_last; ctl->live_logZ = live_logZ_val;
         ctl->gen_cyc[0] += cyT; ctl->gen_cyc[1] += cyI; ctl->gen_cyc[2] += cyK; ctl->gen_cyc[3] += cyE; ctl->nn_walks += cyW; ctl->nn_fallbacks += cyF;
     }
+    pc_publish_ctl(S);
 }
 
 // ------------------------------------------------------------------------------------------

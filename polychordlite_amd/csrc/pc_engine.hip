@@ -21,6 +21,7 @@
 #include <unordered_map>
 #include <atomic>
 #include <mutex>
+#include <thread>
 
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
@@ -185,7 +186,8 @@ struct HandlePool {
     void put_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); events.push_back({dev, e}); }
 };
 HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
-std::atomic<int> g_active_runs{0};         // runs in flight in this process (polychordlite_amd.repeats: one thread each)
+std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
+std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
 
@@ -194,15 +196,16 @@ enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_N };
 struct KTimer {
     bool on = false;
     unsigned mask = 0xFFFFFFFFu;            // kernel classes that are timed
+    unsigned stride = 1; unsigned seen[KT_N] = {0};   // ... every stride-th launch of a class (an event pair costs the stream ~6 us)
     hipStream_t st = nullptr;
     std::vector<hipEvent_t> pool; size_t used = 0;
     struct Span { int k; hipEvent_t a, b; };
     std::vector<Span> open;
     double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
     hipEvent_t get() { if (used == pool.size()) pool.push_back(hpool().get_event()); return pool[used++]; }
-    hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u)) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
+    hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u) || (seen[k]++ % stride) != 0) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
     void end(int k, hipEvent_t a) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
-    void collect() {   // call after a stream synchronisation
+    void collect() {   // call after a stream synchronisation (the run does it once, at its end: a round no longer synchronises)
         if (!on) return;
         for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
         open.clear(); used = 0;
@@ -261,6 +264,10 @@ struct Engine {
     bool pre_ready = false; unsigned pre_batch = 0; int pre_B = 0;
     double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
     PcCtl *h_ctl = nullptr;       // pinned mirror
+    PcCtl *h_note = nullptr;      // pinned, device-visible: the contraction kernels publish the control block here (pc_publish_ctl)
+    unsigned note_seq = 0;
+    hipEvent_t ev_apply = nullptr;
+    double *raw_buf[2] = {nullptr, nullptr};   // orthonormal bases of nursery b live in raw_buf[b & 1]
     // alternate phantom buffers + scratch for the update step
     double *ph2 = nullptr, *phL2 = nullptr; unsigned *phC2 = nullptr; unsigned long long *phU2 = nullptr;
     unsigned char *keep = nullptr; int *blk = nullptr, *d_total = nullptr;
@@ -274,7 +281,7 @@ struct Engine {
     long nsplits = 0; int ncluster_peak = 1;
     Timing tm;
     KTimer kt;
-    int B = 0;
+    int B = 0, dev = 0;
     bool fast_ok = false;
     bool cb_auto_batch = false; int B_small = 1; double cb_eval_seconds = -1.0;   // host callbacks: chains per nursery chosen from the measured cost of a call
     long long nlike_g[PC_MAX_GRADE] = {0};      // RTI%nlike per grade (grade 1 includes the prior samples)
@@ -293,10 +300,12 @@ struct Engine {
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
             engine_fail(PC_RC_DEVICE, "no HIP device available -- this engine has no CPU path");
         }
-        HIPCHK(hipSetDevice(c.device >= 0 ? c.device % ndev : 0));
+        dev = c.device >= 0 ? c.device % ndev : 0;
+        HIPCHK(hipSetDevice(dev));
         st = hpool().get_stream(); st_copy = hpool().get_stream();
         kt.on = c.profile != 0; kt.st = st;
-        kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : ((unsigned)c.profile >> 1);   // 1: every class; else bit k+1 = class k
+        kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x3Fu);   // 1: every class; else bit k+1 = class k
+        kt.stride = std::max(1u, ((unsigned)c.profile >> 8) & 0xFFu);                       // bits 8..15: time every n-th launch of a class
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
         // grades (chordal_sampling.f90:119-130): bases per grade, first direction and first deviate of each
@@ -420,6 +429,8 @@ struct Engine {
         static const bool split_off = std::getenv("PC_NHATS_SPLIT_OFF") != nullptr;
         S.nhat_raw = (D <= 24 && !S.seq_mode && !split_off) ? dalloc<double>((size_t)B * S.nb_total * D * D)
                    : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
+        // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read
+        raw_buf[0] = S.nhat_raw; raw_buf[1] = (D <= 24 && S.nhat_raw) ? dalloc<double>((size_t)B * S.nb_total * D * D) : nullptr;
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
@@ -433,6 +444,10 @@ struct Engine {
             HIPCHK(hipMemset(d_cs, 0, pc_chain_state_size() * B));
         }
         h_ctl = halloc<PcCtl>(1);
+        h_note = halloc<PcCtl>(1);                    // (hipHostMalloc memory is mapped and coherent: the device stores straight into it)
+        std::memset(h_note, 0, sizeof(PcCtl)); note_seq = 0;
+        { void *dp = nullptr; HIPCHK(hipHostGetDevicePointer(&dp, h_note, 0)); S.ctl_host = (PcCtl *)dp; }
+        S.notify_seq = 0;
         // per-cluster initial values and the control block (initialise_run_time_info, run_time_info.f90:164-206)
         pc_launch_init_state(&S, c.logzero, st);
         PcCtl c0{};
@@ -461,10 +476,51 @@ struct Engine {
     void read_ctl()
     {
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
+        // (polling the stream wakes the host a few microseconds after the copy; the blocking wait sleeps on an interrupt)
+        for (int spins = 0; spins < 200000; ++spins) { const hipError_t q = hipStreamQuery(st); if (q != hipErrorNotReady) { HIPCHK(q); break; } __builtin_ia32_pause(); }
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
         nph_stale = false;
-        kt.collect();
+    }
+
+    // The outcome of a round without a copy and without a stream synchronisation: the contraction kernel stamps the
+    // host mirror when it is done.  The row copies of the round (k_apply_*) may still be running when this returns;
+    // everything the host enqueues next is ordered behind them by the stream.
+    void launch_stamp() { S.notify_seq = ++note_seq; }
+    void wait_ctl()
+    {
+        static const bool off = std::getenv("PC_NOTIFY_OFF") != nullptr;
+        if (off || !S.ctl_host) { read_ctl(); return; }
+        const volatile unsigned long long *w = (const volatile unsigned long long *)h_note;
+        unsigned long long got[PC_NOTE_WORDS];
+        for (unsigned long spins = 0;; ++spins) {
+            bool all = true;
+            for (int i = 0; i < PC_NOTE_WORDS; ++i) { got[i] = w[i]; all = all && (unsigned)(got[i] >> 32) == note_seq; }
+            if (all) break;
+            if ((spins & 0x3FFFu) == 0x3FFFu) {
+                // nothing after ~a millisecond: did the stream die (launch failure, fault)?  A finished stream without a
+                // stamp is an error; a busy one just takes long (general contraction kernel, large nurseries)
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    bool ok = true;
+                    for (int i = 0; i < PC_NOTE_WORDS; ++i) ok = ok && (unsigned)(w[i] >> 32) == note_seq;
+                    if (!ok) engine_fail(PC_RC_DEVICE, "a contraction kernel finished without reporting (launch failure?)");
+                } else if (q != hipErrorNotReady) engine_fail(PC_RC_DEVICE, "HIP error %s while waiting for a round", hipGetErrorString(q));
+                if (spins > (1ul << 22)) std::this_thread::yield();
+            } else __builtin_ia32_pause();
+        }
+        PcCtl &c = *h_ctl;
+        const int hi_before = c.i_nursery > 0 ? c.i_nursery - 1 : B - 1;       // the segment starts where the last one stopped
+        c.status = (int)(got[0] & 0xFF); c.error = (int)((got[0] >> 8) & 0xFF); c.cluster_deleted = (int)((got[0] >> 16) & 1);
+        c.i_nursery = (int)(unsigned)got[1]; c.ndead = (int)(unsigned)got[2]; c.nphantom = (int)(unsigned)got[3];
+        c.ncluster = (int)(got[4] & 0xFFFF);
+        {   // the low 16 bits of a counter that only grows
+            int cand = (c.ncluster_dead & ~0xFFFF) | (int)((got[4] >> 16) & 0xFFFF);
+            if (cand < c.ncluster_dead) cand += 0x10000;
+            c.ncluster_dead = cand;
+        }
+        c.seg_hi = hi_before; c.seg_lo = c.i_nursery;
+        nph_stale = false;
     }
 
     void grow_dead(int nd)
@@ -691,6 +747,8 @@ struct Engine {
     void do_update()
     {
         tm.updates++;
+        // the round loop only sees the compact notification; whoever looks at evidences, counters or cluster ids gets the block
+        if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
         call_dumper();
         const int nph = h_ctl->nphantom;
         hipEvent_t e0 = kt.begin(KT_CLEAN);
@@ -1054,6 +1112,7 @@ struct Engine {
     {
         const size_t nd = (size_t)h_ctl->ndead;
         if (!h_dead || nd > h_dead_cap || nd <= h_dead_copied) return;
+        if (ev_apply) HIPCHK(hipStreamWaitEvent(st_copy, ev_apply, 0));     // the rows are written by k_apply_dead_ph, which may still run
         HIPCHK(hipMemcpyAsync(h_dead + h_dead_copied * S.nT, S.dead + h_dead_copied * S.nT,
                               sizeof(double) * (nd - h_dead_copied) * S.nT, hipMemcpyDeviceToHost, st_copy));
         h_dead_copied = nd;
@@ -1204,7 +1263,7 @@ struct Engine {
 
     int run(pchip_result *out)
     {
-        struct ActiveRun { ActiveRun() { g_active_runs.fetch_add(1); } ~ActiveRun() { g_active_runs.fetch_sub(1); } } active_run;
+        struct ActiveRun { int d; explicit ActiveRun(int dv) : d(dv & 63) { g_active_runs.fetch_add(1); g_active_dev[d].fetch_add(1); } ~ActiveRun() { g_active_runs.fetch_sub(1); g_active_dev[d].fetch_sub(1); } } active_run(dev);
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
         h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
@@ -1245,9 +1304,11 @@ struct Engine {
                 ensure_capacity();
                 hipEvent_t e0 = kt.begin(KT_NHATS);
                 // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
-                const bool split = pc_nhats_splittable(&S) != 0 && g_active_runs.load(std::memory_order_relaxed) == 1;
+                const bool split = pc_nhats_splittable(&S) != 0 && raw_buf[1] && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
                 if (split) {
-                    // the bases were drawn on the side stream while the last nursery was consumed (or are drawn now)
+                    // the bases of this nursery were drawn on the side stream while the last one was consumed (or are
+                    // drawn now); bases of nursery b live in raw_buf[b & 1]
+                    S.nhat_raw = raw_buf[batch & 1];
                     if (pre_ready && pre_batch == batch && pre_B == B) HIPCHK(hipStreamWaitEvent(st, ev_side, 0));
                     else (void)pc_launch_nhats_part(&S, batch, B, 1, st);
                     pre_ready = false;
@@ -1260,10 +1321,13 @@ struct Engine {
                 else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
                 if (split) {
-                    if (!st_side) { st_side = hpool().get_stream(); ev_main = hpool().get_event(); ev_side = hpool().get_event(); }
+                    // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
+                    // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
+                    if (!st_side) { st_side = hpool().get_stream(); ev_side = hpool().get_event(); ev_main = hpool().get_event(); }
                     HIPCHK(hipEventRecord(ev_main, st));
-                    HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0));       // the raw bases of this nursery have been read
-                    (void)pc_launch_nhats_part(&S, batch + 1, B, 1, st_side);
+                    HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0));
+                    PcState S1 = S; S1.nhat_raw = raw_buf[(batch + 1) & 1];
+                    (void)pc_launch_nhats_part(&S1, batch + 1, B, 1, st_side);
                     HIPCHK(hipEventRecord(ev_side, st_side));
                     pre_ready = true; pre_batch = batch + 1; pre_B = B;
                 }
@@ -1274,6 +1338,7 @@ struct Engine {
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
+            launch_stamp();
             if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0; S.nn_valid = 0;                     // (the one-cluster kernels do not keep the list bookkeeping)
@@ -1297,7 +1362,9 @@ struct Engine {
             hipEvent_t e3 = kt.begin(KT_APPLY);
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
-            read_ctl();
+            if (!ev_apply) ev_apply = hpool().get_event();
+            HIPCHK(hipEventRecord(ev_apply, st));           // the dead rows of this round are in place behind this point
+            wait_ctl();
             // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
             // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery
             // generated in between was never touched and does not count.
@@ -1322,6 +1389,7 @@ struct Engine {
             (void)pc_launch_final_par(&S, st);
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
         read_ctl();
+        kt.collect();
         if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals) && h_ctl->nphantom > 0) {
             // the last update_posteriors (nested_sampling.F90:386-390): every remaining phantom is below the last death
             pc_launch_clean(&S, h_ctl->nphantom, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
@@ -1402,6 +1470,7 @@ struct Engine {
         if (st) (void)hipStreamSynchronize(st);
         if (st_copy) (void)hipStreamSynchronize(st_copy);
         if (st_side) (void)hipStreamSynchronize(st_side);
+        if (raw_buf[0]) { S.nhat_raw = raw_buf[0]; dfree(raw_buf[1]); raw_buf[0] = nullptr; }     // S.nhat_raw pointed at one of the two
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,
@@ -1421,9 +1490,12 @@ struct Engine {
         kt.destroy();
         if (h_dead) { hfree(h_dead); h_dead = nullptr; }
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
+        if (h_note) hfree((void *)h_note); h_note = nullptr;
+        if (ev_apply) { hpool().put_event(ev_apply); ev_apply = nullptr; }
+
         if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
         if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
-        if (st_side) { (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_main); hpool().put_event(ev_side); } st_side = nullptr; ev_main = ev_side = nullptr;
+        if (st_side) { (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_side); hpool().put_event(ev_main); } st_side = nullptr; ev_side = ev_main = nullptr;
         pre_ready = false;
     }
 };

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(1024) void k_ph_prepare(PcState S)
         __syncthreads();
     }
     if (tid == 0) ctl->nphantom = carry;
+    pc_publish_ctl(S);                                              // the serial kernel's round ends here
 }
 
 // ------------------------------------------------------------------------------------------

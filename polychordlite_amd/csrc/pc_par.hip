@@ -607,6 +607,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         for (int x = 0; x + 1 < ncy && x < 8; ++x) ctl->dbg[x] += cyc[x + 1] - cyc[x];
 #endif
     }
+    pc_publish_ctl(S);
 }
 
 // ------------------------------------------------------------------------------------------

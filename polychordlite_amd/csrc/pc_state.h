@@ -131,7 +131,34 @@ struct PcState {
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     PcCtl *ctl;
+    // host notification: the contraction kernels copy the control block into a pinned, device-visible host mirror when
+    // they are done and stamp it with notify_seq, so the host learns the outcome of a round by watching memory instead
+    // of a copy + stream synchronisation (and goes on enqueueing while the row-copy kernels of the round still run)
+    PcCtl *ctl_host; unsigned notify_seq;
 };
+
+// Called by EVERY thread of the (single) workgroup at the end of a contraction kernel, after thread 0 has stored the new
+// control block to *S.ctl.  The host mirror is fine-grained host memory over PCIe; a system-scope release (fence + L2
+// write-back) in front of a stamp costs the kernel ~15 us, and a dozen dependent stores by one thread ~6 us, so: no
+// ordering is asked for and the words leave in ONE store instruction, one lane each.  Each word carries the launch's
+// sequence number in its upper half -- a word is valid when its stamp is the expected one, whatever order the words
+// arrive in.  Only what the host's round loop needs travels; the rest of the control block is read with a copy at the
+// moments that synchronise anyway (updates with host work, the end of the run).
+#define PC_NOTE_WORDS 5
+__device__ __forceinline__ void pc_publish_ctl(const PcState &S)
+{
+    __shared__ unsigned pc_note_sh[8];
+    if (!S.ctl_host) return;                       // (uniform)
+    if (threadIdx.x == 0) {
+        const PcCtl *c = S.ctl;
+        pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16);
+        pc_note_sh[1] = (unsigned)c->i_nursery; pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
+        pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (the full count comes with the block)
+    }
+    __syncthreads();
+    if (threadIdx.x < PC_NOTE_WORDS)
+        ((volatile unsigned long long *)S.ctl_host)[threadIdx.x] = ((unsigned long long)S.notify_seq << 32) | pc_note_sh[threadIdx.x];
+}
 
 // element g of a small settings array without dynamic indexing of the kernel argument block
 __device__ __forceinline__ int pc_sel(const int (&a)[PC_MAX_GRADE], int g)

@@ -1,42 +1,53 @@
-"""Independent repeats on ONE GPU.
+"""Independent repeats of one problem -- on one GPU, or spread over several (BASELINE's repeat-sharded mode).
 
 A single run keeps about one wavefront per SIMD busy (B <= 1024 chains per nursery, the contraction on one CU), so
-independent repeats of the same problem -- the runs BASELINE's repeat-sharded mode spreads over GPUs --
-also overlap on one: R host threads, each driving its own engine instance on its own HIP stream (the C entry point
-releases nothing Python-side: ctypes drops the GIL for the duration of the call).  The repeats are merged like the
-multi-GPU ones (merge.evidence_replay over the union of their death records): sigma(logZ) falls like 1/sqrt(R).
+independent repeats overlap on one device; and they shard across devices with nothing to exchange until the end.
+`run_repeats` is the front door: the library runs the repeats on host threads of its own (pchip_run_repeats: one engine
+per run in flight, each on its own stream of its device) and merges their dead points on the first device
+(pchip_merge_records): evidence with an error ~ 1/sqrt(repeats), posterior moments, the merged dead points and,
+on request, <root>.stats / <root>_dead-birth.txt / <root>.txt of the union in the reference's formats.
 """
 import ctypes as C
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from . import _ctypes_api as api
-from .merge import evidence_replay, lived_records
+from . import merge as mg
 
 
-def run_repeats(settings, like, prior, seeds, max_in_flight=4):
-    """Run one nested-sampling run per seed, up to `max_in_flight` at a time on the current device, and merge them.
+def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, want_rows=False, write=None):
+    """One nested-sampling run per seed, at most `max_in_flight` at a time per device, on `devices` (HIP ordinals of this
+    process; None = the device of `settings`), merged.
 
-    Returns (merged, runs): merged = {"n_runs", "logZ", "logZerr", "records", "nlike", "t_runs_s", "t_merge_s"}; runs = the per-seed result
-    dicts of `_ctypes_api.run` (zero-copy views of the engine's pinned buffers)."""
-    seeds = list(seeds)
+    Returns (merged, runs): merged = {"n_runs", "logZ", "logZerr", "post_mean", "post_var", "logweights", "nlive", "records",
+    "nlike", "t_runs_s", "t_merge_s"[, "rows"]}; runs = the per-seed result dicts of `_ctypes_api.run`."""
+    seeds = [int(s) for s in seeds]
     if not seeds:
         raise ValueError("run_repeats needs at least one seed")
-    copies = []
-    for sd in seeds:                                  # one settings block per repeat: the call reads it while it runs
-        s = api.Settings()
-        C.memmove(C.byref(s), C.byref(settings), C.sizeof(settings))
-        s.seed = int(sd)
-        copies.append(s)
-    import time
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max(1, min(int(max_in_flight), len(seeds)))) as ex:
-        runs = list(ex.map(lambda s: api.run(s, like, prior), copies))
-    t1 = time.perf_counter()
-    rec = [lived_records(r) for r in runs]
-    logL = np.concatenate([a for a, _ in rec]); entry = np.concatenate([b for _, b in rec])
-    lz, var = evidence_replay(logL, entry)
-    merged = {"n_runs": len(runs), "logZ": lz, "logZerr": float(np.sqrt(abs(var))), "records": int(logL.size),
-              "nlike": int(sum(r["nlike"] for r in runs)), "t_runs_s": t1 - t0, "t_merge_s": time.perf_counter() - t1}
+    lib = mg._lib()
+    f = lib.pchip_run_repeats
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(api.Settings), C.POINTER(api.Like), C.POINTER(api.Prior), C.c_int, C.POINTER(C.c_int), C.c_int,
+                  C.POINTER(C.c_int), C.c_int, C.POINTER(api.Result), C.POINTER(mg.Merged)]
+    n = len(seeds)
+    sd = (C.c_int * n)(*seeds)
+    devs = list(devices) if devices else []
+    dv = (C.c_int * max(len(devs), 1))(*devs) if devs else None
+    res = (api.Result * n)()
+    m = mg.Merged()
+    rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), res, C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"pchip_run_repeats failed with code {rc}")
+    try:
+        if write:
+            if lib.pchip_merged_write(C.byref(m), settings.nDims, settings.nDerived, str(write[0]).encode(), str(write[1]).encode()) != 0:
+                raise RuntimeError("pchip_merged_write failed")
+        merged = mg.merged_dict(m, settings.nDims, settings.nDerived, want_rows)
+    finally:
+        lib.pchip_merged_free(C.byref(m))
+    runs = []
+    for k in range(n):
+        r = api.Result()
+        C.memmove(C.byref(r), C.byref(res[k]), C.sizeof(r))          # each dict owns (and frees) its own result block
+        runs.append(api.result_dict(r, settings))
     return merged, runs

@@ -1,11 +1,20 @@
-"""CPU: repeat-sharded merge: vectorised replay == oracle evidence; world_size-2 gloo."""
+"""Repeat-sharded merge.
+
+CPU: the numpy checker (tests/replay_oracle.py) against the oracle's evidence; the all-gather plumbing of
+polychordlite_amd.merge.gather_records between two processes (gloo): counts, padding, full rows + entry contours.
+GPU (-m gpu): the device merge pchip_merge_records against the checker -- evidence, posterior weights, live counts and
+posterior moments of the union -- on engine-format records, one run (= the engine's own evidence) and several;
+pchip_run_repeats over the visible devices; the merged files."""
+import ctypes as C
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from tests import oracle_api as orc
+from tests.replay_oracle import replay, evidence_replay, lived_records
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,14 +26,15 @@ def _run(seed, nlive=60, batch=1):
 
 
 def test_replay_equals_engine_evidence_linear_mode():
-    from polychordlite_amd.merge import evidence_replay, lived_records
     o = _run(3)
     lz, var = evidence_replay(*lived_records(o))
     assert abs(lz - o["logZ"]) < 1e-9 and abs(var - o["varlogZ"]) < 1e-9
+    r = replay(*lived_records(o), rows=o["dead"], p0=6, nP=6)          # weights and posterior mean of the checker == the oracle's
+    assert np.abs(r["logweights"] - o["logweights"]).max() < 1e-9
+    assert np.allclose(r["post_mean"], o["post_mean"], atol=1e-9)
 
 
 def test_merged_runs_shrink_the_error():
-    from polychordlite_amd.merge import evidence_replay, lived_records
     runs = [_run(s) for s in range(4)]
     L = np.concatenate([lived_records(r)[0] for r in runs]); B = np.concatenate([lived_records(r)[1] for r in runs])
     lz, var = evidence_replay(L, B)
@@ -38,32 +48,151 @@ import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 from tests import oracle_api as orc
-from polychordlite_amd.merge import merge_runs, evidence_replay, lived_records
+from tests.replay_oracle import replay
+from polychordlite_amd.merge import gather_records, lived_records
 dist.init_process_group("gloo")
-rank = dist.get_rank()
-s = orc.settings(6, 0, nlive=60, num_repeats=12, seed=10 + rank, batch=1)
-L, P, keep = orc.make_problem("gaussian", 6)
-o = orc.run(s, L, P)
-o["entry"] = o["dead"][:, -2]
-m = merge_runs(o, dist, torch, 0)
+rank, world = dist.get_rank(), dist.get_world_size()
+D = 6
+def one(r):
+    s = orc.settings(D, 0, nlive=60 + 7 * r, num_repeats=12, seed=10 + r, batch=4)     # ranks hold different numbers of records
+    L, P, keep = orc.make_problem("gaussian", D)
+    o = orc.run(s, L, P)
+    o["entry"] = o["dead"][:, -2].copy()            # engine-format record: rows [cube|theta|phi|birth|logL] + entry contour
+    return o
+mine = one(rank)
+g, ks = gather_records(mine, dist, torch, torch.device("cpu"))
+g = g.numpy()
+runs = [one(r) for r in range(world)]
+rows = np.concatenate([lived_records(x)[0] for x in runs]); entry = np.concatenate([lived_records(x)[1] for x in runs])
+assert ks == [lived_records(x)[0].shape[0] for x in runs], ks
+assert g.shape == (rows.shape[0], rows.shape[1] + 1)
+assert np.array_equal(g[:, :-1], rows) and np.array_equal(g[:, -1], entry)          # every rank holds the identical union
+m = replay(g[:, -2], g[:, -1], rows=g[:, :-1], p0=D, nP=D)
+ref = replay(rows[:, -1], entry, rows=rows, p0=D, nP=D)
+assert m["logZ"] == ref["logZ"] and np.array_equal(m["post_mean"], ref["post_mean"])
+singles = [replay(*[a for a in (lived_records(x)[0][:, -1], lived_records(x)[1])]) for x in runs]
+assert m["varlogZ"] < 0.75 * np.mean([s["varlogZ"] for s in singles])
+assert np.all(np.abs(m["post_mean"] - 0.5) < 0.05)                                   # posterior of the union: theta ~ N(0.5, 0.1)
 if rank == 0:
-    runs = []
-    for r in range(dist.get_world_size()):
-        s2 = orc.settings(6, 0, nlive=60, num_repeats=12, seed=10 + r, batch=1)
-        runs.append(orc.run(s2, L, P))
-    Ls = np.concatenate([lived_records(x)[0] for x in runs]); Bs = np.concatenate([lived_records(x)[1] for x in runs])
-    lz, var = evidence_replay(Ls, Bs)
-    assert m["n_runs"] == 2 and abs(m["logZ"] - lz) < 1e-12, (m, lz)
-    print("MERGE_OK", m["logZ"], lz)
+    print("GATHER_OK", ks, m["logZ"], m["post_mean"][:2])
 dist.barrier(); dist.destroy_process_group()
 """
 
 
-def test_all_gather_merge_world_size_2_gloo(tmp_path):
+def test_all_gather_of_engine_records_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
                          capture_output=True, text=True, env=env, timeout=600)
-    assert "MERGE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_merge_has_no_cpu_path():
+    """without a HIP device the merge fails loudly (return code, no numpy fallback behind it)"""
+    from polychordlite_amd import _ctypes_api as api
+    from polychordlite_amd import merge as mg
+    if api.load().pchip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    o = _run(3)
+    rows, entry = mg.lived_records(o)
+    with pytest.raises(RuntimeError):
+        mg.merge_records(6, 0, [rows.shape[0]], rows, entry)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _engine_runs(api, seeds, D=6, nDer=1, nlive=150, nr=12, batch=50, kind="gaussian", clustering=0, box=(None, None)):
+    lib = api.load()
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+    s.nlive, s.num_repeats, s.batch, s.do_clustering = nlive, nr, batch, clustering
+    L, P, keep = api.make_problem(kind, D, nDer, *box)
+    runs = []
+    for sd in seeds:
+        s.seed = sd
+        runs.append(api.run(s, L, P))
+    return s, L, P, keep, runs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nruns", [1, 2, 5])
+def test_device_merge_matches_the_checker(engine, nruns):
+    from polychordlite_amd import merge as mg
+    D, nDer = 6, 1
+    s, L, P, keep, runs = _engine_runs(engine, [40 + k for k in range(nruns)])
+    recs = [mg.lived_records(r) for r in runs]
+    rows = np.concatenate([a for a, _ in recs]); entry = np.concatenate([b for _, b in recs])
+    m = mg.merge_records(D, nDer, [a.shape[0] for a, _ in recs], rows, entry, want_rows=True)
+    ref = replay(rows[:, -1], entry, rows=rows, p0=D, nP=D + nDer)
+    assert m["records"] == rows.shape[0] and m["n_runs"] == nruns
+    assert abs(m["logZ"] - ref["logZ"]) < 1e-9 and abs(m["varlogZ"] - ref["varlogZ"]) < 1e-9
+    assert np.array_equal(m["nlive"], ref["nlive"])
+    assert np.abs(m["logweights"] - ref["logweights"]).max() < 1e-9
+    assert np.allclose(m["post_mean"], ref["post_mean"], atol=1e-11) and np.allclose(m["post_var"], ref["post_var"], atol=1e-11)
+    mr = m["rows"]
+    assert np.all(np.diff(mr[:, -1]) >= 0)                                  # merged death order
+    assert np.array_equal(np.sort(mr[:, -1]), np.sort(rows[:, -1]))
+    srt = rows[ref["order"]]
+    assert np.array_equal(mr[:, :-2], srt[:, :-2])                          # the same points, row for row
+    assert np.array_equal(mr[:, -2], entry[ref["order"]])                   # birth column = entry contour
+    if nruns == 1:                                                          # one run: the union IS the run
+        g = runs[0]
+        assert abs(m["logZ"] - g["logZ"]) < 1e-7 and abs(m["varlogZ"] - g["varlogZ"]) < 1e-7
+        lw = g["logweights"][g["logweights"] > -1e29]
+        assert np.abs(m["logweights"] - lw).max() < 1e-8
+        assert np.allclose(m["post_mean"], g["post_mean"], atol=1e-9)
+    else:
+        assert m["varlogZ"] < 1.3 * np.mean([r["varlogZ"] for r in runs]) / nruns
+
+
+@pytest.mark.gpu
+def test_device_merge_of_clustered_and_ragged_runs(engine):
+    """runs of different lengths, one of them clustered with dynamic live counts inside (the union does not care how a
+    run arrived at its death sequence), one with a single record, one empty"""
+    from polychordlite_amd import merge as mg
+    api = engine
+    _, _, _, _, a = _engine_runs(api, [3], D=2, nDer=0, nlive=300, nr=6, batch=40, kind="rastrigin", clustering=1, box=(-5.12, 5.12))
+    _, _, _, _, b = _engine_runs(api, [4, 5], D=2, nDer=0, nlive=80, nr=6, batch=1, kind="rastrigin", box=(-5.12, 5.12))
+    recs = [mg.lived_records(r) for r in (a[0], b[0], b[1])]
+    one_row = (recs[1][0][-1:].copy(), np.array([-1e30]))                   # a "run" of one point that lived from the start
+    empty = (np.zeros((0, 6)), np.zeros(0))
+    parts = [recs[0], empty, recs[1], one_row, recs[2]]
+    rows = np.concatenate([p[0] for p in parts]); entry = np.concatenate([p[1] for p in parts])
+    m = mg.merge_records(2, 0, [p[0].shape[0] for p in parts], rows, entry)
+    ref = replay(rows[:, -1], entry, rows=rows, p0=2, nP=2)
+    assert abs(m["logZ"] - ref["logZ"]) < 1e-9 and np.array_equal(m["nlive"], ref["nlive"])
+    assert np.allclose(m["post_mean"], ref["post_mean"], atol=1e-11)
+    assert abs(m["logZ"] - 2 * (-2.326314)) < 4 * m["logZerr"] + 0.05
+
+
+@pytest.mark.gpu
+def test_run_repeats_front_door_and_files(engine, tmp_path):
+    """polychordlite_amd.repeats.run_repeats(devices=[...]): the repeats are the runs they would be one after the other, the
+    union comes from the device merge, and its files read like a single run's (PolyChordOutput parses <root>.stats)"""
+    from polychordlite_amd.repeats import run_repeats
+    from polychordlite_amd.pypolychord.output import PolyChordOutput
+    api = engine
+    ndev = api.load().pchip_device_count()
+    s, L, P, keep, singles = _engine_runs(api, [11, 12, 13, 14, 15, 16])
+    merged, runs = run_repeats(s, L, P, [11, 12, 13, 14, 15, 16], max_in_flight=3, devices=list(range(ndev)),
+                               want_rows=True, write=(str(tmp_path), "u"))
+    for one, r in zip(singles, runs):
+        assert one["ndead"] == r["ndead"] and one["nlike"] == r["nlike"] and one["logZ"] == r["logZ"]
+    assert merged["n_runs"] == 6 and merged["nlike"] == sum(r["nlike"] for r in runs)
+    rows = np.concatenate([r["dead"][r["logweights"] > -1e29] for r in runs]); entry = np.concatenate([r["entry"][r["logweights"] > -1e29] for r in runs])
+    ref = replay(rows[:, -1], entry, rows=rows, p0=6, nP=7)
+    assert abs(merged["logZ"] - ref["logZ"]) < 1e-9 and np.allclose(merged["post_mean"], ref["post_mean"], atol=1e-11)
+    errs = [r["logZerr"] for r in runs]
+    assert 0.3 * np.mean(errs) < merged["logZerr"] < 0.55 * np.mean(errs)          # ~ 1 / sqrt(6)
+    assert abs(merged["logZ"]) < 4 * merged["logZerr"]                             # truth 0
+    assert np.all(np.abs(merged["post_mean"][:6] - 0.5) < 0.02)
+    out = PolyChordOutput(str(tmp_path), "u")
+    assert abs(out.logZ - merged["logZ"]) < 1e-12 and abs(out.logZerr - merged["logZerr"]) < 1e-12
+    db = np.loadtxt(tmp_path / "u_dead-birth.txt")
+    assert db.shape == (merged["records"], 6 + 1 + 2)
+    assert np.allclose(db[:, :7], merged["rows"][:, 6:13], rtol=1e-14) and np.allclose(db[:, 7], merged["rows"][:, -1], rtol=1e-14)
+    lz, var = evidence_replay(db[:, 7], db[:, 8])                                  # the file alone reproduces the evidence
+    assert abs(lz - merged["logZ"]) < 1e-9
+    post = np.loadtxt(tmp_path / "u.txt")
+    w = post[:, 0]
+    assert np.allclose((w[:, None] * post[:, 2:8]).sum(0) / w.sum(), merged["post_mean"][:6], atol=1e-9)
