@@ -55,6 +55,10 @@ void pc_launch_init_state(const PcState *, double, hipStream_t);
 int pc_post_blocks(void);
 void pc_launch_post_moments(const PcState *, int, double *, double *, hipStream_t);
 int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int *, double *, hipStream_t);
+int pc_update_fused_ok(const PcState *, int);
+int pc_update_fused_blocks(const PcState *, int);
+int pc_update_fused_entries(const PcState *);
+void pc_launch_update_fused(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *, unsigned long long *, double *, double *, hipStream_t);
 }
 
 // Fatal conditions unwind to the C ABI entry points (pchip_run_hooks, pchip_slice_chains), which release the run's
@@ -273,6 +277,7 @@ struct Engine {
     unsigned char *keep = nullptr; int *blk = nullptr, *d_total = nullptr;
     double *psum = nullptr, *mean = nullptr, *pcov = nullptr; int *pcnt = nullptr, *count = nullptr;
     size_t cov_chunks_cap = 0;
+    double *upd_part = nullptr, *upd_shift = nullptr; size_t upd_part_cap = 0;   // fused update (pc_update.hip)
     double *d_lo = nullptr, *d_hi = nullptr, *d_invcovT = nullptr, *d_mean = nullptr;
     double *d_dynL = nullptr; int *d_dynN = nullptr; double *d_logn = nullptr;
     // clustering scratch (allocated on first use)
@@ -751,6 +756,30 @@ struct Engine {
         if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
         call_dumper();
         const int nph = h_ctl->nphantom;
+        static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
+        if (!fused_off && nph > 0 && !cfg.do_clustering && cfg.boost_posterior == 0.0 && pc_update_fused_ok(&S, h_ctl->ncluster)) {
+            // one cluster, nDims < 32: clean + covariance + Cholesky in three launches (pc_update.hip)
+            const size_t need = (size_t)pc_update_fused_blocks(&S, nph) * pc_update_fused_entries(&S);
+            if (need > upd_part_cap) { dfree(upd_part); upd_part_cap = 2 * need; upd_part = dalloc<double>(upd_part_cap); }
+            if (!upd_shift) {
+                upd_shift = dalloc<double>(S.D);
+                std::vector<double> half(S.D, 0.5);               // first update: moments about the centre of the hypercube
+                HIPCHK(hipMemcpyAsync(upd_shift, half.data(), sizeof(double) * S.D, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+            hipEvent_t e0 = kt.begin(KT_CLEAN);
+            pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, st);
+            kt.end(KT_CLEAN, e0);
+            if (cfg.resume_write || dumper || on_update) {
+                int total = nph;
+                HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                h_ctl->nphantom = total;
+            } else nph_stale = true;
+            std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
+            write_resume();
+            return;
+        }
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
@@ -1371,9 +1400,10 @@ struct Engine {
             if (fresh_nursery && h_ctl->status == PC_ST_DONE && h_ctl->i_nursery == B) tm.batches--;
             nursery_left = h_ctl->i_nursery;
             tally_grades();
-            stream_dead();
             tm.rounds++;
-            if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; }
+            // dead rows leave for the host at every update (a copy per round, ~350 KB, next to the one-CU contraction cost it
+            // 6 us per launch: 72 against 66 us)
+            if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; stream_dead(); }
         }
         auto t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
@@ -1483,6 +1513,7 @@ struct Engine {
         { char *cs = (char *)d_cs; dfree(cs); d_cs = nullptr; }
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);
         if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
+        dfree(upd_part); dfree(upd_shift); upd_part_cap = 0;
         dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
