@@ -29,6 +29,8 @@ int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_nhats_splittable(const PcState *);
 int pc_launch_nhats_part(const PcState *, unsigned, int, int, hipStream_t);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
+int pc_slice_fusable(const PcState *);
+int pc_launch_slice_fused(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
@@ -1334,6 +1336,7 @@ struct Engine {
                 hipEvent_t e0 = kt.begin(KT_NHATS);
                 // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
                 const bool split = pc_nhats_splittable(&S) != 0 && raw_buf[1] && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
+                bool fused_slice = false;
                 if (split) {
                     // the bases of this nursery were drawn on the side stream while the last one was consumed (or are
                     // drawn now); bases of nursery b live in raw_buf[b & 1]
@@ -1341,13 +1344,14 @@ struct Engine {
                     if (pre_ready && pre_batch == batch && pre_B == B) HIPCHK(hipStreamWaitEvent(st, ev_side, 0));
                     else (void)pc_launch_nhats_part(&S, batch, B, 1, st);
                     pre_ready = false;
-                    (void)pc_launch_nhats_part(&S, batch, B, 2, st);
+                    fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
+                    if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
                 }
                 else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_NHATS, e0);
                 hipEvent_t e1 = kt.begin(KT_SLICE);
                 if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
-                else if (pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
                 if (split) {
                     // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the

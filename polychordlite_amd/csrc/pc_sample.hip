@@ -942,7 +942,12 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 // WPB = chains (wavefronts) per workgroup.  One, except for the correlated Gaussian with its inverse covariance in LDS:
 // an 80 KB matrix per chain left one wave per CU; WPB chains share one copy (every barrier below is executed the same
 // number of times by every chain: per slice, never per likelihood evaluation).
-template <int DPL, int NROWS, bool SPECIAL, int WPB = 1>
+// FW > 0 (production path for nDims <= 24, one grade): the kernel also does what the second half of k_nhats did -- seed
+// choice (GenerateSeed) and whitening of the orthonormal directions with the seed cluster's Cholesky factor -- so that
+// the directions never travel through HBM: a prologue whitens all of the chain's directions at once, lane = direction
+// (the loops of k_nhats, bit for bit: row sums in ascending b, the norm on four partial sums), into LDS, from where the
+// slices pick them up in deck order.  FW = unroll width >= nDims.
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -958,8 +963,32 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
     const bool seq_mode = SPECIAL && S.seq_mode != 0, graded = SPECIAL && S.ngrade > 1;
 
     LaneDims<DPL> ld;
-    const int slot = S.ch_seed_slot[chain];
-    const double contour = S.ch_contour[chain];
+    int slot, seed_cluster = 0;
+    double contour;
+    // FW: the loads of the whitening prologue are issued first -- raw direction `lane` (+64, ...) and the Cholesky factor of
+    // cluster 0 (the seed's cluster unless there are several) -- and travel while the seed is chosen and the deck shuffled
+    constexpr int FWN = FW > 0 ? FW : 1;
+    constexpr int FWL = FW > 0 ? (FW * FW + 63) / 64 : 1;
+    double vv0[FWN], Lpre[FWL];
+    if constexpr (FW > 0) {
+        const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;
+#pragma unroll
+        for (int d = 0; d < FWN; ++d) vv0[d] = (d < D && lane < nr) ? rawc[(size_t)lane * D + d] : 0.0;
+#pragma unroll
+        for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; Lpre[q] = (e < D * D) ? S.chol[e] : 0.0; }
+    }
+    if constexpr (FW > 0) {
+        int sel = 0, sl = 0;
+        if (lane == 0) {                          // GenerateSeed (generate.F90:19-55), nested_sampling.F90:267-273
+            select_seed(S, batch, chain, sel, sl);
+            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = sl;
+            S.ch_contour[chain] = S.logLp[sel];                      // nested_sampling.F90:270
+            S.ch_epoch[chain] = S.ctl->admin_epoch;
+            if (chain == 0) { S.ctl->i_nursery = gridDim.x * WPB; S.ctl->batch_id = batch; }
+        }
+        seed_cluster = __builtin_amdgcn_readfirstlane(sel); slot = __builtin_amdgcn_readfirstlane(sl);
+        contour = S.logLp[seed_cluster];
+    } else { slot = S.ch_seed_slot[chain]; contour = S.ch_contour[chain]; }
     double x0[DPL];
     {
         const double *seed = S.live + (size_t)slot * nT;
@@ -1057,6 +1086,48 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
 
     double ua = 0.0, ub = 0.0;                     // uniforms of 4 consecutive slices, 32 each
     double nh[DPL], nh_next[DPL], w_next;
+    // ---- FW: all directions of the chain whitened up front, lane = direction (what a thread of k_nhats did for its
+    //      vector, same loops): w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82); results in LDS
+    double *nhs = nullptr, *wsh = nullptr;
+    if constexpr (FW > 0) {
+        double *Lsh = tbuf + (phi_lds ? (size_t)nr * (D + 1) : 0);     // [FW][D] Cholesky factor, rows past D zero
+        nhs = Lsh + (size_t)FW * D;                                      // [nr][D + 1]
+        wsh = nhs + (size_t)nr * (D + 1);                               // [nr]
+        if (seed_cluster != 0) {                                         // (uniform) several clusters: the seed's factor
+            const double *Lg = S.chol + (size_t)seed_cluster * D * D;
+#pragma unroll
+            for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; Lpre[q] = (e < D * D) ? Lg[e] : 0.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; if (e < FW * D) Lsh[e] = Lpre[q]; }
+        __syncthreads();                                                // one wave per workgroup
+        const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;   // direction v (generation order) at + v * D
+        for (int v0 = 0; v0 < nr; v0 += 64) {
+            const int v = v0 + lane;
+            if (v < nr) {
+                double vv[FWN], t[FWN];
+#pragma unroll
+                for (int d = 0; d < FWN; ++d) { vv[d] = (v0 == 0) ? vv0[d] : ((d < D) ? rawc[(size_t)v * D + d] : 0.0); t[d] = 0.0; }
+#pragma unroll
+                for (int bb = 0; bb < FWN; ++bb)
+#pragma unroll
+                    for (int aa = bb; aa < FWN; ++aa) t[aa] += Lsh[(size_t)aa * D + bb] * vv[bb];
+#pragma unroll
+                for (int aa = 0; aa < FWN; ++aa) if (aa >= D) t[aa] = 0.0;
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+                for (int d = 0; d < FWN; d += 4) { p0 += t[d] * t[d]; p1 += t[d + 1] * t[d + 1]; p2 += t[d + 2] * t[d + 2]; p3 += t[d + 3] * t[d + 3]; }
+                const double wn = sqrt((p0 + p1) + (p2 + p3)), iw = 1.0 / wn;
+#pragma unroll
+                for (int d = 0; d < FWN; ++d) if (d < D) nhs[(size_t)v * (D + 1) + d] = t[d] * iw;
+                wsh[v] = wn * 3.0;
+            }
+        }
+        __syncthreads();
+        const int v0 = deck_in_regs ? __builtin_amdgcn_readlane(deck, 0) : sdeck[0];
+        nh_next[0] = (lane < D) ? nhs[(size_t)v0 * (D + 1) + lane] : 0.0;
+        w_next = wsh[v0];
+    } else
     {   // prefetch the first direction
         const int v0 = deck_in_regs ? __builtin_amdgcn_readlane(deck, 0) : sdeck[0];
         const double *p = S.nhat + ((size_t)chain * nr + v0) * D;
@@ -1089,6 +1160,13 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
         const int nl_before = C.nlike;
         int my_grade = 0;
         if (graded) my_grade = pc_grade_of(S, deck_in_regs ? __builtin_amdgcn_readlane(deck, s) : sdeck[s]);
+        if constexpr (FW > 0) {
+            if (s + 1 < nr) {
+                const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
+                nh_next[0] = (lane < D) ? nhs[(size_t)v1 * (D + 1) + lane] : 0.0;
+                w_next = wsh[v1];
+            }
+        } else
         if (s + 1 < nr) {                           // prefetch the next direction (hidden under this slice)
             const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
             const double *p = nh_base + v1 * D;
@@ -1332,6 +1410,31 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
     else if (D <= 32) hipLaunchKernelGGL((k_nhats<32, 64>), grid, dim3(64), sh, st, *S, batch);
     else if (D <= 64) hipLaunchKernelGGL((k_nhats<64, 64>), grid, dim3(64), sh, st, *S, batch);
     else return 1;
+    return 0;
+}
+
+extern "C" int pc_slice_fusable(const PcState *S)
+{   // the slice kernel can do seeds + whitening itself: raw bases in HBM (split launch), one grade, nDims <= 24
+    static const bool off = std::getenv("PC_SLICE_FUSED_OFF") != nullptr;
+    return !off && pc_nhats_splittable(S) && S->ngrade <= 1 && S->like.kind != PC_LIKE_CORR_GAUSSIAN && S->nr <= 1024;
+}
+
+extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    if (!pc_slice_fusable(S)) return 1;
+    const size_t sh0 = sizeof(double) * ((size_t)S->D + S->nr) + 16;
+    const size_t tb = sizeof(double) * (size_t)S->nr * (S->D + 1);
+    const int phi_lds = (S->nDer > 0 && sh0 + tb <= 48 * 1024) ? 1 : 0;
+    const int D = S->D, FWv = D <= 8 ? 8 : (D <= 16 ? 16 : 24);
+    const size_t sh = sh0 + (phi_lds ? tb : 0) + sizeof(double) * ((size_t)FWv * D + (size_t)S->nr * (D + 2));   // + L, directions, widths
+    if (sh > 150 * 1024) return 1;
+#define PC_SLICE_FUSED(NROWS, FW) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
+    if (D <= 8) PC_SLICE_FUSED(1, 8)
+    else if (D <= 16) PC_SLICE_FUSED(1, 16)
+    else PC_SLICE_FUSED(2, 24)
+#undef PC_SLICE_FUSED
     return 0;
 }
 
