@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolychord_hip.so")
+LIB_PATH = os.environ.get("PCHIP_LIB") or os.path.join(_HERE, "libpolychord_hip.so")     # (PCHIP_LIB: A/B runs of two builds on one GPU box)
 
 LOGLIKE_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int)
 PRIOR_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)

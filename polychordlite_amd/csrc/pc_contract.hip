@@ -784,14 +784,17 @@ __device__ __forceinline__ int wave_copy_masked(const double *src0, unsigned lon
     return n;
 }
 
-__global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
+// four waves per consumed chain: wave 0 also moves the dead row; the phantoms of a mask word are shared out among the
+// waves by runs of bits (a wave's rows go to consecutive rows behind those of the waves before it)
+#define PC_APPLY_WAVES 4
+__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S, unsigned batch)
 {
     const PcCtl *ctl = S.ctl;
     const int w = ctl->seg_lo + blockIdx.x;
     if (w > ctl->seg_hi) return;
-    const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nT = S.nT, nr = S.nr;
     const int di = S.plan[w].dead_idx;
-    if (di >= 0) {
+    if (di >= 0 && wv == 0) {
         const int src = S.plan[w].dead_src;
         const double *row = (src >= 0) ? S.live + (size_t)src * nT
                                        : S.babies + ((size_t)(-src - 1) * nr + (nr - 1)) * nT;
@@ -807,13 +810,17 @@ __global__ __launch_bounds__(64) void k_apply_dead_ph(PcState S, unsigned batch)
     const unsigned cuid = S.plan[w].ph_cuid;
     for (int m = 0; m < (nr + 62) / 64; ++m) {
         const unsigned long long mask = S.plan[w].ph_mask[m];
-        // side arrays: lane b owns baby m*64+b, its row offset is the number of selected babies before it
-        if ((mask >> lane) & 1ull) {
+        // side arrays: lane b of wave 0 owns baby m*64+b, its row offset is the number of selected babies before it
+        if (wv == 0 && ((mask >> lane) & 1ull)) {
             const int i = m * 64 + lane, dsti = base + __popcll(mask & ((1ull << lane) - 1ull));
             S.ph_logL[dsti] = S.baby_logL[(size_t)w * nr + i]; S.ph_cuid[dsti] = cuid;
             S.ph_uid[dsti] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
         }
-        base += wave_copy_masked(S.babies + ((size_t)w * nr + m * 64) * nT, mask, S.phantom + (size_t)base * nT, nT, lane);
+        // wave k takes bits [16k, 16k + 16)
+        const unsigned long long mine = mask & (0xFFFFull << (16 * wv));
+        const int before = __popcll(mask & ((1ull << (16 * wv)) - 1ull));
+        wave_copy_masked(S.babies + ((size_t)w * nr + m * 64) * nT, mine, S.phantom + (size_t)(base + before) * nT, nT, lane);
+        base += __popcll(mask);
     }
 }
 
@@ -1461,7 +1468,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
 
 extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64), 0, st, *S, batch);
+    hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64 * PC_APPLY_WAVES), 0, st, *S, batch);
     hipLaunchKernelGGL(k_apply_live, dim3(S->Ncap), dim3(64), 0, st, *S);
 }
 

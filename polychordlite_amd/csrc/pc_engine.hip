@@ -267,7 +267,7 @@ struct Engine {
     hipStream_t st_copy = nullptr;            // dead rows leave for the host while the run goes on
     hipStream_t st_side = nullptr;            // the orthonormal bases of the next nursery, while this one is consumed
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    bool pre_ready = false; unsigned pre_batch = 0; int pre_B = 0;
+    bool pre_ready = false, side_waited = false; unsigned pre_batch = 0; int pre_B = 0;
     double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
     PcCtl *h_ctl = nullptr;       // pinned mirror
     PcCtl *h_note = nullptr;      // pinned, device-visible: the contraction kernels publish the control block here (pc_publish_ctl)
@@ -1331,8 +1331,9 @@ struct Engine {
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
             bool fresh_nursery = false;
             if (h_ctl->i_nursery == 0) {
+                // (between the stamp of the last round and the launch of k_slice the device idles: nothing that can wait
+                //  is done in between -- capacity checks precede the contraction, not the sampling)
                 fresh_nursery = true;
-                ensure_capacity();
                 hipEvent_t e0 = kt.begin(KT_NHATS);
                 // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
                 const bool split = pc_nhats_splittable(&S) != 0 && raw_buf[1] && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
@@ -1341,7 +1342,7 @@ struct Engine {
                     // the bases of this nursery were drawn on the side stream while the last one was consumed (or are
                     // drawn now); bases of nursery b live in raw_buf[b & 1]
                     S.nhat_raw = raw_buf[batch & 1];
-                    if (pre_ready && pre_batch == batch && pre_B == B) HIPCHK(hipStreamWaitEvent(st, ev_side, 0));
+                    if (pre_ready && pre_batch == batch && pre_B == B) { if (!side_waited) HIPCHK(hipStreamWaitEvent(st, ev_side, 0)); }
                     else (void)pc_launch_nhats_part(&S, batch, B, 1, st);
                     pre_ready = false;
                     fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
@@ -1357,17 +1358,18 @@ struct Engine {
                     // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
                     // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
                     if (!st_side) { st_side = hpool().get_stream(); ev_side = hpool().get_event(); ev_main = hpool().get_event(); }
-                    HIPCHK(hipEventRecord(ev_main, st));
-                    HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0));
+                    static const bool side_free = std::getenv("PC_SIDE_FREE") != nullptr;
+                    if (!side_free) { HIPCHK(hipEventRecord(ev_main, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0)); }
                     PcState S1 = S; S1.nhat_raw = raw_buf[(batch + 1) & 1];
                     (void)pc_launch_nhats_part(&S1, batch + 1, B, 1, st_side);
                     HIPCHK(hipEventRecord(ev_side, st_side));
-                    pre_ready = true; pre_batch = batch + 1; pre_B = B;
+                    pre_ready = true; pre_batch = batch + 1; pre_B = B; side_waited = false;
                 }
                 if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
                 batch++; tm.batches++;
                 S.nn_valid = 0; nursery_left = B;
             }
+            if (fresh_nursery) ensure_capacity();
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
@@ -1395,8 +1397,9 @@ struct Engine {
             hipEvent_t e3 = kt.begin(KT_APPLY);
             pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
-            if (!ev_apply) ev_apply = hpool().get_event();
-            HIPCHK(hipEventRecord(ev_apply, st));           // the dead rows of this round are in place behind this point
+            // the main stream's wait for the next nursery's bases is enqueued now, behind this round's kernels (long
+            // satisfied when the next k_slice gets there), not between the stamp and the next launch
+            if (pre_ready && !side_waited) { HIPCHK(hipStreamWaitEvent(st, ev_side, 0)); side_waited = true; }
             wait_ctl();
             // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
             // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery
@@ -1407,7 +1410,12 @@ struct Engine {
             tm.rounds++;
             // dead rows leave for the host at every update (a copy per round, ~350 KB, next to the one-CU contraction cost it
             // 6 us per launch: 72 against 66 us)
-            if (h_ctl->status == PC_ST_UPDATE) { do_update(); h_ctl->status = PC_ST_RUNNING; stream_dead(); }
+            if (h_ctl->status == PC_ST_UPDATE) {
+                do_update(); h_ctl->status = PC_ST_RUNNING;
+                if (!ev_apply) ev_apply = hpool().get_event();
+                HIPCHK(hipEventRecord(ev_apply, st));       // the dead rows of the rounds so far are in place behind this point
+                stream_dead();
+            }
         }
         auto t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384

@@ -951,6 +951,7 @@ template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __builtin_amdgcn_s_setprio(3);                 // a chain is one long dependent instruction stream: it goes first on its SIMD
     const int lane = threadIdx.x & 63, wv = (WPB > 1) ? (int)(threadIdx.x >> 6) : 0, chain = blockIdx.x * WPB + wv;
     const size_t per_wave = ((size_t)S.D + S.nr + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0) + 1) & ~(size_t)1;   // doubles
     double *ybuf = (double *)smem + (size_t)wv * per_wave;   // [D] (corr gaussian only)
@@ -1232,25 +1233,64 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
         // shrinkage (:240-271)
         double lnew = logzero, t_last = 0.0;
         bool ok = false;
-        for (int it = 0; it <= 100; ++it) {
+        int it0 = 0;
+        if (C.quad && !seq_mode) {
+            // The first four trial points at once.  Where trial q lands does not depend on the likelihood of the trials
+            // before it, only on their positions (a rejected trial becomes the bracket end on its side of x0), and the
+            // uniforms are known: so the four positions "if everything before was rejected" are computed up front and
+            // their likelihoods -- closed form along the chord, a handful of dependent fp64 operations of ~32 cycles each
+            // on a wave that has its SIMD to itself -- are evaluated side by side instead of one after the other.  The
+            // first accepted one is the baby; the trials after it never happened (not counted, their draws given back):
+            // the same result and the same likelihood count as the loop, a third of its latency.
+            constexpr int NSP = 4;
+            const uint32_t kd0 = kdraw;
+            double tc[NSP], lc[NSP], tLb[NSP], tRb[NSP];
+            bool oc[NSP];
+            double tLc = tL, tRc = tR;
+#pragma unroll
+            for (int q = 0; q < NSP; ++q) {
+                const double dl = fabs(tLc), dr = fabs(tRc);
+                const double t = next_u() * (dr + dl) - dl;
+                tc[q] = t;
+                if (t > 0.0) tRc = t; else tLc = t;
+                tLb[q] = tLc; tRb[q] = tRc;                         // the bracket after rejecting trial q
+                bool outside = false;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) {
+                    const double cb = x0[k] + t * nh[k];
+                    if (ld.on[k]) outside |= (cb < 0.0) | (cb > 1.0);
+                }
+                oc[q] = __ballot(outside) != 0ull;
+                lc[q] = C.qnorm - (C.qa + t * (2.0 * C.qb + t * C.qc)) / 2.0;
+            }
+            int acc = -1;
+#pragma unroll
+            for (int q = 0; q < NSP; ++q) {
+                if (acc < 0) {
+                    const double lg = oc[q] ? logzero : lc[q];     // calculate.f90:36-38
+                    if (!oc[q] && lg > logzero) C.nlike++;
+                    t_last = tc[q]; lnew = lg;
+                    if (lg < contour || lg <= logzero) { tL = tLb[q]; tR = tRb[q]; }
+                    else acc = q;
+                }
+            }
+            if (acc >= 0) {
+                ok = true; kdraw = kd0 + (uint32_t)acc + 1u;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) { cube[k] = x0[k] + t_last * nh[k]; th[k] = ld.lo[k] + ld.span[k] * cube[k]; }
+            }
+            it0 = NSP;
+        }
+        for (int it = it0; it <= 100 && !ok; ++it) {
             const double dl = fabs(tL), dr = fabs(tR);
-#ifdef SLICE_DBG
-            const long long e0 = clock64();
-#endif
             const double t = next_u() * (dr + dl) - dl;
             t_last = t;
-#ifdef SLICE_DBG
-            asm volatile("" :: "v"(t));
-            const long long e1 = clock64();
-#endif
             lnew = eval_at<DPL, NROWS>(C, x0, nh, t, cube, th);
 #ifdef SLICE_DBG
-            asm volatile("" :: "v"(lnew));
-            const long long e2 = clock64();
-            nev++; scy[5] += e1 - e0; ev2 += e2 - e1;
+            nev++;
 #endif
             if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
-            else { ok = true; break; }
+            else ok = true;
         }
         if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
         if (corr) {                                 // the next start point: y and M.y move along the chord
