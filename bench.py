@@ -175,6 +175,7 @@ def main():
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
     s.nlive = nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
     s.do_clustering = wl["clustering"]
+    s.ablate = int(os.environ.get("PC_ABLATE", "0"))      # developer switches of the engine (A/B timing of a code path), 0 in production
     # HIP-event stopwatch on the run's own stream.  Warm-up: the four kernel classes a round consists of, every launch
     # (picks the two heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream
     # ~6 us, every launch of two classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
@@ -249,7 +250,7 @@ def main():
                    "logZ": [r["logZ"] for r in gr],
                    "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
         gr = None
-        s.ablate = 0
+        s.ablate = int(os.environ.get("PC_ABLATE", "0"))
     conc = None
     Rs = [int(x) for x in args.concurrent.split(",") if x.strip() and int(x) > 1] if args.concurrent else []
     if extras and Rs:
