@@ -116,8 +116,45 @@ def seed_runs(name, like, D, nDer, nlive, nr, seeds, comment, workdir=None, reus
         print(name, r)
 
 
+POST_CASES = [  # name like nDims nDerived nlive nrepeats seed clustering REF_POSTERIORS boost cluster_posteriors
+    ("pg", "gaussian", 3, 1, 50, 6, 5, 0, "pe", 0.0, 0), ("pgb", "gaussian", 3, 1, 50, 6, 5, 0, "pe", 3.0, 0),
+    ("pgp", "gaussian", 4, 1, 100, 20, 2, 0, "p", 0.0, 0), ("pr", "rastrigin", 2, 0, 100, 6, 3, 1, "pe", 0.0, 1),
+    ("prb", "rastrigin", 2, 0, 100, 6, 4, 1, "pe", 2.0, 0),
+]
+
+
+def posterior_cases(inj):
+    """update_posteriors / clean_phantoms / write_posterior_file of the reference (run_time_info.f90:820-877, :955-1066,
+    read_write.F90:479-617): injected runs with posteriors and / or equals switched on -- every Bernoulli trial of the
+    thinning is a draw of the injected stream, so the oracle in sequential mode must reproduce nposterior and nequals
+    exactly and the two files row for row.  -> tests/golden/ref_posteriors.json + ref_files/<name>.txt / _equal_weights.txt"""
+    import shutil
+    dst = os.path.join(GOLD, "ref_files")
+    os.makedirs(dst, exist_ok=True)
+    meta = []
+    for name, like, D, nDer, nlive, nr, seed, clus, flags, boost, cpost in POST_CASES:
+        sh(f"rm -rf {TMP}/post_{name}")
+        env = f"REF_POSTERIORS={flags} REF_BOOST={boost} " + ("REF_CLUSTER_POST=1 " if cpost else "")
+        j = last_json(sh(f"{env}{inj} {like} {D} {nDer} {nlive} {nr} {seed} {clus} {TMP}/post_{name} {name} 0"))
+        if "p" in flags:
+            shutil.copy(f"{TMP}/post_{name}/{name}.txt", os.path.join(dst, name + ".txt"))
+        if "e" in flags:
+            shutil.copy(f"{TMP}/post_{name}/{name}_equal_weights.txt", os.path.join(dst, name + "_equal_weights.txt"))
+        meta.append(dict(name=name, like=like, nDims=D, nDerived=nDer, nlive=nlive, num_repeats=nr, seed=seed, clustering=clus,
+                         posteriors=int("p" in flags), equals=int("e" in flags), boost_posterior=boost, cluster_posteriors=cpost,
+                         ndead=j["ndead"], nlike=j["nlike"], logZ=j["logZ"], logZerr=j["logZerr"], nposterior=j["nposterior"],
+                         nequals=j["nequals"], rng_consumed=j["rng_consumed"]))
+        print("posteriors", meta[-1])
+    json.dump(meta, open(os.path.join(GOLD, "ref_posteriors.json"), "w"), indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "posteriors":
+        os.makedirs(TMP, exist_ok=True)
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        posterior_cases(os.path.join(HERE, "_ref", "ref_driver_inject"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c3seeds":      # BASELINE configs[2]; `c3seeds <dir> reuse` collects finished runs
         subprocess.check_call(["make", "-C", HERE, "ref"])
         seed_runs("ref_c3_seeds", "rastrigin", 10, 0, 1000, 30, list(range(1, 13)),

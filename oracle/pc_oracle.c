@@ -1236,6 +1236,20 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
         out->varlogZp[c] = R->logZp2_dead[c] - 2 * R->logZp_dead[c];
     }
     out->nposterior_global = R->posterior_global.n; out->nequals_global = R->equals_global.n;
+    {   /* rows as write_posterior_file prints them, before its normalisation by the largest weight */
+        const int npar = R->D + R->nDer;
+        out->post_rows = (double *)malloc(sizeof(double) * (size_t)(R->posterior_global.n + 1) * (2 + npar));
+        for (int i = 0; i < R->posterior_global.n; ++i) {
+            const double *st = R->posterior_global.a + (size_t)i * R->npost;
+            double *o = out->post_rows + (size_t)i * (2 + npar);
+            o[0] = st[R->pos_w] + st[R->pos_l]; o[1] = st[R->pos_l];
+            memcpy(o + 2, st + R->pos_p0, sizeof(double) * npar);
+        }
+        out->equal_rows = (double *)malloc(sizeof(double) * (size_t)(R->equals_global.n + 1) * (1 + npar));
+        for (int i = 0; i < R->equals_global.n; ++i)
+            memcpy(out->equal_rows + (size_t)i * (1 + npar), R->equals_global.a + (size_t)i * R->np + 1, sizeof(double) * (1 + npar));
+        out->maxlogweight = R->maxlogweight_global;
+    }
     /* posterior mean / variance of theta from dead points: w_i = logweight_i + logL_i */
     out->post_mean = (double *)calloc(D, sizeof(double)); out->post_var = (double *)calloc(D, sizeof(double));
     {
@@ -1268,7 +1282,7 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
 void pc_result_free(pc_result *r)
 {
     free(r->dead); free(r->logweights); free(r->live); free(r->logZp); free(r->varlogZp);
-    free(r->post_mean); free(r->post_var);
+    free(r->post_mean); free(r->post_var); free(r->post_rows); free(r->equal_rows);
     memset(r, 0, sizeof(*r));
 }
 

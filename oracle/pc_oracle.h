@@ -124,6 +124,10 @@ typedef struct {
     double *post_mean; double *post_var;
     long nposterior_global, nequals_global;
     long nlike_grade[8];       /* likelihood calls per grade (RTI%nlike) */
+    /* the posterior arrays behind <root>.txt / <root>_equal_weights.txt (read_write.F90:479-617):
+     * post_rows [nposterior_global][2 + nDims + nDerived] = log posterior weight (logweight + logL), logL, theta, phi;
+     * equal_rows [nequals_global][1 + nDims + nDerived] = -2 logL, theta, phi; maxlogweight = RTI%maxlogweight_global */
+    double *post_rows, *equal_rows; double maxlogweight;
 } pc_result;
 
 void pc_settings_default(pc_settings *s, int nDims, int nDerived);

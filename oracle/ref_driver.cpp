@@ -120,15 +120,21 @@ int main(int argc, char **argv)
     if (pc_shim_reset) pc_shim_reset((unsigned)seed);
     auto t0 = std::chrono::steady_clock::now();
     const bool maximise = std::getenv("REF_MAXIMISE") != nullptr;       // optional: <root>.maximum (maximiser.F90)
-    polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, 0.0,
-                          false, false, false, write_resume, false, false, true, false, write_dead, false, maximise,
+    // optional: REF_POSTERIORS = "pe" / "p" / "e" (weighted and / or equally weighted posterior files, update_posteriors
+    // run_time_info.f90:955-1066), REF_BOOST = boost_posterior, REF_CLUSTER_POST = per-cluster posterior files
+    const char *rp = std::getenv("REF_POSTERIORS");
+    const bool posteriors = rp && std::strchr(rp, 'p'), equals = rp && std::strchr(rp, 'e');
+    const double boost = std::getenv("REF_BOOST") ? atof(std::getenv("REF_BOOST")) : 0.0;
+    const bool cluster_post = std::getenv("REF_CLUSTER_POST") != nullptr;
+    polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, boost,
+                          posteriors, equals, cluster_post, write_resume, false, false, true, false, write_dead, false, maximise,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
                           nGrade, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // parse <base>/<root>.stats (read_write.F90:842-889)
     std::string fn_stats = base + "/" + root + ".stats";
     FILE *f = std::fopen(fn_stats.c_str(), "r");
-    double logZ = 0, err = 0; long ndead = 0, nlike = 0; int ncl = 0; char line[512]; char nlike_line[256] = "";
+    double logZ = 0, err = 0; long ndead = 0, nlike = 0, npost = 0, nequals = 0; int ncl = 0; char line[512]; char nlike_line[256] = "";
     while (f && std::fgets(line, sizeof line, f)) {
         if (std::strncmp(line, "log(Z)", 6) == 0 && std::strstr(line, "+/-")) {
             const char *eq = std::strchr(line, '='); if (eq) std::sscanf(eq + 1, "%lf +/- %lf", &logZ, &err);
@@ -136,11 +142,13 @@ int main(int argc, char **argv)
         if (std::strstr(line, "ndead:")) std::sscanf(std::strstr(line, "ndead:") + 6, "%ld", &ndead);
         if (std::strstr(line, " nlike:")) { std::sscanf(std::strstr(line, "nlike:") + 6, "%ld", &nlike); std::snprintf(nlike_line, sizeof nlike_line, "%s", std::strstr(line, "nlike:") + 6); for (char *q = nlike_line; *q; ++q) if (*q == '\n') *q = 0; }
         if (std::strstr(line, "ncluster:")) std::sscanf(std::strstr(line, "ncluster:") + 9, "%d", &ncl);
+        if (std::strstr(line, "nposterior:")) std::sscanf(std::strstr(line, "nposterior:") + 11, "%ld", &npost);
+        if (std::strstr(line, "nequals:")) std::sscanf(std::strstr(line, "nequals:") + 8, "%ld", &nequals);
     }
     if (f) std::fclose(f);
     std::printf("{\"like\":\"%s\",\"nDims\":%d,\"nlive\":%d,\"num_repeats\":%d,\"seed\":%d,\"logZ\":%.15g,\"logZerr\":%.15g,"
-                "\"ndead\":%ld,\"nlike\":%ld,\"ncluster\":%d,\"calls\":%ld,\"rng_consumed\":%lu,\"wall\":%.4f,\"nlike_grades\":\"%s\"}\n",
-                like.c_str(), nDims, nlive, nrep, seed, logZ, err, ndead, nlike, ncl, g_calls,
+                "\"ndead\":%ld,\"nlike\":%ld,\"ncluster\":%d,\"nposterior\":%ld,\"nequals\":%ld,\"calls\":%ld,\"rng_consumed\":%lu,\"wall\":%.4f,\"nlike_grades\":\"%s\"}\n",
+                like.c_str(), nDims, nlive, nrep, seed, logZ, err, ndead, nlike, ncl, npost, nequals, g_calls,
                 pc_shim_consumed ? pc_shim_consumed() : 0ul, wall, nlike_line);
     return 0;
 }

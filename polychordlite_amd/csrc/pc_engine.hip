@@ -751,11 +751,24 @@ struct Engine {
         }
     }
 
+    // Sequential-stream test mode with posteriors = T: clean_phantoms draws one Bernoulli uniform for every phantom it
+    // removes (run_time_info.f90:857-859, even when thin_posterior = 0), all from the one generator: the engine's stream
+    // position moves on by as many, so that the next nursery draws what the reference binary's draws.  (The trials of
+    // update_posteriors for equals = T depend on the order of the reference's arrays and are not emulated: with
+    // equals = T the sequential mode is a valid run, not the reference's.)
+    void seq_consume(unsigned long long n)
+    {
+        if (!n) return;
+        h_ctl->seq += n;
+        HIPCHK(hipMemcpy(&S.ctl->seq, &h_ctl->seq, sizeof(unsigned long long), hipMemcpyHostToDevice));
+    }
+
     void do_update()
     {
         tm.updates++;
         // the round loop only sees the compact notification; whoever looks at evidences, counters or cluster ids gets the block
-        if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
+        const bool seq_post = S.seq_mode && (cfg.posteriors || cfg.equals);
+        if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
         call_dumper();
         const int nph = h_ctl->nphantom;
         static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
@@ -772,11 +785,12 @@ struct Engine {
             hipEvent_t e0 = kt.begin(KT_CLEAN);
             pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, st);
             kt.end(KT_CLEAN, e0);
-            if (cfg.resume_write || dumper || on_update) {
+            if (cfg.resume_write || dumper || on_update || seq_post) {
                 int total = nph;
                 HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 h_ctl->nphantom = total;
+                if (seq_post) seq_consume((unsigned long long)(nph - total));
             } else nph_stale = true;
             std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
             write_resume();
@@ -789,12 +803,13 @@ struct Engine {
         // The surviving count is written to the control block on the device.  Without clustering / resume files
         // nothing on the host needs it before the next round's read-back, so the update costs no extra sync: the
         // covariance grid is sized with the pre-clean count and the kernels clamp to the device value.
-        const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update || cfg.boost_posterior != 0.0;
+        const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update || cfg.boost_posterior != 0.0 || seq_post;
         int total = nph;
         if (need_count) {
             HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             h_ctl->nphantom = total;
+            if (seq_post) seq_consume((unsigned long long)(nph - total));
         } else nph_stale = true;
         std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
         pc_launch_reset_thresholds(&S, st);

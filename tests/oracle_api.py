@@ -45,7 +45,8 @@ class Result(C.Structure):
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int), ("logZp", C.POINTER(C.c_double)),
                 ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int), ("post_mean", C.POINTER(C.c_double)),
                 ("post_var", C.POINTER(C.c_double)), ("nposterior_global", C.c_long), ("nequals_global", C.c_long),
-                ("nlike_grade", C.c_long * 8)]
+                ("nlike_grade", C.c_long * 8), ("post_rows", C.POINTER(C.c_double)), ("equal_rows", C.POINTER(C.c_double)),
+                ("maxlogweight", C.c_double)]
 
 
 _lib = None
@@ -136,7 +137,10 @@ def run(s, like, prior):
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D,)).copy(),
-               nlike_grade=[int(v) for v in r.nlike_grade])
+               nlike_grade=[int(v) for v in r.nlike_grade], nposterior=int(r.nposterior_global), nequals=int(r.nequals_global),
+               maxlogweight=r.maxlogweight,
+               post_rows=np.ctypeslib.as_array(r.post_rows, shape=(max(r.nposterior_global, 1), 2 + D + s.nDerived))[:r.nposterior_global].copy(),
+               equal_rows=np.ctypeslib.as_array(r.equal_rows, shape=(max(r.nequals_global, 1), 1 + D + s.nDerived))[:r.nequals_global].copy())
     lib.pc_result_free(C.byref(r))
     return out
 

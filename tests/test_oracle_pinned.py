@@ -2,6 +2,7 @@
 `random_number` was fed the same Philox stream (tests/golden/ref_injected.json).  Every integer must
 coincide and logZ must agree to round-off: the restatement is pinned line by line, including kNN
 clustering, cluster splitting / death and the evidence bookkeeping."""
+import numpy as np
 import pytest
 
 from tests import oracle_api as orc
@@ -58,3 +59,35 @@ def test_oracle_keyed_mode_statistics_against_native_reference(golden):
         assert abs(o["post_mean"][0] - 0.5) < 0.02 and abs(np.sqrt(o["post_var"][0]) - 0.1) < 0.02
     ref_mean = np.mean([c["logZ"] for c in ref]); sig = ref[0]["logZerr"]
     assert abs(np.mean(zs) - ref_mean) < 3 * sig * np.sqrt(1 / 4 + 1 / 8)
+
+
+def test_posterior_machinery_reproduces_the_reference_binary(golden):
+    """R13: clean_phantoms / update_posteriors / write_posterior_file (run_time_info.f90:820-877, :955-1066,
+    read_write.F90:479-617).  Every Bernoulli trial of the thinning is a draw of the reference's generator; with the injected
+    stream (oracle/ref_rng_shim.c) the oracle in sequential mode reproduces the runs with posteriors / equals switched on
+    -- with and without boost_posterior, clustered and not, cluster_posteriors -- exactly: nposterior and nequals as
+    integers, <root>.txt and <root>_equal_weights.txt row for row (files written by the reference binary:
+    tests/golden/ref_files/p*.txt, oracle/gen_golden.py posteriors)."""
+    import os
+    box = {"gaussian": (None, None), "rastrigin": (-5.12, 5.12)}
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_files")
+    assert len(golden["ref_posteriors"]) >= 5
+    for c in golden["ref_posteriors"]:
+        lo, hi = box[c["like"]]
+        so = orc.settings(c["nDims"], c["nDerived"], nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"],
+                          do_clustering=c["clustering"], sequential_rng=1, time_speeds_draw=1, posteriors=c["posteriors"],
+                          equals=c["equals"], boost_posterior=c["boost_posterior"], cluster_posteriors=c["cluster_posteriors"])
+        L, P, keep = orc.make_problem(c["like"], c["nDims"], lo, hi)
+        o = orc.run(so, L, P)
+        assert (o["ndead"], o["nlike"], o["nposterior"], o["nequals"]) == (c["ndead"], c["nlike"], c["nposterior"], c["nequals"]), c["name"]
+        assert abs(o["logZ"] - c["logZ"]) < 1e-10
+        if c["posteriors"]:
+            ref = np.loadtxt(os.path.join(gold, c["name"] + ".txt"))
+            w = np.exp(o["post_rows"][:, 0] - o["maxlogweight"])
+            mine = np.column_stack([w, -2 * o["post_rows"][:, 1], o["post_rows"][:, 2:]])[w > 0]
+            assert mine.shape == ref.shape
+            assert (np.abs(mine - ref) / np.maximum(1e-300, np.abs(ref))).max() < 1e-12       # fifteen printed digits
+        if c["equals"]:
+            ref = np.loadtxt(os.path.join(gold, c["name"] + "_equal_weights.txt"))
+            mine = np.column_stack([np.ones(o["nequals"]), o["equal_rows"]])
+            assert mine.shape == ref.shape and np.abs(mine - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())

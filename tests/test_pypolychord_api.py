@@ -801,3 +801,66 @@ def test_feedback_levels_print_like_the_reference(engine, tmp_path, capfd):
     nd = [int(l.split("=")[1]) for l in out1.splitlines() if l.startswith("ndead      =")]
     assert nd == sorted(nd) and 0 < nd[-1] <= loud.ndead
     assert (quiet.ndead, quiet.nlike, quiet.logZ) == (box.ndead, box.nlike, box.logZ) == (loud.ndead, loud.nlike, loud.logZ)
+
+
+@pytest.mark.gpu
+def test_weighted_posterior_file_equals_the_reference_binary(engine, golden, tmp_path, monkeypatch):
+    """R13, engine side: with posteriors = T the reference draws one uniform for every phantom its clean_phantoms removes
+    (run_time_info.f90:857-859) -- the engine's sequential-stream mode accounts for them, so it still walks the reference
+    binary's run, and its <root>.txt (weight, -2 logL, theta, phi of every dead point: update_posteriors :1050-1054,
+    write_posterior_file read_write.F90:560-566) must be the file the reference wrote (tests/golden/ref_files/pgp.txt)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("PC_SEQUENTIAL_RNG", "1")
+    c = [x for x in golden["ref_posteriors"] if x["name"] == "pgp"][0]
+    s = pypolychord.PolyChordSettings(c["nDims"], c["nDerived"], nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"],
+                                      do_clustering=False, read_resume=False, write_resume=False, write_dead=True, write_stats=True,
+                                      posteriors=True, equals=False, write_prior=False, write_live=False, base_dir=str(tmp_path),
+                                      file_root="pgp", feedback=0)
+    out = pypolychord.run_polychord(dl.Gaussian(0.5, 0.1, nDerived=1), c["nDims"], c["nDerived"], s, dl.UniformPrior(0.0, 1.0))
+    assert out.ndead == c["ndead"] and out.nposterior == c["nposterior"] and out.nlike == c["nlike"]
+    assert abs(out.logZ - c["logZ"]) < 1e-9 and abs(out.logZerr - c["logZerr"]) < 1e-9
+    ref = np.loadtxt(os.path.join(root, "tests", "golden", "ref_files", "pgp.txt"))
+    got = np.loadtxt(tmp_path / "pgp.txt")
+    assert got.shape == ref.shape
+    assert (np.abs(got - ref) / np.maximum(1e-300, np.abs(ref))).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,B,boost,clus", [("gaussian", 4, 1, 150, 8, 32, 0.0, 0), ("gaussian", 4, 1, 150, 8, 32, 3.0, 0),
+                                                              ("rastrigin", 2, 0, 200, 6, 25, 2.0, 1)])
+def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nlive, nr, B, boost, clus):
+    """R13 in production mode (keyed streams, B chains per nursery) against the oracle -- whose posterior machinery the
+    reference binary pins (tests/test_oracle_pinned.py): the weighted posterior <root>.txt holds the same points with the
+    same weights, the phantoms kept by boost_posterior included (their Bernoulli trials are keyed by the phantom's id in
+    both); the equally weighted file is thinned once at the end with probability weight / largest weight instead of
+    incrementally at every update (the same marginal probability for every point: run_time_info.f90:975-1026 re-thins
+    survivors by the ratio of successive maxima), so its size is compared with its expectation."""
+    from tests import oracle_api as orc
+    lib = engine.load(); lib.polychord_hip_set_option(b"batch", float(B))
+    try:
+        lo, hi = (-5.12, 5.12) if kind == "rastrigin" else (0.0, 1.0)
+        like = dl.Rastrigin() if kind == "rastrigin" else dl.Gaussian(0.5, 0.1, nDerived=nDer)
+        s = pypolychord.PolyChordSettings(D, nDer, nlive=nlive, num_repeats=nr, seed=17, do_clustering=bool(clus), read_resume=False,
+                                          write_resume=False, write_dead=False, write_stats=True, posteriors=True, equals=True,
+                                          boost_posterior=boost, write_prior=False, write_live=False, base_dir=str(tmp_path),
+                                          file_root="k", feedback=0, cluster_posteriors=False)
+        out = pypolychord.run_polychord(like, D, nDer, s, dl.UniformPrior(lo, hi))
+    finally:
+        lib.polychord_hip_set_option(b"batch", 0.0)
+    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=17, batch=B, do_clustering=clus, posteriors=1, equals=1, boost_posterior=boost)
+    Lo, Po, keep = orc.make_problem(kind, D, None if kind == "gaussian" else lo, None if kind == "gaussian" else hi)
+    o = orc.run(so, Lo, Po)
+    assert out.ndead == o["ndead"] and abs(out.logZ - o["logZ"]) < 1e-8
+    w = np.exp(o["post_rows"][:, 0] - o["maxlogweight"])
+    ref = np.column_stack([w, -2 * o["post_rows"][:, 1], o["post_rows"][:, 2:]])[w > 0]
+    got = np.loadtxt(tmp_path / "k.txt")
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    key = lambda a: a[np.lexsort(a.T[::-1])]                     # the engine lists the kept phantoms after the dead points
+    assert (np.abs(key(got) - key(ref)) / np.maximum(1e-300, np.abs(key(ref)))).max() < 1e-7
+    assert out.nposterior == ref.shape[0]
+    eq = np.loadtxt(tmp_path / "k_equal_weights.txt")
+    expect, var = got[:, 0].sum(), (got[:, 0] * (1 - got[:, 0])).sum()
+    assert abs(eq.shape[0] - expect) < 5 * np.sqrt(var) + 1, (eq.shape[0], expect)
+    assert abs(o["nequals"] - expect) < 5 * np.sqrt(var) + 1                       # and so is the oracle's (the reference's)
+    assert np.all(eq[:, 0] == 1.0)
