@@ -566,6 +566,9 @@ static void c_interface_impl(
         }
         s.nGrade = nGrade; s.grade_dims = grade_dims; s.grade_repeats = g_reps.data();
     } else if (nGrade == 1 && grade_dims && grade_dims[0] != nDims) halt_program("polychord_hip: grade_dims must sum to nDims");
+    // one grade whose grade_frac exceeds 1: the reference takes it as THE number of repeats (generate.F90:303-309,
+    // RTI%num_repeats = int(grade_frac) when no entry is <= 1), whatever num_repeats says
+    if (nGrade == 1 && grade_frac && grade_frac[0] > 1.0) num_repeats = (int)grade_frac[0];
     s.nlive = nlive; s.num_repeats = num_repeats; s.nprior = nprior; s.nfail = nfail; s.do_clustering = do_clustering;
     s.feedback = feedback; s.precision_criterion = precision_criterion; s.logzero = logzero; s.max_ndead = max_ndead;
     s.boost_posterior = boost_posterior; s.posteriors = posteriors; s.equals = equals; s.cluster_posteriors = cluster_posteriors;

@@ -1180,7 +1180,8 @@ struct Engine {
                 r.num_repeats.push_back(S.g_nr[g]); r.nlike.push_back(ng[g]);
             }
         }
-        r.logZ = h_ctl->logZ; r.logZ2 = h_ctl->logZ2; r.thin_posterior = cfg.boost_posterior; r.logX_last_update = h_ctl->logX_last_update;
+        r.logZ = h_ctl->logZ; r.logZ2 = h_ctl->logZ2; r.logX_last_update = h_ctl->logX_last_update;
+        r.thin_posterior = cfg.boost_posterior < 0.0 ? 1.0 : cfg.boost_posterior / (double)S.nr;      // generate.F90:311-316
         auto take = [&](const double *p) { auto v = dl(p, std::max(1, nc)); v.resize(nc); return v; };
         r.logLp = take(S.logLp); r.logXp = take(S.logXp); r.logZXp = take(S.logZXp); r.logZp = take(S.logZp);
         r.logZp2 = take(S.logZp2); r.logZpXp = take(S.logZpXp);
@@ -1216,6 +1217,52 @@ struct Engine {
         r.logweights = dl(S.dead_logw, std::max(1, r.ndead)); r.logweights.resize(r.ndead);
     }
 
+    // The reference's .resume grammar has no place for what this engine derives its posterior files from: the cluster
+    // every dead point died in (a stable id), the genealogy of the splits with the evidence fractions, the phantoms kept
+    // by boost_posterior.  They travel in a sidecar next to the file, <path>.hip (binary, this engine only); a run that
+    // resumes from a .resume without it -- one the reference wrote -- has the evidences and the global posterior of
+    // the dead points, and per-cluster posteriors from the resume point on.
+    void write_sidecar(const std::string &path, int ndead, int nc, int ncd)
+    {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) engine_fail(PC_RC_RESUME, "cannot write %s", path.c_str());
+        auto put = [&](const void *p, size_t n) { if (n && std::fwrite(p, 1, n, f) != n) { std::fclose(f); engine_fail(PC_RC_RESUME, "short write to %s", path.c_str()); } };
+        const unsigned magic = 0x50434831u;   // "PCH1"
+        const int np = S.D + S.nDer + 2, nsplit = (int)split_child.size(), npp = (int)pp_logpost.size();
+        const unsigned next_uid = h_ctl->next_cluster_uid;
+        auto dc = dl(S.dead_cuid, (size_t)std::max(1, ndead)); auto ua = dl(S.cl_uid, (size_t)std::max(1, nc)); auto ud = dl(S.cl_uid_dead, (size_t)std::max(1, ncd));
+        put(&magic, 4); put(&ndead, 4); put(&nc, 4); put(&ncd, 4); put(&next_uid, 4); put(&nsplit, 4); put(&npp, 4); put(&np, 4);
+        put(dc.data(), sizeof(unsigned) * ndead); put(ua.data(), sizeof(unsigned) * nc); put(ud.data(), sizeof(unsigned) * ncd);
+        put(split_child.data(), sizeof(unsigned) * nsplit); put(split_parent.data(), sizeof(unsigned) * nsplit); put(split_logfrac.data(), sizeof(double) * nsplit);
+        put(pp_rows.data(), sizeof(double) * (size_t)npp * np); put(pp_logpost.data(), sizeof(double) * npp); put(pp_cuid.data(), sizeof(unsigned) * npp);
+        std::fclose(f);
+    }
+    struct Sidecar { bool ok = false; unsigned next_uid = 1; std::vector<unsigned> dead_cuid, uid, uid_dead; };
+    Sidecar read_sidecar(const std::string &path, int ndead, int nc, int ncd)
+    {
+        Sidecar sc;
+        FILE *f = std::fopen(path.c_str(), "rb");
+        if (!f) return sc;
+        auto get = [&](void *p, size_t n) { return n == 0 || std::fread(p, 1, n, f) == n; };
+        unsigned magic = 0; int nd = 0, c = 0, cd = 0, nsplit = 0, npp = 0, np = 0;
+        bool good = get(&magic, 4) && magic == 0x50434831u && get(&nd, 4) && get(&c, 4) && get(&cd, 4) && get(&sc.next_uid, 4) &&
+                    get(&nsplit, 4) && get(&npp, 4) && get(&np, 4) && nd == ndead && c == nc && cd == ncd && np == S.D + S.nDer + 2 &&
+                    nsplit >= 0 && npp >= 0;
+        if (good) {
+            sc.dead_cuid.resize(nd); sc.uid.resize(c); sc.uid_dead.resize(cd);
+            split_child.resize(nsplit); split_parent.resize(nsplit); split_logfrac.resize(nsplit);
+            pp_rows.resize((size_t)npp * np); pp_logpost.resize(npp); pp_cuid.resize(npp);
+            good = get(sc.dead_cuid.data(), sizeof(unsigned) * nd) && get(sc.uid.data(), sizeof(unsigned) * c) && get(sc.uid_dead.data(), sizeof(unsigned) * cd) &&
+                   get(split_child.data(), sizeof(unsigned) * nsplit) && get(split_parent.data(), sizeof(unsigned) * nsplit) &&
+                   get(split_logfrac.data(), sizeof(double) * nsplit) && get(pp_rows.data(), sizeof(double) * (size_t)npp * np) &&
+                   get(pp_logpost.data(), sizeof(double) * npp) && get(pp_cuid.data(), sizeof(unsigned) * npp);
+        }
+        std::fclose(f);
+        if (!good) { split_child.clear(); split_parent.clear(); split_logfrac.clear(); pp_rows.clear(); pp_logpost.clear(); pp_cuid.clear(); }
+        sc.ok = good;
+        return sc;
+    }
+
     void write_resume()
     {
         if (!cfg.resume_write) return;
@@ -1223,6 +1270,7 @@ struct Engine {
         export_resume(r);
         std::string err;
         if (!pc_resume_write(cfg.resume_write, r, cfg.logzero, err)) engine_fail(PC_RC_RESUME, "%s", err.c_str());
+        write_sidecar(std::string(cfg.resume_write) + ".hip", r.ndead, r.ncluster, r.ncluster_dead);
     }
 
     // upload a .resume state; the run continues with the counter RNG streams of batch `ndead` onwards
@@ -1244,10 +1292,11 @@ struct Engine {
         std::vector<double> rows((size_t)Ncap * nT, 0.0), lL(Ncap, PC_HUGE), entry(Ncap, cfg.logzero);
         std::vector<int> lc(Ncap, -1), lp(Ncap, 0), cl((size_t)maxc * Ncap, 0), cn(maxc, 0), imin(maxc, 0);
         std::vector<unsigned> uid(maxc, 0u);
+        const Sidecar sc = cfg.resume_read ? read_sidecar(std::string(cfg.resume_read) + ".hip", r.ndead, nc, std::min(r.ncluster_dead, S.maxc_dead)) : Sidecar{};
         std::vector<double> logLp(maxc, cfg.logzero), lref(maxc, 0.0), lsum(maxc, 0.0);
         int slot = 0;
         for (int c = 0; c < nc; ++c) {
-            cn[c] = r.nlive[c]; uid[c] = (unsigned)(c + 1);
+            cn[c] = r.nlive[c]; uid[c] = sc.ok ? sc.uid[c] : (unsigned)(c + 1);
             double lo = PC_HUGE, hi = -PC_HUGE;
             for (int k = 0; k < r.nlive[c]; ++k, ++slot) {
                 const double *row = r.live[c].data() + (size_t)k * nT;
@@ -1278,6 +1327,7 @@ struct Engine {
         ul(S.cov, cov); ul(S.chol, ch);
         const int ncd = std::min(r.ncluster_dead, S.maxc_dead);
         { std::vector<double> a(r.logZp_dead.begin(), r.logZp_dead.begin() + ncd), b(r.logZp2_dead.begin(), r.logZp2_dead.begin() + ncd); ul(S.logZp_dead, a); ul(S.logZp2_dead, b); }
+        if (sc.ok) ul(S.cl_uid_dead, sc.uid_dead);
         // phantoms, cluster by cluster
         std::vector<double> ph((size_t)std::max(1, nph) * nT), phL(std::max(1, nph));
         std::vector<unsigned> phC(std::max(1, nph)); std::vector<unsigned long long> phU(std::max(1, nph));
@@ -1294,11 +1344,13 @@ struct Engine {
             std::vector<double> z(r.ndead, 0.0), en(r.ndead);
             for (int i = 0; i < r.ndead; ++i) en[i] = r.dead[(size_t)i * nT + S.b0];
             ul(S.dead_postX, z); ul(S.dead_postZ, z); ul(S.dead_entry, en);
-            std::vector<unsigned> du(r.ndead, 0u); ul(S.dead_cuid, du);
+            std::vector<unsigned> du(r.ndead, 0u);
+            if (sc.ok) du = sc.dead_cuid;
+            ul(S.dead_cuid, du);
         }
         PcCtl c0 = *h_ctl;
         c0.status = nc >= 1 ? PC_ST_RUNNING : PC_ST_DONE; c0.ncluster = nc; c0.ncluster_dead = ncd; c0.ndead = r.ndead; c0.nphantom = nph;
-        c0.logZ = r.logZ; c0.logZ2 = r.logZ2; c0.logX_last_update = r.logX_last_update; c0.next_cluster_uid = (unsigned)nc + 1;
+        c0.logZ = r.logZ; c0.logZ2 = r.logZ2; c0.logX_last_update = r.logX_last_update; c0.next_cluster_uid = sc.ok ? sc.next_uid : (unsigned)nc + 1;
         c0.nlike = 0;                                  // the engine's counter is the total over the grades
         for (size_t g = 0; g < r.nlike.size(); ++g) { c0.nlike += r.nlike[g]; if (g >= 1 && g < PC_MAX_GRADE) nlike_g[g] = r.nlike[g]; }
         c0.nlike_device = c0.nlike; c0.i_nursery = 0; c0.failures = 0;

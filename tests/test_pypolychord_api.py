@@ -864,3 +864,55 @@ def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nli
     assert abs(eq.shape[0] - expect) < 5 * np.sqrt(var) + 1, (eq.shape[0], expect)
     assert abs(o["nequals"] - expect) < 5 * np.sqrt(var) + 1                       # and so is the oracle's (the reference's)
     assert np.all(eq[:, 0] == 1.0)
+
+
+@pytest.mark.gpu
+def test_resumed_run_keeps_its_posterior_bookkeeping(engine, tmp_path):
+    """a clustered run restarted from a .resume file written while it was under way (a copy taken from the dumper): the
+    cluster every earlier dead point died in, the genealogy of the splits and the phantoms kept by boost_posterior travel
+    in the sidecar <root>.resume.hip, so the per-cluster posterior files of the finished run hold the points from before
+    the interruption too (every weighted dead point is in the file of its cluster and of all that cluster's
+    descendants), and the resume file carries the reference's thin factor boost / num_repeats (generate.F90:311-316)."""
+    import shutil
+    from polychordlite_amd import pypolychord as pc
+    from polychordlite_amd.pypolychord.device_likelihoods import Rastrigin, UniformPrior
+    base1, base = tmp_path / "a", tmp_path / "ch"
+    snap = {}
+
+    def dumper(live, dead, logw, logZ, logZerr):
+        f = base1 / "r.resume"
+        if "nd" not in snap and f.exists() and (base1 / "r.resume.hip").exists():
+            lines = open(f).read().splitlines()
+            if int(lines[7]) >= 3 and int(lines[5]) >= 1200:           # clusters alive, dead points so far
+                (base / "clusters").mkdir(parents=True, exist_ok=True)
+                shutil.copy(f, base / "r.resume"); shutil.copy(base1 / "r.resume.hip", base / "r.resume.hip")
+                snap["nd"] = int(lines[5])
+    kw = dict(file_root="r", nlive=300, num_repeats=6, do_clustering=True, feedback=0, seed=9,
+              prior=UniformPrior(-5.12, 5.12), posteriors=True, equals=True, cluster_posteriors=True, boost_posterior=2.0,
+              write_resume=True, read_resume=True, write_live=False, write_prior=False)
+    pc.run(Rastrigin(), 2, base_dir=str(base1), dumper=dumper, **kw)
+    assert snap.get("nd", 0) >= 1200
+    lines = (base / "r.resume").read_text().splitlines()
+    k = lines.index("=== posterior thin factor ===")
+    assert abs(float(lines[k + 1]) - 2.0 / 6.0) < 1e-12
+    pc.run(Rastrigin(), 2, base_dir=str(base), **kw)
+    st = open(base / "r.stats").read().splitlines()
+    logZ = float(st[8].split("=")[1].split("+/-")[0])
+    zk = sorted((float(l.split("=")[1].split("+/-")[0]) for l in st if l.startswith("log(Z_")), reverse=True)
+    files = sorted((f for f in (base / "clusters").glob("r_[0-9]*.txt") if "equal" not in f.name), key=lambda p: int(p.stem.split("_")[1]))
+    assert len(files) == len(zk) >= 8
+    glob_post = np.loadtxt(base / "r.txt")
+    ndead_file = np.loadtxt(base / "r_dead-birth.txt").shape[0]
+    assert glob_post.shape[0] > ndead_file                           # dead points of both legs + the phantoms boost_posterior kept
+    rows = 0; mix = np.zeros(2); ftot = 0.0
+    for kf, f in enumerate(files):
+        a = np.atleast_2d(np.loadtxt(f))
+        if a.size == 0:
+            continue
+        rows += a.shape[0]
+        frac = np.exp(zk[kf] - logZ)
+        assert abs(a[:, 0].max() - frac) < 1e-9 * max(1.0, frac)
+        mix += frac * (a[:, 0:1] * a[:, 2:4]).sum(0) / a[:, 0].sum(); ftot += frac
+    assert rows >= glob_post.shape[0]                                # nobody is missing (inherited points are counted more than once)
+    gmean = (glob_post[:, 0:1] * glob_post[:, 2:4]).sum(0) / glob_post[:, 0].sum()
+    assert abs(ftot - 1.0) < 0.1 and np.all(np.abs(mix / ftot - gmean) < 0.15)
