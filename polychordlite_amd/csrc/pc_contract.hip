@@ -1438,6 +1438,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
             if (sh > done_) { hipFuncSetAttribute((const void *)k_consume<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_ = sh; } \
             hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x, xq_n, sgl); \
             return 0; }
+        if (wide_nt == 64) PC_CONSUME_LAUNCH(64)
         if (wide_nt == 128) PC_CONSUME_LAUNCH(128)
         if (wide_nt == 512) PC_CONSUME_LAUNCH(512)
         PC_CONSUME_LAUNCH(256)

@@ -3,12 +3,12 @@
 # command, summaries copied to profiles/<tag>_* (rocprofv3 output itself stays under gpurun_out/, which is scratch).
 # PMC passes carry --kernel-trace only (no other trace domain), one counter per pass.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out" profiles
-BENCH="python bench.py --no-cpu --steps 3 --warmup 1 --concurrent 0"
+BENCH="python bench.py --no-cpu --no-extras --steps 3 --warmup 1"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- $BENCH > "$out/stats.log" 2>&1
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_kernel_stats.csv"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o p -- $BENCH > "$out/fetch.log" 2>&1
