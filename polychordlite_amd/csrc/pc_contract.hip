@@ -808,6 +808,38 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
     }
     int base = S.plan[w].ph_base;
     const unsigned cuid = S.plan[w].ph_cuid;
+    if (S.plan[w].ph_count == -2) {
+        // a region of nr rows for this chain (parallel contraction): baby i is a phantom if it lies above the contour
+        // the chain was consumed at and then occupies row base + i; the rest of the region is marked with PC_CUID_NONE
+        const double Lg = S.plan[w].contour;
+        for (int m = 0; m < (nr + 63) / 64; ++m) {
+            const int i = m * 64 + lane;
+            const double bl = (i < nr) ? S.baby_logL[(size_t)w * nr + i] : -PC_HUGE;
+            const bool sel = (i < nr - 1) && bl > Lg;
+            const unsigned long long mask = __ballot(sel);
+            if (wv == 0 && i < nr) {
+                S.ph_logL[base + i] = bl; S.ph_cuid[base + i] = sel ? cuid : PC_CUID_NONE;
+                S.ph_uid[base + i] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
+            }
+            // wave k copies the rows of bits [16k, 16k + 16), eight in flight
+            unsigned long long mine = mask & (0xFFFFull << (16 * wv));
+            const double *src0 = S.babies + ((size_t)w * nr + m * 64) * nT;
+            double *dst0 = S.phantom + (size_t)(base + m * 64) * nT;
+            while (mine) {
+                int idx[8], cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { idx[u] = 0; if (mine) { idx[u] = __ffsll((long long)mine) - 1; mine &= mine - 1; cnt = u + 1; } }
+                for (int e = lane; e < nT; e += 64) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (u < cnt) v[u] = src0[(size_t)idx[u] * nT + e];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (u < cnt) dst0[(size_t)idx[u] * nT + e] = v[u];
+                }
+            }
+        }
+        return;
+    }
     for (int m = 0; m < (nr + 62) / 64; ++m) {
         const unsigned long long mask = S.plan[w].ph_mask[m];
         // side arrays: lane b of wave 0 owns baby m*64+b, its row offset is the number of selected babies before it

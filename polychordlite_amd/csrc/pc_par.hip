@@ -509,45 +509,19 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #ifdef PAR_DBG_PUBLISH
     pcy[1] = clock64();
 #endif
-    // phantoms of the consumed chains (run_time_info.f90:747-757): the babies above the contour their
-    // chain was consumed at; masks, counts and row offsets in consumption order (deterministic layout)
-    int phc = 0;
-    if (inT && tid < ts) {
-        // slice-major copy of the babies' logL: lane = chain, every load of the wave is one contiguous run
-        PcPlan *pw = S.plan + w;
-        const double Lg = valid ? key2d(gk) : PC_HUGE;
-        const double *bl = S.baby_logL_T + w;
-        for (int mw = 0; mw < (nr + 62) / 64; ++mw) {
-            unsigned long long mask = 0ull;
-            const int i1 = min(nr - 1, mw * 64 + 64);
-            for (int i0 = mw * 64; i0 < i1; i0 += 8) {    // eight independent loads in flight
-                double v8[8];
-                #pragma unroll
-                for (int u = 0; u < 8; ++u) v8[u] = (i0 + u < i1) ? bl[(size_t)(i0 + u) * S.B] : -PC_HUGE;
-                #pragma unroll
-                for (int u = 0; u < 8; ++u) if (v8[u] > Lg) mask |= 1ull << ((i0 + u) & 63);
-            }
-            pw->ph_mask[mw] = mask;
-            phc += __popcll(mask);
-        }
-    }
-#ifdef PAR_DBG_PUBLISH
-    pcy[2] = clock64();
-#endif
-    int phi = phc;                                        // inclusive prefix over the steps
-    for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(phi, k); if (lane >= k) phi += o; }
-    if (lane == 63) accStep[wv] = phi;
+    // phantoms of the consumed chains (run_time_info.f90:747-757): the babies above the contour their chain was
+    // consumed at.  Which babies those are is a comparison with pw->contour that the row-copy kernel, one workgroup per
+    // chain on the whole chip, does for itself: every consumed chain gets a region of nr rows of the phantom array in
+    // consumption order (ph_count = -2), its phantoms land in it at their own index and the other rows of the region
+    // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
+    // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
+    if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = nph0 + tid * nr; pw->ph_count = -2; }
     for (int s = tid; s < Ncap; s += PAR_NT) S.slot_src[s] = -1;
     if (lane == 0) accR[wv] = 0ull;
+    if (tid == 0) ish[2] = nph0 + ts * nr;               // rows in use after this launch
     __syncthreads();
-    {
-        int pbase = nph0;
-        for (int x = 0; x < wv; ++x) pbase += accStep[x];
-        if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = pbase + phi - phc; pw->ph_count = phc; }
-        if (tid == PAR_NT - 1) ish[2] = pbase + phi;     // rows in use after this launch
-    }
 #ifdef PAR_DBG_PUBLISH
-    pcy[3] = clock64();
+    pcy[2] = clock64(); pcy[3] = pcy[2];
 #endif
     const bool accT = acc && tid < ts;
     if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));

@@ -43,6 +43,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
 #define PC_MAX_GRADE 8
 #define PC_NN_K 8
 #define PC_NN_NONE (-2147483647 - 1)
+#define PC_CUID_NONE 0xFFFFFFFEu   /* ph_cuid of a row of the phantom array that holds no phantom (no cluster has this id; the first cluster's id is 0) */
 
 struct PcPlan {                  // one record per nursery chain, written by the consume kernel
     int dead_idx;                // index in dead[] or -1
