@@ -60,7 +60,7 @@ int pc_launch_covmats(const PcState *, int, int, double *, int *, double *, int 
 int pc_update_fused_ok(const PcState *, int);
 int pc_update_fused_blocks(const PcState *, int);
 int pc_update_fused_entries(const PcState *);
-void pc_launch_update_fused(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *, unsigned long long *, double *, double *, hipStream_t);
+void pc_launch_update_fused(const PcState *, int, unsigned char *, int *, int *, double *, double *, unsigned *, unsigned long long *, double *, double *, int, hipStream_t);
 }
 
 // Fatal conditions unwind to the C ABI entry points (pchip_run_hooks, pchip_slice_chains), which release the run's
@@ -438,7 +438,7 @@ struct Engine {
                    : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
         // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read
         raw_buf[0] = S.nhat_raw; raw_buf[1] = (D <= 24 && S.nhat_raw) ? dalloc<double>((size_t)B * S.nb_total * D * D) : nullptr;
-        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
+        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
         if (callback_mode) {
@@ -519,6 +519,7 @@ struct Engine {
         PcCtl &c = *h_ctl;
         const int hi_before = c.i_nursery > 0 ? c.i_nursery - 1 : B - 1;       // the segment starts where the last one stopped
         c.status = (int)(got[0] & 0xFF); c.error = (int)((got[0] >> 8) & 0xFF); c.cluster_deleted = (int)((got[0] >> 16) & 1);
+        c.upd_pending = (int)((got[0] >> 17) & 1); c.upd_marks = (int)((got[0] >> 18) & 0xFF);
         c.i_nursery = (int)(unsigned)got[1]; c.ndead = (int)(unsigned)got[2]; c.nphantom = (int)(unsigned)got[3];
         c.ncluster = (int)(got[4] & 0xFFFF);
         {   // the low 16 bits of a counter that only grows
@@ -763,9 +764,9 @@ struct Engine {
         HIPCHK(hipMemcpy(&S.ctl->seq, &h_ctl->seq, sizeof(unsigned long long), hipMemcpyHostToDevice));
     }
 
-    void do_update()
+    void do_update(bool deferred = false)
     {
-        tm.updates++;
+        tm.updates += deferred ? std::max(1, h_ctl->upd_marks) : 1;
         // the round loop only sees the compact notification; whoever looks at evidences, counters or cluster ids gets the block
         const bool seq_post = S.seq_mode && (cfg.posteriors || cfg.equals);
         if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
@@ -783,7 +784,7 @@ struct Engine {
                 HIPCHK(hipStreamSynchronize(st));
             }
             hipEvent_t e0 = kt.begin(KT_CLEAN);
-            pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, st);
+            pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
             kt.end(KT_CLEAN, e0);
             if (cfg.resume_write || dumper || on_update || seq_post) {
                 int total = nph;
@@ -796,6 +797,7 @@ struct Engine {
             write_resume();
             return;
         }
+        if (deferred) engine_fail(PC_RC_DEVICE, "deferred update without the fused update path");
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
@@ -1393,6 +1395,13 @@ struct Engine {
         const bool static_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && resume_static && cfg.force_general != 1;
         fast_ok = static_ok && pc_fast_fits(&S);
         const bool par_ok = static_ok && cfg.force_general == 0 && pc_par_fits(&S);
+        // The parallel contraction may run past an update trigger and have the update made afterwards, for the state at
+        // the trigger (pc_update.hip): a nursery is then consumed in ONE launch instead of being cut where the reference
+        // updates.  Only when nothing on the host is tied to the moment of an update (files, dumper, resume) and the
+        // fused update applies.
+        static const bool defer_off = std::getenv("PC_DEFER_OFF") != nullptr;
+        S.defer_update = (!defer_off && par_ok && !cfg.do_clustering && cfg.boost_posterior == 0.0 && !dumper && !on_update && !cfg.resume_write &&
+                          !S.seq_mode && pc_update_fused_ok(&S, 1) && !std::getenv("PC_UPDATE_FUSED_OFF")) ? 1 : 0;
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
@@ -1477,8 +1486,8 @@ struct Engine {
             tm.rounds++;
             // dead rows leave for the host at every update (a copy per round, ~350 KB, next to the one-CU contraction cost it
             // 6 us per launch: 72 against 66 us)
-            if (h_ctl->status == PC_ST_UPDATE) {
-                do_update(); h_ctl->status = PC_ST_RUNNING;
+            if (h_ctl->status == PC_ST_UPDATE || (h_ctl->upd_pending && h_ctl->status == PC_ST_RUNNING)) {
+                do_update(h_ctl->status != PC_ST_UPDATE); h_ctl->status = PC_ST_RUNNING; h_ctl->upd_pending = 0;
                 if (!ev_apply) ev_apply = hpool().get_event();
                 HIPCHK(hipEventRecord(ev_apply, st));       // the dead rows of the rounds so far are in place behind this point
                 stream_dead();
@@ -1587,7 +1596,7 @@ struct Engine {
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
-                       &S.ch_seed_slot, &S.slot_src, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
+                       &S.ch_seed_slot, &S.slot_src, &S.slot_step, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
         { char *cs = (char *)d_cs; dfree(cs); d_cs = nullptr; }
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);

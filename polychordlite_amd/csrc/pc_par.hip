@@ -425,6 +425,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 
     cyc[ncy++] = clock64();
     // ---- phase 8: the first step at which the reference's loop would have stopped
+    const bool defer = S.defer_update != 0;
     int kupd = 0x7fffffff;                                // deaths until logXp <= logX_last_update + log(compression)
     {
         const double tx = ctl->logX_last_update + S.log_cf;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         const bool tv = t < T && ((vmask[t >> 6] >> (t & 63)) & 1ull), ta = t < T && ((amask[t >> 6] >> (t & 63)) & 1ull);
         if (!more || fb > S.nfail) code = (t << 2) | 1;
         else if (tv && ndead_b >= S.Dcap) code = (t << 2) | 2;
-        else if (ta && kb + 1 == kupd) code = ((t + 1) << 2) | 0;
+        else if (!defer && ta && kb + 1 == kupd) code = ((t + 1) << 2) | 0;
         if (code != 0x7fffffff) atomicMin(&ish[0], code);
     };
     {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
     // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
     if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = nph0 + tid * nr; pw->ph_count = -2; }
-    for (int s = tid; s < Ncap; s += PAR_NT) S.slot_src[s] = -1;
+    for (int s = tid; s < Ncap; s += PAR_NT) { S.slot_src[s] = -1; if (defer) S.slot_step[s] = -1; }
     if (lane == 0) accR[wv] = 0ull;
     if (tid == 0) ish[2] = nph0 + ts * nr;               // rows in use after this launch
     __syncthreads();
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     if (accT && pos2 >= Kp) {                             // accepted and still alive at the end of the launch
         const int sl = slotA[tid];
         S.live_logL[sl] = key2d(ck); S.slot_src[sl] = w;
+        if (defer) S.slot_step[sl] = tid;
         S.sort_key[pos2 - Kp] = ck; S.sort_slot[pos2 - Kp] = sl;
     }
 #ifdef PAR_DBG_PUBLISH
@@ -569,6 +571,24 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2]; ctl->nlike_failed += ish[3];
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
+        ctl->upd_pending = 0; ctl->upd_marks = 0;
+        if (defer && Kp >= kupd) {
+            // Update triggers passed by this launch (nested_sampling.F90:321: logXp <= logX_last_update + log(compression),
+            // tested after every death): the first after kupd deaths, every later one relative to the volume at the one
+            // before.  The update is made once, afterwards, for the state at the last of them.
+            int Kl = kupd, marks = 1;
+            for (;;) {
+                const double txn = (Xp0 + (double)Kl * d01) + S.log_cf;
+                int kn = Kl + 1;
+                while (kn <= Kp && Xp0 + (double)kn * d01 > txn) kn++;
+                if (kn > Kp) break;
+                Kl = kn; marks++;
+            }
+            ctl->upd_pending = 1; ctl->upd_marks = marks;
+            ctl->upd_tmark = accStep[Kl - 1] + 1; ctl->upd_T = T; ctl->upd_ts = ts; ctl->upd_nph0 = nph0;
+            ctl->upd_thr = key2d(uKey[Kl - 1]); ctl->upd_keep_thr = (Kp > Kl) ? 1 : 0;
+            ctl->logX_last_update = Xp0 + (double)Kl * d01;
+        }
         if (S.use_prec) ctl->live_logZ = lse_m + log(lse_s) - l0 + Xp;
         cyc[ncy++] = clock64();
 #ifdef PAR_NO_DBG

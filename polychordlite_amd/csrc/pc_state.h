@@ -38,6 +38,14 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     long long dbg[8];            // developer cycle counters of the contraction kernel
     long long gen_cyc[4];        // general contraction kernel: cycles in termination test / identify / kill+add / tail
     long long nn_walks, nn_fallbacks;   // chains identified from the candidate lists / of those, chains that needed the full search
+    // deferred update (parallel contraction, S.defer_update): the launch ran past its update trigger(s); the update is
+    // made afterwards for the state at the LAST mark of the launch (only that covariance is ever sampled from)
+    int upd_pending, upd_marks;         // an update is due / triggers passed in this launch
+    int upd_tmark;                      // steps of the launch before the mark (the step that caused the triggering death included)
+    int upd_T, upd_ts;                  // steps in the nursery at launch / consumed by the launch
+    int upd_nph0;                       // phantom rows in use when the launch started (its regions begin there)
+    int upd_keep_thr, upd_pad;          // deaths after the mark: death_thr stays the last death's logL
+    double upd_thr;                     // logL of the death that triggered the mark (clean_phantoms' threshold)
 };
 
 #define PC_MAX_GRADE 8
@@ -109,6 +117,8 @@ struct PcState {
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
     unsigned long long *sort_key; // [NS] sortable logL keys (pc_keys.h) in the same order
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
+    int *slot_step;              // [Ncap] step of the last parallel-contraction launch at which the slot's occupant was accepted, -1: older
+    int defer_update;            // the parallel contraction may run past update triggers (no host work is tied to an update)
     // ---- fast/slow parameter grades (chordal_sampling.f90:94-145): grade g moves the parameters from g_off[g] to the
     //      last one with g_nr[g] directions taken from g_nb[g] orthonormal bases of that subspace; nr = sum g_nr.
     //      One grade: g_off = 0, g_nr = nr.  g_col0 = first direction of the grade in generation order, g_e0 = first
@@ -152,7 +162,8 @@ __device__ __forceinline__ void pc_publish_ctl(const PcState &S)
     if (!S.ctl_host) return;                       // (uniform)
     if (threadIdx.x == 0) {
         const PcCtl *c = S.ctl;
-        pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16);
+        pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16) |
+                        ((unsigned)(c->upd_pending != 0) << 17) | ((unsigned)(c->upd_marks & 0xFF) << 18);
         pc_note_sh[1] = (unsigned)c->i_nursery; pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
         pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (the full count comes with the block)
     }

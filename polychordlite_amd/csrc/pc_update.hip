@@ -24,10 +24,11 @@
 #define UPD_ROWS 256
 #define UPD_NT 256
 
-// the wave's rows selected by `mask` (row of bit b = src0 + b*nT), in order: optionally copied to consecutive rows at dst,
-// and their first D elements minus the shift written to consecutive tile rows; sixteen rows in flight, lane = element
-__device__ __forceinline__ void upd_stage_masked(const double *src0, unsigned long long mask, double *dst, double *tile, int TS,
-                                                 const double *sh, int D, int nT, int lane)
+// the wave's rows selected by `mask` (row of bit b = src0 + b*nT), in order: optionally copied to consecutive rows at dst;
+// of those also in `mmask`, the first D elements minus the shift (and a one) go to consecutive tile rows, in order;
+// sixteen rows in flight, lane = element
+__device__ __forceinline__ void upd_stage_masked(const double *src0, unsigned long long mask, unsigned long long mmask, double *dst,
+                                                 double *tile, int TS, const double *sh, int D, int nT, int lane)
 {
     const int ne = dst ? nT : D + 1;
     int n = 0;
@@ -49,19 +50,25 @@ __device__ __forceinline__ void upd_stage_masked(const double *src0, unsigned lo
             if (e <= D) {                              // column D carries a one: its products are the first moments and the count
                 const double s = e < D ? sh[e] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) if (u < cnt) tile[(size_t)(n + u) * TS + e] = e < D ? v[u] - s : 1.0;
+                for (int u = 0; u < 16; ++u)
+                    if (u < cnt && ((mmask >> idx[u]) & 1ull))
+                        tile[(size_t)__popcll(mmask & ((1ull << idx[u]) - 1ull)) * TS + e] = e < D ? v[u] - s : 1.0;
             }
         }
         n += cnt;
     }
 }
 
-__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count)
+// def (here and below): the update is made AFTER the launch of the parallel contraction that passed its trigger, for the
+// state at the mark the launch recorded (PcCtl::upd_*): the threshold of the clean is the logL of the death at the mark;
+// the moments leave out what came after it -- phantoms of later chains, live points accepted later -- and take in the
+// points that were alive then and have died since (their rows are in the dead array)
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def)
 {
     __shared__ int cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned uid0 = S.cl_uid[0];
-    const double thr = S.death_thr[0];
+    const double thr = def ? S.ctl->upd_thr : S.death_thr[0];
     const int j = blockIdx.x * UPD_ROWS + tid;
     bool k = false;
     if (j < nph) { k = (S.ph_cuid[j] == uid0) && !(S.ph_logL[j] < thr); keep[j] = k ? 1 : 0; }
@@ -80,17 +87,18 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigne
 typedef double upd_v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(UPD_NT) void k_upd_move(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_count,
                                                     double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
-                                                    int *d_total, const double *shift, double *part, int E)
+                                                    int *d_total, const double *shift, double *part, int E, int def, int nlb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int red[UPD_NT];
-    __shared__ int wcnt[4];
+    __shared__ int wcnt[4], mcnt[4];
+    const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, D = S.D, nT = S.nT;
     const int ncol = D + 1, TS = (ncol + 1) | 1;   // odd row stride: the four row groups of an operand hit different banks
     double *tile = (double *)smem;                 // [UPD_ROWS + 16][TS] member rows first: cube - shift, then a column of ones
     double *sh = tile + (size_t)(UPD_ROWS + 16) * TS;     // [D]
     const int blk = blockIdx.x;
-    const bool is_ph = blk < nblk;
+    const bool is_ph = blk < nblk, is_live = !is_ph && blk < nblk + nlb;
     for (int d = tid; d < D; d += UPD_NT) sh[d] = shift[d];
     int n = 0;                                     // member rows of this block
     if (is_ph) {
@@ -101,31 +109,60 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_move(PcState S, int nph, int nbl
         const bool k = (j < nph) && keep[j];
         double pl = 0.0; unsigned pc = 0u; unsigned long long pu = 0ull;
         if (j < nph) { pl = S.ph_logL[j]; pc = S.ph_cuid[j]; pu = S.ph_uid[j]; }
+        // moments: the survivors that were phantoms at the mark (rows of regions of later chains stay, but do not count)
+        const bool km = k && (j < nph0u || (j - nph0u) / S.nr < tmark);
         // ---- offset of this block's survivors = survivors of the blocks before it (integer sum: any order)
         red[tid] = s;
-        const unsigned long long m = __ballot(k);
-        if (lane == 0) wcnt[wv] = __popcll(m);
+        const unsigned long long m = __ballot(k), mm = __ballot(km);
+        if (lane == 0) { wcnt[wv] = __popcll(m); mcnt[wv] = __popcll(mm); }
         __syncthreads();
         for (int o = UPD_NT / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
         const int off0 = red[0];
         if (blk == nblk - 1 && tid == 0) { const int tot = off0 + blk_count[blk]; *d_total = tot; S.ctl->nphantom = tot; }
         // ---- compaction, row order kept
-        int woff = 0;
-        for (int x = 0; x < wv; ++x) woff += wcnt[x];
+        int woff = 0, moff = 0;
+        for (int x = 0; x < wv; ++x) { woff += wcnt[x]; moff += mcnt[x]; }
         const int pos = woff + __popcll(m & ((1ull << lane) - 1ull));
         if (k) { phL2[off0 + pos] = pl; phC2[off0 + pos] = pc; phU2[off0 + pos] = pu; }
-        upd_stage_masked(S.phantom + (size_t)(blk * UPD_ROWS + wv * 64) * nT, m, ph2 + (size_t)(off0 + woff) * nT, tile + (size_t)woff * TS, TS, sh, D, nT, lane);
-        n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    } else {
+        upd_stage_masked(S.phantom + (size_t)(blk * UPD_ROWS + wv * 64) * nT, m, mm, ph2 + (size_t)(off0 + woff) * nT, tile + (size_t)moff * TS, TS, sh, D, nT, lane);
+        n = mcnt[0] + mcnt[1] + mcnt[2] + mcnt[3];
+    } else if (is_live) {
         // ---- live points of slots [r0, r0 + UPD_ROWS)
         const int r0 = (blk - nblk) * UPD_ROWS, r = r0 + tid;
-        const bool k = (r < S.Ncap) && S.live_cluster[r] == 0;
+        const bool k = (r < S.Ncap) && S.live_cluster[r] == 0 && (!def || S.slot_step[r] < tmark);
         const unsigned long long m = __ballot(k);
         if (lane == 0) wcnt[wv] = __popcll(m);
         __syncthreads();
         int woff = 0;
         for (int x = 0; x < wv; ++x) woff += wcnt[x];
-        upd_stage_masked(S.live + (size_t)(r0 + wv * 64) * nT, m, nullptr, tile + (size_t)woff * TS, TS, sh, D, nT, lane);
+        upd_stage_masked(S.live + (size_t)(r0 + wv * 64) * nT, m, m, nullptr, tile + (size_t)woff * TS, TS, sh, D, nT, lane);
+        n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    } else {
+        // ---- def: points alive at the mark that died later in the launch: the dead rows of the steps t >= tmark whose
+        //      dying point was a snapshot point or the newcomer of a step before the mark
+        const PcCtl *ctl = S.ctl;
+        const int T = ctl->upd_T, ts = ctl->upd_ts;
+        const int t = tmark + (blk - nblk - nlb) * UPD_ROWS + tid;
+        long long di = -1;
+        if (t < ts) {
+            const PcPlan *pw = S.plan + (T - 1 - t);
+            const int src = pw->dead_src;
+            const bool existed = src >= 0 || (T - 1 - (-src - 1)) < tmark;
+            if (pw->dead_idx >= 0 && pw->logw > S.logzero && existed) di = pw->dead_idx;
+        }
+        const unsigned long long m = __ballot(di >= 0);
+        if (lane == 0) wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int x = 0; x < wv; ++x) woff += wcnt[x];
+        unsigned long long mb = m;
+        int row = woff;
+        while (mb) {                                   // rows are scattered in the dead array: one at a time, lane = coordinate
+            const int b = __ffsll((long long)mb) - 1; mb &= mb - 1;
+            const long long d = __shfl(di, b);
+            if (lane <= D) tile[(size_t)row * TS + lane] = lane < D ? S.dead[(size_t)d * nT + lane] - sh[lane] : 1.0;
+            row++;
+        }
         n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     }
     // rows n .. next multiple of 16: zero (the matrix cores take four rows at a time, four waves)
@@ -188,7 +225,7 @@ __global__ __launch_bounds__(256) void k_upd_fold(const double *part, int nb, in
 }
 
 // fold + mean + covariance + Cholesky; one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const double *part, int E, double *shift)
+__global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const double *part, int E, double *shift, int def)
 {
     __shared__ double acc[4][256];                 // E <= 256 * 2: entries beyond 256 take a second round
     __shared__ double A[32 * 32], L[32 * 32], mu[32];
@@ -268,7 +305,9 @@ __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const dou
     }
     for (int p = tid; p < D * D; p += 1024) S.chol[p] = L[p];
     if (tid < D) shift[tid] += mu[tid];                        // the next update's moments are taken about this mean
-    if (tid == 0) S.death_thr[0] = -PC_HUGE;                   // (every survivor is above the last death: k_reset_thresholds)
+    // every survivor is above the last death (k_reset_thresholds) -- unless the launch went on dying after the mark:
+    // then the threshold of the next clean stays the logL of its last death
+    if (tid == 0) { if (!(def && S.ctl->upd_keep_thr)) S.death_thr[0] = -PC_HUGE; if (def) S.ctl->upd_pending = 0; }
 #ifdef UPD_DBG
     if (tid == 0) { const long long f2 = clock64(); S.ctl->gen_cyc[2] += f1 - f0; S.ctl->gen_cyc[3] += f2 - f1; S.ctl->nn_walks += f0; }
 #endif
@@ -276,27 +315,30 @@ __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const dou
 
 extern "C" int pc_update_fused_ok(const PcState *S, int nc) { return nc == 1 && S->D < 32; }
 extern "C" int pc_update_fused_blocks(const PcState *S, int nph)
-{   // partial records: one per block of k_upd_move, then one per group of UPD_FOLD of them
-    const int nb = (nph + UPD_ROWS - 1) / UPD_ROWS + (S->Ncap + UPD_ROWS - 1) / UPD_ROWS;
+{   // partial records: one per block of k_upd_move (phantom blocks, live blocks, dead-row blocks of a deferred update),
+    // then one per group of UPD_FOLD of them
+    const int nb = (nph + UPD_ROWS - 1) / UPD_ROWS + (S->Ncap + UPD_ROWS - 1) / UPD_ROWS + (S->B + UPD_ROWS - 1) / UPD_ROWS;
     return nb + (nb + UPD_FOLD - 1) / UPD_FOLD;
 }
 extern "C" int pc_update_fused_entries(const PcState *S) { const int e = S->D * (S->D + 1) / 2 + S->D + 1; return (e + 31) & ~31; }
 
-// nph >= 1.  keep [nph], blk [blocks], part [pc_update_fused_blocks * pc_update_fused_entries] doubles, shift [D]
+// nph >= 1.  keep [nph], blk [blocks], part [pc_update_fused_blocks * pc_update_fused_entries] doubles, shift [D].
+// deferred: see k_upd_flag
 extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char *keep, int *blk, int *d_total, double *ph2, double *phL2,
-                                       unsigned *phC2, unsigned long long *phU2, double *part, double *shift, hipStream_t st)
+                                       unsigned *phC2, unsigned long long *phU2, double *part, double *shift, int deferred, hipStream_t st)
 {
     const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
+    const int ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
     const int TS = ((S->D + 2) | 1);
     size_t sh = sizeof(double) * ((size_t)(UPD_ROWS + 16) * TS + S->D);
     if (sh < sizeof(double) * (12 * 256 + S->D)) sh = sizeof(double) * (12 * 256 + S->D);       // the waves' result tiles reuse the row tile
     static size_t done = 0;
     if (sh > done) { (void)hipFuncSetAttribute((const void *)k_upd_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
-    hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk);
-    hipLaunchKernelGGL(k_upd_move, dim3(nblk + nlb), dim3(UPD_NT), sh, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk,
-                       ph2, phL2, phC2, phU2, d_total, (const double *)shift, part, E);
-    const int nb = nblk + nlb, ng = (nb + UPD_FOLD - 1) / UPD_FOLD;
+    hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
+    hipLaunchKernelGGL(k_upd_move, dim3(nblk + nlb + ndb), dim3(UPD_NT), sh, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk,
+                       ph2, phL2, phC2, phU2, d_total, (const double *)shift, part, E, deferred, nlb);
+    const int nb = nblk + nlb + ndb, ng = (nb + UPD_FOLD - 1) / UPD_FOLD;
     double *part2 = part + (size_t)nb * E;
     hipLaunchKernelGGL(k_upd_fold, dim3(ng), dim3(256), 0, st, (const double *)part, nb, E, part2);
-    hipLaunchKernelGGL(k_upd_final, dim3(1), dim3(1024), 0, st, *S, ng, (const double *)part2, E, shift);
+    hipLaunchKernelGGL(k_upd_final, dim3(1), dim3(1024), 0, st, *S, ng, (const double *)part2, E, shift, deferred);
 }
