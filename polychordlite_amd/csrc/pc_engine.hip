@@ -266,14 +266,18 @@ struct Engine {
     hipStream_t st = nullptr;
     hipStream_t st_copy = nullptr;            // dead rows leave for the host while the run goes on
     hipStream_t st_side = nullptr;            // the orthonormal bases of the next nursery, while this one is consumed
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    bool pre_ready = false, side_waited = false; unsigned pre_batch = 0; int pre_B = 0;
+    hipEvent_t ev_main = nullptr;
+    // ring of bases drawn ahead on the side stream: nursery b's live in raw_buf[b % raw_depth]
+    static constexpr int RAW_RING = 4;
+    struct RawSlot { hipEvent_t ready = nullptr, consumed = nullptr; unsigned batch = 0; int B = 0; bool valid = false, waited = false, used = false; };
+    RawSlot ring[RAW_RING];
+    int raw_depth = 2;
     double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
     PcCtl *h_ctl = nullptr;       // pinned mirror
     PcCtl *h_note = nullptr;      // pinned, device-visible: the contraction kernels publish the control block here (pc_publish_ctl)
     unsigned note_seq = 0;
     hipEvent_t ev_apply = nullptr;
-    double *raw_buf[2] = {nullptr, nullptr};   // orthonormal bases of nursery b live in raw_buf[b & 1]
+    double *raw_buf[RAW_RING] = {nullptr, nullptr, nullptr, nullptr};
     // alternate phantom buffers + scratch for the update step
     double *ph2 = nullptr, *phL2 = nullptr; unsigned *phC2 = nullptr; unsigned long long *phU2 = nullptr;
     unsigned char *keep = nullptr; int *blk = nullptr, *d_total = nullptr;
@@ -433,11 +437,22 @@ struct Engine {
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
+        static const bool ms_off = std::getenv("PC_MS_PRE_OFF") != nullptr;
+        const bool ms_pre = S.like.kind == PC_LIKE_CORR_GAUSSIAN && D > 64 && D <= 128 && S.ngrade <= 1 && !S.seq_mode && !(S.ablate & 1) && !ms_off;
+        S.nhat_Ms = ms_pre ? dalloc<double>((size_t)B * nr * D) : nullptr;
+        S.ch_My = ms_pre ? dalloc<double>((size_t)B * D) : nullptr;
         static const bool split_off = std::getenv("PC_NHATS_SPLIT_OFF") != nullptr;
-        S.nhat_raw = (D <= 24 && !S.seq_mode && !split_off) ? dalloc<double>((size_t)B * S.nb_total * D * D)
+        // 64 < nDims <= 128, one grade: k_nhats_q<32, 1> leaves a basis register-major, 32 x 512 doubles
+        const bool split_q = D > 64 && D <= 128 && S.ngrade <= 1 && !S.seq_mode && !split_off && !callback_mode;
+        const size_t raw_n = split_q ? (size_t)B * S.nb_total * 32 * 512 : (size_t)B * S.nb_total * D * D;
+        S.nhat_raw = ((D <= 24 && !S.seq_mode && !split_off) || split_q) ? dalloc<double>(raw_n)
                    : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
         // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read
-        raw_buf[0] = S.nhat_raw; raw_buf[1] = (D <= 24 && S.nhat_raw) ? dalloc<double>((size_t)B * S.nb_total * D * D) : nullptr;
+        // (nDims > 64: the bases cost more than the rest of a nursery's round -- they are drawn up to three nurseries ahead,
+        //  through the updates as well)
+        raw_depth = split_q ? RAW_RING : 2;
+        raw_buf[0] = S.nhat_raw;
+        for (int r = 1; r < raw_depth; ++r) raw_buf[r] = ((D <= 24 || split_q) && S.nhat_raw) ? dalloc<double>(raw_n) : nullptr;
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
@@ -1415,12 +1430,16 @@ struct Engine {
                 const bool split = pc_nhats_splittable(&S) != 0 && raw_buf[1] && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
                 bool fused_slice = false;
                 if (split) {
-                    // the bases of this nursery were drawn on the side stream while the last one was consumed (or are
-                    // drawn now); bases of nursery b live in raw_buf[b & 1]
-                    S.nhat_raw = raw_buf[batch & 1];
-                    if (pre_ready && pre_batch == batch && pre_B == B) { if (!side_waited) HIPCHK(hipStreamWaitEvent(st, ev_side, 0)); }
-                    else (void)pc_launch_nhats_part(&S, batch, B, 1, st);
-                    pre_ready = false;
+                    // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
+                    // are drawn now)
+                    RawSlot &rs = ring[batch % raw_depth];
+                    S.nhat_raw = raw_buf[batch % raw_depth];
+                    if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }
+                    else {
+                        if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
+                        (void)pc_launch_nhats_part(&S, batch, B, 1, st);
+                    }
+                    rs.valid = false;
                     fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
                     if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
                 }
@@ -1433,13 +1452,30 @@ struct Engine {
                 if (split) {
                     // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
                     // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
-                    if (!st_side) { st_side = hpool().get_stream(); ev_side = hpool().get_event(); ev_main = hpool().get_event(); }
-                    static const bool side_free = std::getenv("PC_SIDE_FREE") != nullptr;
+                    if (!st_side) {
+                        st_side = hpool().get_stream(); ev_main = hpool().get_event();
+                        for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_event(); ring[r].consumed = hpool().get_event(); }
+                    }
+                    // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
+                    //  half a millisecond: there they run next to it from the start)
+                    static const bool side_free_env = std::getenv("PC_SIDE_FREE") != nullptr, side_ord_env = std::getenv("PC_SIDE_ORDERED") != nullptr;
+                    const bool side_free = side_free_env || (S.D > 64 && !side_ord_env);
+                    // the buffer of this nursery is free again once its bases have been whitened (fused: once sampled)
+                    RawSlot &cur = ring[batch % raw_depth];
+                    HIPCHK(hipEventRecord(cur.consumed, st)); cur.used = true;
                     if (!side_free) { HIPCHK(hipEventRecord(ev_main, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0)); }
-                    PcState S1 = S; S1.nhat_raw = raw_buf[(batch + 1) & 1];
-                    (void)pc_launch_nhats_part(&S1, batch + 1, B, 1, st_side);
-                    HIPCHK(hipEventRecord(ev_side, st_side));
-                    pre_ready = true; pre_batch = batch + 1; pre_B = B; side_waited = false;
+                    // ordered: the next nursery only; free: as far ahead as there are buffers (the last one is this nursery's own)
+                    const unsigned xmax = batch + (unsigned)raw_depth - (side_free ? 0u : 1u);
+                    for (unsigned x = batch + 1; x <= xmax; ++x) {
+                        RawSlot &rs = ring[x % raw_depth];
+                        if (rs.valid && rs.batch == x && rs.B == B) continue;
+                        if (rs.valid) continue;                                          // (a job for another nursery size: used or replaced when its turn comes)
+                        if (rs.used) HIPCHK(hipStreamWaitEvent(st_side, rs.consumed, 0));
+                        PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+                        (void)pc_launch_nhats_part(&S1, x, B, 1, st_side);
+                        HIPCHK(hipEventRecord(rs.ready, st_side));
+                        rs.valid = true; rs.batch = x; rs.B = B; rs.waited = false;
+                    }
                 }
                 if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
                 batch++; tm.batches++;
@@ -1475,7 +1511,7 @@ struct Engine {
             kt.end(KT_APPLY, e3);
             // the main stream's wait for the next nursery's bases is enqueued now, behind this round's kernels (long
             // satisfied when the next k_slice gets there), not between the stamp and the next launch
-            if (pre_ready && !side_waited) { HIPCHK(hipStreamWaitEvent(st, ev_side, 0)); side_waited = true; }
+            if (st_side) { RawSlot &rs = ring[batch % raw_depth]; if (rs.valid && rs.batch == batch && !rs.waited) { HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); rs.waited = true; } }
             wait_ctl();
             // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
             // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery
@@ -1588,11 +1624,11 @@ struct Engine {
         if (st) (void)hipStreamSynchronize(st);
         if (st_copy) (void)hipStreamSynchronize(st_copy);
         if (st_side) (void)hipStreamSynchronize(st_side);
-        if (raw_buf[0]) { S.nhat_raw = raw_buf[0]; dfree(raw_buf[1]); raw_buf[0] = nullptr; }     // S.nhat_raw pointed at one of the two
+        if (raw_buf[0]) { S.nhat_raw = raw_buf[0]; for (int r = 1; r < RAW_RING; ++r) dfree(raw_buf[r]); raw_buf[0] = nullptr; }     // S.nhat_raw pointed at one of them
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,
-                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.nhat_raw, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
+                          &S.ch_contour, &S.nhat, &S.nhat_w, &S.nhat_raw, &S.nhat_Ms, &S.ch_My, &S.live_entry, &S.dead_entry, &ph2, &phL2, &psum, &mean,
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
@@ -1614,8 +1650,11 @@ struct Engine {
 
         if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
         if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
-        if (st_side) { (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_side); hpool().put_event(ev_main); } st_side = nullptr; ev_side = ev_main = nullptr;
-        pre_ready = false;
+        if (st_side) {
+            (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_main);
+            for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_event(ring[r].ready); if (ring[r].consumed) hpool().put_event(ring[r].consumed); ring[r] = RawSlot(); }
+        }
+        st_side = nullptr; ev_main = nullptr;
     }
 };
 

@@ -591,7 +591,11 @@ __device__ __forceinline__ double quad_sum(double v)
     return v;
 }
 // HV = coordinates per thread: 8 (nDims <= 32), 16 (<= 64), 32 (<= 128); 4*HV vectors of 4*HV padded coordinates
-template <int HV>
+// PART (HV = 32, one grade): 0 = the whole kernel; 1 = deviates + Gram-Schmidt only, the orthonormal basis goes to nhat_raw
+// (register-major: element e of thread t at [e][t], every store a full row of the wave); 2 = seed, whitening and the
+// likelihood's products from a basis made earlier.  Part 1 touches nothing the contraction changes and needs 2 KB of LDS:
+// it is drawn on the side stream while the previous nursery is sampled and consumed, several bases per CU at a time.
+template <int HV, int PART = 0>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
     constexpr int DP = 4 * HV, NTQ = 16 * HV;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #ifdef NHATSQ_DBG
     long long qc[6]; qc[0] = clock64();
 #endif
-    if (tid == 0) {
+    if (PART != 1 && tid == 0) {
         int sel, slot;
         select_seed(S, batch, chain, sel, slot);
         sh[0] = sel; sh[1] = slot;
@@ -623,11 +627,15 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
         }
     }
+    double *rawb = (PART != 0) ? S.nhat_raw + ((size_t)chain * S.nb_total + blockIdx.x) * (size_t)(HV * NTQ) : nullptr;
     // gaussian deviates of my 32 coordinates: element (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT,
     // two per Philox call
     double v[HV];
 #pragma unroll
     for (int e = 0; e < HV; ++e) v[e] = 0.0;
+    double lpre[(HV * DP + NTQ - 1) / NTQ];
+    if constexpr (PART == 2) __syncthreads();                          // sh[] of the seed
+    if constexpr (PART != 2) {
     if (active) {
         // stream element of my register 0 (coordinate d0); registers [r_lo, r_hi) hold coordinates that exist and move
         const long long e0 = (long long)(S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + pc_sel(S.g_e0, grade)
@@ -676,7 +684,6 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     }
     __syncthreads();
     // first tile of the Cholesky factor: requested now, consumed after the loop
-    double lpre[(HV * DP + NTQ - 1) / NTQ];
     if constexpr (HV < 32) {
         const double *Lc0 = S.chol + (size_t)sh[0] * D * D;
 #pragma unroll
@@ -716,6 +723,17 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #ifdef NHATSQ_DBG
     qc[3] = clock64();
 #endif
+    }   // PART != 2
+    if constexpr (PART == 1) {
+        // the layout k_whiten reads as its B operand: [n][group of sixteen vectors][lk][vector in group], coordinate
+        // 32 h + e = 8 (n >> 1) + 2 lk + (n & 1)
+#pragma unroll
+        for (int e = 0; e < HV; ++e) {
+            const int n = 8 * h + 2 * (e >> 3) + (e & 1), lkk = (e & 7) >> 1;
+            rawb[((size_t)n * 8 + (i >> 4)) * 64 + lkk * 16 + (i & 15)] = v[e];
+        }
+        return;
+    }
     // whitening  w = L.n  (chordal_sampling.f90:73): tile k holds rows 32k..32k+31 of L, i.e. exactly the output
     // coordinates of block h = k
     const int col = col0 + basis * Dg + i;
@@ -730,7 +748,35 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
         constexpr int NS = 129;
         const int nt = (D + 15) >> 4, NR = nt * 16;
         double *Nl = (double *)smem_q + 2 * DPP;                       // [NR][NS]
-        double *L16 = Nl + (size_t)NR * NS;                            // [16][NS]
+        double *L16 = Nl + (size_t)NR * NS;                            // [2][16][NS]: the tile in use and the next one
+        const bool dbuf = NR <= 112;                                   // (beyond: one buffer, and a barrier before it is refilled)
+        // tiles of L (and of M below) travel global -> registers -> LDS one tile ahead of the matrix cores: one barrier per tile
+        double pre[4];
+        auto load_L = [&](int ti) __attribute__((always_inline)) {
+            const int kmax = min(NR, 16 * (ti + 1));                   // L(a, b) = 0 for b > a
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = tid + q * NTQ, r = x / kmax, bcol = x - r * kmax, arow = 16 * ti + r;
+                pre[q] = (x < 16 * kmax && arow < D && bcol < D) ? Lc[(size_t)arow * D + bcol] : 0.0;
+            }
+        };
+        auto store_L = [&](int ti) __attribute__((always_inline)) {
+            const int kmax = min(NR, 16 * (ti + 1));
+            double *buf = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
+            if (!dbuf) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = tid + q * NTQ, r = x / kmax, bcol = x - r * kmax;
+                if (x < 16 * kmax) buf[(size_t)r * NS + bcol] = pre[q];
+            }
+        };
+        load_L(0);
+        if constexpr (PART == 2) {
+            for (int x = tid; x < HV * NTQ; x += NTQ) {
+                const int e = x / NTQ, t = x - e * NTQ, ii = t >> 2, hh = t & 3;
+                if (ii < NR) Nl[(size_t)ii * NS + HV * hh + e] = rawb[x];
+            }
+        } else
         if (i < NR) {
 #pragma unroll
             for (int e = 0; e < HV; ++e) Nl[(size_t)i * NS + d0 + e] = v[e];    // zero beyond nDims and beyond the basis
@@ -742,15 +788,12 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #pragma unroll
         for (int ti = 0; ti < 8; ++ti) {
             if (ti < nt) {
-                __syncthreads();                                       // basis complete / previous rows of L consumed
-                const int kmax = min(NR, 16 * (ti + 1));               // L(a, b) = 0 for b > a
-                for (int x = tid; x < 16 * kmax; x += NTQ) {
-                    const int r = x / kmax, bcol = x % kmax, arow = 16 * ti + r;
-                    L16[(size_t)r * NS + bcol] = (arow < D && bcol < D) ? Lc[(size_t)arow * D + bcol] : 0.0;
-                }
-                __syncthreads();
+                store_L(ti);
+                if (ti + 1 < nt) load_L(ti + 1);
+                __syncthreads();                                       // tile ti (and, the first time, the basis) complete
                 if (wv < nt) {
-                    const double *pa = L16 + (size_t)li * NS + lk;
+                    const int kmax = min(NR, 16 * (ti + 1));
+                    const double *pa = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS + (size_t)li * NS + lk;
                     const double *pb = Nl + (size_t)(16 * wv + li) * NS + lk;
                     v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
                     for (int k0 = 0; k0 < kmax; k0 += 4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], a4, 0, 0, 0);
@@ -781,6 +824,84 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
                     double *out = S.nhat + ((size_t)chain * nr + col0 + basis * Dg + iv) * D;
                     const double *src = Nl + (size_t)iv * NS;
                     for (int a2 = lane; a2 < D; a2 += 64) out[a2] = src[a2];
+                }
+            }
+        }
+        if (S.nhat_Ms != nullptr) {
+            // correlated Gaussian (random_gaussian.f90:17-30): along a chord the exponent is quadratic (see ChainCtx) and all a
+            // slice needs of the matrix is M.s, s = span o n^.  Every direction of the chain is known HERE: the products are
+            // one more [D x D] x [D x 16] pass per wave on the matrix cores (rows of M streamed through the tile buffer of L)
+            // instead of a matrix-vector product per slice inside the chain.  Wave 0 of the chain's first basis also forms
+            // M.(theta_seed - mean), the one product the chain needs for its start point.
+            double *spn = (double *)smem_q, *y0s = spn + 128;           // the pivot buffers are free now (2 x 136 doubles)
+            const double *Mt = S.like.invcov;                           // Mt[b * D + a] = M(a, b)
+            auto load_M = [&](int ti) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x = tid + q * NTQ, r = x & 15, bcol = x >> 4, arow = 16 * ti + r;
+                    pre[q] = (x < 16 * NR && arow < D && bcol < D) ? Mt[(size_t)bcol * D + arow] : 0.0;
+                }
+            };
+            auto store_M = [&](int ti) __attribute__((always_inline)) {
+                double *buf = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
+                if (!dbuf) __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x = tid + q * NTQ, r = x & 15, bcol = x >> 4;
+                    if (x < 16 * NR) buf[(size_t)r * NS + bcol] = pre[q];
+                }
+            };
+            __syncthreads();
+            if (tid < NR) {
+                const bool on = tid < D;
+                const double lo = (on && S.prior.lo) ? S.prior.lo[tid] : 0.0, hi = (on && S.prior.hi) ? S.prior.hi[tid] : 1.0;
+                spn[tid] = on ? hi - lo : 0.0;
+                const double c0 = on ? S.live[(size_t)sh[1] * S.nT + tid] : 0.0;
+                y0s[tid] = on ? (lo + (hi - lo) * c0) - (S.like.mean ? S.like.mean[tid] : 0.0) : 0.0;
+            }
+            load_M(0);
+            __syncthreads();
+            if (wv < nt) {                                              // my sixteen rows: n^ -> s
+                for (int x = lane; x < 16 * NR; x += 64) { const int r = x / NR, a2 = x % NR; Nl[(size_t)(16 * wv + r) * NS + a2] *= spn[a2]; }
+            }
+            v4d ac2[8];
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti) ac2[ti] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti) {
+                if (ti < nt) {
+                    store_M(ti);
+                    if (ti + 1 < nt) load_M(ti + 1);
+                    __syncthreads();
+                    const double *tile = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
+                    if (wv < nt) {
+                        const double *pa = tile + (size_t)li * NS + lk;
+                        const double *pb = Nl + (size_t)(16 * wv + li) * NS + lk;
+                        v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
+                        for (int k0 = 0; k0 < NR; k0 += 4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], a4, 0, 0, 0);
+                        ac2[ti] = a4;
+                    }
+                    if (wv == 7 && blockIdx.x == 0) {                  // M.y0, rows of this tile: lane = (row, quarter of the columns)
+                        double t = 0.0;
+                        for (int b = lk; b < NR; b += 4) t += tile[(size_t)li * NS + b] * y0s[b];
+                        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+                        if (lk == 0 && 16 * ti + li < D) S.ch_My[(size_t)chain * D + 16 * ti + li] = t;
+                    }
+                }
+            }
+            if (wv < nt) {
+                double *mine = Nl + (size_t)(16 * wv + li) * NS;
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ti < nt) mine[16 * ti + lk + 4 * r] = ac2[ti][r];
+                for (int cc = 0; cc < 16; ++cc) {
+                    const int iv = 16 * wv + cc;
+                    if (iv < Dg && basis * Dg + iv < nrg) {
+                        double *out = S.nhat_Ms + ((size_t)chain * nr + col0 + basis * Dg + iv) * D;
+                        const double *src = Nl + (size_t)iv * NS;
+                        for (int a2 = lane; a2 < D; a2 += 64) out[a2] = src[a2];
+                    }
                 }
             }
         }
@@ -823,6 +944,307 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
     qc[4] = clock64();
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int x = 0; x < 4; ++x) S.ctl->gen_cyc[x] += qc[x + 1] - qc[x];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// First half of K0 for 64 < nDims <= 128, one grade (split launch): the orthonormal bases (random_utils.F90:381-437),
+// Gram-Schmidt in PANELS of sixteen vectors with the trailing update on the fp64 matrix cores.
+//
+// Eight waves per basis, wave g owns vectors 16 g .. 16 g + 15 in the pair layout of k_whiten (which reads them back as
+// its B operand).  Panel p: wave p orthogonalises its sixteen vectors among themselves -- the reference's loop, pivot by
+// pivot, the pivot travelling through LDS inside ONE wave (no block barrier, the other waves are parked) -- and leaves
+// them, normalised, in LDS; then every later wave projects its sixteen vectors on the whole panel at once:
+//     C = Q V^T   (16 x 16, contraction over the coordinates),    V <- V - C^T Q,
+// two products whose operands are the registers the vectors live in (V is the B operand of the first and the accumulator
+// of the second; C comes out of the first in the layout the second wants it in) and rows of the panel read from LDS.
+// That is the reference's arithmetic inside a panel and block classical Gram-Schmidt across panels: the coefficients
+// of a panel's pivots are taken from the vector as it was BEFORE the panel, not after each pivot -- the same numbers up to
+// rounding of the order of the basis' condition number times epsilon (what k_nhats_big does beyond 128 dimensions).
+// One barrier per panel instead of one per pivot, 56 matrix instructions per wave and panel instead of sixteen rounds of
+// 32 LDS loads + 96 FMAs: the one-pivot-at-a-time kernel spent 110 us per basis here.
+template <int NT>
+__global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
+{
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int NM = 4 * NT, NS = 130, RAWB = 32 * 512;
+    __shared__ __attribute__((aligned(16))) double Qp[2][16 * NS];
+    const int D = S.D;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int chain = blockIdx.y, basis = blockIdx.x;
+    const int ivec = 16 * g + li, np = (D + 15) >> 4;
+    const bool vact = ivec < D;
+    // gaussian deviates: element (basis D + i) D + d of stream (batch, chain) in PC_DOM_NHAT, two per Philox call
+    double v[NM];
+#pragma unroll
+    for (int n = 0; n < NM; ++n) v[n] = 0.0;
+    if (vact) {
+        const long long e0 = (long long)pc_sel(S.g_e0, 0) + ((long long)basis * D + ivec) * D;
+#pragma unroll
+        for (int n = 0; n < NM; n += 2) {
+            const int d = 8 * (n >> 1) + 2 * lk;
+            if (d < D) {
+                const long long e = e0 + d;
+                double ua, ub;
+                pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1), ua, ub);
+                if ((e & 1ll) == 0) { v[n] = pc_inv_normal_cdf(ua); if (d + 1 < D) v[n + 1] = pc_inv_normal_cdf(ub); }
+                else {
+                    v[n] = pc_inv_normal_cdf(ub);
+                    if (d + 1 < D) { pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1) + 1u, ua, ub); v[n + 1] = pc_inv_normal_cdf(ua); }
+                }
+            }
+        }
+    }
+    auto lk_sum = [&](double x) __attribute__((always_inline)) { x += __shfl_xor(x, 16); x += __shfl_xor(x, 32); return x; };
+    {   // random_direction (random_utils.F90:276-298)
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int n = 0; n < NM; n += 2) { p0 += v[n] * v[n]; p1 += v[n + 1] * v[n + 1]; }
+        const double n2 = lk_sum(p0 + p1), inrm = vact ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) v[n] *= inrm;
+    }
+    const int arow_l = 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1);   // row of an output tile that sits in my A-operand slot
+    double *rawb = S.nhat_raw + ((size_t)chain * S.nb_total + basis) * (size_t)RAWB + (size_t)g * 64 + lane;
+    for (int p = 0; p < np; ++p) {
+        double *Q = Qp[p & 1];
+        if (g == p) {
+            // ---- my panel: Gram-Schmidt pivot by pivot (random_utils.F90:391-399), the pivot unnormalised as there
+            const int cnt = min(16, D - 16 * p);
+            for (int j = 0; j < cnt; ++j) {
+                if (li == j) {
+#pragma unroll
+                    for (int n = 0; n < NM; n += 2) *(v2d *)&Q[j * NS + 4 * n + 2 * lk] = v2d{v[n], v[n + 1]};
+                }
+                double q[NM];
+#pragma unroll
+                for (int n = 0; n < NM; n += 2) { const v2d t = *(const v2d *)&Q[j * NS + 4 * n + 2 * lk]; q[n] = t.x; q[n + 1] = t.y; }
+                double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+#pragma unroll
+                for (int n = 0; n < NM; n += 2) { a0 += q[n] * q[n]; a1 += q[n + 1] * q[n + 1]; c0 += q[n] * v[n]; c1 += q[n + 1] * v[n + 1]; }
+                const double qq = lk_sum(a0 + a1), dv = lk_sum(c0 + c1);
+                if (li == j) {
+                    const double inrm = 1.0 / sqrt(qq);
+#pragma unroll
+                    for (int n = 0; n < NM; ++n) v[n] *= inrm;
+                } else if (li > j) {
+                    const double cproj = dv / qq;
+#pragma unroll
+                    for (int n = 0; n < NM; ++n) v[n] -= cproj * q[n];
+                }
+            }
+            // the finished panel, normalised, for the waves behind; and out to HBM
+#pragma unroll
+            for (int n = 0; n < NM; n += 2) *(v2d *)&Q[li * NS + 4 * n + 2 * lk] = v2d{v[n], v[n + 1]};
+#pragma unroll
+            for (int n = 0; n < NM; ++n) rawb[(size_t)n * 512] = v[n];
+        }
+        __syncthreads();
+        if (g > p && 16 * g < D) {
+            // ---- a later wave: C = Q V^T, V <- V - C^T Q
+            v4d c4 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n < NM; n += 2) {
+                const v2d a2 = *(const v2d *)&Q[li * NS + 4 * n + 2 * lk];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, v[n], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, v[n + 1], c4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                v4d a4 = v4d{v[4 * ti], v[4 * ti + 1], v[4 * ti + 2], v[4 * ti + 3]};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Q[(4 * ks + lk) * NS + 16 * ti + arow_l], -c4[ks], a4, 0, 0, 0);
+                v[4 * ti] = a4[0]; v[4 * ti + 1] = a4[1]; v[4 * ti + 2] = a4[2]; v[4 * ti + 3] = a4[3];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Second half of K0 for 64 < nDims <= 128, one grade (split launch, see k_nhats_q<32, 1>): seeds, whitening W = L.N and, for
+// the correlated Gaussian, the products M.(span o n^) -- everything on the fp64 matrix cores, sixteen vectors per wave.
+//
+// Register layout ("pair layout"): lane (li = lane & 15, lk = lane >> 4) of the wave that owns vectors 16 g .. 16 g + 15
+// holds, of vector 16 g + li, the coordinates  dim(n, lk) = 8 (n >> 1) + 2 lk + (n & 1),  n = 0 .. 4 NT - 1  -- pairs of
+// neighbours, so that a row leaves in 16-byte pieces.  That IS the B operand of v_mfma_f64_16x16x4_f64 for contraction
+// step n (B[k = lk][j = li]) once the A operand uses the same numbering of the contracted index, and it is also the D
+// layout of an output tile whose sixteen rows are numbered  row(ti, i) = 16 ti + 8 (i >> 3) + 2 (i & 3) + ((i >> 2) & 1):
+// register r of tile ti of lane lk is row i = lk + 4 r, i.e. dim(4 ti + r, lk).  So the basis read from HBM is the B operand
+// of L.N, its normalised result is the B operand of M.s, and both results leave from the registers they were summed in:
+// no basis in LDS, no transposes.  LDS holds two tiles of sixteen matrix rows (the one in use, the one arriving).
+// A block is four waves = 64 vectors, two blocks per basis; each streams the tiles of L and M itself.
+template <int NT>
+__global__ __launch_bounds__(256) void k_whiten(PcState S, unsigned batch)
+{
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int NM = 4 * NT, NR = 16 * NT, NS = 130, RAWB = 32 * 512;
+    __shared__ __attribute__((aligned(16))) double tiles[2][16 * NS];
+    __shared__ double spn[128], y0s[128];
+    __shared__ int sh[2];
+    const int D = S.D, nr = S.nr;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int chain = blockIdx.y, basis = blockIdx.x >> 1, half = blockIdx.x & 1, g = 4 * half + wv;
+    const bool wact = 16 * g < D;                                       // my sixteen vectors exist (at least one of them)
+    const bool ms = S.nhat_Ms != nullptr;
+    if (tid == 0) {
+        int sel, slot;
+        select_seed(S, batch, chain, sel, slot);
+        sh[0] = sel; sh[1] = slot;
+        if (blockIdx.x == 0) {
+            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
+            S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
+            S.ch_epoch[chain] = S.ctl->admin_epoch;
+            if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
+        }
+    }
+    // the basis, straight into the operand registers
+    double b[NM];
+    {
+        const double *rawb = S.nhat_raw + ((size_t)chain * S.nb_total + basis) * (size_t)RAWB + (size_t)g * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) b[n] = wact ? rawb[(size_t)n * 512] : 0.0;
+    }
+    __syncthreads();
+    const double *Lc = S.chol + (size_t)sh[0] * D * D;
+    if (ms && tid < 128) {
+        const bool on = tid < D;
+        const double lo = (on && S.prior.lo) ? S.prior.lo[tid] : 0.0, hi = (on && S.prior.hi) ? S.prior.hi[tid] : 1.0;
+        spn[tid] = on ? hi - lo : 0.0;
+        const double c0 = on ? S.live[(size_t)sh[1] * S.nT + tid] : 0.0;
+        y0s[tid] = on ? (lo + (hi - lo) * c0) - (S.like.mean ? S.like.mean[tid] : 0.0) : 0.0;
+    }
+    // tiles travel global -> registers -> LDS one tile ahead of the matrix cores: one barrier per tile
+    double pre[8];
+    auto load_L = [&](int ti) __attribute__((always_inline)) {
+        const int kmax = min(NR, 16 * (ti + 1));                        // L(a, b) = 0 for b > a
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int x = tid + q * 256, r = x / kmax, bcol = x - r * kmax, arow = 16 * ti + r;
+            pre[q] = (x < 16 * kmax && arow < D && bcol < D) ? Lc[(size_t)arow * D + bcol] : 0.0;
+        }
+    };
+    auto store_L = [&](int ti) __attribute__((always_inline)) {
+        const int kmax = min(NR, 16 * (ti + 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int x = tid + q * 256, r = x / kmax, bcol = x - r * kmax;
+            if (x < 16 * kmax) tiles[ti & 1][r * NS + bcol] = pre[q];
+        }
+    };
+    const double *Mt = S.like.invcov;                                   // Mt[b * D + a] = M(a, b)
+    auto load_M = [&](int ti) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int x = tid + q * 256, r = x & 15, bcol = x >> 4, arow = 16 * ti + r;
+            pre[q] = (x < 16 * NR && arow < D && bcol < D) ? Mt[(size_t)bcol * D + arow] : 0.0;
+        }
+    };
+    auto store_M = [&](int ti) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int x = tid + q * 256, r = x & 15, bcol = x >> 4;
+            if (x < 16 * NR) tiles[ti & 1][r * NS + bcol] = pre[q];
+        }
+    };
+    // my row of a tile as A operand (row(ti, li) - 16 ti), and where contraction steps n, n + 1 (n even) sit in it
+    const int arow_l = 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1);
+    const int aoff = arow_l * NS + 2 * lk;
+    v4d acc[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) acc[ti] = v4d{0.0, 0.0, 0.0, 0.0};
+    load_L(0);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        store_L(ti);
+        if (ti + 1 < NT) load_L(ti + 1);
+        __syncthreads();
+        if (wact) {
+            const double *pa = &tiles[ti & 1][aoff];
+            v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n < 4 * (ti + 1); n += 2) {
+                const v2d a2 = *(const v2d *)(pa + 4 * n);              // dims 8 (n >> 1) + 2 lk, + 1
+                a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b[n], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b[n + 1], a4, 0, 0, 0);
+            }
+            acc[ti] = a4;
+        }
+    }
+    if (ms) load_M(0);
+    // |w| of my vector (chordal_sampling.f90:80-82): my registers, then the other three lane groups
+    double n2 = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n2 += acc[ti][r] * acc[ti][r];
+    n2 += __shfl_xor(n2, 16); n2 += __shfl_xor(n2, 32);
+    const double wn = sqrt(n2), iw = 1.0 / wn;
+    const int ivec = 16 * g + li;
+    const bool wanted = wact && ivec < D && basis * D + ivec < nr;
+    const size_t orow = ((size_t)chain * nr + (size_t)basis * D + ivec) * D;
+    const bool al16 = (D & 1) == 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[4 * ti + r] = acc[ti][r] * iw;   // n^ in pair layout
+    auto put_rows = [&](double *base) __attribute__((always_inline)) {
+        if (!wanted) return;
+        double *out = base + orow;
+#pragma unroll
+        for (int n = 0; n < NM; n += 2) {
+            const int d = 8 * (n >> 1) + 2 * lk;
+            if (d + 1 < D && al16) *(v2d *)(out + d) = v2d{b[n], b[n + 1]};
+            else { if (d < D) out[d] = b[n]; if (d + 1 < D) out[d + 1] = b[n + 1]; }
+        }
+    };
+    put_rows(S.nhat);
+    if (wanted && lk == 0) S.nhat_w[(size_t)chain * nr + (size_t)basis * D + ivec] = wn * 3.0;
+    if (!ms) return;
+    // ---- correlated Gaussian (random_gaussian.f90:17-30): along a chord the exponent is quadratic (see ChainCtx) and all a
+    //      slice needs of the matrix is M.s, s = span o n^; every direction of the chain is known here.  One wave of the
+    //      chain's first basis also forms M.(theta_seed - mean), the product the chain needs for its start point.
+#pragma unroll
+    for (int n = 0; n < NM; ++n) b[n] *= spn[8 * (n >> 1) + 2 * lk + (n & 1)];
+    const bool do_y0 = basis == 0 && half == 1 && wv == 3;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) acc[ti] = v4d{0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                                                    // the last tile of L has been consumed
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        store_M(ti);
+        if (ti + 1 < NT) load_M(ti + 1);
+        __syncthreads();
+        const double *pa = &tiles[ti & 1][aoff];
+        if (wact) {
+            v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n < NM; n += 2) {
+                const v2d a2 = *(const v2d *)(pa + 4 * n);
+                a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b[n], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b[n + 1], a4, 0, 0, 0);
+            }
+            acc[ti] = a4;
+        }
+        if (do_y0) {
+            double t = 0.0;
+#pragma unroll
+            for (int n = 0; n < NM; n += 2) {
+                const v2d a2 = *(const v2d *)(pa + 4 * n);
+                const int d = 8 * (n >> 1) + 2 * lk;
+                t += a2.x * y0s[d] + a2.y * y0s[d + 1];
+            }
+            t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+            const int a = 16 * ti + arow_l;
+            if (lk == 0 && a < D) S.ch_My[(size_t)chain * D + a] = t;
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[4 * ti + r] = acc[ti][r];
+    put_rows(S.nhat_Ms);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1034,6 +1456,13 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
         }
         __syncthreads();
     };
+    // msp: M.s of every direction and M.y of the start point were formed by k_nhats_q on the matrix cores (nhat_Ms, ch_My):
+    // no matrix here at all; y and M.y are carried along the chords for the whole chain (a rounding error per slice, the
+    // size of the one a direct evaluation makes)
+    const bool msp = corr && S.nhat_Ms != nullptr && C.quad;
+    double Ms_next[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) Ms_next[k] = 0.0;
     if (corr) {
         if (mat_lds) {
             for (int e = threadIdx.x; e < D * D; e += 64 * WPB) Mlds[e] = S.like.invcov[e];
@@ -1042,7 +1471,10 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
         }
 #pragma unroll
         for (int k = 0; k < DPL; ++k) yv[k] = ld.on[k] ? (ld.lo[k] + ld.span[k] * x0[k]) - ld.mean[k] : 0.0;
-        matvec(yv, My);
+        if (msp) {
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) My[k] = ld.on[k] ? S.ch_My[(size_t)chain * D + lane + 64 * k] : 0.0;
+        } else matvec(yv, My);
         double pa = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) pa += yv[k] * My[k];
@@ -1135,6 +1567,11 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
 #pragma unroll
         for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[lane + 64 * k] : 0.0;
         w_next = S.nhat_w[(size_t)chain * nr + v0];
+        if (msp) {
+            const double *pm = S.nhat_Ms + ((size_t)chain * nr + v0) * D;
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) Ms_next[k] = ld.on[k] ? pm[lane + 64 * k] : 0.0;
+        }
     }
 
 #ifdef SLICE_DBG
@@ -1146,6 +1583,11 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
     // loop-invariant addresses (the per-slice address arithmetic was a third of the slice's instructions)
     const double *nh_base = S.nhat + (size_t)chain * nr * D + lane;
     const double *nw_base = S.nhat_w + (size_t)chain * nr;
+    const double *nm_base = msp ? S.nhat_Ms + (size_t)chain * nr * D + lane : nh_base;
+    if (msp) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) Ms[k] = Ms_next[k];
+    }
     double *row = S.babies + (size_t)chain * nr * nT;
     double *bl_row = S.baby_logL + (size_t)chain * nr;
     double *bl_col = S.baby_logL_T + chain;
@@ -1174,6 +1616,11 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
 #pragma unroll
             for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[64 * k] : 0.0;
             w_next = nw_base[v1];
+            if (msp) {
+                const double *pm = nm_base + v1 * D;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) Ms_next[k] = ld.on[k] ? pm[64 * k] : 0.0;
+            }
         }
         if ((s & 3) == 0 && !seq_mode) {          // one Philox call per lane covers 4 slices x 32 uniforms
             const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
@@ -1208,7 +1655,7 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
             } else {
 #pragma unroll
                 for (int k = 0; k < DPL; ++k) sv[k] = ld.on[k] ? ld.span[k] * nh[k] : 0.0;
-                matvec(sv, Ms);
+                if (!msp) matvec(sv, Ms);
 #pragma unroll
                 for (int k = 0; k < DPL; ++k) { pb += sv[k] * My[k]; pc += sv[k] * Ms[k]; }
             }
@@ -1297,7 +1744,7 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
             C.qa = C.qa + t_last * (2.0 * C.qb + t_last * C.qc);
 #pragma unroll
             for (int k = 0; k < DPL; ++k) { yv[k] += t_last * sv[k]; My[k] += t_last * Ms[k]; }
-            if ((s & 15) == 15) {                    // resynchronise the carried products now and then
+            if ((s & 15) == 15 && !msp) {            // resynchronise the carried products now and then
                 matvec(yv, My);
                 double pa = 0.0;
 #pragma unroll
@@ -1316,6 +1763,10 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
 #pragma unroll
         for (int k = 0; k < DPL; ++k) { nh[k] = nh_next[k]; asm volatile("" : "+v"(nh[k])); }
         asm volatile("" : "+v"(w));
+        if (msp) {
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) { Ms[k] = Ms_next[k]; asm volatile("" : "+v"(Ms[k])); }
+        }
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             x0[k] = cube[k];
@@ -1401,13 +1852,36 @@ extern "C" int pc_launch_generate_live(const PcState *S, int attempt0, int n, do
 extern "C" int pc_nhats_splittable(const PcState *S)
 {
     const char *e = std::getenv("PC_NHATS_QUAD_MIN");
+    if (S->D > 64 && S->D <= 128) return S->ngrade <= 1 && !S->seq_mode && S->nhat_raw != nullptr;    // k_nhats_q<32, 1 / 2>
     return S->D <= 24 && S->D < (e ? std::atoi(e) : 25) && !S->seq_mode && S->nhat_raw != nullptr;
 }
+// (two tile buffers up to nDims 112; beyond that one, with a barrier more per tile: 160 KB of LDS)
+static size_t pc_nhats_q32_lds(int D) { const int NR = ((D + 15) / 16) * 16; return sizeof(double) * (2 * 4 * 34 + (size_t)(NR + (NR <= 112 ? 32 : 16)) * 129); }
 extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchains, int part, hipStream_t st)
 {
     if (!pc_nhats_splittable(S)) return 1;
     const int D = S->D;
     dim3 grid(S->nb_total, nchains);
+    if (D > 64) {
+        if (part == 1) {
+            static const bool panel_off = std::getenv("PC_BASIS_PANEL_OFF") != nullptr;
+            const int nt1 = (D + 15) / 16;
+            if (panel_off) hipLaunchKernelGGL((k_nhats_q<32, 1>), grid, dim3(512), sizeof(double) * 2 * 4 * 34, st, *S, batch);
+            else if (nt1 <= 5) hipLaunchKernelGGL((k_basis<5>), grid, dim3(512), 0, st, *S, batch);
+            else if (nt1 == 6) hipLaunchKernelGGL((k_basis<6>), grid, dim3(512), 0, st, *S, batch);
+            else if (nt1 == 7) hipLaunchKernelGGL((k_basis<7>), grid, dim3(512), 0, st, *S, batch);
+            else hipLaunchKernelGGL((k_basis<8>), grid, dim3(512), 0, st, *S, batch);
+        }
+        else {
+            dim3 g2(S->nb_total * 2, nchains);
+            const int nt = (D + 15) / 16;
+            if (nt <= 5) hipLaunchKernelGGL((k_whiten<5>), g2, dim3(256), 0, st, *S, batch);
+            else if (nt == 6) hipLaunchKernelGGL((k_whiten<6>), g2, dim3(256), 0, st, *S, batch);
+            else if (nt == 7) hipLaunchKernelGGL((k_whiten<7>), g2, dim3(256), 0, st, *S, batch);
+            else hipLaunchKernelGGL((k_whiten<8>), g2, dim3(256), 0, st, *S, batch);
+        }
+        return 0;
+    }
     const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
     if (part == 1) {
         if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64, 1>), grid, dim3(64), sh, st, *S, batch);
@@ -1433,7 +1907,7 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
         if (D <= 32) hipLaunchKernelGGL((k_nhats_q<8>), grid, dim3(128), lds_q(8), st, *S, batch);
         else if (D <= 64) hipLaunchKernelGGL((k_nhats_q<16>), grid, dim3(256), lds_q(16), st, *S, batch);
         else if (D <= 128) {
-            const size_t shq = sizeof(double) * (2 * 4 * 34 + (size_t)(((D + 15) / 16) * 16 + 16) * 129);
+            const size_t shq = pc_nhats_q32_lds(D);
             static size_t doneq = 0;
             if (shq > doneq) { (void)hipFuncSetAttribute((const void *)k_nhats_q<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); doneq = shq; }
             hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), shq, st, *S, batch);
@@ -1456,7 +1930,7 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
 extern "C" int pc_slice_fusable(const PcState *S)
 {   // the slice kernel can do seeds + whitening itself: raw bases in HBM (split launch), one grade, nDims <= 24
     static const bool off = std::getenv("PC_SLICE_FUSED_OFF") != nullptr;
-    return !off && pc_nhats_splittable(S) && S->ngrade <= 1 && S->like.kind != PC_LIKE_CORR_GAUSSIAN && S->nr <= 1024;
+    return !off && S->D <= 24 && pc_nhats_splittable(S) && S->ngrade <= 1 && S->like.kind != PC_LIKE_CORR_GAUSSIAN && S->nr <= 1024;
 }
 
 extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchains, hipStream_t st)
@@ -1487,7 +1961,7 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     const int phi_lds = (S->nDer > 0 && sh0 + tb <= 48 * 1024) ? 1 : 0;
     size_t sh = sh0 + (phi_lds ? tb : 0);
     const size_t mb = sizeof(double) * (size_t)S->D * S->D;
-    const int mat_lds = (S->like.kind == PC_LIKE_CORR_GAUSSIAN && sh + mb <= 150 * 1024) ? 1 : 0;
+    const int mat_lds = (S->like.kind == PC_LIKE_CORR_GAUSSIAN && S->nhat_Ms == nullptr && sh + mb <= 150 * 1024) ? 1 : 0;
     const int D = S->D;
     // four chains per workgroup around one LDS copy of the inverse covariance (65 <= nDims <= 128)
     static const bool wpb_off = std::getenv("PC_SLICE_WPB_OFF") != nullptr;

@@ -112,6 +112,10 @@ struct PcState {
     double *nhat;                // [B][nr][D] whitened, normalised directions (generation order)
     double *nhat_w;              // [B][nr] 3*|L n|
     double *nhat_raw;            // [B][nb_total][D][D] orthonormal bases of the next nursery, before whitening (or null)
+    // correlated Gaussian, 64 < nDims <= 128 (or null): the products the chord needs, formed on the matrix cores by the
+    // kernel that makes the directions instead of one matrix-vector product per slice on the chain's critical path
+    double *nhat_Ms;             // [B][nr][D] M.(span o n^) for every direction
+    double *ch_My;               // [B][D] M.(theta_seed - mean) of every chain's start point
     // ---- plan written by the consume kernel for the apply kernels
     PcPlan *plan;                // [B]
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
