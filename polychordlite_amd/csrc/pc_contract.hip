@@ -1577,6 +1577,23 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     return 0;
 }
 
+// pieces of the general update path used by the fused update of pc_update.hip
+extern "C" void pc_launch_scan_blocks(int *blk, int nblk, int *total, int *total2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, blk, nblk, total, total2);
+}
+extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const int *count, hipStream_t st)
+{   // one cluster, one "partial" = n times the covariance
+    const int D = S->D;
+    size_t sh2 = sizeof(double) * (2 * (size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT));
+    int a_global = 0;
+    if (sh2 > 160 * 1024) { a_global = 1; sh2 = sizeof(double) * ((size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT)); }
+    if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
+    static size_t donec1 = 0;
+    if (sh2 > donec1) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec1 = sh2; }
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(1), dim3(PC_CHOL_NT), sh2, st, *S, 1, ncov, count, a_global);
+}
+
 extern "C" void pc_launch_init_state(const PcState *S, double logzero, hipStream_t st)
 {
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(256), 0, st, *S, logzero);

@@ -962,6 +962,48 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 // rounding of the order of the basis' condition number times epsilon (what k_nhats_big does beyond 128 dimensions).
 // One barrier per panel instead of one per pivot, 56 matrix instructions per wave and panel instead of sixteen rounds of
 // 32 LDS loads + 96 FMAs: the one-pivot-at-a-time kernel spent 110 us per basis here.
+// sum over the four lanes 16 apart (the four coordinate classes of a vector in the pair layout), every lane ends with the
+// total: gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap) instead of two trips through the LDS crossbar
+__device__ __forceinline__ double lk_sum4(double x)
+{
+    {
+        const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+        x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+        x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return x;
+}
+// one pivot of the in-panel Gram-Schmidt (random_utils.F90:391-399): the pivot is vector J of the wave, i.e. lane J of every
+// row of sixteen lanes -- its coordinates reach the other lanes of the row by DPP row broadcast, no LDS round trip
+template <int J, int NM>
+__device__ __forceinline__ void gs_pivot(double (&v)[NM], int li)
+{
+    double q[NM];
+#pragma unroll
+    for (int n = 0; n < NM; ++n)
+        q[n] = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v[n]), 0x150 + J, 0xF, 0xF, false),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(v[n]), 0x150 + J, 0xF, 0xF, false));
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+    for (int n = 0; n < NM; n += 4) {
+        a0 += q[n] * q[n]; a1 += q[n + 1] * q[n + 1]; a2 += q[n + 2] * q[n + 2]; a3 += q[n + 3] * q[n + 3];
+        c0 += q[n] * v[n]; c1 += q[n + 1] * v[n + 1]; c2 += q[n + 2] * v[n + 2]; c3 += q[n + 3] * v[n + 3];
+    }
+    const double qq = lk_sum4((a0 + a1) + (a2 + a3)), dv = lk_sum4((c0 + c1) + (c2 + c3));
+    // 1 / qq by Newton from the hardware estimate (two steps: full precision)
+    double rq = __builtin_amdgcn_rcp(qq);
+    rq = fma(rq, fma(-qq, rq, 1.0), rq);
+    rq = fma(rq, fma(-qq, rq, 1.0), rq);
+    const double cproj = (li > J) ? dv * rq : 0.0;                      // (the pivot itself and the vectors before it stay)
+#pragma unroll
+    for (int n = 0; n < NM; ++n) v[n] -= cproj * q[n];
+}
+
 template <int NT>
 __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
 {
@@ -975,6 +1017,9 @@ __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
     const int ivec = 16 * g + li, np = (D + 15) >> 4;
     const bool vact = ivec < D;
     // gaussian deviates: element (basis D + i) D + d of stream (batch, chain) in PC_DOM_NHAT, two per Philox call
+#ifdef BASIS_DBG
+    const long long t_start = clock64();
+#endif
     double v[NM];
 #pragma unroll
     for (int n = 0; n < NM; ++n) v[n] = 0.0;
@@ -995,51 +1040,54 @@ __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
             }
         }
     }
-    auto lk_sum = [&](double x) __attribute__((always_inline)) { x += __shfl_xor(x, 16); x += __shfl_xor(x, 32); return x; };
     {   // random_direction (random_utils.F90:276-298)
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int n = 0; n < NM; n += 2) { p0 += v[n] * v[n]; p1 += v[n + 1] * v[n + 1]; }
-        const double n2 = lk_sum(p0 + p1), inrm = vact ? 1.0 / sqrt(n2) : 0.0;
+        const double n2 = lk_sum4(p0 + p1), inrm = vact ? 1.0 / sqrt(n2) : 0.0;
 #pragma unroll
         for (int n = 0; n < NM; ++n) v[n] *= inrm;
     }
     const int arow_l = 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1);   // row of an output tile that sits in my A-operand slot
     double *rawb = S.nhat_raw + ((size_t)chain * S.nb_total + basis) * (size_t)RAWB + (size_t)g * 64 + lane;
+#ifdef BASIS_DBG
+    const bool dbg = blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;
+    const long long t_rng = clock64();
+    if (dbg && g == 0) atomicAdd((unsigned long long *)&S.ctl->gen_cyc[0], (unsigned long long)(t_rng - t_start));
+#endif
     for (int p = 0; p < np; ++p) {
         double *Q = Qp[p & 1];
+#ifdef BASIS_DBG
+        const long long t_a = clock64();
+#endif
         if (g == p) {
             // ---- my panel: Gram-Schmidt pivot by pivot (random_utils.F90:391-399), the pivot unnormalised as there
             const int cnt = min(16, D - 16 * p);
-            for (int j = 0; j < cnt; ++j) {
-                if (li == j) {
+#define PC_GS(J) if (J < cnt) gs_pivot<J, NM>(v, li);
+            PC_GS(0) PC_GS(1) PC_GS(2) PC_GS(3) PC_GS(4) PC_GS(5) PC_GS(6) PC_GS(7)
+            PC_GS(8) PC_GS(9) PC_GS(10) PC_GS(11) PC_GS(12) PC_GS(13) PC_GS(14) PC_GS(15)
+#undef PC_GS
+            {   // the panel's vectors are final: normalise (the reference does it when a vector becomes the pivot: same vector)
+                double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-                    for (int n = 0; n < NM; n += 2) *(v2d *)&Q[j * NS + 4 * n + 2 * lk] = v2d{v[n], v[n + 1]};
-                }
-                double q[NM];
+                for (int n = 0; n < NM; n += 2) { p0 += v[n] * v[n]; p1 += v[n + 1] * v[n + 1]; }
+                const double n2 = lk_sum4(p0 + p1), inrm = (li < cnt) ? 1.0 / sqrt(n2) : 0.0;
 #pragma unroll
-                for (int n = 0; n < NM; n += 2) { const v2d t = *(const v2d *)&Q[j * NS + 4 * n + 2 * lk]; q[n] = t.x; q[n + 1] = t.y; }
-                double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-#pragma unroll
-                for (int n = 0; n < NM; n += 2) { a0 += q[n] * q[n]; a1 += q[n + 1] * q[n + 1]; c0 += q[n] * v[n]; c1 += q[n + 1] * v[n + 1]; }
-                const double qq = lk_sum(a0 + a1), dv = lk_sum(c0 + c1);
-                if (li == j) {
-                    const double inrm = 1.0 / sqrt(qq);
-#pragma unroll
-                    for (int n = 0; n < NM; ++n) v[n] *= inrm;
-                } else if (li > j) {
-                    const double cproj = dv / qq;
-#pragma unroll
-                    for (int n = 0; n < NM; ++n) v[n] -= cproj * q[n];
-                }
+                for (int n = 0; n < NM; ++n) v[n] *= inrm;
             }
             // the finished panel, normalised, for the waves behind; and out to HBM
 #pragma unroll
             for (int n = 0; n < NM; n += 2) *(v2d *)&Q[li * NS + 4 * n + 2 * lk] = v2d{v[n], v[n + 1]};
 #pragma unroll
             for (int n = 0; n < NM; ++n) rawb[(size_t)n * 512] = v[n];
+#ifdef BASIS_DBG
+            if (dbg) atomicAdd((unsigned long long *)&S.ctl->gen_cyc[1], (unsigned long long)(clock64() - t_a));
+#endif
         }
         __syncthreads();
+#ifdef BASIS_DBG
+        const long long t_b = clock64();
+#endif
         if (g > p && 16 * g < D) {
             // ---- a later wave: C = Q V^T, V <- V - C^T Q
             v4d c4 = v4d{0.0, 0.0, 0.0, 0.0};
@@ -1057,8 +1105,14 @@ __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
                     a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Q[(4 * ks + lk) * NS + 16 * ti + arow_l], -c4[ks], a4, 0, 0, 0);
                 v[4 * ti] = a4[0]; v[4 * ti + 1] = a4[1]; v[4 * ti + 2] = a4[2]; v[4 * ti + 3] = a4[3];
             }
+#ifdef BASIS_DBG
+            if (dbg && g == p + 1) atomicAdd((unsigned long long *)&S.ctl->gen_cyc[2], (unsigned long long)(clock64() - t_b));
+#endif
         }
     }
+#ifdef BASIS_DBG
+    if (dbg && g == 0) { atomicAdd((unsigned long long *)&S.ctl->gen_cyc[3], (unsigned long long)(clock64() - t_start)); atomicAdd((unsigned long long *)&S.ctl->nn_walks, 1ull); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

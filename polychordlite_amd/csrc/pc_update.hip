@@ -313,10 +313,205 @@ __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const dou
 #endif
 }
 
-extern "C" int pc_update_fused_ok(const PcState *S, int nc) { return nc == 1 && S->D < 32; }
+// ------------------------------------------------------------------------------------------------------------------
+// 32 <= nDims <= 128 (one cluster): the same single pass -- compaction of the surviving phantoms and the shifted moments
+// of live + phantom coordinates while the rows go by -- with the moment matrix in 16 x 16 tiles spread over the four
+// waves of a workgroup.  The general path read every phantom row three times (scatter, mean, centred products: 2.5 ms of a
+// 3.4 ms update at nDims = 100, nlive 5000) and gathered the 800 coordinate bytes out of 1616-byte rows for the matrix
+// cores; here a row is read once, whole, written once, and its coordinates are in LDS when the products are formed.
+//   k_upd_flag, k_scan_blocks (offsets of the 256-row blocks), k_upd_move_w, k_upd_fold, k_upd_final_w, k_cov_final_chol
+// Workgroups are persistent: each walks its share of the 64-row chunks with the accumulator tiles (upper triangle of
+// NT x NT tiles of X^T X, X = [cube - shift | 1 | 0...], pairs q = wave, wave + 4, ...) in registers and writes ONE record.
+#define UPDW_ROWS 64
+template <int NT, int W>
+__device__ __forceinline__ void updw_accumulate(const double *tile, int TS, int n16, int li, int lk, upd_v4d (&acc)[(NT * (NT + 1) / 2 + 3) / 4])
+{
+    for (int ks = 0; ks < (n16 >> 2); ++ks) {
+        const double *row = tile + (size_t)(4 * ks + lk) * TS + li;
+        double x[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = row[16 * t];
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < NT; ++tj, ++q)
+                if ((q & 3) == W) acc[q >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[q >> 2], 0, 0, 0);
+    }
+}
+template <int NT, int W>
+__device__ __forceinline__ void updw_store(double *out, int D, int li, int lk, const upd_v4d (&acc)[(NT * (NT + 1) / 2 + 3) / 4])
+{
+    const int npair = D * (D + 1) / 2;
+    int q = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < NT; ++tj, ++q)
+            if ((q & 3) == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * ti + lk + 4 * r, b = 16 * tj + li;
+                    if (a <= b && b <= D) {
+                        const int p = (b < D) ? a * D - a * (a - 1) / 2 + (b - a) : (a < D ? npair + a : npair + D);
+                        out[p] = acc[q >> 2][r];
+                    }
+                }
+            }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_upd_move_w(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
+                                                    double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                    const double *shift, double *part, int E, int def, int nlc, int ndc)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TS = 16 * NT + ((NT & 1) ? 0 : 16);                  // = 16 mod 32 doubles: the four row groups of an operand
+    constexpr int NPW = (NT * (NT + 1) / 2 + 3) / 4;                   //   split over both halves of the LDS banks
+    __shared__ unsigned long long m64[4], mm64[4];
+    __shared__ int wcnt[4];
+    const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, D = S.D, nT = S.nT;
+    double *tile = (double *)smem;                                      // [UPDW_ROWS + 16][TS]
+    double *sh = tile + (size_t)(UPDW_ROWS + 16) * TS;                  // [D]
+    for (int d = tid; d < D; d += 256) sh[d] = shift[d];
+    for (int e = tid; e < (UPDW_ROWS + 16) * TS; e += 256) tile[e] = 0.0;     // (the columns past the ones stay zero)
+    upd_v4d acc[NPW];
+#pragma unroll
+    for (int t = 0; t < NPW; ++t) acc[t] = upd_v4d{0.0, 0.0, 0.0, 0.0};
+    const int npc = 4 * nblk, total = npc + nlc + ndc;
+    __syncthreads();
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+        int n = 0;                                                      // member rows of this chunk
+        if (c < npc) {
+            // ---- 64 phantom rows: sub-chunk `sub` of the 256-row block `blk` (whose offset the scan left in blk_off)
+            const int blk = c >> 2, sub = c & 3, j = blk * 256 + tid;
+            const bool k = (j < nph) && keep[j];
+            const bool km = k && (j < nph0u || (j - nph0u) / S.nr < tmark);       // a phantom at the mark (see k_upd_move)
+            const unsigned long long m = __ballot(k), mm = __ballot(km);
+            if (lane == 0) { m64[wv] = m; mm64[wv] = mm; }
+            __syncthreads();
+            int off = blk_off[blk];
+            for (int x = 0; x < sub; ++x) off += __popcll(m64[x]);
+            if (wv == sub && k) {
+                const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+                phL2[pos] = S.ph_logL[j]; phC2[pos] = S.ph_cuid[j]; phU2[pos] = S.ph_uid[j];
+            }
+            const unsigned long long ms = m64[sub], mms = mm64[sub], below = (1ull << (16 * wv)) - 1ull;
+            upd_stage_masked(S.phantom + (size_t)(blk * 256 + sub * 64 + 16 * wv) * nT, (ms >> (16 * wv)) & 0xFFFFull, (mms >> (16 * wv)) & 0xFFFFull,
+                             ph2 + (size_t)(off + __popcll(ms & below)) * nT, tile + (size_t)__popcll(mms & below) * TS, TS, sh, D, nT, lane);
+            n = __popcll(mms);
+        } else if (c < npc + nlc) {
+            // ---- live points of slots [r0, r0 + 64)
+            const int r0 = (c - npc) * UPDW_ROWS, r = r0 + tid;
+            const bool k = tid < UPDW_ROWS && r < S.Ncap && S.live_cluster[r] == 0 && (!def || S.slot_step[r] < tmark);
+            const unsigned long long m = __ballot(k);
+            if (tid == 0) m64[0] = m;
+            __syncthreads();
+            const unsigned long long ms = m64[0], below = (1ull << (16 * wv)) - 1ull;
+            upd_stage_masked(S.live + (size_t)(r0 + 16 * wv) * nT, (ms >> (16 * wv)) & 0xFFFFull, (ms >> (16 * wv)) & 0xFFFFull, nullptr,
+                             tile + (size_t)__popcll(ms & below) * TS, TS, sh, D, nT, lane);
+            n = __popcll(ms);
+        } else {
+            // ---- def: points alive at the mark that died later in the launch (see k_upd_move); rows scattered in the dead
+            //      array: the four waves take them in turn, lane = coordinate
+            const PcCtl *ctl = S.ctl;
+            const int T = ctl->upd_T, ts = ctl->upd_ts;
+            const int t = tmark + (c - npc - nlc) * UPDW_ROWS + tid;
+            long long di = -1;
+            if (tid < UPDW_ROWS && t < ts) {
+                const PcPlan *pw = S.plan + (T - 1 - t);
+                const int src = pw->dead_src;
+                const bool existed = src >= 0 || (T - 1 - (-src - 1)) < tmark;
+                if (pw->dead_idx >= 0 && pw->logw > S.logzero && existed) di = pw->dead_idx;
+            }
+            long long *dix = (long long *)(tile + (size_t)UPDW_ROWS * TS);       // (rows 64 .. 79 of the tile: zeroed again below)
+            if (tid < UPDW_ROWS) dix[tid] = di;
+            const unsigned long long m = __ballot(di >= 0);
+            if (tid == 0) m64[0] = m;
+            __syncthreads();
+            unsigned long long mb = m64[0];
+            int row = 0;
+            while (mb) {
+                const int b = __ffsll((long long)mb) - 1; mb &= mb - 1;
+                if ((row & 3) == wv) {
+                    const long long d = dix[b];
+                    for (int e = lane; e <= D; e += 64) tile[(size_t)row * TS + e] = e < D ? S.dead[(size_t)d * nT + e] - sh[e] : 1.0;
+                }
+                row++;
+            }
+            n = row;
+            __syncthreads();
+            for (int e = tid; e < 16 * TS; e += 256) tile[(size_t)UPDW_ROWS * TS + e] = 0.0;
+        }
+        __syncthreads();
+        // rows n .. next multiple of 16: zero up to the ones column (the matrix cores take four rows at a time)
+        const int n16 = (n + 15) & ~15;
+        for (int e = tid; e < (n16 - n) * (D + 1); e += 256) tile[(size_t)(n + e / (D + 1)) * TS + e % (D + 1)] = 0.0;
+        __syncthreads();
+        if (wv == 0) updw_accumulate<NT, 0>(tile, TS, n16, li, lk, acc);
+        else if (wv == 1) updw_accumulate<NT, 1>(tile, TS, n16, li, lk, acc);
+        else if (wv == 2) updw_accumulate<NT, 2>(tile, TS, n16, li, lk, acc);
+        else updw_accumulate<NT, 3>(tile, TS, n16, li, lk, acc);
+        __syncthreads();                                                // the tile is free for the next chunk
+    }
+    double *out = part + (size_t)blockIdx.x * E;
+    if (wv == 0) updw_store<NT, 0>(out, D, li, lk, acc);
+    else if (wv == 1) updw_store<NT, 1>(out, D, li, lk, acc);
+    else if (wv == 2) updw_store<NT, 2>(out, D, li, lk, acc);
+    else updw_store<NT, 3>(out, D, li, lk, acc);
+}
+
+// records added up; delta = mean - shift; n cov = M2 - n delta delta^T for k_cov_final_chol (which divides by n, stores the
+// covariance and factorises in the reference's order of operations); new shift; thresholds reset
+__global__ __launch_bounds__(1024) void k_upd_final_w(PcState S, int nb, const double *part, int E, double *shift, int def, double *ncov, int *count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *tot = (double *)smem;                  // [nE]
+    __shared__ double mu[128];
+    const int tid = threadIdx.x, D = S.D, npair = D * (D + 1) / 2, nE = npair + D + 1;
+    for (int e = tid; e < nE; e += 1024) {
+        double s = 0.0;
+        for (int k = 0; k < nb; k += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (k + u < nb) ? part[(size_t)(k + u) * E + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        tot[e] = s;
+    }
+    __syncthreads();
+    const double n = tot[npair + D];
+    if (tid < D) mu[tid] = tot[npair + tid] / n;
+    __syncthreads();
+    for (int p = tid; p < D * D; p += 1024) {
+        const int a = p / D, b = p % D, lo = a < b ? a : b, hi = a < b ? b : a;
+        ncov[p] = tot[lo * D - lo * (lo - 1) / 2 + (hi - lo)] - n * mu[lo] * mu[hi];      // population normalisation, run_time_info.f90:634
+    }
+    if (tid < D) shift[tid] += mu[tid];
+    if (tid == 0) { count[0] = (int)n; if (!(def && S.ctl->upd_keep_thr)) S.death_thr[0] = -PC_HUGE; if (def) S.ctl->upd_pending = 0; }
+}
+
+extern "C" int pc_update_fused_entries(const PcState *S);
+extern "C" void pc_launch_scan_blocks(int *blk, int nblk, int *total, int *total2, hipStream_t st);
+extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const int *count, hipStream_t st);
+static int updw_grid(const PcState *S, int nph, int deferred)
+{
+    const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlc = (S->Ncap + UPDW_ROWS - 1) / UPDW_ROWS, ndc = deferred ? (S->B + UPDW_ROWS - 1) / UPDW_ROWS : 0;
+    const int total = 4 * nblk + nlc + ndc;
+    return total < 512 ? total : 512;
+}
+
+extern "C" int pc_update_fused_ok(const PcState *S, int nc) { return nc == 1 && S->D <= 128; }
+
 extern "C" int pc_update_fused_blocks(const PcState *S, int nph)
 {   // partial records: one per block of k_upd_move (phantom blocks, live blocks, dead-row blocks of a deferred update),
     // then one per group of UPD_FOLD of them
+    if (S->D >= 32) {                                   // persistent workgroups + their groups + room for n cov and n
+        const int G = updw_grid(S, nph, 1), E = pc_update_fused_entries(S);
+        return G + (G + UPD_FOLD - 1) / UPD_FOLD + (S->D * S->D + 2 + E - 1) / E;
+    }
     const int nb = (nph + UPD_ROWS - 1) / UPD_ROWS + (S->Ncap + UPD_ROWS - 1) / UPD_ROWS + (S->B + UPD_ROWS - 1) / UPD_ROWS;
     return nb + (nb + UPD_FOLD - 1) / UPD_FOLD;
 }
@@ -329,6 +524,31 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
 {
     const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
     const int ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
+    if (S->D >= 32) {
+        const int D = S->D, NTv = (D + 1 + 15) / 16, TSv = 16 * NTv + ((NTv & 1) ? 0 : 16);
+        const int nlc = (S->Ncap + UPDW_ROWS - 1) / UPDW_ROWS, ndc = deferred ? (S->B + UPDW_ROWS - 1) / UPDW_ROWS : 0;
+        const int G = updw_grid(S, nph, deferred), ng = (G + UPD_FOLD - 1) / UPD_FOLD;
+        double *part2 = part + (size_t)G * E, *ncov = part2 + (size_t)ng * E;
+        int *count = (int *)(ncov + (size_t)D * D);
+        const size_t shw = sizeof(double) * ((size_t)(UPDW_ROWS + 16) * TSv + D);
+        hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
+        pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
+#define UPDW_LAUNCH(NT) { \
+            static bool done_##NT = false; \
+            if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_move_w<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
+            hipLaunchKernelGGL((k_upd_move_w<NT>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
+                               ph2, phL2, phC2, phU2, (const double *)shift, part, E, deferred, nlc, ndc); }
+        switch (NTv) { case 3: UPDW_LAUNCH(3) break; case 4: UPDW_LAUNCH(4) break; case 5: UPDW_LAUNCH(5) break; case 6: UPDW_LAUNCH(6) break;
+                       case 7: UPDW_LAUNCH(7) break; case 8: UPDW_LAUNCH(8) break; default: UPDW_LAUNCH(9) break; }
+#undef UPDW_LAUNCH
+        hipLaunchKernelGGL(k_upd_fold, dim3(ng), dim3(256), 0, st, (const double *)part, G, E, part2);
+        const size_t shf = sizeof(double) * (size_t)(D * (D + 1) / 2 + D + 1);
+        static size_t donef = 0;
+        if (shf > donef) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef = shf; }
+        hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
+        pc_launch_chol_only(S, ncov, count, st);
+        return;
+    }
     const int TS = ((S->D + 2) | 1);
     size_t sh = sizeof(double) * ((size_t)(UPD_ROWS + 16) * TS + S->D);
     if (sh < sizeof(double) * (12 * 256 + S->D)) sh = sizeof(double) * (12 * 256 + S->D);       // the waves' result tiles reuse the row tile
