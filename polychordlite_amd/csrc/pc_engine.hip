@@ -195,7 +195,7 @@ HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
 std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
-struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0; };
+struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0, compactions = 0; };
 
 // HIP-event stopwatch per kernel class, on the engine's own stream (bench.py's roofline numbers)
 enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_N };
@@ -585,9 +585,28 @@ struct Engine {
         S.Pcap = (int)np;
     }
 
+    // pool mode: the phantom array is full -- drop what the updates have invalidated (general clean: flags, scan, scatter into
+    // the alternate buffers), grow if that is not enough.  Between nurseries only.
+    long long pool_cursor = 0;
+    double *babies_own = nullptr;
+    void pool_compact()
+    {
+        hipEvent_t e0 = kt.begin(KT_CLEAN);
+        pc_launch_clean(&S, (int)pool_cursor, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
+        kt.end(KT_CLEAN, e0);
+        int total = 0;
+        HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
+        pool_cursor = total; h_ctl->nphantom = total; nph_stale = false;
+        if (pool_cursor + (long long)B * S.nr > S.Pcap / 2) grow_phantoms(std::max<long long>(2LL * S.Pcap, 2 * (pool_cursor + (long long)B * S.nr)));
+        tm.compactions++;
+    }
+
     void ensure_capacity()
     {   // the next batch may append B*nr phantoms and B dead points
         if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) grow_dead(S.Dcap * 2);
+        if (S.pool) { if (h_ctl->ncluster_dead + h_ctl->ncluster + 8 > S.maxc_dead) grow_dead_clusters(2 * S.maxc_dead); return; }
         if (nph_stale && (long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) read_ctl();   // pre-clean count: refresh
         if ((long long)h_ctl->nphantom + (long long)B * S.nr > S.Pcap) grow_phantoms((long long)h_ctl->nphantom + (long long)B * S.nr);
         // dead clusters: a segment can retire at most the clusters that are active when it starts
@@ -786,7 +805,7 @@ struct Engine {
         const bool seq_post = S.seq_mode && (cfg.posteriors || cfg.equals);
         if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
         call_dumper();
-        const int nph = h_ctl->nphantom;
+        const int nph = S.pool ? (int)pool_cursor : h_ctl->nphantom;
         static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
         if (!fused_off && nph > 0 && !cfg.do_clustering && cfg.boost_posterior == 0.0 && pc_update_fused_ok(&S, h_ctl->ncluster)) {
             // one cluster, nDims < 32: clean + covariance + Cholesky in three launches (pc_update.hip)
@@ -808,7 +827,7 @@ struct Engine {
                 h_ctl->nphantom = total;
                 if (seq_post) seq_consume((unsigned long long)(nph - total));
             } else nph_stale = true;
-            std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
+            if (!S.pool) { std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2); }
             write_resume();
             return;
         }
@@ -1417,10 +1436,25 @@ struct Engine {
         static const bool defer_off = std::getenv("PC_DEFER_OFF") != nullptr;
         S.defer_update = (!defer_off && par_ok && !cfg.do_clustering && cfg.boost_posterior == 0.0 && !dumper && !on_update && !cfg.resume_write &&
                           !S.seq_mode && pc_update_fused_ok(&S, 1) && !std::getenv("PC_UPDATE_FUSED_OFF")) ? 1 : 0;
+        // Pool mode (same conditions, likelihood on the device): k_slice writes a nursery's babies into the phantom array itself,
+        // updates invalidate phantoms where they lie, and the array is compacted only when it is full -- the rows of a run
+        // are written once and read once (pc_state.h).  The host keeps the cursor: nothing it does not know moves it.
+        static const bool pool_off = std::getenv("PC_POOL_OFF") != nullptr;
+        S.pool = (S.defer_update && !callback_mode && !pool_off) ? 1 : 0;
+        if (S.pool) {
+            pool_cursor = h_ctl->nphantom;
+            babies_own = S.babies;
+            if (g_cap_phantoms.load() <= 0) grow_phantoms(2LL * S.Pcap);        // room for several updates between compactions
+        }
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
             bool fresh_nursery = false;
+            if (h_ctl->i_nursery == 0 && S.pool) {
+                if (pool_cursor + (long long)B * S.nr > S.Pcap) pool_compact();
+                S.pool_base = (int)pool_cursor; S.pool_rows = B * S.nr; S.babies = S.phantom + (size_t)pool_cursor * S.nT;
+                pool_cursor += (long long)B * S.nr;
+            }
             if (h_ctl->i_nursery == 0) {
                 // (between the stamp of the last round and the launch of k_slice the device idles: nothing that can wait
                 //  is done in between -- capacity checks precede the contraction, not the sampling)
@@ -1625,6 +1659,7 @@ struct Engine {
         if (st_copy) (void)hipStreamSynchronize(st_copy);
         if (st_side) (void)hipStreamSynchronize(st_side);
         if (raw_buf[0]) { S.nhat_raw = raw_buf[0]; for (int r = 1; r < RAW_RING; ++r) dfree(raw_buf[r]); raw_buf[0] = nullptr; }     // S.nhat_raw pointed at one of them
+        if (babies_own) { S.babies = babies_own; babies_own = nullptr; }      // (pool mode pointed it into the phantom array)
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
                           &S.lse_ref, &S.lse_sum, &S.death_thr, &S.chol, &S.cov, &S.logZp_dead, &S.logZp2_dead, &S.phantom,
                           &S.ph_logL, &S.dead, &S.dead_logw, &S.dead_postX, &S.dead_postZ, &S.babies, &S.baby_logL, &S.baby_logL_T,

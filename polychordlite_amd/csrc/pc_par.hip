@@ -516,10 +516,10 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // consumption order (ph_count = -2), its phantoms land in it at their own index and the other rows of the region
     // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
     // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
-    if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = nph0 + tid * nr; pw->ph_count = -2; }
+    if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = S.pool ? S.pool_base + w * nr : nph0 + tid * nr; pw->ph_count = -2; }
     for (int s = tid; s < Ncap; s += PAR_NT) { S.slot_src[s] = -1; if (defer) S.slot_step[s] = -1; }
     if (lane == 0) accR[wv] = 0ull;
-    if (tid == 0) ish[2] = nph0 + ts * nr;               // rows in use after this launch
+    if (tid == 0) ish[2] = S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr;               // rows in use after this launch
     __syncthreads();
 #ifdef PAR_DBG_PUBLISH
     pcy[2] = clock64(); pcy[3] = pcy[2];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
                 Kl = kn; marks++;
             }
             ctl->upd_pending = 1; ctl->upd_marks = marks;
-            ctl->upd_tmark = accStep[Kl - 1] + 1; ctl->upd_T = T; ctl->upd_ts = ts; ctl->upd_nph0 = nph0;
+            ctl->upd_tmark = accStep[Kl - 1] + 1; ctl->upd_T = T; ctl->upd_ts = ts; ctl->upd_nph0 = S.pool ? S.pool_base : nph0;
             ctl->upd_thr = key2d(uKey[Kl - 1]); ctl->upd_keep_thr = (Kp > Kl) ? 1 : 0;
             ctl->logX_last_update = Xp0 + (double)Kl * d01;
         }

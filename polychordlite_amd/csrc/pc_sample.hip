@@ -1480,6 +1480,8 @@ __global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, i
             x0[k] = ld.on[k] ? seed[dim] : 0.5;
         }
     }
+    // pool mode: the babies land in this chain's rows of the phantom array; none of them is a phantom before the chain is consumed
+    if (S.pool) for (int i = lane; i < nr; i += 64) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
     ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, false, 0.0, 0.0, 0.0, 0.0};
     const bool corr = S.like.kind == PC_LIKE_CORR_GAUSSIAN;
     C.quad = (corr || S.like.kind == PC_LIKE_GAUSSIAN) && !(S.ablate & 1);

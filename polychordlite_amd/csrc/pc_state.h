@@ -123,6 +123,10 @@ struct PcState {
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
     int *slot_step;              // [Ncap] step of the last parallel-contraction launch at which the slot's occupant was accepted, -1: older
     int defer_update;            // the parallel contraction may run past update triggers (no host work is tied to an update)
+    // pool mode (same conditions): the babies of a nursery are written by k_slice straight into the phantom array -- chain c
+    // owns rows pool_base + c nr .. -- so becoming a phantom is a cluster id in a side array, not a row copy; updates
+    // invalidate in place, and the array is compacted only when it runs full
+    int pool, pool_base, pool_rows;
     // ---- fast/slow parameter grades (chordal_sampling.f90:94-145): grade g moves the parameters from g_off[g] to the
     //      last one with g_nr[g] directions taken from g_nb[g] orthonormal bases of that subspace; nr = sum g_nr.
     //      One grade: g_off = 0, g_nr = nr.  g_col0 = first direction of the grade in generation order, g_e0 = first

@@ -10,9 +10,9 @@
 // with the host's launch rate between them: ~140 us per update, 31 updates per run at the metric configuration = a fifth
 // of the run.  Here:
 //   k_upd_flag   which phantoms survive, survivors per block of 256 rows
-//   k_upd_move   every block: its offset (sum of the counts before it), compaction of its survivors into the alternate
-//                buffer, and -- in the same pass, while the rows are in L2 -- first and second moments of its rows' cube
-//                coordinates about a SHIFT; further blocks do the same for the live points
+//   k_upd_gather persistent workgroups: compaction of the survivors into the alternate buffer (offsets from k_scan_blocks;
+//                pool mode: none) and -- in the same pass -- first and second moments of the rows' cube coordinates about a
+//                SHIFT; the live points likewise
 //   k_upd_fold   the blocks' moments added in groups of sixteen
 //   k_upd_final  the groups' moments added, mean / covariance / Cholesky factor, new shift, thresholds reset
 // One pass instead of two (mean, then centred products) needs the shift: the moments are taken about the PREVIOUS update's
@@ -71,140 +71,220 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigne
     const double thr = def ? S.ctl->upd_thr : S.death_thr[0];
     const int j = blockIdx.x * UPD_ROWS + tid;
     bool k = false;
-    if (j < nph) { k = (S.ph_cuid[j] == uid0) && !(S.ph_logL[j] < thr); keep[j] = k ? 1 : 0; }
+    if (j < nph) {
+        const unsigned cu = S.ph_cuid[j];
+        k = (cu == uid0) && !(S.ph_logL[j] < thr); keep[j] = k ? 1 : 0;
+        if (S.pool && !k && cu == uid0) S.ph_cuid[j] = PC_CUID_NONE;        // pool mode: dropped where it lies
+    }
     const unsigned long long m = __ballot(k);
     if (lane == 0) cnt[wv] = __popcll(m);
     __syncthreads();
     if (tid == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 
-// partial record of a block: [npair second moments (a <= b, row-major upper triangle) | D first moments | count], padded to E
-//
-// The moments are X^T X of the block's member rows X = [cube - shift | 1] (n x (D+1)) on the fp64 matrix cores
-// (v_mfma_f64_16x16x4_f64; operand maps as in k_cov_partial).  Not for the flops: with one product per thread every FMA
-// costs two LDS reads, and twelve waves per CU doing that are bound by the LDS pipe (10 us per block); a 16x16x4 tile
-// needs two reads per 2048 flops.  Wave w takes the rows 4w .. 4w+3, 4w+16 .., the four waves' tiles are added in order.
 typedef double upd_v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(UPD_NT) void k_upd_move(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_count,
+// ------------------------------------------------------------------------------------------------------------------
+// k_upd_gather: ONE pass over the phantom array (and the live points, and for a deferred update the points that died after
+// the mark): the surviving phantoms are compacted into the alternate buffers -- or, in pool mode, left where they lie --
+// and the rows that count go, coordinates minus shift and a column of ones, into an LDS tile; when the tile is full its
+// X^T X is added to accumulator tiles in registers (fp64 matrix cores, v_mfma_f64_16x16x4_f64).  Workgroups are
+// persistent: each walks its share of the 256-row blocks and writes ONE partial record
+//   [npair second moments (a <= b, row-major upper triangle) | D first moments | count], padded to E,
+// so sparse stretches of the array (pool mode: most rows are invalid between compactions) cost a ballot, not a launch
+// of the whole machinery.  The matrix cores are not there for the flops: with one product per thread every FMA costs two
+// LDS reads and the LDS pipe bounds the kernel; a 16x16x4 tile needs two reads per 2048 flops.
+//   NT <= 2 (nDims < 32): every wave holds all tile pairs and takes the rows 4w .. 4w+3 of each group of sixteen;
+//   NT >= 3: the tile pairs are dealt out to the four waves (q = wave, wave + 4, ...), every wave takes all rows.
+template <int NT, int W>
+__device__ __forceinline__ void updg_accumulate(const double *tile, int TS, int n16, int wv, int li, int lk, upd_v4d (&acc)[(NT <= 2) ? NT * (NT + 1) / 2 : (NT * (NT + 1) / 2 + 3) / 4])
+{
+    if constexpr (NT <= 2) {
+        for (int q0 = 4 * wv; q0 < n16; q0 += 16) {
+            const double *row = tile + (size_t)(q0 + lk) * TS + li;
+            double x[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) x[t] = row[16 * t];
+            int q = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[q], 0, 0, 0);
+        }
+    } else {
+        for (int ks = 0; ks < (n16 >> 2); ++ks) {
+            const double *row = tile + (size_t)(4 * ks + lk) * TS + li;
+            double x[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) x[t] = row[16 * t];
+            int q = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++q)
+                    if ((q & 3) == W) acc[q >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[q >> 2], 0, 0, 0);
+        }
+    }
+}
+// element (a, b) of tile pair (ti, tj) held in (lane, register r) -> its place in the record (or -1)
+__device__ __forceinline__ int updg_slot(int D, int ti, int tj, int li, int lk, int r)
+{
+    const int a = 16 * ti + lk + 4 * r, b = 16 * tj + li, npair = D * (D + 1) / 2;
+    if (a > b || b > D) return -1;
+    return (b < D) ? a * D - a * (a - 1) / 2 + (b - a) : (a < D ? npair + a : npair + D);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
                                                     double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
-                                                    int *d_total, const double *shift, double *part, int E, int def, int nlb)
+                                                    const double *shift, double *part, int E, int def, int nlb, int ndb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int red[UPD_NT];
-    __shared__ int wcnt[4], mcnt[4];
-    const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, D = S.D, nT = S.nT;
-    const int ncol = D + 1, TS = (ncol + 1) | 1;   // odd row stride: the four row groups of an operand hit different banks
-    double *tile = (double *)smem;                 // [UPD_ROWS + 16][TS] member rows first: cube - shift, then a column of ones
-    double *sh = tile + (size_t)(UPD_ROWS + 16) * TS;     // [D]
-    const int blk = blockIdx.x;
-    const bool is_ph = blk < nblk, is_live = !is_ph && blk < nblk + nlb;
-    for (int d = tid; d < D; d += UPD_NT) sh[d] = shift[d];
-    int n = 0;                                     // member rows of this block
-    if (is_ph) {
-        // everything this thread will need from memory is requested before the first wait
-        const int j = blk * UPD_ROWS + tid;
-        int s = 0;
-        for (int b = tid; b < blk; b += UPD_NT) s += blk_count[b];
-        const bool k = (j < nph) && keep[j];
-        double pl = 0.0; unsigned pc = 0u; unsigned long long pu = 0ull;
-        if (j < nph) { pl = S.ph_logL[j]; pc = S.ph_cuid[j]; pu = S.ph_uid[j]; }
-        // moments: the survivors that were phantoms at the mark (rows of regions of later chains stay, but do not count)
-        const bool km = k && (j < nph0u || (j - nph0u) / S.nr < tmark);
-        // ---- offset of this block's survivors = survivors of the blocks before it (integer sum: any order)
-        red[tid] = s;
-        const unsigned long long m = __ballot(k), mm = __ballot(km);
-        if (lane == 0) { wcnt[wv] = __popcll(m); mcnt[wv] = __popcll(mm); }
-        __syncthreads();
-        for (int o = UPD_NT / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        const int off0 = red[0];
-        if (blk == nblk - 1 && tid == 0) { const int tot = off0 + blk_count[blk]; *d_total = tot; S.ctl->nphantom = tot; }
-        // ---- compaction, row order kept
-        int woff = 0, moff = 0;
-        for (int x = 0; x < wv; ++x) { woff += wcnt[x]; moff += mcnt[x]; }
-        const int pos = woff + __popcll(m & ((1ull << lane) - 1ull));
-        if (k) { phL2[off0 + pos] = pl; phC2[off0 + pos] = pc; phU2[off0 + pos] = pu; }
-        upd_stage_masked(S.phantom + (size_t)(blk * UPD_ROWS + wv * 64) * nT, m, mm, ph2 + (size_t)(off0 + woff) * nT, tile + (size_t)moff * TS, TS, sh, D, nT, lane);
-        n = mcnt[0] + mcnt[1] + mcnt[2] + mcnt[3];
-    } else if (is_live) {
-        // ---- live points of slots [r0, r0 + UPD_ROWS)
-        const int r0 = (blk - nblk) * UPD_ROWS, r = r0 + tid;
-        const bool k = (r < S.Ncap) && S.live_cluster[r] == 0 && (!def || S.slot_step[r] < tmark);
-        const unsigned long long m = __ballot(k);
-        if (lane == 0) wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int x = 0; x < wv; ++x) woff += wcnt[x];
-        upd_stage_masked(S.live + (size_t)(r0 + wv * 64) * nT, m, m, nullptr, tile + (size_t)woff * TS, TS, sh, D, nT, lane);
-        n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    } else {
-        // ---- def: points alive at the mark that died later in the launch: the dead rows of the steps t >= tmark whose
-        //      dying point was a snapshot point or the newcomer of a step before the mark
-        const PcCtl *ctl = S.ctl;
-        const int T = ctl->upd_T, ts = ctl->upd_ts;
-        const int t = tmark + (blk - nblk - nlb) * UPD_ROWS + tid;
-        long long di = -1;
-        if (t < ts) {
-            const PcPlan *pw = S.plan + (T - 1 - t);
-            const int src = pw->dead_src;
-            const bool existed = src >= 0 || (T - 1 - (-src - 1)) < tmark;
-            if (pw->dead_idx >= 0 && pw->logw > S.logzero && existed) di = pw->dead_idx;
-        }
-        const unsigned long long m = __ballot(di >= 0);
-        if (lane == 0) wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int x = 0; x < wv; ++x) woff += wcnt[x];
-        unsigned long long mb = m;
-        int row = woff;
-        while (mb) {                                   // rows are scattered in the dead array: one at a time, lane = coordinate
-            const int b = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            const long long d = __shfl(di, b);
-            if (lane <= D) tile[(size_t)row * TS + lane] = lane < D ? S.dead[(size_t)d * nT + lane] - sh[lane] : 1.0;
-            row++;
-        }
-        n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    }
-    // rows n .. next multiple of 16: zero (the matrix cores take four rows at a time, four waves)
-    const int n16 = (n + 15) & ~15;
-    for (int e = tid; e < (n16 - n) * TS; e += UPD_NT) tile[(size_t)n * TS + e] = 0.0;
-    __syncthreads();
-    // ---- X^T X, upper triangle of 16 x 16 tiles: (0,0), and with more than 16 columns (0,1), (1,1)
-    const int nt = (ncol + 15) >> 4;               // 1 or 2
-    upd_v4d acc[3];
+    constexpr bool KS = NT <= 2;
+    // row stride: odd (K split: the four row groups of an operand start in different banks) / 16 mod 32 doubles (pair split)
+    constexpr int TS = KS ? 16 * NT + 1 : 16 * NT + ((NT & 1) ? 0 : 16);
+    constexpr int CAP = KS ? 256 : 64;                                  // tile rows; a flush when the next 64-row piece does not fit
+    constexpr int NACC = KS ? NT * (NT + 1) / 2 : (NT * (NT + 1) / 2 + 3) / 4;
+    __shared__ unsigned long long m64[4], mm64[4];
+    __shared__ long long dix[256];
+    const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff, updT = def ? S.ctl->upd_T : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, D = S.D, nT = S.nT;
+    const bool pool = S.pool != 0;
+    double *tile = (double *)smem;                                      // [CAP][TS]
+    double *sh = tile + (size_t)CAP * TS;                               // [D]
+    for (int d = tid; d < D; d += 256) sh[d] = shift[d];
+    for (int e = tid; e < CAP * TS; e += 256) tile[e] = 0.0;            // (the columns past the ones stay zero)
+    upd_v4d acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = upd_v4d{0.0, 0.0, 0.0, 0.0};
-    {
-        const int c0 = lane & 15, c1 = 16 + (lane & 15);
-        const bool on1 = nt > 1 && c1 < ncol;
-        const double *p0 = tile + (size_t)(4 * wv + (lane >> 4)) * TS + c0;
-        const bool on0 = c0 < ncol;
-        for (int q0 = 4 * wv; q0 < n16; q0 += 16, p0 += (size_t)16 * TS) {
-            const double x0 = on0 ? p0[0] : 0.0, x1 = on1 ? p0[16] : 0.0;
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0], 0, 0, 0);
-            if (nt > 1) {
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[2], 0, 0, 0);
+    for (int t = 0; t < NACC; ++t) acc[t] = upd_v4d{0.0, 0.0, 0.0, 0.0};
+    int nfill = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        const int n16 = (nfill + 15) & ~15;
+        for (int e = tid; e < (n16 - nfill) * (D + 1); e += 256) tile[(size_t)(nfill + e / (D + 1)) * TS + e % (D + 1)] = 0.0;
+        __syncthreads();
+        if (KS || wv == 0) updg_accumulate<NT, 0>(tile, TS, n16, wv, li, lk, acc);
+        else if (wv == 1) updg_accumulate<NT, 1>(tile, TS, n16, wv, li, lk, acc);
+        else if (wv == 2) updg_accumulate<NT, 2>(tile, TS, n16, wv, li, lk, acc);
+        else updg_accumulate<NT, 3>(tile, TS, n16, wv, li, lk, acc);
+        __syncthreads();
+        nfill = 0;
+    };
+    // the 64-row piece `sub` of a 256-row block whose masks sit in m64 / mm64: rows selected by the move mask are copied to
+    // consecutive rows at dst (when there is one), those of the moment mask join the tile; wave w takes the bits 16 w ..
+    auto piece = [&](const double *src, int sub, double *dst) __attribute__((always_inline)) {
+        const unsigned long long ms = m64[sub], mms = mm64[sub], below = (1ull << (16 * wv)) - 1ull;
+        const int cnt = __popcll(mms);
+        if (cnt == 0 && (dst == nullptr || ms == 0ull)) return;
+        if (nfill + cnt > CAP) flush();
+        upd_stage_masked(src + (size_t)(sub * 64 + 16 * wv) * nT, ((dst ? ms : mms) >> (16 * wv)) & 0xFFFFull, (mms >> (16 * wv)) & 0xFFFFull,
+                         dst ? dst + (size_t)__popcll(ms & below) * nT : nullptr, tile + (size_t)(nfill + __popcll(mms & below)) * TS, TS, sh, D, nT, lane);
+        nfill += cnt;
+    };
+    const int total = nblk + nlb + ndb;
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        __syncthreads();                                                // the masks of the block before are no longer read
+        if (b < nblk) {
+            // ---- 256 phantom rows
+            const int j = b * 256 + tid;
+            const bool k = (j < nph) && keep[j];
+            // moments: the survivors that were phantoms at the mark (rows of chains consumed later stay, but do not count)
+            const bool km = k && (j < nph0u || (pool ? updT - 1 - (j - nph0u) / S.nr : (j - nph0u) / S.nr) < tmark);
+            const unsigned long long m = __ballot(k), mm = __ballot(km);
+            if (lane == 0) { m64[wv] = m; mm64[wv] = mm; }
+            __syncthreads();
+            int off = 0;
+            if (!pool) {
+                off = blk_off[b];                                       // survivors of the blocks before (k_scan_blocks)
+                for (int x = 0; x < wv; ++x) off += __popcll(m64[x]);
+                if (k) {
+                    const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+                    phL2[pos] = S.ph_logL[j]; phC2[pos] = S.ph_cuid[j]; phU2[pos] = S.ph_uid[j];
+                }
+                off = blk_off[b];
+            }
+            const double *src = S.phantom + (size_t)b * 256 * nT;
+            for (int sub = 0; sub < 4; ++sub) {
+                piece(src, sub, pool ? nullptr : ph2 + (size_t)off * nT);
+                off += __popcll(m64[sub]);
+            }
+        } else if (b < nblk + nlb) {
+            // ---- live points of slots [r0, r0 + 256)
+            const int r0 = (b - nblk) * 256, r = r0 + tid;
+            const bool k = (r < S.Ncap) && S.live_cluster[r] == 0 && (!def || S.slot_step[r] < tmark);
+            const unsigned long long m = __ballot(k);
+            if (lane == 0) { m64[wv] = m; mm64[wv] = m; }
+            __syncthreads();
+            const double *src = S.live + (size_t)r0 * nT;
+            for (int sub = 0; sub < 4; ++sub) piece(src, sub, nullptr);
+        } else {
+            // ---- def: points alive at the mark that died later in the launch: the dead rows of the steps t >= tmark whose
+            //      dying point was a snapshot point or the newcomer of a step before the mark; scattered in the dead array:
+            //      the four waves take them in turn, lane = coordinate
+            const PcCtl *ctl = S.ctl;
+            const int T = ctl->upd_T, ts = ctl->upd_ts;
+            const int t = tmark + (b - nblk - nlb) * 256 + tid;
+            long long di = -1;
+            if (t < ts) {
+                const PcPlan *pw = S.plan + (T - 1 - t);
+                const int src = pw->dead_src;
+                const bool existed = src >= 0 || (T - 1 - (-src - 1)) < tmark;
+                if (pw->dead_idx >= 0 && pw->logw > S.logzero && existed) di = pw->dead_idx;
+            }
+            dix[tid] = di;
+            const unsigned long long m = __ballot(di >= 0);
+            if (lane == 0) m64[wv] = m;
+            __syncthreads();
+            for (int sub = 0; sub < 4; ++sub) {
+                unsigned long long mb = m64[sub];
+                const int cnt = __popcll(mb);
+                if (cnt == 0) continue;
+                if (nfill + cnt > CAP) flush();
+                int row = 0;
+                while (mb) {
+                    const int bit = __ffsll((long long)mb) - 1; mb &= mb - 1;
+                    if ((row & 3) == wv) {
+                        const long long d = dix[sub * 64 + bit];
+                        for (int e = lane; e <= D; e += 64) tile[(size_t)(nfill + row) * TS + e] = e < D ? S.dead[(size_t)d * nT + e] - sh[e] : 1.0;
+                    }
+                    row++;
+                }
+                nfill += cnt;
             }
         }
     }
-    __syncthreads();                               // the tile is no longer read: its memory takes the four waves' results
-    double *wres = tile;                           // [4 waves][3 tiles][256]
+    flush();
+    double *out = part + (size_t)blockIdx.x * E;
+    if constexpr (KS) {
+        // the four waves' tiles added in order (the tile memory takes them)
+        double *wres = tile;                           // [4 waves][NACC][256]
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wres[((size_t)wv * 3 + t) * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[t][r];
-    __syncthreads();
-    double *out = part + (size_t)blk * E;
-    const int npair = D * (D + 1) / 2;
-    for (int p = tid; p < npair + D + 1; p += UPD_NT) {
-        int a, b;                                  // element (a, b), a <= b, of the (D+1) x (D+1) moment matrix
-        if (p < npair) { a = 0; int q = p; while (q >= D - a) { q -= D - a; a++; } b = a + q; }
-        else if (p < npair + D) { a = p - npair; b = D; }
-        else { a = D; b = D; }
-        const int t = (a >> 4) + (b >> 4), idx = (a & 15) * 16 + (b & 15);       // tile (0,0) -> 0, (0,1) -> 1, (1,1) -> 2
-        out[p] = ((wres[(size_t)(0 * 3 + t) * 256 + idx] + wres[(size_t)(1 * 3 + t) * 256 + idx]) +
-                  (wres[(size_t)(2 * 3 + t) * 256 + idx] + wres[(size_t)(3 * 3 + t) * 256 + idx]));
+            for (int r = 0; r < 4; ++r) wres[((size_t)wv * NACC + t) * 256 + (lk + 4 * r) * 16 + li] = acc[t][r];
+        __syncthreads();
+        if (wv == 0) {
+            int q = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = updg_slot(D, ti, tj, li, lk, r), idx = (lk + 4 * r) * 16 + li;
+                        if (p >= 0) out[p] = ((wres[(size_t)(0 * NACC + q) * 256 + idx] + wres[(size_t)(1 * NACC + q) * 256 + idx]) +
+                                              (wres[(size_t)(2 * NACC + q) * 256 + idx] + wres[(size_t)(3 * NACC + q) * 256 + idx]));
+                    }
+        }
+    } else {
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < NT; ++tj, ++q)
+                if ((q & 3) == wv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int p = updg_slot(D, ti, tj, li, lk, r); if (p >= 0) out[p] = acc[q >> 2][r]; }
+                }
     }
 }
 
@@ -313,155 +393,6 @@ __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const dou
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// 32 <= nDims <= 128 (one cluster): the same single pass -- compaction of the surviving phantoms and the shifted moments
-// of live + phantom coordinates while the rows go by -- with the moment matrix in 16 x 16 tiles spread over the four
-// waves of a workgroup.  The general path read every phantom row three times (scatter, mean, centred products: 2.5 ms of a
-// 3.4 ms update at nDims = 100, nlive 5000) and gathered the 800 coordinate bytes out of 1616-byte rows for the matrix
-// cores; here a row is read once, whole, written once, and its coordinates are in LDS when the products are formed.
-//   k_upd_flag, k_scan_blocks (offsets of the 256-row blocks), k_upd_move_w, k_upd_fold, k_upd_final_w, k_cov_final_chol
-// Workgroups are persistent: each walks its share of the 64-row chunks with the accumulator tiles (upper triangle of
-// NT x NT tiles of X^T X, X = [cube - shift | 1 | 0...], pairs q = wave, wave + 4, ...) in registers and writes ONE record.
-#define UPDW_ROWS 64
-template <int NT, int W>
-__device__ __forceinline__ void updw_accumulate(const double *tile, int TS, int n16, int li, int lk, upd_v4d (&acc)[(NT * (NT + 1) / 2 + 3) / 4])
-{
-    for (int ks = 0; ks < (n16 >> 2); ++ks) {
-        const double *row = tile + (size_t)(4 * ks + lk) * TS + li;
-        double x[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = row[16 * t];
-        int q = 0;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int tj = ti; tj < NT; ++tj, ++q)
-                if ((q & 3) == W) acc[q >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[q >> 2], 0, 0, 0);
-    }
-}
-template <int NT, int W>
-__device__ __forceinline__ void updw_store(double *out, int D, int li, int lk, const upd_v4d (&acc)[(NT * (NT + 1) / 2 + 3) / 4])
-{
-    const int npair = D * (D + 1) / 2;
-    int q = 0;
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = ti; tj < NT; ++tj, ++q)
-            if ((q & 3) == W) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = 16 * ti + lk + 4 * r, b = 16 * tj + li;
-                    if (a <= b && b <= D) {
-                        const int p = (b < D) ? a * D - a * (a - 1) / 2 + (b - a) : (a < D ? npair + a : npair + D);
-                        out[p] = acc[q >> 2][r];
-                    }
-                }
-            }
-}
-
-template <int NT>
-__global__ __launch_bounds__(256) void k_upd_move_w(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
-                                                    double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
-                                                    const double *shift, double *part, int E, int def, int nlc, int ndc)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TS = 16 * NT + ((NT & 1) ? 0 : 16);                  // = 16 mod 32 doubles: the four row groups of an operand
-    constexpr int NPW = (NT * (NT + 1) / 2 + 3) / 4;                   //   split over both halves of the LDS banks
-    __shared__ unsigned long long m64[4], mm64[4];
-    __shared__ int wcnt[4];
-    const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, D = S.D, nT = S.nT;
-    double *tile = (double *)smem;                                      // [UPDW_ROWS + 16][TS]
-    double *sh = tile + (size_t)(UPDW_ROWS + 16) * TS;                  // [D]
-    for (int d = tid; d < D; d += 256) sh[d] = shift[d];
-    for (int e = tid; e < (UPDW_ROWS + 16) * TS; e += 256) tile[e] = 0.0;     // (the columns past the ones stay zero)
-    upd_v4d acc[NPW];
-#pragma unroll
-    for (int t = 0; t < NPW; ++t) acc[t] = upd_v4d{0.0, 0.0, 0.0, 0.0};
-    const int npc = 4 * nblk, total = npc + nlc + ndc;
-    __syncthreads();
-    for (int c = blockIdx.x; c < total; c += gridDim.x) {
-        int n = 0;                                                      // member rows of this chunk
-        if (c < npc) {
-            // ---- 64 phantom rows: sub-chunk `sub` of the 256-row block `blk` (whose offset the scan left in blk_off)
-            const int blk = c >> 2, sub = c & 3, j = blk * 256 + tid;
-            const bool k = (j < nph) && keep[j];
-            const bool km = k && (j < nph0u || (j - nph0u) / S.nr < tmark);       // a phantom at the mark (see k_upd_move)
-            const unsigned long long m = __ballot(k), mm = __ballot(km);
-            if (lane == 0) { m64[wv] = m; mm64[wv] = mm; }
-            __syncthreads();
-            int off = blk_off[blk];
-            for (int x = 0; x < sub; ++x) off += __popcll(m64[x]);
-            if (wv == sub && k) {
-                const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-                phL2[pos] = S.ph_logL[j]; phC2[pos] = S.ph_cuid[j]; phU2[pos] = S.ph_uid[j];
-            }
-            const unsigned long long ms = m64[sub], mms = mm64[sub], below = (1ull << (16 * wv)) - 1ull;
-            upd_stage_masked(S.phantom + (size_t)(blk * 256 + sub * 64 + 16 * wv) * nT, (ms >> (16 * wv)) & 0xFFFFull, (mms >> (16 * wv)) & 0xFFFFull,
-                             ph2 + (size_t)(off + __popcll(ms & below)) * nT, tile + (size_t)__popcll(mms & below) * TS, TS, sh, D, nT, lane);
-            n = __popcll(mms);
-        } else if (c < npc + nlc) {
-            // ---- live points of slots [r0, r0 + 64)
-            const int r0 = (c - npc) * UPDW_ROWS, r = r0 + tid;
-            const bool k = tid < UPDW_ROWS && r < S.Ncap && S.live_cluster[r] == 0 && (!def || S.slot_step[r] < tmark);
-            const unsigned long long m = __ballot(k);
-            if (tid == 0) m64[0] = m;
-            __syncthreads();
-            const unsigned long long ms = m64[0], below = (1ull << (16 * wv)) - 1ull;
-            upd_stage_masked(S.live + (size_t)(r0 + 16 * wv) * nT, (ms >> (16 * wv)) & 0xFFFFull, (ms >> (16 * wv)) & 0xFFFFull, nullptr,
-                             tile + (size_t)__popcll(ms & below) * TS, TS, sh, D, nT, lane);
-            n = __popcll(ms);
-        } else {
-            // ---- def: points alive at the mark that died later in the launch (see k_upd_move); rows scattered in the dead
-            //      array: the four waves take them in turn, lane = coordinate
-            const PcCtl *ctl = S.ctl;
-            const int T = ctl->upd_T, ts = ctl->upd_ts;
-            const int t = tmark + (c - npc - nlc) * UPDW_ROWS + tid;
-            long long di = -1;
-            if (tid < UPDW_ROWS && t < ts) {
-                const PcPlan *pw = S.plan + (T - 1 - t);
-                const int src = pw->dead_src;
-                const bool existed = src >= 0 || (T - 1 - (-src - 1)) < tmark;
-                if (pw->dead_idx >= 0 && pw->logw > S.logzero && existed) di = pw->dead_idx;
-            }
-            long long *dix = (long long *)(tile + (size_t)UPDW_ROWS * TS);       // (rows 64 .. 79 of the tile: zeroed again below)
-            if (tid < UPDW_ROWS) dix[tid] = di;
-            const unsigned long long m = __ballot(di >= 0);
-            if (tid == 0) m64[0] = m;
-            __syncthreads();
-            unsigned long long mb = m64[0];
-            int row = 0;
-            while (mb) {
-                const int b = __ffsll((long long)mb) - 1; mb &= mb - 1;
-                if ((row & 3) == wv) {
-                    const long long d = dix[b];
-                    for (int e = lane; e <= D; e += 64) tile[(size_t)row * TS + e] = e < D ? S.dead[(size_t)d * nT + e] - sh[e] : 1.0;
-                }
-                row++;
-            }
-            n = row;
-            __syncthreads();
-            for (int e = tid; e < 16 * TS; e += 256) tile[(size_t)UPDW_ROWS * TS + e] = 0.0;
-        }
-        __syncthreads();
-        // rows n .. next multiple of 16: zero up to the ones column (the matrix cores take four rows at a time)
-        const int n16 = (n + 15) & ~15;
-        for (int e = tid; e < (n16 - n) * (D + 1); e += 256) tile[(size_t)(n + e / (D + 1)) * TS + e % (D + 1)] = 0.0;
-        __syncthreads();
-        if (wv == 0) updw_accumulate<NT, 0>(tile, TS, n16, li, lk, acc);
-        else if (wv == 1) updw_accumulate<NT, 1>(tile, TS, n16, li, lk, acc);
-        else if (wv == 2) updw_accumulate<NT, 2>(tile, TS, n16, li, lk, acc);
-        else updw_accumulate<NT, 3>(tile, TS, n16, li, lk, acc);
-        __syncthreads();                                                // the tile is free for the next chunk
-    }
-    double *out = part + (size_t)blockIdx.x * E;
-    if (wv == 0) updw_store<NT, 0>(out, D, li, lk, acc);
-    else if (wv == 1) updw_store<NT, 1>(out, D, li, lk, acc);
-    else if (wv == 2) updw_store<NT, 2>(out, D, li, lk, acc);
-    else updw_store<NT, 3>(out, D, li, lk, acc);
-}
-
 // records added up; delta = mean - shift; n cov = M2 - n delta delta^T for k_cov_final_chol (which divides by n, stores the
 // covariance and factorises in the reference's order of operations); new shift; thresholds reset
 __global__ __launch_bounds__(1024) void k_upd_final_w(PcState S, int nb, const double *part, int E, double *shift, int def, double *ncov, int *count)
@@ -496,24 +427,20 @@ __global__ __launch_bounds__(1024) void k_upd_final_w(PcState S, int nb, const d
 extern "C" int pc_update_fused_entries(const PcState *S);
 extern "C" void pc_launch_scan_blocks(int *blk, int nblk, int *total, int *total2, hipStream_t st);
 extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const int *count, hipStream_t st);
-static int updw_grid(const PcState *S, int nph, int deferred)
+#define UPD_GRID 512
+static int upd_grid(const PcState *S, int nph, int deferred)
 {
-    const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlc = (S->Ncap + UPDW_ROWS - 1) / UPDW_ROWS, ndc = deferred ? (S->B + UPDW_ROWS - 1) / UPDW_ROWS : 0;
-    const int total = 4 * nblk + nlc + ndc;
-    return total < 512 ? total : 512;
+    const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
+    const int total = nblk + nlb + ndb;
+    return total < UPD_GRID ? total : UPD_GRID;
 }
 
 extern "C" int pc_update_fused_ok(const PcState *S, int nc) { return nc == 1 && S->D <= 128; }
-
 extern "C" int pc_update_fused_blocks(const PcState *S, int nph)
-{   // partial records: one per block of k_upd_move (phantom blocks, live blocks, dead-row blocks of a deferred update),
-    // then one per group of UPD_FOLD of them
-    if (S->D >= 32) {                                   // persistent workgroups + their groups + room for n cov and n
-        const int G = updw_grid(S, nph, 1), E = pc_update_fused_entries(S);
-        return G + (G + UPD_FOLD - 1) / UPD_FOLD + (S->D * S->D + 2 + E - 1) / E;
-    }
-    const int nb = (nph + UPD_ROWS - 1) / UPD_ROWS + (S->Ncap + UPD_ROWS - 1) / UPD_ROWS + (S->B + UPD_ROWS - 1) / UPD_ROWS;
-    return nb + (nb + UPD_FOLD - 1) / UPD_FOLD;
+{   // partial records: one per persistent workgroup of k_upd_gather, then one per group of UPD_FOLD of them, then room for
+    // n cov and n (nDims >= 32: the Cholesky factor is made by k_cov_final_chol)
+    const int G = upd_grid(S, nph, 1), E = pc_update_fused_entries(S);
+    return G + (G + UPD_FOLD - 1) / UPD_FOLD + (S->D * S->D + 2 + E - 1) / E;
 }
 extern "C" int pc_update_fused_entries(const PcState *S) { const int e = S->D * (S->D + 1) / 2 + S->D + 1; return (e + 31) & ~31; }
 
@@ -522,43 +449,31 @@ extern "C" int pc_update_fused_entries(const PcState *S) { const int e = S->D * 
 extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char *keep, int *blk, int *d_total, double *ph2, double *phL2,
                                        unsigned *phC2, unsigned long long *phU2, double *part, double *shift, int deferred, hipStream_t st)
 {
-    const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
+    const int D = S->D, nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
     const int ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
-    if (S->D >= 32) {
-        const int D = S->D, NTv = (D + 1 + 15) / 16, TSv = 16 * NTv + ((NTv & 1) ? 0 : 16);
-        const int nlc = (S->Ncap + UPDW_ROWS - 1) / UPDW_ROWS, ndc = deferred ? (S->B + UPDW_ROWS - 1) / UPDW_ROWS : 0;
-        const int G = updw_grid(S, nph, deferred), ng = (G + UPD_FOLD - 1) / UPD_FOLD;
-        double *part2 = part + (size_t)G * E, *ncov = part2 + (size_t)ng * E;
-        int *count = (int *)(ncov + (size_t)D * D);
-        const size_t shw = sizeof(double) * ((size_t)(UPDW_ROWS + 16) * TSv + D);
-        hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
-        pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
-#define UPDW_LAUNCH(NT) { \
-            static bool done_##NT = false; \
-            if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_move_w<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
-            hipLaunchKernelGGL((k_upd_move_w<NT>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
-                               ph2, phL2, phC2, phU2, (const double *)shift, part, E, deferred, nlc, ndc); }
-        switch (NTv) { case 3: UPDW_LAUNCH(3) break; case 4: UPDW_LAUNCH(4) break; case 5: UPDW_LAUNCH(5) break; case 6: UPDW_LAUNCH(6) break;
-                       case 7: UPDW_LAUNCH(7) break; case 8: UPDW_LAUNCH(8) break; default: UPDW_LAUNCH(9) break; }
-#undef UPDW_LAUNCH
-        hipLaunchKernelGGL(k_upd_fold, dim3(ng), dim3(256), 0, st, (const double *)part, G, E, part2);
-        const size_t shf = sizeof(double) * (size_t)(D * (D + 1) / 2 + D + 1);
-        static size_t donef = 0;
-        if (shf > donef) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef = shf; }
-        hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
-        pc_launch_chol_only(S, ncov, count, st);
-        return;
-    }
-    const int TS = ((S->D + 2) | 1);
-    size_t sh = sizeof(double) * ((size_t)(UPD_ROWS + 16) * TS + S->D);
-    if (sh < sizeof(double) * (12 * 256 + S->D)) sh = sizeof(double) * (12 * 256 + S->D);       // the waves' result tiles reuse the row tile
-    static size_t done = 0;
-    if (sh > done) { (void)hipFuncSetAttribute((const void *)k_upd_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    const int NTv = (D + 1 + 15) / 16, TSv = NTv <= 2 ? 16 * NTv + 1 : 16 * NTv + ((NTv & 1) ? 0 : 16), CAPv = NTv <= 2 ? 256 : 64;
+    const int G = upd_grid(S, nph, deferred), ng = (G + UPD_FOLD - 1) / UPD_FOLD;
+    double *part2 = part + (size_t)G * E;
+    size_t shw = sizeof(double) * ((size_t)CAPv * TSv + D);
+    if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);      // the waves' result tiles reuse the row tile
     hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
-    hipLaunchKernelGGL(k_upd_move, dim3(nblk + nlb + ndb), dim3(UPD_NT), sh, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk,
-                       ph2, phL2, phC2, phU2, d_total, (const double *)shift, part, E, deferred, nlb);
-    const int nb = nblk + nlb + ndb, ng = (nb + UPD_FOLD - 1) / UPD_FOLD;
-    double *part2 = part + (size_t)nb * E;
-    hipLaunchKernelGGL(k_upd_fold, dim3(ng), dim3(256), 0, st, (const double *)part, nb, E, part2);
-    hipLaunchKernelGGL(k_upd_final, dim3(1), dim3(1024), 0, st, *S, ng, (const double *)part2, E, shift, deferred);
+    if (!S->pool) pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
+#define UPDG_LAUNCH(NT) { \
+        static bool done_##NT = false; \
+        if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
+        hipLaunchKernelGGL((k_upd_gather<NT>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
+                           ph2, phL2, phC2, phU2, (const double *)shift, part, E, deferred, nlb, ndb); }
+    switch (NTv) { case 1: UPDG_LAUNCH(1) break; case 2: UPDG_LAUNCH(2) break; case 3: UPDG_LAUNCH(3) break; case 4: UPDG_LAUNCH(4) break;
+                   case 5: UPDG_LAUNCH(5) break; case 6: UPDG_LAUNCH(6) break; case 7: UPDG_LAUNCH(7) break; case 8: UPDG_LAUNCH(8) break;
+                   default: UPDG_LAUNCH(9) break; }
+#undef UPDG_LAUNCH
+    hipLaunchKernelGGL(k_upd_fold, dim3(ng), dim3(256), 0, st, (const double *)part, G, E, part2);
+    if (D < 32) { hipLaunchKernelGGL(k_upd_final, dim3(1), dim3(1024), 0, st, *S, ng, (const double *)part2, E, shift, deferred); return; }
+    double *ncov = part2 + (size_t)ng * E;
+    int *count = (int *)(ncov + (size_t)D * D);
+    const size_t shf = sizeof(double) * (size_t)(D * (D + 1) / 2 + D + 1);
+    static size_t donef = 0;
+    if (shf > donef) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef = shf; }
+    hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
+    pc_launch_chol_only(S, ncov, count, st);
 }
