@@ -70,16 +70,87 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigne
     const unsigned uid0 = S.cl_uid[0];
     const double thr = def ? S.ctl->upd_thr : S.death_thr[0];
     const int j = blockIdx.x * UPD_ROWS + tid;
-    bool k = false;
+    bool k = false, km = false;
     if (j < nph) {
         const unsigned cu = S.ph_cuid[j];
-        k = (cu == uid0) && !(S.ph_logL[j] < thr); keep[j] = k ? 1 : 0;
-        if (S.pool && !k && cu == uid0) S.ph_cuid[j] = PC_CUID_NONE;        // pool mode: dropped where it lies
+        k = (cu == uid0) && !(S.ph_logL[j] < thr);
+        if (S.pool) {
+            // pool mode: a dropped phantom is dropped where it lies; the rows that count in the moments (the survivors that
+            // were phantoms at the mark -- rows of chains consumed later stay, but do not count) are listed by k_upd_index
+            if (!k && cu == uid0) S.ph_cuid[j] = PC_CUID_NONE;
+            const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
+            km = k && (j < nph0u || S.ctl->upd_T - 1 - (j - nph0u) / S.nr < tmark);
+        }
+        keep[j] = (k ? 1 : 0) | (km ? 2 : 0);
     }
-    const unsigned long long m = __ballot(k);
+    const unsigned long long m = __ballot(S.pool ? km : k);
     if (lane == 0) cnt[wv] = __popcll(m);
     __syncthreads();
     if (tid == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+
+// exclusive scan of the block counts in place, one workgroup, 4096 counts at a time (four per thread, coalesced)
+__global__ __launch_bounds__(1024) void k_upd_scan(int *cnt, int n, int *total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * tid;
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (i0 + u < n) ? cnt[i0 + u] : 0;
+        const int s = (c[0] + c[1]) + (c[2] + c[3]);
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int pre = carry;
+        for (int x = 0; x < wv; ++x) pre += wsum[x];
+        int run = pre + inc - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { if (i0 + u < n) cnt[i0 + u] = run; run += c[u]; }
+        if (tid == 1023) carry_s = pre + inc;
+        __syncthreads();
+        carry = carry_s;
+    }
+    if (tid == 0) *total = carry;
+}
+
+// pool mode: the rows that count, by index, in row order
+__global__ __launch_bounds__(UPD_NT) void k_upd_index(int nph, const unsigned char *keep, const int *blk_off, int *idx)
+{
+    __shared__ int cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = blockIdx.x * UPD_ROWS + tid;
+    const bool km = j < nph && (keep[j] & 2);
+    const unsigned long long m = __ballot(km);
+    if (lane == 0) cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = blk_off[blockIdx.x];
+    for (int x = 0; x < wv; ++x) off += cnt[x];
+    if (km) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+}
+
+// sixteen rows given by index, coordinates minus shift and a one, to consecutive tile rows; lane = element, the loads of
+// two passes (elements lane and lane + 64) in flight together
+__device__ __forceinline__ void upd_stage_idx(const double *base, const int *ridx, int cnt, double *tile, int TS, const double *sh, int D, int nT, int lane)
+{
+    if (cnt <= 0) return;
+    int idx[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) idx[u] = u < cnt ? ridx[u] : 0;
+    for (int e0 = lane; e0 <= D; e0 += 128) {
+        const int e1 = e0 + 64;
+        double v0[16], v1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < cnt) { v0[u] = e0 < D ? base[(size_t)idx[u] * nT + e0] : 1.0; v1[u] = e1 < D ? base[(size_t)idx[u] * nT + e1] : 1.0; }
+        const double s0 = e0 < D ? sh[e0] : 0.0, s1 = e1 < D ? sh[e1] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < cnt) { tile[(size_t)u * TS + e0] = v0[u] - s0; if (e1 <= D) tile[(size_t)u * TS + e1] = v1[u] - s1; }
+    }
 }
 
 typedef double upd_v4d __attribute__((ext_vector_type(4)));
@@ -133,7 +204,7 @@ __device__ __forceinline__ int updg_slot(int D, int ti, int tj, int li, int lk, 
     return (b < D) ? a * D - a * (a - 1) / 2 + (b - a) : (a < D ? npair + a : npair + D);
 }
 
-template <int NT>
+template <int NT, bool IDX>
 __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
                                                     double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
                                                     const double *shift, double *part, int E, int def, int nlb, int ndb)
@@ -180,8 +251,20 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
                          dst ? dst + (size_t)__popcll(ms & below) * nT : nullptr, tile + (size_t)(nfill + __popcll(mms & below)) * TS, TS, sh, D, nT, lane);
         nfill += cnt;
     };
+    if constexpr (IDX) {
+        // pool mode: the phantoms that count were listed by k_upd_index (the list in the place of phC2, its length, *d_total, in the place of phU2):
+        // sixty-four of them at a time, sixteen per wave, no masks, no barriers but the flushes
+        const int *idx = (const int *)phC2;                             // (the alternate id buffer is free between compactions)
+        const int nidx = *(const int *)phU2;                            // (d_total)
+        for (int c = blockIdx.x; c * 64 < nidx; c += gridDim.x) {
+            const int have = min(64, nidx - c * 64);
+            if (nfill + have > CAP) flush();
+            upd_stage_idx(S.phantom, idx + c * 64 + 16 * wv, min(16, have - 16 * wv), tile + (size_t)(nfill + 16 * wv) * TS, TS, sh, D, nT, lane);
+            nfill += have;
+        }
+    }
     const int total = nblk + nlb + ndb;
-    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+    for (int b = IDX ? nblk + ((int)gridDim.x - 1 - (int)blockIdx.x) : blockIdx.x; b < total; b += gridDim.x) {
         __syncthreads();                                                // the masks of the block before are no longer read
         if (b < nblk) {
             // ---- 256 phantom rows
@@ -458,10 +541,17 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);      // the waves' result tiles reuse the row tile
     hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
     if (!S->pool) pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
+    else {
+        hipLaunchKernelGGL(k_upd_scan, dim3(1), dim3(1024), 0, st, blk, nblk, d_total);
+        hipLaunchKernelGGL(k_upd_index, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, (int *)phC2);
+    }
 #define UPDG_LAUNCH(NT) { \
         static bool done_##NT = false; \
-        if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
-        hipLaunchKernelGGL((k_upd_gather<NT>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
+        if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); \
+                          (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
+        if (S->pool) hipLaunchKernelGGL((k_upd_gather<NT, true>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
+                           ph2, phL2, phC2, (unsigned long long *)d_total, (const double *)shift, part, E, deferred, nlb, ndb); \
+        else hipLaunchKernelGGL((k_upd_gather<NT, false>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
                            ph2, phL2, phC2, phU2, (const double *)shift, part, E, deferred, nlb, ndb); }
     switch (NTv) { case 1: UPDG_LAUNCH(1) break; case 2: UPDG_LAUNCH(2) break; case 3: UPDG_LAUNCH(3) break; case 4: UPDG_LAUNCH(4) break;
                    case 5: UPDG_LAUNCH(5) break; case 6: UPDG_LAUNCH(6) break; case 7: UPDG_LAUNCH(7) break; case 8: UPDG_LAUNCH(8) break;
