@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
     constexpr bool KS = NT <= 2;
     // row stride: odd (K split: the four row groups of an operand start in different banks) / 16 mod 32 doubles (pair split)
     constexpr int TS = KS ? 16 * NT + 1 : 16 * NT + ((NT & 1) ? 0 : 16);
-    constexpr int CAP = KS ? 256 : 64;                                  // tile rows; a flush when the next 64-row piece does not fit
+    constexpr int CAP = KS ? 128 : 64;                                  // tile rows; a flush when the next 64-row piece does not fit
     constexpr int NACC = KS ? NT * (NT + 1) / 2 : (NT * (NT + 1) / 2 + 3) / 4;
     __shared__ unsigned long long m64[4], mm64[4];
     __shared__ long long dix[256];
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
         // sixty-four of them at a time, sixteen per wave, no masks, no barriers but the flushes
         const int *idx = (const int *)phC2;                             // (the alternate id buffer is free between compactions)
         const int nidx = *(const int *)phU2;                            // (d_total)
-        for (int c = blockIdx.x; c * 64 < nidx; c += gridDim.x) {
+        const int gchunk = (int)gridDim.x - nlb - ndb;                      // the last nlb + ndb workgroups take a live / dead block each
+        for (int c = blockIdx.x; (int)blockIdx.x < gchunk && c * 64 < nidx; c += gchunk) {
             const int have = min(64, nidx - c * 64);
             if (nfill + have > CAP) flush();
             upd_stage_idx(S.phantom, idx + c * 64 + 16 * wv, min(16, have - 16 * wv), tile + (size_t)(nfill + 16 * wv) * TS, TS, sh, D, nT, lane);
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
         }
     }
     const int total = nblk + nlb + ndb;
-    for (int b = IDX ? nblk + ((int)gridDim.x - 1 - (int)blockIdx.x) : blockIdx.x; b < total; b += gridDim.x) {
+    for (int b = IDX ? ((int)blockIdx.x >= (int)gridDim.x - nlb - ndb ? nblk + (int)blockIdx.x - ((int)gridDim.x - nlb - ndb) : total) : blockIdx.x; b < total; b += gridDim.x) {
         __syncthreads();                                                // the masks of the block before are no longer read
         if (b < nblk) {
             // ---- 256 phantom rows
@@ -510,12 +511,13 @@ __global__ __launch_bounds__(1024) void k_upd_final_w(PcState S, int nb, const d
 extern "C" int pc_update_fused_entries(const PcState *S);
 extern "C" void pc_launch_scan_blocks(int *blk, int nblk, int *total, int *total2, hipStream_t st);
 extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const int *count, hipStream_t st);
-#define UPD_GRID 512
 static int upd_grid(const PcState *S, int nph, int deferred)
 {
     const int nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
+    const int cap = S->D < 32 ? 1024 : 512;              // persistent workgroups (four / two per CU)
+    if (S->pool) { const int nch = (nph + 63) / 64; return (nch < cap ? (nch > 0 ? nch : 1) : cap) + nlb + ndb; }     // index chunks + a workgroup per live / dead block
     const int total = nblk + nlb + ndb;
-    return total < UPD_GRID ? total : UPD_GRID;
+    return total < cap ? total : cap;
 }
 
 extern "C" int pc_update_fused_ok(const PcState *S, int nc) { return nc == 1 && S->D <= 128; }
@@ -534,7 +536,7 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
 {
     const int D = S->D, nblk = (nph + UPD_ROWS - 1) / UPD_ROWS, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
     const int ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
-    const int NTv = (D + 1 + 15) / 16, TSv = NTv <= 2 ? 16 * NTv + 1 : 16 * NTv + ((NTv & 1) ? 0 : 16), CAPv = NTv <= 2 ? 256 : 64;
+    const int NTv = (D + 1 + 15) / 16, TSv = NTv <= 2 ? 16 * NTv + 1 : 16 * NTv + ((NTv & 1) ? 0 : 16), CAPv = NTv <= 2 ? 128 : 64;
     const int G = upd_grid(S, nph, deferred), ng = (G + UPD_FOLD - 1) / UPD_FOLD;
     double *part2 = part + (size_t)G * E;
     size_t shw = sizeof(double) * ((size_t)CAPv * TSv + D);
