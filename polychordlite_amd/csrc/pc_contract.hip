@@ -414,20 +414,21 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         // ---- delete_point (array_utils.f90:433-458): the last list element moves into the hole;
         //      find_min_loglikelihoods (run_time_info.f90:883-909) for the shrunk cluster, one pass.
         vk_t best{PC_HUGE, 0x7fffffff};
+        int myslot = -1;                               // slot of this thread's own candidate
         for (int s = tid; s < Ncap; s += NT) {
             if (H.sC[s] != cd) continue;
             int p = H.sP[s];
             if (p == n - 1) { p = pos_del; H.sP[s] = p; }
-            best = vk_min(best, vk_t{H.sL[s], p});
+            const vk_t cand{H.sL[s], p};
+            const vk_t nb = vk_min(best, cand);
+            if (nb.k != best.k || nb.v != best.v) myslot = s;
+            best = nb;
         }
+        const vk_t mine = best;
         best = block_argmin<NT>(best, H.red);
-        __syncthreads();
-        // slot of the new minimum: the one whose (logL,pos) equals the winner
+        // slot of the new minimum: the thread whose own candidate (logL, pos) is the winner knows it (positions are unique)
         if (n - 1 > 0) {
-            for (int s = tid; s < Ncap; s += NT)
-                if (H.sC[s] == cd && H.sP[s] == best.k) H.misc[0] = s;
-            __syncthreads();
-            if (tid == 0) { H.cMinSlot[cd] = H.misc[0]; H.cLogLp[cd] = best.v; }
+            if (myslot >= 0 && mine.k == best.k && mine.v == best.v) { H.cMinSlot[cd] = myslot; H.cLogLp[cd] = best.v; }
         } else if (tid == 0) { H.cMinSlot[cd] = -1; H.cLogLp[cd] = PC_HUGE; }
         __syncthreads();
         // posterior-stack columns (calculate.f90:53-79): volume after the update, logZ after the update
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // main loop: nested_sampling.F90:239-374 for the entries left in the nursery
     // ================================================================================
     long long cyT = 0, cyI = 0, cyK = 0, cyE = 0, cyF = 0, cyW = 0;
+    bool live_changed = true;
     if (!final_mode && nc > 1) {
         // The nursery's records were written by other XCDs: a first touch costs 1-2 us, and the loop below would pay
         // that once per chain and array, serially.  Touch everything it will read now, in bulk, so that the loop's
@@ -546,6 +548,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         else if (S.use_prec) {
             // live_logZ (run_time_info.f90:683-709); per-cluster logsumexp kept incrementally.
             // One cluster per lane, log-sum-exp over the wave; the other waves pick the result up from LDS.
+            // (a chain that replaced nothing left live set and evidence as they were: the estimate stands)
+            if (live_changed)
             {   // every wave for itself (the state it reads was published before the last barrier of the iteration).
                 // live_logZ = log sum_p exp(lse_p - log n_p + logX_p) with lse_p = ref_p + log(sum_p): kept as a pair
                 // (mxv, acc), acc = sum_p (sum_p / n_p) exp(ref_p + logX_p - mxv) -- no log on the critical path
@@ -572,6 +576,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         const long long q1 = clock64(); cyT += q1 - q0;
         const int w = i_nursery - 1;
         i_nursery--;
+        const int n_total_before = n_total;
+        live_changed = false;
         const int w_nlike = S.ch_nlike[w], w_epoch = S.ch_epoch[w], ca = S.ch_cluster[w];
         nlike += w_nlike;
         niter++;
@@ -714,6 +720,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         }
         failures = replaced ? 0 : failures + 1;
         if (!replaced) nlike_failed += w_nlike;
+        live_changed = replaced || n_total != n_total_before;
         const long long q3 = clock64(); cyK += q3 - q2;
 
         // ---- update trigger (nested_sampling.F90:321) and delete_cluster (:339)
