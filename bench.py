@@ -258,7 +258,7 @@ def main():
         s_c = api.Settings(); C.memmove(C.byref(s_c), C.byref(s), C.sizeof(s)); s_c.profile = 0
         conc = []
         for R in Rs:
-            if R * nlive * (4 * nr + 64) * (2 * nDims + nDer + 2) * 8 * 2 > 200e9:      # phantom buffers of R engines
+            if R * nlive * (4 * nr + 64) * (2 * nDims + nDer + 2) * 8 * 5 > 200e9:      # phantom buffers of R engines (pool mode: twice the rows, two buffers)
                 continue
             run_repeats(s_c, L, P, [400000 + j for j in range(R)], max_in_flight=R)      # block cache for R engines
             mc, _ = run_repeats(s_c, L, P, [500000 + j for j in range(R)], max_in_flight=R)
