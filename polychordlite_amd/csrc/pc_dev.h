@@ -112,6 +112,10 @@ __device__ __forceinline__ double pc_logaddexp(double a, double b)
     return (a > b) ? a + log(exp(b - a) + 1.0) : b + log(exp(a - b) + 1.0);
 }
 
+// workgroup barrier for data that lives in LDS only: waits for this wave's LDS traffic, not for its stores to HBM (a
+// __syncthreads() after global stores holds every wave until they are acknowledged -- microseconds on a one-CU kernel)
+__device__ __forceinline__ void pc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------- wave64 DPP reductions
 // Butterfly inside each row of 16 lanes with DPP (no LDS traffic), then the four row
 // results are combined through v_readlane.  Every lane ends with the bit-identical total

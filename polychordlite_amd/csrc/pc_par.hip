@@ -204,6 +204,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     long long cyc[9]; int ncy = 0;
     cyc[ncy++] = clock64();
     // ---- phase 0: stage the sorted snapshot and the candidates
+    // (slot records of the launch before: reset now, a whole kernel ahead of the stores of phase 9 that follow them)
+    for (int s = tid; s < Ncap; s += PAR_NT) { S.slot_src[s] = -1; if (S.defer_update) S.slot_step[s] = -1; }
     for (int i = tid; i < NS; i += PAR_NT) { sSortK[i] = (i < n) ? S.sort_key[i] : KEY_HUGE; sSort[i] = S.sort_slot[i]; }
     const bool inT = tid < T;
     const int w = T - 1 - tid;
@@ -517,19 +519,18 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
     // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
     if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = S.pool ? S.pool_base + w * nr : nph0 + tid * nr; pw->ph_count = -2; }
-    for (int s = tid; s < Ncap; s += PAR_NT) { S.slot_src[s] = -1; if (defer) S.slot_step[s] = -1; }
     if (lane == 0) accR[wv] = 0ull;
     if (tid == 0) ish[2] = S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr;               // rows in use after this launch
-    __syncthreads();
+    pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
 #ifdef PAR_DBG_PUBLISH
     pcy[2] = clock64(); pcy[3] = pcy[2];
 #endif
     const bool accT = acc && tid < ts;
     if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));
-    __syncthreads();
+    pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
     int pos2 = 0;
     if (accT) { const int q2 = prefix_bits(accR, rho); pos2 = q2 + rp; srtK[q2] = ck; }
-    __syncthreads();
+    pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
     if (accT && pos2 >= Kp) {                             // accepted and still alive at the end of the launch
         const int sl = slotA[tid];
         S.live_logL[sl] = key2d(ck); S.slot_src[sl] = w;
@@ -578,8 +579,14 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             // before.  The update is made once, afterwards, for the state at the last of them.
             int Kl = kupd, marks = 1;
             for (;;) {
+                // the first kn > Kl whose volume is below the trigger: the test is monotone in kn, so start at the estimate
+                // Kl + log(cf) / (l0 - l1) and settle with the test itself (a linear search from Kl + 1 was 20 k cycles of
+                // this one lane per launch)
                 const double txn = (Xp0 + (double)Kl * d01) + S.log_cf;
-                int kn = Kl + 1;
+                const double est = (double)Kl + S.log_cf / d01;
+                int kn = !(est < (double)(Kp + 1)) ? Kp + 1 : (int)est;
+                if (kn < Kl + 1) kn = Kl + 1;
+                while (kn > Kl + 1 && !(Xp0 + (double)(kn - 1) * d01 > txn)) kn--;
                 while (kn <= Kp && Xp0 + (double)kn * d01 > txn) kn++;
                 if (kn > Kp) break;
                 Kl = kn; marks++;
