@@ -864,6 +864,64 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
     }
 }
 
+// pool mode: both of the above in ONE launch (a kernel boundary on the main stream costs 6 us, 79 times per run at the metric
+// configuration).  No row is copied to become a phantom, so a chain's workgroup only writes the side arrays of its region and,
+// if the point that died at its step was a newcomer of this launch, that baby's row; the rows of snapshot points that died
+// are moved out by the workgroup of their SLOT (k_consume_par left the killer's chain in slot_dead) just before the slot's
+// new occupant moves in -- the one place where the order of the two copies matters.
+__global__ __launch_bounds__(64) void k_apply_pool(PcState S, unsigned batch, int nchains)
+{
+    const PcCtl *ctl = S.ctl;
+    const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
+    if ((int)blockIdx.x < nchains) {
+        const int w = ctl->seg_lo + blockIdx.x;
+        if (w > ctl->seg_hi) return;
+        const int di = S.plan[w].dead_idx, src = S.plan[w].dead_src;
+        if (di >= 0 && src < 0) {
+            const double *row = S.babies + ((size_t)(-src - 1) * nr + (nr - 1)) * nT;
+            double *dst = S.dead + (size_t)di * nT;
+            for (int e = lane; e < nT; e += 64) dst[e] = row[e];
+            if (lane == 0) {
+                S.dead_logw[di] = S.plan[w].logw; S.dead_postX[di] = S.plan[w].postX + log(S.plan[w].postXs); S.dead_postZ[di] = S.plan[w].postZ;
+                S.dead_cuid[di] = S.plan[w].dead_cuid; S.dead_entry[di] = S.plan[-src - 1].contour;
+            }
+        }
+        const int base = S.plan[w].ph_base;
+        const unsigned cuid = S.plan[w].ph_cuid;
+        const double Lg = S.plan[w].contour;
+        for (int i = lane; i < nr; i += 64) {
+            const double bl = S.baby_logL[(size_t)w * nr + i];
+            S.ph_logL[base + i] = bl; S.ph_cuid[base + i] = ((i < nr - 1) && bl > Lg) ? cuid : PC_CUID_NONE;
+            S.ph_uid[base + i] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
+        }
+        return;
+    }
+    const int slot = blockIdx.x - nchains;
+    const int src = S.slot_src[slot], killer = S.slot_dead[slot];
+    if (src < 0 && killer < 0) return;
+    double *lrow = S.live + (size_t)slot * nT;
+    if (killer >= 0) {
+        const int di = S.plan[killer].dead_idx;
+        double *dst = S.dead + (size_t)di * nT;
+        for (int e = lane; e < nT; e += 64) dst[e] = lrow[e];
+        if (lane == 0) {
+            S.dead_logw[di] = S.plan[killer].logw; S.dead_postX[di] = S.plan[killer].postX + log(S.plan[killer].postXs); S.dead_postZ[di] = S.plan[killer].postZ;
+            S.dead_cuid[di] = S.plan[killer].dead_cuid; S.dead_entry[di] = S.live_entry[slot];
+        }
+    }
+    if (src >= 0) {
+        const double *row = S.babies + ((size_t)src * nr + (nr - 1)) * nT;
+        double v[4];                                    // (nTotal <= 256 elements a lane: the loads before the stores)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (lane + 64 * q < nT) ? row[lane + 64 * q] : 0.0;
+        for (int e = lane + 256; e < nT; e += 64) lrow[e] = row[e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (lane + 64 * q < nT) lrow[lane + 64 * q] = v[q];
+    }
+    __syncthreads();
+    if (lane == 0) { S.slot_src[slot] = -1; S.slot_dead[slot] = -1; if (src >= 0) S.live_entry[slot] = S.plan[src].contour; }
+}
+
 // new live rows: every slot now owned by a chain's last baby
 __global__ __launch_bounds__(64) void k_apply_live(PcState S)
 {
@@ -1509,6 +1567,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
 
 extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
+    if (S->pool) { hipLaunchKernelGGL(k_apply_pool, dim3(nchains + S->Ncap), dim3(64), 0, st, *S, batch, nchains); return; }
     hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64 * PC_APPLY_WAVES), 0, st, *S, batch);
     hipLaunchKernelGGL(k_apply_live, dim3(S->Ncap), dim3(64), 0, st, *S);
 }

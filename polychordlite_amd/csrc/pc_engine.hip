@@ -453,7 +453,7 @@ struct Engine {
         raw_depth = split_q ? RAW_RING : 2;
         raw_buf[0] = S.nhat_raw;
         for (int r = 1; r < raw_depth; ++r) raw_buf[r] = ((D <= 24 || split_q) && S.nhat_raw) ? dalloc<double>(raw_n) : nullptr;
-        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
+        S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.slot_dead = dalloc<int>(Ncap); HIPCHK(hipMemsetAsync(S.slot_dead, 0xFF, sizeof(int) * Ncap, st)); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
         if (callback_mode) {
@@ -1495,8 +1495,10 @@ struct Engine {
                     static const bool side_free_env = std::getenv("PC_SIDE_FREE") != nullptr, side_ord_env = std::getenv("PC_SIDE_ORDERED") != nullptr;
                     const bool side_free = side_free_env || (S.D > 64 && !side_ord_env);
                     // the buffer of this nursery is free again once its bases have been whitened (fused: once sampled)
+                    // (ordered: the side stream follows k_slice anyway -- one event between k_slice and the contraction, not two:
+                    //  every record on the main stream is a few microseconds before the next kernel starts)
                     RawSlot &cur = ring[batch % raw_depth];
-                    HIPCHK(hipEventRecord(cur.consumed, st)); cur.used = true;
+                    if (side_free) { HIPCHK(hipEventRecord(cur.consumed, st)); cur.used = true; }
                     if (!side_free) { HIPCHK(hipEventRecord(ev_main, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0)); }
                     // ordered: the next nursery only; free: as far ahead as there are buffers (the last one is this nursery's own)
                     const unsigned xmax = batch + (unsigned)raw_depth - (side_free ? 0u : 1u);
@@ -1667,7 +1669,7 @@ struct Engine {
                           &pcov, &d_lo, &d_hi, &d_invcovT, &d_mean, &d_dynL };
         for (auto p : dd) dfree(*p);
         int **ii[] = { &S.live_cluster, &S.live_pos, &S.cl_list, &S.cl_n, &S.imin_slot, &S.ch_cluster, &S.ch_epoch, &S.ch_nlike,
-                       &S.ch_seed_slot, &S.slot_src, &S.slot_step, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
+                       &S.ch_seed_slot, &S.slot_src, &S.slot_step, &S.slot_dead, &S.sort_slot, &blk, &d_total, &pcnt, &count, &d_dynN };
         for (auto p : ii) dfree(*p);
         { char *cs = (char *)d_cs; dfree(cs); d_cs = nullptr; }
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (acc) {
             const double Xd = Xp0 + (double)kt * d01;
             pw->dead_src = (src >= 0) ? src : -(1 + (T - 1 - (-src - 1)));
+            if (S.pool && src >= 0) S.slot_dead[src] = w;    // (the apply kernel moves that row out before the slot's new occupant moves in)
             pw->logw = Xd - l1; pw->postX = Xd + d01; pw->postXs = 1.0; pw->postZ = sZi[kt]; pw->dead_cuid = cuid;
         } else if (valid) {                               // failed spawn (run_time_info.f90:781-785)
             pw->dead_src = -(1 + w); pw->logw = S.logzero; pw->postX = 0.0; pw->postXs = 1.0; pw->postZ = 0.0; pw->dead_cuid = 0xFFFFFFFFu;

@@ -121,6 +121,7 @@ struct PcState {
     int *sort_slot;              // [NS] live slots ordered by (logL, list position), written by k_sort_live
     unsigned long long *sort_key; // [NS] sortable logL keys (pc_keys.h) in the same order
     int *slot_src;               // [Ncap] -1: live[] row is current; >=0: chain whose last baby now owns the slot
+    int *slot_dead;              // [Ncap] pool mode: chain whose step killed the slot's occupant in the last launch (its row is still in live[]), -1: none
     int *slot_step;              // [Ncap] step of the last parallel-contraction launch at which the slot's occupant was accepted, -1: older
     int defer_update;            // the parallel contraction may run past update triggers (no host work is tied to an update)
     // pool mode (same conditions): the babies of a nursery are written by k_slice straight into the phantom array -- chain c
