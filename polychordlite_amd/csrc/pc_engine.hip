@@ -190,6 +190,19 @@ struct HandlePool {
         hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;
     }
     void put_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); events.push_back({dev, e}); }
+    // events that only order streams (no timestamps: a cheaper record)
+    std::vector<std::pair<int, hipEvent_t>> sync_events;
+    hipEvent_t get_sync_event()
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = sync_events.size(); i-- > 0;)
+                if (sync_events[i].first == dev) { hipEvent_t e = sync_events[i].second; sync_events.erase(sync_events.begin() + i); return e; }
+        }
+        hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return e;
+    }
+    void put_sync_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); sync_events.push_back({dev, e}); }
 };
 HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
@@ -1487,8 +1500,8 @@ struct Engine {
                     // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
                     // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
                     if (!st_side) {
-                        st_side = hpool().get_stream(); ev_main = hpool().get_event();
-                        for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_event(); ring[r].consumed = hpool().get_event(); }
+                        st_side = hpool().get_stream(); ev_main = hpool().get_sync_event();
+                        for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
                     }
                     // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
                     //  half a millisecond: there they run next to it from the start)
@@ -1560,7 +1573,7 @@ struct Engine {
             // 6 us per launch: 72 against 66 us)
             if (h_ctl->status == PC_ST_UPDATE || (h_ctl->upd_pending && h_ctl->status == PC_ST_RUNNING)) {
                 do_update(h_ctl->status != PC_ST_UPDATE); h_ctl->status = PC_ST_RUNNING; h_ctl->upd_pending = 0;
-                if (!ev_apply) ev_apply = hpool().get_event();
+                if (!ev_apply) ev_apply = hpool().get_sync_event();
                 HIPCHK(hipEventRecord(ev_apply, st));       // the dead rows of the rounds so far are in place behind this point
                 stream_dead();
             }
@@ -1683,13 +1696,13 @@ struct Engine {
         if (h_dead) { hfree(h_dead); h_dead = nullptr; }
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
         if (h_note) hfree((void *)h_note); h_note = nullptr;
-        if (ev_apply) { hpool().put_event(ev_apply); ev_apply = nullptr; }
+        if (ev_apply) { hpool().put_sync_event(ev_apply); ev_apply = nullptr; }
 
         if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
         if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
         if (st_side) {
-            (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_event(ev_main);
-            for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_event(ring[r].ready); if (ring[r].consumed) hpool().put_event(ring[r].consumed); ring[r] = RawSlot(); }
+            (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
+            for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_sync_event(ring[r].ready); if (ring[r].consumed) hpool().put_sync_event(ring[r].consumed); ring[r] = RawSlot(); }
         }
         st_side = nullptr; ev_main = nullptr;
     }
