@@ -393,7 +393,11 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 best = wave_argmin(best);
                 if (n - 1 > 0) { if (myslot >= 0 && mine.k == best.k && mine.v == best.v) { H.misc[0] = myslot; H.jobres[NT - 3] = best.v; } }
                 else if (lane == 0) { H.misc[0] = -1; H.jobres[NT - 3] = PC_HUGE; }
-                // log sum_p X_p after the death (the dying cluster's new volume substituted)
+            }
+            // log sum_p X_p after the death (the dying cluster's new volume substituted): the scanning wave's job, or that of the
+            // last job wave when its lanes have nothing else to do (100 clusters: the scan alone is the long pole)
+            const bool lse_sep = 8 + nc <= NJ - 64;
+            if (lse_sep ? (tid >= NJ - 64 && tid < NJ) : (tid >= NJ)) {
                 double m = -PC_HUGE;
                 for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; m = fmax(m, c < nc ? (c == cd ? Xp + l0 - l1 : H.cLogXp[c]) : -PC_HUGE); }
                 m = wave_max(m);
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 sum = wave_sum<4>(sum);
                 if (nc == 1) { m = Xp + l0 - l1; sum = 1.0; }
                 if (lane == 0) { H.jobres[NT - 1] = m; H.jobres[NT - 2] = sum; }
-            } else {
+            }
+            if (tid < (lse_sep ? NJ - 64 : NJ)) {
                 double a = 0.0, b = 0.0, c3 = 0.0; bool has = false, has3 = false;
                 if (tid == 0) { a = logZ; b = Xp + L - l1; has = true; }
                 else if (tid == 1) { a = H.cLogZp[cd]; b = Xp + L - l1; has = true; }
