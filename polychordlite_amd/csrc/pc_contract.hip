@@ -380,14 +380,21 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 //      is skipped (its label is cleared below, with the rest of the state), the last list element takes its place
                 vk_t best{PC_HUGE, 0x7fffffff};
                 int myslot = -1;
-                for (int s = lane; s < Ncap; s += 64) {
-                    if (s == slot_del || H.sC[s] != cd) continue;
-                    int p = H.sP[s];
-                    if (p == n - 1) { p = pos_del; H.sP[s] = p; }
-                    const vk_t cand{H.sL[s], p};
-                    const vk_t nb = vk_min(best, cand);
-                    if (nb.k != best.k || nb.v != best.v) myslot = s;
-                    best = nb;
+                for (int s0 = lane; s0 < Ncap; s0 += 256) {             // four labels in flight: members are rare (n_p of Ncap slots)
+                    int lab[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lab[u] = (s0 + 64 * u < Ncap) ? H.sC[s0 + 64 * u] : -1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = s0 + 64 * u;
+                        if (lab[u] != cd || s == slot_del) continue;
+                        int p = H.sP[s];
+                        if (p == n - 1) { p = pos_del; H.sP[s] = p; }
+                        const vk_t cand{H.sL[s], p};
+                        const vk_t nb = vk_min(best, cand);
+                        if (nb.k != best.k || nb.v != best.v) myslot = s;
+                        best = nb;
+                    }
                 }
                 const vk_t mine = best;
                 best = wave_argmin(best);
