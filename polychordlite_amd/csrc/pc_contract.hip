@@ -652,6 +652,20 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             for (size_t o = 0; o < sizeof(double) * (size_t)S.D; o += 64) { const int v = *(const volatile int *)(b + o); asm volatile("" :: "v"(v)); }
         }
     }
+    // The records of a chain -- its counters, the logL of its babies, their candidate lists -- are in L2 at best: three
+    // dependent round trips per chain on this serial path.  They do not change during the launch: the next chain's are
+    // requested while this one is processed.
+    int pf_nlike = 0, pf_epoch = 0, pf_ca = 0;
+    double pf_blog = 0.0, pf_last = 0.0;
+    int4 pf_a = make_int4(PC_NN_NONE, PC_NN_NONE, PC_NN_NONE, PC_NN_NONE), pf_b = pf_a;
+    auto prefetch_chain = [&](int wn) {
+        if (wn < 0) return;
+        pf_nlike = S.ch_nlike[wn]; pf_epoch = S.ch_epoch[wn]; pf_ca = S.ch_cluster[wn];
+        const double *bl = S.baby_logL + (size_t)wn * nr;
+        pf_blog = tid < nr ? bl[tid] : 0.0; pf_last = bl[nr - 1];
+        if (nn && tid < nr) { const int4 *L4 = (const int4 *)(S.nn_list + ((size_t)wn * nr + tid) * PC_NN_K); pf_a = L4[0]; pf_b = L4[1]; }
+    };
+    if (!final_mode) prefetch_chain(i_nursery - 1);
     while (!final_mode && status == PC_ST_RUNNING) {
         const long long q0 = clock64();
         // ---- more_samples_needed (nested_sampling.F90:514-543) + failures guard (:239)
@@ -691,7 +705,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         i_nursery--;
         const int n_total_before = n_total;
         live_changed = false;
-        const int w_nlike = S.ch_nlike[w], w_epoch = S.ch_epoch[w], ca = S.ch_cluster[w];
+        const int w_nlike = pf_nlike, w_epoch = pf_epoch, ca = pf_ca;
+        const double my_blog = pf_blog, Llast_pf = pf_last;
+        const int4 my_a = pf_a, my_b = pf_b;
+        prefetch_chain(i_nursery - 1);
         nlike += w_nlike;
         niter++;
         if (tid == 0) { S.plan[w].dead_idx = -1; S.plan[w].ph_base = nph; S.plan[w].ph_count = 0; S.plan[w].contour = S.logzero; for (int m = 0; m < PC_MASK_WORDS; ++m) S.plan[w].ph_mask[m] = 0ull; }
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         if (nc == 1) {
             for (int base = 0; base < nr - 1; base += NT) {
                 const int i = base + tid;
-                const bool f = (i < nr - 1) && (blog[i] > Lg);
+                const bool f = (i < nr - 1) && ((base == 0 ? my_blog : blog[i]) > Lg);
                 const unsigned long long m = __ballot(f);
                 if (lane == 0 && m) S.plan[w].ph_mask[(base >> 6) + (tid >> 6)] = m;
                 if (NT == 64) nph_add += __popcll(m);
@@ -723,10 +740,10 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                 int unresolved = 0;
                 for (int i = tid; i < nr; i += NT) {
                     int res = -1;
-                    if (blog[i] > Lg) {
+                    if ((i == tid ? my_blog : blog[i]) > Lg) {
                         res = -2;
                         const int4 *L4 = (const int4 *)(S.nn_list + ((size_t)w * nr + i) * PC_NN_K);
-                        const int4 a = L4[0], b = L4[1];
+                        const int4 a = (i == tid) ? my_a : L4[0], b = (i == tid) ? my_b : L4[1];
                         const int codes[PC_NN_K] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
 #pragma unroll
                         for (int k = 0; k < PC_NN_K; ++k) {
@@ -746,7 +763,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
             if (NT > 64 && nr <= NT) {
                 // the masks of the 16 waves meet in LDS (scratch of the search); a store to the plan followed by a
                 // load of the same words would cost a global round trip per chain
-                const bool f = (tid < nr - 1) && (blog[tid] > Lg) && (H.ids[tid] == ca);
+                const bool f = (tid < nr - 1) && (my_blog > Lg) && (H.ids[tid] == ca);
                 const unsigned long long m = __ballot(f);
                 if (lane == 0) { H.gkey[2 * (tid >> 6)] = (int)(unsigned)m; H.gkey[2 * (tid >> 6) + 1] = (int)(unsigned)(m >> 32); }
                 __syncthreads();
@@ -775,7 +792,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         if (tid == 0) S.plan[w].ph_cuid = H.cUid[ca];
         nph += nph_add;
 
-        const double Llast = blog[nr - 1];
+        const double Llast = Llast_pf;
         bool replaced = false;
         if (Llast > Lg) {
             const int id = (nc == 1) ? 0 : H.ids[nr - 1];
