@@ -1457,7 +1457,12 @@ struct Engine {
         if (S.pool) {
             pool_cursor = h_ctl->nphantom;
             babies_own = S.babies;
-            if (g_cap_phantoms.load() <= 0) grow_phantoms(2LL * S.Pcap);        // room for several updates between compactions
+            if (g_cap_phantoms.load() <= 0) {                                    // room for several updates between compactions,
+                size_t free_b = 0, total_b = 0;                                  // where the device has it to spare
+                (void)hipMemGetInfo(&free_b, &total_b);
+                const double need = 2.0 * 2.0 * (double)S.Pcap * ((double)S.nT * 8.0 + 24.0);       // both buffers at twice the rows
+                if (need < 0.4 * (double)free_b) grow_phantoms(2LL * S.Pcap);
+            }
         }
         while (true) {
             if (h_ctl->status == PC_ST_DONE) break;
