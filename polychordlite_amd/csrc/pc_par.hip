@@ -482,6 +482,42 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const int ts = code >> 2, pri = code & 3;
     const int Kp = prefix_bits(amask, ts), vps = prefix_bits(vmask, ts);
     const int status = (pri == 0) ? PC_ST_UPDATE : (pri == 1) ? PC_ST_DONE : (pri == 2) ? PC_ST_ERROR : PC_ST_RUNNING;
+    // The host can have the outcome NOW: everything it decides on (status, chains left, counters, update marks) is known, and
+    // what is left of this kernel (plans, merged order, state: 13 us) and the row kernel behind it need nothing from the host.
+    // Stamped here, the next round's launches are in the queue by the time the device gets to them.
+    __shared__ unsigned note_early[8];
+    __shared__ int marks_sh[2];                           // last mark (deaths), number of marks
+    if (tid == 0) {
+        int Kl = 0, marks = 0;
+        if (defer && Kp >= kupd) {
+            // Update triggers passed by this launch (nested_sampling.F90:321: logXp <= logX_last_update + log(compression),
+            // tested after every death): the first after kupd deaths, every later one relative to the volume at the one
+            // before.  The update is made once, afterwards, for the state at the last of them.
+            Kl = kupd; marks = 1;
+            for (;;) {
+                // the first kn > Kl whose volume is below the trigger: the test is monotone in kn, so start at the estimate
+                // Kl + log(cf) / (l0 - l1) and settle with the test itself (a linear search from Kl + 1 was 20 k cycles of
+                // this one lane per launch)
+                const double txn = (Xp0 + (double)Kl * d01) + S.log_cf;
+                const double est = (double)Kl + S.log_cf / d01;
+                int kn = !(est < (double)(Kp + 1)) ? Kp + 1 : (int)est;
+                if (kn < Kl + 1) kn = Kl + 1;
+                while (kn > Kl + 1 && !(Xp0 + (double)(kn - 1) * d01 > txn)) kn--;
+                while (kn <= Kp && Xp0 + (double)kn * d01 > txn) kn++;
+                if (kn > Kp) break;
+                Kl = kn; marks++;
+            }
+        }
+        marks_sh[0] = Kl; marks_sh[1] = marks;
+        const unsigned err = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
+        note_early[0] = (unsigned)status | (err << 8) | ((unsigned)(marks > 0) << 17) | ((unsigned)(marks & 0xFF) << 18);
+        note_early[1] = (unsigned)(T - ts); note_early[2] = (unsigned)(ndead0 + vps);
+        note_early[3] = (unsigned)(S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr);
+        note_early[4] = 1u | ((unsigned)(ctl->ncluster_dead & 0xFFFF) << 16);
+    }
+    pc_lds_barrier();
+    if (S.ctl_host && tid < PC_NOTE_WORDS)
+        ((volatile unsigned long long *)S.ctl_host)[tid] = ((unsigned long long)S.notify_seq << 32) | note_early[tid];
     if (Kp > 0 && tid == Kp - 1) {                        // state after the last death of the launch
         double m = tM, q = tS;
         ls_comb(m, q, Zp0, 1.0);
@@ -574,24 +610,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
         ctl->upd_pending = 0; ctl->upd_marks = 0;
-        if (defer && Kp >= kupd) {
-            // Update triggers passed by this launch (nested_sampling.F90:321: logXp <= logX_last_update + log(compression),
-            // tested after every death): the first after kupd deaths, every later one relative to the volume at the one
-            // before.  The update is made once, afterwards, for the state at the last of them.
-            int Kl = kupd, marks = 1;
-            for (;;) {
-                // the first kn > Kl whose volume is below the trigger: the test is monotone in kn, so start at the estimate
-                // Kl + log(cf) / (l0 - l1) and settle with the test itself (a linear search from Kl + 1 was 20 k cycles of
-                // this one lane per launch)
-                const double txn = (Xp0 + (double)Kl * d01) + S.log_cf;
-                const double est = (double)Kl + S.log_cf / d01;
-                int kn = !(est < (double)(Kp + 1)) ? Kp + 1 : (int)est;
-                if (kn < Kl + 1) kn = Kl + 1;
-                while (kn > Kl + 1 && !(Xp0 + (double)(kn - 1) * d01 > txn)) kn--;
-                while (kn <= Kp && Xp0 + (double)kn * d01 > txn) kn++;
-                if (kn > Kp) break;
-                Kl = kn; marks++;
-            }
+        if (marks_sh[1] > 0) {
+            const int Kl = marks_sh[0], marks = marks_sh[1];
             ctl->upd_pending = 1; ctl->upd_marks = marks;
             ctl->upd_tmark = accStep[Kl - 1] + 1; ctl->upd_T = T; ctl->upd_ts = ts; ctl->upd_nph0 = S.pool ? S.pool_base : nph0;
             ctl->upd_thr = key2d(uKey[Kl - 1]); ctl->upd_keep_thr = (Kp > Kl) ? 1 : 0;
@@ -609,7 +629,6 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         for (int x = 0; x + 1 < ncy && x < 8; ++x) ctl->dbg[x] += cyc[x + 1] - cyc[x];
 #endif
     }
-    pc_publish_ctl(S);
 }
 
 // ------------------------------------------------------------------------------------------

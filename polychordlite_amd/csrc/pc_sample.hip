@@ -592,9 +592,9 @@ __device__ __forceinline__ double quad_sum(double v)
 }
 // HV = coordinates per thread: 8 (nDims <= 32), 16 (<= 64), 32 (<= 128); 4*HV vectors of 4*HV padded coordinates
 // PART (HV = 32, one grade): 0 = the whole kernel; 1 = deviates + Gram-Schmidt only, the orthonormal basis goes to nhat_raw
-// (register-major: element e of thread t at [e][t], every store a full row of the wave); 2 = seed, whitening and the
-// likelihood's products from a basis made earlier.  Part 1 touches nothing the contraction changes and needs 2 KB of LDS:
-// it is drawn on the side stream while the previous nursery is sampled and consumed, several bases per CU at a time.
+// in the operand layout of k_whiten, which does the rest.  Part 1 touches nothing the contraction changes: it is drawn on
+// the side stream while earlier nurseries are sampled and consumed.  (The production first half is k_basis -- Gram-Schmidt
+// in panels; this one, pivot by pivot, stays as the reference-order variant behind PC_BASIS_PANEL_OFF.)
 template <int HV, int PART = 0>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
@@ -634,8 +634,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #pragma unroll
     for (int e = 0; e < HV; ++e) v[e] = 0.0;
     double lpre[(HV * DP + NTQ - 1) / NTQ];
-    if constexpr (PART == 2) __syncthreads();                          // sh[] of the seed
-    if constexpr (PART != 2) {
+    {
     if (active) {
         // stream element of my register 0 (coordinate d0); registers [r_lo, r_hi) hold coordinates that exist and move
         const long long e0 = (long long)(S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + pc_sel(S.g_e0, grade)
@@ -723,7 +722,7 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 #ifdef NHATSQ_DBG
     qc[3] = clock64();
 #endif
-    }   // PART != 2
+    }
     if constexpr (PART == 1) {
         // the layout k_whiten reads as its B operand: [n][group of sixteen vectors][lk][vector in group], coordinate
         // 32 h + e = 8 (n >> 1) + 2 lk + (n & 1)
@@ -771,12 +770,6 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
             }
         };
         load_L(0);
-        if constexpr (PART == 2) {
-            for (int x = tid; x < HV * NTQ; x += NTQ) {
-                const int e = x / NTQ, t = x - e * NTQ, ii = t >> 2, hh = t & 3;
-                if (ii < NR) Nl[(size_t)ii * NS + HV * hh + e] = rawb[x];
-            }
-        } else
         if (i < NR) {
 #pragma unroll
             for (int e = 0; e < HV; ++e) Nl[(size_t)i * NS + d0 + e] = v[e];    // zero beyond nDims and beyond the basis
