@@ -217,6 +217,8 @@ def test_dynamic_nlive_and_nprior_match_oracle(engine, B):
 
 
 @pytest.mark.parametrize("D,nlive,nr,B", [(100, 60, 10, 16), (40, 80, 12, 24), (128, 50, 8, 16), (113, 40, 6, 8),
+                                          # the other tile counts of the panel / matrix-core kernels (k_basis, k_whiten, k_upd_gather)
+                                          (50, 60, 10, 16), (70, 40, 6, 8), (90, 40, 6, 8),
                                           # beyond 128 dimensions: bases in HBM (k_nhats_big), Cholesky factor built in HBM
                                           (150, 170, 6, 16), (200, 30, 210, 4), (256, 280, 4, 32), (131, 150, 140, 8),
                                           # negative nDims: the spherical Gaussian of gaussian.f90 in that many dimensions
