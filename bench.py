@@ -138,7 +138,7 @@ def cpu_baseline(wl, nlive, all_cores=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nlive", type=int, default=0, help="0 = the workload's own")
     ap.add_argument("--batch", type=int, default=0)
