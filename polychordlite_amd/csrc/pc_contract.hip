@@ -958,7 +958,6 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
                 S.ph_logL[base + i] = bl; S.ph_cuid[base + i] = sel ? cuid : PC_CUID_NONE;
                 S.ph_uid[base + i] = ((unsigned long long)batch << 32) | (unsigned)(w * nr + i);
             }
-            if (S.pool) continue;                            // the rows are where k_slice wrote them
             // wave k copies the rows of bits [16k, 16k + 16), eight in flight
             unsigned long long mine = mask & (0xFFFFull << (16 * wv));
             const double *src0 = S.babies + ((size_t)w * nr + m * 64) * nT;

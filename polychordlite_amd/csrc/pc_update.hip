@@ -208,6 +208,7 @@ __device__ __forceinline__ int updg_slot(int D, int ti, int tj, int li, int lk, 
 template <int NT, bool IDX>
 __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
                                                     double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                    const int *idx, const int *nidx_p,
                                                     const double *shift, double *part, int E, int def, int nlb, int ndb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
     __shared__ long long dix[256];
     const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff, updT = def ? S.ctl->upd_T : 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, D = S.D, nT = S.nT;
-    const bool pool = S.pool != 0;
+    constexpr bool pool = IDX;                                          // (pool mode always comes with the index list)
     double *tile = (double *)smem;                                      // [CAP][TS]
     double *sh = tile + (size_t)CAP * TS;                               // [D]
     for (int d = tid; d < D; d += 256) sh[d] = shift[d];
@@ -253,10 +254,9 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
         nfill += cnt;
     };
     if constexpr (IDX) {
-        // pool mode: the phantoms that count were listed by k_upd_index (the list in the place of phC2, its length, *d_total, in the place of phU2):
-        // sixty-four of them at a time, sixteen per wave, no masks, no barriers but the flushes
-        const int *idx = (const int *)phC2;                             // (the alternate id buffer is free between compactions)
-        const int nidx = *(const int *)phU2;                            // (d_total)
+        // pool mode: the phantoms that count were listed by k_upd_index (idx, *nidx_p of them): sixty-four at a time, sixteen per
+        // wave, no masks, no barriers but the flushes
+        const int nidx = *nidx_p;
         const int gchunk = (int)gridDim.x - nlb - ndb;                      // the last nlb + ndb workgroups take a live / dead block each
         for (int c = blockIdx.x; (int)blockIdx.x < gchunk && c * 64 < nidx; c += gchunk) {
             const int have = min(64, nidx - c * 64);
@@ -553,10 +553,11 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
         static bool done_##NT = false; \
         if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); \
                           (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
+        /* pool mode: the alternate id buffer is free between compactions and holds the index list, *d_total its length */ \
         if (S->pool) hipLaunchKernelGGL((k_upd_gather<NT, true>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
-                           ph2, phL2, phC2, (unsigned long long *)d_total, (const double *)shift, part, E, deferred, nlb, ndb); \
+                           ph2, phL2, phC2, phU2, (const int *)phC2, (const int *)d_total, (const double *)shift, part, E, deferred, nlb, ndb); \
         else hipLaunchKernelGGL((k_upd_gather<NT, false>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
-                           ph2, phL2, phC2, phU2, (const double *)shift, part, E, deferred, nlb, ndb); }
+                           ph2, phL2, phC2, phU2, (const int *)nullptr, (const int *)nullptr, (const double *)shift, part, E, deferred, nlb, ndb); }
     switch (NTv) { case 1: UPDG_LAUNCH(1) break; case 2: UPDG_LAUNCH(2) break; case 3: UPDG_LAUNCH(3) break; case 4: UPDG_LAUNCH(4) break;
                    case 5: UPDG_LAUNCH(5) break; case 6: UPDG_LAUNCH(6) break; case 7: UPDG_LAUNCH(7) break; case 8: UPDG_LAUNCH(8) break;
                    default: UPDG_LAUNCH(9) break; }
