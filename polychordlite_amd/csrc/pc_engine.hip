@@ -820,7 +820,7 @@ struct Engine {
         call_dumper();
         const int nph = S.pool ? (int)pool_cursor : h_ctl->nphantom;
         static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
-        if (!fused_off && nph > 0 && !cfg.do_clustering && cfg.boost_posterior == 0.0 && pc_update_fused_ok(&S, h_ctl->ncluster)) {
+        if (!fused_off && !(cfg.ablate & 8) && nph > 0 && !cfg.do_clustering && cfg.boost_posterior == 0.0 && pc_update_fused_ok(&S, h_ctl->ncluster)) {
             // one cluster, nDims < 32: clean + covariance + Cholesky in three launches (pc_update.hip)
             const size_t need = (size_t)pc_update_fused_blocks(&S, nph) * pc_update_fused_entries(&S);
             if (need > upd_part_cap) { dfree(upd_part); upd_part_cap = 2 * need; upd_part = dalloc<double>(upd_part_cap); }
@@ -1447,13 +1447,14 @@ struct Engine {
         // updates.  Only when nothing on the host is tied to the moment of an update (files, dumper, resume) and the
         // fused update applies.
         static const bool defer_off = std::getenv("PC_DEFER_OFF") != nullptr;
-        S.defer_update = (!defer_off && par_ok && !cfg.do_clustering && cfg.boost_posterior == 0.0 && !dumper && !on_update && !cfg.resume_write &&
-                          !S.seq_mode && pc_update_fused_ok(&S, 1) && !std::getenv("PC_UPDATE_FUSED_OFF")) ? 1 : 0;
+        // (ablate bits 1, 2, 3: no pool mode, no deferred update, no fused update -- the same numbers by other kernels: tests/)
+        S.defer_update = (!defer_off && !(cfg.ablate & 4) && par_ok && !cfg.do_clustering && cfg.boost_posterior == 0.0 && !dumper && !on_update && !cfg.resume_write &&
+                          !S.seq_mode && pc_update_fused_ok(&S, 1) && !std::getenv("PC_UPDATE_FUSED_OFF") && !(cfg.ablate & 8)) ? 1 : 0;
         // Pool mode (same conditions, likelihood on the device): k_slice writes a nursery's babies into the phantom array itself,
         // updates invalidate phantoms where they lie, and the array is compacted only when it is full -- the rows of a run
         // are written once and read once (pc_state.h).  The host keeps the cursor: nothing it does not know moves it.
         static const bool pool_off = std::getenv("PC_POOL_OFF") != nullptr;
-        S.pool = (S.defer_update && !callback_mode && !pool_off) ? 1 : 0;
+        S.pool = (S.defer_update && !callback_mode && !pool_off && !(cfg.ablate & 2)) ? 1 : 0;
         if (S.pool) {
             pool_cursor = h_ctl->nphantom;
             babies_own = S.babies;

@@ -491,3 +491,28 @@ def test_twin_gaussian_evidence_statistics_match_the_reference(engine, golden):
     assert abs(z.mean() - zr.mean()) < 3.0 * sem, (z.mean(), zr.mean(), sem)
     assert 0.6 < z.std(ddof=1) / zr.std(ddof=1) < 1.6
     assert abs(np.mean(nd) / np.mean([r["ndead"] for r in ref["runs"]]) - 1.0) < 0.03
+
+
+@pytest.mark.parametrize("D,nDer,nlive,nr,kind", [(20, 2, 400, 20, "gaussian"), (70, 0, 150, 8, "corr_gaussian")])
+def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
+    """pool mode, the deferred update and the fused update are rearrangements of WHERE rows live and WHEN kernels run: a run
+    with each of them switched off (settings.ablate bits 1, 2, 3) must reproduce the default run -- every counter exactly,
+    every number to round-off (the covariance sums group the rows differently: differences of a few 1e-16 in the directions)"""
+    api = engine; olib = orc.load()
+    if kind == "gaussian": L, P, keep = api.make_problem("gaussian", D, nDer)
+    else:
+        ic = np.zeros((D, D)); ld = C.c_double()
+        olib.pc_random_invcov(12345, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
+        L, P, keep = api.make_problem("corr_gaussian", D, nDer, invcov=ic, mean=np.full(D, 0.5), logdet=ld.value)
+    runs = []
+    for ab in (0, 2, 2 | 4, 2 | 4 | 8):
+        s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=11, batch=0, max_ndead=8 * nlive)
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    g0 = runs[0]
+    assert g0["nupdates"] >= 3
+    for g in runs[1:]:
+        for k in ("ndead", "nlike", "niter"):
+            assert g[k] == g0[k], (k, g[k], g0[k])
+        assert abs(g["logZ"] - g0["logZ"]) < 1e-11 * max(1.0, abs(g0["logZ"])) and abs(g["logZerr"] - g0["logZerr"]) < 1e-11
+        assert np.abs(g["dead"] - g0["dead"]).max() < 1e-9 * max(1.0, np.abs(g0["dead"]).max())
