@@ -1414,8 +1414,9 @@ __global__ __launch_bounds__(256) void k_fold_partials(double *buf, int *cnt, in
 }
 
 #define PC_CHOL_NT 1024
-__global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count, int a_global)
+__global__ __launch_bounds__(PC_CHOL_NT) void k_cov_final_chol(PcState S, int nchunk, const double *pcov, const int *count, int a_global, int only_if_suspect)
 {
+    if (only_if_suspect && !S.ctl->chol_suspect) return;          // (uniform) the blocked factorisation in front of this launch stands
     // one workgroup per cluster: fixed-order sum of the partials, then calc_cholesky (utils.F90:621-649)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int c = blockIdx.x, nc = gridDim.x, D = S.D, DD = D * D, tid = threadIdx.x;
@@ -1769,8 +1770,102 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
     static size_t donec = 0;
     if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count, a_global);
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count, a_global, 0);
     return 0;
+}
+
+// calc_cholesky (utils.F90:621-649) for 32 <= nDims <= 128, one cluster, as a blocked right-looking factorisation: panels of
+// sixteen columns -- the 16 x 16 diagonal block by one wave with a row per lane in registers, the rows below it by forward
+// substitution (a thread per row), the trailing matrix A22 -= L21 L21^T in 16 x 16 tiles on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64, four contraction steps per tile and panel) -- with the matrix in LDS throughout.  The reference
+// sums its dot products in ascending k, one column at a time; this sums the same products panel by panel: the factor agrees to
+// round-off.  Where that is not good enough -- a pivot that is not clearly positive, i.e. a covariance that is singular to
+// working precision, where round-off decides whether the reference falls back to the scaled identity (utils.F90:633-638) --
+// the kernel says so (PcCtl::chol_suspect) and the reference-order kernel launched behind it redoes the factorisation;
+// otherwise that launch returns at once.  One-wave kernel: 0.35 ms per update at nDims = 100, this: 0.03.
+template <int NT>
+__global__ __launch_bounds__(256) void k_chol_blocked(PcState S, const double *ncov, const int *count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int NR = 16 * NT, NS = NR + 1;
+    double *A = (double *)smem;                                         // [NR][NS]
+    __shared__ int suspect;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, D = S.D;
+    const double n = (double)count[0];
+    for (int e = tid; e < NR * NR; e += 256) {
+        const int i = e / NR, j = e - i * NR;
+        double v = (i == j) ? 1.0 : 0.0;                                // rows and columns beyond nDims: identity
+        if (i < D && j < D) { v = ncov[(size_t)i * D + j] / n; S.cov[(size_t)i * D + j] = v; }
+        A[i * NS + j] = v;
+    }
+    if (tid == 0) suspect = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NT; ++p) {
+        const int c0 = 16 * p;
+        // ---- diagonal block: lane = row, right-looking in registers
+        if (wv == 0) {
+            double a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = A[(c0 + li) * NS + c0 + k];
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double aii = readlane_f64(a[i], i);
+                if (!(aii > 0.0)) bad = true;
+                const double lii = sqrt(fabs(aii) + (aii > 0.0 ? 0.0 : 1.0));
+                const double lji = (li == i) ? lii : a[i] / lii;
+                if (li >= i) a[i] = lji;
+#pragma unroll
+                for (int k = i + 1; k < 16; ++k) { const double lki = readlane_f64(lji, k); if (li > i) a[k] -= lji * lki; }
+            }
+            if (lk == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) A[(c0 + li) * NS + c0 + k] = (k <= li) ? a[k] : 0.0;
+            }
+            if (bad && lane == 0) suspect = 1;
+        }
+        __syncthreads();
+        // ---- rows below: x L11^T = A21, a thread per row
+        {
+            const int i = c0 + 16 + tid;
+            if (i < NR) {
+                double x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    double s = A[i * NS + c0 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= x[k] * A[(c0 + j) * NS + c0 + k];
+                    x[j] = s / A[(c0 + j) * NS + c0 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) A[i * NS + c0 + j] = x[j];
+            }
+        }
+        __syncthreads();
+        // ---- trailing matrix, lower triangle of tiles, dealt out to the four waves
+        int q = 0;
+        for (int ti = p + 1; ti < NT; ++ti)
+            for (int tj = p + 1; tj <= ti; ++tj, ++q) {
+                if ((q & 3) != wv) continue;
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = A[(16 * ti + lk + 4 * r) * NS + 16 * tj + li];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(16 * ti + li) * NS + c0 + 4 * ks + lk], A[(16 * tj + li) * NS + c0 + 4 * ks + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(16 * ti + lk + 4 * r) * NS + 16 * tj + li] = acc[r];
+            }
+        __syncthreads();
+    }
+    // a pivot that is tiny against its own diagonal element is round-off's to decide as well
+    for (int i = tid; i < D; i += 256) { const double l = A[i * NS + i]; if (!(l * l > 1e-9 * S.cov[(size_t)i * D + i])) suspect = 1; }
+    __syncthreads();
+    if (tid == 0) S.ctl->chol_suspect = suspect;
+    if (suspect) return;
+    for (int e = tid; e < D * D; e += 256) { const int i = e / D, j = e - i * D; S.chol[e] = (j <= i) ? A[i * NS + j] : 0.0; }
 }
 
 // pieces of the general update path used by the fused update of pc_update.hip
@@ -1787,7 +1882,19 @@ extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const 
     if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
     static size_t donec1 = 0;
     if (sh2 > donec1) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec1 = sh2; }
-    hipLaunchKernelGGL(k_cov_final_chol, dim3(1), dim3(PC_CHOL_NT), sh2, st, *S, 1, ncov, count, a_global);
+    static const bool blocked_off = std::getenv("PC_CHOL_BLOCKED_OFF") != nullptr;
+    int guard = 0;
+    if (!blocked_off && D >= 32 && D <= 128) {
+        const int nt = (D + 15) / 16;
+        const size_t shb = sizeof(double) * (size_t)(16 * nt) * (16 * nt + 1);
+#define PC_CHOLB(NT) { static bool done_ = false; if (!done_) { (void)hipFuncSetAttribute((const void *)k_chol_blocked<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb); done_ = true; } \
+            hipLaunchKernelGGL((k_chol_blocked<NT>), dim3(1), dim3(256), shb, st, *S, ncov, count); }
+        switch (nt) { case 2: PC_CHOLB(2) break; case 3: PC_CHOLB(3) break; case 4: PC_CHOLB(4) break; case 5: PC_CHOLB(5) break;
+                      case 6: PC_CHOLB(6) break; case 7: PC_CHOLB(7) break; default: PC_CHOLB(8) break; }
+#undef PC_CHOLB
+        guard = 1;
+    }
+    hipLaunchKernelGGL(k_cov_final_chol, dim3(1), dim3(PC_CHOL_NT), sh2, st, *S, 1, ncov, count, a_global, guard);
 }
 
 extern "C" void pc_launch_init_state(const PcState *S, double logzero, hipStream_t st)

@@ -46,6 +46,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     int upd_nph0;                       // phantom rows in use when the launch started (its regions begin there)
     int upd_keep_thr, upd_pad;          // deaths after the mark: death_thr stays the last death's logL
     double upd_thr;                     // logL of the death that triggered the mark (clean_phantoms' threshold)
+    int chol_suspect, chol_pad;         // the blocked factorisation met a pivot it does not trust: the reference-order kernel behind it decides
 };
 
 #define PC_MAX_GRADE 8
