@@ -106,6 +106,52 @@ __device__ inline double pc_inv_normal_cdf(double p)
     return (q < 0.0) ? -v : v;
 }
 
+// The same function in two halves, for callers that have many deviates to make: the central branch (85 % of the arguments)
+// costs two polynomials and a division, the tails a log and a square root on top -- a wavefront that evaluates the whole
+// function pays for both branches on every call, because some lane is always in a tail.  pc_inv_normal_central returns the
+// value, or sets `tail` and leaves the argument to be finished by pc_inv_normal_tail (collected and done together).
+__device__ inline double pc_inv_normal_central(double p, bool &tail)
+{
+    const double a[8] = { 3.3871328727963666080e+00, 1.3314166789178437745e+02,
+        1.9715909503065514427e+03, 1.3731693765509461125e+04, 4.5921953931549871457e+04,
+        6.7265770927008700853e+04, 3.3430575583588128105e+04, 2.5090809287301226727e+03 };
+    const double b[8] = { 1.0, 4.2313330701600911252e+01, 6.8718700749205790830e+02,
+        5.3941960214247511077e+03, 2.1213794301586595867e+04, 3.9307895800092710610e+04,
+        2.8729085735721942674e+04, 5.2264952788528545610e+03 };
+    tail = false;
+    if (p <= 0.0) return -PC_HUGE;
+    if (p >= 1.0) return PC_HUGE;
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        return q * poly8(a, r) / poly8(b, r);
+    }
+    tail = true;
+    return 0.0;
+}
+__device__ inline double pc_inv_normal_tail(double p)
+{
+    const double c[8] = { 1.42343711074968357734e+00, 4.63033784615654529590e+00,
+        5.76949722146069140550e+00, 3.64784832476320460504e+00, 1.27045825245236838258e+00,
+        2.41780725177450611770e-01, 2.27238449892691845833e-02, 7.74545014278341407640e-04 };
+    const double d[8] = { 1.0, 2.05319162663775882187e+00, 1.67638483018380384940e+00,
+        6.89767334985100004550e-01, 1.48103976427480074590e-01, 1.51986665636164571966e-02,
+        5.47593808499534494600e-04, 1.05075007164441684324e-09 };
+    const double e[8] = { 6.65790464350110377720e+00, 5.46378491116411436990e+00,
+        1.78482653991729133580e+00, 2.96560571828504891230e-01, 2.65321895265761230930e-02,
+        1.24266094738807843860e-03, 2.71155556874348757815e-05, 2.01033439929228813265e-07 };
+    const double f[8] = { 1.0, 5.99832206555887937690e-01, 1.36929880922735805310e-01,
+        1.48753612908506148525e-02, 7.86869131145613259100e-04, 1.84631831751005468180e-05,
+        1.42151175831644588870e-07, 2.04426310338993978564e-15 };
+    const double q = p - 0.5;
+    double r = (q < 0.0) ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    double v;
+    if (r <= 5.0) { r -= 1.6; v = poly8(c, r) / poly8(d, r); }
+    else          { r -= 5.0; v = poly8(e, r) / poly8(f, r); }
+    return (q < 0.0) ? -v : v;
+}
+
 // ---------------------------------------------------------------- log-space sums
 __device__ __forceinline__ double pc_logaddexp(double a, double b)
 {   // utils.F90:377-389

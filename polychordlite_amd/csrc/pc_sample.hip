@@ -1016,22 +1016,40 @@ __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
     double v[NM];
 #pragma unroll
     for (int n = 0; n < NM; ++n) v[n] = 0.0;
-    if (vact) {
-        const long long e0 = (long long)pc_sel(S.g_e0, 0) + ((long long)basis * D + ivec) * D;
+    {
+        // AS241 in two halves (pc_dev.h): the central branch inline; the arguments that fall in a tail (15 %) wait in an LDS
+        // queue and are finished together, so a wave runs the log / sqrt branch about ten times instead of 4 NT times
+        constexpr int TQ = 16;                                           // queue slots a lane (beyond: the whole function inline)
+        __shared__ double tailq[TQ * 512];
+        unsigned tmask = 0u; int tcount = 0;
+        auto deviate = [&](double u, int n) __attribute__((always_inline)) {
+            bool t;
+            double x = pc_inv_normal_central(u, t);
+            if (t) { if (tcount < TQ) { tailq[tcount * 512 + tid] = u; tmask |= 1u << n; tcount++; } else x = pc_inv_normal_cdf(u); }
+            return x;
+        };
+        if (vact) {
+            const long long e0 = (long long)pc_sel(S.g_e0, 0) + ((long long)basis * D + ivec) * D;
 #pragma unroll
-        for (int n = 0; n < NM; n += 2) {
-            const int d = 8 * (n >> 1) + 2 * lk;
-            if (d < D) {
-                const long long e = e0 + d;
-                double ua, ub;
-                pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1), ua, ub);
-                if ((e & 1ll) == 0) { v[n] = pc_inv_normal_cdf(ua); if (d + 1 < D) v[n + 1] = pc_inv_normal_cdf(ub); }
-                else {
-                    v[n] = pc_inv_normal_cdf(ub);
-                    if (d + 1 < D) { pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1) + 1u, ua, ub); v[n + 1] = pc_inv_normal_cdf(ua); }
+            for (int n = 0; n < NM; n += 2) {
+                const int d = 8 * (n >> 1) + 2 * lk;
+                if (d < D) {
+                    const long long e = e0 + d;
+                    double ua, ub;
+                    pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1), ua, ub);
+                    if ((e & 1ll) == 0) { v[n] = deviate(ua, n); if (d + 1 < D) v[n + 1] = deviate(ub, n + 1); }
+                    else {
+                        v[n] = deviate(ub, n);
+                        if (d + 1 < D) { pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, (uint32_t)(e >> 1) + 1u, ua, ub); v[n + 1] = deviate(ua, n + 1); }
+                    }
                 }
             }
         }
+        for (int k = 0; __any(k < tcount); ++k)
+            if (k < tcount) tailq[k * 512 + tid] = pc_inv_normal_tail(tailq[k * 512 + tid]);
+        int c = 0;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) if ((tmask >> n) & 1u) { v[n] = tailq[c * 512 + tid]; c++; }
     }
     {   // random_direction (random_utils.F90:276-298)
         double p0 = 0.0, p1 = 0.0;
