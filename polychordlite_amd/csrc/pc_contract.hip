@@ -1073,8 +1073,7 @@ __global__ __launch_bounds__(256) void k_install_live(PcState S, const double *r
     const int tid = threadIdx.x;
     __shared__ vk_t red[4];
     for (int s = tid; s < S.Ncap; s += 256) {
-        if (s < n) {
-            for (int e = 0; e < S.nT; ++e) S.live[(size_t)s * S.nT + e] = rows[(size_t)s * S.nT + e];
+        if (s < n) {                                       // (the rows themselves: one device-to-device copy in front of this launch)
             S.live_logL[s] = rows[(size_t)s * S.nT + S.l0]; S.live_cluster[s] = 0; S.live_pos[s] = s; S.live_entry[s] = S.logzero;
             S.cl_list[s] = s;
         } else { S.live_logL[s] = PC_HUGE; S.live_cluster[s] = -1; S.live_pos[s] = 0; S.live_entry[s] = S.logzero; }
@@ -1704,6 +1703,7 @@ extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, h
 
 extern "C" void pc_launch_install_live(const PcState *S, const double *rows, int n, hipStream_t st)
 {
+    if (n > 0) (void)hipMemcpyAsync(S->live, rows, sizeof(double) * (size_t)n * S->nT, hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(k_install_live, dim3(1), dim3(256), 0, st, *S, rows, n);
 }
 
@@ -1902,7 +1902,7 @@ extern "C" void pc_launch_init_state(const PcState *S, double logzero, hipStream
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(256), 0, st, *S, logzero);
 }
 
-#define PC_POST_BLOCKS 128
+#define PC_POST_BLOCKS 512
 extern "C" int pc_post_blocks(void) { return PC_POST_BLOCKS; }
 extern "C" void pc_launch_post_moments(const PcState *S, int nd, double *pmax, double *part, hipStream_t st)
 {
