@@ -1587,6 +1587,7 @@ __global__ __launch_bounds__(256) void k_init_state(PcState S, double logzero)
 __global__ __launch_bounds__(256) void k_post_max(PcState S, int nd, double *pmax)
 {
     __shared__ double red[256];
+    if (nd < 0) nd = S.ctl->ndead;                      // (enqueued behind the kill-off, before the host knows the count)
     double m = -PC_HUGE;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nd; i += gridDim.x * 256) {
         const double lw = S.dead_logw[i];
@@ -1605,8 +1606,14 @@ __global__ __launch_bounds__(256) void k_post_moments(PcState S, int nd, const d
     __shared__ double red2[256];
     const int tid = threadIdx.x, D = S.D + S.nDer;          // theta then phi, contiguous from p0
     const int DPc = cov_dpc(D), G = 256 / DPc, g = tid / DPc;
+    if (nd < 0) nd = S.ctl->ndead;
     double m = -PC_HUGE;
-    for (int b = 0; b < (int)gridDim.x; ++b) m = fmax(m, pmax[b]);
+    for (int b = tid; b < (int)gridDim.x; b += 256) m = fmax(m, pmax[b]);
+    red[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] = fmax(red[tid], red[tid + off]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
     for (int d0 = 0; d0 < D; d0 += DPc) {
         const int d = d0 + tid % DPc;
         double s1 = 0.0, s2 = 0.0, sw = 0.0;

@@ -1587,9 +1587,13 @@ struct Engine {
         auto t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
         const int nT = S.nT;
-        std::vector<double> hlive((size_t)S.Ncap * nT); std::vector<int> hcl(S.Ncap);
-        HIPCHK(hipMemcpy(hlive.data(), S.live, sizeof(double) * hlive.size(), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hcl.data(), S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost));
+        // (pinned buffers, copies in stream order in front of the kill-off: the host does not stop here; read_ctl below waits)
+        struct HostBuf { double *live = nullptr; int *cl = nullptr; hipStream_t s = nullptr;
+                         ~HostBuf() { if (s) (void)hipStreamSynchronize(s); if (live) hfree(live); if (cl) hfree(cl); } } hb;
+        hb.s = st; hb.live = halloc<double>((size_t)S.Ncap * nT); hb.cl = halloc<int>(S.Ncap);
+        double *hlive = hb.live; int *hcl = hb.cl;
+        HIPCHK(hipMemcpyAsync(hlive, S.live, sizeof(double) * (size_t)S.Ncap * nT, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hcl, S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost, st));
         const int nc_end = h_ctl->ncluster;
         if (h_ctl->ncluster == 0) {
             // a finished run read back from its .resume file: nothing to kill
@@ -1597,6 +1601,19 @@ struct Engine {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
+        // what the results need from the device is requested here, behind the kill-off and before the host waits for it: the
+        // posterior moments of theta over the dead points (device reduction, fixed order; the kernels take the count from the
+        // control block) and the evidences of the retired clusters -- one wait (read_ctl) instead of four
+        const int pmD = S.D + S.nDer, pm_nb = pc_post_blocks(), pm_pw = 2 * pmD + 1;   // theta and phi columns are contiguous in a row
+        const int ncd_max = std::min(h_ctl->ncluster_dead + h_ctl->ncluster, S.maxc_dead);
+        double *d_pmax = dalloc<double>(pm_nb), *d_part = dalloc<double>((size_t)pm_nb * pm_pw), *h_part = halloc<double>((size_t)pm_nb * pm_pw);
+        double *h_zp = halloc<double>(2 * (size_t)std::max(1, ncd_max));
+        pc_launch_post_moments(&S, -1, d_pmax, d_part, st);
+        HIPCHK(hipMemcpyAsync(h_part, d_part, sizeof(double) * pm_nb * pm_pw, hipMemcpyDeviceToHost, st));
+        if (ncd_max > 0) {
+            HIPCHK(hipMemcpyAsync(h_zp, S.logZp_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_zp + ncd_max, S.logZp2_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
+        }
         read_ctl();
         kt.collect();
         if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals) && h_ctl->nphantom > 0) {
@@ -1644,22 +1661,17 @@ struct Engine {
         out->nlive_final = nl;
         out->live = (double *)std::malloc(sizeof(double) * (size_t)std::max(1, nl) * nT);
         out->live_cluster = (int *)std::malloc(sizeof(int) * (size_t)std::max(1, nl));
-        for (int s = 0, k = 0; s < S.Ncap; ++s) if (hcl[s] >= 0) { std::memcpy(out->live + (size_t)k * nT, hlive.data() + (size_t)s * nT, sizeof(double) * nT); out->live_cluster[k] = hcl[s]; k++; }
+        for (int s = 0, k = 0; s < S.Ncap; ++s) if (hcl[s] >= 0) { std::memcpy(out->live + (size_t)k * nT, hlive + (size_t)s * nT, sizeof(double) * nT); out->live_cluster[k] = hcl[s]; k++; }
         const int ncd = std::min(h_ctl->ncluster_dead, S.maxc_dead);
         out->nZp = ncd;
         out->logZp = (double *)std::malloc(sizeof(double) * std::max(1, ncd));
         out->varlogZp = (double *)std::malloc(sizeof(double) * std::max(1, ncd));
-        std::vector<double> zp(std::max(1, ncd)), zp2(std::max(1, ncd));
-        HIPCHK(hipMemcpy(zp.data(), S.logZp_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(zp2.data(), S.logZp2_dead, sizeof(double) * ncd, hipMemcpyDeviceToHost));
-        for (int i = 0; i < ncd; ++i) { out->logZp[i] = 2 * zp[i] - 0.5 * zp2[i]; out->varlogZp[i] = zp2[i] - 2 * zp[i]; }
-        // posterior moments of theta from the dead points (device reduction, fixed order)
-        const int D = S.D + S.nDer, nb = pc_post_blocks(), pw = 2 * D + 1;   // theta and phi columns are contiguous in a row
+        if (ncd > ncd_max) engine_fail(PC_RC_DEVICE, "more retired clusters (%d) than the final stage could have left (%d)", ncd, ncd_max);
+        for (int i = 0; i < ncd; ++i) { const double zp = h_zp[i], zp2 = h_zp[ncd_max + i]; out->logZp[i] = 2 * zp - 0.5 * zp2; out->varlogZp[i] = zp2 - 2 * zp; }
+        hfree(h_zp);
+        // posterior moments of theta from the dead points (requested above)
+        const int D = pmD, nb = pm_nb, pw = pm_pw;
         out->post_mean = (double *)std::calloc(D, sizeof(double)); out->post_var = (double *)std::calloc(D, sizeof(double));
-        double *d_pmax = dalloc<double>(nb), *d_part = dalloc<double>((size_t)nb * pw), *h_part = halloc<double>((size_t)nb * pw);
-        pc_launch_post_moments(&S, h_ctl->ndead, d_pmax, d_part, st);
-        HIPCHK(hipMemcpyAsync(h_part, d_part, sizeof(double) * nb * pw, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
         double sw = 0.0;
         for (int b = 0; b < nb; ++b) {
             sw += h_part[(size_t)b * pw + 2 * D];
