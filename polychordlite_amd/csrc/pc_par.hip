@@ -307,8 +307,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             tot += __popcll(am);
             __threadfence_block();
             {   // refresh the per-word offsets
-                int cw = (lane < PAR_W) ? __popcll(accR[lane]) : 0, inc = cw;
-                for (int k = 1; k < PAR_W; k <<= 1) { const int o = __shfl_up(inc, k); if (lane >= k) inc += o; }
+                int cw = (lane < PAR_W) ? __popcll(accR[lane]) : 0, inc = cw;      // (sixteen words = one DPP row: row shifts, no LDS crossbar)
+                inc += dpp_i32<0x111>(inc); inc += dpp_i32<0x112>(inc); inc += dpp_i32<0x114>(inc); inc += dpp_i32<0x118>(inc);
                 if (lane < PAR_W) cum[lane] = inc - cw;
             }
             __threadfence_block();
