@@ -147,9 +147,24 @@ __device__ __forceinline__ void block_scan_ls2(double &am, double &as, double &b
     block_scan_ls3(am, as, bm, bs, cm, cs, tid, nact, X0, X1, X2, X3, nullptr, nullptr, wtot);
 }
 
+// inclusive prefix sums over a wavefront by DPP (row shifts, then the two row broadcasts): no LDS crossbar round trips
+__device__ __forceinline__ int wave_scan_i32(int v, int lane)
+{
+    v += dpp_i32<0x111>(v); v += dpp_i32<0x112>(v); v += dpp_i32<0x114>(v); v += dpp_i32<0x118>(v);
+    { const int t = dpp_i32<0x142>(v); if ((lane >> 4) & 1) v += t; }
+    { const int t = dpp_i32<0x143>(v); if (lane >= 32) v += t; }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_f64(double v, int lane)
+{
+    v += dpp_f64<0x111>(v); v += dpp_f64<0x112>(v); v += dpp_f64<0x114>(v); v += dpp_f64<0x118>(v);
+    { const double t = dpp_f64<0x142>(v); if ((lane >> 4) & 1) v += t; }
+    { const double t = dpp_f64<0x143>(v); if (lane >= 32) v += t; }
+    return v;
+}
 __device__ __forceinline__ double block_scan_add(double v, int lane, int wv, double *wtot)
 {
-    for (int k = 1; k < 64; k <<= 1) { const double o = __shfl_up(v, k); if (lane >= k) v += o; }
+    v = wave_scan_f64(v, lane);
     if (lane == 63) wtot[wv] = v;
     __syncthreads();
     double p = 0.0;
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         int sum = 0;
         for (int x = 0; x < per; ++x) if (b0 + x < nb) sum += hist[b0 + x];
         int inc = sum;
-        for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(inc, k); if (lane >= k) inc += o; }
+        inc = wave_scan_i32(inc, lane);
         if (lane == 63) accStep[wv] = inc;
         __syncthreads();
         int run = inc - sum;
@@ -527,7 +542,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
     {
         int nls = (inT && tid < ts) ? nl : 0, nlf = (inT && tid < ts && !acc) ? nl : 0;
-        for (int k = 32; k > 0; k >>= 1) { nls += __shfl_xor(nls, k); nlf += __shfl_xor(nlf, k); }
+        nls = (int)wave_sum<4>((double)nls); nlf = (int)wave_sum<4>((double)nlf);       // (exact: counts below 2^31)
         if (lane == 0 && nls) atomicAdd(&ish[1], nls);
         if (lane == 0 && nlf) atomicAdd(&ish[3], nlf);
     }
