@@ -88,8 +88,13 @@ def gather_records(run, dist, torch, device):
     """all-gather of the lived records of every rank: counts first, then ONE padded [nmax][nTotal + 1] buffer per rank
     (rows | entry contour).  Returns (gathered [sum counts][nTotal + 1] tensor on `device`, counts).  dist = None: this
     rank's records alone."""
-    rows, entry = lived_records(run)
-    rec = torch.from_numpy(np.concatenate([rows, entry[:, None]], axis=1)).to(device)
+    # the run's arrays go to the device whole (views of the engine's pinned result buffers: one DMA each) and the points that
+    # lived are picked there -- a boolean-mask copy of 30 MB on the host cost more than the merge itself
+    dead = torch.from_numpy(run["dead"]).to(device, non_blocking=True)
+    lw = torch.from_numpy(run["logweights"]).to(device, non_blocking=True)
+    entry = (torch.from_numpy(run["entry"]) if "entry" in run else torch.from_numpy(run["dead"][:, -2].copy())).to(device, non_blocking=True)
+    keep = lw > -1e29
+    rec = torch.cat([dead[keep], entry[keep][:, None]], dim=1)
     if dist is None:
         return rec.contiguous(), [int(rec.shape[0])]
     world = dist.get_world_size()
@@ -108,7 +113,7 @@ def gather_records(run, dist, torch, device):
 def merge_runs(run, dist, torch, local_rank, nDims, nDerived, want_rows=False, write=None):
     """this rank's run + everybody else's -> the merged result (every rank computes it, like an all-reduce)."""
     on_gpu = torch is not None and torch.cuda.is_available()
-    if dist is None or not on_gpu:
+    if not on_gpu:
         if dist is not None:
             raise RuntimeError("merge_runs between processes needs the GPUs (backend nccl); gather_records is the part that also runs on gloo")
         rows, entry = lived_records(run)
