@@ -43,6 +43,15 @@ __device__ __forceinline__ int prefix_bits(const u64 *words, int t)
     return c;
 }
 
+// the same from the exclusive per-word counts cum[0..PAR_W] (cum[PAR_W] = all bits)
+__device__ __forceinline__ int prefix_cum(const u64 *words, const int *cum, int t)
+{
+    const int wq = t >> 6;
+    return (wq >= PAR_W) ? cum[PAR_W] : cum[wq] + __popcll(words[wq] & ((1ull << (t & 63)) - 1ull));
+}
+// orders the LDS operations of ONE wave for the compiler; the hardware executes them in issue order
+#define PAR_WAVE_ORDER() asm volatile("" ::: "memory")
+
 // Sums of exponentials are carried as (m, s) pairs meaning m + log(s): combining two pairs costs one
 // exp and no log (the log is taken once, where a value is needed).  Neutral element: (NEGBIG, 0).
 __device__ __forceinline__ void ls_comb(double &m, double &s, double m2, double s2)
@@ -214,7 +223,11 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     const double lseRef0 = S.lse_ref[0], lseSum0 = S.lse_sum[0];
     const unsigned cuid = S.cl_uid[0];
     const double log2v = 0.6931471805599453;
-    const double l0 = log((double)n + 0.0), l1 = log((double)n + 1.0), l2 = log((double)n + 2.0), d01 = l0 - l1, d02 = l0 - l2;
+    // exclusive per-word bit counts of the three bitmaps (a prefix count is then one word and one offset, not sixteen words)
+    __shared__ int cumA[PAR_W + 1], cumV[PAR_W + 1], cumR[PAR_W + 1];
+    // the launch-wide logarithms, one lane each (as per-thread constants they were 4 x 480 cycles of every wave, four waves to a SIMD)
+    __shared__ double ulog[4];
+    if (wv == PAR_W - 1 && lane < 4) ulog[lane] = log(lane == 3 ? lseSum0 : (double)n + (double)lane);
 
     long long cyc[9]; int ncy = 0;
     cyc[ncy++] = clock64();
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     }
     if (tid == 0) { ish[0] = (T << 2) | 3; ish[1] = 0; ish[3] = 0; }
     __syncthreads();
+    const double l0 = ulog[0], l1 = ulog[1], l2 = ulog[2], d01 = l0 - l1, d02 = l0 - l2;
 
     // ---- phase 1: snapshot points strictly below / not above the candidate
     int rl = 0, rp = 0;
@@ -320,27 +334,38 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             if ((am >> lane) & 1ull) atomicOr(&accR[wq], 1ull << bq);
             if (lane == 0) amask[c] = am;
             tot += __popcll(am);
-            __threadfence_block();
+            PAR_WAVE_ORDER();                             // (LDS operations of one wave execute in issue order: nothing to wait for)
             {   // refresh the per-word offsets
                 int cw = (lane < PAR_W) ? __popcll(accR[lane]) : 0, inc = cw;      // (sixteen words = one DPP row: row shifts, no LDS crossbar)
                 inc += dpp_i32<0x111>(inc); inc += dpp_i32<0x112>(inc); inc += dpp_i32<0x114>(inc); inc += dpp_i32<0x118>(inc);
                 if (lane < PAR_W) cum[lane] = inc - cw;
             }
-            __threadfence_block();
+            PAR_WAVE_ORDER();
             rho_t = nrho; r = nr2; Gt = nG;
+        }
+        {   // the offsets every thread counts from in the phases below
+            const int ca = (lane < PAR_W) ? __popcll(amask[lane]) : 0, cv = (lane < PAR_W) ? __popcll(vmask[lane]) : 0,
+                      cr = (lane < PAR_W) ? __popcll(accR[lane]) : 0;
+            int ia = ca, iv = cv, ir = cr;
+            ia += dpp_i32<0x111>(ia); ia += dpp_i32<0x112>(ia); ia += dpp_i32<0x114>(ia); ia += dpp_i32<0x118>(ia);
+            iv += dpp_i32<0x111>(iv); iv += dpp_i32<0x112>(iv); iv += dpp_i32<0x114>(iv); iv += dpp_i32<0x118>(iv);
+            ir += dpp_i32<0x111>(ir); ir += dpp_i32<0x112>(ir); ir += dpp_i32<0x114>(ir); ir += dpp_i32<0x118>(ir);
+            if (lane < PAR_W) { cumA[lane] = ia - ca; cumV[lane] = iv - cv; cumR[lane] = ir - cr; }
+            if (lane == PAR_W - 1) { cumA[PAR_W] = ia; cumV[PAR_W] = iv; cumR[PAR_W] = ir; }
         }
     }
     __syncthreads();
 
     cyc[ncy++] = clock64();
     // ---- phase 4: counts
-    const bool acc = (amask[wv] >> lane) & 1ull;
-    const int kt = prefix_bits(amask, tid);               // acceptances (= deaths) before my step
-    const int K = prefix_bits(amask, PAR_NT);
-    const int vp = prefix_bits(vmask, tid);               // dead records written before my step
-    int pos = 0;
+    const u64 amw = amask[wv], ltm = (1ull << lane) - 1ull;
+    const bool acc = (amw >> lane) & 1ull;
+    const int kt = cumA[wv] + __popcll(amw & ltm);        // acceptances (= deaths) before my step
+    const int K = cumA[PAR_W];
+    const int vp = cumV[wv] + __popcll(vmask[wv] & ltm);  // dead records written before my step
+    int pos = 0, q = 0;
     if (acc) {
-        const int q = prefix_bits(accR, rho);             // rank among the accepted
+        q = cumR[rho >> 6] + __popcll(accR[rho >> 6] & ((1ull << (rho & 63)) - 1ull));   // rank among the accepted
         pos = q + rp;                                     // index in sorted(snapshot u accepted)
         accStep[kt] = tid; srtK[q] = ck;
     }
@@ -403,11 +428,15 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #ifdef PAR_DBG_EVID
     ecy[2] = clock64();
 #endif
-    double ziM = tM, ziS = tS;
-    ls_comb(ziM, ziS, logZ0, 1.0);
-    const double Zi = ls_val(ziM, ziS);                                // logZ after my death
+    const bool wact = wv * 64 < K;                    // waves past the last death have nothing to work out (their values are read by nobody)
+    double Zi = NEGBIG;
     double zxM = vM, zxS = vS, zpxM = vM, zpxS = vS;                   // <Z X> = Sd + (zxM + log zxS)
-    ls_comb(zxM, zxS, ZXp0, 1.0); ls_comb(zpxM, zpxS, ZpXp0, 1.0);
+    if (wact) {
+        double ziM = tM, ziS = tS;
+        ls_comb(ziM, ziS, logZ0, 1.0);
+        Zi = ls_val(ziM, ziS);                                         // logZ after my death
+        ls_comb(zxM, zxS, ZXp0, 1.0); ls_comb(zpxM, zpxS, ZpXp0, 1.0);
+    }
     if (lane == 63) { wtot[wv] = zxM; wtot[PAR_W + wv] = zxS; wtot[2 * PAR_W + wv] = zpxM; wtot[3 * PAR_W + wv] = zpxS; }
     __syncthreads();
     double pzxM = __shfl_up(zxM, 1), pzxS = __shfl_up(zxS, 1), pzpxM = __shfl_up(zpxM, 1), pzpxS = __shfl_up(zpxS, 1);
@@ -428,12 +457,12 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
 #endif
-    ls_comb(lsM, lsS, lseRef0, lseSum0);              // + the live set before the launch
+    if (wact) ls_comb(lsM, lsS, lseRef0, lseSum0);    // + the live set before the launch
 #ifdef PAR_DBG_EVID
     ecy[5] = clock64(); ecy[6] = ecy[5];
 #endif
-    const double lse_log0 = lseRef0 + log(lseSum0);
-    const double lsei = lsM + log(lsS);
+    const double lse_log0 = lseRef0 + ulog[3];
+    const double lsei = wact ? lsM + log(lsS) : NEGBIG;
     sZi[tid] = Zi; sLse[tid] = lsei;
     __syncthreads();
 #ifdef PAR_DBG_EVID
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #endif
     const int code = ish[0];
     const int ts = code >> 2, pri = code & 3;
-    const int Kp = prefix_bits(amask, ts), vps = prefix_bits(vmask, ts);
+    const int Kp = prefix_cum(amask, cumA, ts), vps = prefix_cum(vmask, cumV, ts);
     const int status = (pri == 0) ? PC_ST_UPDATE : (pri == 1) ? PC_ST_DONE : (pri == 2) ? PC_ST_ERROR : PC_ST_RUNNING;
     // The host can have the outcome NOW: everything it decides on (status, chains left, counters, update marks) is known, and
     // what is left of this kernel (plans, merged order, state: 13 us) and the row kernel behind it need nothing from the host.
@@ -571,17 +600,22 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
     // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
     if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = S.pool ? S.pool_base + w * nr : nph0 + tid * nr; pw->ph_count = -2; }
-    if (lane == 0) accR[wv] = 0ull;
     if (tid == 0) ish[2] = S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr;               // rows in use after this launch
-    pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
+    const bool accT = acc && tid < ts;
+    int pos2 = pos;
+    if (ts >= T) {
+        // nothing truncated (every launch but a run's last, with the deferred update): the accepted keep the ranks of phase 4
+        if (acc) srtK[q] = ck;
+    } else {
+        if (lane == 0) accR[wv] = 0ull;
+        pc_lds_barrier();                                 // (LDS only: the plan's stores to HBM need not have landed)
+        if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));
+        pc_lds_barrier();
+        if (accT) { const int q2 = prefix_bits(accR, rho); pos2 = q2 + rp; srtK[q2] = ck; }
+    }
 #ifdef PAR_DBG_PUBLISH
     pcy[2] = clock64(); pcy[3] = pcy[2];
 #endif
-    const bool accT = acc && tid < ts;
-    if (accT) atomicOr(&accR[rho >> 6], 1ull << (rho & 63));
-    pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
-    int pos2 = 0;
-    if (accT) { const int q2 = prefix_bits(accR, rho); pos2 = q2 + rp; srtK[q2] = ck; }
     pc_lds_barrier();                                     // (LDS only: the plan's stores to HBM need not have landed)
     if (accT && pos2 >= Kp) {                             // accepted and still alive at the end of the launch
         const int sl = slotA[tid];
@@ -618,7 +652,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             if (x > (ts >> 6)) word = 0ull; else if (x == (ts >> 6)) word &= (1ull << (ts & 63)) - 1ull;
             if (word) { tl = x * 64 + 63 - __clzll((long long)word); break; }
         }
-        ctl->failures = (tl >= 0) ? vps - prefix_bits(vmask, tl) - 1 : fail0 + vps;
+        ctl->failures = (tl >= 0) ? vps - prefix_cum(vmask, cumV, tl) - 1 : fail0 + vps;
         ctl->status = status; ctl->error = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
         ctl->i_nursery = T - ts; ctl->ndead = ndead0 + vps; ctl->seg_hi = T - 1; ctl->seg_lo = T - ts; ctl->cluster_deleted = 0;
         ctl->nlike = nlike0 + ish[1]; ctl->niter = niter0 + ts; ctl->nphantom = ish[2]; ctl->nlike_failed += ish[3];
