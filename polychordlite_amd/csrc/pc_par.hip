@@ -171,6 +171,53 @@ __device__ __forceinline__ double wave_scan_f64(double v, int lane)
     { const double t = dpp_f64<0x143>(v); if (lane >= 32) v += t; }
     return v;
 }
+// The same prefixes in LINEAR space, for the launches (nearly all of them) whose terms lie within PAR_LIN_SPAN nats of
+// the first one: every term is rescaled to that reference with ONE exp, the prefixes are plain sums, and the pair
+// (reference, sum) is handed back -- a pair means m + log(s) whatever its scale, so nothing downstream can tell.  The pair
+// scan above costs 16 wave-level log-add-exps per sequence on each SIMD (180 cycles of fp64 issue each: 24 k cycles of a
+// launch for the five sequences); this one costs one exp.  Early in a run the newcomers of a launch can be thousands of
+// nats above its first deaths: then the terms do not fit one scale, this function says so (false, nothing changed) and the
+// caller scans pairs.
+#define PAR_LIN_SPAN 300.0
+template <int NSEQ>
+__device__ __forceinline__ bool block_scan_lin(double (&m)[NSEQ], double (&s)[NSEQ], int tid, double *sc /* [(NSEQ + 1) * 16] */)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    double *ref = sc + NSEQ * PAR_W;                      // [NSEQ] references, then the verdict
+    if (tid == 0) {
+        #pragma unroll
+        for (int q = 0; q < NSEQ; ++q) ref[q] = m[q];
+        ref[NSEQ] = 0.0;
+    }
+    pc_lds_barrier();
+    double inc[NSEQ], R[NSEQ];
+    bool bad = false;
+    #pragma unroll
+    for (int q = 0; q < NSEQ; ++q) {
+        R[q] = ref[q];
+        const bool has = s[q] != 0.0 && m[q] > 0.5 * NEGBIG;
+        const double d = m[q] - R[q];
+        bad = bad || (has && !(fabs(d) <= PAR_LIN_SPAN));
+        inc[q] = wave_scan_f64(has ? s[q] * exp(d) : 0.0, lane);
+        if (lane == 63) sc[q * PAR_W + wv] = inc[q];
+    }
+    if (__ballot(bad) != 0ull && lane == 0) ref[NSEQ] = 1.0;
+    pc_lds_barrier();
+    const bool ok = ref[NSEQ] == 0.0;
+    if (ok) {
+        #pragma unroll
+        for (int q = 0; q < NSEQ; ++q) {
+            const double t = sc[q * PAR_W + (lane & 15)];
+            double pre = t;
+            pre += dpp_f64<0x111>(pre); pre += dpp_f64<0x112>(pre); pre += dpp_f64<0x114>(pre); pre += dpp_f64<0x118>(pre);
+            s[q] = inc[q] + readlane_f64(pre - t, wv);
+            m[q] = R[q];
+        }
+    }
+    pc_lds_barrier();                                     // the scratch is free again
+    return ok;
+}
+
 __device__ __forceinline__ double block_scan_add(double v, int lane, int wv, double *wtot)
 {
     v = wave_scan_f64(v, lane);
@@ -423,8 +470,15 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // It rides in the same pass as the two evidence sequences, on waves 4-7.
     double lsM = NEGBIG, lsS = 0.0;
     if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
-    __syncthreads();                                  // every thread has read its candidate key: cK becomes scratch
-    block_scan_ls3(tM, tS, vM, vS, lsM, lsS, tid, K, X0, X1, X2, X3, (double *)cK, X5, wtot);
+    __shared__ double lsc[4 * PAR_W];
+    {
+        double mm[3] = {tM, vM, lsM}, ss[3] = {tS, vS, lsS};
+        if (block_scan_lin<3>(mm, ss, tid, lsc)) { tM = mm[0]; tS = ss[0]; vM = mm[1]; vS = ss[1]; lsM = mm[2]; lsS = ss[2]; }
+        else {
+            __syncthreads();                          // every thread has read its candidate key: cK becomes scratch
+            block_scan_ls3(tM, tS, vM, vS, lsM, lsS, tid, K, X0, X1, X2, X3, (double *)cK, X5, wtot);
+        }
+    }
 #ifdef PAR_DBG_EVID
     ecy[2] = clock64();
 #endif
@@ -453,7 +507,11 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     double wM = isd ? cw + pzxM : NEGBIG, wS = isd ? pzxS : 0.0;
     double wpM = isd ? cw + pzpxM : NEGBIG, wpS = isd ? pzpxS : 0.0;
     if (isd) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
-    block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot);
+    {
+        double mm[2] = {wM, wpM}, ss[2] = {wS, wpS};
+        if (block_scan_lin<2>(mm, ss, tid, lsc)) { wM = mm[0]; wS = ss[0]; wpM = mm[1]; wpS = ss[1]; }
+        else block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot);
+    }
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
 #endif
@@ -773,12 +831,13 @@ static size_t par_lds(const PcState *S)
     return 8 * (NS + 4 * PAR_NT + 64 + 3 * PAR_W + PAR_NT + 64 + 16 + PAR_NT) + 4 * (2 * NS + 7 * PAR_NT + 2 * 64 + 16) + 64;
 }
 
-extern "C" int pc_par_fits(const PcState *S) { return par_lds(S) <= 160 * 1024 && S->B <= PAR_NT; }
+#define PAR_STATIC_LDS 2048   /* the kernel's __shared__ tables, on top of the dynamic carve */
+extern "C" int pc_par_fits(const PcState *S) { return par_lds(S) + PAR_STATIC_LDS <= 160 * 1024 && S->B <= PAR_NT; }
 
 extern "C" int pc_launch_consume_par(const PcState *S, hipStream_t st)
 {
     const size_t sh = par_lds(S);
-    if (sh > 160 * 1024 || S->B > PAR_NT) return 1;
+    if (sh + PAR_STATIC_LDS > 160 * 1024 || S->B > PAR_NT) return 1;
     static size_t d = 0;
     if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
     hipLaunchKernelGGL(k_consume_par, dim3(1), dim3(PAR_NT), sh, st, *S);
