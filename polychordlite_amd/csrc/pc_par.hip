@@ -634,30 +634,29 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (lane == 0 && nlf) atomicAdd(&ish[3], nlf);
     }
     if (inT && tid < ts) {
-        PcPlan *pw = S.plan + w;
-        const double Lg = key2d(gk);
-        pw->ph_cuid = cuid;
-        pw->contour = valid ? Lg : PC_HUGE;               // chains of an old epoch get no phantoms
-        pw->dead_idx = valid ? ndead0 + vp : -1;
+        // the chain's record: failed spawn (run_time_info.f90:781-785) unless accepted; a chain of an old epoch has no dead
+        // record at all (dead_idx -1: nobody reads the rest) and gets no phantoms
+        PcPlanHead h;
+        h.ph_cuid = cuid; h.contour = valid ? key2d(gk) : PC_HUGE; h.dead_idx = valid ? ndead0 + vp : -1;
+        h.dead_src = -(1 + w); h.logw = S.logzero; h.postX = 0.0; h.postXs = 1.0; h.postZ = 0.0; h.dead_cuid = 0xFFFFFFFFu;
         if (acc) {
             const double Xd = Xp0 + (double)kt * d01;
-            pw->dead_src = (src >= 0) ? src : -(1 + (T - 1 - (-src - 1)));
+            h.dead_src = (src >= 0) ? src : -(1 + (T - 1 - (-src - 1)));
             if (S.pool && src >= 0) S.slot_dead[src] = w;    // (the apply kernel moves that row out before the slot's new occupant moves in)
-            pw->logw = Xd - l1; pw->postX = Xd + d01; pw->postXs = 1.0; pw->postZ = sZi[kt]; pw->dead_cuid = cuid;
-        } else if (valid) {                               // failed spawn (run_time_info.f90:781-785)
-            pw->dead_src = -(1 + w); pw->logw = S.logzero; pw->postX = 0.0; pw->postXs = 1.0; pw->postZ = 0.0; pw->dead_cuid = 0xFFFFFFFFu;
+            h.logw = Xd - l1; h.postX = Xd + d01; h.postZ = sZi[kt]; h.dead_cuid = cuid;
         }
+        // phantoms of the consumed chains (run_time_info.f90:747-757): the babies above the contour their chain was
+        // consumed at.  Which babies those are is a comparison with the contour that the row-copy kernel, one workgroup per
+        // chain on the whole chip, does for itself: every consumed chain gets a region of nr rows of the phantom array in
+        // consumption order (ph_count = -2), its phantoms land in it at their own index and the other rows of the region
+        // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the
+        // masks, the prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
+        h.ph_base = S.pool ? S.pool_base + w * nr : nph0 + tid * nr; h.ph_count = -2;
+        *static_cast<PcPlanHead *>(S.plan + w) = h;       // four 16-byte stores
     }
 #ifdef PAR_DBG_PUBLISH
     pcy[1] = clock64();
 #endif
-    // phantoms of the consumed chains (run_time_info.f90:747-757): the babies above the contour their chain was
-    // consumed at.  Which babies those are is a comparison with pw->contour that the row-copy kernel, one workgroup per
-    // chain on the whole chip, does for itself: every consumed chain gets a region of nr rows of the phantom array in
-    // consumption order (ph_count = -2), its phantoms land in it at their own index and the other rows of the region
-    // carry the cluster id PC_CUID_NONE, which no clean keeps -- a layout as deterministic as the packed one, without the masks, the
-    // prefix sums and 39 strided loads per chain on this one CU (10 us of a 60 us launch).
-    if (inT && tid < ts) { PcPlan *pw = S.plan + w; pw->ph_base = S.pool ? S.pool_base + w * nr : nph0 + tid * nr; pw->ph_count = -2; }
     if (tid == 0) ish[2] = S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr;               // rows in use after this launch
     const bool accT = acc && tid < ts;
     int pos2 = pos;

@@ -54,17 +54,24 @@ struct PcCtl {                   // written by the consume kernel, read by the h
 #define PC_NN_NONE (-2147483647 - 1)
 #define PC_CUID_NONE 0xFFFFFFFEu   /* ph_cuid of a row of the phantom array that holds no phantom (no cluster has this id; the first cluster's id is 0) */
 
-struct PcPlan {                  // one record per nursery chain, written by the consume kernel
+// one record per nursery chain, written by the consume kernel.  The scalar fields are the first 64 bytes, in 16-byte groups:
+// the parallel contraction writes them as four 16-byte stores per chain (PcPlanHead), not eleven scattered ones
+struct alignas(16) PcPlanHead {
     int dead_idx;                // index in dead[] or -1
     int dead_src;                // >=0: live slot; <0: -(1+chain) whose last baby is the row
     int ph_base;                 // first phantom row of the chain
-    unsigned dead_cuid, ph_cuid;
+    unsigned dead_cuid;
+    unsigned ph_cuid;
     int ph_count;                // -1: the apply side derives mask/count/base from `contour` (one cluster)
-    double logw, postX, postZ;
+    double logw;
+    double postX, postZ;
     double postXs;               // the volume column is postX + log(postXs): the serial kernel leaves the log to the apply side
     double contour;              // global contour when the chain was consumed (phantom test, entry contour)
+};
+struct alignas(16) PcPlan : PcPlanHead {
     unsigned long long ph_mask[PC_MASK_WORDS];
 };
+static_assert(sizeof(PcPlanHead) == 64 && sizeof(PcPlan) == 64 + 8 * PC_MASK_WORDS, "plan record layout");
 
 struct PcState {
     // ---- geometry / settings
