@@ -234,6 +234,11 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ncap = S.Ncap, nr = S.nr, NS = (Ncap + 63) & ~63;
+    // The candidates sit at indices that depend on the number of chains left in the nursery, which is the whole batch for
+    // every launch but a resumed one: requested now, next to the state words, instead of a memory round trip behind them.
+    const int Bh = S.B;
+    double bl = 0.0; int ep = 0, nl = 0;
+    if (tid < Bh) { const int wh = Bh - 1 - tid; bl = S.baby_logL_T[(size_t)(nr - 1) * Bh + wh]; ep = S.ch_epoch[wh]; nl = S.ch_nlike[wh]; }
     PcCtl *ctl = S.ctl;
     const int T = ctl->i_nursery;            // steps of this launch: step t consumes chain T-1-t
     const int n = S.cl_n[0];
@@ -284,8 +289,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     for (int i = tid; i < NS; i += PAR_NT) { sSortK[i] = (i < n) ? S.sort_key[i] : KEY_HUGE; sSort[i] = S.sort_slot[i]; }
     const bool inT = tid < T;
     const int w = T - 1 - tid;
-    u64 ck = KEY_HUGE; bool valid = false; int nl = 0;
-    if (inT) { ck = d2key(S.baby_logL_T[(size_t)(nr - 1) * S.B + w]); valid = S.ch_epoch[w] == epoch; nl = S.ch_nlike[w]; }
+    u64 ck = KEY_HUGE; bool valid = false;
+    if (T != Bh && inT) { bl = S.baby_logL_T[(size_t)(nr - 1) * S.B + w]; ep = S.ch_epoch[w]; nl = S.ch_nlike[w]; }
+    if (inT) { ck = d2key(bl); valid = ep == epoch; } else nl = 0;
     cK[tid] = ck;
     for (int i = tid; i < NS + 64; i += PAR_NT) hist[i] = 0;
     {
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
             ctl->upd_thr = key2d(uKey[Kl - 1]); ctl->upd_keep_thr = (Kp > Kl) ? 1 : 0;
             ctl->logX_last_update = Xp0 + (double)Kl * d01;
         }
-        if (S.use_prec) ctl->live_logZ = lse_m + log(lse_s) - l0 + Xp;
+        if (S.use_prec) ctl->live_logZ = (Kp ? sLse[Kp - 1] : lseRef0 + ulog[3]) - l0 + Xp;   // (= lse_m + log(lse_s), taken in phase 7)
         cyc[ncy++] = clock64();
 #ifdef PAR_NO_DBG
 #elif defined(PAR_DBG_EVID)
