@@ -1,12 +1,8 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not high_dim" > gpurun_out/ab_pytest.log 2>&1; echo "pytest rc $?" > gpurun_out/ab_par.log
-grep -E "passed|failed" gpurun_out/ab_pytest.log | tail -2 >> gpurun_out/ab_par.log
-for i in 1 2 3; do
-for which in base new; do
-if [ $which = base ]; then export PCHIP_LIB=$PWD/polychordlite_amd/libpc_base.so; else unset PCHIP_LIB; fi
-python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$which', round(d['ms_per_step'],3), [(k['kernel'], round(k['avg_launch_us'],1)) for k in d['roofline'].get('kernels', [])], d['logZ'][:2])" >> gpurun_out/ab_par.log
-done; done
-unset PCHIP_LIB
-PC_DEBUG=4 python bench.py --steps 2 --warmup 1 --no-cpu 2>&1 >/dev/null | grep "dbg par" | tail -1 >> gpurun_out/ab_par.log
-cat gpurun_out/ab_par.log
+timeout 300 python bench.py --workload c3 --steps 3 --warmup 1 > gpurun_out/r02_bench_c3.json 2> gpurun_out/c3err.log
+timeout 300 python bench.py --workload c4 --steps 3 --warmup 1 > gpurun_out/r02_bench_c4.json 2> gpurun_out/c4err.log
+timeout 400 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu > gpurun_out/r02_bench_c5.json 2> gpurun_out/c5err.log
+bash tools/collect_c5_profile.sh r02 > gpurun_out/c5prof.log 2>&1
+for c in c3 c4 c5; do python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_$c.json')); print('$c', d['ms_per_step'], d['value'], d['logZ'])"; done
+head -6 gpurun_out/r02_c5_kernel_stats.csv | cut -c1-160
