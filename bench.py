@@ -320,6 +320,7 @@ def main():
                "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "roofline": roof,
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
+               "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                "reference_cpu_evals_per_s_survey_container": 357e3}
         if not args.no_cpu and world == 1:

@@ -1606,10 +1606,12 @@ struct Engine {
         // control block) and the evidences of the retired clusters -- one wait (read_ctl) instead of four
         const int pmD = S.D + S.nDer, pm_nb = pc_post_blocks(), pm_pw = 2 * pmD + 1;   // theta and phi columns are contiguous in a row
         const int ncd_max = std::min(h_ctl->ncluster_dead + h_ctl->ncluster, S.maxc_dead);
-        double *d_pmax = dalloc<double>(pm_nb), *d_part = dalloc<double>((size_t)pm_nb * pm_pw), *h_part = halloc<double>((size_t)pm_nb * pm_pw);
+        // (the partial sums go straight into pinned host memory, which the device addresses like its own: 180 KB over the
+        //  link instead of a D2H copy request behind the kernel -- that request stalled its caller for 5-6 ms once per process,
+        //  in the second or third run)
+        double *d_pmax = dalloc<double>(pm_nb), *h_part = halloc<double>((size_t)pm_nb * pm_pw);
         double *h_zp = halloc<double>(2 * (size_t)std::max(1, ncd_max));
-        pc_launch_post_moments(&S, -1, d_pmax, d_part, st);
-        HIPCHK(hipMemcpyAsync(h_part, d_part, sizeof(double) * pm_nb * pm_pw, hipMemcpyDeviceToHost, st));
+        pc_launch_post_moments(&S, -1, d_pmax, h_part, st);
         if (ncd_max > 0) {
             HIPCHK(hipMemcpyAsync(h_zp, S.logZp_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(h_zp + ncd_max, S.logZp2_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
@@ -1678,7 +1680,7 @@ struct Engine {
             for (int d = 0; d < D; ++d) { out->post_mean[d] += h_part[(size_t)b * pw + d]; out->post_var[d] += h_part[(size_t)b * pw + D + d]; }
         }
         for (int d = 0; d < D; ++d) { out->post_mean[d] /= sw; out->post_var[d] = out->post_var[d] / sw - out->post_mean[d] * out->post_mean[d]; }
-        dfree(d_pmax); dfree(d_part); hfree(h_part);
+        dfree(d_pmax); hfree(h_part);
         HIPCHK(hipStreamSynchronize(st_copy));
         return 0;
     }
