@@ -477,10 +477,13 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     double lsM = NEGBIG, lsS = 0.0;
     if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
     __shared__ double lsc[4 * PAR_W];
+    const bool lin_on = !(S.ablate & 16);             // (bit 4: pair scans only -- tests compare the two paths on the same run)
+    int npair = 0;                                    // scans of this launch that went the pair way
     {
         double mm[3] = {tM, vM, lsM}, ss[3] = {tS, vS, lsS};
-        if (block_scan_lin<3>(mm, ss, tid, lsc)) { tM = mm[0]; tS = ss[0]; vM = mm[1]; vS = ss[1]; lsM = mm[2]; lsS = ss[2]; }
+        if (lin_on && block_scan_lin<3>(mm, ss, tid, lsc)) { tM = mm[0]; tS = ss[0]; vM = mm[1]; vS = ss[1]; lsM = mm[2]; lsS = ss[2]; }
         else {
+            npair++;
             __syncthreads();                          // every thread has read its candidate key: cK becomes scratch
             block_scan_ls3(tM, tS, vM, vS, lsM, lsS, tid, K, X0, X1, X2, X3, (double *)cK, X5, wtot);
         }
@@ -515,8 +518,8 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     if (isd) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
     {
         double mm[2] = {wM, wpM}, ss[2] = {wS, wpS};
-        if (block_scan_lin<2>(mm, ss, tid, lsc)) { wM = mm[0]; wS = ss[0]; wpM = mm[1]; wpS = ss[1]; }
-        else block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot);
+        if (lin_on && block_scan_lin<2>(mm, ss, tid, lsc)) { wM = mm[0]; wS = ss[0]; wpM = mm[1]; wpS = ss[1]; }
+        else { npair++; block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot); }
     }
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         for (int x = 0; x < 6; ++x) ctl->dbg[x] += pcy[x + 1] - pcy[x];
 #else
         for (int x = 0; x + 1 < ncy && x < 8; ++x) ctl->dbg[x] += cyc[x + 1] - cyc[x];
+        ctl->dbg[7] += npair;                             // (PC_DEBUG=4: evidence scans that did not fit one scale)
 #endif
     }
 }

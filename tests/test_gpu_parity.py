@@ -496,7 +496,7 @@ def test_twin_gaussian_evidence_statistics_match_the_reference(engine, golden):
 @pytest.mark.parametrize("D,nDer,nlive,nr,kind", [(20, 2, 400, 20, "gaussian"), (70, 0, 150, 8, "corr_gaussian")])
 def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
     """pool mode, the deferred update and the fused update are rearrangements of WHERE rows live and WHEN kernels run: a run
-    with each of them switched off (settings.ablate bits 1, 2, 3) must reproduce the default run -- every counter exactly,
+    with each of them switched off (settings.ablate bits 1, 2, 3; bit 4 for the two ways of the evidence prefix sums) must reproduce the default run -- every counter exactly,
     every number to round-off (the covariance sums group the rows differently: differences of a few 1e-16 in the directions)"""
     api = engine; olib = orc.load()
     if kind == "gaussian": L, P, keep = api.make_problem("gaussian", D, nDer)
@@ -505,7 +505,7 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
         olib.pc_random_invcov(12345, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
         L, P, keep = api.make_problem("corr_gaussian", D, nDer, invcov=ic, mean=np.full(D, 0.5), logdet=ld.value)
     runs = []
-    for ab in (0, 2, 2 | 4, 2 | 4 | 8):
+    for ab in (0, 2, 2 | 4, 2 | 4 | 8, 16):            # (bit 4: the contraction's evidence prefixes as pair scans instead of in linear space)
         s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=11, batch=0, max_ndead=8 * nlive)
         s.ablate = ab
         runs.append(api.run(s, L, P))
