@@ -179,8 +179,12 @@ __device__ __forceinline__ double wave_scan_f64(double v, int lane)
 // nats above its first deaths: then the terms do not fit one scale, this function says so (false, nothing changed) and the
 // caller scans pairs.
 #define PAR_LIN_SPAN 300.0
-template <int NSEQ>
-__device__ __forceinline__ bool block_scan_lin(double (&m)[NSEQ], double (&s)[NSEQ], int tid, double *sc /* [(NSEQ + 1) * 16] */)
+// NC > 0: the prefixes are combined afterwards with launch-wide values cv[c] (the state before the launch) -- with ONE
+// reference per sequence exp(-|reference - cv[c]|) is the same number in every thread: worked out here by NC lanes of the
+// last wave between the two barriers and left in uexp[c] (cq[c] = the sequence cv[c] goes with).
+template <int NSEQ, int NC>
+__device__ __forceinline__ bool block_scan_lin(double (&m)[NSEQ], double (&s)[NSEQ], int tid, double *sc /* [(NSEQ + 1) * 16] */,
+                                               const double *cv = nullptr, const int *cq = nullptr, double *uexp = nullptr)
 {
     const int lane = tid & 63, wv = tid >> 6;
     double *ref = sc + NSEQ * PAR_W;                      // [NSEQ] references, then the verdict
@@ -190,6 +194,7 @@ __device__ __forceinline__ bool block_scan_lin(double (&m)[NSEQ], double (&s)[NS
         ref[NSEQ] = 0.0;
     }
     pc_lds_barrier();
+    if (NC > 0 && wv == PAR_W - 1 && lane < NC) uexp[lane] = exp(-fabs(ref[cq[lane]] - cv[lane]));
     double inc[NSEQ], R[NSEQ];
     bool bad = false;
     #pragma unroll
@@ -475,13 +480,26 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     // newcomers are hundreds of nats above the points they replace (early in a run, narrow posteriors).
     // It rides in the same pass as the two evidence sequences, on waves 4-7.
     double lsM = NEGBIG, lsS = 0.0;
-    if (isd) { lsM = fmax(Ladd, L); lsS = exp(Ladd - lsM) - exp(L - lsM); }
+    if (isd) {                                        // (one of the two exponentials is exp(0))
+        const double dl = L - Ladd, e = exp(-fabs(dl));
+        lsM = fmax(Ladd, L); lsS = (dl <= 0.0) ? 1.0 - e : e - 1.0;
+    }
     __shared__ double lsc[4 * PAR_W];
     const bool lin_on = !(S.ablate & 16);             // (bit 4: pair scans only -- tests compare the two paths on the same run)
+    __shared__ double ucv[4], uexp[4];
+    __shared__ int ucq[4];
+    bool lin1 = false;
+    // log-add-exp of a prefix pair with a launch-wide value: on the linear path the exponential is launch-wide too
+    auto comb_u = [&](double &m, double &s, double m2, double s2, int c) __attribute__((always_inline)) {
+        if (lin1) { const double e = uexp[c]; s = (m >= m2) ? s + s2 * e : s * e + s2; m = fmax(m, m2); }
+        else ls_comb(m, s, m2, s2);
+    };
     int npair = 0;                                    // scans of this launch that went the pair way
     {
         double mm[3] = {tM, vM, lsM}, ss[3] = {tS, vS, lsS};
-        if (lin_on && block_scan_lin<3>(mm, ss, tid, lsc)) { tM = mm[0]; tS = ss[0]; vM = mm[1]; vS = ss[1]; lsM = mm[2]; lsS = ss[2]; }
+        if (tid < 4) { ucv[tid] = tid == 0 ? logZ0 : tid == 1 ? ZXp0 : tid == 2 ? ZpXp0 : lseRef0; ucq[tid] = tid == 0 ? 0 : tid == 3 ? 2 : 1; }
+        lin1 = lin_on && block_scan_lin<3, 4>(mm, ss, tid, lsc, ucv, ucq, uexp);     // (its first barrier publishes ucv / ucq)
+        if (lin1) { tM = mm[0]; tS = ss[0]; vM = mm[1]; vS = ss[1]; lsM = mm[2]; lsS = ss[2]; }
         else {
             npair++;
             __syncthreads();                          // every thread has read its candidate key: cK becomes scratch
@@ -496,9 +514,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     double zxM = vM, zxS = vS, zpxM = vM, zpxS = vS;                   // <Z X> = Sd + (zxM + log zxS)
     if (wact) {
         double ziM = tM, ziS = tS;
-        ls_comb(ziM, ziS, logZ0, 1.0);
+        comb_u(ziM, ziS, logZ0, 1.0, 0);
         Zi = ls_val(ziM, ziS);                                         // logZ after my death
-        ls_comb(zxM, zxS, ZXp0, 1.0); ls_comb(zpxM, zpxS, ZpXp0, 1.0);
+        comb_u(zxM, zxS, ZXp0, 1.0, 1); comb_u(zpxM, zpxS, ZpXp0, 1.0, 2);
     }
     if (lane == 63) { wtot[wv] = zxM; wtot[PAR_W + wv] = zxS; wtot[2 * PAR_W + wv] = zpxM; wtot[3 * PAR_W + wv] = zpxS; }
     __syncthreads();
@@ -518,13 +536,13 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
     if (isd) { ls_comb(wM, wS, cz, 1.0); ls_comb(wpM, wpS, cz, 1.0); }
     {
         double mm[2] = {wM, wpM}, ss[2] = {wS, wpS};
-        if (lin_on && block_scan_lin<2>(mm, ss, tid, lsc)) { wM = mm[0]; wS = ss[0]; wpM = mm[1]; wpS = ss[1]; }
+        if (lin_on && block_scan_lin<2, 0>(mm, ss, tid, lsc)) { wM = mm[0]; wS = ss[0]; wpM = mm[1]; wpS = ss[1]; }
         else { npair++; block_scan_ls2(wM, wS, wpM, wpS, tid, K, X0, X1, X2, X3, wtot); }
     }
 #ifdef PAR_DBG_EVID
     ecy[4] = clock64();
 #endif
-    if (wact) ls_comb(lsM, lsS, lseRef0, lseSum0);    // + the live set before the launch
+    if (wact) comb_u(lsM, lsS, lseRef0, lseSum0, 3);  // + the live set before the launch
 #ifdef PAR_DBG_EVID
     ecy[5] = clock64(); ecy[6] = ecy[5];
 #endif
