@@ -135,6 +135,29 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_index(int nph, const unsigned ch
     if (km) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
 }
 
+// the same without the scan launch in front, for index lists of up to UPD_SELF_BLOCKS blocks: a block's offset is the sum of
+// the counts of the blocks before it, which 256 threads add up from L2 in about a microsecond (at 3750 blocks: 7 M loads on the
+// whole chip) -- less than the one-workgroup scan kernel and the launch boundary behind it (4.7 + 3.5 us per update)
+#define UPD_SELF_BLOCKS 4096
+__global__ __launch_bounds__(UPD_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total)
+{
+    __shared__ int cnt[4], part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = blockIdx.x * UPD_ROWS + tid;
+    const bool km = j < nph && (keep[j] & 2);
+    const unsigned long long m = __ballot(km);
+    int s = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += UPD_NT) s += blk_count[b];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { cnt[wv] = __popcll(m); part[wv] = s; }
+    __syncthreads();
+    int off = (part[0] + part[1]) + (part[2] + part[3]);
+    if ((int)blockIdx.x == nblk - 1 && tid == 0) *total = off + (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+    for (int x = 0; x < wv; ++x) off += cnt[x];
+    if (km) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+}
+
 // sixteen rows given by index, coordinates minus shift and a one, to consecutive tile rows; lane = element, the loads of
 // two passes (elements lane and lane + 64) in flight together
 __device__ __forceinline__ void upd_stage_idx(const double *base, const int *ridx, int cnt, double *tile, int TS, const double *sh, int D, int nT, int lane)
@@ -545,6 +568,8 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);      // the waves' result tiles reuse the row tile
     hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
     if (!S->pool) pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
+    else if (nblk <= UPD_SELF_BLOCKS && !std::getenv("PC_UPD_SCAN_LAUNCH"))
+        hipLaunchKernelGGL(k_upd_index_self, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, nblk, (int *)phC2, d_total);
     else {
         hipLaunchKernelGGL(k_upd_scan, dim3(1), dim3(1024), 0, st, blk, nblk, d_total);
         hipLaunchKernelGGL(k_upd_index, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, (int *)phC2);
