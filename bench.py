@@ -98,10 +98,23 @@ def cpu_baseline(wl, nlive, all_cores=True):
     sample = "the workload itself (%s), one full run per measurement, seed 7 (all_cores: seeds 7 .. 7 + cores - 1, one run per core in parallel)" % (wl["name"] % nlive)
     kind, D, nDer, nr, clus = wl["kind"], wl["D"], wl["nDer"], wl["nr"], wl["clustering"]
 
+    # Long configurations get a BOUNDED sample: the reference stops after max_ndead deaths (settings%max_ndead), ~10-30 s of
+    # one core; its evals/s is the cost of the same evaluations and the same bookkeeping, early in the run.
+    env, bounded = "", None
+    if kind == "corr_gaussian":
+        covf = "/tmp/pc_ref_bench_cov%d.bin" % D
+        ic, mean, logdet = random_correlated_gaussian(D)
+        with open(covf, "wb") as f:
+            f.write(np.ascontiguousarray(ic).tobytes()); f.write(np.ascontiguousarray(mean).tobytes()); f.write(np.float64(logdet).tobytes())
+        bounded = 2500
+        env = "REF_COV_FILE=%s REF_MAX_NDEAD=%d " % (covf, bounded)
+        sample = ("the first %d deaths of the workload (%s; the reference stopped by max_ndead: a full run takes it hours), seed 7 "
+                  "(all_cores: seeds 7 .. 7 + cores - 1, one run per core in parallel)" % (bounded, wl["name"] % nlive))
+
     def ref_run(seed, tag):
         tmp = "/tmp/pc_ref_bench_%s" % tag
         os.makedirs(tmp, exist_ok=True)
-        cmd = f"ulimit -s unlimited; {ref} {kind} {D} {nDer} {nlive} {nr} {seed} {clus} {tmp} ref 0"
+        cmd = f"ulimit -s unlimited; {env}{ref} {kind} {D} {nDer} {nlive} {nr} {seed} {clus} {tmp} ref 0"
         return subprocess.Popen(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=tmp)
 
     def parse(p):
@@ -109,12 +122,13 @@ def cpu_baseline(wl, nlive, all_cores=True):
         line = [l for l in out.splitlines() if l.startswith("{")]
         return json.loads(line[-1]) if line else None
 
-    if os.path.exists(ref) and kind != "corr_gaussian":
+    if os.path.exists(ref):
         j = parse(ref_run(7, "one"))
         if j:
             res = {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
                    "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off", "cpu_model": cpu_model(),
-                   "logZ": j["logZ"], "logZerr": j["logZerr"], "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"]}
+                   "logZ": j["logZ"] if not bounded else None, "logZerr": j["logZerr"] if not bounded else None, "ndead": j["ndead"], "nlike": j["nlike"],
+                   "wall_s": j["wall"], "bounded_max_ndead": bounded}
             if all_cores and ncores > 1:
                 t0 = time.time()
                 js = [parse(p) for p in [ref_run(7 + c, "c%d" % c) for c in range(ncores)]]
@@ -149,13 +163,36 @@ def main():
     ap.add_argument("--concurrent", default="4,8,16,32",
                     help="after the timed steps (N = 1): R independent runs in flight on this GPU for each R of the list "
                          "(polychordlite_amd.repeats.run_repeats; reported separately, never part of `value`); '' or 0 = skip")
+    ap.add_argument("--other-configs", default="c3,c4,c5",
+                    help="after the timed steps of the default workload (N = 1): one step each of these BASELINE configurations, reported "
+                         "as `other_configs`; '' = skip")
     ap.add_argument("--no-extras", action="store_true", help="skip the figures after the timed region (general functor, concurrent sweep)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) here, the way the driver does
+        from polychordlite_amd import _ctypes_api as api0
+        ndev = api0.load().pchip_device_count()
+        if ndev < args.gpus:
+            raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible -- one rank per GPU, no oversubscription" % (args.gpus, ndev))
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     import torch
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -164,29 +201,37 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from polychordlite_amd import _ctypes_api as api
-    from polychordlite_amd.merge import merge_runs
+    from polychordlite_amd.merge import merge_runs, Comm
     lib = api.load()
     if lib.pchip_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
+    # the exchange step's communicator: RCCL inside the library (its id travels through the process group the ranks were
+    # started with); one rank needs none
+    comm = Comm(rank, world, local_rank) if world > 1 else None
 
     wl = WORKLOADS[args.workload]
     nlive = args.nlive if args.nlive > 0 else wl["nlive"]
     nDims, nDer, nr = wl["D"], wl["nDer"], wl["nr"]
-    s = api.Settings(); lib.pchip_settings_default(C.byref(s), nDims, nDer)
-    s.nlive = nlive; s.num_repeats = nr; s.batch = args.batch; s.device = local_rank
-    s.do_clustering = wl["clustering"]
-    s.ablate = int(os.environ.get("PC_ABLATE", "0"))      # developer switches of the engine (A/B timing of a code path), 0 in production
+    cls_bit = lambda name: 1 << (api.KERNEL_CLASSES.index(name) + 1)
+
+    def problem(w, nl, batch=0):
+        s_ = api.Settings(); lib.pchip_settings_default(C.byref(s_), w["D"], w["nDer"])
+        s_.nlive = nl; s_.num_repeats = w["nr"]; s_.batch = batch; s_.device = local_rank
+        s_.do_clustering = w["clustering"]
+        s_.ablate = int(os.environ.get("PC_ABLATE", "0"))      # developer switches of the engine (A/B timing of a code path), 0 in production
+        if w["kind"] == "corr_gaussian":
+            ic, mean, logdet = random_correlated_gaussian(w["D"])
+            L_, P_, keep_ = api.make_problem("corr_gaussian", w["D"], w["nDer"], invcov=ic, mean=mean, logdet=logdet)
+        else:
+            lo, hi = w["box"] if w["box"] else (None, None)
+            L_, P_, keep_ = api.make_problem(w["kind"], w["D"], w["nDer"], lo, hi)
+        return s_, L_, P_, keep_
+
+    s, L, P, keep = problem(wl, nlive, args.batch)
     # HIP-event stopwatch on the run's own stream.  Warm-up: the four kernel classes a round consists of, every launch
     # (picks the two heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream
     # ~6 us, every launch of two classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
-    cls_bit = lambda name: 1 << (api.KERNEL_CLASSES.index(name) + 1)
     s.profile = cls_bit("k_nhats") | cls_bit("k_slice") | cls_bit("k_consume") | cls_bit("k_apply")
-    if wl["kind"] == "corr_gaussian":
-        ic, mean, logdet = random_correlated_gaussian(nDims)
-        L, P, keep = api.make_problem("corr_gaussian", nDims, nDer, invcov=ic, mean=mean, logdet=logdet)
-    else:
-        lo, hi = wl["box"] if wl["box"] else (None, None)
-        L, P, keep = api.make_problem(wl["kind"], nDims, nDer, lo, hi)
 
     def one(i):
         s.seed = 1000 + i + 100003 * rank
@@ -201,7 +246,7 @@ def main():
     top2 = ["k_slice", "k_consume"]
     for i in range(args.warmup):
         w = one(-1 - i)
-        merge_runs(w, dist, torch, local_rank, nDims, nDer)
+        merge_runs(w, comm, nDims, nDer)
         kw = w["kernel_time"]
         if kw:
             top2 = sorted(kw, key=lambda n: -kw[n]["total_s"])[:2]
@@ -213,7 +258,7 @@ def main():
     # Every step hands back its dead points in pinned host memory (zero-copy views).  Only the last step's arrays are
     # kept (for the merge); of the earlier ones the numbers: holding all of them made every later run allocate a fresh
     # 45 MB pinned buffer (~3 ms) instead of getting the previous one back from the engine's block cache.
-    BIG = ("dead", "logweights", "entry", "live")
+    BIG = ("dead", "logweights", "entry", "live", "_owner")
     runs, step_ms, last = [], [], None
     for i in range(args.steps):
         ts0 = time.perf_counter()
@@ -221,9 +266,9 @@ def main():
         last = one(i)
         runs.append({k: v for k, v in last.items() if k not in BIG})
         step_ms.append((time.perf_counter() - ts0) * 1e3)
-    # the exchange step: all-gather of the last step's dead points (rows + entry contours), merged on the device
+    # the exchange step: all-gather of the last step's dead points (rows + entry contours) over RCCL, merged on the device
     tm0 = time.perf_counter()
-    merged = merge_runs(last, dist, torch, local_rank, nDims, nDer) if args.steps > 0 else None
+    merged = merge_runs(last, comm, nDims, nDer) if args.steps > 0 else None
     merge_ms = (time.perf_counter() - tm0) * 1e3
     sync()
     dt = time.perf_counter() - t0
@@ -234,6 +279,7 @@ def main():
         t = torch.tensor([dt, nlike, nfailed], dtype=torch.float64, device=f"cuda:{local_rank}")
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); tmax = float(tm[0])
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1]); nfailed = float(ts[2])
+    last = None
 
     extras = rank == 0 and world == 1 and not args.no_extras and args.steps > 0
     general = None
@@ -264,6 +310,39 @@ def main():
             mc, _ = run_repeats(s_c, L, P, [500000 + j for j in range(R)], max_in_flight=R)
             conc.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": mc["nlike"] / mc["t_runs_s"], "unit": "likelihood evals/s",
                          "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"]})
+        sync()
+    # the other BASELINE configurations through the same engine, one timed step each (after one untimed step that sizes the
+    # block cache): reported next to the headline, never part of `value`
+    others = None
+    if extras and args.workload == "c2" and args.other_configs:
+        others = {}
+        for name in [x for x in args.other_configs.split(",") if x.strip()]:
+            w2 = WORKLOADS[name]
+            s2, L2, P2, keep2 = problem(w2, w2["nlive"])
+            s2.profile = 1
+            s2.seed = 2000
+            try:
+                api.run(s2, L2, P2)
+                torch.cuda.synchronize()
+                s2.seed = 2001
+                to0 = time.perf_counter()
+                r2 = api.run(s2, L2, P2)
+                torch.cuda.synchronize()
+                to = time.perf_counter() - to0
+            except RuntimeError as e:           # (e.g. a device without the memory for c5)
+                others[name] = {"error": str(e)}
+                continue
+            kt2 = r2["kernel_time"]
+            dom2 = max(kt2, key=lambda n: kt2[n]["total_s"]) if kt2 else None
+            bpe2 = algorithmic_bytes_per_iteration(w2["D"], w2["nDer"], w2["nr"], w2["nlive"]) * r2["niter"] / r2["nlike"]
+            others[name] = {"workload": w2["name"] % w2["nlive"], "value": r2["nlike"] / to, "unit": "likelihood evals/s", "ms_per_step": to * 1e3,
+                            "engine_ms": r2["t_total"] * 1e3, "logZ": r2["logZ"], "logZerr": r2["logZerr"], "logZ_truth": w2["truth"],
+                            "ndead": int(r2["ndead"]), "nlike": int(r2["nlike"]), "clusters_peak": int(r2["ncluster_peak"]),
+                            "dominant_kernel": dom2, "dominant_share_of_kernel_time": (kt2[dom2]["total_s"] / sum(v["total_s"] for v in kt2.values())) if dom2 else None,
+                            "kernel_time_s": {n: round(v["total_s"], 6) for n, v in kt2.items()},
+                            "bytes_per_eval": bpe2, "whole_run_frac": r2["nlike"] * bpe2 / to / 1e9 / HBM_PEAK_GBS,
+                            "note": "HIP-event stopwatch around every kernel class of the run's main stream (profile = 1: a few percent slower than an untimed run)"}
+            r2 = None
         sync()
     if rank == 0:
         value = nlike / tmax
@@ -317,7 +396,8 @@ def main():
                # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
                "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
                "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "records", "post_mean", "t_merge_s")} if merged else None,
-               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "roofline": roof,
+               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "other_configs": others, "roofline": roof,
+               "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (comm.library, world)) if comm is not None else "one rank: no exchange",
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
                "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
@@ -328,11 +408,13 @@ def main():
             out["cpu_baseline"] = cb
             # wall clock of one run of the reference / of the engine: what a user waits for (the evals/s ratio also counts the
             # engine's failed spawns as work)
-            out["speedup_wall_per_run"] = cb["wall_s"] / (tmax / max(args.steps, 1))
+            out["speedup_wall_per_run"] = cb["wall_s"] / (tmax / max(args.steps, 1)) if not cb.get("bounded_max_ndead") else None
             out["speedup_evals_per_s"] = value / cb["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -258,6 +258,26 @@ int  pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const ch
 int  pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
                        int ndevices, const int *devices, int max_in_flight, pchip_result *results, pchip_merged *merged);
 
+/* ---- between processes: one rank per GPU, RCCL inside the library (dlopen of librccl.so at first use, none at link time).
+ * Replaces the reference's MPI exchange (mpi_utils.F90:376-463 throw_baby / catch_babies, nested_sampling.F90:262-301) for
+ * the repeat-sharded mode: the only message of a job is ONE all-gather of the runs' lived records at its end.
+ *   pchip_comm_get_id: 128 opaque bytes (an ncclUniqueId) made by ONE rank and handed to all others by the caller -- a
+ *       file, MPI_Bcast, a torch.distributed store: the library does not care;
+ *   pchip_comm_create: collective over the nranks processes (ncclCommInitRank), `device` = this rank's HIP ordinal;
+ *   pchip_comm_merge: picks the points of `run` that entered a live set (logweight > logzero) on the device, all-gathers
+ *       the counts and then one padded block [nmax][nTotal] | [nmax] per rank (ncclAllGather over xGMI), and merges the
+ *       union on every rank with pchip_merge_records; nlike / ndead_all of the result are the totals over the ranks.
+ *       c = NULL: this process alone (no collective library is touched).
+ * All return 0 or a pchip_run code; nothing has a CPU path. */
+typedef struct pchip_comm pchip_comm;
+#define PCHIP_COMM_ID_BYTES 128
+int  pchip_comm_get_id(char *id128);
+int  pchip_comm_create(const char *id128, int nranks, int rank, int device, pchip_comm **out);
+void pchip_comm_destroy(pchip_comm *c);
+int  pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int nDims, int nDerived, int want_rows,
+                      pchip_merged *out);
+const char *pchip_comm_library(void);   /* the RCCL that was resolved (path or soname), NULL if none could be loaded */
+
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */
 int  pchip_slice_chains(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior,
                         unsigned batch, int nchains, const double *seeds, const double *chol,

@@ -87,7 +87,19 @@ def file_cases(inj):
     json.dump(meta, open(os.path.join(GOLD, "ref_files.json"), "w"), indent=1)
 
 
-def seed_runs(name, like, D, nDer, nlive, nr, seeds, comment, workdir=None, reuse=False):
+def random_correlated_gaussian_file(D, path, seed=12345, sigma0=0.1):
+    """the matrix of bench.py / tests (random_utils.F90:581-614: random orthonormal eigenbasis, eigen-sigma_j = sigma0 (1e-2)^(j/(D-1)))
+    in the binary layout ref_driver's REF_COV_FILE reads: D x D inverse covariance, D means, log det(covariance)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    sig = sigma0 * (1e-2) ** (np.arange(D) / max(D - 1, 1))
+    with open(path, "wb") as f:
+        f.write(np.ascontiguousarray(Q @ np.diag(sig ** -2) @ Q.T).tobytes()); f.write(np.full(D, 0.5).tobytes())
+        f.write(np.float64(2.0 * np.log(sig).sum()).tobytes())
+
+
+def seed_runs(name, like, D, nDer, nlive, nr, seeds, comment, workdir=None, reuse=False, clustering=1, env="", workers=6):
     """N runs of the untouched reference binary (own RNG) of one BASELINE configuration -> tests/golden/<name>.json:
     logZ, logZerr, ndead, nlike and the number of clusters that died (local evidences listed in .stats), per seed.
     The runs are independent: 6 at a time on the cores of this container (a 10-D Rastrigin run takes 140-270 s)."""
@@ -100,18 +112,18 @@ def seed_runs(name, like, D, nDer, nlive, nr, seeds, comment, workdir=None, reus
         d = f"{work}/d{seed}"
         stats = f"{d}/r{seed}.stats"
         if not (reuse and os.path.exists(stats) and os.path.getsize(f"{work}/out{seed}.json") > 0):
-            out = subprocess.run(["bash", "-c", f"ulimit -s unlimited; {nat} {like} {D} {nDer} {nlive} {nr} {seed} 1 {d} r{seed} 0"],
+            out = subprocess.run(["bash", "-c", f"ulimit -s unlimited; {env} {nat} {like} {D} {nDer} {nlive} {nr} {seed} {clustering} {d} r{seed} 0"],
                                  capture_output=True, text=True, cwd=work)
             open(f"{work}/out{seed}.json", "w").write(out.stdout)
         line = [l for l in open(f"{work}/out{seed}.json").read().splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         ncd = sum(1 for l in open(stats) if l.startswith("log(Z_"))
-        return dict(seed=seed, logZ=j["logZ"], logZerr=j["logZerr"], ndead=j["ndead"], nlike=j["nlike"], ncluster_dead=ncd)
+        return dict(seed=seed, logZ=j["logZ"], logZerr=j["logZerr"], ndead=j["ndead"], nlike=j["nlike"], ncluster_dead=ncd, wall_s=j.get("wall"))
 
-    with cf.ThreadPoolExecutor(6) as ex:
+    with cf.ThreadPoolExecutor(workers) as ex:
         runs = list(ex.map(one, seeds))
     json.dump({"_comment": comment, "config": dict(like=like, nDims=D, nDerived=nDer, nlive=nlive, num_repeats=nr, clustering=1),
-               "runs": runs}, open(os.path.join(GOLD, name + ".json"), "w"), indent=0)
+               "runs": runs}, open(os.path.join(GOLD, name + ".json"), "w"), indent=0)   # (config.clustering below)
     for r in runs:
         print(name, r)
 
@@ -163,6 +175,18 @@ def main():
                   "(oracle/Makefile builds the driver from /root/reference with amdflang; python oracle/gen_golden.py c3seeds); "
                   "analytic logZ = -23.263; ncluster_dead = local evidences listed in <root>.stats",
                   workdir=sys.argv[2] if len(sys.argv) > 2 else None, reuse=len(sys.argv) > 3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "c5seeds":      # BASELINE configs[4] at a live-set size the reference finishes in an hour
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        work = sys.argv[2] if len(sys.argv) > 2 else TMP + "/ref_c5_seeds"
+        os.makedirs(work, exist_ok=True)
+        random_correlated_gaussian_file(100, work + "/cov100.bin")
+        seed_runs("ref_c5_seeds", "corr_gaussian", 100, 0, 500, 200, list(range(1, 9)),
+                  "BASELINE configs[4]'s likelihood and repeats (100-D correlated Gaussian of random_gaussian.f90: random eigenbasis, eigen-sigma 0.1 .. 0.001, "
+                  "U(0,1)^100, num_repeats 200 = 2 nDims, no clustering) at nlive 500, run by the REFERENCE BINARY with its own RNG, seeds 1..8: "
+                  "REF_COV_FILE=<matrix of bench.py random_correlated_gaussian(100, seed 12345)> oracle/_ref/ref_driver corr_gaussian 100 0 500 200 $s 0 <dir> r$s "
+                  "(python oracle/gen_golden.py c5seeds); analytic logZ = 0 up to the mass outside the unit box (< 1e-6); about an hour per run",
+                  workdir=work, reuse=len(sys.argv) > 3, clustering=0, env="REF_COV_FILE=" + work + "/cov100.bin", workers=8)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "files":
         os.makedirs(TMP + "/chains/clusters", exist_ok=True)

@@ -1,12 +1,17 @@
 /*
  * ref_driver.cpp -- drives the REFERENCE's own C entry point
  * polychord_c_interface (src/polychord/interfaces.h:2-45) with C likelihoods that
- * restate the Fortran examples (gaussian.f90, rastrigin.f90, twin_gaussian.f90),
+ * restate the Fortran examples (gaussian.f90, rastrigin.f90, twin_gaussian.f90, random_gaussian.f90),
  * exactly as SURVEY.md 8(c) prescribes.  Used (a) to generate tests/golden/*.json
  * in this container and (b) as bench.py's cpu_baseline kind="reference" on the GPU box.
  * Test infrastructure only.
  *
  * usage: ref_driver <like> <nDims> <nDerived> <nlive> <nrepeats> <seed> <clustering> <base_dir> <root> [write_dead [resume_snapshot_after_ndead]]
+ * like = corr_gaussian (likelihoods/examples/random_gaussian.f90:17-30, log_gauss utils.F90:1028-1048): the inverse covariance
+ *   comes from the file REF_COV_FILE names -- nDims x nDims doubles (row-major), nDims means, log det(covariance) -- because
+ *   the reference draws its matrix from the compiler's generator BEFORE the seed is applied (gotcha 6): the caller
+ *   builds the matrix by the same construction (random_utils.F90:581-614) and hands the same one to the engine.
+ * REF_MAX_NDEAD=<n>: stop after n dead points (settings%max_ndead), for bounded timing samples of long configurations.
  * prints one JSON line: {"logZ":..,"logZerr":..,"ndead":..,"nlike":..,"wall":..}
  */
 #include <cstdio>
@@ -14,6 +19,7 @@
 #include <cstring>
 #include <cmath>
 #include <string>
+#include <vector>
 #include <chrono>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -62,6 +68,19 @@ static double twin(double *th, int D, double *phi, int nDer)
     double la = a > b ? a + std::log(std::exp(b - a) + 1) : b + std::log(std::exp(a - b) + 1);
     return la - std::log(2.0);
 }
+static std::vector<double> g_invcov, g_mean; static double g_logdet = 0.0;
+static double corr_gaussian(double *th, int D, double *, int)
+{   // likelihoods/examples/random_gaussian.f90:17-30 -> utils.F90 log_gauss
+    g_calls++;
+    double q = 0;
+    for (int a = 0; a < D; ++a) {
+        double t = 0;
+        const double *row = g_invcov.data() + (size_t)a * D;
+        for (int b = 0; b < D; ++b) t += row[b] * (th[b] - g_mean[b]);
+        q += (th[a] - g_mean[a]) * t;
+    }
+    return -((double)D * LOG_TWO_PI + g_logdet) / 2.0 - q / 2.0;
+}
 static void prior(double *cube, double *theta, int D) { for (int d = 0; d < D; ++d) theta[d] = g_lo + (g_hi - g_lo) * cube[d]; }
 // with write_resume the dumper keeps a copy of the first .resume file written after `g_snap_after` deaths:
 // the file at the end of a run holds no live points any more (golden fixture for the resume grammar)
@@ -92,6 +111,18 @@ int main(int argc, char **argv)
     double (*fn)(double *, int, double *, int) = gaussian;
     if (like == "rastrigin") { fn = rastrigin; g_lo = -5.12; g_hi = 5.12; }
     else if (like == "twin_gaussian") { fn = twin; g_lo = -1.0; g_hi = 1.0; }
+    else if (like == "corr_gaussian") {
+        const char *cf = std::getenv("REF_COV_FILE");
+        FILE *f = cf ? std::fopen(cf, "rb") : nullptr;
+        if (!f) { std::fprintf(stderr, "corr_gaussian needs REF_COV_FILE\n"); return 2; }
+        g_invcov.resize((size_t)nDims * nDims); g_mean.resize(nDims);
+        const bool ok = std::fread(g_invcov.data(), sizeof(double), g_invcov.size(), f) == g_invcov.size() &&
+                        std::fread(g_mean.data(), sizeof(double), nDims, f) == (size_t)nDims && std::fread(&g_logdet, sizeof(double), 1, f) == 1;
+        std::fclose(f);
+        if (!ok) { std::fprintf(stderr, "REF_COV_FILE: short read\n"); return 2; }
+        fn = corr_gaussian;
+    }
+    else if (like != "gaussian") { std::fprintf(stderr, "unknown likelihood %s\n", like.c_str()); return 2; }
     // optional: REF_GRADES="dims,dims;repeats,repeats" -- explicit repeats per grade (every grade_frac > 1:
     // the deterministic branch of generate.F90:303-309)
     double grade_frac[8] = { 1.0 }; int grade_dims[8] = { nDims }; int nGrade = 1;
@@ -126,7 +157,8 @@ int main(int argc, char **argv)
     const bool posteriors = rp && std::strchr(rp, 'p'), equals = rp && std::strchr(rp, 'e');
     const double boost = std::getenv("REF_BOOST") ? atof(std::getenv("REF_BOOST")) : 0.0;
     const bool cluster_post = std::getenv("REF_CLUSTER_POST") != nullptr;
-    polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, -1, boost,
+    const int max_ndead = std::getenv("REF_MAX_NDEAD") ? atoi(std::getenv("REF_MAX_NDEAD")) : -1;
+    polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, max_ndead, boost,
                           posteriors, equals, cluster_post, write_resume, false, false, true, false, write_dead, false, maximise,
                           0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
                           nGrade, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);

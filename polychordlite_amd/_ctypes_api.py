@@ -183,5 +183,7 @@ def result_dict(r, settings):
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
                nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak,
-               varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy())
+               varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
+               logzero=settings.logzero,
+               _owner=own)          # the pchip_result itself (merge.comm_merge hands it back to the library)
     return out

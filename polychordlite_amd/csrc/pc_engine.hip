@@ -83,9 +83,15 @@ static std::atomic<int> g_inject_fault{0};           // polychord_hip_set_option
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     engine_fail(PC_RC_DEVICE, "HIP error %s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-static volatile int g_stop_requested = 0;
+// polychord_hip_set_batch_callback / polychord_hip_request_stop are process-level calls of the C ABI (no run handle, like
+// the reference's setup_loglikelihood state).  A run takes its OWN copy of the batch callback when it is set up and owns
+// its OWN stop flag; a stop request raises the flag of every run in flight at that moment (the registry below) and of no
+// later one -- runs on other threads (pchip_run_repeats) neither lose a request nor inherit a stale one.
+static std::mutex g_cb_mutex;
 static polychord_batch_fn g_batch_fn = nullptr;     // polychord_hip_set_batch_callback
 static void *g_batch_user = nullptr;
+static std::mutex g_run_mutex;
+static std::vector<std::atomic<int> *> g_run_stop;  // stop flags of the runs in flight
 extern "C" double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx);
 
 namespace {
@@ -222,9 +228,13 @@ struct KTimer {
     std::vector<Span> open;
     double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
     hipEvent_t get() { if (used == pool.size()) pool.push_back(hpool().get_event()); return pool[used++]; }
-    hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u) || (seen[k]++ % stride) != 0) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
+    hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u) || (seen[k]++ % stride) != 0 || open.size() >= MAX_OPEN) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
     void end(int k, hipEvent_t a) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
-    void collect() {   // call after a stream synchronisation (the run does it once, at its end: a round no longer synchronises)
+    // Call after a stream synchronisation.  A round no longer synchronises, so the spans pile up between the moments that
+    // do (an update with host work, a compaction, a growth, the end of the run); beyond MAX_OPEN open spans launches go
+    // untimed (k_launches counts the timed ones) instead of creating events without bound.
+    static constexpr size_t MAX_OPEN = 8192;
+    void collect() {
         if (!on) return;
         for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
         open.clear(); used = 0;
@@ -252,6 +262,8 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
 
 struct Engine {
     pchip_settings cfg{};
+    std::atomic<int> stop{0};                   // polychord_hip_request_stop reached this run
+    polychord_batch_fn batch_fn = nullptr; void *batch_user = nullptr;     // the batch callback registered when the run was set up
     // host-callback mode (device proposes, host evaluates): pc_callback.hip
     polychord_loglike_fn cb_like = nullptr; polychord_prior_fn cb_prior = nullptr;
     bool callback_mode = false;
@@ -320,6 +332,7 @@ struct Engine {
     void setup(const pchip_settings &c, const pchip_like &like, const pchip_prior &prior)
     {
         cfg = c;
+        { std::lock_guard<std::mutex> g(g_cb_mutex); batch_fn = g_batch_fn; batch_user = g_batch_user; }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
             engine_fail(PC_RC_DEVICE, "no HIP device available -- this engine has no CPU path");
@@ -516,6 +529,7 @@ struct Engine {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
         nph_stale = false;
+        kt.collect();                                 // (the stream is idle: every open span is complete)
     }
 
     // The outcome of a round without a copy and without a stream synchronisation: the contraction kernel stamps the
@@ -547,7 +561,7 @@ struct Engine {
         PcCtl &c = *h_ctl;
         const int hi_before = c.i_nursery > 0 ? c.i_nursery - 1 : B - 1;       // the segment starts where the last one stopped
         c.status = (int)(got[0] & 0xFF); c.error = (int)((got[0] >> 8) & 0xFF); c.cluster_deleted = (int)((got[0] >> 16) & 1);
-        c.upd_pending = (int)((got[0] >> 17) & 1); c.upd_marks = (int)((got[0] >> 18) & 0xFF);
+        c.upd_pending = (int)((got[0] >> 17) & 1); c.upd_marks = (int)((got[0] >> 18) & 0x3FFF);
         c.i_nursery = (int)(unsigned)got[1]; c.ndead = (int)(unsigned)got[2]; c.nphantom = (int)(unsigned)got[3];
         c.ncluster = (int)(got[4] & 0xFFFF);
         {   // the low 16 bits of a counter that only grows
@@ -610,6 +624,7 @@ struct Engine {
         int total = 0;
         HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        kt.collect();
         std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
         pool_cursor = total; h_ctl->nphantom = total; nph_stale = false;
         if (pool_cursor + (long long)B * S.nr > S.Pcap / 2) grow_phantoms(std::max<long long>(2LL * S.Pcap, 2 * (pool_cursor + (long long)B * S.nr)));
@@ -1064,7 +1079,7 @@ struct Engine {
     void host_eval_batch(int n, const double *cubes, double *thetas, double *phis, double *logLs)
     {
         const int D = S.D, nDer = S.nDer, pd = std::max(1, nDer);
-        if (g_batch_fn) { g_batch_fn(g_batch_user, n, D, nDer, cubes, thetas, phis, logLs); cb_evals += n; return; }
+        if (batch_fn) { batch_fn(batch_user, n, D, nDer, cubes, thetas, phis, logLs); cb_evals += n; return; }
         for (int i = 0; i < n; ++i) logLs[i] = host_eval(cubes + (size_t)i * D, thetas + (size_t)i * D, phis + (size_t)i * pd);
     }
 
@@ -1086,7 +1101,7 @@ struct Engine {
             const auto te0 = std::chrono::steady_clock::now();
             host_eval_batch(m, bc.data(), bt.data(), bp.data(), bl.data());
             t_eval += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
-            if (g_stop_requested) return;
+            if (stop.load(std::memory_order_relaxed)) return;
             for (int i = 0; i < m; ++i) {
                 if (!(bl[i] > cfg.logzero)) continue;
                 double *row = rows.data() + (size_t)have * nT;
@@ -1122,11 +1137,11 @@ struct Engine {
             pc_launch_slice_tick(&S, batch, B, d_cs, d_x0s, d_decks, d_prop, d_ans, d_ans + B, d_ans + B + (size_t)B * D, first, hp_prop, hp_need, st);
             first = 0; cb_ticks++;
             HIPCHK(hipStreamSynchronize(st));
-            if (g_stop_requested) return;
+            if (stop.load(std::memory_order_relaxed)) return;
             double *evL = hp_ans, *evT = hp_ans + B, *evP = evT + (size_t)B * D;
             const int pd = std::max(1, nDer);
             int nneed = 0;
-            if (g_batch_fn) {                              // the parked proposals of this round in one call
+            if (batch_fn) {                                // the parked proposals of this round in one call
                 cb_idx.clear();
                 for (int c = 0; c < B; ++c) if (hp_need[c]) cb_idx.push_back(c);
                 nneed = (int)cb_idx.size();
@@ -1140,7 +1155,7 @@ struct Engine {
                         std::copy(cb_t.begin() + (size_t)i * D, cb_t.begin() + (size_t)(i + 1) * D, evT + (size_t)c * D);
                         std::copy(cb_p.begin() + (size_t)i * pd, cb_p.begin() + (size_t)(i + 1) * pd, evP + (size_t)c * pd);
                     }
-                    if (g_stop_requested) return;
+                    if (stop.load(std::memory_order_relaxed)) return;
                 }
             } else
             for (int c = 0; c < B; ++c)
@@ -1410,7 +1425,11 @@ struct Engine {
 
     int run(pchip_result *out)
     {
-        struct ActiveRun { int d; explicit ActiveRun(int dv) : d(dv & 63) { g_active_runs.fetch_add(1); g_active_dev[d].fetch_add(1); } ~ActiveRun() { g_active_runs.fetch_sub(1); g_active_dev[d].fetch_sub(1); } } active_run(dev);
+        struct ActiveRun {
+            int d; std::atomic<int> *flag;
+            ActiveRun(int dv, std::atomic<int> *f) : d(dv & 63), flag(f) { g_active_runs.fetch_add(1); g_active_dev[d].fetch_add(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.push_back(flag); }
+            ~ActiveRun() { g_active_runs.fetch_sub(1); g_active_dev[d].fetch_sub(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.erase(std::find(g_run_stop.begin(), g_run_stop.end(), flag)); }
+        } active_run(dev, &stop);
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
         h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
@@ -1429,7 +1448,7 @@ struct Engine {
             }
         }
         if (!resumed) { if (callback_mode) generate_live_callback(); else generate_live(); }
-        if (g_stop_requested) return 5;
+        if (stop.load(std::memory_order_relaxed)) return 5;
         if (cb_auto_batch && !(cb_eval_seconds >= 0.0 && cb_eval_seconds < 2e-6)) { B = B_small; S.B = B; }   // expensive (or unmeasured) callback
         auto t1 = clk::now();
         unsigned batch = resume_batch0;               // fresh counter-RNG streams after a resume
@@ -1499,7 +1518,7 @@ struct Engine {
                 else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_NHATS, e0);
                 hipEvent_t e1 = kt.begin(KT_SLICE);
-                if (callback_mode) { slice_callback(batch); if (g_stop_requested) return 5; }
+                if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) return 5; }
                 else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
                 kt.end(KT_SLICE, e1);
                 if (split) {
@@ -1732,14 +1751,14 @@ struct Engine {
 
 extern "C" {
 
-void polychord_hip_request_stop(void) { g_stop_requested = 1; }
+void polychord_hip_request_stop(void) { std::lock_guard<std::mutex> g(g_run_mutex); for (auto *f : g_run_stop) f->store(1); }
 // tests of the error paths: the next run fails once at the chosen point (1: a device allocation, 2: the cluster
 // capacity at the next split, 3: the phantom array at its next growth); 0 disarms
 void pchip_inject_fault(int kind) { g_inject_fault = kind; }
 // initial capacity of the per-cluster arrays (default 128) and of the phantom array in rows (0 = the engine's estimate);
 // both grow on demand, so these only matter to tests of the growth paths
 void pchip_set_capacity(int clusters, int phantom_rows) { if (clusters > 0) g_cap_clusters = clusters; if (phantom_rows >= 0) g_cap_phantoms = phantom_rows; }   // negative: leave as is
-void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { g_batch_fn = fn; g_batch_user = user; }
+void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { std::lock_guard<std::mutex> g(g_cb_mutex); g_batch_fn = fn; g_batch_user = user; }
 
 double polychord_hip_keyed_uniform(unsigned seed, unsigned dom, unsigned shi, unsigned slo, unsigned idx)
 {   // the engine's counter RNG on the host (same numbers as pc_dev.h pc_uniform)
@@ -1773,7 +1792,6 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
     if (like->kind == PC_LIKE_CALLBACK && !like->fn) { std::fprintf(stderr, "polychord_hip: callback likelihood without a function pointer\n"); return 1; }
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    if (g_active_runs.load() == 0) g_stop_requested = 0;      // (a stop requested for a run in flight on another thread stays)
     std::memset(out, 0, sizeof(*out));
     Engine E;
     if (hooks) { E.dumper = hooks->dumper; E.on_update = hooks->on_update; E.hook_user = hooks->user; }

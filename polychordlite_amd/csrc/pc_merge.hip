@@ -29,6 +29,9 @@
 #include <thread>
 #include <atomic>
 #include <algorithm>
+#include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: the library is dlopen'ed (no link-time dependency on RCCL)
 
 namespace {
 
@@ -304,13 +307,163 @@ __global__ __launch_bounds__(64) void k_merge_gather(MergeDev M, int b0, double 
     for (int e = threadIdx.x; e < M.nT; e += 64) dst[e] = (e == b0) ? M.entry[g] : src[e];
 }
 
+
+// ---- the lived records of ONE run, picked on the device.  A run hands back every dead point (pinned host memory); the
+// points that never entered a live set (failed spawns, logweight = logzero) are no part of its death sequence.  The
+// arrays go to the device whole (one DMA each) and are compacted there: flags + counts per 256 rows, the offsets of the
+// blocks by one workgroup, one wave per surviving row.
+#define PK_ROWS 256
+__global__ __launch_bounds__(PK_ROWS) void k_pack_flag(const double *logw, long long nd, double logzero, int *blk_count)
+{
+    const long long i = (long long)blockIdx.x * PK_ROWS + threadIdx.x;
+    const int keep = (i < nd) && (logw[i] > logzero);
+    const unsigned long long m = __ballot(keep);
+    __shared__ int wc[PK_ROWS / 64];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < PK_ROWS / 64; ++w) t += wc[w]; blk_count[blockIdx.x] = t; }
+}
+// exclusive offsets of the blocks in place, the total behind them (one workgroup; fixed order)
+__global__ __launch_bounds__(1024) void k_pack_scan(int *blk, int nb, long long *total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int b = b0 + tid, x = (b < nb) ? blk[b] : 0;
+        int v = x;
+        for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(v, s); if (lane >= s) v += t; }
+        if (lane == 63) wsum[wv] = v;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wv; ++w) pre += wsum[w];
+        v += pre;
+        __syncthreads();
+        if (b < nb) blk[b] = v - x;
+        if (tid == 1023) carry = v;
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+// surviving row i of block b -> rows_out[off_b + rank in block]; entry contour next to it.  One wave per row of the block
+// in turn (4 waves), lane = column
+__global__ __launch_bounds__(PK_ROWS) void k_pack_scatter(const double *dead, const double *logw, const double *entry, long long nd, int nT,
+                                                        double logzero, const int *blk_off, double *rows_out, double *entry_out)
+{
+    __shared__ int dst[PK_ROWS];
+    __shared__ int wc[PK_ROWS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long i = (long long)blockIdx.x * PK_ROWS + tid;
+    const int keep = (i < nd) && (logw[i] > logzero);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wc[wv] = __popcll(m);
+    __syncthreads();
+    int pre = blk_off[blockIdx.x];
+    for (int w = 0; w < wv; ++w) pre += wc[w];
+    dst[tid] = keep ? pre + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    if (keep) entry_out[dst[tid]] = entry[i];
+    __syncthreads();
+    for (int r = wv; r < PK_ROWS; r += PK_ROWS / 64) {
+        const int d = dst[r];
+        if (d < 0) continue;
+        const double *src = dead + ((size_t)blockIdx.x * PK_ROWS + r) * nT;
+        double *o = rows_out + (size_t)d * nT;
+        for (int e = lane; e < nT; e += 64) o[e] = src[e];
+    }
+}
+// gathered blocks [rank][rows nmax x nT | entry nmax] -> the runs one after the other
+__global__ __launch_bounds__(64) void k_unpad(const double *recv, long long nmax, int nT, int R, const long long *off, double *rows, double *entry)
+{
+    const long long g = blockIdx.x;                // merged record index
+    int q = 0;
+    for (int r = 1; r < R; ++r) q = (g >= off[r]) ? r : q;
+    const long long k = g - off[q];
+    const double *blk = recv + (size_t)q * (size_t)nmax * (nT + 1);
+    const double *src = blk + (size_t)k * nT;
+    double *dst = rows + (size_t)g * nT;
+    for (int e = threadIdx.x; e < nT; e += 64) dst[e] = src[e];
+    if (threadIdx.x == 0) entry[g] = blk[(size_t)nmax * nT + k];
+}
+
+// ---- RCCL, resolved at run time: the engine has no link-time dependency on a collective library (a single-GPU user needs
+// none), and inside a torch process the RCCL that is already loaded is the one that is used.
+struct Rccl {
+    void *h = nullptr; bool tried = false; std::string where;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        static std::mutex m;
+        std::lock_guard<std::mutex> g(m);
+        if (tried) return h != nullptr;
+        tried = true;
+        const char *env = std::getenv("PCHIP_RCCL_LIB");
+        const char *names[] = { env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+        for (int pass = 0; pass < 2 && !h; ++pass)             // first a copy that is already in the process, then from disk
+            for (const char *n : names) {
+                if (!n || !*n) continue;
+                h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) { where = n; break; }
+            }
+        if (!h) return false;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { h = nullptr; return false; }
+        return true;
+    }
+};
+Rccl &rccl() { static Rccl *r = new Rccl; return *r; }
+
 struct DevBuf {
     std::vector<void *> v;
     template <class T> T *get(size_t n) { void *p = nullptr; if (hipMalloc(&p, sizeof(T) * (n ? n : 1)) != hipSuccess) { (void)hipGetLastError(); return nullptr; } v.push_back(p); return (T *)p; }
     ~DevBuf() { for (void *p : v) (void)hipFree(p); }
 };
 
+// two steps, because the caller sizes the destination with the counts of ALL runs (or ranks): count() uploads the weights,
+// flags and scans (one host wait for the number of records); scatter() uploads the rows and writes the survivors where
+// the caller wants them, on the run's device
+struct PackJob {
+    const pchip_result *r = nullptr; double logzero = 0.0; int device = 0, nT = 0, nb = 0; long long nd = 0, count = 0;
+    double *d_logw = nullptr; int *d_blk = nullptr; long long *d_total = nullptr;
+    bool count_records(DevBuf &B, hipStream_t st)
+    {
+        nd = r->ndead; nT = r->nTotal; nb = (int)((nd + PK_ROWS - 1) / PK_ROWS); count = 0;
+        if (nd <= 0) return true;
+        if (hipSetDevice(device) != hipSuccess) return false;
+        d_logw = B.get<double>(nd); d_blk = B.get<int>(nb + 1); d_total = B.get<long long>(1);
+        if (!d_logw || !d_blk || !d_total) return false;
+        if (hipMemcpyAsync(d_logw, r->logweights, sizeof(double) * nd, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_pack_flag, dim3(nb), dim3(PK_ROWS), 0, st, (const double *)d_logw, nd, logzero, d_blk);
+        hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, d_blk, nb, d_total);
+        if (hipMemcpyAsync(&count, d_total, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        return hipStreamSynchronize(st) == hipSuccess;
+    }
+    bool scatter(DevBuf &B, double *rows_out, double *entry_out, hipStream_t st)
+    {
+        if (nd <= 0 || count <= 0) return true;
+        if (hipSetDevice(device) != hipSuccess) return false;
+        double *d_dead = B.get<double>((size_t)nd * nT), *d_entry = B.get<double>(nd);
+        if (!d_dead || !d_entry) return false;
+        if (hipMemcpyAsync(d_dead, r->dead, sizeof(double) * (size_t)nd * nT, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        if (hipMemcpyAsync(d_entry, r->entry, sizeof(double) * nd, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(PK_ROWS), 0, st, (const double *)d_dead, (const double *)d_logw, (const double *)d_entry,
+                           nd, nT, logzero, (const int *)d_blk, rows_out, entry_out);
+        return hipGetLastError() == hipSuccess;
+    }
+};
+
 }  // namespace
+
+struct pchip_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
 
 extern "C" {
 
@@ -439,20 +592,146 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
     const double t_runs = std::chrono::duration<double>(clk::now() - t0).count();
     if (worst.load() != 0) { for (int k = 0; k < nseeds; ++k) pchip_result_free(&results[k]); return worst.load(); }
     if (!merged) return 0;
-    // the union of the points that entered a live set (failed spawns carry logweight = logzero), run after run
-    const int nT = results[0].nTotal, l0 = nT - 1;
+    // the union of the points that entered a live set (failed spawns carry logweight = logzero), run after run: every run's
+    // records are picked on the device it ran on and land in ONE buffer on devices[0] -- written there directly, or over
+    // xGMI by a peer copy; nothing passes through host vectors
+    const int nT = results[0].nTotal;
     std::vector<long> counts(nseeds, 0);
-    size_t ntot = 0;
-    for (int k = 0; k < nseeds; ++k) { for (long i = 0; i < results[k].ndead; ++i) counts[k] += results[k].logweights[i] > s->logzero; ntot += (size_t)counts[k]; }
-    std::vector<double> rows(ntot * nT), entry(ntot);
-    size_t o = 0;
-    for (int k = 0; k < nseeds; ++k)
-        for (long i = 0; i < results[k].ndead; ++i)
-            if (results[k].logweights[i] > s->logzero) { std::memcpy(rows.data() + o * nT, results[k].dead + (size_t)i * nT, sizeof(double) * nT); entry[o] = results[k].entry[i]; o++; }
-    (void)l0;
-    (void)hipSetDevice(devs[0]);
-    const int rc = pchip_merge_records(s->nDims, s->nDerived, nseeds, counts.data(), rows.data(), entry.data(), 0, 1, merged);
+    int rc = 0;
+    {
+        std::vector<DevBuf> scratch(devs.size());                       // per device: freed with that device current
+        std::vector<PackJob> jobs(nseeds);
+        size_t ntot = 0;
+        for (int k = 0; k < nseeds && rc == 0; ++k) {
+            PackJob &J = jobs[k];
+            J.r = &results[k]; J.logzero = s->logzero; J.device = devs[k % devs.size()];
+            if (!J.count_records(scratch[k % devs.size()], nullptr)) rc = 7;
+            counts[k] = (long)J.count; ntot += (size_t)J.count;
+        }
+        DevBuf U;
+        double *rows_all = nullptr, *entry_all = nullptr;
+        if (rc == 0) {
+            (void)hipSetDevice(devs[0]);
+            rows_all = U.get<double>(ntot * nT); entry_all = U.get<double>(ntot);
+            if (!rows_all || !entry_all) rc = 7;
+        }
+        size_t o = 0;
+        for (int k = 0; k < nseeds && rc == 0; ++k) {
+            PackJob &J = jobs[k];
+            DevBuf &B = scratch[k % devs.size()];
+            if (J.device == devs[0]) { if (!J.scatter(B, rows_all + o * nT, entry_all + o, nullptr)) rc = 7; }
+            else if (J.count > 0) {
+                (void)hipSetDevice(J.device);
+                double *tr = B.get<double>((size_t)J.count * nT), *te = B.get<double>(J.count);
+                if (!tr || !te || !J.scatter(B, tr, te, nullptr)) { rc = 7; break; }
+                if (hipMemcpyPeerAsync(rows_all + o * nT, devs[0], tr, J.device, sizeof(double) * (size_t)J.count * nT, nullptr) != hipSuccess ||
+                    hipMemcpyPeerAsync(entry_all + o, devs[0], te, J.device, sizeof(double) * J.count, nullptr) != hipSuccess) rc = 2;
+            }
+            o += (size_t)J.count;
+        }
+        for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); if (hipDeviceSynchronize() != hipSuccess) rc = rc ? rc : 2; }
+        for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); std::vector<void *> v; v.swap(scratch[d].v); for (void *p : v) (void)hipFree(p); }
+        (void)hipSetDevice(devs[0]);
+        if (rc == 0) rc = pchip_merge_records(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, 1, 1, merged);
+        else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
+    }
     if (rc == 0) { merged->t_runs_s = t_runs; for (int k = 0; k < nseeds; ++k) { merged->nlike += results[k].nlike; merged->ndead_all += results[k].ndead; } }
+    else { for (int k = 0; k < nseeds; ++k) pchip_result_free(&results[k]); }        // (nothing is left for the caller to free on failure)
+    return rc;
+}
+
+// ---- between processes (one per GPU): RCCL inside the library ---------------------------------------------------------
+// The reference's farm exchanges babies with MPI point-to-point messages (mpi_utils.F90:376-463); here the only exchange of
+// a repeat-sharded job is ONE all-gather of the runs' lived records at its end (counts first), over xGMI.
+int pchip_comm_get_id(char *id128)
+{
+    if (!rccl().load()) { std::fprintf(stderr, "polychord_hip: librccl.so not found (PCHIP_RCCL_LIB names it)\n"); return 2; }
+    ncclUniqueId id;
+    const ncclResult_t e = rccl().GetUniqueId(&id);
+    if (e != ncclSuccess) { std::fprintf(stderr, "polychord_hip: ncclGetUniqueId: %s\n", rccl().GetErrorString(e)); return 2; }
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int pchip_comm_create(const char *id128, int nranks, int rank, int device, pchip_comm **out)
+{
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return 1;
+    if (!rccl().load()) { std::fprintf(stderr, "polychord_hip: librccl.so not found (PCHIP_RCCL_LIB names it)\n"); return 2; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { std::fprintf(stderr, "polychord_hip: comm: device %d of %d\n", device, ndev); return 2; }
+    if (hipSetDevice(device) != hipSuccess) return 2;
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    pchip_comm *c = new pchip_comm;
+    c->nranks = nranks; c->rank = rank; c->device = device;
+    const ncclResult_t e = rccl().CommInitRank(&c->comm, nranks, id, rank);
+    if (e != ncclSuccess) { std::fprintf(stderr, "polychord_hip: ncclCommInitRank: %s\n", rccl().GetErrorString(e)); delete c; return 2; }
+    *out = c;
+    return 0;
+}
+
+void pchip_comm_destroy(pchip_comm *c)
+{
+    if (!c) return;
+    if (c->comm) { (void)hipSetDevice(c->device); (void)rccl().CommDestroy(c->comm); }
+    delete c;
+}
+
+const char *pchip_comm_library(void) { return rccl().load() ? rccl().where.c_str() : nullptr; }
+
+int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int nDims, int nDerived, int want_rows, pchip_merged *out)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    std::memset(out, 0, sizeof(*out));
+    const int R = c ? c->nranks : 1, nT = 2 * nDims + nDerived + 2;
+    if (run->ndead > 0 && run->nTotal != nT) { std::fprintf(stderr, "polychord_hip: comm merge: the run's rows have %d columns, not %d\n", run->nTotal, nT); return 1; }
+    int device = 0;
+    if (c) device = c->device; else if (hipGetDevice(&device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
+    if (hipSetDevice(device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
+    hipStream_t st = nullptr;
+    DevBuf B;
+    auto fail = [&](const char *what, int code) { std::fprintf(stderr, "polychord_hip: comm merge: %s (%s)\n", what, hipGetErrorString(hipGetLastError())); return code; };
+    auto nfail = [&](const char *what, ncclResult_t e) { std::fprintf(stderr, "polychord_hip: comm merge: %s: %s\n", what, rccl().GetErrorString(e)); return 2; };
+    PackJob J;
+    J.r = run; J.logzero = logzero; J.device = device;
+    if (!J.count_records(B, st)) return fail("packing the run's records", 7);
+    // counts (and the runs' totals) of every rank
+    std::vector<long long> meta((size_t)3 * R, 0);
+    meta[0] = J.count; meta[1] = run->nlike; meta[2] = run->ndead;
+    if (c && c->comm) {
+        long long *d_meta = B.get<long long>((size_t)3 * (R + 1));
+        if (!d_meta) return fail("out of device memory", 7);
+        if (hipMemcpyAsync(d_meta, meta.data(), sizeof(long long) * 3, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
+        const ncclResult_t e = rccl().AllGather(d_meta, d_meta + 3, 3, ncclInt64, c->comm, st);
+        if (e != ncclSuccess) return nfail("ncclAllGather (counts)", e);
+        if (hipMemcpyAsync(meta.data(), d_meta + 3, sizeof(long long) * 3 * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("counts", 2);
+    }
+    std::vector<long> counts(R);
+    std::vector<long long> off(R + 1, 0);
+    long long nmax = 1, nlike = 0, ndead_all = 0;
+    for (int q = 0; q < R; ++q) { counts[q] = (long)meta[(size_t)3 * q]; off[q + 1] = off[q] + counts[q]; nmax = std::max(nmax, meta[(size_t)3 * q]); nlike += meta[(size_t)3 * q + 1]; ndead_all += meta[(size_t)3 * q + 2]; }
+    const size_t per = (size_t)nmax * (nT + 1);                 // one rank's block: rows [nmax][nT], then entry [nmax]
+    double *send = B.get<double>(per);
+    if (!send) return fail("out of device memory", 7);
+    if (!J.scatter(B, send, send + (size_t)nmax * nT, st)) return fail("packing the run's records", 7);
+    const double *rows_all = send, *entry_all = send + (size_t)nmax * nT;
+    if (c && c->comm) {
+        double *recv = B.get<double>(per * R);
+        long long *d_off = B.get<long long>(R + 1);
+        const long long ntot = off[R];
+        double *ra = B.get<double>((size_t)std::max<long long>(ntot, 1) * nT), *ea = B.get<double>(std::max<long long>(ntot, 1));
+        if (!recv || !d_off || !ra || !ea) return fail("out of device memory", 7);
+        const ncclResult_t e = rccl().AllGather(send, recv, per, ncclDouble, c->comm, st);       // the exchange: one padded block per rank over xGMI
+        if (e != ncclSuccess) return nfail("ncclAllGather (records)", e);
+        if (hipMemcpyAsync(d_off, off.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
+        if (ntot > 0) hipLaunchKernelGGL(k_unpad, dim3((unsigned)ntot), dim3(64), 0, st, (const double *)recv, nmax, nT, R, (const long long *)d_off, ra, ea);
+        rows_all = ra; entry_all = ea;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("exchange", 2);
+    const int rc = pchip_merge_records(nDims, nDerived, R, counts.data(), rows_all, entry_all, 1, want_rows, out);
+    if (rc == 0) { out->nlike = (long)nlike; out->ndead_all = (long)ndead_all; out->t_merge_s = std::chrono::duration<double>(clk::now() - t0).count(); }
     return rc;
 }
 

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         }
         marks_sh[0] = Kl; marks_sh[1] = marks;
         const unsigned err = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
-        note_early[0] = (unsigned)status | (err << 8) | ((unsigned)(marks > 0) << 17) | ((unsigned)(marks & 0xFF) << 18);
+        note_early[0] = (unsigned)status | (err << 8) | ((unsigned)(marks > 0) << 17) | ((unsigned)(marks > 0x3FFF ? 0x3FFF : marks) << 18);
         note_early[1] = (unsigned)(T - ts); note_early[2] = (unsigned)(ndead0 + vps);
         note_early[3] = (unsigned)(S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr);
         note_early[4] = 1u | ((unsigned)(ctl->ncluster_dead & 0xFFFF) << 16);

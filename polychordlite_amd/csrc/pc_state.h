@@ -182,9 +182,9 @@ __device__ __forceinline__ void pc_publish_ctl(const PcState &S)
     if (threadIdx.x == 0) {
         const PcCtl *c = S.ctl;
         pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16) |
-                        ((unsigned)(c->upd_pending != 0) << 17) | ((unsigned)(c->upd_marks & 0xFF) << 18);
+                        ((unsigned)(c->upd_pending != 0) << 17) | ((unsigned)(c->upd_marks > 0x3FFF ? 0x3FFF : c->upd_marks) << 18);   // (a launch consumes <= 1024 chains: <= 1024 marks)
         pc_note_sh[1] = (unsigned)c->i_nursery; pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
-        pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (the full count comes with the block)
+        pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (ncluster <= 16384: Engine::grow_clusters; the full dead count comes with the block)
     }
     __syncthreads();
     if (threadIdx.x < PC_NOTE_WORDS)

@@ -19,6 +19,7 @@
 // mean (the cube centre at first), which the new mean is within a fraction of a standard deviation of, so the
 // subtraction cov = M2/n - delta delta^T loses a digit at most, not the six it would lose about the origin.
 #include "pc_state.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -574,10 +575,11 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
         hipLaunchKernelGGL(k_upd_scan, dim3(1), dim3(1024), 0, st, blk, nblk, d_total);
         hipLaunchKernelGGL(k_upd_index, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, (int *)phC2);
     }
+    int devi = 0; (void)hipGetDevice(&devi); devi &= 63;
 #define UPDG_LAUNCH(NT) { \
-        static bool done_##NT = false; \
-        if (!done_##NT) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); \
-                          (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT = true; } \
+        static std::atomic<size_t> done_##NT[64];      /* largest size asked for so far, per device (shw grows with D inside one NT) */ \
+        if (shw > done_##NT[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); \
+                          (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT[devi].store(shw); } \
         /* pool mode: the alternate id buffer is free between compactions and holds the index list, *d_total its length */ \
         if (S->pool) hipLaunchKernelGGL((k_upd_gather<NT, true>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
                            ph2, phL2, phC2, phU2, (const int *)phC2, (const int *)d_total, (const double *)shift, part, E, deferred, nlb, ndb); \
@@ -592,8 +594,8 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     double *ncov = part2 + (size_t)ng * E;
     int *count = (int *)(ncov + (size_t)D * D);
     const size_t shf = sizeof(double) * (size_t)(D * (D + 1) / 2 + D + 1);
-    static size_t donef = 0;
-    if (shf > donef) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef = shf; }
+    static std::atomic<size_t> donef[64];
+    if (shf > donef[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef[devi].store(shf); }
     hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
     pc_launch_chol_only(S, ncov, count, st);
 }

@@ -3,10 +3,14 @@
 Every rank runs an independent nested-sampling run (own seed) on its own MI355X.  The runs are statistically
 combinable: gather the dead points of every run -- the full rows (cube, theta, phi, birth, logL) and the contour at
 which each point entered its live set -- and the union is a nested-sampling run with n(L) = sum of the runs' live
-points.  Between processes the gather is ONE padded RCCL all-gather over xGMI (torch.distributed backend "nccl": counts
-first, then rows; `gloo` on CPU in the tests); the merge itself -- evidence recursion of run_time_info.f90:211-296 and
-:652-678 over the merged death sequence, posterior weights and moments -- runs on the device in the library
-(pchip_merge_records, csrc/pc_merge.hip).  There is no CPU merge in the product: without a HIP device it fails loudly.
+points.  Between processes the gather is ONE padded RCCL all-gather over xGMI (counts first, then rows), made INSIDE the
+library (pchip_comm_merge, csrc/pc_merge.hip: librccl.so resolved with dlopen, the lived records picked on the device,
+ncclAllGather, device merge); `Comm` below is its handle, and the only thing it needs from the launcher is a way to hand
+128 bytes from rank 0 to the others (here: the torch.distributed store the ranks were started with).  The merge itself
+-- evidence recursion of run_time_info.f90:211-296 and :652-678 over the merged death sequence, posterior weights and
+moments -- runs on the device (pchip_merge_records).  `gather_records` is the same exchange on torch tensors: the CPU /
+gloo transport of the tests (two ranks that share one GPU cannot form an RCCL communicator).  There is no CPU merge in
+the product: without a HIP device it fails loudly.
 """
 import ctypes as C
 
@@ -32,28 +36,46 @@ def _lib():
         lib.pchip_merged_free.restype = None
         lib.pchip_merged_write.argtypes = [C.POINTER(Merged), C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         lib.pchip_merged_write.restype = C.c_int
+        lib.pchip_comm_get_id.argtypes = [C.c_char_p]
+        lib.pchip_comm_get_id.restype = C.c_int
+        lib.pchip_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.pchip_comm_create.restype = C.c_int
+        lib.pchip_comm_destroy.argtypes = [C.c_void_p]
+        lib.pchip_comm_destroy.restype = None
+        lib.pchip_comm_merge.argtypes = [C.c_void_p, C.POINTER(api.Result), C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Merged)]
+        lib.pchip_comm_merge.restype = C.c_int
+        lib.pchip_comm_library.argtypes = []
+        lib.pchip_comm_library.restype = C.c_char_p
         lib._merge_bound = True
     return lib
 
 
-def lived_records(run):
+def _logzero(run, logzero):
+    """the run's own logzero (settings.logzero travels with the result dict); -1e30 is the reference's default"""
+    if logzero is not None:
+        return float(logzero)
+    return float(run.get("logzero", -1e30))
+
+
+def lived_records(run, logzero=None):
     """(rows, entry) of the points that entered the live set, in the order they died (failed spawns carry logweight =
-    logzero and are no part of the run's death sequence).  entry = the contour when the point joined the live set, not
-    the birth column: with B > 1 chains per nursery a baby is born under an older contour than the one it replaces a
-    point at."""
+    logzero and are no part of the run's death sequence: the same test as the library's, logweight > logzero).  entry =
+    the contour when the point joined the live set, not the birth column: with B > 1 chains per nursery a baby is born
+    under an older contour than the one it replaces a point at."""
     dead, lw = run["dead"], run["logweights"]
-    keep = lw > -1e29
+    keep = lw > _logzero(run, logzero)
     entry = run["entry"] if "entry" in run else dead[:, -2]
     return np.ascontiguousarray(dead[keep]), np.ascontiguousarray(entry[keep])
 
 
 def merged_dict(m, nDims, nDerived, want_rows):
     n, nT, nP = m.n, m.nTotal, nDims + nDerived
+    arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(k,)).copy() if (k > 0 and bool(p)) else np.zeros(0, dtype=dt)   # (a union without records has no arrays)
     out = {"n_runs": m.nruns, "logZ": m.logZ, "varlogZ": m.varlogZ, "logZerr": float(np.sqrt(abs(m.varlogZ))), "records": int(n),
            "post_mean": np.ctypeslib.as_array(m.post_mean, shape=(nP,)).copy(),
            "post_var": np.ctypeslib.as_array(m.post_var, shape=(nP,)).copy(),
-           "logweights": np.ctypeslib.as_array(m.logweights, shape=(max(n, 1),))[:n].copy(),
-           "nlive": np.ctypeslib.as_array(m.nlive, shape=(max(n, 1),))[:n].copy(),
+           "logweights": arr(m.logweights, n, np.float64),
+           "nlive": arr(m.nlive, n, np.int32),
            "t_merge_s": m.t_merge_s, "t_runs_s": m.t_runs_s, "nlike": int(m.nlike), "ndead_all": int(m.ndead_all)}
     if want_rows and n > 0:
         out["rows"] = np.ctypeslib.as_array(m.rows, shape=(n, nT)).copy()
@@ -84,17 +106,72 @@ def merge_records(nDims, nDerived, counts, rows, entry, on_device=False, want_ro
         lib.pchip_merged_free(C.byref(m))
 
 
-def gather_records(run, dist, torch, device):
-    """all-gather of the lived records of every rank: counts first, then ONE padded [nmax][nTotal + 1] buffer per rank
-    (rows | entry contour).  Returns (gathered [sum counts][nTotal + 1] tensor on `device`, counts).  dist = None: this
-    rank's records alone."""
-    # the run's arrays go to the device whole (views of the engine's pinned result buffers: one DMA each) and the points that
-    # lived are picked there -- a boolean-mask copy of 30 MB on the host cost more than the merge itself
-    dead = torch.from_numpy(run["dead"]).to(device, non_blocking=True)
-    lw = torch.from_numpy(run["logweights"]).to(device, non_blocking=True)
-    entry = (torch.from_numpy(run["entry"]) if "entry" in run else torch.from_numpy(run["dead"][:, -2].copy())).to(device, non_blocking=True)
-    keep = lw > -1e29
-    rec = torch.cat([dead[keep], entry[keep][:, None]], dim=1)
+class Comm:
+    """RCCL communicator of the library (pchip_comm_*): one rank per GPU.  `exchange(id_bytes_or_None) -> id_bytes` hands
+    rank 0's 128 bytes to everybody (default: torch.distributed's object broadcast over whatever backend the ranks were
+    started with -- control plane only; the records travel over RCCL inside the library)."""
+
+    def __init__(self, rank, world, device, exchange=None):
+        lib = _lib()
+        self.lib, self.rank, self.world, self.device, self.h = lib, rank, world, device, C.c_void_p()
+        ident = C.create_string_buffer(128)
+        if rank == 0 and lib.pchip_comm_get_id(ident) != 0:
+            raise RuntimeError("pchip_comm_get_id failed (librccl.so not loadable?)")
+        if exchange is None:
+            import torch.distributed as dist
+
+            def exchange(b):
+                box = [b]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+        raw = exchange(ident.raw if rank == 0 else None) if world > 1 else ident.raw
+        if lib.pchip_comm_create(raw, world, rank, device, C.byref(self.h)) != 0:
+            raise RuntimeError("pchip_comm_create failed")
+
+    @property
+    def library(self):
+        p = self.lib.pchip_comm_library()
+        return p.decode() if p else None
+
+    def close(self):
+        if self.h:
+            self.lib.pchip_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_merge(run, comm, nDims, nDerived, want_rows=False, write=None, logzero=None):
+    """this rank's run + everybody else's -> the merged result, all inside the library: records picked on the device,
+    all-gathered over RCCL (comm = None: this process alone), merged on every rank (like an all-reduce)."""
+    lib = _lib()
+    own = run.get("_owner")
+    if own is None:
+        raise ValueError("comm_merge needs a result of _ctypes_api.run (the pchip_result travels with it)")
+    m = Merged()
+    want = 1 if (want_rows or write) else 0
+    rc = lib.pchip_comm_merge(comm.h if comm is not None else None, C.byref(own.res), _logzero(run, logzero), nDims, nDerived, want, C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"pchip_comm_merge failed with code {rc}")
+    try:
+        if write:
+            if lib.pchip_merged_write(C.byref(m), nDims, nDerived, str(write[0]).encode(), str(write[1]).encode()) != 0:
+                raise RuntimeError("pchip_merged_write failed")
+        return merged_dict(m, nDims, nDerived, want_rows)
+    finally:
+        lib.pchip_merged_free(C.byref(m))
+
+
+def gather_records(run, dist, torch, device, logzero=None):
+    """The exchange on torch tensors (tests: gloo between ranks that share a GPU, or CPU only): counts first, then ONE padded
+    [nmax][nTotal + 1] buffer per rank (rows | entry contour).  Returns (gathered [sum counts][nTotal + 1] tensor on
+    `device`, counts).  dist = None: this rank's records alone.  The product path between GPUs is comm_merge."""
+    rows, entry = lived_records(run, logzero)
+    rec = torch.cat([torch.from_numpy(rows), torch.from_numpy(entry)[:, None]], dim=1).to(device)
     if dist is None:
         return rec.contiguous(), [int(rec.shape[0])]
     world = dist.get_world_size()
@@ -106,21 +183,10 @@ def gather_records(run, dist, torch, device):
     pad = torch.zeros((nmax, rec.shape[1]), dtype=torch.float64, device=device)
     pad[:rec.shape[0]] = rec
     bufs = torch.empty((world * nmax, rec.shape[1]), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(bufs, pad)               # RCCL all-gather over xGMI (gloo: same call on CPU tensors)
+    dist.all_gather_into_tensor(bufs, pad)
     return torch.cat([bufs[r * nmax:r * nmax + k] for r, k in enumerate(ks)]).contiguous(), ks
 
 
-def merge_runs(run, dist, torch, local_rank, nDims, nDerived, want_rows=False, write=None):
-    """this rank's run + everybody else's -> the merged result (every rank computes it, like an all-reduce)."""
-    on_gpu = torch is not None and torch.cuda.is_available()
-    if not on_gpu:
-        if dist is not None:
-            raise RuntimeError("merge_runs between processes needs the GPUs (backend nccl); gather_records is the part that also runs on gloo")
-        rows, entry = lived_records(run)
-        return merge_records(nDims, nDerived, [rows.shape[0]], rows, entry, want_rows=want_rows, write=write)
-    dev = torch.device("cuda", local_rank)
-    g, ks = gather_records(run, dist, torch, dev)
-    nT = g.shape[1] - 1
-    rows = g[:, :nT].contiguous(); entry = g[:, nT].contiguous()
-    torch.cuda.synchronize(dev)
-    return merge_records(nDims, nDerived, ks, rows.data_ptr(), entry.data_ptr(), on_device=True, want_rows=want_rows, write=write)
+def merge_runs(run, comm, nDims, nDerived, want_rows=False, write=None):
+    """this rank's run (+ the other ranks' through `comm`) -> the merged result; what bench.py calls once per job"""
+    return comm_merge(run, comm, nDims, nDerived, want_rows=want_rows, write=write)

@@ -121,7 +121,7 @@ def test_c3_full_runs_against_the_reference_binary(engine, golden):
     truth = -23.263
     sem = np.sqrt(z.var(ddof=1) / z.size + zr.var(ddof=1) / zr.size)
     assert abs(z.mean() - zr.mean()) < 3.0 * sem, (z.mean(), zr.mean(), sem)
-    assert abs(z.mean() - truth) < 3.0 * max(z.std(ddof=1) / np.sqrt(z.size), np.mean(errs) / np.sqrt(z.size)) + 0.25, (z.mean(), z.std(ddof=1))
+    assert abs(z.mean() - truth) < 3.0 * max(z.std(ddof=1) / np.sqrt(z.size), np.mean(errs) / np.sqrt(z.size)), (z.mean(), z.std(ddof=1))
     assert abs(np.mean(errs) / np.mean([r["logZerr"] for r in ref["runs"]]) - 1.0) < 0.15
     assert abs(np.mean(nd) / np.mean([r["ndead"] for r in ref["runs"]]) - 1.0) < 0.05
     assert min(ncl) >= 50, ncl                           # every run resolves dozens of the modes as separate clusters

@@ -196,3 +196,108 @@ def test_run_repeats_front_door_and_files(engine, tmp_path):
     post = np.loadtxt(tmp_path / "u.txt")
     w = post[:, 0]
     assert np.allclose((w[:, None] * post[:, 2:8]).sum(0) / w.sum(), merged["post_mean"][:6], atol=1e-9)
+
+
+WORKER_GPU = r"""
+import os, sys, hashlib
+sys.path.insert(0, sys.argv[1])
+out_dir = sys.argv[2]
+import ctypes as C
+import numpy as np, torch, torch.distributed as dist
+from tests.replay_oracle import replay
+from polychordlite_amd import _ctypes_api as api
+from polychordlite_amd import merge as mg
+from polychordlite_amd.pypolychord.output import PolyChordOutput
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = api.load()
+assert lib.pchip_device_count() >= 1
+D, nDer = 6, 1
+s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+s.nlive, s.num_repeats, s.batch, s.seed, s.device = 150 + 20 * rank, 12, 50, 70 + rank, 0      # both ranks on device 0, ragged record counts
+L, P, keep = api.make_problem("gaussian", D, nDer)
+mine = api.run(s, L, P)                                             # an ENGINE run on this rank
+g, ks = mg.gather_records(mine, dist, torch, torch.device("cpu"))   # counts + one padded all-gather (gloo)
+g = g.numpy()
+rows, entry = np.ascontiguousarray(g[:, :-1]), np.ascontiguousarray(g[:, -1])
+assert ks[rank] == int((mine["logweights"] > s.logzero).sum()) and sum(ks) == g.shape[0] and ks[0] != ks[1]
+m = mg.merge_records(D, nDer, ks, rows, entry, want_rows=True, write=(out_dir, "u%d" % rank))      # device merge, on every rank
+ref = replay(rows[:, -1], entry, rows=rows, p0=D, nP=D + nDer)
+assert abs(m["logZ"] - ref["logZ"]) < 1e-9 and abs(m["varlogZ"] - ref["varlogZ"]) < 1e-9
+assert np.array_equal(m["nlive"], ref["nlive"]) and np.allclose(m["post_mean"], ref["post_mean"], atol=1e-11)
+assert m["n_runs"] == world and m["records"] == g.shape[0]
+assert m["logZerr"] < 0.85 * mine["logZerr"] and abs(m["logZ"]) < 4 * m["logZerr"] + 0.05
+# the library's own single-process path (records picked on the device, no collective) gives this rank's run back
+own = mg.comm_merge(mine, None, D, nDer, want_rows=True)
+r1, e1 = mg.lived_records(mine)
+chk = mg.merge_records(D, nDer, [r1.shape[0]], r1, e1, want_rows=True)
+assert own["records"] == ks[rank] and own["logZ"] == chk["logZ"] and np.array_equal(own["rows"], chk["rows"]) and np.array_equal(own["logweights"], chk["logweights"])
+assert abs(own["logZ"] - mine["logZ"]) < 1e-7
+# every rank holds the identical union and the identical merged result
+dig = (hashlib.sha256(g.tobytes()).hexdigest(), m["logZ"], m["varlogZ"], m["post_mean"].tolist(), hashlib.sha256(m["rows"].tobytes()).hexdigest())
+box = [None] * world
+dist.all_gather_object(box, dig)
+assert all(b == box[0] for b in box), box
+dist.barrier()
+if rank == 0:
+    a, b = PolyChordOutput(out_dir, "u0"), PolyChordOutput(out_dir, "u1")
+    assert a.logZ == b.logZ and abs(a.logZ - m["logZ"]) < 1e-12
+    for suffix in (".stats", "_dead-birth.txt", ".txt"):
+        assert open(os.path.join(out_dir, "u0" + suffix)).read() == open(os.path.join(out_dir, "u1" + suffix)).read(), suffix
+    print("MERGE2_OK", ks, m["logZ"], m["logZerr"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_merge_engine_records(engine, tmp_path):
+    """the N > 1 path with ENGINE runs on a 1-GPU box: two ranks share device 0 (RCCL refuses two ranks on one GPU, so
+    the records travel over gloo), each merges the union on the device; both must hold the same union, the merged
+    evidence must equal the numpy checker's, and the merged files must be identical"""
+    script = tmp_path / "worker_gpu.py"
+    script.write_text(WORKER_GPU)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", str(script), ROOT, str(tmp_path)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert "MERGE2_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_library_rccl_exchange_one_rank(engine):
+    """pchip_comm_*: librccl.so resolved by the library itself, a communicator of one rank, the run's records through
+    ncclAllGather (counts, then the padded block) and the un-padding kernel -- the result must be the plain device merge
+    of the same records, bit for bit"""
+    from polychordlite_amd import merge as mg
+    s, L, P, keep, runs = _engine_runs(engine, [31], nlive=120)
+    run = runs[0]
+    comm = mg.Comm(0, 1, 0)
+    try:
+        assert comm.library and "rccl" in comm.library
+        a = mg.comm_merge(run, comm, 6, 1, want_rows=True)
+    finally:
+        comm.close()
+    r1, e1 = mg.lived_records(run)
+    b = mg.merge_records(6, 1, [r1.shape[0]], r1, e1, want_rows=True)
+    assert a["records"] == b["records"] == r1.shape[0] and a["n_runs"] == 1
+    assert a["logZ"] == b["logZ"] and a["varlogZ"] == b["varlogZ"]
+    assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["logweights"], b["logweights"]) and np.array_equal(a["nlive"], b["nlive"])
+    assert a["nlike"] == run["nlike"] and a["ndead_all"] == run["ndead"]
+    assert abs(a["logZ"] - run["logZ"]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_lived_records_follow_the_runs_logzero(engine):
+    """failed spawns carry logweight = settings.logzero, whatever it is: with logzero = -1e20 the Python selection and the
+    library's must both drop them (a hard-coded -1e29 kept them and handed the merge a sequence that does not ascend)"""
+    from polychordlite_amd import merge as mg
+    lib = engine.load()
+    s = engine.Settings(); lib.pchip_settings_default(C.byref(s), 6, 1)
+    s.nlive, s.num_repeats, s.batch, s.seed, s.logzero = 150, 12, 75, 5, -1e20
+    L, P, keep = engine.make_problem("gaussian", 6, 1)
+    run = engine.run(s, L, P)
+    assert run["logzero"] == -1e20 and (run["logweights"] <= -1e20).sum() > 0           # this run has failed spawns
+    rows, entry = mg.lived_records(run)
+    assert rows.shape[0] == int((run["logweights"] > -1e20).sum()) and np.all(np.diff(rows[:, -1]) >= 0)
+    a = mg.comm_merge(run, None, 6, 1)
+    assert a["records"] == rows.shape[0] and abs(a["logZ"] - run["logZ"]) < 1e-7
