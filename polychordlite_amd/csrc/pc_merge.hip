@@ -407,7 +407,11 @@ struct Rccl {
         for (int pass = 0; pass < 2 && !h; ++pass)             // first a copy that is already in the process, then from disk
             for (const char *n : names) {
                 if (!n || !*n) continue;
-                h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                // RTLD_LOCAL: with RTLD_GLOBAL the static objects of /opt/rocm's librocm_smi64 (a dependency of RCCL) were torn
+                // down twice at process exit ("free(): invalid pointer" in ~map<amd::smi::DevInfoTypes, ...>, rc 134)
+                int fl = RTLD_NOW | RTLD_LOCAL;
+                if (const char *e = std::getenv("PCHIP_RCCL_DLOPEN")) { if (std::strstr(e, "global")) fl = RTLD_NOW | RTLD_GLOBAL; }   // (developer switch)
+                h = dlopen(n, fl | (pass == 0 ? RTLD_NOLOAD : 0));
                 if (h) { where = n; break; }
             }
         if (!h) return false;
