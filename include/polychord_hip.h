@@ -123,7 +123,8 @@ typedef struct {
     int force_general;  /* 1: always use the general contraction kernel (tests) */
     int ablate;         /* developer / test switches, 0 = product: bit 0 = built-in quadratic likelihoods evaluated like a general functor;
                            bits 1, 2, 3 = no pool mode, no deferred update, no fused update (identical results by the older kernels);
-                           bit 4 = evidence prefixes of the parallel contraction by pair scans only */
+                           bit 4 = evidence prefixes of the parallel contraction by pair scans only; bit 5 = several clusters: every
+                           launch by the general contraction kernel (no one-wave kernel) */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

@@ -39,6 +39,8 @@ int pc_par_fits(const PcState *);
 int pc_launch_sort_live(const PcState *, hipStream_t);
 int pc_launch_consume_par(const PcState *, hipStream_t);
 int pc_launch_final_par(const PcState *, hipStream_t);
+int pc_consume_cl_fits(const PcState *, int);
+int pc_launch_consume_cl(const PcState *, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
@@ -1576,6 +1578,13 @@ struct Engine {
                     pc_launch_nn_lists(&S, nursery_left, st);
                     S.nn_valid = 1;
                 }
+                // several clusters, static number of live points, lists in place: the one-wave contraction (pc_clus.hip); everything
+                // else -- and every launch when settings.ablate bit 5 is set -- goes to the general kernel, which is its arbiter
+                static const bool cl_off = std::getenv("PC_CONSUME_CL_OFF") != nullptr;
+                if (static_ok && cfg.force_general == 0 && !cl_off && !(cfg.ablate & 32) && S.nn_valid && !S.seq_mode && h_ctl->ncluster > 1 &&
+                    pc_consume_cl_fits(&S, h_ctl->ncluster)) {
+                    rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_cl(&S, st);
+                } else
                 rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             }
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }

@@ -156,7 +156,8 @@ struct PcState {
                                  // likelihoods are evaluated like any device functor (one reduction per trial) instead of in closed form
                                  // along the chord; bits 1 / 2 / 3 = no pool mode / no deferred update / no fused update (the same numbers
                                  // by the older kernels: tests/test_gpu_parity.py); bit 4 = the parallel contraction's evidence prefixes by pair
-                                 // scans only (no linear-space path); bit 30 = trace of Cholesky fallbacks
+                                 // scans only (no linear-space path); bit 5 = several clusters: the general contraction kernel for every launch (not
+                                 // the one-wave kernel of pc_clus.hip); bit 30 = trace of Cholesky fallbacks
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed

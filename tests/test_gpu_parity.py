@@ -516,3 +516,28 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
             assert g[k] == g0[k], (k, g[k], g0[k])
         assert abs(g["logZ"] - g0["logZ"]) < 1e-11 * max(1.0, abs(g0["logZ"])) and abs(g["logZerr"] - g0["logZerr"]) < 1e-11
         assert np.abs(g["dead"] - g0["dead"]).max() < 1e-9 * max(1.0, np.abs(g0["dead"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,box", [("rastrigin", 4, 0, 400, 12, (-5.12, 5.12)), ("twin_gaussian", 8, 1, 300, 16, (-1.0, 1.0)),
+                                                     ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12))])
+def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, box):
+    """several clusters: the one-wave contraction (pc_clus.hip: deaths from the sorted snapshot, evidence accumulators as
+    (m, s) pairs, one cluster per lane) against the general kernel it replaces (settings.ablate bit 5 sends every launch
+    there) -- the same run: every counter, every dead row, the evidences of all clusters, the live set"""
+    api = engine
+    L, P, keep = api.make_problem(kind, D, nDer, *box)
+    runs = []
+    for ab in (0, 32):
+        s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=21, batch=0, do_clustering=1)
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    a, b = runs
+    assert a["ncluster_peak"] >= 2 and a["ncluster_dead"] >= 2          # clusters were found, and clusters died on the way
+    for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert abs(a["logZ"] - b["logZ"]) < 1e-10 and abs(a["logZerr"] - b["logZerr"]) < 1e-10
+    assert np.array_equal(a["dead"][:, :-2], b["dead"][:, :-2]) and np.array_equal(a["dead"][:, -1], b["dead"][:, -1])
+    assert np.abs(a["logweights"] - b["logweights"]).max() < 1e-9
+    assert np.allclose(a["logZp"], b["logZp"], atol=1e-9) and np.allclose(a["varlogZp"], b["varlogZp"], atol=1e-9)
+    assert np.array_equal(a["live"], b["live"])
