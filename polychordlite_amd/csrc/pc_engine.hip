@@ -40,7 +40,7 @@ int pc_launch_sort_live(const PcState *, hipStream_t);
 int pc_launch_consume_par(const PcState *, hipStream_t);
 int pc_launch_final_par(const PcState *, hipStream_t);
 int pc_consume_cl_fits(const PcState *, int);
-int pc_launch_consume_cl(const PcState *, hipStream_t);
+int pc_launch_consume_cl(const PcState *, int, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
@@ -1583,7 +1583,7 @@ struct Engine {
                 static const bool cl_off = std::getenv("PC_CONSUME_CL_OFF") != nullptr;
                 if (static_ok && cfg.force_general == 0 && !cl_off && !(cfg.ablate & 32) && S.nn_valid && !S.seq_mode && h_ctl->ncluster > 1 &&
                     pc_consume_cl_fits(&S, h_ctl->ncluster)) {
-                    rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_cl(&S, st);
+                    rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
                 } else
                 rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             }
