@@ -109,6 +109,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     __shared__ double ref_d[8];        // launch-wide references: Lhi, lxm0
 
     PcCtl *ctl = S.ctl;
+    const long long t_start = clock64();
     const int T = ctl->i_nursery;                     // chains in the nursery at launch: w = T-1 ... 0
     int nc = ctl->ncluster;
     const int epoch0 = ctl->admin_epoch;
@@ -164,13 +165,21 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     for (int c = tid; c <= S.B; c += CL_NT) { const int sl = c < S.B ? sCS[c] : -1; tag[Ncap + c] = (sl >= 0 && sS[sl].o == c) ? sS[sl].c : -1; }
     {   // The nursery's records and the cross-volume matrix were written by other XCDs: a first touch costs 1-2 us, and the loop
         // would pay that once per chain, serially.  Touch what it will read now, in bulk, so that its loads hit this XCD's L2.
-        auto touch = [&](const void *base, size_t bytes) {
+        auto touch = [&](const void *base, size_t bytes) {           // (eight lines in flight per thread; nothing waits until the end)
             const char *b = (const char *)base;
-            for (size_t o = (size_t)tid * 64; o < bytes; o += (size_t)CL_NT * 64) { const int v = *(const volatile int *)(b + o); asm volatile("" :: "v"(v)); }
+            int acc = 0;
+            for (size_t o0 = (size_t)tid * 64; o0 < bytes; o0 += (size_t)CL_NT * 64 * 8) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const size_t o = o0 + (size_t)u * CL_NT * 64; v[u] = (o < bytes) ? *(const volatile int *)(b + o) : 0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= v[u];
+            }
+            asm volatile("" :: "v"(acc));
         };
         touch(S.baby_logL, sizeof(double) * (size_t)T * nr);
         touch(S.nn_list, sizeof(int) * (size_t)T * nr * PC_NN_K);
-        for (int c = 0; c < nc; ++c) touch(S.XpXq + (size_t)c * maxc, sizeof(double) * (size_t)nc);
+        touch(S.XpXq, sizeof(double) * (size_t)nc * maxc);            // (one sweep: a call per row would wait for each row's miss in turn)
     }
     __syncthreads();
 
@@ -240,7 +249,8 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         };
         prefetch(T - 1);
         const int seg_hi = T - 1;
-        long long cyc0 = clock64(), walks = 0, fallbacks = 0, cyA = 0, cyB = 0, cyC = 0;
+        long long cyc0 = clock64(), walks = 0, fallbacks = 0;
+        if (lane == 0) ctl->gen_cyc[1] += cyc0 - t_start;
 
         while (true) {
             // ---- more_samples_needed (nested_sampling.F90:514-543) + the failures guard (:239)
@@ -252,7 +262,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
             if (i_nursery == 0) break;
             const double Lg = fmin(curL, nmL);
             if (Lg > Lhi) break;                                    // the next death leaves the launch's window: new references (host relaunches)
-            const long long q0 = clock64();
             const int w = i_nursery - 1;
             i_nursery--;
             const double my_blog = pf_blog; const int4 my_a = pf_a, my_b = pf_b;
@@ -321,7 +330,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                 if (pm) { if (lane == 0) masks[(size_t)w * nw + m] = pm; nph_add += __popcll(pm); }
                 if (m == (nr - 1) / 64) id_last = __builtin_amdgcn_readlane(res, (nr - 1) & 63);
             }
-            const long long q1 = clock64(); cyA += q1 - q0;
             if (nph + nph_add > S.Pcap) { status = PC_ST_ERROR; error = PC_ERR_PHANTOM_CAP; break; }
             ClHead hd{};
             hd.dead_idx = -1; hd.ph_base = nph; hd.contour = Lg; hd.ph_cuid = (unsigned)cl_geti<J>((const int (&)[J])uid, ca);
@@ -379,7 +387,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                       hd.dead_idx = ndead; hd.dead_src = (src >= 0) ? -(1 + src) : slot_del; hd.logw = logweight;
                       hd.dead_cuid = (unsigned)cl_geti<J>((const int (&)[J])uid, cd); hd.zl = Zl; }
                     ndead++; any_death = 1;
-                    const long long q2 = clock64(); cyB += q2 - q1;
                     // ---- the order of deaths moves on
                     if (from_snap) {
                         ptr++;
@@ -451,7 +458,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                         for (int j = 0; j < J; ++j) xlin[j] = exp(xr[j] - 2.0 * lxm0);
                     }
                     replaced = true;
-                    cyC += clock64() - q2;
                     if (nd - 1 == 0 && cd != ca) need_drop = 1;                 // a cluster died (delete_cluster): the workgroup takes over
                 }
             } else {
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
             { const double v = acc > 0.0 ? log(acc) + lxm0 + R0 : logzero; out_d[3] = (v > logzero + 800.0) ? v : pc_logaddexp(logzero, v); }
             out_d[4] = rZ;
             ctl->nlike = nlike; ctl->niter = niter; ctl->nlike_failed = nlike_failed;
-            ctl->gen_cyc[0] += clock64() - cyc0; ctl->gen_cyc[1] += cyA; ctl->gen_cyc[2] += cyB; ctl->gen_cyc[3] += cyC; ctl->nn_walks += walks; ctl->nn_fallbacks += fallbacks;
+            ctl->gen_cyc[0] += clock64() - cyc0; ctl->nn_walks += walks; ctl->nn_fallbacks += fallbacks;
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     }
     __syncthreads();
     // ------------------------------------------------------------------ write back (all waves)
+    const long long T0c = clock64();
     int status = out_i[0];
     const int i_nursery = out_i[2], need_drop = out_i[7], seg_hi = out_i[8];
     int epoch = out_i[3];
@@ -519,17 +526,26 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         S.live_logL[s] = sL[s]; S.live_cluster[s] = r.c; S.live_pos[s] = r.p; S.nn_slot_owner[s] = r.o; S.slot_src[s] = r.src;
         if (r.c >= 0) S.cl_list[(size_t)r.c * Ncap + r.p] = s;
     }
+    const long long T1 = clock64(); if (tid == 0) ctl->dbg[0] += T1 - T0c;
     for (int c = tid; c < S.B; c += CL_NT) S.nn_chain_slot[c] = sCS[c];
     for (int c = tid; c < nc; c += CL_NT) {
         const ClOwn o = sOwn[c];
         if (o.touched) { S.logZp[c] = cl_log(o.rzp, o.zp, S.logzero); S.logZp2[c] = cl_log(o.rzp2, o.zp2, S.logzero); S.logZpXp[c] = cl_log(o.rzpx, o.zpx, S.logzero); }
     }
     // the cross-volume matrix picks up the factors of the launch's deaths: X_p X_q *= f_p f_q, X_p^2 *= g_p
-    for (int e = tid; e < nc * nc; e += CL_NT) {
-        const int p = e / nc, q = e % nc;
-        const double add = (p == q) ? Gbuf[p] : Fbuf[p] + Fbuf[q];
-        if (add != 0.0) S.XpXq[(size_t)p * maxc + q] += add;
+    for (int e0 = tid; e0 < nc * nc; e0 += 4 * CL_NT) {               // (four entries in flight per thread: the loads before the stores)
+        double v[4], add[4]; size_t at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * CL_NT; const bool in = e < nc * nc;
+            const int p = in ? e / nc : 0, q = in ? e % nc : 0;
+            at[u] = (size_t)p * maxc + q; add[u] = !in ? 0.0 : ((p == q) ? Gbuf[p] : Fbuf[p] + Fbuf[q]);
+            v[u] = S.XpXq[at[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (add[u] != 0.0) S.XpXq[at[u]] = v[u] + add[u];
     }
+    const long long T2 = clock64(); if (tid == 0) ctl->dbg[1] += T2 - T1;
     // plan records of the chains this launch consumed
     for (int w = i_nursery + tid; w <= seg_hi; w += CL_NT) {
         const ClHead r = sHead[w];
@@ -543,6 +559,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         *(PcPlanHead *)&S.plan[w] = h;
         for (int m = 0; m < nw; ++m) S.plan[w].ph_mask[m] = masks[(size_t)w * nw + m];
     }
+    const long long T3 = clock64(); if (tid == 0) ctl->dbg[2] += T3 - T2;
     // find_min_loglikelihoods (run_time_info.f90:883-909), once: lowest (logL, list position) of every cluster
     for (int c = tid; c < CL_MAXC; c += CL_NT) { kmin[c] = KEY_HUGE; lstOff[c] = 0x7fffffff; }
     __syncthreads();
@@ -553,6 +570,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     for (int s = tid; s < Ncap; s += CL_NT) { const ClSlot r = sS[s]; if (r.c >= 0 && d2key(sL[s]) == kmin[r.c] && r.p == lstOff[r.c]) { S.imin_slot[r.c] = s; S.logLp[r.c] = sL[s]; } }
     for (int c = tid; c < nc; c += CL_NT) if (kmin[c] == KEY_HUGE) { S.imin_slot[c] = -1; S.logLp[c] = PC_HUGE; }
     __syncthreads();
+    const long long T4 = clock64(); if (tid == 0) ctl->dbg[3] += T4 - T3;
     int ncd = ctl->ncluster_dead, cluster_deleted = 0;
     if (need_drop) {
         // delete_cluster (run_time_info.f90:507-598): drop the first empty cluster, keep the others' order
@@ -564,22 +582,49 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
             if (tid == 0 && ncd < S.maxc_dead) { S.logZp_dead[ncd] = S.logZp[p]; S.logZp2_dead[ncd] = S.logZp2[p]; S.cl_uid_dead[ncd] = S.cl_uid[p]; }
             __syncthreads();
             ncd++;
-            if (tid == 0) {
-                for (int a = 0, na = 0; a < nc; ++a) {
-                    if (a == p) continue;
-                    for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; S.XpXq[(size_t)na * maxc + nb] = S.XpXq[(size_t)a * maxc + b]; nb++; }
-                    na++;
+            // Everything moves up by one cluster, in place: every thread takes its share of the sources into registers, the
+            // workgroup meets, then the stores (a thread that walks the arrays alone pays a memory round trip per element: 2 ms for
+            // the cross-volume matrix of 70 clusters, a hundred times per run)
+            {
+                const int m1 = nc - 1;
+                double v[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+                    const int e = tid + u * CL_NT;
+                    if (e < m1 * m1) { const int na = e / m1, nb = e % m1; v[u] = S.XpXq[(size_t)(na + (na >= p)) * maxc + nb + (nb >= p)]; }
                 }
-                for (int c = p; c < nc - 1; ++c) {
-                    S.logLp[c] = S.logLp[c + 1]; S.logXp[c] = S.logXp[c + 1]; S.logZp[c] = S.logZp[c + 1]; S.logZXp[c] = S.logZXp[c + 1];
-                    S.logZp2[c] = S.logZp2[c + 1]; S.logZpXp[c] = S.logZpXp[c + 1]; S.lse_ref[c] = S.lse_ref[c + 1]; S.lse_sum[c] = S.lse_sum[c + 1];
-                    S.death_thr[c] = S.death_thr[c + 1]; S.cl_n[c] = S.cl_n[c + 1]; S.imin_slot[c] = S.imin_slot[c + 1]; S.cl_uid[c] = S.cl_uid[c + 1];
+                double t[9]; int ti[2]; unsigned tu = 0u;
+                const int c = p + tid;
+                if (c < m1) {
+                    t[0] = S.logLp[c + 1]; t[1] = S.logXp[c + 1]; t[2] = S.logZp[c + 1]; t[3] = S.logZXp[c + 1]; t[4] = S.logZp2[c + 1]; t[5] = S.logZpXp[c + 1];
+                    t[6] = S.lse_ref[c + 1]; t[7] = S.lse_sum[c + 1]; t[8] = S.death_thr[c + 1]; ti[0] = S.cl_n[c + 1]; ti[1] = S.imin_slot[c + 1]; tu = S.cl_uid[c + 1];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+                    const int e = tid + u * CL_NT;
+                    if (e < m1 * m1) S.XpXq[(size_t)(e / m1) * maxc + e % m1] = v[u];
+                }
+                if (c < m1) {
+                    S.logLp[c] = t[0]; S.logXp[c] = t[1]; S.logZp[c] = t[2]; S.logZXp[c] = t[3]; S.logZp2[c] = t[4]; S.logZpXp[c] = t[5];
+                    S.lse_ref[c] = t[6]; S.lse_sum[c] = t[7]; S.death_thr[c] = t[8]; S.cl_n[c] = ti[0]; S.imin_slot[c] = ti[1]; S.cl_uid[c] = tu;
                 }
             }
-            const int DD = D * D;
-            for (int c = p; c < nc - 1; ++c) {
-                for (int e = tid; e < DD; e += CL_NT) { S.chol[(size_t)c * DD + e] = S.chol[(size_t)(c + 1) * DD + e]; S.cov[(size_t)c * DD + e] = S.cov[(size_t)(c + 1) * DD + e]; }
-                __syncthreads();
+            {   // Cholesky factors and covariance matrices: groups of clusters whose elements fit sixteen to a thread
+                const int DD = D * D;
+                int G = (16 * CL_NT) / DD; if (G < 1) G = 1;
+                for (int c0 = p; c0 < nc - 1; c0 += G) {
+                    const int g = (nc - 1 - c0 < G) ? nc - 1 - c0 : G, tot = g * DD;
+                    for (int e0 = 0; e0 < tot; e0 += 16 * CL_NT) {               // (one pass unless a single matrix exceeds the share)
+                        double a[16], b[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { const int e = e0 + tid + u * CL_NT; if (e < tot) { a[u] = S.chol[(size_t)(c0 + 1) * DD + e]; b[u] = S.cov[(size_t)(c0 + 1) * DD + e]; } }
+                        __syncthreads();
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { const int e = e0 + tid + u * CL_NT; if (e < tot) { S.chol[(size_t)c0 * DD + e] = a[u]; S.cov[(size_t)c0 * DD + e] = b[u]; } }
+                        if (tot > 16 * CL_NT) __syncthreads();                   // (the next pass reads what this one's neighbours write)
+                    }
+                }
             }
             for (int s = tid; s < Ncap; s += CL_NT) if (sS[s].c > p) { sS[s].c -= 1; S.live_cluster[s] = sS[s].c; }
             __syncthreads();
@@ -596,6 +641,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         ctl->logZ = out_d[0]; ctl->logZ2 = out_d[1]; ctl->logX_last_update = out_d[2]; ctl->live_logZ = out_d[3];
     }
     __syncthreads();
+    if (tid == 0) ctl->gen_cyc[3] += clock64() - t_start;            // (developer counters: staging, loop, whole kernel)
     pc_publish_ctl(S);
 }
 
