@@ -21,13 +21,13 @@
 // (run_time_info.f90:458-503) are driven from the host (pc_engine.hip); they touch a few integers.
 #include "pc_state.h"
 
-__global__ __launch_bounds__(256) void k_similarity(PcState S, const int *pts /* slots in list order */, int n, double *Sm)
+__device__ __forceinline__ void similarity_body(const PcState &S, const int *pts /* slots in list order */, int n, double *Sm, int ybase, int ystride)
 {
     const int a = blockIdx.x, D = S.D;
     const double *xa = S.live + (size_t)pts[a] * S.nT;
     double ra = 0.0;
     for (int d = 0; d < D; ++d) ra = __dadd_rn(ra, __dmul_rn(xa[d], xa[d]));
-    for (int b = blockIdx.y * 256 + threadIdx.x; b < n; b += gridDim.y * 256) {
+    for (int b = ybase + threadIdx.x; b < n; b += ystride) {
         const double *xb = S.live + (size_t)pts[b] * S.nT;
         double rb = 0.0, s = 0.0;
         for (int d = 0; d < D; ++d) { rb = __dadd_rn(rb, __dmul_rn(xb[d], xb[d])); s = __dadd_rn(s, __dmul_rn(xa[d], xb[d])); }
@@ -35,15 +35,31 @@ __global__ __launch_bounds__(256) void k_similarity(PcState S, const int *pts /*
     }
 }
 
+__global__ __launch_bounds__(256) void k_similarity(PcState S, const int *pts, int n, double *Sm)
+{
+    similarity_body(S, pts, n, Sm, blockIdx.y * 256, gridDim.y * 256);
+}
+// One descriptor per cluster that is looked at in an update: {cluster, points, offset of its n x n blocks, offset of its labels}.
+// The first pass of do_clustering (clustering.f90:253-324) over ALL clusters of an update is three launches with the cluster
+// in blockIdx.y instead of three launches and two host round trips per cluster (70 clusters, 130 updates per run at
+// BASELINE configs[2]); only a cluster in which the pass finds a split goes through the per-cluster path, with its recursion.
+struct ClusDesc { int c, n, off2, off1; };
+__global__ __launch_bounds__(256) void k_similarity_b(PcState S, const ClusDesc *desc, double *Sm)
+{
+    const ClusDesc d = desc[blockIdx.y];
+    if ((int)blockIdx.x >= d.n) return;
+    similarity_body(S, S.cl_list + (size_t)d.c * S.Ncap, d.n, Sm + d.off2, 0, 256);
+}
+
 // rows of the sub-matrix S(gidx, gidx) sorted by (distance, local index): knn[a*m + r] = r-th neighbour
-__global__ __launch_bounds__(256) void k_knn_sort(const double *Sm, int nroot, const int *gidx, int m, int npow2, int *knn)
+__device__ __forceinline__ void knn_sort_body(const double *Sm, int nroot, const int *gidx /* null: identity */, int m, int npow2, int *knn)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *kv = (double *)smem;
     int *ki = (int *)(kv + npow2);
     const int a = blockIdx.x, tid = threadIdx.x;
-    const double *row = Sm + (size_t)gidx[a] * nroot;
-    for (int i = tid; i < npow2; i += 256) { kv[i] = (i < m) ? row[gidx[i]] : PC_HUGE; ki[i] = (i < m) ? i : 0x7fffffff; }
+    const double *row = Sm + (size_t)(gidx ? gidx[a] : a) * nroot;
+    for (int i = tid; i < npow2; i += 256) { kv[i] = (i < m) ? row[gidx ? gidx[i] : i] : PC_HUGE; ki[i] = (i < m) ? i : 0x7fffffff; }
     __syncthreads();
     for (int k = 2; k <= npow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -60,9 +76,21 @@ __global__ __launch_bounds__(256) void k_knn_sort(const double *Sm, int nroot, c
         }
     for (int i = tid; i < m; i += 256) knn[(size_t)a * m + i] = ki[i];
 }
+__global__ __launch_bounds__(256) void k_knn_sort(const double *Sm, int nroot, const int *gidx, int m, int npow2, int *knn)
+{
+    knn_sort_body(Sm, nroot, gidx, m, npow2, knn);
+}
+__global__ __launch_bounds__(256) void k_knn_sort_b(const double *Sm, const ClusDesc *desc, int *knn)
+{
+    const ClusDesc d = desc[blockIdx.y];
+    if ((int)blockIdx.x >= d.n) return;
+    int npow2 = 2;
+    while (npow2 < d.n) npow2 <<= 1;
+    knn_sort_body(Sm + d.off2, d.n, nullptr, d.n, npow2, knn + d.off2);
+}
 
 // NN_clustering main loop for one point set (no recursion).  out[0] = number of clusters.
-__global__ __launch_bounds__(1024) void k_nn_cluster(const int *knn, int m, int *labels_out, int *out)
+__device__ __forceinline__ void nn_cluster_body(const int *knn, int m, int *labels_out, int *out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lab = (int *)smem;          // [m] component label (min index), then 1-based cluster label
@@ -145,6 +173,15 @@ __global__ __launch_bounds__(1024) void k_nn_cluster(const int *knn, int m, int 
     }
     if (tid == 0) { out[0] = num; sh_num = num; }
 }
+__global__ __launch_bounds__(1024) void k_nn_cluster(const int *knn, int m, int *labels_out, int *out)
+{
+    nn_cluster_body(knn, m, labels_out, out);
+}
+__global__ __launch_bounds__(1024) void k_nn_cluster_b(const int *knn, const ClusDesc *desc, int *labels, int *out)
+{
+    const ClusDesc d = desc[blockIdx.x];
+    nn_cluster_body(knn + d.off2, d.n, labels + d.off1, out + blockIdx.x);
+}
 
 // cl_list / cl_n from the (cluster, position) labels of every slot
 __global__ __launch_bounds__(256) void k_rebuild_lists(PcState S, int nc)
@@ -193,33 +230,57 @@ __global__ __launch_bounds__(256) void k_cluster_stats(PcState S)
 }
 
 // every phantom goes to the cluster of its nearest live point and survives only above that cluster's
-// contour (run_time_info.f90:444-453); one wavefront per phantom
-__global__ __launch_bounds__(64) void k_ph_rehome(PcState S, int nph, int nc, const unsigned *old_uids, int nold_uids)
+// contour (run_time_info.f90:444-453).  A workgroup takes 64 phantoms, four threads each; the live points pass through an
+// LDS tile of 64 (a wave per phantom reading the live set from L2 took 0.6 ms per split at 20 k phantoms x 1000 points)
+#define PHR_P 64
+#define PHR_T 64
+__global__ __launch_bounds__(256) void k_ph_rehome(PcState S, int nph, int nc, const unsigned *old_uids, int nold_uids)
 {
-    const int j = blockIdx.x, lane = threadIdx.x;
-    if (j >= nph) return;
-    {   // phantoms of clusters that no longer exist are gone (run_time_info.f90:367-368 saves live clusters only)
-        const unsigned u = S.ph_cuid[j];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, D = S.D, nT = S.nT, Ncap = S.Ncap;
+    const int DP = D | 1;                                  // odd row stride: the four scanners of a phantom and the rows of a tile fall in different banks
+    double *xs = (double *)smem;                           // [PHR_P][DP] phantoms of this block
+    double *ys = xs + (size_t)PHR_P * DP;                  // [PHR_T][DP] tile of live points
+    double *bd = ys + (size_t)PHR_T * DP;                  // [256] partial minima
+    int *ykey = (int *)(bd + 256);                         // [PHR_T] cluster * Ncap + list position, or -1
+    int *bk = ykey + PHR_T;                                // [256]
+    int *alive = bk + 256;                                 // [PHR_P] the phantom's cluster still exists
+    const int j0 = blockIdx.x * PHR_P;
+    for (int e = tid; e < PHR_P * D; e += 256) { const int p = e / D, d = e % D, j = j0 + p; xs[(size_t)p * DP + d] = (j < nph) ? S.phantom[(size_t)j * nT + d] : 0.0; }
+    if (tid < PHR_P) {
+        // phantoms of clusters that no longer exist are gone (run_time_info.f90:367-368 saves live clusters only)
+        const int j = j0 + tid;
         bool ok = false;
-        for (int q = 0; q < nold_uids; ++q) ok |= (old_uids[q] == u);
-        if (!ok) { if (lane == 0) S.ph_cuid[j] = 0xFFFFFFFFu; return; }
+        if (j < nph) { const unsigned u = S.ph_cuid[j]; for (int q = 0; q < nold_uids; ++q) ok |= (old_uids[q] == u); }
+        alive[tid] = ok ? 1 : 0;
     }
-    const double *x = S.phantom + (size_t)j * S.nT;
-    vk_t best{PC_HUGE, 0x7fffffff};
-    for (int s = lane; s < S.Ncap; s += 64) {
-        const int c = S.live_cluster[s];
-        if (c < 0) continue;
-        const double *q = S.live + (size_t)s * S.nT;
-        double d2 = 0.0;
-        for (int d = 0; d < S.D; ++d) { const double t = x[d] - q[d]; d2 += t * t; }
-        best = vk_min(best, vk_t{d2, c * S.Ncap + S.live_pos[s]});
+    const int p = tid >> 2, sc = tid & 3;
+    double best = PC_HUGE; int bkey = 0x7fffffff;
+    for (int t0 = 0; t0 < Ncap; t0 += PHR_T) {
+        __syncthreads();
+        for (int e = tid; e < PHR_T * D; e += 256) { const int q = e / D, d = e % D, s = t0 + q; ys[(size_t)q * DP + d] = (s < Ncap) ? S.live[(size_t)s * nT + d] : 0.0; }
+        if (tid < PHR_T) { const int s = t0 + tid; const int c = (s < Ncap) ? S.live_cluster[s] : -1; ykey[tid] = (c >= 0) ? c * Ncap + S.live_pos[s] : -1; }
+        __syncthreads();
+        const double *x = xs + (size_t)p * DP;
+        for (int q = sc; q < PHR_T; q += 4) {
+            const int key = ykey[q];
+            if (key < 0) continue;
+            const double *y = ys + (size_t)q * DP;
+            double d2 = 0.0;
+            for (int d = 0; d < D; ++d) { const double t = x[d] - y[d]; d2 += t * t; }
+            if (d2 < best || (d2 == best && key < bkey)) { best = d2; bkey = key; }
+        }
     }
-    best = wave_argmin(best);
-    if (lane == 0) {
-        const int c = best.k / S.Ncap;
-        S.ph_cuid[j] = (S.ph_logL[j] > S.logLp[c]) ? S.cl_uid[c] : 0xFFFFFFFFu;
-        (void)nc;
+    bd[tid] = best; bk[tid] = bkey;
+    __syncthreads();
+    if (tid < PHR_P && j0 + tid < nph) {
+        const int j = j0 + tid;
+        double b = bd[4 * tid]; int k = bk[4 * tid];
+        for (int u = 1; u < 4; ++u) { const double v = bd[4 * tid + u]; const int kk = bk[4 * tid + u]; if (v < b || (v == b && kk < k)) { b = v; k = kk; } }
+        if (!alive[tid]) S.ph_cuid[j] = 0xFFFFFFFFu;
+        else { const int c = k / Ncap; S.ph_cuid[j] = (S.ph_logL[j] > S.logLp[c]) ? S.cl_uid[c] : 0xFFFFFFFFu; }
     }
+    (void)nc;
 }
 
 // number of phantoms per cluster uid (fixed order: one workgroup, serial accumulation per cluster)
@@ -259,6 +320,26 @@ int pc_launch_knn_cluster(const double *Sm, int nroot, const int *gidx, int m, i
     return 0;
 }
 
+// first pass over `nd` clusters at once (descriptors on the device, host copy for the grid): out[k] = clusters found in the k-th
+int pc_launch_knn_cluster_batch(const PcState *S, const int *h_desc, const int *d_desc, int nd, double *Sm, int *knn, int *labels, int *out, hipStream_t st)
+{
+    if (nd <= 0) return 0;
+    int nmax = 0;
+    for (int k = 0; k < nd; ++k) nmax = h_desc[4 * k + 1] > nmax ? h_desc[4 * k + 1] : nmax;
+    int npow2 = 2;
+    while (npow2 < nmax) npow2 <<= 1;
+    const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
+    if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
+    static size_t d1 = 0, d2 = 0;
+    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
+    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    const ClusDesc *dd = (const ClusDesc *)d_desc;
+    hipLaunchKernelGGL(k_similarity_b, dim3(nmax, nd), dim3(256), 0, st, *S, dd, Sm);
+    hipLaunchKernelGGL(k_knn_sort_b, dim3(nmax, nd), dim3(256), sh, st, (const double *)Sm, dd, knn);
+    hipLaunchKernelGGL(k_nn_cluster_b, dim3(nd), dim3(1024), sh2, st, (const int *)knn, dd, labels, out);
+    return 0;
+}
+
 void pc_launch_rebuild(const PcState *S, int nc, hipStream_t st)
 {
     const int n = S->Ncap > S->maxc ? S->Ncap : S->maxc;
@@ -268,7 +349,13 @@ void pc_launch_rebuild(const PcState *S, int nc, hipStream_t st)
 
 void pc_launch_ph_rehome(const PcState *S, int nph, int nc, const unsigned *old_uids, int nold_uids, int *counts, hipStream_t st)
 {
-    if (nph > 0) hipLaunchKernelGGL(k_ph_rehome, dim3(nph), dim3(64), 0, st, *S, nph, nc, old_uids, nold_uids);
+    if (nph > 0) {
+        const int DP = S->D | 1;
+        const size_t sh = sizeof(double) * ((size_t)(PHR_P + PHR_T) * DP + 256) + sizeof(int) * (PHR_T + 256 + PHR_P);
+        static size_t done = 0;
+        if (sh > done) { (void)hipFuncSetAttribute((const void *)k_ph_rehome, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+        hipLaunchKernelGGL(k_ph_rehome, dim3((nph + PHR_P - 1) / PHR_P), dim3(256), sh, st, *S, nph, nc, old_uids, nold_uids);
+    }
     hipLaunchKernelGGL(k_ph_count, dim3(nc), dim3(256), 0, st, *S, nph, nc, counts);
 }
 

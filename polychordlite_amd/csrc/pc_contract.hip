@@ -1660,7 +1660,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
     // With the candidate lists the heavy parallel part (the nearest-cluster search) is gone and what is left is barriers
     // and short scans: 256 threads (4 waves) run it 1.4x faster than 1024 (16 waves, 128-VGPR cap).  PC_CONSUME_NT overrides.
     static const int wide_nt = std::getenv("PC_CONSUME_NT") ? std::atoi(std::getenv("PC_CONSUME_NT")) : 256;
-    if (wide && S->nn_valid && wide_nt != 1024) {
+    if (wide && (S->nn_valid || final_mode == 1) && wide_nt != 1024) {
 #define PC_CONSUME_LAUNCH(NTV) { \
             /* the lists make the coordinate cache a fallback: a tile is enough, the LDS goes to the cross-volume matrix */ \
             const int sgl = consume_slots_global(S, NTV); \

@@ -50,6 +50,7 @@ void pc_launch_reset_thresholds(const PcState *, hipStream_t);
 int pc_cov_nchunk(const PcState *, int);
 void pc_launch_similarity(const PcState *, const int *, int, double *, hipStream_t);
 int pc_launch_knn_cluster(const double *, int, const int *, int, int *, int *, int *, hipStream_t);
+int pc_launch_knn_cluster_batch(const PcState *, const int *, const int *, int, double *, int *, int *, int *, hipStream_t);
 void pc_launch_rebuild(const PcState *, int, hipStream_t);
 void pc_launch_ph_rehome(const PcState *, int, int, const unsigned *, int, int *, hipStream_t);
 void pc_launch_slice_tick(const PcState *, unsigned, int, void *, double *, int *, double *, const double *, const double *,
@@ -1017,18 +1018,38 @@ struct Engine {
         ncluster_peak = std::max(ncluster_peak, ncn);
     }
 
-    // do_clustering (clustering.f90:253-324)
+    // do_clustering (clustering.f90:253-324).  First pass: every cluster with more than two points at once (three launches, the
+    // counts down and the verdicts back: two host waits per update); a cluster in which the pass finds more than one group
+    // goes through the per-cluster path with its recursion and add_cluster, in the reference's order
+    int *c_desc = nullptr, *c_bout = nullptr; int c_desc_cap = 0;
     bool do_clustering()
     {
         ensure_cluster_scratch();
         bool found = false;
         const int nold = h_ctl->ncluster;
+        if (c_desc_cap < nold) { dfree(c_desc); dfree(c_bout); c_desc_cap = std::max(2 * nold, 64); c_desc = dalloc<int>((size_t)4 * c_desc_cap); c_bout = dalloc<int>(c_desc_cap); }
+        std::vector<int> cn = dl(S.cl_n, (size_t)nold), desc, verdict(nold, 1);
+        {
+            int o1 = 0; long long o2 = 0;
+            std::vector<int> which;
+            for (int c = 0; c < nold; ++c)
+                if (cn[c] > 2) { desc.push_back(c); desc.push_back(cn[c]); desc.push_back((int)o2); desc.push_back(o1); which.push_back(c); o1 += cn[c]; o2 += (long long)cn[c] * cn[c]; }
+            const int nd = (int)which.size();
+            static const bool batch_off = std::getenv("PC_CLUSTER_BATCH_OFF") != nullptr;
+            if (nd > 0 && !batch_off && o2 <= (long long)c_cap * c_cap) {
+                HIPCHK(hipMemcpyAsync(c_desc, desc.data(), sizeof(int) * desc.size(), hipMemcpyHostToDevice, st));
+                if (pc_launch_knn_cluster_batch(&S, desc.data(), c_desc, nd, c_Sm, c_knn, c_lab, c_bout, st)) engine_fail(PC_RC_LDS, "a cluster too large for the LDS kNN sort");
+                std::vector<int> out(nd);
+                HIPCHK(hipMemcpyAsync(out.data(), c_bout, sizeof(int) * nd, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int k = 0; k < nd; ++k) verdict[which[k]] = out[k];
+            } else for (int c = 0; c < nold; ++c) verdict[c] = cn[c] > 2 ? 2 : 1;      // (no first pass: look at every cluster)
+        }
         int ic = 0;
-        while (ic < nold) {
+        for (int j = 0; j < nold; ++j) {                 // j: the cluster's number when the update began; ic: its number now
             if (ic >= h_ctl->ncluster) break;
-            int n = 0;
-            HIPCHK(hipMemcpy(&n, S.cl_n + ic, sizeof(int), hipMemcpyDeviceToHost));
-            if (n > 2) {
+            const int n = cn[j];
+            if (n > 2 && verdict[j] > 1) {
                 HIPCHK(hipMemcpyAsync(c_pts, S.cl_list + (size_t)ic * S.Ncap, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
                 pc_launch_similarity(&S, c_pts, n, c_Sm, st);
                 std::vector<int> gidx(n), labels;
@@ -1628,7 +1649,7 @@ struct Engine {
         } else if (par_ok && h_ctl->ncluster == 1) {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
-        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, 0, st);
+        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st);   // (several clusters: four waves, a death's jobs side by side)
         // what the results need from the device is requested here, behind the kill-off and before the host waits for it: the
         // posterior moments of theta over the dead points (device reduction, fixed order; the kernels take the count from the
         // control block) and the evidences of the retired clusters -- one wait (read_ctl) instead of four
@@ -1736,6 +1757,7 @@ struct Engine {
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);
         if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
         dfree(upd_part); dfree(upd_shift); upd_part_cap = 0;
+        dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
         dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
