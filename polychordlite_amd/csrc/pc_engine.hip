@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cmath>
 #include <vector>
+#include <memory>
 #include <string>
 #include <chrono>
 #include <algorithm>
@@ -539,17 +540,18 @@ struct Engine {
     // host mirror when it is done.  The row copies of the round (k_apply_*) may still be running when this returns;
     // everything the host enqueues next is ordered behind them by the stream.
     void launch_stamp() { S.notify_seq = ++note_seq; }
-    void wait_ctl()
+    unsigned long ready_spins = 0;
+    // has the round's contraction kernel reported?  (non-blocking; a stream that finished without a stamp is an error)
+    bool round_ready()
     {
         static const bool off = std::getenv("PC_NOTIFY_OFF") != nullptr;
-        if (off || !S.ctl_host) { read_ctl(); return; }
+        if (off || !S.ctl_host) { read_ctl(); return true; }
         const volatile unsigned long long *w = (const volatile unsigned long long *)h_note;
         unsigned long long got[PC_NOTE_WORDS];
-        for (unsigned long spins = 0;; ++spins) {
-            bool all = true;
-            for (int i = 0; i < PC_NOTE_WORDS; ++i) { got[i] = w[i]; all = all && (unsigned)(got[i] >> 32) == note_seq; }
-            if (all) break;
-            if ((spins & 0x3FFFu) == 0x3FFFu) {
+        bool all = true;
+        for (int i = 0; i < PC_NOTE_WORDS; ++i) { got[i] = w[i]; all = all && (unsigned)(got[i] >> 32) == note_seq; }
+        if (!all) {
+            if ((++ready_spins & 0x3FFFu) == 0x3FFFu) {
                 // nothing after ~a millisecond: did the stream die (launch failure, fault)?  A finished stream without a
                 // stamp is an error; a busy one just takes long (general contraction kernel, large nurseries)
                 const hipError_t q = hipStreamQuery(st);
@@ -558,8 +560,9 @@ struct Engine {
                     for (int i = 0; i < PC_NOTE_WORDS; ++i) ok = ok && (unsigned)(w[i] >> 32) == note_seq;
                     if (!ok) engine_fail(PC_RC_DEVICE, "a contraction kernel finished without reporting (launch failure?)");
                 } else if (q != hipErrorNotReady) engine_fail(PC_RC_DEVICE, "HIP error %s while waiting for a round", hipGetErrorString(q));
-                if (spins > (1ul << 22)) std::this_thread::yield();
-            } else __builtin_ia32_pause();
+                if (ready_spins > (1ul << 22)) std::this_thread::yield();
+            }
+            return false;
         }
         PcCtl &c = *h_ctl;
         const int hi_before = c.i_nursery > 0 ? c.i_nursery - 1 : B - 1;       // the segment starts where the last one stopped
@@ -574,6 +577,7 @@ struct Engine {
         }
         c.seg_hi = hi_before; c.seg_lo = c.i_nursery;
         nph_stale = false;
+        return true;
     }
 
     void grow_dead(int nd)
@@ -1446,15 +1450,38 @@ struct Engine {
         return true;
     }
 
+    // ---- a run in phases, so that ONE host thread can keep several runs of a device in flight (pchip_run_repeats): begin(),
+    //      then round_enqueue() / round_ready() / round_finish() until it says stop, then end().  run() is the same sequence
+    //      for a single run, spinning in between.  State that lives across the phases:
+    struct ActiveRun {
+        int d; std::atomic<int> *flag;
+        ActiveRun(int dv, std::atomic<int> *f) : d(dv & 63), flag(f) { g_active_runs.fetch_add(1); g_active_dev[d].fetch_add(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.push_back(flag); }
+        ~ActiveRun() { g_active_runs.fetch_sub(1); g_active_dev[d].fetch_sub(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.erase(std::find(g_run_stop.begin(), g_run_stop.end(), flag)); }
+    };
+    std::unique_ptr<ActiveRun> active_run;
+    using clk = std::chrono::steady_clock;
+    clk::time_point r_t0, r_t1, r_t2;
+    unsigned r_batch = 0; bool r_sort_valid = false, r_fresh = false, r_par_ok = false, r_static_ok = false; int r_nursery_left = 0;
+    int r_rc = 0;                                 // outcome of the loop: 0, or the code run() returns
+
     int run(pchip_result *out)
     {
-        struct ActiveRun {
-            int d; std::atomic<int> *flag;
-            ActiveRun(int dv, std::atomic<int> *f) : d(dv & 63), flag(f) { g_active_runs.fetch_add(1); g_active_dev[d].fetch_add(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.push_back(flag); }
-            ~ActiveRun() { g_active_runs.fetch_sub(1); g_active_dev[d].fetch_sub(1); std::lock_guard<std::mutex> g(g_run_mutex); g_run_stop.erase(std::find(g_run_stop.begin(), g_run_stop.end(), flag)); }
-        } active_run(dev, &stop);
-        using clk = std::chrono::steady_clock;
-        auto t0 = clk::now();
+        int rc = begin();
+        if (rc >= 0) return rc;
+        while (true) {
+            if (!round_enqueue()) break;
+            while (!round_ready()) __builtin_ia32_pause();
+            if (!round_finish()) break;
+        }
+        if (r_rc != 0) return r_rc;
+        return end(out);
+    }
+
+    // everything before the first round; -1: go on, else the code to return
+    int begin()
+    {
+        active_run.reset(new ActiveRun(dev, &stop));
+        r_t0 = clk::now();
         h_dead_cap = (size_t)S.Dcap; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0;
         bool resumed = false;
         if (cfg.resume_read) {                         // read_write.F90:384-476; a missing file means a fresh start
@@ -1473,17 +1500,16 @@ struct Engine {
         if (!resumed) { if (callback_mode) generate_live_callback(); else generate_live(); }
         if (stop.load(std::memory_order_relaxed)) return 5;
         if (cb_auto_batch && !(cb_eval_seconds >= 0.0 && cb_eval_seconds < 2e-6)) { B = B_small; S.B = B; }   // expensive (or unmeasured) callback
-        auto t1 = clk::now();
-        unsigned batch = resume_batch0;               // fresh counter-RNG streams after a resume
-        bool sort_valid = false;
-        int nursery_left = 0;
-        const int wide = 0;
-        long long nlike_dev = h_ctl->nlike;
+        r_t1 = clk::now();
+        r_batch = resume_batch0;                      // fresh counter-RNG streams after a resume
+        r_sort_valid = false;
+        r_nursery_left = 0;
         const int nprior0 = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior;
         // the one-cluster kernels assume a static number of live points; each has its own LDS budget
         const bool static_ok = (cfg.n_nlives == 0) && (nprior0 >= cfg.nlive) && resume_static && cfg.force_general != 1;
         fast_ok = static_ok && pc_fast_fits(&S);
         const bool par_ok = static_ok && cfg.force_general == 0 && pc_par_fits(&S);
+        r_static_ok = static_ok; r_par_ok = par_ok;
         // The parallel contraction may run past an update trigger and have the update made afterwards, for the state at
         // the trigger (pc_update.hip): a nursery is then consumed in ONE launch instead of being cut where the reference
         // updates.  Only when nothing on the host is tied to the moment of an update (files, dumper, resume) and the
@@ -1507,9 +1533,18 @@ struct Engine {
                 if (need < 0.4 * (double)free_b) grow_phantoms(2LL * S.Pcap);
             }
         }
-        while (true) {
-            if (h_ctl->status == PC_ST_DONE) break;
-            if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); return 2; }
+        r_rc = 0;
+        return -1;
+    }
+
+    // enqueue one round (sampling when the nursery is empty, contraction, row copies); false: the loop is over (r_rc says how)
+    bool round_enqueue()
+    {
+        unsigned &batch = r_batch; bool &sort_valid = r_sort_valid; int &nursery_left = r_nursery_left;
+        const bool par_ok = r_par_ok, static_ok = r_static_ok; const int wide = 0;
+        {
+            if (h_ctl->status == PC_ST_DONE) return false;
+            if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); r_rc = 2; return false; }
             bool fresh_nursery = false;
             if (h_ctl->i_nursery == 0 && S.pool) {
                 if (pool_cursor + (long long)B * S.nr > S.Pcap) pool_compact();
@@ -1522,9 +1557,12 @@ struct Engine {
                 fresh_nursery = true;
                 hipEvent_t e0 = kt.begin(KT_NHATS);
                 // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
-                const bool split = pc_nhats_splittable(&S) != 0 && raw_buf[1] && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
+                // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
+                //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
+                const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
+                const bool split = splittable && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
                 bool fused_slice = false;
-                if (split) {
+                if (splittable) {
                     // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
                     // are drawn now)
                     RawSlot &rs = ring[batch % raw_depth];
@@ -1538,11 +1576,11 @@ struct Engine {
                     fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
                     if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
                 }
-                else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
                 kt.end(KT_NHATS, e0);
                 hipEvent_t e1 = kt.begin(KT_SLICE);
-                if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) return 5; }
-                else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); return 3; }
+                if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
+                else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
                 kt.end(KT_SLICE, e1);
                 if (split) {
                     // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
@@ -1608,7 +1646,7 @@ struct Engine {
                 } else
                 rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
             }
-            if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); return 4; }
+            if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); r_rc = 4; return false; }
             kt.end(KT_CONSUME, e2);
             hipEvent_t e3 = kt.begin(KT_APPLY);
             pc_launch_apply(&S, batch - 1, B, st);
@@ -1616,7 +1654,18 @@ struct Engine {
             // the main stream's wait for the next nursery's bases is enqueued now, behind this round's kernels (long
             // satisfied when the next k_slice gets there), not between the stamp and the next launch
             if (st_side) { RawSlot &rs = ring[batch % raw_depth]; if (rs.valid && rs.batch == batch && !rs.waited) { HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); rs.waited = true; } }
-            wait_ctl();
+            r_fresh = fresh_nursery;
+            ready_spins = 0;
+        }
+        return true;
+    }
+
+    // what the round did, once its stamp is in; false: the loop is over
+    bool round_finish()
+    {
+        unsigned &batch = r_batch; int &nursery_left = r_nursery_left; const bool fresh_nursery = r_fresh;
+        (void)batch;
+        {
             // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
             // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery
             // generated in between was never touched and does not count.
@@ -1633,6 +1682,14 @@ struct Engine {
                 stream_dead();
             }
         }
+        return true;
+    }
+
+    // kill-off, results; the code pchip_run returns
+    int end(pchip_result *out)
+    {
+        const bool par_ok = r_par_ok; bool &sort_valid = r_sort_valid;
+        const auto t0 = r_t0, t1 = r_t1;
         auto t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
         const int nT = S.nT;
@@ -1690,7 +1747,6 @@ struct Engine {
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
         out->t_generate = tm.t_gen; out->t_loop = tm.t_loop; out->t_final = tm.t_final; out->t_total = tm.t_total;
         for (int k = 0; k < KT_N; ++k) { out->k_time_s[k] = kt.total_ms[k] * 1e-3; out->k_launches[k] = kt.launches[k]; }
-        (void)nlike_dev;
         // developer counters (PC_DEBUG=2|3|4); the feedback setting keeps the reference's meaning (feedback.f90)
         static const int dbg_lvl = std::getenv("PC_DEBUG") ? std::atoi(std::getenv("PC_DEBUG")) : 0;
         if (dbg_lvl >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles; %lld chains identified from the candidate lists, %lld of them fell back to the full search\n", h_ctl->gen_cyc[0], h_ctl->gen_cyc[1], h_ctl->gen_cyc[2], h_ctl->gen_cyc[3], h_ctl->nn_walks, h_ctl->nn_fallbacks);
@@ -1731,11 +1787,13 @@ struct Engine {
         for (int d = 0; d < D; ++d) { out->post_mean[d] /= sw; out->post_var[d] = out->post_var[d] / sw - out->post_mean[d] * out->post_mean[d]; }
         dfree(d_pmax); hfree(h_part);
         HIPCHK(hipStreamSynchronize(st_copy));
+        active_run.reset();
         return 0;
     }
 
     void destroy()
     {
+        active_run.reset();
         // work may still be in flight on any of the run's streams (early returns, the prefetched bases of a nursery
         // that was never consumed): the blocks below go back to a process-wide cache and may be handed to another
         // run's thread at once
@@ -1857,6 +1915,69 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
         out->t_results = std::chrono::duration<double>(t2 - t1).count() - out->t_total;
     }
     return rc;
+}
+
+// Several runs of one problem on ONE device, driven by the calling thread: every run is an engine of its own (own stream, own
+// state), and the thread goes round them -- enqueue a round, look whether a stamp has arrived, finish that round, enqueue the
+// next -- so that the kernels of up to `max_in_flight` runs are in the device's queues at any time.  (One host thread per
+// run, as before, spent its time in the HIP runtime's locks: 533 launches per run from sixteen threads at once gave 1.5 x the
+// throughput of one run; a single run keeps one wavefront per SIMD busy and the contraction kernel one CU.)
+// Built-in device likelihoods only: a host callback belongs to its caller's thread.  Returns 0 or the first failing run's code.
+int pc_run_many(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds, int device,
+                int max_in_flight, pchip_result *results)
+{
+    struct Job { Engine *E = nullptr; int k = -1; bool waiting = false; };
+    std::vector<Job> jobs((size_t)std::max(1, std::min(max_in_flight, nseeds)));
+    int next = 0, active = 0, worst = 0;
+    for (int k = 0; k < nseeds; ++k) std::memset(&results[k], 0, sizeof(pchip_result));
+    auto finish = [&](Job &j, int rc) {
+        if (rc != 0) { pchip_result_free(&results[j.k]); if (!worst) worst = rc; }
+        j.E->destroy(); delete j.E; j.E = nullptr; j.waiting = false; active--;
+    };
+    // one step of a job; exceptions of the engine end that job only
+    auto guarded = [&](Job &j, auto &&fn) {
+        try { fn(); }
+        catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); (void)hipGetLastError(); finish(j, e.code); }
+        catch (const std::bad_alloc &) { std::fprintf(stderr, "polychord_hip: out of host memory\n"); finish(j, PC_RC_MEMORY); }
+    };
+    static const bool prof = std::getenv("PC_DEBUG") && std::atoi(std::getenv("PC_DEBUG")) == 5;
+    double t_begin = 0, t_enq = 0, t_fin = 0, t_end = 0; long n_enq = 0, n_poll = 0;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    while (next < nseeds || active > 0) {
+        for (Job &j : jobs) {
+            if (!j.E) {
+                if (next >= nseeds || worst) continue;
+                j.k = next++; j.E = new Engine; active++;
+                guarded(j, [&] {
+                    pchip_settings c = *s; c.seed = seeds[j.k]; c.device = device;
+                    j.E->setup(c, *like, *prior);
+                    const auto a0 = now();
+                    const int rc = j.E->begin();
+                    t_begin += secs(a0, now());
+                    if (rc >= 0) { finish(j, rc ? rc : PC_RC_DEVICE); return; }
+                    if (!j.E->round_enqueue()) { const int r = j.E->r_rc ? j.E->r_rc : j.E->end(&results[j.k]); finish(j, r); return; }
+                    j.waiting = true;
+                });
+            } else if (j.waiting) {
+                guarded(j, [&] {
+                    n_poll++;
+                    if (!j.E->round_ready()) return;
+                    const auto a0 = now();
+                    const bool go = j.E->round_finish();
+                    const auto a1 = now(); t_fin += secs(a0, a1);
+                    const bool go2 = go && j.E->round_enqueue();
+                    const auto a2 = now(); t_enq += secs(a1, a2); n_enq++;
+                    if (!go2) { const int r = j.E->r_rc ? j.E->r_rc : j.E->end(&results[j.k]); t_end += secs(a2, now()); finish(j, r); }
+                });
+            }
+        }
+        if (worst && active == 0) break;
+    }
+    if (prof) std::fprintf(stderr, "polychord_hip dbg many: %d runs, wall %.2f ms; begin %.2f, finish(+updates) %.2f, enqueue %.2f (%ld rounds), end %.2f ms; %ld polls\n",
+                           nseeds, secs(T0, now()) * 1e3, t_begin * 1e3, t_fin * 1e3, t_enq * 1e3, n_enq, t_end * 1e3, n_poll);
+    return worst;
 }
 
 void pchip_result_free(pchip_result *r)

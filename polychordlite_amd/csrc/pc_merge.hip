@@ -33,6 +33,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and enums only: the library is dlopen'ed (no link-time dependency on RCCL)
 
+extern "C" int pc_run_many(const pchip_settings *, const pchip_like *, const pchip_prior *, int, const int *, int, int, pchip_result *);
+
 namespace {
 
 struct P2 { double a, b; };
@@ -577,22 +579,45 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
     std::vector<int> devs;
     if (ndevices > 0 && devices) { for (int k = 0; k < ndevices; ++k) { if (devices[k] < 0 || devices[k] >= ndev_all) { std::fprintf(stderr, "polychord_hip: device %d of %d\n", devices[k], ndev_all); return 1; } devs.push_back(devices[k]); } }
     else devs.push_back(s->device >= 0 ? s->device % ndev_all : 0);
-    const int per_dev = std::max(1, max_in_flight), nworkers = std::min(nseeds, per_dev * (int)devs.size());
+    // Built-in device likelihoods: one host thread per DEVICE keeps up to max_in_flight runs in flight there (pc_run_many).  Host
+    // callbacks: one thread per run in flight, as the caller's callbacks have to be called from somewhere.
+    const int per_dev = std::max(1, max_in_flight);
     std::atomic<int> next{0}, worst{0};
     const auto t0 = clk::now();
-    auto work = [&](int wid) {
-        const int dev = devs[wid % devs.size()];
-        for (int k = next.fetch_add(1); k < nseeds; k = next.fetch_add(1)) {
-            pchip_settings c = *s;
-            c.seed = seeds[k]; c.device = dev;
-            const int rc = pchip_run_hooks(&c, like, prior, nullptr, &results[k]);
+    const bool device_like = like->kind != PCHIP_LIKE_CALLBACK && prior->kind == 1 && !std::getenv("PC_REPEATS_THREADS");
+    if (device_like) {
+        // seeds dealt round-robin to the devices: run k on devs[k % ndev] (what the merge below assumes)
+        auto work = [&](int di) {
+            std::vector<int> mine, idx;
+            for (int k = di; k < nseeds; k += (int)devs.size()) { mine.push_back(seeds[k]); idx.push_back(k); }
+            if (mine.empty()) return;
+            std::vector<pchip_result> res(mine.size());
+            const int rc = pc_run_many(s, like, prior, (int)mine.size(), mine.data(), devs[di], per_dev, res.data());
             if (rc != 0) { int z = 0; worst.compare_exchange_strong(z, rc); }
-        }
-    };
-    std::vector<std::thread> th;
-    for (int w = 1; w < nworkers; ++w) th.emplace_back(work, w);
-    work(0);
-    for (auto &t : th) t.join();
+            for (size_t a = 0; a < idx.size(); ++a) results[idx[a]] = res[a];
+        };
+        std::vector<std::thread> th;
+        for (int d = 1; d < (int)devs.size(); ++d) th.emplace_back(work, d);
+        work(0);
+        for (auto &t : th) t.join();
+    } else {
+        const int nworkers = std::min(nseeds, per_dev * (int)devs.size());
+        auto work = [&](int wid) {
+            // (run k must land on devs[k % ndev]: a worker takes the seeds of its own device only)
+            const int di = wid % (int)devs.size();
+            for (int k = next.fetch_add(1); k < nseeds; k = next.fetch_add(1)) {
+                pchip_settings c = *s;
+                c.seed = seeds[k]; c.device = devs[k % devs.size()];
+                (void)di;
+                const int rc = pchip_run_hooks(&c, like, prior, nullptr, &results[k]);
+                if (rc != 0) { int z = 0; worst.compare_exchange_strong(z, rc); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int w = 1; w < nworkers; ++w) th.emplace_back(work, w);
+        work(0);
+        for (auto &t : th) t.join();
+    }
     const double t_runs = std::chrono::duration<double>(clk::now() - t0).count();
     if (worst.load() != 0) { for (int k = 0; k < nseeds; ++k) pchip_result_free(&results[k]); return worst.load(); }
     if (!merged) return 0;

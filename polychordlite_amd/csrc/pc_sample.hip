@@ -1434,8 +1434,14 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 // the directions never travel through HBM: a prologue whitens all of the chain's directions at once, lane = direction
 // (the loops of k_nhats, bit for bit: row sums in ascending b, the norm on four partial sums), into LDS, from where the
 // slices pick them up in deck order.  FW = unroll width >= nDims.
+// PC_SLICE_WAVES (build-time experiment): cap the registers so that this many waves share a SIMD
+#ifdef PC_SLICE_WAVES
+#define PC_SLICE_ATTR __attribute__((amdgpu_waves_per_eu(PC_SLICE_WAVES, PC_SLICE_WAVES)))
+#else
+#define PC_SLICE_ATTR
+#endif
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
-__global__ __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
+__global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(3);                 // a chain is one long dependent instruction stream: it goes first on its SIMD

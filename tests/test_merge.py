@@ -176,8 +176,9 @@ def test_run_repeats_front_door_and_files(engine, tmp_path):
     s, L, P, keep, singles = _engine_runs(api, [11, 12, 13, 14, 15, 16])
     merged, runs = run_repeats(s, L, P, [11, 12, 13, 14, 15, 16], max_in_flight=3, devices=list(range(ndev)),
                                want_rows=True, write=(str(tmp_path), "u"))
-    for one, r in zip(singles, runs):
+    for one, r in zip(singles, runs):               # several runs in flight on one host thread: each is bit for bit its solo run
         assert one["ndead"] == r["ndead"] and one["nlike"] == r["nlike"] and one["logZ"] == r["logZ"]
+        assert np.array_equal(one["dead"], r["dead"]) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"])
     assert merged["n_runs"] == 6 and merged["nlike"] == sum(r["nlike"] for r in runs)
     rows = np.concatenate([r["dead"][r["logweights"] > -1e29] for r in runs]); entry = np.concatenate([r["entry"][r["logweights"] > -1e29] for r in runs])
     ref = replay(rows[:, -1], entry, rows=rows, p0=6, nP=7)
