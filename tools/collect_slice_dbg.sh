@@ -1,0 +1,10 @@
+#!/bin/bash
+# collect_slice_dbg.sh <tag> -- run ON THE GPU BOX (gpurun), after `make -C polychordlite_amd/csrc ../libpolychord_hip_slicedbg.so`
+# here: cycles of the sections of a slice inside k_slice (chain 0 of every nursery, s_memtime) at the metric configuration,
+# and the single-wave latencies of tools/ubench.hip; summary to gpurun_out/<tag>_slice_cycles.json (copy into profiles/).
+set -u
+tag=${1:-r03}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+hipcc -O2 --offload-arch=gfx950 tools/ubench.hip -o /tmp/ubench 2>/dev/null && /tmp/ubench | tail -2 > gpurun_out/${tag}_ubench.txt
+PCHIP_LIB=$PWD/polychordlite_amd/libpolychord_hip_slicedbg.so PC_DEBUG=4 python tools/dev/gpu_slice_dbg.py gpurun_out/${tag}_ubench.txt > gpurun_out/${tag}_slice_cycles.json 2> gpurun_out/${tag}_slice_dbg.err
+cat gpurun_out/${tag}_slice_cycles.json
