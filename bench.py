@@ -73,6 +73,46 @@ def random_correlated_gaussian(D, seed=12345, sigma0=0.1):
     return Q @ np.diag(sig ** -2) @ Q.T, np.full(D, 0.5), float(2.0 * np.log(sig).sum())
 
 
+# ---- latency model of the dominant kernel (the path is latency bound, not bandwidth bound: SURVEY 8d).  k_slice runs one
+# wavefront per chain with one cube coordinate per lane; a slice is a chain of DEPENDENT fp64 operations, and on a wave that has
+# its SIMD to itself a dependent fp64 operation issues every 32 cycles (tools/ubench.hip on this hardware: fma 32, LDS round
+# trip 70, exp 140, log 480, div 100 cycles at 2.4 GHz; profiles/r03_slice_cycles.json).  Dependent operations per slice of the
+# closed-form Gaussian chord (pc_sample.hip k_slice), section by section:
+SLICE_CHAIN = {  # section: (dependent fp64 ops, LDS round trips, what)
+    "take_over_and_philox": (2, 1, "next direction from LDS; one Philox4x32-10 call per four slices (10 rounds x ~3 integer ops / 4)"),
+    "coefficients_and_initial_bracket": (19, 0, "z = (lo + span x - mu)/sigma: 3; squares: 1; three wave sums side by side (4 DPP row steps + 2 cross-row): 6; "
+                                                "bracket ends: 2; closed form qnorm - (qa + t (2 qb + t qc))/2: 5; cube test: 2"),
+    "stepping_out": (8, 0, "PER EVALUATION beyond the bracket: position 1, closed form 5, cube test 2"),
+    "shrinkage": (21, 0, "four speculative positions, each 3 behind the previous: 12; closed form: 5; first-accepted select: 4"),
+    "stores": (2, 1, "cube -> theta: 2; LDS hop for the derived parameters' row"),
+}
+DEP_FP64_CYCLES, LDS_CYCLES, PHILOX_CYCLES_PER_SLICE, CLOCK_MHZ = 32.0, 70.0, 60.0, 2400.0
+
+
+def latency_model(runs, kern):
+    """modelled minimum cycles per slice (dependent-operation count x measured single-wave latencies) next to the measured ones"""
+    ks = [k for k in kern if k["kernel"] == "k_slice"]
+    nr = 40
+    evals_per_slice = sum(r["nlike"] for r in runs) / max(sum(r["niter"] for r in runs), 1) / nr
+    e_out = max(evals_per_slice - 2.0 - 1.54, 0.0)        # 2 = the bracket's ends; 1.54 = counted shrink trials per slice (measured: slice_cycles.json)
+    model = {}
+    for name, (dep, lds, what) in SLICE_CHAIN.items():
+        n = dep * (e_out if name == "stepping_out" else 1.0)
+        model[name] = n * DEP_FP64_CYCLES + lds * LDS_CYCLES + (PHILOX_CYCLES_PER_SLICE if name == "take_over_and_philox" else 0.0)
+    out = {"unit": "shader cycles per slice (one wavefront = one chain, 2.4 GHz)", "model_min_by_section": model, "model_min": sum(model.values()),
+           "dependent_fp64_cycles": DEP_FP64_CYCLES, "lds_round_trip_cycles": LDS_CYCLES, "evaluations_per_slice": evals_per_slice,
+           "chain": {k: v[2] for k, v in SLICE_CHAIN.items()}}
+    pth = os.path.join(ROOT, "profiles", "r03_slice_cycles.json")
+    if os.path.exists(pth):
+        m = json.load(open(pth))
+        out["measured_by_section"] = m["cycles_per_slice"]; out["measured"] = m["cycles_per_slice_total"]
+        out["measured_source"] = "profiles/r03_slice_cycles.json (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)"
+        out["frac_of_model"] = out["model_min"] / m["cycles_per_slice_total"]
+    if ks:
+        out["launch_cycles_per_slice_this_run"] = ks[0]["avg_launch_us"] * CLOCK_MHZ / nr      # whole launch / slices: includes seed choice, shuffle, whitening, derived parameters
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -393,6 +433,8 @@ def main():
                             "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
                             "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
                             "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
+        if roof and args.workload == "c2":
+            roof["latency"] = latency_model(runs, kern)
         out = {"metric": METRIC[args.workload] % nlive, "value": value,
                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",

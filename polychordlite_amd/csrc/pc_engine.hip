@@ -1537,84 +1537,120 @@ struct Engine {
         return -1;
     }
 
+    // The sampling of one nursery: pool rows, the bases (drawn ahead on the side stream, or now), k_slice, the bases of the
+    // nurseries to come.  spec: enqueued BEHIND the previous nursery's contraction before the host has seen its outcome; the
+    // kernel starts by asking the device whether that nursery was consumed whole with neither an update nor the end of the
+    // run in its way (PcCtl::spec_ok, left by k_consume_par) and returns at once if not.
+    bool enqueue_nursery(bool spec)
+    {
+        unsigned &batch = r_batch; int &nursery_left = r_nursery_left;
+        if (S.pool) {
+            if (pool_cursor + (long long)B * S.nr > S.Pcap) pool_compact();
+            S.pool_base = (int)pool_cursor; S.pool_rows = B * S.nr; S.babies = S.phantom + (size_t)pool_cursor * S.nT;
+            pool_cursor += (long long)B * S.nr;
+        }
+        {
+            // (between the stamp of the last round and the launch of k_slice the device idles: nothing that can wait
+            //  is done in between -- capacity checks precede the contraction, not the sampling)
+            hipEvent_t e0 = spec ? nullptr : kt.begin(KT_NHATS);
+            // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
+            // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
+            //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
+            const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
+            const bool split = splittable && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
+            bool fused_slice = false;
+            if (splittable) {
+                // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
+                // are drawn now)
+                RawSlot &rs = ring[batch % raw_depth];
+                S.nhat_raw = raw_buf[batch % raw_depth];
+                if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }
+                else {
+                    if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
+                    (void)pc_launch_nhats_part(&S, batch, B, 1, st);
+                }
+                rs.valid = false;
+                fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
+                if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
+            }
+            else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            kt.end(KT_NHATS, e0);
+            hipEvent_t e1 = spec ? nullptr : kt.begin(KT_SLICE);
+            S.spec_guard = spec ? 1 : 0;                                         // (the kernel looks at the contraction's verdict first)
+            if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
+            else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            S.spec_guard = 0;
+            kt.end(KT_SLICE, e1);
+            if (split && !spec) side_prefetch(batch);      // (speculative: only once the device is known to have taken the nursery)
+            if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
+            batch++; tm.batches++;
+            S.nn_valid = 0; nursery_left = B;
+        }
+        return true;
+    }
+
+    // the bases of the nurseries after `cur`, on the side stream (behind cur's sampling kernel on the main stream)
+    void side_prefetch(unsigned cur)
+    {
+        const unsigned batch = cur;
+        {
+                // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
+        // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
+        if (!st_side) {
+            st_side = hpool().get_stream(); ev_main = hpool().get_sync_event();
+            for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
+        }
+        // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
+        //  half a millisecond: there they run next to it from the start)
+        static const bool side_free_env = std::getenv("PC_SIDE_FREE") != nullptr, side_ord_env = std::getenv("PC_SIDE_ORDERED") != nullptr;
+        const bool side_free = side_free_env || (S.D > 64 && !side_ord_env);
+        // the buffer of this nursery is free again once its bases have been whitened (fused: once sampled)
+        // (ordered: the side stream follows k_slice anyway -- one event between k_slice and the contraction, not two:
+        //  every record on the main stream is a few microseconds before the next kernel starts)
+        RawSlot &cur = ring[batch % raw_depth];
+        if (side_free) { HIPCHK(hipEventRecord(cur.consumed, st)); cur.used = true; }
+        if (!side_free) { HIPCHK(hipEventRecord(ev_main, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0)); }
+        // ordered: the next nursery only; free: as far ahead as there are buffers (the last one is this nursery's own)
+        const unsigned xmax = batch + (unsigned)raw_depth - (side_free ? 0u : 1u);
+        for (unsigned x = batch + 1; x <= xmax; ++x) {
+            RawSlot &rs = ring[x % raw_depth];
+            if (rs.valid && rs.batch == x && rs.B == B) continue;
+            if (rs.valid) continue;                                          // (a job for another nursery size: used or replaced when its turn comes)
+            if (rs.used) HIPCHK(hipStreamWaitEvent(st_side, rs.consumed, 0));
+            PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+            (void)pc_launch_nhats_part(&S1, x, B, 1, st_side);
+            HIPCHK(hipEventRecord(rs.ready, st_side));
+            rs.valid = true; rs.batch = x; rs.B = B; rs.waited = false;
+        }
+    }
+    }
+
+    // a speculative nursery the device declined: the host's bookkeeping of it is taken back (its bases stay where they are,
+    // drawn and waited for: the real launch finds them)
+    bool spec_pending = false, spec_hit = false;
+    void spec_undo()
+    {
+        r_batch--; tm.batches--;
+        if (S.pool) pool_cursor -= (long long)B * S.nr;
+        RawSlot &rs = ring[r_batch % raw_depth];
+        rs.valid = true; rs.batch = r_batch; rs.B = B; rs.waited = true;
+    }
+
     // enqueue one round (sampling when the nursery is empty, contraction, row copies); false: the loop is over (r_rc says how)
     bool round_enqueue()
     {
         unsigned &batch = r_batch; bool &sort_valid = r_sort_valid; int &nursery_left = r_nursery_left;
         const bool par_ok = r_par_ok, static_ok = r_static_ok; const int wide = 0;
         {
-            if (h_ctl->status == PC_ST_DONE) return false;
+            if (h_ctl->status == PC_ST_DONE) { if (spec_pending) { spec_pending = false; spec_undo(); } return false; }
             if (h_ctl->status == PC_ST_ERROR) { std::fprintf(stderr, "polychord_hip: device error %d\n", h_ctl->error); r_rc = 2; return false; }
             bool fresh_nursery = false;
-            if (h_ctl->i_nursery == 0 && S.pool) {
-                if (pool_cursor + (long long)B * S.nr > S.Pcap) pool_compact();
-                S.pool_base = (int)pool_cursor; S.pool_rows = B * S.nr; S.babies = S.phantom + (size_t)pool_cursor * S.nT;
-                pool_cursor += (long long)B * S.nr;
-            }
             if (h_ctl->i_nursery == 0) {
-                // (between the stamp of the last round and the launch of k_slice the device idles: nothing that can wait
-                //  is done in between -- capacity checks precede the contraction, not the sampling)
                 fresh_nursery = true;
-                hipEvent_t e0 = kt.begin(KT_NHATS);
-                // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
-                // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
-                //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
-                const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
-                const bool split = splittable && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
-                bool fused_slice = false;
-                if (splittable) {
-                    // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
-                    // are drawn now)
-                    RawSlot &rs = ring[batch % raw_depth];
-                    S.nhat_raw = raw_buf[batch % raw_depth];
-                    if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }
-                    else {
-                        if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
-                        (void)pc_launch_nhats_part(&S, batch, B, 1, st);
-                    }
-                    rs.valid = false;
-                    fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
-                    if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
-                }
-                else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
-                kt.end(KT_NHATS, e0);
-                hipEvent_t e1 = kt.begin(KT_SLICE);
-                if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
-                else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
-                kt.end(KT_SLICE, e1);
-                if (split) {
-                    // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
-                    // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
-                    if (!st_side) {
-                        st_side = hpool().get_stream(); ev_main = hpool().get_sync_event();
-                        for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
-                    }
-                    // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
-                    //  half a millisecond: there they run next to it from the start)
-                    static const bool side_free_env = std::getenv("PC_SIDE_FREE") != nullptr, side_ord_env = std::getenv("PC_SIDE_ORDERED") != nullptr;
-                    const bool side_free = side_free_env || (S.D > 64 && !side_ord_env);
-                    // the buffer of this nursery is free again once its bases have been whitened (fused: once sampled)
-                    // (ordered: the side stream follows k_slice anyway -- one event between k_slice and the contraction, not two:
-                    //  every record on the main stream is a few microseconds before the next kernel starts)
-                    RawSlot &cur = ring[batch % raw_depth];
-                    if (side_free) { HIPCHK(hipEventRecord(cur.consumed, st)); cur.used = true; }
-                    if (!side_free) { HIPCHK(hipEventRecord(ev_main, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_main, 0)); }
-                    // ordered: the next nursery only; free: as far ahead as there are buffers (the last one is this nursery's own)
-                    const unsigned xmax = batch + (unsigned)raw_depth - (side_free ? 0u : 1u);
-                    for (unsigned x = batch + 1; x <= xmax; ++x) {
-                        RawSlot &rs = ring[x % raw_depth];
-                        if (rs.valid && rs.batch == x && rs.B == B) continue;
-                        if (rs.valid) continue;                                          // (a job for another nursery size: used or replaced when its turn comes)
-                        if (rs.used) HIPCHK(hipStreamWaitEvent(st_side, rs.consumed, 0));
-                        PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
-                        (void)pc_launch_nhats_part(&S1, x, B, 1, st_side);
-                        HIPCHK(hipEventRecord(rs.ready, st_side));
-                        rs.valid = true; rs.batch = x; rs.B = B; rs.waited = false;
-                    }
-                }
-                if (S.ngrade > 1) HIPCHK(hipMemcpyAsync(h_nlike_g.data(), S.ch_nlike_g, sizeof(int) * h_nlike_g.size(), hipMemcpyDeviceToHost, st));
-                batch++; tm.batches++;
-                S.nn_valid = 0; nursery_left = B;
+                const bool have = spec_pending;                 // (still pending here = the device took it: round_finish undid the others)
+                spec_pending = false;
+                if (have) side_prefetch(batch - 1);
+                else if (!enqueue_nursery(false)) return false;
             }
             if (fresh_nursery) ensure_capacity();
             hipEvent_t e2 = kt.begin(KT_CONSUME);
@@ -1656,6 +1692,22 @@ struct Engine {
             if (st_side) { RawSlot &rs = ring[batch % raw_depth]; if (rs.valid && rs.batch == batch && !rs.waited) { HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); rs.waited = true; } }
             r_fresh = fresh_nursery;
             ready_spins = 0;
+            // PC_SPEC=1 (experiment, off by default): the next nursery's sampling enqueued behind this round's kernels before the
+            // host knows how the round ends; k_slice asks the device first (PcCtl::spec_ok) and returns at once when an update or
+            // the end of the run is in the way.  48 of the 79 rounds of the metric configuration end with an empty nursery and no
+            // update, and in those the device goes from the row copies straight into k_slice -- but the run is no shorter for it
+            // (14.75 ms against 14.65, A/B in one call, identical results): the 31 declined launches and the second trip through
+            // the launch path cost what the 48 saved host round trips give.
+            static const bool spec_off = !(std::getenv("PC_SPEC") && std::atoi(std::getenv("PC_SPEC")) == 1);
+            if (!spec_off && S.pool && par_ok && h_ctl->ncluster == 1 && !callback_mode && st_side && pc_slice_fusable(&S) != 0 &&
+                g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1 &&
+                pool_cursor + (long long)B * S.nr <= S.Pcap && (long long)h_ctl->ndead + 2LL * B + S.Ncap + 16 <= S.Dcap) {
+                RawSlot &rs = ring[batch % raw_depth];
+                if (rs.valid && rs.batch == batch && rs.B == B && rs.waited) {
+                    if (!enqueue_nursery(true)) return false;
+                    spec_pending = true; spec_hit = false;
+                }
+            }
         }
         return true;
     }
@@ -1665,6 +1717,10 @@ struct Engine {
     {
         unsigned &batch = r_batch; int &nursery_left = r_nursery_left; const bool fresh_nursery = r_fresh;
         (void)batch;
+        if (spec_pending) {
+            spec_hit = h_ctl->status == PC_ST_RUNNING && !h_ctl->upd_pending && h_ctl->i_nursery == 0 && h_ctl->error == 0;   // what the device's guard saw
+            if (!spec_hit) { spec_pending = false; spec_undo(); }      // (before the update looks at the pool's cursor)
+        }
         {
             // A run whose last death exhausts a nursery AND triggers an update learns that it is over only from the next
             // launch (the kernels test more_samples_needed before a death, nested_sampling.F90:237): the nursery

@@ -743,6 +743,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
         if (Kp) { ctl->logZ = fin[0]; ctl->logZ2 = fin[4]; }
         if (pri == 0) ctl->logX_last_update = Xp;
         ctl->upd_pending = 0; ctl->upd_marks = 0;
+        ctl->spec_ok = (status == PC_ST_RUNNING && marks_sh[1] == 0 && T - ts == 0 && pri != 2) ? (int)(ctl->batch_id + 1u) : -1;
         if (marks_sh[1] > 0) {
             const int Kl = marks_sh[0], marks = marks_sh[1];
             ctl->upd_pending = 1; ctl->upd_marks = marks;

@@ -1444,6 +1444,8 @@ template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // enqueued before the host knew how the previous nursery ended: only if the contraction left its go-ahead for THIS nursery
+    if (S.spec_guard && S.ctl->spec_ok != (int)batch) return;
     __builtin_amdgcn_s_setprio(3);                 // a chain is one long dependent instruction stream: it goes first on its SIMD
     const int lane = threadIdx.x & 63, wv = (WPB > 1) ? (int)(threadIdx.x >> 6) : 0, chain = blockIdx.x * WPB + wv;
     const size_t per_wave = ((size_t)S.D + S.nr + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0) + 1) & ~(size_t)1;   // doubles

@@ -47,6 +47,8 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     int upd_keep_thr, upd_pad;          // deaths after the mark: death_thr stays the last death's logL
     double upd_thr;                     // logL of the death that triggered the mark (clean_phantoms' threshold)
     int chol_suspect, chol_pad;         // the blocked factorisation met a pivot it does not trust: the reference-order kernel behind it decides
+    int spec_ok, spec_pad;              // parallel contraction: number of the nursery that may be sampled at once (this one was consumed whole, no
+                                        // update is due, the run goes on), or -1: what a speculatively enqueued k_slice asks first
 };
 
 #define PC_MAX_GRADE 8
@@ -161,6 +163,7 @@ struct PcState {
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
+    int spec_guard;              // k_slice: enqueued ahead of the host's decision -- return unless ctl->spec_ok names this nursery
     PcCtl *ctl;
     // host notification: the contraction kernels copy the control block into a pinned, device-visible host mirror when
     // they are done and stamp it with notify_seq, so the host learns the outcome of a round by watching memory instead
