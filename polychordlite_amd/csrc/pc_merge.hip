@@ -587,17 +587,22 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
     const bool device_like = like->kind != PCHIP_LIKE_CALLBACK && prior->kind == 1 && !std::getenv("PC_REPEATS_THREADS");
     if (device_like) {
         // seeds dealt round-robin to the devices: run k on devs[k % ndev] (what the merge below assumes)
-        auto work = [&](int di) {
+        // (a device's runs may be shared out among a few scheduler threads: one thread's launch path saturates at about eight runs)
+        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : 1;
+        const int nd = (int)devs.size();
+        auto work = [&](int wi) {
+            const int di = wi % nd, part = wi / nd;
             std::vector<int> mine, idx;
-            for (int k = di; k < nseeds; k += (int)devs.size()) { mine.push_back(seeds[k]); idx.push_back(k); }
+            int j = 0;
+            for (int k = di; k < nseeds; k += nd, ++j) if (j % sched == part) { mine.push_back(seeds[k]); idx.push_back(k); }
             if (mine.empty()) return;
             std::vector<pchip_result> res(mine.size());
-            const int rc = pc_run_many(s, like, prior, (int)mine.size(), mine.data(), devs[di], per_dev, res.data());
+            const int rc = pc_run_many(s, like, prior, (int)mine.size(), mine.data(), devs[di], std::max(1, (per_dev + sched - 1) / sched), res.data());
             if (rc != 0) { int z = 0; worst.compare_exchange_strong(z, rc); }
             for (size_t a = 0; a < idx.size(); ++a) results[idx[a]] = res[a];
         };
         std::vector<std::thread> th;
-        for (int d = 1; d < (int)devs.size(); ++d) th.emplace_back(work, d);
+        for (int w = 1; w < nd * sched; ++w) th.emplace_back(work, w);
         work(0);
         for (auto &t : th) t.join();
     } else {
