@@ -62,6 +62,9 @@ def own_bytes_per_launch(kernel, D, nDer, nr, N, B):
     return {"k_slice": B * (8 * nT * (1 + nr) + 8 * nr * (D + 1) + 16 * nr),    # seed row in, nr baby rows out, directions + widths in, logL twice
             "k_consume": 8 * (2 * N + 3 * B) + 8 * nr * B + 184 * B,               # sorted keys + slots in and out, candidates, the babies' logL (phantom masks), plan records
             "k_nhats": B * 8 * nr * (D + 1) * 2 + 8 * D * D,                       # raw bases in, whitened directions + widths out, the Cholesky factor
+            # the orthonormal bases drawn ahead on the side stream: one record per basis and chain (nDims > 64: 16384 doubles in the
+            # matrix cores' operand layout; else nDims x nDims)
+            "k_bases_side": B * ((nr + D - 1) // D) * 8 * (16384 if D > 64 else D * D),
             "k_apply": B * 8 * nT * (1 + nr) + 8 * nT * B}.get(kernel)
 
 
@@ -271,7 +274,7 @@ def main():
     # HIP-event stopwatch on the run's own stream.  Warm-up: the four kernel classes a round consists of, every launch
     # (picks the two heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream
     # ~6 us, every launch of two classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
-    s.profile = cls_bit("k_nhats") | cls_bit("k_slice") | cls_bit("k_consume") | cls_bit("k_apply")
+    s.profile = cls_bit("k_nhats") | cls_bit("k_slice") | cls_bit("k_consume") | cls_bit("k_apply") | cls_bit("k_bases_side")
 
     def one(i):
         s.seed = 1000 + i + 100003 * rank
@@ -422,13 +425,14 @@ def main():
         if kern:
             # launches of the dominant class per run: nurseries (k_slice, k_nhats) or rounds (k_consume, k_apply)
             dom = kern[0]
-            per_launch_evals = evals / (nurseries if dom["kernel"] in ("k_slice", "k_nhats") else float(sum(r["nrounds"] for r in runs)))
+            per_launch_evals = evals / (nurseries if dom["kernel"] in ("k_slice", "k_nhats", "k_bases_side") else float(sum(r["nrounds"] for r in runs)))
             achieved = per_launch_evals * bpe / (dom["avg_launch_us"] * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
                     "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe,
                     "whole_run_frac": evals * bpe / dt / 1e9 / HBM_PEAK_GBS,
                     "kernels": kern,
+                    "stream": "side (drawn ahead of the nursery that uses them, next to the main stream's kernels)" if dom["kernel"] == "k_bases_side" else "main",
                     "note": "latency/parallelism bound path (SURVEY 8d): <= B chains x nDims lanes are live.  achieved = SURVEY 8(d) algorithmic "
                             "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
                             "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "

@@ -117,7 +117,7 @@ typedef struct {
     int device;         /* HIP device ordinal, -1 = current/0 */
     int feedback;
     int profile;        /* 0: off; 1: HIP-event stopwatch around every kernel class; otherwise a bit mask,
-                           bit k+1 = time kernel class k (0 nhats, 1 slice, 2 consume, 3 apply, 4 clean, 5 covmats):
+                           bit k+1 = time kernel class k (0 nhats, 1 slice, 2 consume, 3 apply, 4 clean, 5 covmats, 6 side-stream bases):
                            a few hundred event records per run instead of a few thousand; bits 8..15 = n: only every
                            n-th launch of a class is timed (k_launches then counts the timed ones) */
     int force_general;  /* 1: always use the general contraction kernel (tests) */
@@ -160,8 +160,8 @@ typedef struct {
     int ncluster, ncluster_dead, nTotal, batch;
     double t_generate, t_loop, t_final, t_total;   /* host wall-clock of the phases, seconds */
     double t_setup, t_results, t_teardown;         /* allocation / result download / free */
-    double k_time_s[6]; long k_launches[6];        /* HIP-event time per kernel class: nhats, slice,
-                                                      consume, apply, clean, covmats (profile=1) */
+    double k_time_s[8]; long k_launches[8];        /* HIP-event time per kernel class: nhats, slice, consume, apply,
+                                                      clean, covmats, bases drawn ahead on the side stream (profile=1) */
     double *dead, *logweights;     /* [ndead][nTotal] rows [cube|theta|phi|birth|logL], [ndead] */
     double *entry;                 /* [ndead] global contour when the point entered the live set
                                       (== birth column when batch = 1); used by the multi-run merge */

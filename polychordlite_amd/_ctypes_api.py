@@ -17,7 +17,7 @@ DUMPER_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), 
                         C.POINTER(C.c_double), C.c_double, C.c_double)
 
 LIKE_CALLBACK, LIKE_GAUSSIAN, LIKE_RASTRIGIN, LIKE_TWIN_GAUSSIAN, LIKE_CORR_GAUSSIAN = range(5)
-KERNEL_CLASSES = ("k_nhats", "k_slice", "k_consume", "k_apply", "k_clean", "k_covmats")
+KERNEL_CLASSES = ("k_nhats", "k_slice", "k_consume", "k_apply", "k_clean", "k_covmats", "k_bases_side")
 LIKE_KINDS = {"gaussian": LIKE_GAUSSIAN, "rastrigin": LIKE_RASTRIGIN, "twin_gaussian": LIKE_TWIN_GAUSSIAN,
               "corr_gaussian": LIKE_CORR_GAUSSIAN}
 
@@ -50,7 +50,7 @@ class Result(C.Structure):
                 ("ncluster", C.c_int), ("ncluster_dead", C.c_int), ("nTotal", C.c_int), ("batch", C.c_int),
                 ("t_generate", C.c_double), ("t_loop", C.c_double), ("t_final", C.c_double), ("t_total", C.c_double),
                 ("t_setup", C.c_double), ("t_results", C.c_double), ("t_teardown", C.c_double),
-                ("k_time_s", C.c_double * 6), ("k_launches", C.c_long * 6),
+                ("k_time_s", C.c_double * 8), ("k_launches", C.c_long * 8),
                 ("dead", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("entry", C.POINTER(C.c_double)),
                 ("live", C.POINTER(C.c_double)), ("nlive_final", C.c_int),
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),

@@ -221,26 +221,29 @@ std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialis
 struct Timing { double t_gen = 0, t_loop = 0, t_final = 0, t_total = 0; long rounds = 0, updates = 0, batches = 0, compactions = 0; };
 
 // HIP-event stopwatch per kernel class, on the engine's own stream (bench.py's roofline numbers)
-enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_N };
+enum { KT_NHATS = 0, KT_SLICE, KT_CONSUME, KT_APPLY, KT_CLEAN, KT_COV, KT_SIDE /* bases drawn ahead on the side stream */, KT_N };
 struct KTimer {
     bool on = false;
     unsigned mask = 0xFFFFFFFFu;            // kernel classes that are timed
     unsigned stride = 1; unsigned seen[KT_N] = {0};   // ... every stride-th launch of a class (an event pair costs the stream ~6 us)
     hipStream_t st = nullptr;
     std::vector<hipEvent_t> pool; size_t used = 0;
-    struct Span { int k; hipEvent_t a, b; };
+    struct Span { int k; hipEvent_t a, b; bool side; };
     std::vector<Span> open;
     double total_ms[KT_N] = {0}; long launches[KT_N] = {0};
     hipEvent_t get() { if (used == pool.size()) pool.push_back(hpool().get_event()); return pool[used++]; }
     hipEvent_t begin(int k) { if (!on || !((mask >> k) & 1u) || (seen[k]++ % stride) != 0 || open.size() >= MAX_OPEN) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); return e; }
-    void end(int k, hipEvent_t a) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e}); }
+    void end(int k, hipEvent_t a) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, st)); open.push_back({k, a, e, false}); }
+    // the same around a launch on another stream of the run (the bases drawn ahead): collect() waits for that span's end itself
+    hipEvent_t begin_on(int k, hipStream_t s2) { if (!on || !((mask >> k) & 1u) || (seen[k]++ % stride) != 0 || open.size() >= MAX_OPEN) return nullptr; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, s2)); return e; }
+    void end_on(int k, hipEvent_t a, hipStream_t s2) { if (!on || !a) return; hipEvent_t e = get(); HIPCHK(hipEventRecord(e, s2)); open.push_back({k, a, e, true}); }
     // Call after a stream synchronisation.  A round no longer synchronises, so the spans pile up between the moments that
     // do (an update with host work, a compaction, a growth, the end of the run); beyond MAX_OPEN open spans launches go
     // untimed (k_launches counts the timed ones) instead of creating events without bound.
     static constexpr size_t MAX_OPEN = 8192;
     void collect() {
         if (!on) return;
-        for (auto &sp : open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
+        for (auto &sp : open) { float ms = 0; if (sp.side) HIPCHK(hipEventSynchronize(sp.b)); HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b)); total_ms[sp.k] += ms; launches[sp.k]++; }
         open.clear(); used = 0;
     }
     void destroy() { for (auto e : pool) hpool().put_event(e); pool.clear(); }
@@ -345,7 +348,7 @@ struct Engine {
         HIPCHK(hipSetDevice(dev));
         st = hpool().get_stream(); st_copy = hpool().get_stream();
         kt.on = c.profile != 0; kt.st = st;
-        kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x3Fu);   // 1: every class; else bit k+1 = class k
+        kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x7Fu);   // 1: every class; else bit k+1 = class k
         kt.stride = std::max(1u, ((unsigned)c.profile >> 8) & 0xFFu);                       // bits 8..15: time every n-th launch of a class
         const int D = c.nDims, nDer = c.nDerived;
         S.D = D; S.nDer = nDer; S.nT = 2 * D + nDer + 2; S.nr = c.num_repeats; S.N = c.nlive;
@@ -1618,7 +1621,9 @@ struct Engine {
             if (rs.valid) continue;                                          // (a job for another nursery size: used or replaced when its turn comes)
             if (rs.used) HIPCHK(hipStreamWaitEvent(st_side, rs.consumed, 0));
             PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+            hipEvent_t es = kt.begin_on(KT_SIDE, st_side);
             (void)pc_launch_nhats_part(&S1, x, B, 1, st_side);
+            kt.end_on(KT_SIDE, es, st_side);
             HIPCHK(hipEventRecord(rs.ready, st_side));
             rs.valid = true; rs.batch = x; rs.B = B; rs.waited = false;
         }
