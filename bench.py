@@ -116,6 +116,40 @@ def latency_model(runs, kern):
     return out
 
 
+def live_pmc(workload):
+    """HBM bytes per launch of every kernel, measured now: two rocprofv3 passes over a short run of this script (FETCH_SIZE, then
+    WRITE_SIZE; --pmc with --kernel-trace only, one counter per pass, as MI355X_MICROARCH.md prescribes), summarised like
+    tools/pmc_summary.py (gfx950: FETCH_SIZE counts 64 B per 128-B request and is doubled).  None if the profiler is not there."""
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        tmp = tempfile.mkdtemp(prefix="pc_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        acc = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.abspath(__file__), "--workload", workload, "--no-cpu", "--no-extras", "--steps", "2", "--warmup", "1"],
+                           cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            acc[counter] = pmc_summary.per_kernel(d, counter)
+        shutil.rmtree(tmp, ignore_errors=True)
+        F, W = acc["FETCH_SIZE"], acc["WRITE_SIZE"]
+        if not F or not W:
+            return None
+        out = {}
+        for k in set(F) | set(W):
+            nf, sf = F.get(k, [0, 0.0]); nw, sw = W.get(k, [0, 0.0])
+            out[k] = {"launches": max(nf, nw, 1), "hbm_bytes_per_launch": (2.0 * sf / max(nf, 1) + sw / max(nw, 1)) * 1024.0}
+        return out
+    except Exception:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -209,6 +243,7 @@ def main():
     ap.add_argument("--other-configs", default="c3,c4,c5",
                     help="after the timed steps of the default workload (N = 1): one step each of these BASELINE configurations, reported "
                          "as `other_configs`; '' = skip")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/ instead of two profiled runs now")
     ap.add_argument("--no-extras", action="store_true", help="skip the figures after the timed region (general functor, concurrent sweep)")
     args = ap.parse_args()
 
@@ -402,12 +437,19 @@ def main():
         evals = float(sum(r["nlike"] for r in runs)); niter = float(sum(r["niter"] for r in runs))
         nurseries = float(sum(r["nbatches"] for r in runs))
         bpe = BYTES_PER_EVAL if args.workload == "c2" else algorithmic_bytes_per_iteration(nDims, nDer, nr, nlive) * niter / evals
-        pmc = {}
-        for name in ("r02_pmc.json", "r01_pmc.json"):
-            pth = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pth) and args.workload == "c2":
-                pmc = json.load(open(pth))["kernels"]; pmc_src = name
-                break
+        # HBM traffic per launch (PMC counters): measured now when the profiler is at hand (two short profiled runs of this
+        # script behind the timed region), else the committed passes of profiles/ for the metric configuration
+        pmc, pmc_src = {}, None
+        if extras and not args.no_live_pmc:
+            lp = live_pmc(args.workload)
+            if lp:
+                pmc, pmc_src = lp, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each, over 3 runs of this workload"
+        if not pmc:
+            for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+                pth = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(pth) and args.workload == "c2":
+                    pmc = json.load(open(pth))["kernels"]; pmc_src = "profiles/" + name
+                    break
         kern = []
         k_last = runs[-1]["kernel_time"]
         for name in sorted(k_last, key=lambda n: -sum(r["kernel_time"][n]["total_s"] for r in runs)):
@@ -416,7 +458,9 @@ def main():
                 continue
             own = own_bytes_per_launch(name, nDims, nDer, nr, nlive, B_)
             avg = kt / kl
-            hit = [v for k, v in pmc.items() if k.startswith(name if name != "k_consume" else "k_consume_par")]
+            pmc_name = {"k_consume": "k_consume_par" if wl["clustering"] == 0 else "k_consume_cl", "k_bases_side": "k_basis" if nDims > 64 else "k_nhats",
+                        "k_nhats": "k_whiten" if nDims > 64 else "k_nhats"}.get(name, name)
+            hit = sorted([v for k, v in pmc.items() if k.startswith(pmc_name)], key=lambda v: -v["launches"])
             kern.append({"kernel": name, "avg_launch_us": avg * 1e6, "launches_timed": kl, "timed_every": TIMED_STRIDE,
                          "own_bytes_per_launch": own, "own_achieved_GBs": own / avg / 1e9 if own else None,
                          "own_frac": own / avg / 1e9 / HBM_PEAK_GBS if own else None,
@@ -429,7 +473,7 @@ def main():
             achieved = per_launch_evals * bpe / (dom["avg_launch_us"] * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
-                    "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe,
+                    "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe, "traffic_source": pmc_src,
                     "whole_run_frac": evals * bpe / dt / 1e9 / HBM_PEAK_GBS,
                     "kernels": kern,
                     "stream": "side (drawn ahead of the nursery that uses them, next to the main stream's kernels)" if dom["kernel"] == "k_bases_side" else "main",

@@ -69,7 +69,8 @@ std::string fmt_e24(double v)
 //                                       every update -- most of its wall time at small nlive)
 //   <root>_phys_live.txt / -birth.txt   rewritten at every update
 //   <root>.stats                        rewritten at every update ("Still Active" clusters listed first)
-//   <root>.txt / _equal_weights.txt     weighted / equally weighted posterior from the dead points, at the end
+//   <root>.txt / _equal_weights.txt     weighted posterior from the dead points at the end; the equally weighted one is
+//                                       thinned at every update like the reference's and written at the end
 struct FileSink {
     std::string base, root;
     int nDims = 0, nDer = 0;
@@ -77,6 +78,10 @@ struct FileSink {
          cluster_posteriors = false;
     unsigned seed = 0; double logzero = -1e30, compression = 0.36787944117144233; int num_repeats = 1;
     long dead_written = 0, nlike_last = 0; int nposterior = 0, nequals = 0;
+    // the equally weighted posterior, thinned at every update like the reference's (run_time_info.f90:975-1026): entries =
+    // (log weight the entry was last accepted at, index of the point: dead point, or ndead_final + phantom kept by boost)
+    std::vector<double> eq_w; std::vector<long> eq_i; std::vector<char> eq_x;
+    long eq_done = 0, eq_xdone = 0; unsigned long long eq_draws = 0; double eq_max = -1.7e308;
     std::vector<long> nlike_last_g;
     std::vector<double> mu, sig;
     int feedback = 0, nlive_set = 1;
@@ -199,8 +204,33 @@ struct FileSink {
         std::fclose(f);
     }
     // weighted / equally weighted posteriors from the dead points (update_posteriors, run_time_info.f90:955-1066;
-    // write_posterior_file, read_write.F90:479-617).  A dead point is an equal-weight sample with probability
-    // weight / max weight; the uniform is keyed by its index so the thinning is reproducible.
+    // write_posterior_file, read_write.F90:479-617); the equally weighted list comes from thin_equals_round.
+    // One round of update_posteriors for the global equal-weight list: survivors of the earlier rounds are re-drawn against
+    // the ratio of their weight to the largest weight so far and move up to it, the points that joined the posterior stack
+    // since the last round (deaths in death order, then the phantoms boost_posterior kept) are drawn against it.  The trials
+    // are the numbered draws of the posterior domain of the counter RNG, in the order the reference's loops make them
+    // (thin_equals: array order with delete = overwrite-with-last, array_utils.f90:433-458; then the stack) -- so that with
+    // one cluster the list is, entry for entry, the one the oracle (and through it the reference) builds.
+    void thin_equals_round(const pchip_update &u)
+    {
+        auto draw = [&]() { const unsigned long long n = eq_draws++; return polychord_hip_keyed_uniform(seed, 6u, (unsigned)(n >> 32), 0u, (unsigned)n); };
+        for (long i = eq_done; i < u.ndead; ++i) if (u.logpost[i] > -1e29) eq_max = std::max(eq_max, u.logpost[i]);
+        for (long i = eq_xdone; i < u.n_extra; ++i) eq_max = std::max(eq_max, u.extra_logpost[i]);
+        for (size_t i = 0; i < eq_w.size();) {
+            if (eq_w[i] < eq_max) {
+                if (draw() < std::exp(eq_w[i] - eq_max)) { eq_w[i] = eq_max; ++i; }
+                else { eq_w[i] = eq_w.back(); eq_i[i] = eq_i.back(); eq_x[i] = eq_x.back(); eq_w.pop_back(); eq_i.pop_back(); eq_x.pop_back(); }
+            } else ++i;
+        }
+        for (long i = eq_done; i < u.ndead; ++i) {
+            if (!(u.logpost[i] > -1e29)) continue;              // failed spawns never entered the stack
+            if (draw() < std::exp(u.logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(0); }
+        }
+        for (long i = eq_xdone; i < u.n_extra; ++i)
+            if (draw() < std::exp(u.extra_logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(1); }
+        eq_done = u.ndead; eq_xdone = u.n_extra;
+    }
+
     void posterior_files(const pchip_update &u)
     {
         const int np = nDims + nDer, npars = u.npars;
@@ -221,11 +251,18 @@ struct FileSink {
             const double wgt = std::exp(lp(i) - mx);
             sw += wgt;
             for (int k = 0; k < np; ++k) { mu[k] += wgt * row[k]; sig[k] += wgt * row[k] * row[k]; }
-            if (!fp && !fe) continue;
+            if (!fp) continue;
             tail = fmt_e24(-2 * row[np + 1]);
             for (int k = 0; k < np; ++k) tail += fmt_e24(row[k]);
             if (fp && wgt > 0.0) { std::fprintf(fp, "%s%s\n", fmt_e24(wgt).c_str(), tail.c_str()); nposterior++; }
-            if (fe && polychord_hip_keyed_uniform(seed, 6u, 0u, 0u, (unsigned)i) < wgt) { std::fprintf(fe, "%s%s\n", fmt_e24(1.0).c_str(), tail.c_str()); nequals++; }
+        }
+        if (fe) {                                              // the list the update rounds left, in its own order
+            for (size_t k = 0; k < eq_i.size(); ++k) {
+                const double *row = eq_x[k] ? u.extra + (size_t)eq_i[k] * npars : u.dead + (size_t)eq_i[k] * npars;
+                tail = fmt_e24(-2 * row[np + 1]);
+                for (int c = 0; c < np; ++c) tail += fmt_e24(row[c]);
+                std::fprintf(fe, "%s%s\n", fmt_e24(1.0).c_str(), tail.c_str()); nequals++;
+            }
         }
         for (int k = 0; k < np; ++k) { mu[k] /= sw; sig[k] = std::sqrt(std::fabs(sig[k] / sw - mu[k] * mu[k])); }
         if (fp) std::fclose(fp);
@@ -312,6 +349,7 @@ struct FileSink {
             rows(f2, u.live, 0, u.nlive, u.npars, false, true);
             std::fclose(f1); std::fclose(f2);
         }
+        if (equals && u.final_call != 2) thin_equals_round(u);
         if (u.final_call == 1 && (posteriors || equals)) { posterior_files(u); if (cluster_posteriors) cluster_files(u); }
         if (write_stats) stats(u);
         if (feedback >= 1 && u.final_call == 0) progress(u);

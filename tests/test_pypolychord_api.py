@@ -833,9 +833,10 @@ def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nli
     """R13 in production mode (keyed streams, B chains per nursery) against the oracle -- whose posterior machinery the
     reference binary pins (tests/test_oracle_pinned.py): the weighted posterior <root>.txt holds the same points with the
     same weights, the phantoms kept by boost_posterior included (their Bernoulli trials are keyed by the phantom's id in
-    both); the equally weighted file is thinned once at the end with probability weight / largest weight instead of
-    incrementally at every update (the same marginal probability for every point: run_time_info.f90:975-1026 re-thins
-    survivors by the ratio of successive maxima), so its size is compared with its expectation."""
+    both); the equally weighted file is thinned at every update like the reference's (run_time_info.f90:975-1026: survivors
+    re-drawn against the ratio of successive maxima, newcomers against the current one), with the numbered draws of the
+    posterior stream in the reference's order: with one cluster and no boost it is the oracle's list ROW FOR ROW; where
+    clusters die between updates or phantoms join the stack the rounds differ and its size is compared with its expectation."""
     from tests import oracle_api as orc
     lib = engine.load(); lib.polychord_hip_set_option(b"batch", float(B))
     try:
@@ -864,6 +865,10 @@ def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nli
     assert abs(eq.shape[0] - expect) < 5 * np.sqrt(var) + 1, (eq.shape[0], expect)
     assert abs(o["nequals"] - expect) < 5 * np.sqrt(var) + 1                       # and so is the oracle's (the reference's)
     assert np.all(eq[:, 0] == 1.0)
+    if boost == 0.0 and not clus:
+        ref_eq = o["equal_rows"]                                   # [-2 logL, theta, phi] in the order of RTI%equals_global
+        assert eq.shape[0] == o["nequals"] == ref_eq.shape[0], (eq.shape[0], o["nequals"])
+        assert (np.abs(eq[:, 1:] - ref_eq) / np.maximum(1e-300, np.abs(ref_eq))).max() < 1e-7
 
 
 @pytest.mark.gpu
