@@ -45,7 +45,7 @@
 struct ClSlot { int c, p, o, src; };                       // cluster, list position, nn owner code, chain whose last baby owns the slot in this launch (-1)
 struct ClChain { double last; int nlike, epoch, ca, rank; };
 struct ClSorted { double L, e; int slot, pad; };             // logL, exp(logL - Lhi), slot (sorted snapshot) / chain (candidates)
-struct ClCand { double L, e, inv; int w, pad; };           // ... and exp(Lhi - logL)
+struct ClCand { double L, e; int w, pad; };
 struct ClHead { double logw, postXs, zl, contour; int dead_idx, dead_src; unsigned dead_cuid, ph_cuid; int ph_base, pad; };
 struct ClOwn { double zp, zp2, zpx, kzp, kp2a, kp2b, kzpx, rzp, rzp2, rzpx; int touched, pad; };   // a cluster's own accumulators (linear) and their scales
 
@@ -150,13 +150,16 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     __syncthreads();
     for (int s = tid; s < Ncap; s += CL_NT) if (sS[s].c >= 0) lst[lstOff[sS[s].c] + sS[s].p] = s;
     // ranks of the candidates (last babies) among themselves: (logL, chain) ascending
+    // (by integer key: a strict total order whatever the values -- a NaN logL, which a singular covariance can produce, must not
+    //  make two candidates share a rank)
     for (int w = tid; w < T; w += CL_NT) {
         const double x = sCh[w].last;
+        const unsigned long long kx = d2key(x);
         int r = 0;
-        for (int v = 0; v < T; ++v) { const double y = sCh[v].last; r += (y < x) || (y == x && v < w); }
-        sCh[w].rank = r; sCand[r] = ClCand{x, exp(x - Lhi), exp(Lhi - x), w, 0};
+        for (int v = 0; v < T; ++v) { const unsigned long long ky = d2key(sCh[v].last); r += (ky < kx) || (ky == kx && v < w); }
+        sCh[w].rank = r; sCand[r] = ClCand{x, exp(x - Lhi), w, 0};
     }
-    if (tid == 0) sCand[T] = ClCand{PC_HUGE, 0.0, 0.0, -1, 0};
+    if (tid == 0) sCand[T] = ClCand{PC_HUGE, 0.0, -1, 0};
     // the exponential of every death this launch can make (its first T snapshot points), and the liveness tags of the candidate
     // lists: entry s < Ncap = cluster of the point that occupied slot s when the lists were made, while it lives; entry
     // Ncap + w = cluster of the last baby of chain w, from its acceptance to its death; -1 otherwise (the last entry: no candidate)
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         int status = PC_ST_RUNNING, error = PC_ERR_NONE, need_drop = 0, any_death = 0;
         const double logzero = S.logzero, logZ0 = ctl->logZ, logZ20 = ctl->logZ2;
         // ---- per-lane cluster state (cluster q = lane + 64 j): log volume, linear volume / factors / <Z X_q>, live log-sum-exp
-        double Xp[J], XL[J], Fl[J], Gl[J], Flog[J], Glog[J], ZX[J], kZX[J], rZX[J], k2a[J], lref[J], lsum[J], Eq[J], kd[J], ikd[J], thr[J];
+        double Xp[J], XL[J], Fl[J], Gl[J], Flog[J], Glog[J], ZX[J], kZX[J], rZX[J], k2a[J], lref[J], lsum[J], Eq[J], kd[J], thr[J];
         int n[J]; unsigned uid[J];
         double R0 = -PC_HUGE, rZXmax = -PC_HUGE;
 #pragma unroll
@@ -219,14 +222,19 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                 XL[j] = in ? exp(Xp[j] - lxm0) : 0.0;
                 k2a[j] = exp(rZX[j] + Lhi - rZ2);
                 Eq[j] = (in && n[j] > 0) ? exp(lref[j] - R0) : 0.0;
-                kd[j] = in ? exp(Lhi - lref[j]) : 0.0; ikd[j] = in ? exp(lref[j] - Lhi) : 0.0;
+                kd[j] = in ? exp(Lhi - lref[j]) : 0.0;
                 a += XL[j]; b += (in && n[j] > 0) ? (lsum[j] * srcp[n[j]]) * XL[j] * Eq[j] : 0.0;
             }
             sumXL = wave_sum<4>(a); acc = wave_sum<4>(b);
         }
         double E0 = exp(S.log_prec + rZ - lxm0 - R0);              // more_samples_needed in linear space: acc < Zl * E0
         double kR = exp(Lhi - R0);
-        const double UT = exp(lx_last + S.log_cf - lxm0);          // update trigger: sum_p X_p <= X_last_update * compression_factor
+        // (the launch's constants live in vector registers: the loop has more wave-uniform values than scalar registers, and a
+        //  spilled scalar costs a v_readlane and its hazard slots at every use)
+        double kZv = kZ, k2bv = k2b, UTv = exp(lx_last + S.log_cf - lxm0), Lhiv = Lhi, lxm0v = lxm0, lprec = S.log_prec, rZv = rZ;
+        asm volatile("" : "+v"(kZv), "+v"(k2bv), "+v"(UTv), "+v"(Lhiv), "+v"(lxm0v), "+v"(lprec), "+v"(rZv));
+        asm volatile("" : "+v"(E0), "+v"(kR), "+v"(R0));
+        // update trigger: sum_p X_p <= X_last_update * compression_factor (UTv)
         // ---- death order: the sorted snapshot and the newcomers of this launch
         int ptr = 0;
         double curL; int curS, curC; double eCur;
@@ -258,10 +266,13 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
             if (S.max_ndead == 0) more = false;
             else if (S.max_ndead > 0 && ndead >= S.max_ndead) more = false;
             else if (S.use_prec) { if (!(acc > 0.0) || acc < Zl * E0) more = false; }
-            if (!more || failures > S.nfail) { status = PC_ST_DONE; break; }
+            if (!more || failures > S.nfail) {
+                status = PC_ST_DONE;
+                break;
+            }
             if (i_nursery == 0) break;
             const double Lg = fmin(curL, nmL);
-            if (Lg > Lhi) break;                                    // the next death leaves the launch's window: new references (host relaunches)
+            if (Lg > Lhiv) break;                                   // the next death leaves the launch's window: new references (host relaunches)
             const int w = i_nursery - 1;
             i_nursery--;
             const double my_blog = pf_blog; const int4 my_a = pf_a, my_b = pf_b;
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                     const double l0 = slogn[nd], l1 = slogn[nd + 1], l2 = slogn[nd + 2], r1 = srcp[nd + 1], r2 = srcp[nd + 2];
                     if (cd != predC) {                 // (a newcomer died where a snapshot point was expected: fetch the row now)
 #pragma unroll
-                        for (int j = 0; j < J; ++j) { const int q = lane + 64 * j; const double xr = (q < nc) ? S.XpXq[(size_t)cd * maxc + q] : NEGBIG; xlin[j] = exp(xr - 2.0 * lxm0); }
+                        for (int j = 0; j < J; ++j) { const int q = lane + 64 * j; const double xr = (q < nc) ? S.XpXq[(size_t)cd * maxc + q] : NEGBIG; xlin[j] = exp(xr - 2.0 * lxm0v); }
                     }
                     const ClOwn own = sOwn[cd];
                     const double XLd = cl_get<J>(XL, cd), Fd = cl_get<J>(Fl, cd), Gd = cl_get<J>(Gl, cd), ZXd = cl_get<J>(ZX, cd), k2ad = cl_get<J>(k2a, cd);
@@ -359,8 +370,8 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                     // ---- update_evidence (run_time_info.f90:211-296); every accumulation reads the state before the death
                     const double tZ = XLd * c1;
                     const double tXX = XXs * (eL * c1 * r2);                       // <X^2> L^2 / ((n+1)(n+2))
-                    Zl += tZ * kZ;                                                 // <Z> += X L / (n+1)
-                    Z2l += 2.0 * (ZXd * c1 * k2ad + tXX * k2b);                    // <Z^2> += 2 <Z X> L/(n+1) + 2 <X^2> L^2/((n+1)(n+2))
+                    Zl += tZ * kZv;                                                // <Z> += X L / (n+1)
+                    Z2l += 2.0 * (ZXd * c1 * k2ad + tXX * k2bv);                    // <Z^2> += 2 <Z X> L/(n+1) + 2 <X^2> L^2/((n+1)(n+2))
 #pragma unroll
                     for (int j = 0; j < J; ++j) {                                  // <Z X_q>, one cluster per lane
                         const bool self = lane + 64 * j == cd;
@@ -412,22 +423,26 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                     const int slot = slot_del;
                     const int na = cl_geti<J>(n, ca);                               // (after the death: cd may be ca)
                     const double lref_a = cl_get<J>(lref, ca), lsum_a = cl_get<J>(lsum, ca);
-                    const ClCand me = sCand[ch.rank];                            // exp(Llast - Lhi) and its inverse, made with the ranks
-                    double nref = lref_a, nsum, nEq = cl_get<J>(Eq, ca), nkd = cl_get<J>(kd, ca), nikd = cl_get<J>(ikd, ca);
+                    const ClCand me = sCand[ch.rank];                            // exp(Llast - Lhi), made with the ranks
+                    double nref = lref_a, nsum, nEq = cl_get<J>(Eq, ca), nkd = cl_get<J>(kd, ca);
                     if (na == 0 || Llast > lref_a) {                             // the cluster's reference moves to the newcomer (utils.F90 logsumexp bookkeeping)
-                        nsum = (na == 0) ? 1.0 : lsum_a * (me.inv * nikd) + 1.0; // lsum exp(lref - Llast) + 1
+                        nsum = (na == 0) ? 1.0 : lsum_a * exp(lref_a - Llast) + 1.0;
                         nref = Llast;
                         if (nref - R0 > 600.0) {                                 // (cannot be represented about the launch's reference: re-base every cluster)
                             const double R1 = nref;
 #pragma unroll
                             for (int j = 0; j < J; ++j) Eq[j] = (lane + 64 * j < nc && n[j] > 0) ? exp(lref[j] - R1) : 0.0;
-                            E0 = exp(S.log_prec + rZ - lxm0 - R1); kR = exp(Lhi - R1);
+                            E0 = exp(lprec + rZv - lxm0v - R1); kR = exp(Lhiv - R1);
                             R0 = R1;
                         }
-                        nEq = me.e * kR; nkd = me.inv; nikd = me.e;
-                    } else nsum = lsum_a + me.e * nkd;                           // lsum + exp(Llast - lref)
+                        nEq = exp(nref - R0); nkd = exp(Lhiv - nref);            // (a newcomer may sit far above the window: no products of precomputed factors here)
+                    } else {
+                        // lsum + exp(Llast - lref): the product of the two precomputed factors where both are ordinary numbers
+                        const bool plain = fabs(Llast - Lhiv) < 600.0 && fabs(Lhiv - lref_a) < 600.0;
+                        nsum = lsum_a + (plain ? me.e * nkd : exp(Llast - lref_a));
+                    }
 #pragma unroll
-                    for (int j = 0; j < J; ++j) if (lane + 64 * j == ca) { n[j] = na + 1; lref[j] = nref; lsum[j] = nsum; Eq[j] = nEq; kd[j] = nkd; ikd[j] = nikd; }
+                    for (int j = 0; j < J; ++j) if (lane + 64 * j == ca) { n[j] = na + 1; lref[j] = nref; lsum[j] = nsum; Eq[j] = nEq; kd[j] = nkd; }
                     if (lane == 0) {
                         // list bookkeeping.  Engine rule (oracle keyed mode): a newcomer that replaces a death of its own cluster takes
                         // the dead point's position -- nothing moves.  Otherwise the dying cluster's last entry fills the hole
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
                     predC = (curL <= nmL) ? curC : -1;                            // (a newcomer that dies next has its row fetched when it does)
                     if (predC >= 0) {
 #pragma unroll
-                        for (int j = 0; j < J; ++j) xlin[j] = exp(xr[j] - 2.0 * lxm0);
+                        for (int j = 0; j < J; ++j) xlin[j] = exp(xr[j] - 2.0 * lxm0v);
                     }
                     replaced = true;
                     if (nd - 1 == 0 && cd != ca) need_drop = 1;                 // a cluster died (delete_cluster): the workgroup takes over
@@ -470,8 +485,8 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
             failures = replaced ? 0 : failures + 1;
             if (!replaced) nlike_failed += w_nlike;
             // ---- update trigger (nested_sampling.F90:321), delete_cluster (:339)
-            const bool update = sumXL <= UT;
-            if (update) lx_last = lxm0 + log(sumXL);
+            const bool update = sumXL <= UTv;
+            if (update) lx_last = lxm0v + log(sumXL);
             if (need_drop) { if (update) status = PC_ST_UPDATE; break; }
             if (update) { status = PC_ST_UPDATE; break; }
         }
@@ -516,7 +531,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     }
     __syncthreads();
     // ------------------------------------------------------------------ write back (all waves)
-    const long long T0c = clock64();
     int status = out_i[0];
     const int i_nursery = out_i[2], need_drop = out_i[7], seg_hi = out_i[8];
     int epoch = out_i[3];
@@ -526,7 +540,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         S.live_logL[s] = sL[s]; S.live_cluster[s] = r.c; S.live_pos[s] = r.p; S.nn_slot_owner[s] = r.o; S.slot_src[s] = r.src;
         if (r.c >= 0) S.cl_list[(size_t)r.c * Ncap + r.p] = s;
     }
-    const long long T1 = clock64(); if (tid == 0) ctl->dbg[0] += T1 - T0c;
     for (int c = tid; c < S.B; c += CL_NT) S.nn_chain_slot[c] = sCS[c];
     for (int c = tid; c < nc; c += CL_NT) {
         const ClOwn o = sOwn[c];
@@ -545,7 +558,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (add[u] != 0.0) S.XpXq[at[u]] = v[u] + add[u];
     }
-    const long long T2 = clock64(); if (tid == 0) ctl->dbg[1] += T2 - T1;
     // plan records of the chains this launch consumed
     for (int w = i_nursery + tid; w <= seg_hi; w += CL_NT) {
         const ClHead r = sHead[w];
@@ -559,7 +571,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
         *(PcPlanHead *)&S.plan[w] = h;
         for (int m = 0; m < nw; ++m) S.plan[w].ph_mask[m] = masks[(size_t)w * nw + m];
     }
-    const long long T3 = clock64(); if (tid == 0) ctl->dbg[2] += T3 - T2;
     // find_min_loglikelihoods (run_time_info.f90:883-909), once: lowest (logL, list position) of every cluster
     for (int c = tid; c < CL_MAXC; c += CL_NT) { kmin[c] = KEY_HUGE; lstOff[c] = 0x7fffffff; }
     __syncthreads();
@@ -570,7 +581,6 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
     for (int s = tid; s < Ncap; s += CL_NT) { const ClSlot r = sS[s]; if (r.c >= 0 && d2key(sL[s]) == kmin[r.c] && r.p == lstOff[r.c]) { S.imin_slot[r.c] = s; S.logLp[r.c] = sL[s]; } }
     for (int c = tid; c < nc; c += CL_NT) if (kmin[c] == KEY_HUGE) { S.imin_slot[c] = -1; S.logLp[c] = PC_HUGE; }
     __syncthreads();
-    const long long T4 = clock64(); if (tid == 0) ctl->dbg[3] += T4 - T3;
     int ncd = ctl->ncluster_dead, cluster_deleted = 0;
     if (need_drop) {
         // delete_cluster (run_time_info.f90:507-598): drop the first empty cluster, keep the others' order

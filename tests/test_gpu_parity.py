@@ -520,7 +520,10 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,nDer,nlive,nr,box", [("rastrigin", 4, 0, 400, 12, (-5.12, 5.12)), ("twin_gaussian", 8, 1, 300, 16, (-1.0, 1.0)),
-                                                     ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12))])
+                                                     ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12)),
+                                                     ("rastrigin", 2, 0, 400, 70, (-5.12, 5.12)),          # two phantom-mask words per chain
+                                                     ("rastrigin", 3, 0, 2400, 9, (-5.12, 5.12)),          # more than 64 clusters alive: two clusters per lane
+                                                     ("twin_gaussian", 20, 1, 400, 10, (-1.0, 1.0))])      # steep: launches that end at their 300-nat window
 def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, box):
     """several clusters: the one-wave contraction (pc_clus.hip: deaths from the sorted snapshot, evidence accumulators as
     (m, s) pairs, one cluster per lane) against the general kernel it replaces (settings.ablate bit 5 sends every launch
@@ -534,6 +537,7 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
         runs.append(api.run(s, L, P))
     a, b = runs
     assert a["ncluster_peak"] >= 2 and a["ncluster_dead"] >= 2          # clusters were found, and clusters died on the way
+    if D == 3: assert a["ncluster_peak"] > 64
     for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak"):
         assert a[k] == b[k], (k, a[k], b[k])
     assert abs(a["logZ"] - b["logZ"]) < 1e-10 and abs(a["logZerr"] - b["logZerr"]) < 1e-10
@@ -541,3 +545,26 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
     assert np.abs(a["logweights"] - b["logweights"]).max() < 1e-9
     assert np.allclose(a["logZp"], b["logZp"], atol=1e-9) and np.allclose(a["varlogZp"], b["varlogZp"], atol=1e-9)
     assert np.array_equal(a["live"], b["live"])
+
+
+@pytest.mark.gpu
+def test_clustered_contraction_with_a_chain_that_has_no_number(engine):
+    """two repeats in ten dimensions, 200 live points and a nursery of 100: clusters of fewer points than dimensions have singular
+    covariances, and a chain that starts there comes back with NaN for its last logL.  Such a chain must take the same place among
+    the launch's candidates in both contraction kernels (it used to share rank 0 with the lowest real candidate in the one-wave
+    kernel: two writers of one record, a run that ended early and not the same way twice); found by tools/dev/fuzz_parity.py"""
+    api = engine
+    L, P, keep = api.make_problem("rastrigin", 10, 0, -5.12, 5.12)
+    runs = []
+    for ab in (0, 0, 32):
+        s = _settings(api, 10, 0, nlive=200, num_repeats=2, seed=8222, batch=100, do_clustering=1, compression_factor=0.9)
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    a, a2, b = runs
+    assert a["ncluster_dead"] >= 2 and a["ndead"] > 4000
+    for o in (a2, b):
+        for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates"):
+            assert a[k] == o[k], (k, a[k], o[k])
+        assert abs(a["logZ"] - o["logZ"]) < 1e-10
+        assert np.array_equal(a["dead"][:, :-2], o["dead"][:, :-2], equal_nan=True)
+        assert np.array_equal(a["live"], o["live"], equal_nan=True)
