@@ -28,10 +28,12 @@ extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
 int pc_nhats_splittable(const PcState *);
-int pc_launch_nhats_part(const PcState *, unsigned, int, int, hipStream_t);
+int pc_launch_nhats_part(const PcState *, unsigned, int, int, hipStream_t, int);
 int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_slice_fusable(const PcState *);
 int pc_launch_slice_fused(const PcState *, unsigned, int, hipStream_t);
+int pc_slice_t_ok(const PcState *, int);
+int pc_launch_slice_t(const PcState *, unsigned, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
@@ -1560,7 +1562,8 @@ struct Engine {
             // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
             //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
             const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
-            const bool split = splittable && g_active_dev[dev & 63].load(std::memory_order_relaxed) == 1;
+            const bool multi = g_active_dev[dev & 63].load(std::memory_order_relaxed) > 1;
+            const bool split = splittable && !multi;
             bool fused_slice = false;
             if (splittable) {
                 // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
@@ -1570,17 +1573,20 @@ struct Engine {
                 if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }
                 else {
                     if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
-                    (void)pc_launch_nhats_part(&S, batch, B, 1, st);
+                    (void)pc_launch_nhats_part(&S, batch, B, 1, st, (multi || (cfg.ablate & 128)) ? 1 : 0);
                 }
                 rs.valid = false;
                 fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
-                if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st);
+                if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st, 0);
             }
             else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             kt.end(KT_NHATS, e0);
             hipEvent_t e1 = spec ? nullptr : kt.begin(KT_SLICE);
             S.spec_guard = spec ? 1 : 0;                                         // (the kernel looks at the contraction's verdict first)
             if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
+            // next to other runs of this device (or settings.ablate bit 6): the lane = chain kernel (pc_slice_t.hip), the same
+            // numbers from 1/60 of the wavefronts
+            else if (fused_slice && !spec && (multi || (cfg.ablate & 64)) && pc_slice_t_ok(&S, h_ctl->ncluster)) (void)pc_launch_slice_t(&S, batch, B, st);
             else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             S.spec_guard = 0;
             kt.end(KT_SLICE, e1);
@@ -1622,7 +1628,7 @@ struct Engine {
             if (rs.used) HIPCHK(hipStreamWaitEvent(st_side, rs.consumed, 0));
             PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
             hipEvent_t es = kt.begin_on(KT_SIDE, st_side);
-            (void)pc_launch_nhats_part(&S1, x, B, 1, st_side);
+            (void)pc_launch_nhats_part(&S1, x, B, 1, st_side, (cfg.ablate & 128) ? 1 : 0);
             kt.end_on(KT_SIDE, es, st_side);
             HIPCHK(hipEventRecord(rs.ready, st_side));
             rs.valid = true; rs.batch = x; rs.B = B; rs.waited = false;

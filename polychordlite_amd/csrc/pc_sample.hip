@@ -1447,6 +1447,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
     // enqueued before the host knew how the previous nursery ended: only if the contraction left its go-ahead for THIS nursery
     if (S.spec_guard && S.ctl->spec_ok != (int)batch) return;
     __builtin_amdgcn_s_setprio(3);                 // a chain is one long dependent instruction stream: it goes first on its SIMD
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    const long long kc0 = clock64(), kw0 = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63, wv = (WPB > 1) ? (int)(threadIdx.x >> 6) : 0, chain = blockIdx.x * WPB + wv;
     const size_t per_wave = ((size_t)S.D + S.nr + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0) + 1) & ~(size_t)1;   // doubles
     double *ybuf = (double *)smem + (size_t)wv * per_wave;   // [D] (corr gaussian only)
@@ -1485,6 +1488,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
         seed_cluster = __builtin_amdgcn_readfirstlane(sel); slot = __builtin_amdgcn_readfirstlane(sl);
         contour = S.logLp[seed_cluster];
     } else { slot = S.ch_seed_slot[chain]; contour = S.ch_contour[chain]; }
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    const long long kp1 = clock64();
+#endif
     double x0[DPL];
     {
         const double *seed = S.live + (size_t)slot * nT;
@@ -1501,6 +1507,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
     }
     // pool mode: the babies land in this chain's rows of the phantom array; none of them is a phantom before the chain is consumed
     if (S.pool) for (int i = lane; i < nr; i += 64) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    const long long kp2 = clock64();
+#endif
     ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, false, 0.0, 0.0, 0.0, 0.0};
     const bool corr = S.like.kind == PC_LIKE_CORR_GAUSSIAN;
     C.quad = (corr || S.like.kind == PC_LIKE_GAUSSIAN) && !(S.ablate & 1);
@@ -1592,6 +1601,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
         __syncthreads();
     }
 
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    const long long kp3 = clock64();
+#endif
     double ua = 0.0, ub = 0.0;                     // uniforms of 4 consecutive slices, 32 each
     double nh[DPL], nh_next[DPL], w_next;
     // ---- FW: all directions of the chain whitened up front, lane = direction (what a thread of k_nhats did for its
@@ -1651,6 +1663,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
 
 #ifdef SLICE_DBG
     long long scy[6] = {0, 0, 0, 0, 0, 0}; long long nev = 0, ev2 = 0;
+#if SLICE_DBG == 2
+    const long long kc1 = clock64();
+#endif
 #endif
     double w = w_next;
 #pragma unroll
@@ -1873,7 +1888,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
         scy[0] += c1 - c0; scy[1] += c2 - c1; scy[2] += c3 - c2; scy[3] += c4 - c3; scy[4] += c5 - c4;
 #endif
     }
-#ifdef SLICE_DBG
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    const long long kc2 = clock64();
+#elif defined(SLICE_DBG)
     if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; S.ctl->dbg[6] += scy[5]; S.ctl->dbg[7] += ev2; }
 #endif
     if (lane == 0) S.ch_nlike[chain] = C.nlike;
@@ -1907,6 +1924,18 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
             for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
         }
     }
+#if defined(SLICE_DBG) && SLICE_DBG == 2
+    // whole-kernel view, all chains: cycles before / inside / after the slice loop (sums and maxima), launch-relative start
+    {
+        const long long kc3 = clock64(), kw3 = wall_clock64();
+        unsigned long long *g = (unsigned long long *)S.ctl->dbg;
+        if (lane == 0) {
+            atomicAdd(&g[0], (unsigned long long)(kp1 - kc0)); atomicAdd(&g[1], (unsigned long long)(kp2 - kp1)); atomicAdd(&g[2], (unsigned long long)(kp3 - kp2));
+            atomicAdd(&g[3], (unsigned long long)(kc1 - kp3)); atomicAdd(&g[4], (unsigned long long)(kc2 - kc1)); atomicAdd(&g[5], (unsigned long long)(kc3 - kc2));
+            atomicMax(&g[6], (unsigned long long)(kw3 - kw0));       // longest chain, 100 MHz ticks
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1932,7 +1961,8 @@ extern "C" int pc_nhats_splittable(const PcState *S)
 }
 // (two tile buffers up to nDims 112; beyond that one, with a barrier more per tile: 160 KB of LDS)
 static size_t pc_nhats_q32_lds(int D) { const int NR = ((D + 15) / 16) * 16; return sizeof(double) * (2 * 4 * 34 + (size_t)(NR + (NR <= 112 ? 32 : 16)) * 129); }
-extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchains, int part, hipStream_t st)
+extern "C" int pc_launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st);
+extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchains, int part, hipStream_t st, int packed)
 {
     if (!pc_nhats_splittable(S)) return 1;
     const int D = S->D;
@@ -1958,6 +1988,8 @@ extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchain
         return 0;
     }
     const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
+    // several runs on the device (packed != 0): the same bases, lane = basis (pc_slice_t.hip)
+    if (part == 1 && packed && pc_launch_bases_t(S, batch, nchains, st) == 0) return 0;
     if (part == 1) {
         if (D <= 8) hipLaunchKernelGGL((k_nhats<8, 64, 1>), grid, dim3(64), sh, st, *S, batch);
         else if (D <= 16) hipLaunchKernelGGL((k_nhats<16, 64, 1>), grid, dim3(64), sh, st, *S, batch);

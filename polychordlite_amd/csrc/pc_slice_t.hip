@@ -1,0 +1,540 @@
+// pc_slice_t.hip -- the slice-sampling chains with the layout turned round: lane = chain.
+//
+// k_slice (pc_sample.hip) gives a chain a whole wavefront, lane = coordinate: the shortest path for ONE run, whose nursery of
+// B chains then occupies B wavefronts for the length of a launch although 20 of 64 lanes work and the wave waits on its own
+// dependent operations most of the time.  When several runs share a device (pchip_run_repeats: repeats of one problem) the
+// chip's time is what counts, not a launch's latency.  Here a wavefront carries 64 chains, one per lane, every coordinate loop
+// runs inside the lane, and a nursery of 1000 chains is 16 wavefronts: sixteen runs in flight leave each other the chip.
+//
+// The same numbers as k_slice's fused path (template FW > 0: seed choice and whitening inside the kernel), bit for bit:
+// the same keyed draws (seed: PC_DOM_SEED; deck: PC_DOM_SHUFFLE; slice s, draw k: PC_DOM_SLICE index 128 s + k), the same
+// operations in the same order -- whitening row sums in ascending column, the norm on four partial sums, the chord's
+// coefficients summed in the order of the wave butterfly (a balanced tree over rows of 16 coordinates), the closed form
+// along the chord, derived parameters summed in ascending coordinate.  tests/test_gpu_parity.py runs both on the same
+// problems and compares every row.
+//
+// Restates SliceSampling / slice_sample (chordal_sampling.f90:7-92, 163-273), GenerateSeed (generate.F90:19-55) for one
+// cluster, generate_nhats' whitening (chordal_sampling.f90:73-82), calculate_point (calculate.f90:6-50) for the built-in
+// Gaussian (gaussian.f90:25-37) under the uniform box prior (priors.f90:40-55).
+//
+// Scope (pc_slice_t_ok): what the fused k_slice takes (nDims <= 24, one grade, keyed draws, raw bases in HBM), the built-in
+// Gaussian in closed form along the chord, ONE cluster at launch, num_repeats <= 255, derived parameters from the
+// per-baby theta rows (the order k_slice uses whenever those rows fit its LDS).
+#include "pc_state.h"
+#include <cstdlib>
+
+namespace {
+
+struct Q3 { double a, b, c; };
+
+// the lower triangle of the Cholesky factor in the order the whitening uses it: column after column, rows downwards
+template <int D>
+struct TriMap {
+    int aa[D * (D + 1) / 2], bb[D * (D + 1) / 2];
+    constexpr TriMap() : aa{}, bb{} { int e = 0; for (int b = 0; b < D; ++b) for (int a = b; a < D; ++a) { aa[e] = a; bb[e] = b; ++e; } }
+};
+
+// Sums in the order of wave_sum<NROWS> (pc_dev.h) over lanes = coordinates: a balanced tree over each row of 16 coordinates,
+// rows added left to right.  Leaves past nDims are the +0.0 the idle lanes of k_slice hold (the additions of those zeros
+// are made, as the butterfly makes them).  Depth first: log2(16) partial results alive, not all the leaves.
+template <int DT, int LO, int N, class F>
+__device__ __forceinline__ Q3 tree3(const F &leaf)
+{
+#pragma clang fp contract(off)
+    if constexpr (LO >= DT) return Q3{0.0, 0.0, 0.0};
+    else if constexpr (N == 1) return leaf(LO);
+    else {
+        const Q3 l = tree3<DT, LO, N / 2>(leaf);
+        if constexpr (LO + N / 2 >= DT && N / 2 >= 16) return l;       // (never: rows are combined below)
+        const Q3 r = tree3<DT, LO + N / 2, N / 2>(leaf);
+        return Q3{l.a + r.a, l.b + r.b, l.c + r.c};
+    }
+}
+template <int DT, class F>
+__device__ __forceinline__ Q3 wave_order_sum3(const F &leaf)
+{
+#pragma clang fp contract(off)
+    const Q3 r0 = tree3<DT, 0, 16>(leaf);
+    if constexpr (DT <= 16) return r0;
+    else { const Q3 r1 = tree3<DT, 16, 16>(leaf); return Q3{r0.a + r1.a, r0.b + r1.b, r0.c + r1.c}; }
+}
+
+// DT = nDims (1 .. 24); UNIT: the prior is the unit hypercube itself (lo = 0, span = 1: theta = cube, bit for bit)
+template <int DT, bool UNIT>
+__global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp)
+{
+#pragma clang fp contract(off)       // every fused multiply-add below is written out: the roundings of k_slice, whatever this kernel's shape suggests to the compiler
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = DT, FW = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24), NP = D * (D + 1) / 2;
+#ifdef SLICE_T_DBG
+    const long long cB = clock64();
+#endif
+    const int lane = threadIdx.x;
+    const int chain_raw = blockIdx.x * 64 + lane;
+    const bool act = chain_raw < nchains;                 // lanes past the nursery follow its last chain and store nothing
+    const int chain = act ? chain_raw : nchains - 1;
+    const int nr = S.nr, nT = S.nT;
+    const double logzero = S.logzero;
+    double *sL = (double *)smem;                          // [D][D] Cholesky factor of the (one) cluster, transposed
+    double *sLo = sL + (size_t)D * D;                     // [FW] prior box
+    double *sSpan = sLo + FW;                             // [FW]
+    unsigned char *sDeck = (unsigned char *)(sSpan + FW); // [64][nrp] each lane's deck of directions
+    double *sRow = (double *)(sDeck + (size_t)64 * nrp);  // [64][nT | 1] the babies' records on their way out (nrp is a multiple of 4, 64 nrp of 8)
+    {
+        constexpr TriMap<D> tm{};
+        for (int e = lane; e < NP; e += 64) sL[e] = S.chol[tm.aa[e] * D + tm.bb[e]];      // packed, in the order of use
+    }
+    if (lane < FW) {
+        const bool on = lane < D;
+        const double lo = (on && S.prior.lo) ? S.prior.lo[lane] : 0.0;
+        const double hi = (on && S.prior.hi) ? S.prior.hi[lane] : 1.0;
+        sLo[lane] = lo; sSpan[lane] = hi - lo;
+    }
+    // ---- GenerateSeed (generate.F90:19-55), one cluster: a live point drawn evenly (select_seed of pc_sample.hip)
+    int slot;
+    {
+        const double u2s = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+        const int ns = S.cl_n[0];
+        int is = (int)ceil(u2s * ns);
+        is = is < 1 ? 1 : (is > ns ? ns : is);
+        slot = S.cl_list[is - 1];
+        if (S.seed_override) slot = chain;
+    }
+    const double contour = S.logLp[0];
+    if (act) {
+        S.ch_cluster[chain] = 0; S.ch_seed_slot[chain] = slot;
+        S.ch_contour[chain] = contour;                                   // nested_sampling.F90:270
+        S.ch_epoch[chain] = S.ctl->admin_epoch;
+        if (chain == 0) { S.ctl->i_nursery = nchains; S.ctl->batch_id = batch; }
+    }
+    double x0[D];
+    {
+        const double *seed = S.live + (size_t)slot * nT;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x0[d] = seed[d];
+    }
+    if (S.pool && act) for (int i = 0; i < nr; ++i) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
+    // ---- deck: the first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142, random_utils.F90:505-532)
+    unsigned char *deck = sDeck + (size_t)lane * nrp;
+    for (int i = 0; i < nr; ++i) deck[i] = (unsigned char)i;
+    for (int i = nr - 1; i >= 1; --i) {
+        const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
+        int j = (int)ceil(u * i);
+        j = j < 1 ? 1 : (j > i ? i : j);
+        const unsigned char di = deck[i], dj = deck[j];
+        deck[i] = dj; deck[j] = di;
+    }
+    __syncthreads();                                       // (one wave: the factor and the box are in LDS)
+    const double mu = S.like.mu, inv_sigma = S.like.inv_sigma, qnorm = S.like.norm;
+    const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;    // direction v (generation order) at + v * D
+    double vv[D];
+    {
+        const double *p = rawc + (size_t)deck[0] * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) vv[d] = p[d];
+    }
+    double *bl_row = S.baby_logL + (size_t)chain * nr;
+    double *bl_col = S.baby_logL_T + chain;
+    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
+    const uint32_t k0 = S.k0, k1 = S.k1;
+    int nlike = 0;
+    // the records' way out (see the end of the loop): lane's first pair of a record and its stride through the 64 records
+    const int RS = nT | 1, chain0 = blockIdx.x * 64, nrows = min(64, nchains - chain0);
+    const size_t rstride = (size_t)nr * nT;
+    const int Hq = max(nT >> 1, 1), cq0 = lane / Hq, fq0 = lane - cq0 * Hq, cstep = 64 / Hq, fstep = 64 - cstep * Hq;
+#ifdef SLICE_T_DBG
+    long long cy[6] = {0, 0, 0, 0, 0, 0}; const long long cA = clock64();
+#endif
+    for (int s = 0; s < nr; ++s, bl_col += Bstride) {
+        // ---- whitening of this slice's direction: w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82)
+        //      (row sums in ascending column; the norm on four partial sums, coordinate d on sum d mod 4)
+        double nh[D], w;
+#ifdef SLICE_T_DBG
+        const long long c0 = clock64();
+#endif
+        asm volatile("" ::: "memory");                     // (the factor is read from LDS in every slice: 2 D^2 registers if the compiler keeps it)
+        {
+#pragma unroll
+            for (int d = 0; d < D; ++d) nh[d] = 0.0;
+            // the factor streams through a window of registers, W entries at a time in the order of use, the next window on its
+            // way from LDS while this one is multiplied; every row sum still takes its columns in ascending order.  The sums are
+            // pinned between windows: left alone, the compiler fetches all D (D + 1) / 2 entries first
+            constexpr TriMap<D> tm{};
+            constexpr int W = 32, NG = (NP + W - 1) / W;
+            double wa[W], wb[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) { wa[i] = (i < NP) ? sL[i] : 0.0; wb[i] = 0.0; }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < W; ++i) if ((gq + 1) * W + i < NP) wb[i] = sL[(gq + 1) * W + i];
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const int e = gq * W + i;
+                    if (e < NP) nh[tm.aa[e]] = fma(wa[i], vv[tm.bb[e]], nh[tm.aa[e]]);
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) asm volatile("" : "+v"(nh[d]));
+#pragma unroll
+                for (int i = 0; i < W; ++i) wa[i] = wb[i];
+            }
+            // (k_slice's `p += t t` over an unrolled loop from p = 0: the compiler takes 0 + t0 t0 + t4 t4 as fma(t0, t0, t4 t4))
+            double pp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pp[k] = (k < D) ? fma(nh[k], nh[k], (k + 4 < D) ? nh[k + 4] * nh[k + 4] : 0.0) : 0.0;
+#pragma unroll
+            for (int d = 8; d < D; ++d) pp[d & 3] = fma(nh[d], nh[d], pp[d & 3]);
+            const double wn = sqrt((pp[0] + pp[1]) + (pp[2] + pp[3])), iw = 1.0 / wn;
+#pragma unroll
+            for (int d = 0; d < D; ++d) nh[d] = nh[d] * iw;
+            w = wn * 3.0;
+        }
+        // ---- where the chord leaves the unit hypercube, once per slice: t in [loS, hiS] is inside in every coordinate, t < loO or
+        //      t > hiO is outside in one, whatever the rounding of x0 + t n^ (bounds from an approximate reciprocal, with a margin
+        //      far above its error and the fused multiply-add's); in the two slivers between, the trial's own test decides
+        double loS, hiS, loO, hiO;
+        {
+            double hi_min = PC_HUGE, lo_max = -PC_HUGE, rmax = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const double n = nh[d];
+                double r = __builtin_amdgcn_rcp(n);
+                r = fma(fma(-n, r, 1.0), r, r);                  // (n = 0: NaN from here on, and fmin / fmax pass it over: no bound from this coordinate)
+                const double a = (0.0 - x0[d]) * r, b = (1.0 - x0[d]) * r;
+                hi_min = fmin(hi_min, fmax(a, b)); lo_max = fmax(lo_max, fmin(a, b)); rmax = fmax(rmax, fabs(r));
+            }
+            const double m_hi = fma(1e-9, fabs(hi_min), 1e-15 * rmax), m_lo = fma(1e-9, fabs(lo_max), 1e-15 * rmax);
+            hiS = hi_min - m_hi; hiO = hi_min + m_hi; loS = lo_max + m_lo; loO = lo_max - m_lo;
+            // (the start point is inside: lo_max <= 0 <= hi_min.  Anything else -- a NaN that got through, a start point on a wall
+            //  whose coordinate does not move -- and every trial of this slice takes its own test)
+            if (!((lo_max <= 0.0) & (hi_min >= 0.0) & (m_hi < PC_HUGE) & (m_lo < PC_HUGE))) { hiS = -PC_HUGE; loS = PC_HUGE; hiO = PC_HUGE; loO = -PC_HUGE; }
+        }
+        if (s + 1 < nr) {                                   // the next direction's raw vector travels while this slice is made
+            const double *p = rawc + (size_t)deck[s + 1] * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) vv[d] = p[d];
+        }
+#ifdef SLICE_T_DBG
+        const long long c1 = clock64();
+#endif
+        // ---- the chord's quadratic: logL(x0 + t n^) = qnorm - (qa + 2 qb t + qc t^2) / 2
+        const Q3 q = wave_order_sum3<D>([&](int d) -> Q3 {
+            double zA, zB;
+            if constexpr (UNIT) { zA = (x0[d] - mu) * inv_sigma; zB = nh[d] * inv_sigma; }
+            else { zA = (fma(sSpan[d], x0[d], sLo[d]) - mu) * inv_sigma; zB = (sSpan[d] * nh[d]) * inv_sigma; }
+            return Q3{fma(zA, zA, 0.0), fma(zA, zB, 0.0), fma(zB, zB, 0.0)};      // (a lane's `0.0 + z z` of k_slice: rounded before the butterfly)
+        });
+        const double qa = q.a, qb = q.b, qc = q.c;
+        // draw k of this slice (k = 0: the bracket; trial q: k = 1 + q)
+        const uint32_t idx0 = (uint32_t)s * PC_SLICE_STRIDE;
+        uint32_t have_call = 0xFFFFFFFFu; double ua = 0.0, ub = 0.0;
+        auto draw = [&](uint32_t k) -> double {
+            const uint32_t call = (idx0 + k) >> 1;
+            if (call != have_call) { pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, call, ua, ub); have_call = call; }
+            return (k & 1u) ? ub : ua;
+        };
+        // calculate_point (calculate.f90:6-50) along the chord: logzero outside the unit hypercube, not counted
+        auto eval = [&](double t, bool &outside) -> double {
+            bool o = (t > hiO) | (t < loO);
+            if (!o && !((t <= hiS) & (t >= loS))) {        // (rare: within a margin of the cube's wall)
+                double mn = 0.5, mx = 0.5;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { const double cb = fma(t, nh[d], x0[d]); mn = fmin(mn, cb); mx = fmax(mx, cb); }
+                o = (mn < 0.0) | (mx > 1.0);
+            }
+            outside = o;
+            double lg = qnorm - fma(t, fma(t, qc, 2.0 * qb), qa) / 2.0;
+            if (o) lg = logzero;                            // calculate.f90:36-38
+            else if (lg > logzero) nlike++;
+            return lg;
+        };
+#ifdef SLICE_T_DBG
+        const long long c2 = clock64();
+#endif
+        // initial bracket (chordal_sampling.f90:213-219)
+        const double u0 = draw(0u);
+        double tR = (1 - u0) * w, tL = -(u0 * w);
+        bool oo;
+        double lR = eval(tR, oo), lL = eval(tL, oo);
+        // stepping out (:223-236): the two ends step independently of each other -- one loop for both, as long as either goes on
+        {
+            int iR = 0, iL = 0;
+            bool goR = lR >= contour && lR > logzero, goL = lL >= contour && lL > logzero;
+            while (goR || goL) {
+                if (goR) { iR++; tR = w * iR; lR = eval(tR, oo); goR = lR >= contour && lR > logzero; }
+                if (goL) { iL++; tL = -(w * iL); lL = eval(tL, oo); goL = lL >= contour && lL > logzero; }
+            }
+        }
+#ifdef SLICE_T_DBG
+        const long long c3 = clock64();
+#endif
+        // shrinkage (:240-271)
+        double lnew = logzero, t_last = 0.0;
+        bool ok = false, last_out = false;
+        for (int it = 0; it <= 100 && !ok; ++it) {
+            const double dl = fabs(tL), dr = fabs(tR);
+            const double t = fma(draw(1u + (uint32_t)it), dr + dl, -dl);
+            t_last = t;
+            lnew = eval(t, last_out);
+            if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
+            else ok = true;
+        }
+        if (!ok) lnew = logzero;                            // "Non deterministic loglikelihood"
+#ifdef SLICE_T_DBG
+        const long long c4 = clock64();
+#endif
+        // the baby becomes the next start point (chordal_sampling.f90:85-88); its derived parameters (gaussian.f90:36-37)
+        // (last_out: a slice that found no point in 101 trials and whose last trial was outside the cube keeps theta = 0 for its
+        //  record, as calculate_point leaves it: practically never, and off the common path)
+        double r2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            x0[d] = fma(t_last, nh[d], x0[d]);
+            double th;
+            if constexpr (UNIT) th = x0[d]; else th = fma(sSpan[d], x0[d], sLo[d]);
+            const double z = th - mu;
+            r2 = fma(z, z, r2);
+        }
+        if (__builtin_expect(last_out, 0)) {
+            r2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { const double z = 0.0 - mu; r2 = fma(z, z, r2); }
+        }
+        // ---- the record of the baby: the lane lays it down in LDS, and the wave writes the 64 records out in runs of consecutive
+        //      addresses (a lane's own stores would be 64 cache lines per instruction, 2 nDims + 4 instructions per slice)
+        {
+            double *mine = sRow + (size_t)lane * RS;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double th;
+                if constexpr (UNIT) th = x0[d]; else th = fma(sSpan[d], x0[d], sLo[d]);
+                mine[d] = x0[d]; mine[o_p0 + d] = __builtin_expect(last_out, 0) ? 0.0 : th;
+            }
+            if (nDer > 0) {
+                const double phi0 = sqrt(r2);
+                mine[o_d0] = phi0;
+                if (nDer >= 2) mine[o_d0 + 1] = fma((double)D, log(phi0), S.like.log_vn);      // pc_log_ball
+                for (int e = 2; e < nDer; ++e) mine[o_d0 + e] = 0.0;
+            }
+            mine[o_b0] = contour;                           // nested_sampling.F90:260
+            mine[o_l0] = lnew;
+            if (act) { bl_row[s] = lnew; *bl_col = lnew; }
+            __syncthreads();                                // (one wave)
+            double *out0 = S.babies + ((size_t)chain0 * nr + s) * nT;       // record of the wave's first chain; chain c: + c nr nT
+            if ((nT & 1) == 0) {
+                const int H = nT >> 1;
+                int c = cq0, f2 = fq0;
+                for (int i = 0; i < H; ++i) {
+                    if (c < nrows) {
+                        const double *src = sRow + (size_t)c * RS + 2 * f2;
+                        const double2 v = make_double2(src[0], src[1]);
+                        *(double2 *)(out0 + (size_t)c * rstride + 2 * f2) = v;
+                    }
+                    f2 += fstep; c += cstep;
+                    if (f2 >= H) { f2 -= H; c++; }
+                }
+            } else {
+                for (int e = lane; e < nrows * nT; e += 64) { const int c = e / nT, f = e - c * nT; out0[(size_t)c * rstride + f] = sRow[(size_t)c * RS + f]; }
+            }
+            __syncthreads();
+        }
+#ifdef SLICE_T_DBG
+        { const long long c5 = clock64(); cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3; cy[4] += c5 - c4; }
+#endif
+    }
+#ifdef SLICE_T_DBG
+    if (lane == 0) { unsigned long long *g = (unsigned long long *)S.ctl->dbg; for (int x = 0; x < 5; ++x) atomicAdd(&g[x], (unsigned long long)cy[x]); atomicAdd(&g[5], (unsigned long long)(cA - cB)); atomicAdd(&g[6], (unsigned long long)(clock64() - cA)); atomicAdd(&g[7], 1ull); }
+#endif
+    if (act) S.ch_nlike[chain] = nlike;
+}
+
+static int deck_stride(int nr) { int q = (nr + 3) / 4; if ((q & 1) == 0) q++; return 4 * q; }   // bytes, an odd number of words: lanes on different banks
+
+template <int DT>
+static void launch_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    constexpr int FW = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
+    const int nrp = deck_stride(S->nr), grid = (nchains + 63) / 64;
+    const size_t sh = sizeof(double) * ((size_t)DT * DT + 2 * FW) + (size_t)64 * nrp + sizeof(double) * 64 * (size_t)(S->nT | 1);
+    if (S->prior.lo == nullptr && S->prior.hi == nullptr) hipLaunchKernelGGL((k_slice_t<DT, true>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
+    else hipLaunchKernelGGL((k_slice_t<DT, false>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
+}
+
+}   // namespace
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// The orthonormal bases of k_nhats<.., 1> (pc_sample.hip: one grade, keyed draws, nDims <= 24) with lane = basis: k_nhats gives a
+// basis a wavefront (thread = vector, nDims of 64 lanes busy, a barrier per Gram-Schmidt step); here a lane makes a whole basis
+// by itself in its own stretch of LDS -- the deviates of its nDims^2 stream positions (random_utils.F90:251-263: the same calls
+// of the same stream, AS241's centre at once and its tails together afterwards), every vector normalised (:276-298), then
+// Gram-Schmidt in the reference's order (:391-399) with k_nhats' arithmetic, operation for operation: dot products on four
+// partial sums (and the way the compiler fuses `0 + a0 a0 + a4 a4` there), the projection as one fused multiply-add per
+// coordinate.  A nursery of 1000 chains x 2 bases is 42 wavefronts instead of 2000.
+// ------------------------------------------------------------------------------------------
+// a.a as k_nhats' PC_DOT4(x, a, a) comes out of the compiler: four partial sums over coordinates d = k, k + 4, ...; each starts as
+// 0 + a_k a_k + a_{k+4} a_{k+4}, of which ONE product is rounded and the other fused into the addition -- which one is the
+// compiler's choice per site (read from the ISA of libpolychord_hip.so: the pivot's q.q fuses a_k everywhere; the norm of a raw
+// vector fuses a_4, not a_0, in the kernels compiled for nDims <= 16).  tests/test_gpu_parity.py holds the two kernels together.
+template <int D, bool FIRST_RIGHT>
+__device__ __forceinline__ double dot4_same(const double (&a)[D])
+{
+#pragma clang fp contract(off)
+    double pp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= D) pp[k] = 0.0;
+        else if (k + 4 >= D) pp[k] = fma(a[k], a[k], 0.0);
+        else if (FIRST_RIGHT && k == 0) pp[k] = fma(a[k + 4 < D ? k + 4 : 0], a[k + 4 < D ? k + 4 : 0], a[k] * a[k]);
+        else pp[k] = fma(a[k], a[k], a[k + 4 < D ? k + 4 : 0] * a[k + 4 < D ? k + 4 : 0]);
+    }
+#pragma unroll
+    for (int d = 8; d < D; ++d) pp[d & 3] = fma(a[d], a[d], pp[d & 3]);
+    return (pp[0] + pp[1]) + (pp[2] + pp[3]);
+}
+template <int D>
+__device__ __forceinline__ double dot4(const double (&a)[D], const double (&b)[D])
+{
+#pragma clang fp contract(off)
+    double pp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < D; ++d) pp[d & 3] = fma(a[d], b[d], pp[d & 3]);
+    return (pp[0] + pp[1]) + (pp[2] + pp[3]);
+}
+
+// step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
+__global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, int nbases, int NC)
+{
+    const int D = S.D, DD = D * D;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)nbases * NC) return;
+    const int g = (int)(t / NC), m = (int)(t - (long long)g * NC);
+    const int chain = g / S.nb_total, basis = g - chain * S.nb_total;
+    const uint32_t e0 = (uint32_t)pc_sel(S.g_e0, 0) + (uint32_t)basis * DD, e1 = e0 + (uint32_t)DD;
+    const uint32_t call = (e0 >> 1) + (uint32_t)m;
+    double ua, ub;
+    pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+    const uint32_t ia = 2 * call, ib = ia + 1;
+    double *G = S.nhat_raw + (size_t)g * DD;
+    if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
+    if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+}
+
+// step 2, lane = basis: normalise, Gram-Schmidt, in the lane's own stretch of LDS
+template <int DT>
+__global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int nbases /* chains x bases per chain */, int per /* bases per workgroup */)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = DT, DD = D * D, ST = DD | 1;
+    const int lane = threadIdx.x, g = blockIdx.x * per + lane;
+    const bool active = lane < per && g < nbases;
+    double *sG = (double *)smem;                                 // [per][ST] a basis per lane, vector-major; odd stride: lanes on different banks
+    const int nb_here = min(per, nbases - (int)blockIdx.x * per);
+    // ---- the deviates arrive in runs of 64 consecutive addresses: [chain][basis][vector][D] is linear in the basis number
+    for (int b = 0; b < nb_here; ++b) {
+        double *dstl = sG + (size_t)b * ST;
+        const double *src = S.nhat_raw + ((size_t)blockIdx.x * per + b) * DD;
+        for (int e = lane; e < DD; e += 64) dstl[e] = src[e];
+    }
+    __syncthreads();                                              // (one wave)
+    if (active) {
+        double *G = sG + (size_t)lane * ST;
+        // ---- random_direction (random_utils.F90:276-298): every vector normalised
+        for (int i = 0; i < D; ++i) {
+            double v[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) v[d] = G[i * D + d];
+            const double inrm = 1.0 / sqrt(dot4_same<D, (D <= 16)>(v));
+#pragma unroll
+            for (int d = 0; d < D; ++d) G[i * D + d] = v[d] * inrm;
+        }
+        // ---- Gram-Schmidt (random_utils.F90:391-399): the pivot is vector j, orthogonal to its predecessors and not yet normalised
+        for (int j = 0; j < D; ++j) {
+            double q[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) q[d] = G[j * D + d];
+            const double qq = dot4_same<D, false>(q);
+            const double inrm = 1.0 / sqrt(qq);
+#pragma unroll
+            for (int d = 0; d < D; ++d) G[j * D + d] = q[d] * inrm;
+            for (int k = j + 1; k < D; ++k) {
+                double v[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) v[d] = G[k * D + d];
+                const double cproj = dot4<D>(q, v) / qq;
+#pragma unroll
+                for (int d = 0; d < D; ++d) G[k * D + d] = fma(-cproj, q[d], v[d]);
+            }
+        }
+    }
+    __syncthreads();                                              // (one wave)
+    // ---- the bases leave the way the deviates came
+    for (int b = 0; b < nb_here; ++b) {
+        const double *src = sG + (size_t)b * ST;
+        double *dst = S.nhat_raw + ((size_t)blockIdx.x * per + b) * DD;
+        for (int e = lane; e < DD; e += 64) dst[e] = src[e];
+    }
+}
+
+template <int DT>
+static int launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    constexpr int DD = DT * DT, ST = DD | 1, NC = (DD + 1) / 2;
+    const size_t per_b = sizeof(double) * ST;
+    // (a workgroup's LDS is what it costs the runs next to it: 64 KB leaves room on the CU for their sampling waves)
+    int per = (int)((size_t)(64 * 1024 - 64) / per_b);
+    if (per > 64) per = 64;
+    if (per < 8) return 1;
+    const int nbases = nchains * S->nb_total, blocks = (nbases + per - 1) / per;
+    const long long ncalls = (long long)nbases * NC;
+    hipLaunchKernelGGL(k_deviates_t, dim3((unsigned)((ncalls + 255) / 256)), dim3(256), 0, st, *S, batch, nbases, NC);
+    const size_t sh = per_b * per + 16;
+    static size_t done = 0;                                       // (per instantiation)
+    if (sh > 48 * 1024 && sh > done) { (void)hipFuncSetAttribute((const void *)k_bases_t<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    hipLaunchKernelGGL((k_bases_t<DT>), dim3(blocks), dim3(64), sh, st, *S, batch, nbases, per);
+    return 0;
+}
+
+}   // namespace
+
+extern "C" int pc_launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    static const bool off = std::getenv("PC_BASES_T_OFF") != nullptr;
+    if (off || S->ngrade > 1 || S->seq_mode || S->nhat_raw == nullptr || S->D < 2 || S->D > 24) return 1;
+    switch (S->D) {
+#define PC_T(n) case n: return launch_bases_t<n>(S, batch, nchains, st);
+        PC_T(2) PC_T(3) PC_T(4) PC_T(5) PC_T(6) PC_T(7) PC_T(8) PC_T(9) PC_T(10) PC_T(11) PC_T(12)
+        PC_T(13) PC_T(14) PC_T(15) PC_T(16) PC_T(17) PC_T(18) PC_T(19) PC_T(20) PC_T(21) PC_T(22) PC_T(23) PC_T(24)
+#undef PC_T
+    }
+    return 1;
+}
+
+namespace {
+}   // namespace
+
+// what k_slice_t takes; phi_lds_fits = the condition under which k_slice keeps the babies' theta rows in LDS (pc_launch_slice_fused)
+extern "C" int pc_slice_t_ok(const PcState *S, int ncluster)
+{
+    static const bool off = std::getenv("PC_SLICE_T_OFF") != nullptr;
+    if (off || ncluster != 1) return 0;
+    if (S->D > 24 || S->ngrade > 1 || S->seq_mode || S->nhat_raw == nullptr || S->nr > 255) return 0;
+    if (S->like.kind != PC_LIKE_GAUSSIAN || (S->ablate & 1)) return 0;
+    const size_t sh0 = sizeof(double) * ((size_t)S->D + S->nr) + 16, tb = sizeof(double) * (size_t)S->nr * (S->D + 1);
+    if (S->nDer > 0 && sh0 + tb > 48 * 1024) return 0;      // (k_slice would take the derived parameters' other summation order)
+    return 1;
+}
+
+extern "C" int pc_launch_slice_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+{
+    switch (S->D) {
+#define PC_T(n) case n: launch_t<n>(S, batch, nchains, st); return 0;
+        PC_T(1) PC_T(2) PC_T(3) PC_T(4) PC_T(5) PC_T(6) PC_T(7) PC_T(8) PC_T(9) PC_T(10) PC_T(11) PC_T(12)
+        PC_T(13) PC_T(14) PC_T(15) PC_T(16) PC_T(17) PC_T(18) PC_T(19) PC_T(20) PC_T(21) PC_T(22) PC_T(23) PC_T(24)
+#undef PC_T
+    }
+    return 1;
+}

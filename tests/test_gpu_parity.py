@@ -568,3 +568,31 @@ def test_clustered_contraction_with_a_chain_that_has_no_number(engine):
         assert abs(a["logZ"] - o["logZ"]) < 1e-10
         assert np.array_equal(a["dead"][:, :-2], o["dead"][:, :-2], equal_nan=True)
         assert np.array_equal(a["live"], o["live"], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,nDer,nlive,nr,kw", [(20, 2, 2000, 40, {}), (8, 0, 300, 16, {}), (16, 1, 500, 32, {}), (24, 2, 400, 48, {}),
+                                                (5, 2, 200, 25, dict(box=(-0.5, 1.5))), (20, 2, 2000, 40, dict(batch=700)),
+                                                (3, 1, 120, 9, dict(batch=70)), (17, 0, 250, 17, dict(box=(0.1, 0.9)))])
+def test_lane_per_chain_kernels_change_no_number(engine, D, nDer, nlive, nr, kw):
+    """the kernels a run uses next to other runs of its device (pc_slice_t.hip: 64 chains to a wavefront, one per lane; a basis
+    per lane) against the ones it uses alone (k_slice: a wavefront per chain; k_nhats: a wavefront per basis) -- the same run
+    bit for bit: settings.ablate bit 6 = lane-per-chain sampling, bit 7 = lane-per-basis directions, both, neither.  Covers the
+    three compiled widths of the old kernels (nDims <= 8, <= 16, <= 24), a prior box that is not the unit cube, nurseries that
+    do not fill their last wavefront, odd nDims (an odd number of deviates per basis: stream calls shared between bases)"""
+    api = engine
+    box = kw.get("box", (None, None))
+    L, P, keep = api.make_problem("gaussian", D, nDer, *box) if box[0] is not None else api.make_problem("gaussian", D, nDer)
+    runs = []
+    for ab in (0, 64, 128, 192):
+        s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=11, batch=kw.get("batch", 0))
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    a = runs[0]
+    assert a["ndead"] > 3 * nlive
+    for b in runs[1:]:
+        for k in ("ndead", "nlike", "niter", "nupdates", "nbatches"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert a["logZ"] == b["logZ"] and a["logZerr"] == b["logZerr"]
+        assert np.array_equal(a["dead"], b["dead"]) and np.array_equal(a["logweights"], b["logweights"]) and np.array_equal(a["live"], b["live"])
+        assert np.array_equal(a["post_mean"], b["post_mean"])
