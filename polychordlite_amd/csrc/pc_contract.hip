@@ -998,7 +998,7 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
 // if the point that died at its step was a newcomer of this launch, that baby's row; the rows of snapshot points that died
 // are moved out by the workgroup of their SLOT (k_consume_par left the killer's chain in slot_dead) just before the slot's
 // new occupant moves in -- the one place where the order of the two copies matters.
-__global__ __launch_bounds__(64) void k_apply_pool(PcState S, unsigned batch, int nchains)
+__device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch, int nchains)
 {
     const PcCtl *ctl = S.ctl;
     const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
@@ -1050,6 +1050,9 @@ __global__ __launch_bounds__(64) void k_apply_pool(PcState S, unsigned batch, in
     __syncthreads();
     if (lane == 0) { S.slot_src[slot] = -1; S.slot_dead[slot] = -1; if (src >= 0) S.live_entry[slot] = S.plan[src].contour; }
 }
+__global__ __launch_bounds__(64) void k_apply_pool(PcState S, unsigned batch, int nchains) { apply_pool_body(S, batch, nchains); }
+__global__ __launch_bounds__(64) void k_apply_pool_many(const PcManyRec *R, int nchains) { apply_pool_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains); }
+
 
 // new live rows: every slot now owned by a chain's last baby
 __global__ __launch_bounds__(64) void k_apply_live(PcState S)
@@ -1113,7 +1116,7 @@ __device__ __forceinline__ int cluster_of_uid(const PcState &S, unsigned uid, in
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned char *keep, int *blk_count)
+__device__ __forceinline__ void clean_flag_body(const PcState &S, int nph, unsigned char *keep, int *blk_count)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int nc = S.ctl->ncluster;
@@ -1129,8 +1132,11 @@ __global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned
     __syncthreads();
     if (threadIdx.x == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
+__global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned char *keep, int *blk_count) { clean_flag_body(S, nph, keep, blk_count); }
+__global__ __launch_bounds__(256) void k_clean_flag_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; clean_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1]); }
 
-__global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total, int *total2)
+
+__device__ __forceinline__ void scan_blocks_body(int *blk_count, int nblk, int *total, int *total2)
 {   // exclusive scan, single workgroup, fixed order
     __shared__ int carry;
     __shared__ int tmp[256];
@@ -1154,10 +1160,13 @@ __global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, i
     }
     if (threadIdx.x == 0) { *total = carry; if (total2) *total2 = carry; }   // total2: the control block's phantom count
 }
+__global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total, int *total2) { scan_blocks_body(blk_count, nblk, total, total2); }
+__global__ __launch_bounds__(256) void k_scan_blocks_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; scan_blocks_body((int *)r.p[1], r.ia[2], (int *)r.p[2], &r.S.ctl->nphantom); }
 
-__global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const unsigned char *keep, const int *blk_off,
-                                                      double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
-                                                      int *dst_index /* [nph] or nullptr */)
+
+__device__ __forceinline__ void clean_scatter_body(const PcState &S, int nph, const unsigned char *keep, const int *blk_off,
+                                                   double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                   int *dst_index /* [nph] or nullptr */)
 {
     const int j = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool k = (j < nph) && keep[j];
@@ -1174,6 +1183,16 @@ __global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const
     const int j0 = blockIdx.x * 256 + wid * 64;
     wave_copy_masked(S.phantom + (size_t)j0 * S.nT, m, ph2 + (size_t)woff * S.nT, S.nT, lane);
 }
+__global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const unsigned char *keep, const int *blk_off,
+                                                      double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2, int *dst_index)
+{ clean_scatter_body(S, nph, keep, blk_off, ph2, phL2, phC2, phU2, dst_index); }
+__global__ __launch_bounds__(256) void k_clean_scatter_many(const PcManyRec *R)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    if ((int)blockIdx.x >= r.ia[2]) return;
+    clean_scatter_body(r.S, r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5], (unsigned long long *)r.p[6], nullptr);
+}
+
 
 __global__ void k_reset_thresholds(PcState S) { if (threadIdx.x < S.maxc) S.death_thr[threadIdx.x] = -PC_HUGE; }
 
@@ -1706,6 +1725,23 @@ extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, h
     if (S->pool) { hipLaunchKernelGGL(k_apply_pool, dim3(nchains + S->Ncap), dim3(64), 0, st, *S, batch, nchains); return; }
     hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64 * PC_APPLY_WAVES), 0, st, *S, batch);
     hipLaunchKernelGGL(k_apply_live, dim3(S->Ncap), dim3(64), 0, st, *S);
+}
+
+extern "C" int pc_launch_apply_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
+{
+    if (!S->pool) return 1;
+    hipLaunchKernelGGL(k_apply_pool_many, dim3(nchains + S->Ncap, R), dim3(64), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
+    return 0;
+}
+
+// the phantom clean for R runs at once (pool compaction of runs in step): every run its own row count (PcManyRec::ia[1], blocks ia[2])
+extern "C" int pc_launch_clean_many(const PcManyRec *dR, int R, int nblk_max, hipStream_t st)
+{
+    if (nblk_max < 1) return 1;
+    hipLaunchKernelGGL(k_clean_flag_many, dim3(nblk_max, R), dim3(256), 0, st, dR);
+    hipLaunchKernelGGL(k_scan_blocks_many, dim3(1, R), dim3(256), 0, st, dR);
+    hipLaunchKernelGGL(k_clean_scatter_many, dim3(nblk_max, R), dim3(256), 0, st, dR);
+    return 0;
 }
 
 extern "C" void pc_launch_install_live(const PcState *S, const double *rows, int n, hipStream_t st)

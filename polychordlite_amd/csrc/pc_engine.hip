@@ -34,6 +34,15 @@ int pc_slice_fusable(const PcState *);
 int pc_launch_slice_fused(const PcState *, unsigned, int, hipStream_t);
 int pc_slice_t_ok(const PcState *, int);
 int pc_launch_slice_t(const PcState *, unsigned, int, hipStream_t);
+int pc_bases_t_ok(const PcState *);
+int pc_launch_slice_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
+int pc_launch_bases_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
+int pc_update_fused_grid(const PcState *, int, int);
+int pc_launch_clean_many(const PcManyRec *, int, int, hipStream_t);
+int pc_launch_sort_live_many(const PcState *, const PcManyRec *, int, hipStream_t);
+int pc_launch_consume_par_many(const PcState *, const PcManyRec *, int, hipStream_t);
+int pc_launch_apply_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
+int pc_launch_update_fused_many(const PcState *, const PcManyRec *, int, int, int, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
@@ -269,7 +278,126 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
     return ((double)(w >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+// ---- the runs of a device in step (pchip_run_repeats with a built-in likelihood): a kernel launched on N streams at once costs
+//      every one of them tens of microseconds on this device (tools/dev/ubench_queues.hip: an empty kernel 3 us alone, 36 us
+//      each with sixteen streams busy; at most ~8 kernels at a time whatever the number of hardware queues), so the runs share
+//      ONE stream and go round by round together: what each engine would launch in a phase of the round it writes down here, and
+//      every kernel of the phase is launched ONCE for all of them (blockIdx.y = run, PcManyRec).  The same kernels' bodies on
+//      the same states: the numbers of a run do not know whether it ran alone.
+enum { CK_COMPACT = 0, CK_BASES, CK_SLICE, CK_BASES_NEXT, CK_SORT, CK_CONSUME, CK_APPLY, CK_UPDATE, CK_N };      // (in the order they are launched)
+struct Cohort {
+    hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr;          // the bases of the NEXT nursery, next to this one's sampling and contraction
+    hipEvent_t ev_up = nullptr, ev_next = nullptr; bool next_pending = false;
+    struct Rec { int kind; PcState S; void *p[10]; long long a[4]; int ia[6]; };      // a: what the runs of one launch must share; ia: each run's own (PcManyRec::ia)
+    std::vector<Rec> pend;
+    static constexpr int RING = 4;
+    PcManyRec *h_stage[RING] = {}, *d_recs[RING] = {};
+    hipEvent_t ev[RING] = {}; bool ev_used[RING] = {};
+    size_t cap = 0; int ring = 0;
+    long n_fused = 0, n_single = 0;
+    void rec(int kind, const PcState &S, std::initializer_list<void *> p, std::initializer_list<long long> a, std::initializer_list<int> ia)
+    {
+        pend.emplace_back();
+        Rec &r = pend.back();
+        r.kind = kind; r.S = S;
+        int i = 0; for (void *x : p) r.p[i++] = x; for (; i < 10; ++i) r.p[i] = nullptr;
+        i = 0; for (long long x : a) r.a[i++] = x; for (; i < 4; ++i) r.a[i] = 0;
+        i = 0; for (int x : ia) r.ia[i++] = x; for (; i < 6; ++i) r.ia[i] = 0;
+    }
+    static void single(const Rec &r, hipStream_t st)
+    {
+        switch (r.kind) {
+        case CK_COMPACT: pc_launch_clean(&r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], (int *)r.p[2], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5], (unsigned long long *)r.p[6], nullptr, st); break;
+        case CK_BASES: case CK_BASES_NEXT: (void)pc_launch_nhats_part(&r.S, (unsigned)r.ia[0], (int)r.a[0], 1, st, 1); break;
+        case CK_SLICE: (void)pc_launch_slice_t(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
+        case CK_SORT: (void)pc_launch_sort_live(&r.S, st); break;
+        case CK_CONSUME: (void)pc_launch_consume_par(&r.S, st); break;
+        case CK_APPLY: pc_launch_apply(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
+        case CK_UPDATE: pc_launch_update_fused(&r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], (int *)r.p[2], (double *)r.p[3], (double *)r.p[4],
+                                               (unsigned *)r.p[5], (unsigned long long *)r.p[6], (double *)r.p[7], (double *)r.p[8], (int)r.a[1], st); break;
+        }
+    }
+    void flush()
+    {
+        if (pend.empty()) return;
+        const size_t n = pend.size();
+        if (n > cap) {
+            for (int k = 0; k < RING; ++k) {
+                if (ev_used[k]) { (void)hipEventSynchronize(ev[k]); ev_used[k] = false; }
+                if (h_stage[k]) (void)hipHostFree(h_stage[k]);
+                if (d_recs[k]) (void)hipFree(d_recs[k]);
+                HIPCHK(hipHostMalloc((void **)&h_stage[k], sizeof(PcManyRec) * 2 * n, hipHostMallocDefault));
+                HIPCHK(hipMalloc((void **)&d_recs[k], sizeof(PcManyRec) * 2 * n));
+                if (!ev[k]) HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+            }
+            cap = 2 * n;
+        }
+        const int slot = ring++ % RING;
+        if (ev_used[slot]) { HIPCHK(hipEventSynchronize(ev[slot])); ev_used[slot] = false; }
+        PcManyRec *hs = h_stage[slot], *dr = d_recs[slot];
+        // records in launch order: by kind, and inside a kind by the arguments all runs of a launch must share
+        std::vector<const Rec *> ord; ord.reserve(n);
+        for (const Rec &r : pend) ord.push_back(&r);
+        auto shape_less = [](const Rec *x, const Rec *y) {
+            if (x->kind != y->kind) return x->kind < y->kind;
+            const int c = std::memcmp(x->a, y->a, sizeof(x->a));
+            if (c != 0) return c < 0;
+            if (x->S.Ncap != y->S.Ncap) return x->S.Ncap < y->S.Ncap;
+            if (x->S.B != y->S.B) return x->S.B < y->S.B;
+            return (x->S.prior.lo == nullptr) < (y->S.prior.lo == nullptr);
+        };
+        std::stable_sort(ord.begin(), ord.end(), shape_less);
+        for (size_t i = 0; i < n; ++i) { hs[i].S = ord[i]->S; std::memcpy(hs[i].p, ord[i]->p, sizeof(ord[i]->p)); std::memcpy(hs[i].ia, ord[i]->ia, sizeof(ord[i]->ia)); }
+        HIPCHK(hipMemcpyAsync(dr, hs, sizeof(PcManyRec) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(ev[slot], st)); ev_used[slot] = true;
+        bool up_marked = false;
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while (j < n && !shape_less(ord[i], ord[j]) && !shape_less(ord[j], ord[i])) ++j;
+            const Rec &f = *ord[i];
+            const PcManyRec *d = dr + i;
+            const int cnt = (int)(j - i), k = f.kind;
+            hipStream_t q = st;
+            if (k == CK_BASES_NEXT && st2) {         // on the second stream, behind the upload of the records
+                if (!up_marked) { HIPCHK(hipEventRecord(ev_up, st)); up_marked = true; }
+                HIPCHK(hipStreamWaitEvent(st2, ev_up, 0));
+                q = st2;
+            }
+            if (k == CK_SLICE && next_pending) { HIPCHK(hipStreamWaitEvent(st, ev_next, 0)); next_pending = false; }   // (its bases were drawn over there)
+            int rc = 1;
+            switch (k) {
+            case CK_COMPACT: { int nbm = 0; for (size_t x = i; x < j; ++x) nbm = std::max(nbm, ord[x]->ia[2]); rc = pc_launch_clean_many(d, cnt, nbm, q); } break;
+            case CK_BASES: case CK_BASES_NEXT: rc = pc_launch_bases_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
+            case CK_SLICE: rc = pc_launch_slice_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
+            case CK_SORT: rc = pc_launch_sort_live_many(&f.S, d, cnt, q); break;
+            case CK_CONSUME: rc = pc_launch_consume_par_many(&f.S, d, cnt, q); break;
+            case CK_APPLY: rc = pc_launch_apply_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
+            case CK_UPDATE: { int nbm = 0; for (size_t x = i; x < j; ++x) nbm = std::max(nbm, ord[x]->ia[2]); rc = pc_launch_update_fused_many(&f.S, d, cnt, nbm, (int)f.a[0], (int)f.a[1], q); } break;
+            }
+            if (rc == 0) n_fused += cnt;
+            else for (size_t x = i; x < j; ++x) { single(*ord[x], q); n_single++; }
+            if (k == CK_BASES_NEXT && st2) { HIPCHK(hipEventRecord(ev_next, st2)); next_pending = true; }
+            i = j;
+        }
+        pend.clear();
+    }
+    void destroy()
+    {
+        for (int k = 0; k < RING; ++k) {
+            if (ev_used[k]) (void)hipEventSynchronize(ev[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            if (h_stage[k]) (void)hipHostFree(h_stage[k]);
+            if (d_recs[k]) (void)hipFree(d_recs[k]);
+            ev[k] = nullptr; h_stage[k] = nullptr; d_recs[k] = nullptr; ev_used[k] = false;
+        }
+        cap = 0;
+    }
+};
+
+static double g_dbg_compact_s = 0, g_dbg_nursery_s = 0, g_dbg_capacity_s = 0;      // (PC_DEBUG=5, one scheduler thread: where round_enqueue's time goes)
 struct Engine {
+    Cohort *co = nullptr;               // not null: this run goes in step with others of its device, on their common stream
     pchip_settings cfg{};
     std::atomic<int> stop{0};                   // polychord_hip_request_stop reached this run
     polychord_batch_fn batch_fn = nullptr; void *batch_user = nullptr;     // the batch callback registered when the run was set up
@@ -348,7 +476,7 @@ struct Engine {
         }
         dev = c.device >= 0 ? c.device % ndev : 0;
         HIPCHK(hipSetDevice(dev));
-        st = hpool().get_stream(); st_copy = hpool().get_stream();
+        st = co ? co->st : hpool().get_stream(); st_copy = hpool().get_stream();
         kt.on = c.profile != 0; kt.st = st;
         kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x7Fu);   // 1: every class; else bit k+1 = class k
         kt.stride = std::max(1u, ((unsigned)c.profile >> 8) & 0xFFu);                       // bits 8..15: time every n-th launch of a class
@@ -532,6 +660,7 @@ struct Engine {
 
     void read_ctl()
     {
+        if (co) co->flush();
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
         // (polling the stream wakes the host a few microseconds after the copy; the blocking wait sleeps on an interrupt)
         for (int spins = 0; spins < 200000; ++spins) { const hipError_t q = hipStreamQuery(st); if (q != hipErrorNotReady) { HIPCHK(q); break; } __builtin_ia32_pause(); }
@@ -628,8 +757,22 @@ struct Engine {
     // the alternate buffers), grow if that is not enough.  Between nurseries only.
     long long pool_cursor = 0;
     double *babies_own = nullptr;
+    // the phantom array is full: the phantoms that are still wanted move to the front of the alternate buffers.  In step with other
+    // runs the clean is launched for all of them at once and waited for once (compact_wanted / compact_record / compact_finish)
+    bool compact_wanted() const { return S.pool && h_ctl->status == PC_ST_RUNNING && h_ctl->i_nursery == 0 && pool_cursor + (long long)B * S.nr > S.Pcap; }
+    void compact_record() { co->rec(CK_COMPACT, S, {keep, blk, d_total, ph2, phL2, phC2, phU2}, {}, {0, (int)pool_cursor, ((int)pool_cursor + 255) / 256}); }
+    void compact_finish(int total)
+    {
+        std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
+        pool_cursor = total; h_ctl->nphantom = total; nph_stale = false;
+        if (pool_cursor + (long long)B * S.nr > S.Pcap / 2) grow_phantoms(std::max<long long>(2LL * S.Pcap, 2 * (pool_cursor + (long long)B * S.nr)));
+        tm.compactions++;
+    }
     void pool_compact()
     {
+        const auto dbg_t0 = std::chrono::steady_clock::now();
+        struct DbgT { std::chrono::steady_clock::time_point t0; ~DbgT() { g_dbg_compact_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } dbg_t{dbg_t0};
+        if (co) co->flush();
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, (int)pool_cursor, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
         kt.end(KT_CLEAN, e0);
@@ -637,12 +780,8 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         kt.collect();
-        std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
-        pool_cursor = total; h_ctl->nphantom = total; nph_stale = false;
-        if (pool_cursor + (long long)B * S.nr > S.Pcap / 2) grow_phantoms(std::max<long long>(2LL * S.Pcap, 2 * (pool_cursor + (long long)B * S.nr)));
-        tm.compactions++;
+        compact_finish(total);
     }
-
     void ensure_capacity()
     {   // the next batch may append B*nr phantoms and B dead points
         if ((long long)h_ctl->ndead + B + S.Ncap + 16 > S.Dcap) grow_dead(S.Dcap * 2);
@@ -858,7 +997,8 @@ struct Engine {
                 HIPCHK(hipStreamSynchronize(st));
             }
             hipEvent_t e0 = kt.begin(KT_CLEAN);
-            pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
+            if (co) co->rec(CK_UPDATE, S, {keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift}, {(long long)pc_update_fused_grid(&S, nph, deferred ? 1 : 0), deferred ? 1LL : 0LL}, {0, nph, (nph + 255) / 256});
+            else pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
             kt.end(KT_CLEAN, e0);
             if (cfg.resume_write || dumper || on_update || seq_post) {
                 int total = nph;
@@ -1562,7 +1702,7 @@ struct Engine {
             // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
             //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
             const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
-            const bool multi = g_active_dev[dev & 63].load(std::memory_order_relaxed) > 1;
+            const bool multi = co != nullptr || g_active_dev[dev & 63].load(std::memory_order_relaxed) > 1;
             const bool split = splittable && !multi;
             bool fused_slice = false;
             if (splittable) {
@@ -1570,24 +1710,35 @@ struct Engine {
                 // are drawn now)
                 RawSlot &rs = ring[batch % raw_depth];
                 S.nhat_raw = raw_buf[batch % raw_depth];
-                if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }
+                if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }      // (in step with other runs: their common wait, Cohort::flush)
                 else {
                     if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
-                    (void)pc_launch_nhats_part(&S, batch, B, 1, st, (multi || (cfg.ablate & 128)) ? 1 : 0);
+                    if (co && pc_bases_t_ok(&S)) co->rec(CK_BASES, S, {}, {(long long)B}, {(int)batch});
+                    else (void)pc_launch_nhats_part(&S, batch, B, 1, st, (multi || (cfg.ablate & 128)) ? 1 : 0);
                 }
                 rs.valid = false;
                 fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
-                if (!fused_slice) (void)pc_launch_nhats_part(&S, batch, B, 2, st, 0);
+                if (!fused_slice) { if (co) co->flush(); (void)pc_launch_nhats_part(&S, batch, B, 2, st, 0); }
             }
-            else if (pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            else if ((co ? (co->flush(), 0) : 0) || pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             kt.end(KT_NHATS, e0);
             hipEvent_t e1 = spec ? nullptr : kt.begin(KT_SLICE);
             S.spec_guard = spec ? 1 : 0;                                         // (the kernel looks at the contraction's verdict first)
-            if (callback_mode) { slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
+            if (callback_mode) { if (co) co->flush(); slice_callback(batch); if (stop.load(std::memory_order_relaxed)) { r_rc = 5; return false; } }
             // next to other runs of this device (or settings.ablate bit 6): the lane = chain kernel (pc_slice_t.hip), the same
             // numbers from 1/60 of the wavefronts
-            else if (fused_slice && !spec && (multi || (cfg.ablate & 64)) && pc_slice_t_ok(&S, h_ctl->ncluster)) (void)pc_launch_slice_t(&S, batch, B, st);
-            else if (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            else if (fused_slice && !spec && (multi || (cfg.ablate & 64)) && pc_slice_t_ok(&S, h_ctl->ncluster)) {
+                if (co) co->rec(CK_SLICE, S, {}, {(long long)B}, {(int)batch}); else (void)pc_launch_slice_t(&S, batch, B, st);
+                // in step with other runs: the bases of the next nursery on the runs' second stream, next to this round's kernels
+                if (co && co->st2 && splittable && raw_depth >= 2 && pc_bases_t_ok(&S)) {
+                    const unsigned x = batch + 1;
+                    RawSlot &rn = ring[x % raw_depth];
+                    PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+                    co->rec(CK_BASES_NEXT, S1, {}, {(long long)B}, {(int)x});
+                    rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true;
+                }
+            }
+            else if ((co ? (co->flush(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             S.spec_guard = 0;
             kt.end(KT_SLICE, e1);
             if (split && !spec) side_prefetch(batch);      // (speculative: only once the device is known to have taken the nursery)
@@ -1661,9 +1812,9 @@ struct Engine {
                 const bool have = spec_pending;                 // (still pending here = the device took it: round_finish undid the others)
                 spec_pending = false;
                 if (have) side_prefetch(batch - 1);
-                else if (!enqueue_nursery(false)) return false;
+                else { const auto n0 = std::chrono::steady_clock::now(); const bool okn = enqueue_nursery(false); g_dbg_nursery_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - n0).count(); if (!okn) return false; }
             }
-            if (fresh_nursery) ensure_capacity();
+            if (fresh_nursery) { const auto n0 = std::chrono::steady_clock::now(); ensure_capacity(); g_dbg_capacity_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - n0).count(); }
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
@@ -1671,11 +1822,15 @@ struct Engine {
             if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0; S.nn_valid = 0;                     // (the one-cluster kernels do not keep the list bookkeeping)
+                if (co) { if (!sort_valid) { co->rec(CK_SORT, S, {}, {}, {}); sort_valid = true; } co->rec(CK_CONSUME, S, {}, {}, {}); }
+                else {
                 if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }
                 rc2 = rc2 || pc_launch_consume_par(&S, st);      // also lays out the phantoms
+                }
             }
-            else if (use_fast) { sort_valid = false; S.nn_valid = 0; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
+            else if (use_fast) { if (co) co->flush(); sort_valid = false; S.nn_valid = 0; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else {
+                if (co) co->flush();
                 sort_valid = false;
                 // several clusters: rank the possible nearest neighbours of every baby still in the nursery once, on
                 // the whole chip; the serial contraction then walks short lists instead of searching the live set
@@ -1696,7 +1851,7 @@ struct Engine {
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); r_rc = 4; return false; }
             kt.end(KT_CONSUME, e2);
             hipEvent_t e3 = kt.begin(KT_APPLY);
-            pc_launch_apply(&S, batch - 1, B, st);
+            if (co && S.pool) co->rec(CK_APPLY, S, {}, {(long long)B}, {(int)(batch - 1)}); else { if (co) co->flush(); pc_launch_apply(&S, batch - 1, B, st); }
             kt.end(KT_APPLY, e3);
             // the main stream's wait for the next nursery's bases is enqueued now, behind this round's kernels (long
             // satisfied when the next k_slice gets there), not between the stamp and the next launch
@@ -1755,6 +1910,7 @@ struct Engine {
     // kill-off, results; the code pchip_run returns
     int end(pchip_result *out)
     {
+        if (co) co->flush();
         const bool par_ok = r_par_ok; bool &sort_valid = r_sort_valid;
         const auto t0 = r_t0, t1 = r_t1;
         auto t2 = clk::now();
@@ -1893,7 +2049,7 @@ struct Engine {
         if (h_note) hfree((void *)h_note); h_note = nullptr;
         if (ev_apply) { hpool().put_sync_event(ev_apply); ev_apply = nullptr; }
 
-        if (st) { (void)hipStreamSynchronize(st); hpool().put_stream(st); } st = nullptr;
+        if (st) { (void)hipStreamSynchronize(st); if (!co) hpool().put_stream(st); } st = nullptr;
         if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
         if (st_side) {
             (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
@@ -1990,9 +2146,98 @@ int pchip_run_hooks(const pchip_settings *s, const pchip_like *like, const pchip
 // run, as before, spent its time in the HIP runtime's locks: 533 launches per run from sixteen threads at once gave 1.5 x the
 // throughput of one run; a single run keeps one wavefront per SIMD busy and the contraction kernel one CU.)
 // Built-in device likelihoods only: a host callback belongs to its caller's thread.  Returns 0 or the first failing run's code.
+// The runs of `seeds` on `device`, up to max_in_flight of them in step on one stream (Cohort): every phase of the round is gone
+// through for all of them before anything is launched, then each kernel of the phase once for all.  PC_COHORT=0: the older
+// scheduler below (one stream per run, kernels launched run by run).
+static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds, int device,
+                         int max_in_flight, pchip_result *results)
+{
+    static const bool prof = std::getenv("PC_DEBUG") && std::atoi(std::getenv("PC_DEBUG")) == 5;
+    for (int k = 0; k < nseeds; ++k) std::memset(&results[k], 0, sizeof(pchip_result));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::fprintf(stderr, "polychord_hip: no HIP device available -- this engine has no CPU path\n"); return PC_RC_DEVICE; }
+    (void)hipSetDevice(device >= 0 ? device % ndev : 0);
+    const int W = std::max(1, std::min(std::min(max_in_flight, nseeds), 64));
+    int worst = 0;
+    for (int base = 0; base < nseeds && !worst; base += W) {
+        const int n = std::min(W, nseeds - base);
+        Cohort co;
+        co.st = hpool().get_stream();
+        static const bool side_off = std::getenv("PC_COHORT_SIDE") && std::atoi(std::getenv("PC_COHORT_SIDE")) == 0;
+        if (!side_off) { co.st2 = hpool().get_stream(); co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
+        std::vector<Engine *> E((size_t)n, nullptr);
+        std::vector<char> live((size_t)n, 0), enq((size_t)n, 0);
+        const auto T0 = std::chrono::steady_clock::now();
+        long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0;
+        int *h_totals = nullptr; size_t totals_cap = 0;
+        auto nowc = [] { return std::chrono::steady_clock::now(); };
+        auto secc = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        auto close = [&](int k, int rc) {
+            if (rc != 0) { pchip_result_free(&results[base + k]); if (!worst) worst = rc; }
+            E[k]->destroy(); delete E[k]; E[k] = nullptr; live[k] = 0;
+        };
+        try {
+            for (int k = 0; k < n; ++k) {
+                E[k] = new Engine; E[k]->co = &co;
+                pchip_settings c = *s; c.seed = seeds[base + k]; c.device = device;
+                const auto b0 = nowc();
+                E[k]->setup(c, *like, *prior);
+                const int rc = E[k]->begin();
+                t_begin += secc(b0, nowc());
+                if (rc >= 0) { close(k, rc ? rc : PC_RC_DEVICE); continue; }
+                live[k] = 1;
+            }
+            int nlive = 0;
+            for (int k = 0; k < n; ++k) nlive += live[k];
+            while (nlive > 0 && !worst) {
+                {   // phantom arrays that are full: compacted together, one wait for all
+                    int nc = 0;
+                    for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) { E[k]->compact_record(); nc++; }
+                    if (nc) {
+                        const auto c0 = nowc();
+                        co.flush();
+                        if ((size_t)n > totals_cap) { if (h_totals) (void)hipHostFree(h_totals); HIPCHK(hipHostMalloc((void **)&h_totals, sizeof(int) * n, hipHostMallocDefault)); totals_cap = (size_t)n; }
+                        for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) HIPCHK(hipMemcpyAsync(&h_totals[k], E[k]->d_total, sizeof(int), hipMemcpyDeviceToHost, co.st));
+                        HIPCHK(hipStreamSynchronize(co.st));
+                        for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) E[k]->compact_finish(h_totals[k]);
+                        t_comp += secc(c0, nowc());
+                    }
+                }
+                { const auto a0 = nowc(); for (int k = 0; k < n; ++k) enq[k] = (live[k] && E[k]->round_enqueue()) ? 1 : 0; const auto a1 = nowc(); t_enq += secc(a0, a1);
+                  co.flush(); t_fl += secc(a1, nowc()); }
+                { const auto w0 = nowc(); for (int k = 0; k < n; ++k) if (enq[k]) while (!E[k]->round_ready()) __builtin_ia32_pause(); t_wait += secc(w0, nowc()); }
+                { const auto a0 = nowc(); for (int k = 0; k < n; ++k) if (enq[k] && !E[k]->round_finish()) enq[k] = 0; const auto a1 = nowc(); t_fin += secc(a0, a1);
+                  co.flush(); t_fl += secc(a1, nowc()); }
+                rounds++;
+                bool any_done = false;
+                for (int k = 0; k < n; ++k) any_done = any_done || (live[k] && !enq[k]);
+                if (any_done && co.st2) HIPCHK(hipStreamSynchronize(co.st2));      // (bases drawn ahead for a run that is over: not into freed memory)
+                for (int k = 0; k < n; ++k) if (live[k] && !enq[k]) { const auto e0 = nowc(); const int r = E[k]->r_rc ? E[k]->r_rc : E[k]->end(&results[base + k]); close(k, r); nlive--; t_end += secc(e0, nowc()); }
+            }
+        }
+        catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); (void)hipGetLastError(); if (!worst) worst = e.code; }
+        catch (const std::bad_alloc &) { std::fprintf(stderr, "polychord_hip: out of host memory\n"); if (!worst) worst = PC_RC_MEMORY; }
+        if (co.st2) (void)hipStreamSynchronize(co.st2);
+        for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
+        if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_s * 1e3, g_dbg_compact_s * 1e3, g_dbg_capacity_s * 1e3); g_dbg_nursery_s = g_dbg_compact_s = g_dbg_capacity_s = 0; }
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, end + teardown %.2f); %ld records launched together, %ld one by one\n", n, rounds,
+                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end * 1e3, co.n_fused, co.n_single);
+        co.destroy();
+        if (h_totals) (void)hipHostFree(h_totals);
+        (void)hipStreamSynchronize(co.st);
+        hpool().put_stream(co.st);
+        if (co.st2) { (void)hipStreamSynchronize(co.st2); hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
+    }
+    return worst;
+}
+
 int pc_run_many(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds, int device,
                 int max_in_flight, pchip_result *results)
 {
+    {
+        static const bool cohort_off = std::getenv("PC_COHORT") && std::atoi(std::getenv("PC_COHORT")) == 0;
+        if (!cohort_off) return pc_run_cohort(s, like, prior, nseeds, seeds, device, max_in_flight, results);
+    }
     struct Job { Engine *E = nullptr; int k = -1; bool waiting = false; };
     std::vector<Job> jobs((size_t)std::max(1, std::min(max_in_flight, nseeds)));
     int next = 0, active = 0, worst = 0;

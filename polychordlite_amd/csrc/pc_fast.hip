@@ -60,7 +60,7 @@ __device__ __forceinline__ double scan_add(double v, int lane, int m)
 // ------------------------------------------------------------------------------------------
 // sort of the live slots by (logL, list position); free slots last
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2)
+__device__ __forceinline__ void sort_live_body(const PcState &S, int npow2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *kv = (double *)smem;            // [npow2]
@@ -88,6 +88,9 @@ __global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2)
     const int NS = (S.Ncap + 63) & ~63;
     for (int i = tid; i < NS; i += 1024) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
 }
+__global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2) { sort_live_body(S, npow2); }
+__global__ __launch_bounds__(1024) void k_sort_live_many(const PcManyRec *R, int npow2) { sort_live_body(R[blockIdx.y].S, npow2); }
+
 
 // ------------------------------------------------------------------------------------------
 // the contraction
@@ -463,6 +466,18 @@ extern "C" int pc_launch_sort_live(const PcState *S, hipStream_t st)
     static size_t d1 = 0;
     if (shs > d1) { (void)hipFuncSetAttribute((const void *)k_sort_live, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs); d1 = shs; }
     hipLaunchKernelGGL(k_sort_live, dim3(1), dim3(1024), shs, st, *S, npow2);
+    return 0;
+}
+
+extern "C" int pc_launch_sort_live_many(const PcState *S, const PcManyRec *dR, int R, hipStream_t st)
+{
+    int npow2 = 64;
+    while (npow2 < S->Ncap) npow2 <<= 1;
+    const size_t shs = (size_t)npow2 * 16;
+    if (shs > 160 * 1024) return 1;
+    static size_t d1 = 0;
+    if (shs > d1) { (void)hipFuncSetAttribute((const void *)k_sort_live_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs); d1 = shs; }
+    hipLaunchKernelGGL(k_sort_live_many, dim3(1, R), dim3(1024), shs, st, dR, npow2);
     return 0;
 }
 

@@ -234,7 +234,7 @@ __device__ __forceinline__ double block_scan_add(double v, int lane, int wv, dou
     return v + p;
 }
 
-__global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
+__device__ __forceinline__ void consume_par_body(const PcState &S)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -765,6 +765,9 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S)
 #endif
     }
 }
+__global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S) { consume_par_body(S); }
+__global__ __launch_bounds__(PAR_NT) void k_consume_par_many(const PcManyRec *R) { consume_par_body(R[blockIdx.y].S); }
+
 
 // ------------------------------------------------------------------------------------------
 // Kill-off (nested_sampling.F90:381-384): every remaining live point dies, lowest first.  Death i of
@@ -869,6 +872,17 @@ extern "C" int pc_launch_consume_par(const PcState *S, hipStream_t st)
     static size_t d = 0;
     if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
     hipLaunchKernelGGL(k_consume_par, dim3(1), dim3(PAR_NT), sh, st, *S);
+    return 0;
+}
+
+// the same launch for R runs of one shape at once (blockIdx.y = run; dR: device array of their records)
+extern "C" int pc_launch_consume_par_many(const PcState *S, const PcManyRec *dR, int R, hipStream_t st)
+{
+    const size_t sh = par_lds(S);
+    if (sh + PAR_STATIC_LDS > 160 * 1024 || S->B > PAR_NT) return 1;
+    static size_t d = 0;
+    if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
+    hipLaunchKernelGGL(k_consume_par_many, dim3(1, R), dim3(PAR_NT), sh, st, dR);
     return 0;
 }
 

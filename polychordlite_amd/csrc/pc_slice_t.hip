@@ -61,7 +61,7 @@ __device__ __forceinline__ Q3 wave_order_sum3(const F &leaf)
 
 // DT = nDims (1 .. 24); UNIT: the prior is the unit hypercube itself (lo = 0, span = 1: theta = cube, bit for bit)
 template <int DT, bool UNIT>
-__global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp)
+__device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, int nchains, int nrp)
 {
 #pragma clang fp contract(off)       // every fused multiply-add below is written out: the roundings of k_slice, whatever this kernel's shape suggests to the compiler
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -348,16 +348,25 @@ __global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int n
 #endif
     if (act) S.ch_nlike[chain] = nlike;
 }
+template <int DT, bool UNIT>
+__global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp) { slice_t_body<DT, UNIT>(S, batch, nchains, nrp); }
+template <int DT, bool UNIT>
+__global__ __launch_bounds__(64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
+
 
 static int deck_stride(int nr) { int q = (nr + 3) / 4; if ((q & 1) == 0) q++; return 4 * q; }   // bytes, an odd number of words: lanes on different banks
 
 template <int DT>
-static void launch_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
     constexpr int FW = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
     const int nrp = deck_stride(S->nr), grid = (nchains + 63) / 64;
     const size_t sh = sizeof(double) * ((size_t)DT * DT + 2 * FW) + (size_t)64 * nrp + sizeof(double) * 64 * (size_t)(S->nT | 1);
-    if (S->prior.lo == nullptr && S->prior.hi == nullptr) hipLaunchKernelGGL((k_slice_t<DT, true>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
+    const bool unit = S->prior.lo == nullptr && S->prior.hi == nullptr;
+    if (dR) {
+        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
+        else hipLaunchKernelGGL((k_slice_t_many<DT, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
+    } else if (unit) hipLaunchKernelGGL((k_slice_t<DT, true>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
     else hipLaunchKernelGGL((k_slice_t<DT, false>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
 }
 
@@ -405,7 +414,7 @@ __device__ __forceinline__ double dot4(const double (&a)[D], const double (&b)[D
 }
 
 // step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
-__global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, int nbases, int NC)
+__device__ __forceinline__ void deviates_t_body(const PcState &S, unsigned batch, int nbases, int NC)
 {
     const int D = S.D, DD = D * D;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -421,17 +430,22 @@ __global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, i
     if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
     if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
 }
+__global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, int nbases, int NC) { deviates_t_body(S, batch, nbases, NC); }
+__global__ __launch_bounds__(256) void k_deviates_t_many(const PcManyRec *R, int nbases, int NC) { deviates_t_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, NC); }
+
 
 // step 2, lane = basis: normalise, Gram-Schmidt, in the lane's own stretch of LDS
 template <int DT>
-__global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int nbases /* chains x bases per chain */, int per /* bases per workgroup */)
+__device__ __forceinline__ void bases_t_body(const PcState &S, unsigned batch, int nbases /* chains x bases per chain */, int per /* bases per workgroup */)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = DT, DD = D * D, ST = DD | 1;
-    const int lane = threadIdx.x, g = blockIdx.x * per + lane;
-    const bool active = lane < per && g < nbases;
-    double *sG = (double *)smem;                                 // [per][ST] a basis per lane, vector-major; odd stride: lanes on different banks
+    // P = 64 / per lanes share a basis (what fits the workgroup's LDS leaves lanes over): lane p of a basis takes the vectors
+    // k = p, p + P, ... in every pass -- at a Gram-Schmidt step the projections of the later vectors are independent of each other
+    const int P = 64 / per, lane = threadIdx.x, bl = lane / P, pl = lane - bl * P, g = blockIdx.x * per + bl;
+    const bool active = bl < per && g < nbases;
+    double *sG = (double *)smem;                                 // [per][ST] a basis per lane group, vector-major; odd stride: bases on different banks
     const int nb_here = min(per, nbases - (int)blockIdx.x * per);
     // ---- the deviates arrive in runs of 64 consecutive addresses: [chain][basis][vector][D] is linear in the basis number
     for (int b = 0; b < nb_here; ++b) {
@@ -439,11 +453,11 @@ __global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int n
         const double *src = S.nhat_raw + ((size_t)blockIdx.x * per + b) * DD;
         for (int e = lane; e < DD; e += 64) dstl[e] = src[e];
     }
-    __syncthreads();                                              // (one wave)
-    if (active) {
-        double *G = sG + (size_t)lane * ST;
-        // ---- random_direction (random_utils.F90:276-298): every vector normalised
-        for (int i = 0; i < D; ++i) {
+    __syncthreads();                                              // (one wave; the barriers below order the lanes' LDS traffic for the compiler too)
+    double *G = sG + (size_t)(active ? bl : 0) * ST;
+    // ---- random_direction (random_utils.F90:276-298): every vector normalised
+    if (active)
+        for (int i = pl; i < D; i += P) {
             double v[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) v[d] = G[i * D + d];
@@ -451,16 +465,21 @@ __global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int n
 #pragma unroll
             for (int d = 0; d < D; ++d) G[i * D + d] = v[d] * inrm;
         }
-        // ---- Gram-Schmidt (random_utils.F90:391-399): the pivot is vector j, orthogonal to its predecessors and not yet normalised
-        for (int j = 0; j < D; ++j) {
+    __syncthreads();
+    // ---- Gram-Schmidt (random_utils.F90:391-399): the pivot is vector j, orthogonal to its predecessors and not yet normalised
+    for (int j = 0; j < D; ++j) {
+        if (active) {
             double q[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] = G[j * D + d];
             const double qq = dot4_same<D, false>(q);
-            const double inrm = 1.0 / sqrt(qq);
+            if (pl == j % P) {
+                const double inrm = 1.0 / sqrt(qq);
 #pragma unroll
-            for (int d = 0; d < D; ++d) G[j * D + d] = q[d] * inrm;
-            for (int k = j + 1; k < D; ++k) {
+                for (int d = 0; d < D; ++d) G[j * D + d] = q[d] * inrm;
+            }
+            int k = j + 1 + ((pl - (j + 1)) % P + P) % P;       // the first vector after j that is this lane's
+            for (; k < D; k += P) {
                 double v[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) v[d] = G[k * D + d];
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int n
                 for (int d = 0; d < D; ++d) G[k * D + d] = fma(-cproj, q[d], v[d]);
             }
         }
+        __syncthreads();
     }
     __syncthreads();                                              // (one wave)
     // ---- the bases leave the way the deviates came
@@ -478,21 +498,35 @@ __global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int n
         for (int e = lane; e < DD; e += 64) dst[e] = src[e];
     }
 }
+template <int DT>
+__global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int nbases, int per) { bases_t_body<DT>(S, batch, nbases, per); }
+template <int DT>
+__global__ __launch_bounds__(64) void k_bases_t_many(const PcManyRec *R, int nbases, int per) { bases_t_body<DT>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, per); }
+
 
 template <int DT>
-static int launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+static int launch_bases_t(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
     constexpr int DD = DT * DT, ST = DD | 1, NC = (DD + 1) / 2;
     const size_t per_b = sizeof(double) * ST;
-    // (a workgroup's LDS is what it costs the runs next to it: 64 KB leaves room on the CU for their sampling waves)
-    int per = (int)((size_t)(64 * 1024 - 64) / per_b);
+    // (few bases to a workgroup: 64 / per lanes work on each, the workgroup is over sooner, and its LDS -- what it costs the
+    //  kernels next to it -- is small: ten of them to a CU)
+    static const int lds_kb = std::getenv("PC_BASES_T_LDS") ? std::atoi(std::getenv("PC_BASES_T_LDS")) : 16;
+    int per = (int)((size_t)(lds_kb * 1024 - 64) / per_b);
     if (per > 64) per = 64;
-    if (per < 8) return 1;
+    if (per < 1) per = 1;
     const int nbases = nchains * S->nb_total, blocks = (nbases + per - 1) / per;
     const long long ncalls = (long long)nbases * NC;
-    hipLaunchKernelGGL(k_deviates_t, dim3((unsigned)((ncalls + 255) / 256)), dim3(256), 0, st, *S, batch, nbases, NC);
+    const unsigned gdev = (unsigned)((ncalls + 255) / 256);
     const size_t sh = per_b * per + 16;
-    static size_t done = 0;                                       // (per instantiation)
+    static size_t done = 0, done_m = 0;                           // (per instantiation)
+    if (dR) {
+        hipLaunchKernelGGL(k_deviates_t_many, dim3(gdev, R), dim3(256), 0, st, dR, nbases, NC);
+        if (sh > 48 * 1024 && sh > done_m) { (void)hipFuncSetAttribute((const void *)k_bases_t_many<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_m = sh; }
+        hipLaunchKernelGGL((k_bases_t_many<DT>), dim3(blocks, R), dim3(64), sh, st, dR, nbases, per);
+        return 0;
+    }
+    hipLaunchKernelGGL(k_deviates_t, dim3(gdev), dim3(256), 0, st, *S, batch, nbases, NC);
     if (sh > 48 * 1024 && sh > done) { (void)hipFuncSetAttribute((const void *)k_bases_t<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
     hipLaunchKernelGGL((k_bases_t<DT>), dim3(blocks), dim3(64), sh, st, *S, batch, nbases, per);
     return 0;
@@ -500,18 +534,25 @@ static int launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStre
 
 }   // namespace
 
-extern "C" int pc_launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+static bool bases_t_takes(const PcState *S)
 {
     static const bool off = std::getenv("PC_BASES_T_OFF") != nullptr;
-    if (off || S->ngrade > 1 || S->seq_mode || S->nhat_raw == nullptr || S->D < 2 || S->D > 24) return 1;
+    return !(off || S->ngrade > 1 || S->seq_mode || S->nhat_raw == nullptr || S->D < 2 || S->D > 24);
+}
+static int bases_t_dispatch(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
+{
+    if (!bases_t_takes(S)) return 1;
     switch (S->D) {
-#define PC_T(n) case n: return launch_bases_t<n>(S, batch, nchains, st);
+#define PC_T(n) case n: return launch_bases_t<n>(S, dR, R, batch, nchains, st);
         PC_T(2) PC_T(3) PC_T(4) PC_T(5) PC_T(6) PC_T(7) PC_T(8) PC_T(9) PC_T(10) PC_T(11) PC_T(12)
         PC_T(13) PC_T(14) PC_T(15) PC_T(16) PC_T(17) PC_T(18) PC_T(19) PC_T(20) PC_T(21) PC_T(22) PC_T(23) PC_T(24)
 #undef PC_T
     }
     return 1;
 }
+extern "C" int pc_bases_t_ok(const PcState *S) { return bases_t_takes(S) ? 1 : 0; }
+extern "C" int pc_launch_bases_t(const PcState *S, unsigned batch, int nchains, hipStream_t st) { return bases_t_dispatch(S, nullptr, 0, batch, nchains, st); }
+extern "C" int pc_launch_bases_t_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st) { return bases_t_dispatch(S, dR, R, batch, nchains, st); }
 
 namespace {
 }   // namespace
@@ -528,13 +569,15 @@ extern "C" int pc_slice_t_ok(const PcState *S, int ncluster)
     return 1;
 }
 
-extern "C" int pc_launch_slice_t(const PcState *S, unsigned batch, int nchains, hipStream_t st)
+static int slice_t_dispatch(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
     switch (S->D) {
-#define PC_T(n) case n: launch_t<n>(S, batch, nchains, st); return 0;
+#define PC_T(n) case n: launch_t<n>(S, dR, R, batch, nchains, st); return 0;
         PC_T(1) PC_T(2) PC_T(3) PC_T(4) PC_T(5) PC_T(6) PC_T(7) PC_T(8) PC_T(9) PC_T(10) PC_T(11) PC_T(12)
         PC_T(13) PC_T(14) PC_T(15) PC_T(16) PC_T(17) PC_T(18) PC_T(19) PC_T(20) PC_T(21) PC_T(22) PC_T(23) PC_T(24)
 #undef PC_T
     }
     return 1;
 }
+extern "C" int pc_launch_slice_t(const PcState *S, unsigned batch, int nchains, hipStream_t st) { return slice_t_dispatch(S, nullptr, 0, batch, nchains, st); }
+extern "C" int pc_launch_slice_t_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st) { return slice_t_dispatch(S, dR, R, batch, nchains, st); }

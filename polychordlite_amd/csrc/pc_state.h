@@ -171,6 +171,11 @@ struct PcState {
     PcCtl *ctl_host; unsigned notify_seq;
 };
 
+// One run's share of a launch made for several runs at once (pchip_run_repeats: the runs of a device go round by round together,
+// and each kernel of a round is launched ONCE for all of them, blockIdx.y = run): its state, and the buffers the one-run
+// kernel takes as arguments (update: 0 keep, 1 block counts, 2 total, 3-6 the alternate phantom arrays, 7 partial sums, 8 shift).
+struct PcManyRec { PcState S; void *p[10]; int ia[6]; int pad[2]; };      // ia: 0 the nursery's number, 1 phantom rows in use (update), 2 its blocks
+
 // Called by EVERY thread of the (single) workgroup at the end of a contraction kernel, after thread 0 has stored the new
 // control block to *S.ctl.  The host mirror is fine-grained host memory over PCIe; a system-scope release (fence + L2
 // write-back) in front of a stamp costs the kernel ~15 us, and a dozen dependent stores by one thread ~6 us, so: no

@@ -65,7 +65,7 @@ __device__ __forceinline__ void upd_stage_masked(const double *src0, unsigned lo
 // state at the mark the launch recorded (PcCtl::upd_*): the threshold of the clean is the logL of the death at the mark;
 // the moments leave out what came after it -- phantoms of later chains, live points accepted later -- and take in the
 // points that were alive then and have died since (their rows are in the dead array)
-__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def)
+__device__ __forceinline__ void upd_flag_body(const PcState &S, int nph, unsigned char *keep, int *blk_count, int def)
 {
     __shared__ int cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -90,6 +90,9 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigne
     __syncthreads();
     if (tid == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def) { upd_flag_body(S, nph, keep, blk_count, def); }
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag_many(const PcManyRec *R, int def) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; upd_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], def); }
+
 
 // exclusive scan of the block counts in place, one workgroup, 4096 counts at a time (four per thread, coalesced)
 __global__ __launch_bounds__(1024) void k_upd_scan(int *cnt, int n, int *total)
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_index(int nph, const unsigned ch
 // the counts of the blocks before it, which 256 threads add up from L2 in about a microsecond (at 3750 blocks: 7 M loads on the
 // whole chip) -- less than the one-workgroup scan kernel and the launch boundary behind it (4.7 + 3.5 us per update)
 #define UPD_SELF_BLOCKS 4096
-__global__ __launch_bounds__(UPD_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total)
+__device__ __forceinline__ void upd_index_self_body(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total)
 {
     __shared__ int cnt[4], part[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_index_self(int nph, const unsign
     for (int x = 0; x < wv; ++x) off += cnt[x];
     if (km) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
 }
+__global__ __launch_bounds__(UPD_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total) { upd_index_self_body(nph, keep, blk_count, nblk, idx, total); }
+__global__ __launch_bounds__(UPD_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
+
 
 // sixteen rows given by index, coordinates minus shift and a one, to consecutive tile rows; lane = element, the loads of
 // two passes (elements lane and lane + 64) in flight together
@@ -230,10 +236,10 @@ __device__ __forceinline__ int updg_slot(int D, int ti, int tj, int li, int lk, 
 }
 
 template <int NT, bool IDX>
-__global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
-                                                    double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
-                                                    const int *idx, const int *nidx_p,
-                                                    const double *shift, double *part, int E, int def, int nlb, int ndb)
+__device__ __forceinline__ void upd_gather_body(const PcState &S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
+                                                double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                const int *idx, const int *nidx_p,
+                                                const double *shift, double *part, int E, int def, int nlb, int ndb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool KS = NT <= 2;
@@ -396,10 +402,24 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
                 }
     }
 }
+template <int NT, bool IDX>
+__global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk, const unsigned char *keep, const int *blk_off,
+                                                    double *ph2, double *phL2, unsigned *phC2, unsigned long long *phU2,
+                                                    const int *idx, const int *nidx_p,
+                                                    const double *shift, double *part, int E, int def, int nlb, int ndb)
+{ upd_gather_body<NT, IDX>(S, nph, nblk, keep, blk_off, ph2, phL2, phC2, phU2, idx, nidx_p, shift, part, E, def, nlb, ndb); }
+template <int NT>
+__global__ __launch_bounds__(256) void k_upd_gather_many(const PcManyRec *R, int E, int def, int nlb, int ndb)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    upd_gather_body<NT, true>(r.S, r.ia[1], r.ia[2], (const unsigned char *)r.p[0], (const int *)r.p[1], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5],
+                              (unsigned long long *)r.p[6], (const int *)r.p[5], (const int *)r.p[2], (const double *)r.p[8], (double *)r.p[7], E, def, nlb, ndb);
+}
+
 
 // partial records folded in groups of sixteen (one batch of loads per thread), in block order
 #define UPD_FOLD 16
-__global__ __launch_bounds__(256) void k_upd_fold(const double *part, int nb, int E, double *part2)
+__device__ __forceinline__ void upd_fold_body(const double *part, int nb, int E, double *part2)
 {
     const int g = blockIdx.x;
     for (int e = threadIdx.x; e < E; e += 256) {
@@ -412,9 +432,12 @@ __global__ __launch_bounds__(256) void k_upd_fold(const double *part, int nb, in
         part2[(size_t)g * E + e] = s;
     }
 }
+__global__ __launch_bounds__(256) void k_upd_fold(const double *part, int nb, int E, double *part2) { upd_fold_body(part, nb, E, part2); }
+__global__ __launch_bounds__(256) void k_upd_fold_many(const PcManyRec *R, int nb, int E) { double *part = (double *)R[blockIdx.y].p[7]; upd_fold_body(part, nb, E, part + (size_t)nb * E); }
+
 
 // fold + mean + covariance + Cholesky; one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const double *part, int E, double *shift, int def)
+__device__ __forceinline__ void upd_final_body(const PcState &S, int nb, const double *part, int E, double *shift, int def)
 {
     __shared__ double acc[4][256];                 // E <= 256 * 2: entries beyond 256 take a second round
     __shared__ double A[32 * 32], L[32 * 32], mu[32];
@@ -501,6 +524,9 @@ __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const dou
     if (tid == 0) { const long long f2 = clock64(); S.ctl->gen_cyc[2] += f1 - f0; S.ctl->gen_cyc[3] += f2 - f1; S.ctl->nn_walks += f0; }
 #endif
 }
+__global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const double *part, int E, double *shift, int def) { upd_final_body(S, nb, part, E, shift, def); }
+__global__ __launch_bounds__(1024) void k_upd_final_many(const PcManyRec *R, int nb, int E, int def, int G) { const PcManyRec &r = R[blockIdx.y]; upd_final_body(r.S, nb, (const double *)r.p[7] + (size_t)G * E, E, (double *)r.p[8], def); }
+
 
 // records added up; delta = mean - shift; n cov = M2 - n delta delta^T for k_cov_final_chol (which divides by n, stores the
 // covariance and factorises in the reference's order of operations); new shift; thresholds reset
@@ -598,4 +624,31 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     if (shf > donef[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef[devi].store(shf); }
     hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
     pc_launch_chol_only(S, ncov, count, st);
+}
+
+extern "C" int pc_update_fused_grid(const PcState *S, int nph, int deferred) { return upd_grid(S, nph, deferred); }
+// the fused update for R runs of one shape at once (blockIdx.y = run); every run brings its own number of phantom rows
+// (PcManyRec::ia[1], its blocks in ia[2]); all of them the same number G of gathering workgroups (pc_update_fused_grid) and
+// nblk_max >= their blocks.  1: not this way (the caller launches them one by one)
+extern "C" int pc_launch_update_fused_many(const PcState *S, const PcManyRec *dR, int R, int nblk_max, int G, int deferred, hipStream_t st)
+{
+    const int D = S->D, nlb = (S->Ncap + UPD_ROWS - 1) / UPD_ROWS, E = pc_update_fused_entries(S);
+    if (!S->pool || nblk_max > UPD_SELF_BLOCKS || D >= 32 || nblk_max < 1) return 1;
+    const int ndb = deferred ? (S->B + UPD_ROWS - 1) / UPD_ROWS : 0;
+    const int NTv = (D + 1 + 15) / 16, TSv = NTv <= 2 ? 16 * NTv + 1 : 16 * NTv + ((NTv & 1) ? 0 : 16), CAPv = NTv <= 2 ? 128 : 64;
+    const int ng = (G + UPD_FOLD - 1) / UPD_FOLD;
+    size_t shw = sizeof(double) * ((size_t)CAPv * TSv + D);
+    if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);
+    hipLaunchKernelGGL(k_upd_flag_many, dim3(nblk_max, R), dim3(UPD_NT), 0, st, dR, deferred);
+    hipLaunchKernelGGL(k_upd_index_self_many, dim3(nblk_max, R), dim3(UPD_NT), 0, st, dR);
+    int devi = 0; (void)hipGetDevice(&devi); devi &= 63;
+#define UPDM_LAUNCH(NT) { \
+        static std::atomic<size_t> donem_##NT[64]; \
+        if (shw > donem_##NT[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_gather_many<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); donem_##NT[devi].store(shw); } \
+        hipLaunchKernelGGL((k_upd_gather_many<NT>), dim3(G, R), dim3(256), shw, st, dR, E, deferred, nlb, ndb); }
+    if (NTv == 1) UPDM_LAUNCH(1) else UPDM_LAUNCH(2)
+#undef UPDM_LAUNCH
+    hipLaunchKernelGGL(k_upd_fold_many, dim3(ng, R), dim3(256), 0, st, dR, G, E);
+    hipLaunchKernelGGL(k_upd_final_many, dim3(1, R), dim3(1024), 0, st, dR, ng, E, deferred, G);
+    return 0;
 }
