@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1], the metric configuration (default, what the driver runs); c3 / c4 / c5 = "
                          "BASELINE configs[2..4] through the same harness, also with --gpus N (their lines are kept under profiles/)")
-    ap.add_argument("--concurrent", default="4,8,16,32",
+    ap.add_argument("--concurrent", default="4,8,16,32,64",
                     help="after the timed steps (N = 1): R independent runs in flight on this GPU for each R of the list "
                          "(polychordlite_amd.repeats.run_repeats; reported separately, never part of `value`); '' or 0 = skip")
     ap.add_argument("--other-configs", default="c3,c4,c5",
@@ -396,7 +396,8 @@ def main():
             mc = samples[-1]
             conc.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": vals[1], "value_min": vals[0], "value_max": vals[2], "samples": 3,
                          "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
-                         "note": "R independent runs in flight on this GPU, one host thread going round their engines (pchip_run_repeats); median of 3 samples"})
+                         "per_run_ms": mc["t_runs_s"] * 1e3 / R,
+                         "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
         sync()
     # the other BASELINE configurations through the same engine, one timed step each (after one untimed step that sizes the
     # block cache): reported next to the headline, never part of `value`

@@ -39,6 +39,7 @@ int pc_launch_slice_t_many(const PcState *, const PcManyRec *, int, unsigned, in
 int pc_launch_bases_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
 int pc_update_fused_grid(const PcState *, int, int);
 int pc_launch_clean_many(const PcManyRec *, int, int, hipStream_t);
+int pc_launch_final_par_many(const PcManyRec *, int, hipStream_t);
 int pc_launch_sort_live_many(const PcState *, const PcManyRec *, int, hipStream_t);
 int pc_launch_consume_par_many(const PcState *, const PcManyRec *, int, hipStream_t);
 int pc_launch_apply_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
@@ -284,7 +285,7 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
 //      ONE stream and go round by round together: what each engine would launch in a phase of the round it writes down here, and
 //      every kernel of the phase is launched ONCE for all of them (blockIdx.y = run, PcManyRec).  The same kernels' bodies on
 //      the same states: the numbers of a run do not know whether it ran alone.
-enum { CK_COMPACT = 0, CK_BASES, CK_SLICE, CK_BASES_NEXT, CK_SORT, CK_CONSUME, CK_APPLY, CK_UPDATE, CK_N };      // (in the order they are launched)
+enum { CK_COMPACT = 0, CK_BASES, CK_SLICE, CK_BASES_NEXT, CK_SORT, CK_CONSUME, CK_APPLY, CK_UPDATE, CK_FINAL, CK_N };      // (in the order they are launched)
 struct Cohort {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // the bases of the NEXT nursery, next to this one's sampling and contraction
@@ -313,6 +314,7 @@ struct Cohort {
         case CK_SLICE: (void)pc_launch_slice_t(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_SORT: (void)pc_launch_sort_live(&r.S, st); break;
         case CK_CONSUME: (void)pc_launch_consume_par(&r.S, st); break;
+        case CK_FINAL: (void)pc_launch_final_par(&r.S, st); break;
         case CK_APPLY: pc_launch_apply(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_UPDATE: pc_launch_update_fused(&r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], (int *)r.p[2], (double *)r.p[3], (double *)r.p[4],
                                                (unsigned *)r.p[5], (unsigned long long *)r.p[6], (double *)r.p[7], (double *)r.p[8], (int)r.a[1], st); break;
@@ -372,6 +374,7 @@ struct Cohort {
             case CK_SLICE: rc = pc_launch_slice_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
             case CK_SORT: rc = pc_launch_sort_live_many(&f.S, d, cnt, q); break;
             case CK_CONSUME: rc = pc_launch_consume_par_many(&f.S, d, cnt, q); break;
+            case CK_FINAL: rc = pc_launch_final_par_many(d, cnt, q); break;
             case CK_APPLY: rc = pc_launch_apply_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
             case CK_UPDATE: { int nbm = 0; for (size_t x = i; x < j; ++x) nbm = std::max(nbm, ord[x]->ia[2]); rc = pc_launch_update_fused_many(&f.S, d, cnt, nbm, (int)f.a[0], (int)f.a[1], q); } break;
             }
@@ -1899,53 +1902,75 @@ struct Engine {
             // 6 us per launch: 72 against 66 us)
             if (h_ctl->status == PC_ST_UPDATE || (h_ctl->upd_pending && h_ctl->status == PC_ST_RUNNING)) {
                 do_update(h_ctl->status != PC_ST_UPDATE); h_ctl->status = PC_ST_RUNNING; h_ctl->upd_pending = 0;
+                // (in step with other runs: every few updates -- a copy request costs the one thread that drives them all ~10 us)
+                if (!co || (size_t)h_ctl->ndead >= h_dead_copied + 4 * (size_t)cfg.nlive) {
                 if (!ev_apply) ev_apply = hpool().get_sync_event();
                 HIPCHK(hipEventRecord(ev_apply, st));       // the dead rows of the rounds so far are in place behind this point
                 stream_dead();
+                }
             }
         }
         return true;
     }
 
     // kill-off, results; the code pchip_run returns
-    int end(pchip_result *out)
+    // ---- the end of a run in two halves, so that runs in step can end together: end_a asks the device for everything (kill-off,
+    //      moments, copies), end_b -- once the stream has been waited for -- makes the results.  end() = both, for a run on its own.
+    struct EndState {
+        double *hlive = nullptr; int *hcl = nullptr; double *d_pmax = nullptr, *h_part = nullptr, *h_zp = nullptr;
+        int nc_end = 0, ncd_max = 0, pmD = 0, pm_nb = 0, pm_pw = 0; clk::time_point t2;
+    } es;
+    void end_a(bool fused_final = false)
     {
         if (co) co->flush();
         const bool par_ok = r_par_ok; bool &sort_valid = r_sort_valid;
-        const auto t0 = r_t0, t1 = r_t1;
-        auto t2 = clk::now();
+        es.t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
         const int nT = S.nT;
-        // (pinned buffers, copies in stream order in front of the kill-off: the host does not stop here; read_ctl below waits)
-        struct HostBuf { double *live = nullptr; int *cl = nullptr; hipStream_t s = nullptr;
-                         ~HostBuf() { if (s) (void)hipStreamSynchronize(s); if (live) hfree(live); if (cl) hfree(cl); } } hb;
-        hb.s = st; hb.live = halloc<double>((size_t)S.Ncap * nT); hb.cl = halloc<int>(S.Ncap);
-        double *hlive = hb.live; int *hcl = hb.cl;
-        HIPCHK(hipMemcpyAsync(hlive, S.live, sizeof(double) * (size_t)S.Ncap * nT, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(hcl, S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost, st));
-        const int nc_end = h_ctl->ncluster;
+        // (pinned buffers, copies in stream order in front of the kill-off: the host does not stop here)
+        es.hlive = halloc<double>((size_t)S.Ncap * nT); es.hcl = halloc<int>(S.Ncap);
+        HIPCHK(hipMemcpyAsync(es.hlive, S.live, sizeof(double) * (size_t)S.Ncap * nT, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(es.hcl, S.live_cluster, sizeof(int) * S.Ncap, hipMemcpyDeviceToHost, st));
+        es.nc_end = h_ctl->ncluster;
         if (h_ctl->ncluster == 0) {
             // a finished run read back from its .resume file: nothing to kill
         } else if (par_ok && h_ctl->ncluster == 1) {
+            if (co && sort_valid) { co->rec(CK_FINAL, S, {}, {}, {}); if (!fused_final) co->flush(); }      // (fused: the caller launches the kill-off of all runs that end now, then calls end_a2)
+            else {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
+            }
         } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st);   // (several clusters: four waves, a death's jobs side by side)
+        if (!fused_final) end_a2();
+    }
+    void end_a2()
+    {
         // what the results need from the device is requested here, behind the kill-off and before the host waits for it: the
         // posterior moments of theta over the dead points (device reduction, fixed order; the kernels take the count from the
-        // control block) and the evidences of the retired clusters -- one wait (read_ctl) instead of four
-        const int pmD = S.D + S.nDer, pm_nb = pc_post_blocks(), pm_pw = 2 * pmD + 1;   // theta and phi columns are contiguous in a row
-        const int ncd_max = std::min(h_ctl->ncluster_dead + h_ctl->ncluster, S.maxc_dead);
+        // control block) and the evidences of the retired clusters -- one wait instead of four
+        es.pmD = S.D + S.nDer; es.pm_nb = pc_post_blocks(); es.pm_pw = 2 * es.pmD + 1;   // theta and phi columns are contiguous in a row
+        es.ncd_max = std::min(h_ctl->ncluster_dead + h_ctl->ncluster, S.maxc_dead);
         // (the partial sums go straight into pinned host memory, which the device addresses like its own: 180 KB over the
         //  link instead of a D2H copy request behind the kernel -- that request stalled its caller for 5-6 ms once per process,
         //  in the second or third run)
-        double *d_pmax = dalloc<double>(pm_nb), *h_part = halloc<double>((size_t)pm_nb * pm_pw);
-        double *h_zp = halloc<double>(2 * (size_t)std::max(1, ncd_max));
-        pc_launch_post_moments(&S, -1, d_pmax, h_part, st);
-        if (ncd_max > 0) {
-            HIPCHK(hipMemcpyAsync(h_zp, S.logZp_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(h_zp + ncd_max, S.logZp2_dead, sizeof(double) * ncd_max, hipMemcpyDeviceToHost, st));
+        es.d_pmax = dalloc<double>(es.pm_nb); es.h_part = halloc<double>((size_t)es.pm_nb * es.pm_pw);
+        es.h_zp = halloc<double>(2 * (size_t)std::max(1, es.ncd_max));
+        pc_launch_post_moments(&S, -1, es.d_pmax, es.h_part, st);
+        if (es.ncd_max > 0) {
+            HIPCHK(hipMemcpyAsync(es.h_zp, S.logZp_dead, sizeof(double) * es.ncd_max, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(es.h_zp + es.ncd_max, S.logZp2_dead, sizeof(double) * es.ncd_max, hipMemcpyDeviceToHost, st));
         }
-        read_ctl();
+        HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));       // (read_ctl without its wait: end_b's caller waits)
+    }
+    int end(pchip_result *out) { end_a(); HIPCHK(hipStreamSynchronize(st)); return end_b(out); }
+    int end_b(pchip_result *out)
+    {
+        struct HostBuf { EndState &e; ~HostBuf() { if (e.hlive) hfree(e.hlive); if (e.hcl) hfree(e.hcl); e.hlive = nullptr; e.hcl = nullptr; } } hb{es};
+        double *hlive = es.hlive; int *hcl = es.hcl; double *d_pmax = es.d_pmax, *h_part = es.h_part, *h_zp = es.h_zp;
+        const int nc_end = es.nc_end, ncd_max = es.ncd_max, pmD = es.pmD, pm_nb = es.pm_nb, pm_pw = es.pm_pw, nT = S.nT;
+        const auto t0 = r_t0, t1 = r_t1; auto t2 = es.t2;
+        HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
+        nph_stale = false;
         kt.collect();
         if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals) && h_ctl->nphantom > 0) {
             // the last update_posteriors (nested_sampling.F90:386-390): every remaining phantom is below the last death
@@ -2161,14 +2186,19 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
     int worst = 0;
     for (int base = 0; base < nseeds && !worst; base += W) {
         const int n = std::min(W, nseeds - base);
-        Cohort co;
-        co.st = hpool().get_stream();
+        Cohort co; bool own_streams = false;
         static const bool side_off = std::getenv("PC_COHORT_SIDE") && std::atoi(std::getenv("PC_COHORT_SIDE")) == 0;
-        if (!side_off) { co.st2 = hpool().get_stream(); co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
+        static const bool prio_off = !(std::getenv("PC_COHORT_PRIO") && std::atoi(std::getenv("PC_COHORT_PRIO")) == 1);      // (tried: 79 ms against 70 for sixteen runs -- off)
+        // (the round's own kernels first, the bases of the next round in what they leave: stream priorities)
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (least, greatest: numerically lower = more urgent)
+        if (prio_off || plo == phi) { co.st = hpool().get_stream(); if (!side_off) co.st2 = hpool().get_stream(); }
+        else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
+        if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
         std::vector<Engine *> E((size_t)n, nullptr);
         std::vector<char> live((size_t)n, 0), enq((size_t)n, 0);
         const auto T0 = std::chrono::steady_clock::now();
-        long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0;
+        long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
         int *h_totals = nullptr; size_t totals_cap = 0;
         auto nowc = [] { return std::chrono::steady_clock::now(); };
         auto secc = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -2212,7 +2242,44 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 bool any_done = false;
                 for (int k = 0; k < n; ++k) any_done = any_done || (live[k] && !enq[k]);
                 if (any_done && co.st2) HIPCHK(hipStreamSynchronize(co.st2));      // (bases drawn ahead for a run that is over: not into freed memory)
-                for (int k = 0; k < n; ++k) if (live[k] && !enq[k]) { const auto e0 = nowc(); const int r = E[k]->r_rc ? E[k]->r_rc : E[k]->end(&results[base + k]); close(k, r); nlive--; t_end += secc(e0, nowc()); }
+                if (any_done) {     // the runs that are over end together: their kill-off in one launch, one wait for all their results
+                    const auto e0 = nowc();
+                    for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a(true);
+                    co.flush();
+                    for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a2();
+                    HIPCHK(hipStreamSynchronize(co.st));
+                    t_end_dev += secc(e0, nowc());
+                    // (the host's half of an ending -- results, buffers given back -- is a third of a millisecond per run: the runs that end now
+                    //  are shared out among a few threads)
+                    std::vector<int> fin;
+                    for (int k = 0; k < n; ++k) if (live[k] && !enq[k]) fin.push_back(k);
+                    std::vector<int> rcs(fin.size(), 0);
+                    auto finish_one = [&](size_t a) {
+                        const int k = fin[a];
+                        int r = E[k]->r_rc;
+                        if (!r) {
+                            try { r = E[k]->end_b(&results[base + k]); }
+                            catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); r = e.code; }
+                            catch (const std::bad_alloc &) { r = PC_RC_MEMORY; }
+                        }
+                        if (r != 0) pchip_result_free(&results[base + k]);
+                        try { E[k]->destroy(); } catch (...) {}
+                        delete E[k]; E[k] = nullptr; rcs[a] = r;
+                    };
+                    const size_t nth = std::min<size_t>(fin.size(), 8);
+                    if (nth <= 1) { for (size_t a = 0; a < fin.size(); ++a) finish_one(a); }
+                    else {
+                        std::atomic<size_t> nexta{0};
+                        const int devnow = E[fin[0]]->dev;
+                        auto worker = [&] { (void)hipSetDevice(devnow); for (size_t a; (a = nexta.fetch_add(1)) < fin.size();) finish_one(a); };
+                        std::vector<std::thread> th;
+                        for (size_t t = 1; t < nth; ++t) th.emplace_back(worker);
+                        worker();
+                        for (auto &t : th) t.join();
+                    }
+                    for (size_t a = 0; a < fin.size(); ++a) { live[fin[a]] = 0; nlive--; if (rcs[a] != 0 && !worst) worst = rcs[a]; }
+                    t_end += secc(e0, nowc());
+                }
             }
         }
         catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); (void)hipGetLastError(); if (!worst) worst = e.code; }
@@ -2220,13 +2287,13 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         if (co.st2) (void)hipStreamSynchronize(co.st2);
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
         if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_s * 1e3, g_dbg_compact_s * 1e3, g_dbg_capacity_s * 1e3); g_dbg_nursery_s = g_dbg_compact_s = g_dbg_capacity_s = 0; }
-        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, end + teardown %.2f); %ld records launched together, %ld one by one\n", n, rounds,
-                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end * 1e3, co.n_fused, co.n_single);
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, end + teardown %.2f of which the device's half %.2f); %ld records launched together, %ld one by one\n", n, rounds,
+                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end * 1e3, t_end_dev * 1e3, co.n_fused, co.n_single);
         co.destroy();
         if (h_totals) (void)hipHostFree(h_totals);
         (void)hipStreamSynchronize(co.st);
-        hpool().put_stream(co.st);
-        if (co.st2) { (void)hipStreamSynchronize(co.st2); hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
+        if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
+        if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
     }
     return worst;
 }

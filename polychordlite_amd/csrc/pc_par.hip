@@ -774,7 +774,7 @@ __global__ __launch_bounds__(PAR_NT) void k_consume_par_many(const PcManyRec *R)
 // the sorted live set leaves n-i points behind, so volumes are prefix sums of log((n-i)/(n-i+1)) and the
 // evidence is the same pair scan as above, 1024 deaths per pass with the state carried between passes.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S)
+__device__ __forceinline__ void final_par_body(const PcState &S)
 {
     __shared__ __attribute__((aligned(16))) double X0[PAR_NT], X1[PAR_NT], X2[PAR_NT], X3[PAR_NT];
     __shared__ double wtot[64];
@@ -855,6 +855,9 @@ __global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S)
         ctl->logZ = carry[0]; ctl->logZ2 = carry[1]; ctl->cluster_deleted = 0;
     }
 }
+__global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S) { final_par_body(S); }
+__global__ __launch_bounds__(PAR_NT) void k_final_par_many(const PcManyRec *R) { final_par_body(R[blockIdx.y].S); }
+
 
 static size_t par_lds(const PcState *S)
 {
@@ -889,5 +892,10 @@ extern "C" int pc_launch_consume_par_many(const PcState *S, const PcManyRec *dR,
 extern "C" int pc_launch_final_par(const PcState *S, hipStream_t st)
 {
     hipLaunchKernelGGL(k_final_par, dim3(1), dim3(PAR_NT), 0, st, *S);
+    return 0;
+}
+extern "C" int pc_launch_final_par_many(const PcManyRec *dR, int R, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_final_par_many, dim3(1, R), dim3(PAR_NT), 0, st, dR);
     return 0;
 }

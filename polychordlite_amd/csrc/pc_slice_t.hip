@@ -375,13 +375,12 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// The orthonormal bases of k_nhats<.., 1> (pc_sample.hip: one grade, keyed draws, nDims <= 24) with lane = basis: k_nhats gives a
-// basis a wavefront (thread = vector, nDims of 64 lanes busy, a barrier per Gram-Schmidt step); here a lane makes a whole basis
-// by itself in its own stretch of LDS -- the deviates of its nDims^2 stream positions (random_utils.F90:251-263: the same calls
-// of the same stream, AS241's centre at once and its tails together afterwards), every vector normalised (:276-298), then
-// Gram-Schmidt in the reference's order (:391-399) with k_nhats' arithmetic, operation for operation: dot products on four
-// partial sums (and the way the compiler fuses `0 + a0 a0 + a4 a4` there), the projection as one fused multiply-add per
-// coordinate.  A nursery of 1000 chains x 2 bases is 42 wavefronts instead of 2000.
+// The orthonormal bases of k_nhats<.., 1> (pc_sample.hip: one grade, keyed draws, nDims <= 24) in two kernels that leave the chip
+// to the runs next door: the deviates of all bases by a thread per stream call (k_deviates_t: no LDS, as wide as the nursery:
+// random_utils.F90:251-263), then normalisation and Gram-Schmidt (random_utils.F90:276-298, 391-399) with thread = vector and
+// 64 / nDims bases to a wavefront (k_bases_packed) -- k_nhats' arithmetic operation for operation: dot products on four partial
+// sums (and the way the compiler fuses `0 + a0 a0 + a4 a4` there), the projection as one fused multiply-add per coordinate.
+// (Tried and dropped: a basis per lane in LDS -- 3.2 KB a basis, a CU holds fifty: the runs queue for LDS.)
 // ------------------------------------------------------------------------------------------
 // a.a as k_nhats' PC_DOT4(x, a, a) comes out of the compiler: four partial sums over coordinates d = k, k + 4, ...; each starts as
 // 0 + a_k a_k + a_{k+4} a_{k+4}, of which ONE product is rounded and the other fused into the addition -- which one is the
@@ -413,6 +412,65 @@ __device__ __forceinline__ double dot4(const double (&a)[D], const double (&b)[D
     return (pp[0] + pp[1]) + (pp[2] + pp[3]);
 }
 
+// step 2: thread = vector, as in k_nhats, but 64 / nDims bases to a wavefront (a basis keeps nDims of a wave's lanes busy) and
+// the deviates already made: every thread keeps its vector in registers, the pivot goes round through a few hundred bytes of
+// LDS, a barrier per Gram-Schmidt step.  The same operations per vector as k_nhats<DMAX, 64, 1>.
+template <int DMAX>
+__device__ __forceinline__ void bases_packed_body(const PcState &S, int nbases)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = S.D, per = 64 / D;
+    const int tid = threadIdx.x, sub = tid / D, i = tid - sub * D;
+    const int g = blockIdx.x * per + sub;
+    const bool active = sub < per && g < nbases;
+    double *Q = (double *)smem + (size_t)(sub < per ? sub : 0) * 2 * DMAX;      // [2][DMAX] the pivot of this basis, double buffered
+    double v[DMAX];
+    double *raw = S.nhat_raw + ((size_t)(active ? g : 0) * D + i) * D;          // [chain][basis][vector][D], linear in the basis number
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? raw[d] : 0.0;
+    {   // random_direction (random_utils.F90:276-298)
+        const double inrm = 1.0 / sqrt(dot4_same<DMAX, (DMAX <= 16)>(v));
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = v[d] * inrm;
+    }
+    if (i == 0 && active) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) Q[d] = v[d];
+    }
+    __syncthreads();
+    for (int j = 0; j < D; ++j) {                                               // Gram-Schmidt (random_utils.F90:391-399), k_nhats' steps
+        const double *q = Q + (size_t)(j & 1) * DMAX;
+        double qv[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) qv[d] = active ? q[d] : 0.0;
+        const double qq = dot4_same<DMAX, false>(qv), dv = dot4<DMAX>(qv, v);
+        if (i == j) {
+            const double inrm = 1.0 / sqrt(qq);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) v[d] = v[d] * inrm;
+        } else if (active && i > j) {
+            const double cproj = dv / qq;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) v[d] = fma(-cproj, qv[d], v[d]);
+            if (i == j + 1) {
+                double *qn = Q + (size_t)((j + 1) & 1) * DMAX;
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) qn[d] = v[d];
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) raw[d] = v[d];
+    }
+}
+template <int DMAX>
+__global__ __launch_bounds__(64) void k_bases_packed(PcState S, int nbases) { bases_packed_body<DMAX>(S, nbases); }
+template <int DMAX>
+__global__ __launch_bounds__(64) void k_bases_packed_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX>(R[blockIdx.y].S, nbases); }
+
 // step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
 __device__ __forceinline__ void deviates_t_body(const PcState &S, unsigned batch, int nbases, int NC)
 {
@@ -434,101 +492,22 @@ __global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, i
 __global__ __launch_bounds__(256) void k_deviates_t_many(const PcManyRec *R, int nbases, int NC) { deviates_t_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, NC); }
 
 
-// step 2, lane = basis: normalise, Gram-Schmidt, in the lane's own stretch of LDS
-template <int DT>
-__device__ __forceinline__ void bases_t_body(const PcState &S, unsigned batch, int nbases /* chains x bases per chain */, int per /* bases per workgroup */)
-{
-#pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = DT, DD = D * D, ST = DD | 1;
-    // P = 64 / per lanes share a basis (what fits the workgroup's LDS leaves lanes over): lane p of a basis takes the vectors
-    // k = p, p + P, ... in every pass -- at a Gram-Schmidt step the projections of the later vectors are independent of each other
-    const int P = 64 / per, lane = threadIdx.x, bl = lane / P, pl = lane - bl * P, g = blockIdx.x * per + bl;
-    const bool active = bl < per && g < nbases;
-    double *sG = (double *)smem;                                 // [per][ST] a basis per lane group, vector-major; odd stride: bases on different banks
-    const int nb_here = min(per, nbases - (int)blockIdx.x * per);
-    // ---- the deviates arrive in runs of 64 consecutive addresses: [chain][basis][vector][D] is linear in the basis number
-    for (int b = 0; b < nb_here; ++b) {
-        double *dstl = sG + (size_t)b * ST;
-        const double *src = S.nhat_raw + ((size_t)blockIdx.x * per + b) * DD;
-        for (int e = lane; e < DD; e += 64) dstl[e] = src[e];
-    }
-    __syncthreads();                                              // (one wave; the barriers below order the lanes' LDS traffic for the compiler too)
-    double *G = sG + (size_t)(active ? bl : 0) * ST;
-    // ---- random_direction (random_utils.F90:276-298): every vector normalised
-    if (active)
-        for (int i = pl; i < D; i += P) {
-            double v[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) v[d] = G[i * D + d];
-            const double inrm = 1.0 / sqrt(dot4_same<D, (D <= 16)>(v));
-#pragma unroll
-            for (int d = 0; d < D; ++d) G[i * D + d] = v[d] * inrm;
-        }
-    __syncthreads();
-    // ---- Gram-Schmidt (random_utils.F90:391-399): the pivot is vector j, orthogonal to its predecessors and not yet normalised
-    for (int j = 0; j < D; ++j) {
-        if (active) {
-            double q[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) q[d] = G[j * D + d];
-            const double qq = dot4_same<D, false>(q);
-            if (pl == j % P) {
-                const double inrm = 1.0 / sqrt(qq);
-#pragma unroll
-                for (int d = 0; d < D; ++d) G[j * D + d] = q[d] * inrm;
-            }
-            int k = j + 1 + ((pl - (j + 1)) % P + P) % P;       // the first vector after j that is this lane's
-            for (; k < D; k += P) {
-                double v[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) v[d] = G[k * D + d];
-                const double cproj = dot4<D>(q, v) / qq;
-#pragma unroll
-                for (int d = 0; d < D; ++d) G[k * D + d] = fma(-cproj, q[d], v[d]);
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();                                              // (one wave)
-    // ---- the bases leave the way the deviates came
-    for (int b = 0; b < nb_here; ++b) {
-        const double *src = sG + (size_t)b * ST;
-        double *dst = S.nhat_raw + ((size_t)blockIdx.x * per + b) * DD;
-        for (int e = lane; e < DD; e += 64) dst[e] = src[e];
-    }
-}
-template <int DT>
-__global__ __launch_bounds__(64) void k_bases_t(PcState S, unsigned batch, int nbases, int per) { bases_t_body<DT>(S, batch, nbases, per); }
-template <int DT>
-__global__ __launch_bounds__(64) void k_bases_t_many(const PcManyRec *R, int nbases, int per) { bases_t_body<DT>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, per); }
-
-
 template <int DT>
 static int launch_bases_t(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
-    constexpr int DD = DT * DT, ST = DD | 1, NC = (DD + 1) / 2;
-    const size_t per_b = sizeof(double) * ST;
-    // (few bases to a workgroup: 64 / per lanes work on each, the workgroup is over sooner, and its LDS -- what it costs the
-    //  kernels next to it -- is small: ten of them to a CU)
-    static const int lds_kb = std::getenv("PC_BASES_T_LDS") ? std::atoi(std::getenv("PC_BASES_T_LDS")) : 16;
-    int per = (int)((size_t)(lds_kb * 1024 - 64) / per_b);
-    if (per > 64) per = 64;
-    if (per < 1) per = 1;
-    const int nbases = nchains * S->nb_total, blocks = (nbases + per - 1) / per;
+    constexpr int DD = DT * DT, NC = (DD + 1) / 2, DM = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
+    const int nbases = nchains * S->nb_total;
     const long long ncalls = (long long)nbases * NC;
     const unsigned gdev = (unsigned)((ncalls + 255) / 256);
-    const size_t sh = per_b * per + 16;
-    static size_t done = 0, done_m = 0;                           // (per instantiation)
+    const int perw = 64 / DT, blocksw = (nbases + perw - 1) / perw;
+    const size_t shw = sizeof(double) * (size_t)perw * 2 * DM;
     if (dR) {
         hipLaunchKernelGGL(k_deviates_t_many, dim3(gdev, R), dim3(256), 0, st, dR, nbases, NC);
-        if (sh > 48 * 1024 && sh > done_m) { (void)hipFuncSetAttribute((const void *)k_bases_t_many<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_m = sh; }
-        hipLaunchKernelGGL((k_bases_t_many<DT>), dim3(blocks, R), dim3(64), sh, st, dR, nbases, per);
-        return 0;
+        hipLaunchKernelGGL((k_bases_packed_many<DM>), dim3(blocksw, R), dim3(64), shw, st, dR, nbases);
+    } else {
+        hipLaunchKernelGGL(k_deviates_t, dim3(gdev), dim3(256), 0, st, *S, batch, nbases, NC);
+        hipLaunchKernelGGL((k_bases_packed<DM>), dim3(blocksw), dim3(64), shw, st, *S, nbases);
     }
-    hipLaunchKernelGGL(k_deviates_t, dim3(gdev), dim3(256), 0, st, *S, batch, nbases, NC);
-    if (sh > 48 * 1024 && sh > done) { (void)hipFuncSetAttribute((const void *)k_bases_t<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
-    hipLaunchKernelGGL((k_bases_t<DT>), dim3(blocks), dim3(64), sh, st, *S, batch, nbases, per);
     return 0;
 }
 

@@ -302,3 +302,32 @@ def test_lived_records_follow_the_runs_logzero(engine):
     assert rows.shape[0] == int((run["logweights"] > -1e20).sum()) and np.all(np.diff(rows[:, -1]) >= 0)
     a = mg.comm_merge(run, None, 6, 1)
     assert a["records"] == rows.shape[0] and abs(a["logZ"] - run["logZ"]) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,clus,box", [("gaussian", 20, 2, 400, 20, 0, None), ("gaussian", 7, 1, 300, 14, 0, (-0.25, 1.5)),
+                                                            ("rastrigin", 3, 0, 200, 9, 1, (-5.12, 5.12)), ("twin_gaussian", 6, 1, 250, 12, 0, (-1.0, 1.0))])
+def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus, box):
+    """pchip_run_repeats with all runs of the device in flight: they go round by round together on one stream, every kernel of a
+    round launched once for all of them (Gaussian: the lane-per-chain kernels, fused update, pool compaction for all at once;
+    the other likelihoods and clustered runs: the engines' ordinary launches in between the common ones) -- each run bit for
+    bit the run it is alone, whatever round the others update, compact or end in"""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    seeds = [31, 32, 33, 34, 35, 36, 37, 38, 39]
+    L, P, keep = api.make_problem(kind, D, nDer, *box) if box else api.make_problem(kind, D, nDer)
+    def settings(seed):
+        s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+        s.nlive, s.num_repeats, s.seed, s.do_clustering = nlive, nr, seed, clus
+        return s
+    singles = [api.run(settings(sd), L, P) for sd in seeds]
+    merged, runs = run_repeats(settings(0), L, P, seeds, max_in_flight=len(seeds))
+    assert len({r["nrounds"] for r in singles}) > 1 or kind != "gaussian"      # (they do not all end in the same round)
+    for one, r in zip(singles, runs):
+        for k in ("ndead", "nlike", "niter", "nupdates", "nbatches", "ncluster_dead"):
+            assert one[k] == r[k], (k, one[k], r[k])
+        assert one["logZ"] == r["logZ"] and one["logZerr"] == r["logZerr"]
+        assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
+        assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
+    assert merged["n_runs"] == len(seeds)
