@@ -398,6 +398,7 @@ def main():
                          "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
                          "per_run_ms": mc["t_runs_s"] * 1e3 / R,
                          "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
+        lib.polychord_hip_set_option(b"trim_cache", 0.0)      # (the blocks of 64 engines: the next configurations size their buffers by what is free)
         sync()
     # the other BASELINE configurations through the same engine, one timed step each (after one untimed step that sizes the
     # block cache): reported next to the headline, never part of `value`

@@ -101,6 +101,10 @@ void pchip_inject_fault(int kind);
 /* initial capacities of the per-cluster arrays (default 128) and of the phantom array (rows; 0 = estimate); both grow on
    demand like the reference's reallocating arrays (run_time_info.f90:392-418), options "cluster_capacity" / "phantom_capacity" */
 void pchip_set_capacity(int clusters, int phantom_rows);
+/* The engine keeps the device and pinned blocks of finished runs for the next ones (up to 48 GB / 4 GB); this gives them back
+ * to the driver -- e.g. after many runs in flight, before a run that sizes its buffers by the memory that is free.
+ * polychord_hip_set_option("trim_cache", 0) does the same. */
+void pchip_trim_cache(void);
 
 typedef struct {
     int nDims, nDerived;

@@ -425,6 +425,7 @@ void polychord_hip_set_option(const char *name, double value)
     else if (!std::strcmp(name, "inject_fault")) pchip_inject_fault((int)value);
     else if (!std::strcmp(name, "cluster_capacity")) pchip_set_capacity((int)value, -1);
     else if (!std::strcmp(name, "phantom_capacity")) pchip_set_capacity(-1, (int)value);
+    else if (!std::strcmp(name, "trim_cache")) pchip_trim_cache();
     else if (!std::strcmp(name, "halt_returns")) G.halt_returns = value != 0.0;
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }

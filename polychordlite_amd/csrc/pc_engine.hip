@@ -1922,7 +1922,7 @@ struct Engine {
     } es;
     void end_a(bool fused_final = false)
     {
-        if (co) co->flush();
+        if (co && !fused_final) co->flush();      // (fused: the caller has launched what was pending, and launches the kill-offs together)
         const bool par_ok = r_par_ok; bool &sort_valid = r_sort_valid;
         es.t2 = clk::now();
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
@@ -2094,6 +2094,7 @@ void polychord_hip_request_stop(void) { std::lock_guard<std::mutex> g(g_run_mute
 void pchip_inject_fault(int kind) { g_inject_fault = kind; }
 // initial capacity of the per-cluster arrays (default 128) and of the phantom array in rows (0 = the engine's estimate);
 // both grow on demand, so these only matter to tests of the growth paths
+void pchip_trim_cache(void) { (void)hipDeviceSynchronize(); dcache().trim(); hcache().trim(); }      // the blocks finished runs left for the next ones go back to the driver
 void pchip_set_capacity(int clusters, int phantom_rows) { if (clusters > 0) g_cap_clusters = clusters; if (phantom_rows >= 0) g_cap_phantoms = phantom_rows; }   // negative: leave as is
 void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { std::lock_guard<std::mutex> g(g_cb_mutex); g_batch_fn = fn; g_batch_user = user; }
 
@@ -2244,6 +2245,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 if (any_done && co.st2) HIPCHK(hipStreamSynchronize(co.st2));      // (bases drawn ahead for a run that is over: not into freed memory)
                 if (any_done) {     // the runs that are over end together: their kill-off in one launch, one wait for all their results
                     const auto e0 = nowc();
+                    co.flush();
                     for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a(true);
                     co.flush();
                     for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a2();

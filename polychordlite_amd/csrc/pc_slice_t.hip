@@ -320,24 +320,38 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             mine[o_b0] = contour;                           // nested_sampling.F90:260
             mine[o_l0] = lnew;
             if (act) { bl_row[s] = lnew; *bl_col = lnew; }
-            __syncthreads();                                // (one wave)
+            pc_lds_barrier();                               // (one wave; not __syncthreads: that waits for the global stores of the slice before too)
             double *out0 = S.babies + ((size_t)chain0 * nr + s) * nT;       // record of the wave's first chain; chain c: + c nr nT
             if ((nT & 1) == 0) {
+                // lane l takes the pairs l, l + 64, ... of the wave's 64 records laid end to end: record c, pair f2 -> the next is
+                // cstep records and fstep pairs on (one record more when the pair index wraps); both addresses move by increments
                 const int H = nT >> 1;
-                int c = cq0, f2 = fq0;
-                for (int i = 0; i < H; ++i) {
-                    if (c < nrows) {
-                        const double *src = sRow + (size_t)c * RS + 2 * f2;
-                        const double2 v = make_double2(src[0], src[1]);
-                        *(double2 *)(out0 + (size_t)c * rstride + 2 * f2) = v;
+                int f2 = fq0, c = cq0;
+                const double *src = sRow + (size_t)cq0 * RS + 2 * fq0;
+                double *dst = out0 + (size_t)cq0 * rstride + 2 * fq0;
+                const int sstep = cstep * RS + 2 * fstep, swrap = RS - nT;
+                const size_t dstep = (size_t)cstep * rstride + 2 * fstep, dwrap = rstride - nT;
+                if (nrows == 64) {
+                    double2 cur = make_double2(src[0], src[1]);               // (the next pair is on its way from LDS while this one is stored)
+                    for (int i = 0; i < H; ++i) {
+                        double *d0 = dst;
+                        f2 += fstep; src += sstep; dst += dstep;
+                        if (f2 >= H) { f2 -= H; src += swrap; dst += dwrap; }
+                        const double2 nxt = (i + 1 < H) ? make_double2(src[0], src[1]) : cur;
+                        *(double2 *)d0 = cur;
+                        cur = nxt;
                     }
-                    f2 += fstep; c += cstep;
-                    if (f2 >= H) { f2 -= H; c++; }
+                } else {
+                    for (int i = 0; i < H; ++i) {
+                        if (c < nrows) *(double2 *)dst = make_double2(src[0], src[1]);
+                        f2 += fstep; c += cstep; src += sstep; dst += dstep;
+                        if (f2 >= H) { f2 -= H; c++; src += swrap; dst += dwrap; }
+                    }
                 }
             } else {
                 for (int e = lane; e < nrows * nT; e += 64) { const int c = e / nT, f = e - c * nT; out0[(size_t)c * rstride + f] = sRow[(size_t)c * RS + f]; }
             }
-            __syncthreads();
+            pc_lds_barrier();                               // (the records' LDS is free for the next slice once it has been read)
         }
 #ifdef SLICE_T_DBG
         { const long long c5 = clock64(); cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3; cy[4] += c5 - c4; }
