@@ -397,6 +397,7 @@ def main():
             conc.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": vals[1], "value_min": vals[0], "value_max": vals[2], "samples": 3,
                          "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
                          "per_run_ms": mc["t_runs_s"] * 1e3 / R,
+                         "whole_run_frac": mc["nlike"] * 258.0 / mc["t_runs_s"] / 8e12,      # algorithmic bytes (258 B per evaluation) / wall / 8 TB/s
                          "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
         lib.polychord_hip_set_option(b"trim_cache", 0.0)      # (the blocks of 64 engines: the next configurations size their buffers by what is free)
         sync()

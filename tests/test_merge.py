@@ -331,3 +331,21 @@ def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus
         assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
         assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
     assert merged["n_runs"] == len(seeds)
+
+
+@pytest.mark.gpu
+def test_a_failing_run_ends_the_runs_in_step_cleanly(engine):
+    """one of several runs in step fails (injected: a device allocation during its setup): pchip_run_repeats reports the failure, gives
+    every buffer back, and the next call -- the same seeds -- makes the runs as if nothing had happened"""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    L, P, keep = api.make_problem("gaussian", 6, 1)
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), 6, 1)
+    s.nlive, s.num_repeats = 150, 12
+    good, _ = run_repeats(s, L, P, [71, 72, 73, 74], max_in_flight=4)
+    lib.polychord_hip_set_option(b"inject_fault", 1.0)
+    with pytest.raises(RuntimeError):
+        run_repeats(s, L, P, [71, 72, 73, 74], max_in_flight=4)
+    again, runs = run_repeats(s, L, P, [71, 72, 73, 74], max_in_flight=4)
+    assert again["logZ"] == good["logZ"] and again["nlike"] == good["nlike"] and len(runs) == 4
