@@ -377,6 +377,10 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
     const int nrp = deck_stride(S->nr), grid = (nchains + 63) / 64;
     const size_t sh = sizeof(double) * ((size_t)DT * DT + 2 * FW) + (size_t)64 * nrp + sizeof(double) * 64 * (size_t)(S->nT | 1);
     const bool unit = S->prior.lo == nullptr && S->prior.hi == nullptr;
+    if (sh > 48 * 1024) {                                         // (long decks and wide records: pc_slice_t_ok keeps it under 64 KB)
+        if (dR) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
+        else { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
+    }
     if (dR) {
         if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
         else hipLaunchKernelGGL((k_slice_t_many<DT, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
@@ -559,6 +563,9 @@ extern "C" int pc_slice_t_ok(const PcState *S, int ncluster)
     if (S->like.kind != PC_LIKE_GAUSSIAN || (S->ablate & 1)) return 0;
     const size_t sh0 = sizeof(double) * ((size_t)S->D + S->nr) + 16, tb = sizeof(double) * (size_t)S->nr * (S->D + 1);
     if (S->nDer > 0 && sh0 + tb > 48 * 1024) return 0;      // (k_slice would take the derived parameters' other summation order)
+    const int FW = S->D <= 8 ? 8 : (S->D <= 16 ? 16 : 24);
+    const size_t sh = sizeof(double) * ((size_t)S->D * S->D + 2 * FW) + (size_t)64 * deck_stride(S->nr) + sizeof(double) * 64 * (size_t)(S->nT | 1);
+    if (sh > 64 * 1024) return 0;                           // (the wave's LDS: factor, box, 64 decks, 64 records)
     return 1;
 }
 
