@@ -227,6 +227,60 @@ struct HandlePool {
     void put_sync_event(hipEvent_t e) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); sync_events.push_back({dev, e}); }
 };
 HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
+
+// A second stream is worth something only if the device runs it NEXT TO the first: the runtime deals streams onto a few hardware
+// queues (GPU_MAX_HW_QUEUES, four by default), and two streams of one queue take turns -- after a sweep of sixty-four runs in
+// step the pool held dozens of streams, and a single run that drew two of one queue was 2.3 ms (16 %) slower.  So a side stream
+// is tried against its main stream once (two 40-us spinning kernels: together or one after the other?) and the verdict kept.
+__global__ void k_engine_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) {} }
+static bool streams_overlap_test(hipStream_t a, hipStream_t b)
+{
+    auto timed = [&](bool both) {
+        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, a, 4000LL);               // 40 us of the 100 MHz clock
+        if (both) hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, b, 4000LL);
+        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)timed(true);                                       // (the kernel's first launch loads its code)
+    const double one = timed(false), two = std::min(timed(true), timed(true));
+    return two < one + 25e-6;                               // side by side: about the time of one; in turn: 40 us more
+}
+// streams that take turns are streams of one hardware queue: every stream is put into its class once (one test against a
+// member of each class known so far), and two streams run side by side when their classes differ
+static bool streams_overlap(hipStream_t a, hipStream_t b)
+{
+    static std::mutex mm;
+    static std::map<void *, int> cls;
+    static std::vector<hipStream_t> reps;
+    std::lock_guard<std::mutex> g(mm);
+    auto classify = [&](hipStream_t x) {
+        auto it = cls.find((void *)x);
+        if (it != cls.end()) return it->second;
+        int c = -1;
+        for (size_t r = 0; r < reps.size() && c < 0; ++r) if (!streams_overlap_test(reps[r], x)) c = (int)r;
+        if (c < 0) { c = (int)reps.size(); reps.push_back(x); }
+        cls[(void *)x] = c;
+        return c;
+    };
+    return classify(a) != classify(b);
+}
+// a pooled (or new) stream that runs next to `main_st`; the ones tried and found wanting go back to the pool
+static hipStream_t side_stream_for(hipStream_t main_st)
+{
+    static const bool off = std::getenv("PC_SIDE_PICK_OFF") != nullptr;
+    if (off) return hpool().get_stream();
+    std::vector<hipStream_t> tried;
+    hipStream_t pick = nullptr;
+    for (int k = 0; k < 6 && !pick; ++k) {
+        hipStream_t c = hpool().get_stream();
+        if (streams_overlap(main_st, c)) pick = c; else tried.push_back(c);
+    }
+    if (!pick) { pick = tried.back(); tried.pop_back(); }   // (none: any will do)
+    for (hipStream_t t : tried) hpool().put_stream(t);
+    return pick;
+}
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
 std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
@@ -1760,7 +1814,7 @@ struct Engine {
                 // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
         // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
         if (!st_side) {
-            st_side = hpool().get_stream(); ev_main = hpool().get_sync_event();
+            st_side = side_stream_for(st); ev_main = hpool().get_sync_event();
             for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
         }
         // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
@@ -2193,7 +2247,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         // (the round's own kernels first, the bases of the next round in what they leave: stream priorities)
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (least, greatest: numerically lower = more urgent)
-        if (prio_off || plo == phi) { co.st = hpool().get_stream(); if (!side_off) co.st2 = hpool().get_stream(); }
+        if (prio_off || plo == phi) { co.st = hpool().get_stream(); if (!side_off) co.st2 = side_stream_for(co.st); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
         if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
         std::vector<Engine *> E((size_t)n, nullptr);
