@@ -2239,8 +2239,9 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
     (void)hipSetDevice(device >= 0 ? device % ndev : 0);
     const int W = std::max(1, std::min(std::min(max_in_flight, nseeds), 64));
     int worst = 0;
-    for (int base = 0; base < nseeds && !worst; base += W) {
-        const int n = std::min(W, nseeds - base);
+    int done_here = 0;
+    for (int base = 0; base < nseeds && !worst; base += done_here) {
+        int n = std::min(W, nseeds - base);
         Cohort co; bool own_streams = false;
         static const bool side_off = std::getenv("PC_COHORT_SIDE") && std::atoi(std::getenv("PC_COHORT_SIDE")) == 0;
         static const bool prio_off = !(std::getenv("PC_COHORT_PRIO") && std::atoi(std::getenv("PC_COHORT_PRIO")) == 1);      // (tried: 79 ms against 70 for sixteen runs -- off)
@@ -2266,8 +2267,17 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 E[k] = new Engine; E[k]->co = &co;
                 pchip_settings c = *s; c.seed = seeds[base + k]; c.device = device;
                 const auto b0 = nowc();
-                E[k]->setup(c, *like, *prior);
-                const int rc = E[k]->begin();
+                int rc;
+                try { E[k]->setup(c, *like, *prior); rc = E[k]->begin(); }
+                catch (const EngineError &e) {
+                    // no memory for one more run of this size next to the k that are set up: those go in step, the others after them
+                    if (e.code != PC_RC_MEMORY || k == 0) throw;
+                    (void)hipGetLastError();
+                    try { E[k]->destroy(); } catch (...) {}
+                    delete E[k]; E[k] = nullptr;
+                    n = k;
+                    break;
+                }
                 t_begin += secc(b0, nowc());
                 if (rc >= 0) { close(k, rc ? rc : PC_RC_DEVICE); continue; }
                 live[k] = 1;
@@ -2350,6 +2360,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         (void)hipStreamSynchronize(co.st);
         if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
         if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
+        done_here = n;
     }
     return worst;
 }
