@@ -169,7 +169,7 @@ struct BlockCache {
 };
 // never destroyed: the HIP runtime may already be gone when static destructors run
 BlockCache &dcache() { static BlockCache *c = new BlockCache(false, (size_t)48 << 30); return *c; }
-BlockCache &hcache() { static BlockCache *c = new BlockCache(true, (size_t)4 << 30); return *c; }
+BlockCache &hcache() { static BlockCache *c = new BlockCache(true, (size_t)12 << 30); return *c; }
 
 // PC_POISON=1 (tests): every device block is filled with 0x5A bytes when it is handed out -- ints become 1515870810,
 // doubles 2.6e127 -- so that a buffer some path forgets to initialise fails loudly instead of working by the luck of
@@ -201,6 +201,14 @@ struct HandlePool {
         hipStream_t s; HIPCHK(hipStreamCreate(&s)); return s;
     }
     void put_stream(hipStream_t s) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); streams.push_back({dev, s}); }
+    template <class Pred> hipStream_t take_stream_if(Pred pred)          // a pooled stream of this device the predicate accepts, or null
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(m);
+        for (size_t i = 0; i < streams.size(); ++i)
+            if (streams[i].first == dev && pred(streams[i].second)) { hipStream_t s = streams[i].second; streams.erase(streams.begin() + i); return s; }
+        return nullptr;
+    }
     hipEvent_t get_event()
     {
         int dev = 0; (void)hipGetDevice(&dev);
@@ -235,27 +243,31 @@ HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
 __global__ void k_engine_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) {} }
 static bool streams_overlap_test(hipStream_t a, hipStream_t b)
 {
-    auto timed = [&](bool both) {
+    auto both = [&] {
         (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, a, 4000LL);               // 40 us of the 100 MHz clock
-        if (both) hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, b, 4000LL);
+        hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, a, 10000LL);              // 100 us of the 100 MHz clock
+        hipLaunchKernelGGL(k_engine_spin, dim3(1), dim3(64), 0, b, 10000LL);
         (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
-    (void)timed(true);                                       // (the kernel's first launch loads its code)
-    const double one = timed(false), two = std::min(timed(true), timed(true));
-    return two < one + 25e-6;                               // side by side: about the time of one; in turn: 40 us more
+    static std::atomic<bool> warmed{false};
+    if (!warmed.exchange(true)) (void)both();                // (the kernel's first launch loads its code)
+    const double two = std::min(both(), both());
+    static const bool dbg = std::getenv("PC_DEBUG") && std::atoi(std::getenv("PC_DEBUG")) == 5;
+    if (dbg) std::fprintf(stderr, "polychord_hip dbg streams %p %p: both %.1f us\n", (void *)a, (void *)b, two * 1e6);
+    return two < 170e-6;                                    // side by side: ~120 us (one spin and the launches); in turn: ~225 us
 }
 // streams that take turns are streams of one hardware queue: every stream is put into its class once (one test against a
 // member of each class known so far), and two streams run side by side when their classes differ
-static bool streams_overlap(hipStream_t a, hipStream_t b)
-{
-    static std::mutex mm;
-    static std::map<void *, int> cls;
-    static std::vector<hipStream_t> reps;
-    std::lock_guard<std::mutex> g(mm);
-    auto classify = [&](hipStream_t x) {
+struct StreamClasses {
+    std::mutex mm;
+    std::map<void *, int> cls;
+    std::vector<hipStream_t> reps;
+    int known(hipStream_t x) { std::lock_guard<std::mutex> g(mm); auto it = cls.find((void *)x); return it == cls.end() ? -1 : it->second; }
+    int classify(hipStream_t x)
+    {
+        std::lock_guard<std::mutex> g(mm);
         auto it = cls.find((void *)x);
         if (it != cls.end()) return it->second;
         int c = -1;
@@ -263,24 +275,31 @@ static bool streams_overlap(hipStream_t a, hipStream_t b)
         if (c < 0) { c = (int)reps.size(); reps.push_back(x); }
         cls[(void *)x] = c;
         return c;
-    };
-    return classify(a) != classify(b);
-}
-// a pooled (or new) stream that runs next to `main_st`; the ones tried and found wanting go back to the pool
-static hipStream_t side_stream_for(hipStream_t main_st)
+    }
+};
+static StreamClasses &sclasses() { static StreamClasses *p = new StreamClasses; return *p; }
+// a pooled (or new) stream that runs next to all of `others` (null entries ignored): one whose class is known first, then the
+// pool's unknown ones, classed as they come; the ones found wanting go back to the pool
+static hipStream_t stream_beside(std::initializer_list<hipStream_t> others)
 {
     static const bool off = std::getenv("PC_SIDE_PICK_OFF") != nullptr;
     if (off) return hpool().get_stream();
+    std::vector<int> avoid;
+    for (hipStream_t o : others) if (o) avoid.push_back(sclasses().classify(o));
+    auto fits = [&](int c) { return c >= 0 && std::find(avoid.begin(), avoid.end(), c) == avoid.end(); };
+    if (hipStream_t k = hpool().take_stream_if([&](hipStream_t x) { return fits(sclasses().known(x)); })) return k;
     std::vector<hipStream_t> tried;
     hipStream_t pick = nullptr;
-    for (int k = 0; k < 6 && !pick; ++k) {
-        hipStream_t c = hpool().get_stream();
-        if (streams_overlap(main_st, c)) pick = c; else tried.push_back(c);
+    for (int k = 0; k < 8 && !pick; ++k) {
+        hipStream_t c = hpool().take_stream_if([&](hipStream_t x) { return sclasses().known(x) < 0; });
+        if (!c) { HIPCHK(hipStreamCreate(&c)); }
+        if (fits(sclasses().classify(c))) pick = c; else tried.push_back(c);
     }
     if (!pick) { pick = tried.back(); tried.pop_back(); }   // (none: any will do)
     for (hipStream_t t : tried) hpool().put_stream(t);
     return pick;
 }
+static hipStream_t side_stream_for(hipStream_t main_st) { return stream_beside({main_st}); }
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
 std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
@@ -452,7 +471,7 @@ struct Cohort {
     }
 };
 
-static double g_dbg_compact_s = 0, g_dbg_nursery_s = 0, g_dbg_capacity_s = 0;      // (PC_DEBUG=5, one scheduler thread: where round_enqueue's time goes)
+static std::atomic<long long> g_dbg_compact_ns{0}, g_dbg_nursery_ns{0}, g_dbg_capacity_ns{0};      // (PC_DEBUG=5: where round_enqueue's time goes)
 struct Engine {
     Cohort *co = nullptr;               // not null: this run goes in step with others of its device, on their common stream
     pchip_settings cfg{};
@@ -533,8 +552,9 @@ struct Engine {
         }
         dev = c.device >= 0 ? c.device % ndev : 0;
         HIPCHK(hipSetDevice(dev));
-        st = co ? co->st : hpool().get_stream(); st_copy = hpool().get_stream();
-        kt.on = c.profile != 0; kt.st = st;
+        st = co ? co->st : hpool().get_stream();
+        st_copy = co ? hpool().get_stream() : stream_beside({st});      // (a run on its own: its copies on another hardware queue than its kernels)
+        kt.on = c.profile != 0 && !co; kt.st = st;      // (in step with other runs the launches are made elsewhere: nothing of its own to time)
         kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x7Fu);   // 1: every class; else bit k+1 = class k
         kt.stride = std::max(1u, ((unsigned)c.profile >> 8) & 0xFFu);                       // bits 8..15: time every n-th launch of a class
         const int D = c.nDims, nDer = c.nDerived;
@@ -783,6 +803,9 @@ struct Engine {
         };
         grow(S.dead, S.nT); grow(S.dead_logw, 1); grow(S.dead_postX, 1); grow(S.dead_postZ, 1); grow(S.dead_cuid, 1); grow(S.dead_entry, 1);
         S.Dcap = nd;
+        // the pinned mirror the rows are streamed into grows with the array (the same capacities in every run: the block comes
+        // back from the cache; sized by the final count at the end it was a fresh multi-GB pinning and a second copy of every row)
+        if (h_dead && (size_t)nd > h_dead_cap) { hfree(h_dead); h_dead_cap = (size_t)nd; h_dead = halloc<double>(h_dead_cap * S.nT); h_dead_copied = 0; }
     }
 
     // The reference reallocates its phantom arrays whenever they fill up (run_time_info.f90:747-757 via
@@ -828,7 +851,7 @@ struct Engine {
     void pool_compact()
     {
         const auto dbg_t0 = std::chrono::steady_clock::now();
-        struct DbgT { std::chrono::steady_clock::time_point t0; ~DbgT() { g_dbg_compact_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } dbg_t{dbg_t0};
+        struct DbgT { std::chrono::steady_clock::time_point t0; ~DbgT() { g_dbg_compact_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } dbg_t{dbg_t0};
         if (co) co->flush();
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         pc_launch_clean(&S, (int)pool_cursor, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
@@ -1814,7 +1837,7 @@ struct Engine {
                 // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
         // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
         if (!st_side) {
-            st_side = side_stream_for(st); ev_main = hpool().get_sync_event();
+            st_side = stream_beside({st, st_copy}); ev_main = hpool().get_sync_event();
             for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
         }
         // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
@@ -1869,9 +1892,9 @@ struct Engine {
                 const bool have = spec_pending;                 // (still pending here = the device took it: round_finish undid the others)
                 spec_pending = false;
                 if (have) side_prefetch(batch - 1);
-                else { const auto n0 = std::chrono::steady_clock::now(); const bool okn = enqueue_nursery(false); g_dbg_nursery_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - n0).count(); if (!okn) return false; }
+                else { const auto n0 = std::chrono::steady_clock::now(); const bool okn = enqueue_nursery(false); g_dbg_nursery_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n0).count(); if (!okn) return false; }
             }
-            if (fresh_nursery) { const auto n0 = std::chrono::steady_clock::now(); ensure_capacity(); g_dbg_capacity_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - n0).count(); }
+            if (fresh_nursery) { const auto n0 = std::chrono::steady_clock::now(); ensure_capacity(); g_dbg_capacity_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n0).count(); }
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
@@ -2352,7 +2375,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         catch (const std::bad_alloc &) { std::fprintf(stderr, "polychord_hip: out of host memory\n"); if (!worst) worst = PC_RC_MEMORY; }
         if (co.st2) (void)hipStreamSynchronize(co.st2);
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
-        if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_s * 1e3, g_dbg_compact_s * 1e3, g_dbg_capacity_s * 1e3); g_dbg_nursery_s = g_dbg_compact_s = g_dbg_capacity_s = 0; }
+        if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6); }
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, end + teardown %.2f of which the device's half %.2f); %ld records launched together, %ld one by one\n", n, rounds,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end * 1e3, t_end_dev * 1e3, co.n_fused, co.n_single);
         co.destroy();
