@@ -60,7 +60,9 @@ __device__ __forceinline__ Q3 wave_order_sum3(const F &leaf)
 }
 
 // DT = nDims (1 .. 24); UNIT: the prior is the unit hypercube itself (lo = 0, span = 1: theta = cube, bit for bit)
-template <int DT, bool UNIT>
+// HELP: a second wavefront per 64 chains works ahead of the first -- the whitened direction and the first eight uniforms of the next
+// slice, which depend on nothing the chain does, wait in LDS when the chain gets there (two buffers, one barrier per slice)
+template <int DT, bool UNIT, bool HELP>
 __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, int nchains, int nrp)
 {
 #pragma clang fp contract(off)       // every fused multiply-add below is written out: the roundings of k_slice, whatever this kernel's shape suggests to the compiler
@@ -69,7 +71,8 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 #ifdef SLICE_T_DBG
     const long long cB = clock64();
 #endif
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = HELP ? (tid >> 6) : 0;
+    constexpr int NTH = HELP ? 128 : 64;
     const int chain_raw = blockIdx.x * 64 + lane;
     const bool act = chain_raw < nchains;                 // lanes past the nursery follow its last chain and store nothing
     const int chain = act ? chain_raw : nchains - 1;
@@ -80,19 +83,22 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     double *sSpan = sLo + FW;                             // [FW]
     unsigned char *sDeck = (unsigned char *)(sSpan + FW); // [64][nrp] each lane's deck of directions
     double *sRow = (double *)(sDeck + (size_t)64 * nrp);  // [64][nT | 1] the babies' records on their way out (nrp is a multiple of 4, 64 nrp of 8)
+    double *sNh = sRow + (size_t)64 * (nT | 1);           // HELP: [2][64][D + 1] direction and width of the slice to come
+    double *sU = sNh + (size_t)2 * 64 * (D + 1);          // HELP: [2][64][9] its first eight uniforms (odd stride)
     {
         constexpr TriMap<D> tm{};
-        for (int e = lane; e < NP; e += 64) sL[e] = S.chol[tm.aa[e] * D + tm.bb[e]];      // packed, in the order of use
+        for (int e = tid; e < NP; e += NTH) sL[e] = S.chol[tm.aa[e] * D + tm.bb[e]];      // packed, in the order of use
     }
-    if (lane < FW) {
-        const bool on = lane < D;
-        const double lo = (on && S.prior.lo) ? S.prior.lo[lane] : 0.0;
-        const double hi = (on && S.prior.hi) ? S.prior.hi[lane] : 1.0;
-        sLo[lane] = lo; sSpan[lane] = hi - lo;
+    if (tid < FW) {
+        const bool on = tid < D;
+        const double lo = (on && S.prior.lo) ? S.prior.lo[tid] : 0.0;
+        const double hi = (on && S.prior.hi) ? S.prior.hi[tid] : 1.0;
+        sLo[tid] = lo; sSpan[tid] = hi - lo;
     }
     // ---- GenerateSeed (generate.F90:19-55), one cluster: a live point drawn evenly (select_seed of pc_sample.hip)
-    int slot;
-    {
+    int slot = 0;
+    const bool chain_wave = !HELP || wv == 0;             // the wavefront that walks the chains (HELP: the other one makes directions and uniforms)
+    if (chain_wave) {
         const double u2s = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
         const int ns = S.cl_n[0];
         int is = (int)ceil(u2s * ns);
@@ -101,7 +107,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
         if (S.seed_override) slot = chain;
     }
     const double contour = S.logLp[0];
-    if (act) {
+    if (act && chain_wave) {
         S.ch_cluster[chain] = 0; S.ch_seed_slot[chain] = slot;
         S.ch_contour[chain] = contour;                                   // nested_sampling.F90:270
         S.ch_epoch[chain] = S.ctl->admin_epoch;
@@ -111,13 +117,14 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     {
         const double *seed = S.live + (size_t)slot * nT;
 #pragma unroll
-        for (int d = 0; d < D; ++d) x0[d] = seed[d];
+        for (int d = 0; d < D; ++d) x0[d] = chain_wave ? seed[d] : 0.5;
     }
-    if (S.pool && act) for (int i = 0; i < nr; ++i) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
+    if (S.pool && act && chain_wave) for (int i = 0; i < nr; ++i) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
     // ---- deck: the first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142, random_utils.F90:505-532)
     unsigned char *deck = sDeck + (size_t)lane * nrp;
-    for (int i = 0; i < nr; ++i) deck[i] = (unsigned char)i;
-    for (int i = nr - 1; i >= 1; --i) {
+    const bool deck_wave = !HELP || wv == 1;
+    if (deck_wave) for (int i = 0; i < nr; ++i) deck[i] = (unsigned char)i;
+    for (int i = nr - 1; i >= 1 && deck_wave; --i) {
         const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
         int j = (int)ceil(u * i);
         j = j < 1 ? 1 : (j > i ? i : j);
@@ -129,29 +136,13 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;    // direction v (generation order) at + v * D
     double vv[D];
     {
-        const double *p = rawc + (size_t)deck[0] * D;
+        const double *p = rawc + (size_t)(deck_wave ? deck[0] : 0) * D;
 #pragma unroll
-        for (int d = 0; d < D; ++d) vv[d] = p[d];
+        for (int d = 0; d < D; ++d) vv[d] = deck_wave ? p[d] : 0.0;
     }
-    double *bl_row = S.baby_logL + (size_t)chain * nr;
-    double *bl_col = S.baby_logL_T + chain;
-    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
-    const uint32_t k0 = S.k0, k1 = S.k1;
-    int nlike = 0;
-    // the records' way out (see the end of the loop): lane's first pair of a record and its stride through the 64 records
-    const int RS = nT | 1, chain0 = blockIdx.x * 64, nrows = min(64, nchains - chain0);
-    const size_t rstride = (size_t)nr * nT;
-    const int Hq = max(nT >> 1, 1), cq0 = lane / Hq, fq0 = lane - cq0 * Hq, cstep = 64 / Hq, fstep = 64 - cstep * Hq;
-#ifdef SLICE_T_DBG
-    long long cy[6] = {0, 0, 0, 0, 0, 0}; const long long cA = clock64();
-#endif
-    for (int s = 0; s < nr; ++s, bl_col += Bstride) {
-        // ---- whitening of this slice's direction: w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82)
-        //      (row sums in ascending column; the norm on four partial sums, coordinate d on sum d mod 4)
-        double nh[D], w;
-#ifdef SLICE_T_DBG
-        const long long c0 = clock64();
-#endif
+    // ---- whitening of a slice's direction: w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82)
+    //      (row sums in ascending column; the norm on four partial sums, coordinate d on sum d mod 4)
+    auto whiten = [&](const double (&vv_)[D], double (&nh)[D], double &w) __attribute__((always_inline)) {
         asm volatile("" ::: "memory");                     // (the factor is read from LDS in every slice: 2 D^2 registers if the compiler keeps it)
         {
 #pragma unroll
@@ -172,7 +163,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 #pragma unroll
                 for (int i = 0; i < W; ++i) {
                     const int e = gq * W + i;
-                    if (e < NP) nh[tm.aa[e]] = fma(wa[i], vv[tm.bb[e]], nh[tm.aa[e]]);
+                    if (e < NP) nh[tm.aa[e]] = fma(wa[i], vv_[tm.bb[e]], nh[tm.aa[e]]);
                 }
 #pragma unroll
                 for (int d = 0; d < D; ++d) asm volatile("" : "+v"(nh[d]));
@@ -189,6 +180,60 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 #pragma unroll
             for (int d = 0; d < D; ++d) nh[d] = nh[d] * iw;
             w = wn * 3.0;
+        }
+    };
+    const uint32_t k0 = S.k0, k1 = S.k1;
+    if constexpr (HELP) {
+        if (wv == 1) {
+            // ---- the wavefront that works ahead: slice s's direction and uniforms into buffer s & 1, a barrier, the next slice
+            for (int s = 0; s <= nr; ++s) {
+                if (s < nr) {
+                    double nh[D], w;
+                    whiten(vv, nh, w);
+                    if (s + 1 < nr) {
+                        const double *p = rawc + (size_t)deck[s + 1] * D;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) vv[d] = p[d];
+                    }
+                    double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) pn[d] = nh[d];
+                    pn[D] = w;
+                    double *pu = sU + ((size_t)(s & 1) * 64 + lane) * 9;
+                    const uint32_t c0 = ((uint32_t)s * PC_SLICE_STRIDE) >> 1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { double ua, ub; pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, c0 + (uint32_t)c, ua, ub); pu[2 * c] = ua; pu[2 * c + 1] = ub; }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+        __syncthreads();                                   // (slice 0's direction and uniforms are there)
+    }
+    double *bl_row = S.baby_logL + (size_t)chain * nr;
+    double *bl_col = S.baby_logL_T + chain;
+    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
+    int nlike = 0;
+    // the records' way out (see the end of the loop): lane's first pair of a record and its stride through the 64 records
+    const int RS = nT | 1, chain0 = blockIdx.x * 64, nrows = min(64, nchains - chain0);
+    const size_t rstride = (size_t)nr * nT;
+    const int Hq = max(nT >> 1, 1), cq0 = lane / Hq, fq0 = lane - cq0 * Hq, cstep = 64 / Hq, fstep = 64 - cstep * Hq;
+#ifdef SLICE_T_DBG
+    long long cy[6] = {0, 0, 0, 0, 0, 0}; const long long cA = clock64();
+#endif
+    for (int s = 0; s < nr; ++s, bl_col += Bstride) {
+        // ---- whitening of this slice's direction: w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82)
+        //      (row sums in ascending column; the norm on four partial sums, coordinate d on sum d mod 4)
+        double nh[D], w;
+#ifdef SLICE_T_DBG
+        const long long c0 = clock64();
+#endif
+        if constexpr (!HELP) whiten(vv, nh, w);
+        else {                                              // made by the other wavefront, a slice ahead
+            const double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
+#pragma unroll
+            for (int d = 0; d < D; ++d) nh[d] = pn[d];
+            w = pn[D];
         }
         // ---- where the chord leaves the unit hypercube, once per slice: t in [loS, hiS] is inside in every coordinate, t < loO or
         //      t > hiO is outside in one, whatever the rounding of x0 + t n^ (bounds from an approximate reciprocal, with a margin
@@ -210,7 +255,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             //  whose coordinate does not move -- and every trial of this slice takes its own test)
             if (!((lo_max <= 0.0) & (hi_min >= 0.0) & (m_hi < PC_HUGE) & (m_lo < PC_HUGE))) { hiS = -PC_HUGE; loS = PC_HUGE; hiO = PC_HUGE; loO = -PC_HUGE; }
         }
-        if (s + 1 < nr) {                                   // the next direction's raw vector travels while this slice is made
+        if (!HELP && s + 1 < nr) {                          // the next direction's raw vector travels while this slice is made
             const double *p = rawc + (size_t)deck[s + 1] * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) vv[d] = p[d];
@@ -230,6 +275,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
         const uint32_t idx0 = (uint32_t)s * PC_SLICE_STRIDE;
         uint32_t have_call = 0xFFFFFFFFu; double ua = 0.0, ub = 0.0;
         auto draw = [&](uint32_t k) -> double {
+            if constexpr (HELP) { if (k < 8u) return sU[((size_t)(s & 1) * 64 + lane) * 9 + k]; }
             const uint32_t call = (idx0 + k) >> 1;
             if (call != have_call) { pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, call, ua, ub); have_call = call; }
             return (k & 1u) ? ub : ua;
@@ -320,7 +366,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             mine[o_b0] = contour;                           // nested_sampling.F90:260
             mine[o_l0] = lnew;
             if (act) { bl_row[s] = lnew; *bl_col = lnew; }
-            pc_lds_barrier();                               // (one wave; not __syncthreads: that waits for the global stores of the slice before too)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS traffic, in order: no barrier -- with HELP the other wavefront is not here)
             double *out0 = S.babies + ((size_t)chain0 * nr + s) * nT;       // record of the wave's first chain; chain c: + c nr nT
             if ((nT & 1) == 0) {
                 // lane l takes the pairs l, l + 64, ... of the wave's 64 records laid end to end: record c, pair f2 -> the next is
@@ -351,11 +397,12 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             } else {
                 for (int e = lane; e < nrows * nT; e += 64) { const int c = e / nT, f = e - c * nT; out0[(size_t)c * rstride + f] = sRow[(size_t)c * RS + f]; }
             }
-            pc_lds_barrier();                               // (the records' LDS is free for the next slice once it has been read)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the records' LDS is free for the next slice once it has been read)
         }
 #ifdef SLICE_T_DBG
         { const long long c5 = clock64(); cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3; cy[4] += c5 - c4; }
 #endif
+        if constexpr (HELP) __syncthreads();               // (this slice's buffer may be written again, the next one's is complete)
     }
 #ifdef SLICE_T_DBG
     if (lane == 0) { unsigned long long *g = (unsigned long long *)S.ctl->dbg; for (int x = 0; x < 5; ++x) atomicAdd(&g[x], (unsigned long long)cy[x]); atomicAdd(&g[5], (unsigned long long)(cA - cB)); atomicAdd(&g[6], (unsigned long long)(clock64() - cA)); atomicAdd(&g[7], 1ull); }
@@ -363,9 +410,9 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     if (act) S.ch_nlike[chain] = nlike;
 }
 template <int DT, bool UNIT>
-__global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp) { slice_t_body<DT, UNIT>(S, batch, nchains, nrp); }
-template <int DT, bool UNIT>
-__global__ __launch_bounds__(64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
+__global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp) { slice_t_body<DT, UNIT, false>(S, batch, nchains, nrp); }
+template <int DT, bool UNIT, bool HELP>
+__global__ __launch_bounds__(HELP ? 128 : 64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT, HELP>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
 
 
 static int deck_stride(int nr) { int q = (nr + 3) / 4; if ((q & 1) == 0) q++; return 4 * q; }   // bytes, an odd number of words: lanes on different banks
@@ -376,14 +423,23 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
     constexpr int FW = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
     const int nrp = deck_stride(S->nr), grid = (nchains + 63) / 64;
     const size_t sh = sizeof(double) * ((size_t)DT * DT + 2 * FW) + (size_t)64 * nrp + sizeof(double) * 64 * (size_t)(S->nT | 1);
+    const size_t shh = sh + sizeof(double) * (size_t)2 * 64 * (DT + 1 + 9);      // + two buffers of directions and uniforms
     const bool unit = S->prior.lo == nullptr && S->prior.hi == nullptr;
+    static const bool help_off = std::getenv("PC_SLICE_T_HELP_OFF") != nullptr;
+    // (worth it while the helpers find SIMDs of their own: 16 runs 66 ms against 75, 32 runs 102.5 against 106, 64 runs 201 against 184)
+    if (dR && !help_off && shh <= 64 * 1024 && (long long)grid * R <= 512) {      // runs in step: a second wavefront per 64 chains works a slice ahead
+        if (shh > 48 * 1024) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); }
+        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, true>), dim3(grid, R), dim3(128), shh, st, dR, nchains, nrp);
+        else hipLaunchKernelGGL((k_slice_t_many<DT, false, true>), dim3(grid, R), dim3(128), shh, st, dR, nchains, nrp);
+        return;
+    }
     if (sh > 48 * 1024) {                                         // (long decks and wide records: pc_slice_t_ok keeps it under 64 KB)
-        if (dR) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
+        if (dR) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
         else { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
     }
     if (dR) {
-        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
-        else hipLaunchKernelGGL((k_slice_t_many<DT, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
+        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
+        else hipLaunchKernelGGL((k_slice_t_many<DT, false, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);
     } else if (unit) hipLaunchKernelGGL((k_slice_t<DT, true>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
     else hipLaunchKernelGGL((k_slice_t<DT, false>), dim3(grid), dim3(64), sh, st, *S, batch, nchains, nrp);
 }
