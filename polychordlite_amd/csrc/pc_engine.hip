@@ -153,12 +153,31 @@ struct BlockCache {
     }
     bool put(void *p)                   // false: not one of ours
     {
-        std::lock_guard<std::mutex> g(m);
-        auto it = owner.find(p);
-        if (it == owner.end()) return false;
-        if (cached + it->second.second > limit) { if (host) (void)hipHostFree(p); else (void)hipFree(p); owner.erase(it); return true; }
-        free_.insert({it->second, p}); cached += it->second.second;
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto it = owner.find(p);
+            if (it == owner.end()) return false;
+            if (cached + it->second.second <= limit) { free_.insert({it->second, p}); cached += it->second.second; return true; }
+            owner.erase(it);
+        }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);      // (over the limit: back to the driver, and not under the lock)
         return true;
+    }
+    // a run's hundred-odd blocks at its end in one visit: eight threads tearing runs down at once spent most of that time queueing
+    // for the lock, block by block
+    void put_many(const std::vector<void *> &ps)
+    {
+        std::vector<void *> over;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (void *p : ps) {
+                auto it = owner.find(p);
+                if (it == owner.end()) continue;
+                if (cached + it->second.second <= limit) { free_.insert({it->second, p}); cached += it->second.second; }
+                else { owner.erase(it); over.push_back(p); }
+            }
+        }
+        for (void *p : over) { if (host) (void)hipHostFree(p); else (void)hipFree(p); }
     }
     void trim()
     {
@@ -168,7 +187,7 @@ struct BlockCache {
     }
 };
 // never destroyed: the HIP runtime may already be gone when static destructors run
-BlockCache &dcache() { static BlockCache *c = new BlockCache(false, (size_t)48 << 30); return *c; }
+BlockCache &dcache() { static BlockCache *c = new BlockCache(false, (size_t)64 << 30); return *c; }
 BlockCache &hcache() { static BlockCache *c = new BlockCache(true, (size_t)12 << 30); return *c; }
 
 // PC_POISON=1 (tests): every device block is filled with 0x5A bytes when it is handed out -- ints become 1515870810,
@@ -181,7 +200,8 @@ template <class T> T *dalloc(size_t n)
     if (poison) { (void)hipMemset((void *)p, 0x5A, sizeof(T) * (n ? n : 1)); (void)hipDeviceSynchronize(); }
     return p;
 }
-template <class T> void dfree(T *&p) { if (p) dcache().put((void *)p); p = nullptr; }
+static thread_local std::vector<void *> *tl_dfree_batch = nullptr;      // (Engine::destroy: the blocks are collected and given back together)
+template <class T> void dfree(T *&p) { if (p) { if (tl_dfree_batch) tl_dfree_batch->push_back((void *)p); else dcache().put((void *)p); } p = nullptr; }
 template <class T> T *halloc(size_t n) { return (T *)hcache().get(sizeof(T) * (n ? n : 1)); }
 void hfree(void *p) { if (p && !hcache().put(p)) std::free(p); }
 
@@ -400,11 +420,12 @@ struct Cohort {
         if (n > cap) {
             for (int k = 0; k < RING; ++k) {
                 if (ev_used[k]) { (void)hipEventSynchronize(ev[k]); ev_used[k] = false; }
-                if (h_stage[k]) (void)hipHostFree(h_stage[k]);
-                if (d_recs[k]) (void)hipFree(d_recs[k]);
-                HIPCHK(hipHostMalloc((void **)&h_stage[k], sizeof(PcManyRec) * 2 * n, hipHostMallocDefault));
-                HIPCHK(hipMalloc((void **)&d_recs[k], sizeof(PcManyRec) * 2 * n));
-                if (!ev[k]) HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+                // (from the block caches and the event pool: asking the driver -- and giving back to it at the end -- was 2 ms per call)
+                if (h_stage[k]) hfree(h_stage[k]);
+                if (d_recs[k]) dfree(d_recs[k]);
+                h_stage[k] = halloc<PcManyRec>(2 * n);
+                d_recs[k] = dalloc<PcManyRec>(2 * n);
+                if (!ev[k]) ev[k] = hpool().get_sync_event();
             }
             cap = 2 * n;
         }
@@ -462,16 +483,16 @@ struct Cohort {
     {
         for (int k = 0; k < RING; ++k) {
             if (ev_used[k]) (void)hipEventSynchronize(ev[k]);
-            if (ev[k]) (void)hipEventDestroy(ev[k]);
-            if (h_stage[k]) (void)hipHostFree(h_stage[k]);
-            if (d_recs[k]) (void)hipFree(d_recs[k]);
+            if (ev[k]) hpool().put_sync_event(ev[k]);
+            if (h_stage[k]) hfree(h_stage[k]);
+            if (d_recs[k]) dfree(d_recs[k]);
             ev[k] = nullptr; h_stage[k] = nullptr; d_recs[k] = nullptr; ev_used[k] = false;
         }
         cap = 0;
     }
 };
 
-static std::atomic<long long> g_dbg_compact_ns{0}, g_dbg_nursery_ns{0}, g_dbg_capacity_ns{0};      // (PC_DEBUG=5: where round_enqueue's time goes)
+static std::atomic<long long> g_dbg_compact_ns{0}, g_dbg_nursery_ns{0}, g_dbg_capacity_ns{0}, g_dbg_endb_ns{0}, g_dbg_destroy_ns{0}, g_dbg_evwait_ns{0}, g_dbg_d1{0}, g_dbg_d2{0};      // (PC_DEBUG=5: where round_enqueue's time goes)
 struct Engine {
     Cohort *co = nullptr;               // not null: this run goes in step with others of its device, on their common stream
     pchip_settings cfg{};
@@ -2116,15 +2137,24 @@ struct Engine {
         return 0;
     }
 
-    void destroy()
+    // (streams_idle: the caller has waited for everything the run's streams were given -- a run in step whose ending was waited
+    //  for by event; six stream waits from each of eight threads at once were half of the teardown's time)
+    void destroy(bool streams_idle = false)
     {
         active_run.reset();
         // work may still be in flight on any of the run's streams (early returns, the prefetched bases of a nursery
         // that was never consumed): the blocks below go back to a process-wide cache and may be handed to another
         // run's thread at once
+        if (!streams_idle) {
         if (st) (void)hipStreamSynchronize(st);
         if (st_copy) (void)hipStreamSynchronize(st_copy);
         if (st_side) (void)hipStreamSynchronize(st_side);
+        }
+        const auto dq0 = std::chrono::steady_clock::now();
+        std::vector<void *> blocks; blocks.reserve(160);
+        struct Batch { std::vector<void *> &b; Batch(std::vector<void *> &v) : b(v) { tl_dfree_batch = &b; } ~Batch() { tl_dfree_batch = nullptr; dcache().put_many(b); b.clear(); } };
+        {
+        Batch batch_guard(blocks);
         if (raw_buf[0]) { S.nhat_raw = raw_buf[0]; for (int r = 1; r < RAW_RING; ++r) dfree(raw_buf[r]); raw_buf[0] = nullptr; }     // S.nhat_raw pointed at one of them
         if (babies_own) { S.babies = babies_own; babies_own = nullptr; }      // (pool mode pointed it into the phantom array)
         double **dd[] = { &S.live, &S.live_logL, &S.logZp, &S.logXp, &S.logZXp, &S.logZp2, &S.logZpXp, &S.logLp, &S.XpXq,
@@ -2145,19 +2175,24 @@ struct Engine {
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
+        }
+        const auto dq1 = std::chrono::steady_clock::now();
         kt.destroy();
         if (h_dead) { hfree(h_dead); h_dead = nullptr; }
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
         if (h_note) hfree((void *)h_note); h_note = nullptr;
         if (ev_apply) { hpool().put_sync_event(ev_apply); ev_apply = nullptr; }
 
-        if (st) { (void)hipStreamSynchronize(st); if (!co) hpool().put_stream(st); } st = nullptr;
-        if (st_copy) { (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
+        if (st) { if (!streams_idle) (void)hipStreamSynchronize(st); if (!co) hpool().put_stream(st); } st = nullptr;
+        if (st_copy) { if (!streams_idle) (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
         if (st_side) {
-            (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
+            if (!streams_idle) (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
             for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_sync_event(ring[r].ready); if (ring[r].consumed) hpool().put_sync_event(ring[r].consumed); ring[r] = RawSlot(); }
         }
         st_side = nullptr; ev_main = nullptr;
+        const auto dq2 = std::chrono::steady_clock::now();
+        g_dbg_d1 += std::chrono::duration_cast<std::chrono::nanoseconds>(dq1 - dq0).count();
+        g_dbg_d2 += std::chrono::duration_cast<std::chrono::nanoseconds>(dq2 - dq1).count();
     }
 };
 
@@ -2279,6 +2314,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         const auto T0 = std::chrono::steady_clock::now();
         long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
         int *h_totals = nullptr; size_t totals_cap = 0;
+        struct EndBatch { std::vector<int> fin, rcs; hipEvent_t ev = nullptr, ev2 = nullptr; int dev = 0; std::thread th; };
+        std::vector<std::unique_ptr<EndBatch>> endings;
         auto nowc = [] { return std::chrono::steady_clock::now(); };
         auto secc = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         auto close = [&](int k, int rc) {
@@ -2314,7 +2351,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                     if (nc) {
                         const auto c0 = nowc();
                         co.flush();
-                        if ((size_t)n > totals_cap) { if (h_totals) (void)hipHostFree(h_totals); HIPCHK(hipHostMalloc((void **)&h_totals, sizeof(int) * n, hipHostMallocDefault)); totals_cap = (size_t)n; }
+                        if ((size_t)n > totals_cap) { if (h_totals) hfree(h_totals); h_totals = halloc<int>((size_t)n); totals_cap = (size_t)n; }
                         for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) HIPCHK(hipMemcpyAsync(&h_totals[k], E[k]->d_total, sizeof(int), hipMemcpyDeviceToHost, co.st));
                         HIPCHK(hipStreamSynchronize(co.st));
                         for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) E[k]->compact_finish(h_totals[k]);
@@ -2329,57 +2366,80 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 rounds++;
                 bool any_done = false;
                 for (int k = 0; k < n; ++k) any_done = any_done || (live[k] && !enq[k]);
-                if (any_done && co.st2) HIPCHK(hipStreamSynchronize(co.st2));      // (bases drawn ahead for a run that is over: not into freed memory)
-                if (any_done) {     // the runs that are over end together: their kill-off in one launch, one wait for all their results
+                if (any_done) {
+                    // the runs that are over end together: their kill-off in one launch, and what their results need asked of the
+                    // device behind it.  Nobody waits here: a thread takes the batch from there (two events, then the host's half
+                    // of the endings -- results, buffers given back, a third of a millisecond per run, shared out among a few
+                    // threads) while the runs that are left go on with their rounds
                     const auto e0 = nowc();
                     co.flush();
                     for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a(true);
                     co.flush();
                     for (int k = 0; k < n; ++k) if (live[k] && !enq[k] && !E[k]->r_rc) E[k]->end_a2();
-                    HIPCHK(hipStreamSynchronize(co.st));
-                    t_end_dev += secc(e0, nowc());
-                    // (the host's half of an ending -- results, buffers given back -- is a third of a millisecond per run: the runs that end now
-                    //  are shared out among a few threads)
-                    std::vector<int> fin;
-                    for (int k = 0; k < n; ++k) if (live[k] && !enq[k]) fin.push_back(k);
-                    std::vector<int> rcs(fin.size(), 0);
-                    auto finish_one = [&](size_t a) {
-                        const int k = fin[a];
-                        int r = E[k]->r_rc;
-                        if (!r) {
-                            try { r = E[k]->end_b(&results[base + k]); }
-                            catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); r = e.code; }
-                            catch (const std::bad_alloc &) { r = PC_RC_MEMORY; }
+                    endings.emplace_back(new EndBatch);
+                    EndBatch *eb = endings.back().get();
+                    for (int k = 0; k < n; ++k) if (live[k] && !enq[k]) eb->fin.push_back(k);
+                    eb->rcs.assign(eb->fin.size(), 0);
+                    eb->dev = E[eb->fin[0]]->dev;
+                    eb->ev = hpool().get_sync_event(); HIPCHK(hipEventRecord(eb->ev, co.st));
+                    if (co.st2) { eb->ev2 = hpool().get_sync_event(); HIPCHK(hipEventRecord(eb->ev2, co.st2)); }      // (bases drawn ahead for a run that is over: not into freed memory)
+                    for (int k : eb->fin) { live[k] = 0; nlive--; if (E[k]->r_rc && !worst) worst = E[k]->r_rc; }      // (a run that failed stops the others at once)
+                    eb->th = std::thread([&E, &results, base, eb] {
+                        (void)hipSetDevice(eb->dev);
+                        const auto w0 = std::chrono::steady_clock::now();
+                        const hipError_t w1 = hipEventSynchronize(eb->ev), w2 = eb->ev2 ? hipEventSynchronize(eb->ev2) : hipSuccess;
+                        g_dbg_evwait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+                        auto finish_one = [&](size_t a) {
+                            const int k = eb->fin[a];
+                            int r = E[k]->r_rc;
+                            if (!r && (w1 != hipSuccess || w2 != hipSuccess)) r = PC_RC_DEVICE;
+                            const auto q0 = std::chrono::steady_clock::now();
+                            if (!r) {
+                                try { r = E[k]->end_b(&results[base + k]); }
+                                catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); r = e.code; }
+                                catch (const std::bad_alloc &) { r = PC_RC_MEMORY; }
+                            }
+                            const auto q1 = std::chrono::steady_clock::now();
+                            if (r != 0) pchip_result_free(&results[base + k]);
+                            try { E[k]->destroy(r == 0 && E[k]->st_side == nullptr); } catch (...) {}      // (end_b has waited for the copy stream, this thread for the cohort's two)
+                            delete E[k]; E[k] = nullptr; eb->rcs[a] = r;
+                            g_dbg_endb_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(q1 - q0).count();
+                            g_dbg_destroy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q1).count();
+                        };
+                        const size_t nth = std::min<size_t>(eb->fin.size(), 8);
+                        if (nth <= 1) { for (size_t a = 0; a < eb->fin.size(); ++a) finish_one(a); }
+                        else {
+                            std::atomic<size_t> nexta{0};
+                            auto worker = [&] { (void)hipSetDevice(eb->dev); for (size_t a; (a = nexta.fetch_add(1)) < eb->fin.size();) finish_one(a); };
+                            std::vector<std::thread> th;
+                            for (size_t t = 1; t < nth; ++t) th.emplace_back(worker);
+                            worker();
+                            for (auto &t : th) t.join();
                         }
-                        if (r != 0) pchip_result_free(&results[base + k]);
-                        try { E[k]->destroy(); } catch (...) {}
-                        delete E[k]; E[k] = nullptr; rcs[a] = r;
-                    };
-                    const size_t nth = std::min<size_t>(fin.size(), 8);
-                    if (nth <= 1) { for (size_t a = 0; a < fin.size(); ++a) finish_one(a); }
-                    else {
-                        std::atomic<size_t> nexta{0};
-                        const int devnow = E[fin[0]]->dev;
-                        auto worker = [&] { (void)hipSetDevice(devnow); for (size_t a; (a = nexta.fetch_add(1)) < fin.size();) finish_one(a); };
-                        std::vector<std::thread> th;
-                        for (size_t t = 1; t < nth; ++t) th.emplace_back(worker);
-                        worker();
-                        for (auto &t : th) t.join();
-                    }
-                    for (size_t a = 0; a < fin.size(); ++a) { live[fin[a]] = 0; nlive--; if (rcs[a] != 0 && !worst) worst = rcs[a]; }
-                    t_end += secc(e0, nowc());
+                    });
+                    t_end_dev += secc(e0, nowc());
                 }
             }
         }
         catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); (void)hipGetLastError(); if (!worst) worst = e.code; }
         catch (const std::bad_alloc &) { std::fprintf(stderr, "polychord_hip: out of host memory\n"); if (!worst) worst = PC_RC_MEMORY; }
+        {   // the endings under way
+            const auto e0 = nowc();
+            for (auto &eb : endings) {
+                if (eb->th.joinable()) eb->th.join();
+                for (int r : eb->rcs) if (r != 0 && !worst) worst = r;
+                hpool().put_sync_event(eb->ev); if (eb->ev2) hpool().put_sync_event(eb->ev2);
+            }
+            t_end += secc(e0, nowc());
+        }
         if (co.st2) (void)hipStreamSynchronize(co.st2);
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
-        if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6); }
-        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, end + teardown %.2f of which the device's half %.2f); %ld records launched together, %ld one by one\n", n, rounds,
-                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end * 1e3, t_end_dev * 1e3, co.n_fused, co.n_single);
+        if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6);
+                    std::fprintf(stderr, "polychord_hip dbg cohort: %zu ending batches: events %.2f ms, results %.2f ms, teardown %.2f ms (summed over threads); the block caches hold %.2f GB of device and %.2f GB of pinned memory; teardown: device blocks %.2f, the rest %.2f ms\n", endings.size(), g_dbg_evwait_ns.exchange(0) * 1e-6, g_dbg_endb_ns.exchange(0) * 1e-6, g_dbg_destroy_ns.exchange(0) * 1e-6, dcache().cached / 1073741824.0, hcache().cached / 1073741824.0, g_dbg_d1.exchange(0) * 1e-6, g_dbg_d2.exchange(0) * 1e-6); }
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds,
+                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
         co.destroy();
-        if (h_totals) (void)hipHostFree(h_totals);
+        if (h_totals) hfree(h_totals);
         (void)hipStreamSynchronize(co.st);
         if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
         if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }

@@ -72,7 +72,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     const long long cB = clock64();
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wv = HELP ? (tid >> 6) : 0;
-    constexpr int NTH = HELP ? 128 : 64;
+    constexpr int NTH = HELP ? 192 : 64;
     const int chain_raw = blockIdx.x * 64 + lane;
     const bool act = chain_raw < nchains;                 // lanes past the nursery follow its last chain and store nothing
     const int chain = act ? chain_raw : nchains - 1;
@@ -182,42 +182,109 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             w = wn * 3.0;
         }
     };
+    double *bl_row = S.baby_logL + (size_t)chain * nr;
+    double *bl_col = S.baby_logL_T + chain;
+    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
+    // the records' way out (see the end of the loop): lane's first pair of a record and its stride through the 64 records
+    const int RS = nT | 1, chain0 = blockIdx.x * 64, nrows = min(64, nchains - chain0);
+    const size_t rstride = (size_t)nr * nT;
+    const int Hq = max(nT >> 1, 1), cq0 = lane / Hq, fq0 = lane - cq0 * Hq, cstep = 64 / Hq, fstep = 64 - cstep * Hq;
+    // the wave writes the 64 records of slice s out of LDS in runs of consecutive addresses
+    auto copy_out = [&](int s) __attribute__((always_inline)) {
+        double *out0 = S.babies + ((size_t)chain0 * nr + s) * nT;       // record of the wave's first chain; chain c: + c nr nT
+        if ((nT & 1) == 0) {
+            // lane l takes the pairs l, l + 64, ... of the wave's 64 records laid end to end: record c, pair f2 -> the next is
+            // cstep records and fstep pairs on (one record more when the pair index wraps); both addresses move by increments
+            const int H = nT >> 1;
+            int f2 = fq0, c = cq0;
+            const double *src = sRow + (size_t)cq0 * RS + 2 * fq0;
+            double *dst = out0 + (size_t)cq0 * rstride + 2 * fq0;
+            const int sstep = cstep * RS + 2 * fstep, swrap = RS - nT;
+            const size_t dstep = (size_t)cstep * rstride + 2 * fstep, dwrap = rstride - nT;
+            if (nrows == 64) {
+                double2 cur = make_double2(src[0], src[1]);               // (the next pair is on its way from LDS while this one is stored)
+                for (int i = 0; i < H; ++i) {
+                    double *d0 = dst;
+                    f2 += fstep; src += sstep; dst += dstep;
+                    if (f2 >= H) { f2 -= H; src += swrap; dst += dwrap; }
+                    const double2 nxt = (i + 1 < H) ? make_double2(src[0], src[1]) : cur;
+                    *(double2 *)d0 = cur;
+                    cur = nxt;
+                }
+            } else {
+                for (int i = 0; i < H; ++i) {
+                    if (c < nrows) *(double2 *)dst = make_double2(src[0], src[1]);
+                    f2 += fstep; c += cstep; src += sstep; dst += dstep;
+                    if (f2 >= H) { f2 -= H; c++; src += swrap; dst += dwrap; }
+                }
+            }
+        } else {
+            for (int e = lane; e < nrows * nT; e += 64) { const int c = e / nT, f = e - c * nT; out0[(size_t)c * rstride + f] = sRow[(size_t)c * RS + f]; }
+        }
+    };
     const uint32_t k0 = S.k0, k1 = S.k1;
     if constexpr (HELP) {
-        if (wv == 1) {
-            // ---- the wavefront that works ahead: slice s's direction and uniforms into buffer s & 1, a barrier, the next slice
-            for (int s = 0; s <= nr; ++s) {
-                if (s < nr) {
-                    double nh[D], w;
-                    whiten(vv, nh, w);
-                    if (s + 1 < nr) {
-                        const double *p = rawc + (size_t)deck[s + 1] * D;
+        if (wv >= 1) {
+            // ---- the wavefront that works ahead and behind: while the first walks slice s, this one sends the records of slice
+            //      s - 1 out (their derived parameters first: gaussian.f90:36-37 from the record's theta) and makes slice s + 1's
+            //      direction and uniforms into buffer (s + 1) & 1.  Two barriers per slice: X (the records' LDS is free), Y (the
+            //      records of slice s are laid down, slice s + 1's direction is complete)
+            auto produce = [&](int s) __attribute__((always_inline)) {
+                double nh[D], w;
+                whiten(vv, nh, w);
+                if (s + 1 < nr) {
+                    const double *p = rawc + (size_t)deck[s + 1] * D;
 #pragma unroll
-                        for (int d = 0; d < D; ++d) vv[d] = p[d];
-                    }
-                    double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
-#pragma unroll
-                    for (int d = 0; d < D; ++d) pn[d] = nh[d];
-                    pn[D] = w;
-                    double *pu = sU + ((size_t)(s & 1) * 64 + lane) * 9;
-                    const uint32_t c0 = ((uint32_t)s * PC_SLICE_STRIDE) >> 1;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { double ua, ub; pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, c0 + (uint32_t)c, ua, ub); pu[2 * c] = ua; pu[2 * c + 1] = ub; }
+                    for (int d = 0; d < D; ++d) vv[d] = p[d];
                 }
-                __syncthreads();
+                double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
+#pragma unroll
+                for (int d = 0; d < D; ++d) pn[d] = nh[d];
+                pn[D] = w;
+                double *pu = sU + ((size_t)(s & 1) * 64 + lane) * 9;
+                const uint32_t c0 = ((uint32_t)s * PC_SLICE_STRIDE) >> 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { double ua, ub; pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, c0 + (uint32_t)c, ua, ub); pu[2 * c] = ua; pu[2 * c + 1] = ub; }
+            };
+            auto ship = [&](int s) __attribute__((always_inline)) {
+                double *mine = sRow + (size_t)lane * RS;
+                if (nDer > 0) {
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) { const double z = mine[o_p0 + d] - mu; r2 = fma(z, z, r2); }
+                    const double phi0 = sqrt(r2);
+                    mine[o_d0] = phi0;
+                    if (nDer >= 2) mine[o_d0 + 1] = fma((double)D, log(phi0), S.like.log_vn);      // pc_log_ball
+                    for (int e = 2; e < nDer; ++e) mine[o_d0 + e] = 0.0;
+                }
+                const double lnew = mine[o_l0];
+                if (act) { bl_row[s] = lnew; bl_col[(size_t)s * Bstride] = lnew; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                copy_out(s);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            if (wv == 1) {
+                produce(0);
+                pc_lds_barrier();
+                for (int s = 0; s < nr; ++s) {
+                    if (s + 1 < nr) produce(s + 1);
+                    pc_lds_barrier();                      // X
+                    pc_lds_barrier();                      // Y
+                }
+            } else {
+                pc_lds_barrier();
+                for (int s = 0; s < nr; ++s) {
+                    if (s >= 1) ship(s - 1);
+                    pc_lds_barrier();                      // X
+                    pc_lds_barrier();                      // Y
+                }
+                ship(nr - 1);
             }
             return;
         }
         __syncthreads();                                   // (slice 0's direction and uniforms are there)
     }
-    double *bl_row = S.baby_logL + (size_t)chain * nr;
-    double *bl_col = S.baby_logL_T + chain;
-    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
     int nlike = 0;
-    // the records' way out (see the end of the loop): lane's first pair of a record and its stride through the 64 records
-    const int RS = nT | 1, chain0 = blockIdx.x * 64, nrows = min(64, nchains - chain0);
-    const size_t rstride = (size_t)nr * nT;
-    const int Hq = max(nT >> 1, 1), cq0 = lane / Hq, fq0 = lane - cq0 * Hq, cstep = 64 / Hq, fstep = 64 - cstep * Hq;
 #ifdef SLICE_T_DBG
     long long cy[6] = {0, 0, 0, 0, 0, 0}; const long long cA = clock64();
 #endif
@@ -337,18 +404,33 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             x0[d] = fma(t_last, nh[d], x0[d]);
-            double th;
-            if constexpr (UNIT) th = x0[d]; else th = fma(sSpan[d], x0[d], sLo[d]);
-            const double z = th - mu;
-            r2 = fma(z, z, r2);
+            if constexpr (!HELP) {
+                double th;
+                if constexpr (UNIT) th = x0[d]; else th = fma(sSpan[d], x0[d], sLo[d]);
+                const double z = th - mu;
+                r2 = fma(z, z, r2);
+            }
         }
-        if (__builtin_expect(last_out, 0)) {
+        if constexpr (!HELP) if (__builtin_expect(last_out, 0)) {
             r2 = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) { const double z = 0.0 - mu; r2 = fma(z, z, r2); }
         }
-        // ---- the record of the baby: the lane lays it down in LDS, and the wave writes the 64 records out in runs of consecutive
-        //      addresses (a lane's own stores would be 64 cache lines per instruction, 2 nDims + 4 instructions per slice)
+        // ---- the record of the baby: the lane lays it down in LDS, and a wave writes the 64 records out in runs of consecutive
+        //      addresses (a lane's own stores would be 64 cache lines per instruction, 2 nDims + 4 instructions per slice).
+        //      HELP: the other wavefront does that, and the derived parameters, while this one walks the next slice
+        if constexpr (HELP) {
+            __syncthreads();                                // X: the records of the slice before have left LDS
+            double *mine = sRow + (size_t)lane * RS;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double th;
+                if constexpr (UNIT) th = x0[d]; else th = fma(sSpan[d], x0[d], sLo[d]);
+                mine[d] = x0[d]; mine[o_p0 + d] = __builtin_expect(last_out, 0) ? 0.0 : th;
+            }
+            mine[o_b0] = contour;                           // nested_sampling.F90:260
+            mine[o_l0] = lnew;
+        } else
         {
             double *mine = sRow + (size_t)lane * RS;
 #pragma unroll
@@ -367,42 +449,13 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             mine[o_l0] = lnew;
             if (act) { bl_row[s] = lnew; *bl_col = lnew; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS traffic, in order: no barrier -- with HELP the other wavefront is not here)
-            double *out0 = S.babies + ((size_t)chain0 * nr + s) * nT;       // record of the wave's first chain; chain c: + c nr nT
-            if ((nT & 1) == 0) {
-                // lane l takes the pairs l, l + 64, ... of the wave's 64 records laid end to end: record c, pair f2 -> the next is
-                // cstep records and fstep pairs on (one record more when the pair index wraps); both addresses move by increments
-                const int H = nT >> 1;
-                int f2 = fq0, c = cq0;
-                const double *src = sRow + (size_t)cq0 * RS + 2 * fq0;
-                double *dst = out0 + (size_t)cq0 * rstride + 2 * fq0;
-                const int sstep = cstep * RS + 2 * fstep, swrap = RS - nT;
-                const size_t dstep = (size_t)cstep * rstride + 2 * fstep, dwrap = rstride - nT;
-                if (nrows == 64) {
-                    double2 cur = make_double2(src[0], src[1]);               // (the next pair is on its way from LDS while this one is stored)
-                    for (int i = 0; i < H; ++i) {
-                        double *d0 = dst;
-                        f2 += fstep; src += sstep; dst += dstep;
-                        if (f2 >= H) { f2 -= H; src += swrap; dst += dwrap; }
-                        const double2 nxt = (i + 1 < H) ? make_double2(src[0], src[1]) : cur;
-                        *(double2 *)d0 = cur;
-                        cur = nxt;
-                    }
-                } else {
-                    for (int i = 0; i < H; ++i) {
-                        if (c < nrows) *(double2 *)dst = make_double2(src[0], src[1]);
-                        f2 += fstep; c += cstep; src += sstep; dst += dstep;
-                        if (f2 >= H) { f2 -= H; c++; src += swrap; dst += dwrap; }
-                    }
-                }
-            } else {
-                for (int e = lane; e < nrows * nT; e += 64) { const int c = e / nT, f = e - c * nT; out0[(size_t)c * rstride + f] = sRow[(size_t)c * RS + f]; }
-            }
+            copy_out(s);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the records' LDS is free for the next slice once it has been read)
         }
 #ifdef SLICE_T_DBG
         { const long long c5 = clock64(); cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3; cy[4] += c5 - c4; }
 #endif
-        if constexpr (HELP) __syncthreads();               // (this slice's buffer may be written again, the next one's is complete)
+        if constexpr (HELP) __syncthreads();               // Y: these records are laid down; the next slice's direction and uniforms are complete
     }
 #ifdef SLICE_T_DBG
     if (lane == 0) { unsigned long long *g = (unsigned long long *)S.ctl->dbg; for (int x = 0; x < 5; ++x) atomicAdd(&g[x], (unsigned long long)cy[x]); atomicAdd(&g[5], (unsigned long long)(cA - cB)); atomicAdd(&g[6], (unsigned long long)(clock64() - cA)); atomicAdd(&g[7], 1ull); }
@@ -412,7 +465,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 template <int DT, bool UNIT>
 __global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp) { slice_t_body<DT, UNIT, false>(S, batch, nchains, nrp); }
 template <int DT, bool UNIT, bool HELP>
-__global__ __launch_bounds__(HELP ? 128 : 64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT, HELP>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
+__global__ __launch_bounds__(HELP ? 192 : 64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT, HELP>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
 
 
 static int deck_stride(int nr) { int q = (nr + 3) / 4; if ((q & 1) == 0) q++; return 4 * q; }   // bytes, an odd number of words: lanes on different banks
@@ -427,10 +480,11 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
     const bool unit = S->prior.lo == nullptr && S->prior.hi == nullptr;
     static const bool help_off = std::getenv("PC_SLICE_T_HELP_OFF") != nullptr;
     // (worth it while the helpers find SIMDs of their own: 16 runs 66 ms against 75, 32 runs 102.5 against 106, 64 runs 201 against 184)
-    if (dR && !help_off && shh <= 64 * 1024 && (long long)grid * R <= 512) {      // runs in step: a second wavefront per 64 chains works a slice ahead
+    static const long long help_max = std::getenv("PC_SLICE_T_HELP_MAX") ? std::atoll(std::getenv("PC_SLICE_T_HELP_MAX")) : 512;
+    if (dR && !help_off && shh <= 64 * 1024 && (long long)grid * R <= help_max) {      // runs in step: a second wavefront per 64 chains works a slice ahead
         if (shh > 48 * 1024) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); }
-        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, true>), dim3(grid, R), dim3(128), shh, st, dR, nchains, nrp);
-        else hipLaunchKernelGGL((k_slice_t_many<DT, false, true>), dim3(grid, R), dim3(128), shh, st, dR, nchains, nrp);
+        if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, true>), dim3(grid, R), dim3(192), shh, st, dR, nchains, nrp);
+        else hipLaunchKernelGGL((k_slice_t_many<DT, false, true>), dim3(grid, R), dim3(192), shh, st, dR, nchains, nrp);
         return;
     }
     if (sh > 48 * 1024) {                                         // (long decks and wide records: pc_slice_t_ok keeps it under 64 KB)
