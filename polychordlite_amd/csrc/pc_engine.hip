@@ -116,6 +116,7 @@ namespace {
 // hipFree cost O(100 us) each and hipFree synchronises the device, which is as long as the sampling
 // itself at the metric config.  Blocks are keyed by (device, rounded size) and handed back on free;
 // nothing relies on their contents (hipMalloc does not zero either).
+static std::atomic<long long> g_dbg_miss_n[2], g_dbg_miss_ns[2], g_dbg_mk_stream_n{0}, g_dbg_mk_stream_ns{0};      // (PC_DEBUG=5: trips to the driver -- device / pinned blocks, streams)
 struct BlockCache {
     std::mutex m;
     std::multimap<std::pair<int, size_t>, void *> free_;
@@ -123,11 +124,15 @@ struct BlockCache {
     size_t cached = 0, limit;
     bool host;
     BlockCache(bool h, size_t lim) : limit(lim), host(h) {}
+    // eight sizes per octave above 4 KB (at most an eighth more than asked for): arrays sized by what a run found -- its dead
+    // points, its weights -- differ by a few rows from seed to seed, and every near miss was a trip to the driver (a pinned
+    // allocation is milliseconds there once another runtime, PyTorch's, lives in the process)
     static size_t round_up(size_t b)
     {
         if (b < 4096) return (b + 255) & ~(size_t)255;
-        if (b < (1u << 20)) return (b + 4095) & ~(size_t)4095;
-        return (b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        int top = 63 - __builtin_clzll((unsigned long long)b);
+        const size_t step = (size_t)1 << (top - 3);
+        return (b + step - 1) & ~(step - 1);
     }
     void *get(size_t bytes)
     {
@@ -141,7 +146,9 @@ struct BlockCache {
             if (it != free_.end()) { void *p = it->second; free_.erase(it); cached -= sz; return p; }
         }
         void *p = nullptr;
+        const auto q0 = std::chrono::steady_clock::now();
         hipError_t e = host ? hipHostMalloc(&p, sz) : hipMalloc(&p, sz);
+        g_dbg_miss_n[host ? 1 : 0]++; g_dbg_miss_ns[host ? 1 : 0] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q0).count();
         if (e != hipSuccess) {          // give the cached blocks back and retry once
             trim();
             e = host ? hipHostMalloc(&p, sz) : hipMalloc(&p, sz);
@@ -218,7 +225,10 @@ struct HandlePool {
             for (size_t i = 0; i < streams.size(); ++i)
                 if (streams[i].first == dev) { hipStream_t s = streams[i].second; streams.erase(streams.begin() + i); return s; }
         }
-        hipStream_t s; HIPCHK(hipStreamCreate(&s)); return s;
+        const auto q0 = std::chrono::steady_clock::now();
+        hipStream_t s; HIPCHK(hipStreamCreate(&s));
+        g_dbg_mk_stream_n++; g_dbg_mk_stream_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q0).count();
+        return s;
     }
     void put_stream(hipStream_t s) { int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(m); streams.push_back({dev, s}); }
     template <class Pred> hipStream_t take_stream_if(Pred pred)          // a pooled stream of this device the predicate accepts, or null
@@ -312,8 +322,14 @@ static hipStream_t stream_beside(std::initializer_list<hipStream_t> others)
     hipStream_t pick = nullptr;
     for (int k = 0; k < 8 && !pick; ++k) {
         hipStream_t c = hpool().take_stream_if([&](hipStream_t x) { return sclasses().known(x) < 0; });
+        static const bool dbg = std::getenv("PC_DEBUG") && std::atoi(std::getenv("PC_DEBUG")) == 5;
+        const auto q0 = std::chrono::steady_clock::now();
+        const bool made = !c;
         if (!c) { HIPCHK(hipStreamCreate(&c)); }
-        if (fits(sclasses().classify(c))) pick = c; else tried.push_back(c);
+        const auto q1 = std::chrono::steady_clock::now();
+        const int cc = sclasses().classify(c);
+        if (dbg) std::fprintf(stderr, "polychord_hip dbg stream_beside: try %d, %s stream %p (%.2f ms), class %d (%.2f ms), avoid %d\n", k, made ? "new" : "pooled", (void *)c, std::chrono::duration<double>(q1 - q0).count() * 1e3, cc, std::chrono::duration<double>(std::chrono::steady_clock::now() - q1).count() * 1e3, avoid.empty() ? -1 : avoid[0]);
+        if (fits(cc)) pick = c; else tried.push_back(c);
     }
     if (!pick) { pick = tried.back(); tried.pop_back(); }   // (none: any will do)
     for (hipStream_t t : tried) hpool().put_stream(t);
@@ -2300,13 +2316,19 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
     int done_here = 0;
     for (int base = 0; base < nseeds && !worst; base += done_here) {
         int n = std::min(W, nseeds - base);
+        const auto Tpre = std::chrono::steady_clock::now();
         Cohort co; bool own_streams = false;
         static const bool side_off = std::getenv("PC_COHORT_SIDE") && std::atoi(std::getenv("PC_COHORT_SIDE")) == 0;
         static const bool prio_off = !(std::getenv("PC_COHORT_PRIO") && std::atoi(std::getenv("PC_COHORT_PRIO")) == 1);      // (tried: 79 ms against 70 for sixteen runs -- off)
         // (the round's own kernels first, the bases of the next round in what they leave: stream priorities)
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (least, greatest: numerically lower = more urgent)
-        if (prio_off || plo == phi) { co.st = hpool().get_stream(); if (!side_off) co.st2 = side_stream_for(co.st); }
+        const auto Tp1 = std::chrono::steady_clock::now();
+        // (a main stream whose hardware queue is known already, if the pool has one: the side stream is then picked without a test --
+        //  a test is a millisecond, several once PyTorch lives in the process, and the pool's first stream was a different one of
+        //  the engines' copy streams at every call)
+        if (prio_off || plo == phi) { co.st = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) >= 0; }); if (!co.st) co.st = hpool().get_stream(); const auto Tp2 = std::chrono::steady_clock::now(); if (!side_off) co.st2 = side_stream_for(co.st);
+            if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
         if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
         std::vector<Engine *> E((size_t)n, nullptr);
@@ -2436,7 +2458,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
         if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6);
                     std::fprintf(stderr, "polychord_hip dbg cohort: %zu ending batches: events %.2f ms, results %.2f ms, teardown %.2f ms (summed over threads); the block caches hold %.2f GB of device and %.2f GB of pinned memory; teardown: device blocks %.2f, the rest %.2f ms\n", endings.size(), g_dbg_evwait_ns.exchange(0) * 1e-6, g_dbg_endb_ns.exchange(0) * 1e-6, g_dbg_destroy_ns.exchange(0) * 1e-6, dcache().cached / 1073741824.0, hcache().cached / 1073741824.0, g_dbg_d1.exchange(0) * 1e-6, g_dbg_d2.exchange(0) * 1e-6); }
-        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds,
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
         co.destroy();
         if (h_totals) hfree(h_totals);

@@ -65,33 +65,56 @@ __device__ __forceinline__ void upd_stage_masked(const double *src0, unsigned lo
 // state at the mark the launch recorded (PcCtl::upd_*): the threshold of the clean is the logL of the death at the mark;
 // the moments leave out what came after it -- phantoms of later chains, live points accepted later -- and take in the
 // points that were alive then and have died since (their rows are in the dead array)
-__device__ __forceinline__ void upd_flag_body(const PcState &S, int nph, unsigned char *keep, int *blk_count, int def)
+// (a wavefront takes one block of the counts -- 256 rows, four consecutive rows per lane: 32-byte, 16-byte and 4-byte accesses in
+//  place of 8, 4 and 1 -- and a workgroup four of them; the survivors of a block are counted by ballots, no LDS)
+__device__ __forceinline__ void upd_flag_body(const PcState &S, int nph, unsigned char *keep, int *blk_count, int def, int nblk)
 {
-    __shared__ int cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sb = blockIdx.x * 4 + wv;
+    if (sb >= nblk) return;
     const unsigned uid0 = S.cl_uid[0];
     const double thr = def ? S.ctl->upd_thr : S.death_thr[0];
-    const int j = blockIdx.x * UPD_ROWS + tid;
-    bool k = false, km = false;
-    if (j < nph) {
-        const unsigned cu = S.ph_cuid[j];
-        k = (cu == uid0) && !(S.ph_logL[j] < thr);
-        if (S.pool) {
-            // pool mode: a dropped phantom is dropped where it lies; the rows that count in the moments (the survivors that
-            // were phantoms at the mark -- rows of chains consumed later stay, but do not count) are listed by k_upd_index
-            if (!k && cu == uid0) S.ph_cuid[j] = PC_CUID_NONE;
-            const int tmark = def ? S.ctl->upd_tmark : 0x7fffffff, nph0u = def ? S.ctl->upd_nph0 : 0x7fffffff;
-            km = k && (j < nph0u || S.ctl->upd_T - 1 - (j - nph0u) / S.nr < tmark);
-        }
-        keep[j] = (k ? 1 : 0) | (km ? 2 : 0);
+    const bool pool = S.pool;
+    // pool mode: a dropped phantom is dropped where it lies; the rows that count in the moments (the survivors that were
+    // phantoms at the mark -- rows of chains consumed later stay, but do not count) are listed by k_upd_index
+    const int tmark = (pool && def) ? S.ctl->upd_tmark : 0x7fffffff, nph0u = (pool && def) ? S.ctl->upd_nph0 : 0x7fffffff;
+    const int T = (pool && def) ? S.ctl->upd_T : 0, nr = S.nr;
+    const int j0 = sb * UPD_ROWS + 4 * lane;
+    const bool full = j0 + 3 < nph;
+    unsigned cu[4] = {PC_CUID_NONE, PC_CUID_NONE, PC_CUID_NONE, PC_CUID_NONE};
+    double ll[4] = {0.0, 0.0, 0.0, 0.0};
+    if (full) {
+        const uint4 c = *(const uint4 *)(S.ph_cuid + j0);
+        const double2 a = *(const double2 *)(S.ph_logL + j0), b2 = *(const double2 *)(S.ph_logL + j0 + 2);
+        cu[0] = c.x; cu[1] = c.y; cu[2] = c.z; cu[3] = c.w; ll[0] = a.x; ll[1] = a.y; ll[2] = b2.x; ll[3] = b2.y;
+    } else {
+        for (int u = 0; u < 4; ++u) if (j0 + u < nph) { cu[u] = S.ph_cuid[j0 + u]; ll[u] = S.ph_logL[j0 + u]; }
     }
-    const unsigned long long m = __ballot(S.pool ? km : k);
-    if (lane == 0) cnt[wv] = __popcll(m);
-    __syncthreads();
-    if (tid == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    unsigned kb = 0; bool wr = false; int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        bool k = false, km = false;
+        if (j < nph) {
+            k = (cu[u] == uid0) && !(ll[u] < thr);
+            if (pool) {
+                if (!k && cu[u] == uid0) { cu[u] = PC_CUID_NONE; wr = true; }
+                km = k && (j < nph0u || T - 1 - (j - nph0u) / nr < tmark);
+            }
+            kb |= (unsigned)((k ? 1 : 0) | (km ? 2 : 0)) << (8 * u);
+        }
+        cnt += __popcll(__ballot(pool ? km : k));
+    }
+    if (full) {
+        *(unsigned *)(keep + j0) = kb;
+        if (wr) *(uint4 *)(S.ph_cuid + j0) = make_uint4(cu[0], cu[1], cu[2], cu[3]);
+    } else {
+        for (int u = 0; u < 4; ++u) if (j0 + u < nph) { keep[j0 + u] = (unsigned char)((kb >> (8 * u)) & 0xFFu); if (wr) S.ph_cuid[j0 + u] = cu[u]; }
+    }
+    if (lane == 0) blk_count[sb] = cnt;
 }
-__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def) { upd_flag_body(S, nph, keep, blk_count, def); }
-__global__ __launch_bounds__(UPD_NT) void k_upd_flag_many(const PcManyRec *R, int def) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; upd_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], def); }
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def, int nblk) { upd_flag_body(S, nph, keep, blk_count, def, nblk); }
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag_many(const PcManyRec *R, int def) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x * 4 >= r.ia[2]) return; upd_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], def, r.ia[2]); }
 
 
 // exclusive scan of the block counts in place, one workgroup, 4096 counts at a time (four per thread, coalesced)
@@ -143,26 +166,44 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_index(int nph, const unsigned ch
 // the counts of the blocks before it, which 256 threads add up from L2 in about a microsecond (at 3750 blocks: 7 M loads on the
 // whole chip) -- less than the one-workgroup scan kernel and the launch boundary behind it (4.7 + 3.5 us per update)
 #define UPD_SELF_BLOCKS 4096
+// (sixteen wavefronts a workgroup, a block of 256 rows each, four rows a lane: the counts before the workgroup's first block are
+//  added up once for sixteen blocks -- with 2500 blocks a run and sixteen runs in step the sums were the kernel's time)
+#define UPD_IDX_NT 1024
 __device__ __forceinline__ void upd_index_self_body(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total)
 {
-    __shared__ int cnt[4], part[4];
+    __shared__ int part[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j = blockIdx.x * UPD_ROWS + tid;
-    const bool km = j < nph && (keep[j] & 2);
-    const unsigned long long m = __ballot(km);
+    const int sb0 = blockIdx.x * 16, sb = sb0 + wv;
     int s = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += UPD_NT) s += blk_count[b];
+    for (int b = tid; b < sb0; b += UPD_IDX_NT) s += blk_count[b];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) { cnt[wv] = __popcll(m); part[wv] = s; }
+    if (lane == 0) part[wv] = s;
     __syncthreads();
-    int off = (part[0] + part[1]) + (part[2] + part[3]);
-    if ((int)blockIdx.x == nblk - 1 && tid == 0) *total = off + (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
-    for (int x = 0; x < wv; ++x) off += cnt[x];
-    if (km) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    if (sb >= nblk) return;
+    int off = 0;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) off += part[x];
+    for (int x = sb0; x < sb; ++x) off += blk_count[x];
+    const int j0 = sb * UPD_ROWS + 4 * lane;
+    unsigned w = 0;
+    if (j0 + 3 < nph) w = *(const unsigned *)(keep + j0);
+    else for (int u = 0; u < 4; ++u) if (j0 + u < nph) w |= (unsigned)keep[j0 + u] << (8 * u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int pos = off, all = 0;
+    bool f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        f[u] = (w >> (8 * u + 1)) & 1u;
+        const unsigned long long m = __ballot(f[u]);
+        pos += __popcll(m & below); all += __popcll(m);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (f[u]) { idx[pos] = j0 + u; pos++; }
+    if (sb == nblk - 1 && lane == 0) *total = off + all;
 }
-__global__ __launch_bounds__(UPD_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total) { upd_index_self_body(nph, keep, blk_count, nblk, idx, total); }
-__global__ __launch_bounds__(UPD_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
+__global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total) { upd_index_self_body(nph, keep, blk_count, nblk, idx, total); }
+__global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x * 16 >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
 
 
 // sixteen rows given by index, coordinates minus shift and a one, to consecutive tile rows; lane = element, the loads of
@@ -593,10 +634,10 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     double *part2 = part + (size_t)G * E;
     size_t shw = sizeof(double) * ((size_t)CAPv * TSv + D);
     if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);      // the waves' result tiles reuse the row tile
-    hipLaunchKernelGGL(k_upd_flag, dim3(nblk), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred);
+    hipLaunchKernelGGL(k_upd_flag, dim3((nblk + 3) / 4), dim3(UPD_NT), 0, st, *S, nph, keep, blk, deferred, nblk);
     if (!S->pool) pc_launch_scan_blocks(blk, nblk, d_total, &S->ctl->nphantom, st);
     else if (nblk <= UPD_SELF_BLOCKS && !std::getenv("PC_UPD_SCAN_LAUNCH"))
-        hipLaunchKernelGGL(k_upd_index_self, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, nblk, (int *)phC2, d_total);
+        hipLaunchKernelGGL(k_upd_index_self, dim3((nblk + 15) / 16), dim3(UPD_IDX_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, nblk, (int *)phC2, d_total);
     else {
         hipLaunchKernelGGL(k_upd_scan, dim3(1), dim3(1024), 0, st, blk, nblk, d_total);
         hipLaunchKernelGGL(k_upd_index, dim3(nblk), dim3(UPD_NT), 0, st, nph, (const unsigned char *)keep, (const int *)blk, (int *)phC2);
@@ -639,8 +680,8 @@ extern "C" int pc_launch_update_fused_many(const PcState *S, const PcManyRec *dR
     const int ng = (G + UPD_FOLD - 1) / UPD_FOLD;
     size_t shw = sizeof(double) * ((size_t)CAPv * TSv + D);
     if (NTv <= 2 && shw < sizeof(double) * (size_t)(4 * 3 * 256)) shw = sizeof(double) * (size_t)(4 * 3 * 256);
-    hipLaunchKernelGGL(k_upd_flag_many, dim3(nblk_max, R), dim3(UPD_NT), 0, st, dR, deferred);
-    hipLaunchKernelGGL(k_upd_index_self_many, dim3(nblk_max, R), dim3(UPD_NT), 0, st, dR);
+    hipLaunchKernelGGL(k_upd_flag_many, dim3((nblk_max + 3) / 4, R), dim3(UPD_NT), 0, st, dR, deferred);
+    hipLaunchKernelGGL(k_upd_index_self_many, dim3((nblk_max + 15) / 16, R), dim3(UPD_IDX_NT), 0, st, dR);
     int devi = 0; (void)hipGetDevice(&devi); devi &= 63;
 #define UPDM_LAUNCH(NT) { \
         static std::atomic<size_t> donem_##NT[64]; \
