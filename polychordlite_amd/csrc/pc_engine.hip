@@ -579,6 +579,17 @@ struct Engine {
         phU2 = dalloc<unsigned long long>(Pcap); keep = dalloc<unsigned char>(Pcap); blk = dalloc<int>((Pcap + 255) / 256 + 1);
     }
 
+    // a small table of the set-up on its way to the device: through a pinned block of the cache, in stream order (a blocking copy
+    // from pageable memory was 0.1 ms as a rule and 4 ... 11 ms now and then -- one run in eight or so -- while the driver pinned
+    // the vector's pages); the blocks go back at the teardown
+    std::vector<void *> setup_staged;
+    void upload(void *dst, const void *src, size_t bytes)
+    {
+        void *h = halloc<char>(bytes);
+        setup_staged.push_back(h);
+        std::memcpy(h, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st));
+    }
     void setup(const pchip_settings &c, const pchip_like &like, const pchip_prior &prior)
     {
         cfg = c;
@@ -649,8 +660,8 @@ struct Engine {
         S.n_nlives = c.n_nlives;
         if (c.n_nlives > 0) {
             d_dynL = dalloc<double>(c.n_nlives); d_dynN = dalloc<int>(c.n_nlives);
-            HIPCHK(hipMemcpy(d_dynL, c.loglikes, sizeof(double) * c.n_nlives, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_dynN, c.nlives, sizeof(int) * c.n_nlives, hipMemcpyHostToDevice));
+            upload(d_dynL, c.loglikes, sizeof(double) * c.n_nlives);
+            upload(d_dynN, c.nlives, sizeof(int) * c.n_nlives);
         }
         S.dyn_loglikes = d_dynL; S.dyn_nlives = d_dynN;
         // likelihood / prior
@@ -663,8 +674,8 @@ struct Engine {
             std::vector<double> T((size_t)D * D);
             for (int a = 0; a < D; ++a) for (int b = 0; b < D; ++b) T[(size_t)b * D + a] = like.invcov[(size_t)a * D + b];
             d_invcovT = dalloc<double>((size_t)D * D); d_mean = dalloc<double>(D);
-            HIPCHK(hipMemcpy(d_invcovT, T.data(), sizeof(double) * D * D, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_mean, like.mean, sizeof(double) * D, hipMemcpyHostToDevice));
+            upload(d_invcovT, T.data(), sizeof(double) * D * D);
+            upload(d_mean, like.mean, sizeof(double) * D);
             S.like.invcov = d_invcovT; S.like.mean = d_mean;
         }
         callback_mode = (like.kind == PC_LIKE_CALLBACK) || (prior.kind != 1);
@@ -675,8 +686,8 @@ struct Engine {
         S.prior.kind = prior.kind; S.prior.lo = nullptr; S.prior.hi = nullptr;
         if (prior.kind == 1 && prior.lo && prior.hi) {
             d_lo = dalloc<double>(D); d_hi = dalloc<double>(D);
-            HIPCHK(hipMemcpy(d_lo, prior.lo, sizeof(double) * D, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_hi, prior.hi, sizeof(double) * D, hipMemcpyHostToDevice));
+            upload(d_lo, prior.lo, sizeof(double) * D);
+            upload(d_hi, prior.hi, sizeof(double) * D);
             S.prior.lo = d_lo; S.prior.hi = d_hi;
         }
         // state arrays
@@ -706,7 +717,7 @@ struct Engine {
             ln[0] = -PC_HUGE;
             for (int k = 1; k < Ncap + 4; ++k) ln[k] = std::log((double)k);
             d_logn = dalloc<double>(ln.size());
-            HIPCHK(hipMemcpy(d_logn, ln.data(), sizeof(double) * ln.size(), hipMemcpyHostToDevice));
+            upload(d_logn, ln.data(), sizeof(double) * ln.size());
             S.logn = d_logn;
         }
         S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_valid = 0;
@@ -2195,6 +2206,8 @@ struct Engine {
         const auto dq1 = std::chrono::steady_clock::now();
         kt.destroy();
         if (h_dead) { hfree(h_dead); h_dead = nullptr; }
+        for (void *h : setup_staged) hfree(h);
+        setup_staged.clear();
         if (h_ctl) hfree(h_ctl); h_ctl = nullptr;
         if (h_note) hfree((void *)h_note); h_note = nullptr;
         if (ev_apply) { hpool().put_sync_event(ev_apply); ev_apply = nullptr; }
@@ -2336,6 +2349,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         const auto T0 = std::chrono::steady_clock::now();
         long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
         int *h_totals = nullptr; size_t totals_cap = 0;
+        double t_setup_only = 0, t_setup_max = 0, t_begin_max = 0;
         struct EndBatch { std::vector<int> fin, rcs; hipEvent_t ev = nullptr, ev2 = nullptr; int dev = 0; std::thread th; };
         std::vector<std::unique_ptr<EndBatch>> endings;
         auto nowc = [] { return std::chrono::steady_clock::now(); };
@@ -2350,7 +2364,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 pchip_settings c = *s; c.seed = seeds[base + k]; c.device = device;
                 const auto b0 = nowc();
                 int rc;
-                try { E[k]->setup(c, *like, *prior); rc = E[k]->begin(); }
+                try { E[k]->setup(c, *like, *prior); const auto b1 = nowc(); t_setup_only += secc(b0, b1); t_setup_max = std::max(t_setup_max, secc(b0, b1)); rc = E[k]->begin(); t_begin_max = std::max(t_begin_max, secc(b1, nowc())); }
                 catch (const EngineError &e) {
                     // no memory for one more run of this size next to the k that are set up: those go in step, the others after them
                     if (e.code != PC_RC_MEMORY || k == 0) throw;
@@ -2458,6 +2472,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
         if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6);
                     std::fprintf(stderr, "polychord_hip dbg cohort: %zu ending batches: events %.2f ms, results %.2f ms, teardown %.2f ms (summed over threads); the block caches hold %.2f GB of device and %.2f GB of pinned memory; teardown: device blocks %.2f, the rest %.2f ms\n", endings.size(), g_dbg_evwait_ns.exchange(0) * 1e-6, g_dbg_endb_ns.exchange(0) * 1e-6, g_dbg_destroy_ns.exchange(0) * 1e-6, dcache().cached / 1073741824.0, hcache().cached / 1073741824.0, g_dbg_d1.exchange(0) * 1e-6, g_dbg_d2.exchange(0) * 1e-6); }
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: setup %.2f ms of setup + begin; the longest setup %.2f ms, the longest begin %.2f ms\n", t_setup_only * 1e3, t_setup_max * 1e3, t_begin_max * 1e3);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
