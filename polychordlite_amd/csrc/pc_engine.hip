@@ -2349,7 +2349,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         const auto T0 = std::chrono::steady_clock::now();
         long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
         int *h_totals = nullptr; size_t totals_cap = 0;
-        double t_setup_only = 0, t_setup_max = 0, t_begin_max = 0;
+        double t_setup_max = 0;
         struct EndBatch { std::vector<int> fin, rcs; hipEvent_t ev = nullptr, ev2 = nullptr; int dev = 0; std::thread th; };
         std::vector<std::unique_ptr<EndBatch>> endings;
         auto nowc = [] { return std::chrono::steady_clock::now(); };
@@ -2359,24 +2359,50 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
             E[k]->destroy(); delete E[k]; E[k] = nullptr; live[k] = 0;
         };
         try {
-            for (int k = 0; k < n; ++k) {
-                E[k] = new Engine; E[k]->co = &co;
-                pchip_settings c = *s; c.seed = seeds[base + k]; c.device = device;
+            {
+                // set-up and live points of the runs: the first one by itself (a run that does not fit, or fails, alone is the
+                // call's failure), then the others -- a tenth of a millisecond of host work each, 7 ms of sixty-four runs' 175.
+                // (Shared out among four threads it was TWICE as long -- 13 ms -- the runtime's calls queue for one another:
+                //  PC_COHORT_SETUP_THREADS, one by default)
+                std::vector<int> rc_begin((size_t)n, -1), err((size_t)n, 0);
+                std::vector<std::string> errmsg((size_t)n);
+                std::atomic<bool> failed{false};
+                int devnow = 0; (void)hipGetDevice(&devnow);
+                auto setup_one = [&](int k) {
+                    E[k] = new Engine; E[k]->co = &co;
+                    pchip_settings c = *s; c.seed = seeds[base + k]; c.device = device;
+                    const auto q0 = nowc();
+                    try { E[k]->setup(c, *like, *prior); rc_begin[k] = E[k]->begin(); }
+                    catch (const EngineError &e) { err[k] = e.code ? e.code : PC_RC_DEVICE; errmsg[k] = e.msg; failed = true; }
+                    catch (const std::bad_alloc &) { err[k] = PC_RC_MEMORY; errmsg[k] = "out of host memory"; failed = true; }
+                    if (k == 0) t_setup_max = secc(q0, nowc());
+                };
                 const auto b0 = nowc();
-                int rc;
-                try { E[k]->setup(c, *like, *prior); const auto b1 = nowc(); t_setup_only += secc(b0, b1); t_setup_max = std::max(t_setup_max, secc(b0, b1)); rc = E[k]->begin(); t_begin_max = std::max(t_begin_max, secc(b1, nowc())); }
-                catch (const EngineError &e) {
+                setup_one(0);
+                static const int setup_threads = std::getenv("PC_COHORT_SETUP_THREADS") ? std::max(1, std::atoi(std::getenv("PC_COHORT_SETUP_THREADS"))) : 1;
+                if (n > 1 && !failed) {
+                    std::atomic<int> nextk{1};
+                    auto worker = [&] { (void)hipSetDevice(devnow); for (int k; !failed && (k = nextk.fetch_add(1)) < n;) setup_one(k); };
+                    std::vector<std::thread> th;
+                    for (int t = 1; t < std::min(setup_threads, n - 1) && n >= 8; ++t) th.emplace_back(worker);
+                    worker();
+                    for (auto &t : th) t.join();
+                }
+                t_begin += secc(b0, nowc());
+                for (int k = 0; k < n; ++k) {
+                    if (!err[k] && E[k]) continue;
+                    if (err[k] && (err[k] != PC_RC_MEMORY || k == 0)) throw EngineError{err[k], errmsg[k]};
                     // no memory for one more run of this size next to the k that are set up: those go in step, the others after them
-                    if (e.code != PC_RC_MEMORY || k == 0) throw;
                     (void)hipGetLastError();
-                    try { E[k]->destroy(); } catch (...) {}
-                    delete E[k]; E[k] = nullptr;
+                    for (int j = k; j < n; ++j) if (E[j]) { try { E[j]->destroy(); } catch (...) {} delete E[j]; E[j] = nullptr; }
                     n = k;
                     break;
                 }
-                t_begin += secc(b0, nowc());
-                if (rc >= 0) { close(k, rc ? rc : PC_RC_DEVICE); continue; }
-                live[k] = 1;
+                for (int k = 0; k < n; ++k) {
+                    const int rc = rc_begin[k];
+                    if (rc >= 0) { close(k, rc ? rc : PC_RC_DEVICE); continue; }
+                    live[k] = 1;
+                }
             }
             int nlive = 0;
             for (int k = 0; k < n; ++k) nlive += live[k];
@@ -2472,7 +2498,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         for (int k = 0; k < n; ++k) if (E[k]) { pchip_result_free(&results[base + k]); try { E[k]->destroy(); } catch (...) {} delete E[k]; E[k] = nullptr; }
         if (prof) { std::fprintf(stderr, "polychord_hip dbg cohort: of enqueue: nursery %.2f ms (compaction %.2f), capacity %.2f\n", g_dbg_nursery_ns.exchange(0) * 1e-6, g_dbg_compact_ns.exchange(0) * 1e-6, g_dbg_capacity_ns.exchange(0) * 1e-6);
                     std::fprintf(stderr, "polychord_hip dbg cohort: %zu ending batches: events %.2f ms, results %.2f ms, teardown %.2f ms (summed over threads); the block caches hold %.2f GB of device and %.2f GB of pinned memory; teardown: device blocks %.2f, the rest %.2f ms\n", endings.size(), g_dbg_evwait_ns.exchange(0) * 1e-6, g_dbg_endb_ns.exchange(0) * 1e-6, g_dbg_destroy_ns.exchange(0) * 1e-6, dcache().cached / 1073741824.0, hcache().cached / 1073741824.0, g_dbg_d1.exchange(0) * 1e-6, g_dbg_d2.exchange(0) * 1e-6); }
-        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: setup %.2f ms of setup + begin; the longest setup %.2f ms, the longest begin %.2f ms\n", t_setup_only * 1e3, t_setup_max * 1e3, t_begin_max * 1e3);
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: the first run's set-up and live points %.2f ms\n", t_setup_max * 1e3);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
