@@ -398,7 +398,7 @@ def main():
                 held = None
                 samples.append(mc)
             vals = sorted(m["nlike"] / m["t_runs_s"] for m in samples)
-            mc = samples[-1]
+            mc = sorted(samples, key=lambda m: m["nlike"] / m["t_runs_s"])[1]      # the median sample: wall_ms, per_run_ms and value belong together
             conc.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": vals[1], "value_min": vals[0], "value_max": vals[2], "samples": 3,
                          "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
                          "per_run_ms": mc["t_runs_s"] * 1e3 / R,
