@@ -2233,9 +2233,16 @@ void polychord_hip_request_stop(void) { std::lock_guard<std::mutex> g(g_run_mute
 // tests of the error paths: the next run fails once at the chosen point (1: a device allocation, 2: the cluster
 // capacity at the next split, 3: the phantom array at its next growth); 0 disarms
 void pchip_inject_fault(int kind) { g_inject_fault = kind; }
+// the block caches for the library's other files (the merge's scratch and its rows): null when there is no memory.  The merge
+// took its scratch from the driver and gave it back at its end: the driver then works the frees off for 10 ... 30 ms, and the
+// next call's first wait for the device -- if it came at once -- sat behind that
+void *pc_cache_dev_alloc(size_t bytes) { try { return dcache().get(bytes); } catch (const EngineError &) { (void)hipGetLastError(); return nullptr; } }
+void pc_cache_dev_free(void *p) { if (p && !dcache().put(p)) (void)hipFree(p); }
+void *pc_cache_host_alloc(size_t bytes) { try { return hcache().get(bytes); } catch (const EngineError &) { (void)hipGetLastError(); return nullptr; } }
+void pc_cache_host_free(void *p) { if (p && !hcache().put(p)) (void)hipHostFree(p); }
+void pchip_trim_cache(void) { (void)hipDeviceSynchronize(); dcache().trim(); hcache().trim(); }      // the blocks finished runs left for the next ones go back to the driver
 // initial capacity of the per-cluster arrays (default 128) and of the phantom array in rows (0 = the engine's estimate);
 // both grow on demand, so these only matter to tests of the growth paths
-void pchip_trim_cache(void) { (void)hipDeviceSynchronize(); dcache().trim(); hcache().trim(); }      // the blocks finished runs left for the next ones go back to the driver
 void pchip_set_capacity(int clusters, int phantom_rows) { if (clusters > 0) g_cap_clusters = clusters; if (phantom_rows >= 0) g_cap_phantoms = phantom_rows; }   // negative: leave as is
 void polychord_hip_set_batch_callback(polychord_batch_fn fn, void *user) { std::lock_guard<std::mutex> g(g_cb_mutex); g_batch_fn = fn; g_batch_user = user; }
 
@@ -2340,7 +2347,22 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         // (a main stream whose hardware queue is known already, if the pool has one: the side stream is then picked without a test --
         //  a test is a millisecond, several once PyTorch lives in the process, and the pool's first stream was a different one of
         //  the engines' copy streams at every call)
-        if (prio_off || plo == phi) { co.st = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) >= 0; }); if (!co.st) co.st = hpool().get_stream(); const auto Tp2 = std::chrono::steady_clock::now(); if (!side_off) co.st2 = side_stream_for(co.st);
+        // (and the pair of the call before, if the pool still has it: whatever the runtime sets up for a stream at its first copy or
+        //  launch is then there -- a call's first wait was 10 ... 24 ms now and then while the pair changed from call to call)
+        static std::mutex last_m; static hipStream_t last_st[64] = {nullptr}, last_st2[64] = {nullptr};
+        int devq = 0; (void)hipGetDevice(&devq); devq &= 63;
+        if (prio_off || plo == phi) {
+            hipStream_t want, want2;
+            { std::lock_guard<std::mutex> g(last_m); want = last_st[devq]; want2 = last_st2[devq]; }
+            if (want) co.st = hpool().take_stream_if([&](hipStream_t x) { return x == want; });
+            if (!co.st) co.st = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) >= 0; });
+            if (!co.st) co.st = hpool().get_stream();
+            const auto Tp2 = std::chrono::steady_clock::now();
+            if (!side_off) {
+                if (co.st == want && want2) co.st2 = hpool().take_stream_if([&](hipStream_t x) { return x == want2; });
+                if (!co.st2) co.st2 = side_stream_for(co.st);
+            }
+            { std::lock_guard<std::mutex> g(last_m); last_st[devq] = co.st; last_st2[devq] = co.st2; }
             if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
         if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }

@@ -428,10 +428,15 @@ struct Rccl {
 };
 Rccl &rccl() { static Rccl *r = new Rccl; return *r; }
 
+// (device scratch and the merged rows come from the engine's block caches, pc_engine.hip)
+extern "C" void *pc_cache_dev_alloc(size_t bytes);
+extern "C" void pc_cache_dev_free(void *p);
+extern "C" void *pc_cache_host_alloc(size_t bytes);
+extern "C" void pc_cache_host_free(void *p);
 struct DevBuf {
     std::vector<void *> v;
-    template <class T> T *get(size_t n) { void *p = nullptr; if (hipMalloc(&p, sizeof(T) * (n ? n : 1)) != hipSuccess) { (void)hipGetLastError(); return nullptr; } v.push_back(p); return (T *)p; }
-    ~DevBuf() { for (void *p : v) (void)hipFree(p); }
+    template <class T> T *get(size_t n) { void *p = pc_cache_dev_alloc(sizeof(T) * (n ? n : 1)); if (!p) return nullptr; v.push_back(p); return (T *)p; }
+    ~DevBuf() { for (void *p : v) pc_cache_dev_free(p); }
 };
 
 // two steps, because the caller sizes the destination with the counts of ALL runs (or ranks): count() uploads the weights,
@@ -476,8 +481,8 @@ extern "C" {
 void pchip_merged_free(pchip_merged *m)
 {
     if (!m) return;
-    if (m->rows) (void)hipHostFree(m->rows);
-    std::free(m->logweights); std::free(m->nlive); std::free(m->post_mean); std::free(m->post_var);
+    if (m->rows) pc_cache_host_free(m->rows);
+    pc_cache_host_free(m->logweights); pc_cache_host_free(m->nlive); std::free(m->post_mean); std::free(m->post_var);
     std::memset(m, 0, sizeof(*m));
 }
 
@@ -550,14 +555,19 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
         for (int c = 0; c < nP; ++c) { out->post_mean[c] += p[c]; out->post_var[c] += p[nP + c]; }
     }
     for (int c = 0; c < nP; ++c) { out->post_mean[c] /= sw; out->post_var[c] = out->post_var[c] / sw - out->post_mean[c] * out->post_mean[c]; }
-    out->logweights = (double *)std::malloc(sizeof(double) * n); out->nlive = (int *)std::malloc(sizeof(int) * n);
+    // (pinned blocks of the cache: a blocking copy into pageable memory has the driver pin the pages for the copy, and when the caller
+    //  gives the arrays back -- megabytes: unmapped at once -- the kernel driver takes the process's queues off the device and puts
+    //  them back some 20 ms later: the next call's first wait for the device, if it came at once, sat behind that)
+    out->logweights = (double *)pc_cache_host_alloc(sizeof(double) * n); out->nlive = (int *)pc_cache_host_alloc(sizeof(int) * n);
+    if (!out->logweights || !out->nlive) return fail("out of pinned memory");
     (void)hipMemcpy(out->logweights, d_logw, sizeof(double) * n, hipMemcpyDeviceToHost);
     (void)hipMemcpy(out->nlive, M.nl, sizeof(int) * n, hipMemcpyDeviceToHost);
     if (want_rows) {
         double *d_out = B.get<double>((size_t)n * nT);
         if (!d_out) return fail("out of device memory");
         hipLaunchKernelGGL(k_merge_gather, dim3((unsigned)n), dim3(64), 0, st, M, b0, d_out);
-        if (hipHostMalloc((void **)&out->rows, sizeof(double) * (size_t)n * nT) != hipSuccess) return fail("out of pinned memory");
+        out->rows = (double *)pc_cache_host_alloc(sizeof(double) * (size_t)n * nT);
+        if (!out->rows) return fail("out of pinned memory");
         if (hipMemcpy(out->rows, d_out, sizeof(double) * (size_t)n * nT, hipMemcpyDeviceToHost) != hipSuccess) return fail("download");
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail("kernels");
@@ -664,7 +674,7 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
             o += (size_t)J.count;
         }
         for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); if (hipDeviceSynchronize() != hipSuccess) rc = rc ? rc : 2; }
-        for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); std::vector<void *> v; v.swap(scratch[d].v); for (void *p : v) (void)hipFree(p); }
+        for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); std::vector<void *> v; v.swap(scratch[d].v); for (void *p : v) pc_cache_dev_free(p); }
         (void)hipSetDevice(devs[0]);
         if (rc == 0) rc = pchip_merge_records(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, 1, 1, merged);
         else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
