@@ -166,41 +166,47 @@ __global__ __launch_bounds__(UPD_NT) void k_upd_index(int nph, const unsigned ch
 // the counts of the blocks before it, which 256 threads add up from L2 in about a microsecond (at 3750 blocks: 7 M loads on the
 // whole chip) -- less than the one-workgroup scan kernel and the launch boundary behind it (4.7 + 3.5 us per update)
 #define UPD_SELF_BLOCKS 4096
-// (sixteen wavefronts a workgroup, a block of 256 rows each, four rows a lane: the counts before the workgroup's first block are
-//  added up once for sixteen blocks -- with 2500 blocks a run and sixteen runs in step the sums were the kernel's time)
-#define UPD_IDX_NT 1024
+// (a workgroup of four wavefronts takes sixteen blocks of 256 rows, a wavefront four of them one after the other, four rows a lane:
+//  the counts before the workgroup's first block are added up once for sixteen blocks -- with 2500 blocks a run and sixteen runs
+//  in step the sums were the kernel's time.  Sixteen wavefronts a workgroup did the same at sixteen runs and took 457 us at
+//  sixty-four: a workgroup that needs sixteen free slots on one CU waits while the second stream's kernels hold some)
+#define UPD_IDX_NT 256
+#define UPD_IDX_BLOCKS 16
 __device__ __forceinline__ void upd_index_self_body(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total)
 {
-    __shared__ int part[16];
+    __shared__ int part[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int sb0 = blockIdx.x * 16, sb = sb0 + wv;
+    const int sb0 = blockIdx.x * UPD_IDX_BLOCKS;
     int s = 0;
     for (int b = tid; b < sb0; b += UPD_IDX_NT) s += blk_count[b];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) part[wv] = s;
     __syncthreads();
-    if (sb >= nblk) return;
-    int off = 0;
-#pragma unroll
-    for (int x = 0; x < 16; ++x) off += part[x];
-    for (int x = sb0; x < sb; ++x) off += blk_count[x];
-    const int j0 = sb * UPD_ROWS + 4 * lane;
-    unsigned w = 0;
-    if (j0 + 3 < nph) w = *(const unsigned *)(keep + j0);
-    else for (int u = 0; u < 4; ++u) if (j0 + u < nph) w |= (unsigned)keep[j0 + u] << (8 * u);
+    int off = (part[0] + part[1]) + (part[2] + part[3]);
+    const int sbw = sb0 + 4 * wv;                      // this wavefront's four blocks
+    for (int x = sb0; x < sbw && x < nblk; ++x) off += blk_count[x];
     const unsigned long long below = (1ull << lane) - 1ull;
-    int pos = off, all = 0;
-    bool f[4];
+    for (int q = 0; q < 4; ++q) {
+        const int sb = sbw + q;
+        if (sb >= nblk) return;
+        const int j0 = sb * UPD_ROWS + 4 * lane;
+        unsigned w = 0;
+        if (j0 + 3 < nph) w = *(const unsigned *)(keep + j0);
+        else for (int u = 0; u < 4; ++u) if (j0 + u < nph) w |= (unsigned)keep[j0 + u] << (8 * u);
+        int pos = off, all = 0;
+        bool f[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        f[u] = (w >> (8 * u + 1)) & 1u;
-        const unsigned long long m = __ballot(f[u]);
-        pos += __popcll(m & below); all += __popcll(m);
+        for (int u = 0; u < 4; ++u) {
+            f[u] = (w >> (8 * u + 1)) & 1u;
+            const unsigned long long m = __ballot(f[u]);
+            pos += __popcll(m & below); all += __popcll(m);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (f[u]) { idx[pos] = j0 + u; pos++; }
+        off += all;
+        if (sb == nblk - 1 && lane == 0) *total = off;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (f[u]) { idx[pos] = j0 + u; pos++; }
-    if (sb == nblk - 1 && lane == 0) *total = off + all;
 }
 __global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total) { upd_index_self_body(nph, keep, blk_count, nblk, idx, total); }
 __global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x * 16 >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
