@@ -2512,7 +2512,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
             for (auto &eb : endings) {
                 if (eb->th.joinable()) eb->th.join();
                 for (int r : eb->rcs) if (r != 0 && !worst) worst = r;
-                hpool().put_sync_event(eb->ev); if (eb->ev2) hpool().put_sync_event(eb->ev2);
+                if (eb->ev) hpool().put_sync_event(eb->ev); if (eb->ev2) hpool().put_sync_event(eb->ev2);
             }
             t_end += secc(e0, nowc());
         }
