@@ -887,6 +887,7 @@ struct Engine {
     double *babies_own = nullptr;
     // the phantom array is full: the phantoms that are still wanted move to the front of the alternate buffers.  In step with other
     // runs the clean is launched for all of them at once and waited for once (compact_wanted / compact_record / compact_finish)
+    bool compact_worth_it() const { return S.pool && h_ctl->status == PC_ST_RUNNING && h_ctl->i_nursery == 0 && 2 * pool_cursor > (long long)S.Pcap; }      // (next to a run that has to: pc_run_cohort)
     bool compact_wanted() const { return S.pool && h_ctl->status == PC_ST_RUNNING && h_ctl->i_nursery == 0 && pool_cursor + (long long)B * S.nr > S.Pcap; }
     void compact_record() { co->rec(CK_COMPACT, S, {keep, blk, d_total, ph2, phL2, phC2, phU2}, {}, {0, (int)pool_cursor, ((int)pool_cursor + 255) / 256}); }
     void compact_finish(int total)
@@ -2371,7 +2372,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         const auto T0 = std::chrono::steady_clock::now();
         long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
         int *h_totals = nullptr; size_t totals_cap = 0;
-        double t_setup_max = 0;
+        double t_setup_max = 0; int n_comp_pass = 0;
         struct EndBatch { std::vector<int> fin, rcs; hipEvent_t ev = nullptr, ev2 = nullptr; int dev = 0; std::thread th; };
         std::vector<std::unique_ptr<EndBatch>> endings;
         auto nowc = [] { return std::chrono::steady_clock::now(); };
@@ -2429,17 +2430,22 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
             int nlive = 0;
             for (int k = 0; k < n; ++k) nlive += live[k];
             while (nlive > 0 && !worst) {
-                {   // phantom arrays that are full: compacted together, one wait for all
+                {   // phantom arrays that are full: compacted together, one wait for all -- and with them the arrays that are more
+                    // than half full: the runs fill theirs at slightly different rates, and a pass of their own (a wait of the
+                    // whole cohort) a round or two later costs more than moving their rows early
                     int nc = 0;
-                    for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) { E[k]->compact_record(); nc++; }
+                    for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) nc++;
                     if (nc) {
                         const auto c0 = nowc();
+                        static const bool align_off = std::getenv("PC_COHORT_COMPACT_ALIGN") && std::atoi(std::getenv("PC_COHORT_COMPACT_ALIGN")) == 0;
+                        std::vector<char> cmp((size_t)n, 0);
+                        for (int k = 0; k < n; ++k) if (live[k] && (E[k]->compact_wanted() || (!align_off && E[k]->compact_worth_it()))) { cmp[k] = 1; E[k]->compact_record(); }
                         co.flush();
                         if ((size_t)n > totals_cap) { if (h_totals) hfree(h_totals); h_totals = halloc<int>((size_t)n); totals_cap = (size_t)n; }
-                        for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) HIPCHK(hipMemcpyAsync(&h_totals[k], E[k]->d_total, sizeof(int), hipMemcpyDeviceToHost, co.st));
+                        for (int k = 0; k < n; ++k) if (cmp[k]) HIPCHK(hipMemcpyAsync(&h_totals[k], E[k]->d_total, sizeof(int), hipMemcpyDeviceToHost, co.st));
                         HIPCHK(hipStreamSynchronize(co.st));
-                        for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) E[k]->compact_finish(h_totals[k]);
-                        t_comp += secc(c0, nowc());
+                        for (int k = 0; k < n; ++k) if (cmp[k]) E[k]->compact_finish(h_totals[k]);
+                        t_comp += secc(c0, nowc()); n_comp_pass++;
                     }
                 }
                 { const auto a0 = nowc(); for (int k = 0; k < n; ++k) enq[k] = (live[k] && E[k]->round_enqueue()) ? 1 : 0; const auto a1 = nowc(); t_enq += secc(a0, a1);
@@ -2522,8 +2528,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                     std::fprintf(stderr, "polychord_hip dbg cohort: %zu ending batches: events %.2f ms, results %.2f ms, teardown %.2f ms (summed over threads); the block caches hold %.2f GB of device and %.2f GB of pinned memory; teardown: device blocks %.2f, the rest %.2f ms\n", endings.size(), g_dbg_evwait_ns.exchange(0) * 1e-6, g_dbg_endb_ns.exchange(0) * 1e-6, g_dbg_destroy_ns.exchange(0) * 1e-6, dcache().cached / 1073741824.0, hcache().cached / 1073741824.0, g_dbg_d1.exchange(0) * 1e-6, g_dbg_d2.exchange(0) * 1e-6); }
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: the first run's set-up and live points %.2f ms\n", t_setup_max * 1e3);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
-        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
-                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f in %d passes, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
+                               std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, n_comp_pass, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
         co.destroy();
         if (h_totals) hfree(h_totals);
         (void)hipStreamSynchronize(co.st);

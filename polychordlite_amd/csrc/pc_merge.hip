@@ -433,6 +433,15 @@ extern "C" void *pc_cache_dev_alloc(size_t bytes);
 extern "C" void pc_cache_dev_free(void *p);
 extern "C" void *pc_cache_host_alloc(size_t bytes);
 extern "C" void pc_cache_host_free(void *p);
+// host side of a blocking copy: a pinned block of the cache (see pchip_merge_records on why not a vector)
+template <class T> struct PinBuf {
+    T *p; size_t n;
+    explicit PinBuf(size_t n_) : p((T *)pc_cache_host_alloc(sizeof(T) * (n_ ? n_ : 1))), n(n_) {}
+    ~PinBuf() { pc_cache_host_free(p); }
+    PinBuf(const PinBuf &) = delete; PinBuf &operator=(const PinBuf &) = delete;
+    T *data() { return p; } size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+};
 struct DevBuf {
     std::vector<void *> v;
     template <class T> T *get(size_t n) { void *p = pc_cache_dev_alloc(sizeof(T) * (n ? n : 1)); if (!p) return nullptr; v.push_back(p); return (T *)p; }
@@ -537,7 +546,8 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
     hipLaunchKernelGGL(k_merge_t, dim3(nb256), dim3(256), 0, st, (const int *)M.nl, (const double *)M.Ls, (const P2 *)X, n, T);
     device_scan<OpLse>(T, n, tot, st);
     hipLaunchKernelGGL(k_merge_terms, dim3(nbt), dim3(1024), 0, st, (const int *)M.nl, (const double *)M.Ls, (const P2 *)X, (const P2 *)T, n, d_logw, pA, pB, pM);
-    std::vector<P2> hA(nbt), hB(nbt); std::vector<double> hM(nbt);
+    PinBuf<P2> hA(nbt), hB(nbt); PinBuf<double> hM(nbt);
+    if (!hA.p || !hB.p || !hM.p) return fail("out of pinned memory");
     if (hipMemcpy(hA.data(), pA, sizeof(P2) * nbt, hipMemcpyDeviceToHost) != hipSuccess) return fail("evidence kernels");
     (void)hipMemcpy(hB.data(), pB, sizeof(P2) * nbt, hipMemcpyDeviceToHost); (void)hipMemcpy(hM.data(), pM, sizeof(double) * nbt, hipMemcpyDeviceToHost);
     auto comb = [](P2 x, P2 y) { const double e = std::exp(-std::fabs(x.a - y.a)); return P2{std::max(x.a, y.a), x.a >= y.a ? x.b + y.b * e : x.b * e + y.b}; };
@@ -546,7 +556,8 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
     const double lZ = a.a + std::log(a.b), lZ2 = b.a + std::log(b.b);       // log <Z>, log <Z^2>
     out->logZ = 2.0 * lZ - 0.5 * lZ2; out->varlogZ = lZ2 - 2.0 * lZ;       // run_time_info.f90:652-678
     hipLaunchKernelGGL(k_merge_moments, dim3(nbm), dim3(256), 0, st, M, (const double *)d_logw, wmax, p0, nP, pmom);
-    std::vector<double> hm((size_t)nbm * (2 * nP + 1));
+    PinBuf<double> hm((size_t)nbm * (2 * nP + 1));
+    if (!hm.p) return fail("out of pinned memory");
     if (hipMemcpy(hm.data(), pmom, sizeof(double) * hm.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail("moment kernel");
     double sw = 0.0;
     for (int k = 0; k < nbm; ++k) {
