@@ -306,7 +306,8 @@ def test_lived_records_follow_the_runs_logzero(engine):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,nDer,nlive,nr,clus,box", [("gaussian", 20, 2, 400, 20, 0, None), ("gaussian", 7, 1, 300, 14, 0, (-0.25, 1.5)),
-                                                            ("rastrigin", 3, 0, 200, 9, 1, (-5.12, 5.12)), ("twin_gaussian", 6, 1, 250, 12, 0, (-1.0, 1.0))])
+                                                            ("rastrigin", 3, 0, 200, 9, 1, (-5.12, 5.12)), ("twin_gaussian", 6, 1, 250, 12, 0, (-1.0, 1.0)),
+                                                            ("gaussian", 24, 0, 256, 24, 0, None), ("gaussian", 3, 4, 200, 6, 0, (0.1, 0.9))])
 def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus, box):
     """pchip_run_repeats with all runs of the device in flight: they go round by round together on one stream, every kernel of a
     round launched once for all of them (Gaussian: the lane-per-chain kernels, fused update, pool compaction for all at once;
