@@ -998,12 +998,16 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
 // if the point that died at its step was a newcomer of this launch, that baby's row; the rows of snapshot points that died
 // are moved out by the workgroup of their SLOT (k_consume_par left the killer's chain in slot_dead) just before the slot's
 // new occupant moves in -- the one place where the order of the two copies matters.
+// (four wavefronts a workgroup, a chain or a slot each: with one wavefront a workgroup the launch was as long as the dispatcher
+//  took to hand 3000 workgroups out -- 192 k of them for sixty-four runs in step, 122 us)
 __device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch, int nchains)
 {
     const PcCtl *ctl = S.ctl;
-    const int lane = threadIdx.x, nT = S.nT, nr = S.nr;
-    if ((int)blockIdx.x < nchains) {
-        const int w = ctl->seg_lo + blockIdx.x;
+    const int lane = threadIdx.x & 63, nT = S.nT, nr = S.nr;
+    const int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (item >= nchains + S.Ncap) return;
+    if (item < nchains) {
+        const int w = ctl->seg_lo + item;
         if (w > ctl->seg_hi) return;
         const int di = S.plan[w].dead_idx, src = S.plan[w].dead_src;
         if (di >= 0 && src < 0) {
@@ -1025,7 +1029,7 @@ __device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch
         }
         return;
     }
-    const int slot = blockIdx.x - nchains;
+    const int slot = item - nchains;
     const int src = S.slot_src[slot], killer = S.slot_dead[slot];
     if (src < 0 && killer < 0) return;
     double *lrow = S.live + (size_t)slot * nT;
@@ -1047,11 +1051,11 @@ __device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (lane + 64 * q < nT) lrow[lane + 64 * q] = v[q];
     }
-    __syncthreads();
+    // (a lane's copies are in program order, and the slot's records below are its wavefront's alone: no barrier)
     if (lane == 0) { S.slot_src[slot] = -1; S.slot_dead[slot] = -1; if (src >= 0) S.live_entry[slot] = S.plan[src].contour; }
 }
-__global__ __launch_bounds__(64) void k_apply_pool(PcState S, unsigned batch, int nchains) { apply_pool_body(S, batch, nchains); }
-__global__ __launch_bounds__(64) void k_apply_pool_many(const PcManyRec *R, int nchains) { apply_pool_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains); }
+__global__ __launch_bounds__(256) void k_apply_pool(PcState S, unsigned batch, int nchains) { apply_pool_body(S, batch, nchains); }
+__global__ __launch_bounds__(256) void k_apply_pool_many(const PcManyRec *R, int nchains) { apply_pool_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains); }
 
 
 // new live rows: every slot now owned by a chain's last baby
@@ -1722,7 +1726,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
 
 extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
-    if (S->pool) { hipLaunchKernelGGL(k_apply_pool, dim3(nchains + S->Ncap), dim3(64), 0, st, *S, batch, nchains); return; }
+    if (S->pool) { hipLaunchKernelGGL(k_apply_pool, dim3((nchains + S->Ncap + 3) / 4), dim3(256), 0, st, *S, batch, nchains); return; }
     hipLaunchKernelGGL(k_apply_dead_ph, dim3(nchains), dim3(64 * PC_APPLY_WAVES), 0, st, *S, batch);
     hipLaunchKernelGGL(k_apply_live, dim3(S->Ncap), dim3(64), 0, st, *S);
 }
@@ -1730,7 +1734,7 @@ extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, h
 extern "C" int pc_launch_apply_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
     if (!S->pool) return 1;
-    hipLaunchKernelGGL(k_apply_pool_many, dim3(nchains + S->Ncap, R), dim3(64), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
+    hipLaunchKernelGGL(k_apply_pool_many, dim3((nchains + S->Ncap + 3) / 4, R), dim3(256), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
     return 0;
 }
 
