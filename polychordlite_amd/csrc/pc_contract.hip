@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch
 {
     const PcCtl *ctl = S.ctl;
     const int lane = threadIdx.x & 63, nT = S.nT, nr = S.nr;
-    const int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int item = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (item >= nchains + S.Ncap) return;
     if (item < nchains) {
         const int w = ctl->seg_lo + item;
@@ -1734,7 +1734,8 @@ extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, h
 extern "C" int pc_launch_apply_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
     if (!S->pool) return 1;
-    hipLaunchKernelGGL(k_apply_pool_many, dim3((nchains + S->Ncap + 3) / 4, R), dim3(256), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
+    static const int wpg = std::getenv("PC_APPLY_WAVES") ? std::max(1, std::min(4, std::atoi(std::getenv("PC_APPLY_WAVES")))) : 4;
+    hipLaunchKernelGGL(k_apply_pool_many, dim3((nchains + S->Ncap + wpg - 1) / wpg, R), dim3(64 * wpg), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
     return 0;
 }
 
