@@ -1471,7 +1471,7 @@ struct Engine {
         const int nprior = cfg.nprior <= 0 ? cfg.nlive : cfg.nprior, nT = S.nT;
         double *rows = dalloc<double>((size_t)nprior * nT), *rl = dalloc<double>(nprior);
         std::vector<double> keep_rows; keep_rows.reserve((size_t)nprior * nT);
-        std::vector<double> hrows((size_t)nprior * nT), hl(nprior);
+        std::vector<double> hrows, hl(nprior);        // (hrows: only when a prior sample was not valid -- 736 KB zeroed for nothing was a third of a run's set-up)
         int have = 0, attempt0 = 0, last_attempt = -1;
         long long nlike = 0;
         bool direct = true;
@@ -1483,6 +1483,7 @@ struct Engine {
             for (int i = 0; i < nprior; ++i) nvalid += hl[i] > cfg.logzero;
             if (nvalid == nprior && have == 0) { have = nprior; nlike = nprior; last_attempt = nprior - 1; break; }   // common case: all valid
             direct = false;
+            hrows.resize((size_t)nprior * nT);
             HIPCHK(hipMemcpy(hrows.data(), rows, sizeof(double) * (size_t)nprior * nT, hipMemcpyDeviceToHost));
             for (int i = 0; i < nprior && have < nprior; ++i)
                 if (hl[i] > cfg.logzero) { keep_rows.insert(keep_rows.end(), hrows.begin() + (size_t)i * nT, hrows.begin() + (size_t)(i + 1) * nT); have++; nlike++; last_attempt = attempt0 + i; }
