@@ -2431,14 +2431,16 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
             int nlive = 0;
             for (int k = 0; k < n; ++k) nlive += live[k];
             while (nlive > 0 && !worst) {
-                {   // phantom arrays that are full: compacted together, one wait for all -- and with them the arrays that are more
-                    // than half full: the runs fill theirs at slightly different rates, and a pass of their own (a wait of the
-                    // whole cohort) a round or two later costs more than moving their rows early
+                {   // phantom arrays that are full: compacted together, one wait for all.  (Only the full ones: taking the arrays
+                    // that are more than half full along -- the runs fill theirs at slightly different rates, and a pass a round
+                    // later is another wait of the whole cohort -- kept the passes at three a call, and changed the last bits of
+                    // some runs: the update's partial sums are grouped by the array's extent, so a run must compact exactly
+                    // when it would alone.  tools/dev/fuzz_in_step.py found it; PC_COHORT_COMPACT_ALIGN=1 brings it back)
                     int nc = 0;
                     for (int k = 0; k < n; ++k) if (live[k] && E[k]->compact_wanted()) nc++;
                     if (nc) {
                         const auto c0 = nowc();
-                        static const bool align_off = std::getenv("PC_COHORT_COMPACT_ALIGN") && std::atoi(std::getenv("PC_COHORT_COMPACT_ALIGN")) == 0;
+                        static const bool align_off = !(std::getenv("PC_COHORT_COMPACT_ALIGN") && std::atoi(std::getenv("PC_COHORT_COMPACT_ALIGN")) == 1);
                         std::vector<char> cmp((size_t)n, 0);
                         for (int k = 0; k < n; ++k) if (live[k] && (E[k]->compact_wanted() || (!align_off && E[k]->compact_worth_it()))) { cmp[k] = 1; E[k]->compact_record(); }
                         co.flush();

@@ -335,6 +335,35 @@ def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", list(range(1, 25)))
+def test_runs_in_step_at_every_width(engine, D):
+    """every compiled width of the lane-per-chain kernels (nDims 1 .. 24) with 0 .. 3 derived parameters, unit and other prior boxes,
+    nurseries that do not fill their last wavefront: five runs in step, each bit for bit the run it is alone.  (These shapes caught a
+    cohort that compacted its phantom arrays a round early: the update's partial sums are grouped by the array's extent.)"""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    nDer = D % 4
+    box = None if D % 2 else (-0.5 + 0.01 * D, 1.25)
+    nlive = 100 + 37 * (D % 5)
+    nr = max(2, 2 * D if D < 8 else D + (D % 3))
+    L, P, keep = api.make_problem("gaussian", D, nDer, *box) if box else api.make_problem("gaussian", D, nDer)
+    def settings(seed):
+        s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+        s.nlive, s.num_repeats, s.seed = nlive, nr, seed
+        return s
+    seeds = [900 + D * 10 + j for j in range(5)]
+    singles = [api.run(settings(sd), L, P) for sd in seeds]
+    merged, runs = run_repeats(settings(0), L, P, seeds, max_in_flight=len(seeds))
+    for one, r in zip(singles, runs):
+        for k in ("ndead", "nlike", "niter", "nupdates", "nbatches"):
+            assert one[k] == r[k], (k, one[k], r[k])
+        assert one["logZ"] == r["logZ"] and one["logZerr"] == r["logZerr"]
+        assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
+        assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_a_failing_run_ends_the_runs_in_step_cleanly(engine):
     """one of several runs in step fails (injected: a device allocation during its setup): pchip_run_repeats reports the failure, gives
     every buffer back, and the next call -- the same seeds -- makes the runs as if nothing had happened"""
