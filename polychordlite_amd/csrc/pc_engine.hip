@@ -406,6 +406,10 @@ struct Cohort {
     hipEvent_t ev[RING] = {}; bool ev_used[RING] = {};
     size_t cap = 0; int ring = 0;
     long n_fused = 0, n_single = 0;
+    // the runs' copies to the host (dead rows, results) share two streams of the cohort, on hardware queues other than the two its
+    // kernels use: a copy stream per run came from the pool, on whatever queue -- and where copies are shader blits (the HIP runtime
+    // PyTorch ships: 48 us each) a round's kernels queued behind them
+    hipStream_t stc[2] = {nullptr, nullptr}; int n_stc = 0;
     void rec(int kind, const PcState &S, std::initializer_list<void *> p, std::initializer_list<long long> a, std::initializer_list<int> ia)
     {
         pend.emplace_back();
@@ -540,6 +544,7 @@ struct Engine {
     PcState S{};
     hipStream_t st = nullptr;
     hipStream_t st_copy = nullptr;            // dead rows leave for the host while the run goes on
+    bool st_copy_shared = false;              // ... one of the cohort's two (not this run's to give back)
     hipStream_t st_side = nullptr;            // the orthonormal bases of the next nursery, while this one is consumed
     hipEvent_t ev_main = nullptr;
     // ring of bases drawn ahead on the side stream: nursery b's live in raw_buf[b % raw_depth]
@@ -601,7 +606,8 @@ struct Engine {
         dev = c.device >= 0 ? c.device % ndev : 0;
         HIPCHK(hipSetDevice(dev));
         st = co ? co->st : hpool().get_stream();
-        st_copy = co ? hpool().get_stream() : stream_beside({st});      // (a run on its own: its copies on another hardware queue than its kernels)
+        st_copy = (co && co->stc[0]) ? co->stc[(co->n_stc++) & 1] : (co ? hpool().get_stream() : stream_beside({st}));      // (a run on its own: its copies on another hardware queue than its kernels)
+        st_copy_shared = co && co->stc[0];
         kt.on = c.profile != 0 && !co; kt.st = st;      // (in step with other runs the launches are made elsewhere: nothing of its own to time)
         kt.mask = (c.profile == 1) ? 0xFFFFFFFFu : (((unsigned)c.profile >> 1) & 0x7Fu);   // 1: every class; else bit k+1 = class k
         kt.stride = std::max(1u, ((unsigned)c.profile >> 8) & 0xFFu);                       // bits 8..15: time every n-th launch of a class
@@ -2215,7 +2221,7 @@ struct Engine {
         if (ev_apply) { hpool().put_sync_event(ev_apply); ev_apply = nullptr; }
 
         if (st) { if (!streams_idle) (void)hipStreamSynchronize(st); if (!co) hpool().put_stream(st); } st = nullptr;
-        if (st_copy) { if (!streams_idle) (void)hipStreamSynchronize(st_copy); hpool().put_stream(st_copy); } st_copy = nullptr;
+        if (st_copy) { if (!streams_idle) (void)hipStreamSynchronize(st_copy); if (!st_copy_shared) hpool().put_stream(st_copy); } st_copy = nullptr;
         if (st_side) {
             if (!streams_idle) (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
             for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_sync_event(ring[r].ready); if (ring[r].consumed) hpool().put_sync_event(ring[r].consumed); ring[r] = RawSlot(); }
@@ -2368,6 +2374,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
             if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
         if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
+        static const bool stc_off = std::getenv("PC_COHORT_COPY_STREAMS") && std::atoi(std::getenv("PC_COHORT_COPY_STREAMS")) == 0;
+        if (!stc_off && !own_streams) { co.stc[0] = stream_beside({co.st, co.st2}); co.stc[1] = stream_beside({co.st, co.st2, co.stc[0]}); }
         std::vector<Engine *> E((size_t)n, nullptr);
         std::vector<char> live((size_t)n, 0), enq((size_t)n, 0);
         const auto T0 = std::chrono::steady_clock::now();
@@ -2538,6 +2546,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         (void)hipStreamSynchronize(co.st);
         if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
         if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
+        for (int q = 0; q < 2; ++q) if (co.stc[q]) { (void)hipStreamSynchronize(co.stc[q]); hpool().put_stream(co.stc[q]); co.stc[q] = nullptr; }
         done_here = n;
     }
     return worst;
