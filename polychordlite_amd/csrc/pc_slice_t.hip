@@ -83,8 +83,8 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
     double *sSpan = sLo + FW;                             // [FW]
     unsigned char *sDeck = (unsigned char *)(sSpan + FW); // [64][nrp] each lane's deck of directions
     double *sRow = (double *)(sDeck + (size_t)64 * nrp);  // [64][nT | 1] the babies' records on their way out (nrp is a multiple of 4, 64 nrp of 8)
-    double *sNh = sRow + (size_t)64 * (nT | 1);           // HELP: [2][64][D + 1] direction and width of the slice to come
-    double *sU = sNh + (size_t)2 * 64 * (D + 1);          // HELP: [2][64][9] its first eight uniforms (odd stride)
+    double *sNh = sRow + (size_t)64 * (nT | 1);           // HELP: [64][D + 1] direction and width of the slice to come
+    double *sU = sNh + (size_t)64 * (D + 1);              // HELP: [64][9] its first eight uniforms (odd stride)
     {
         constexpr TriMap<D> tm{};
         for (int e = tid; e < NP; e += NTH) sL[e] = S.chol[tm.aa[e] * D + tm.bb[e]];      // packed, in the order of use
@@ -229,22 +229,28 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
             //      s - 1 out (their derived parameters first: gaussian.f90:36-37 from the record's theta) and makes slice s + 1's
             //      direction and uniforms into buffer (s + 1) & 1.  Two barriers per slice: X (the records' LDS is free), Y (the
             //      records of slice s are laid down, slice s + 1's direction is complete)
-            auto produce = [&](int s) __attribute__((always_inline)) {
-                double nh[D], w;
+            // (one buffer: the direction and the uniforms of slice s + 1 are made in registers while the chain walks slice s, and laid
+            //  down between the slice's two barriers -- the chain reads them before X and after Y only; 44 KB of LDS for twenty
+            //  dimensions, three workgroups to a CU)
+            auto compute = [&](int s, double (&nh)[D], double &w, double (&uu)[8]) __attribute__((always_inline)) {
                 whiten(vv, nh, w);
                 if (s + 1 < nr) {
                     const double *p = rawc + (size_t)deck[s + 1] * D;
 #pragma unroll
                     for (int d = 0; d < D; ++d) vv[d] = p[d];
                 }
-                double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
+                const uint32_t c0 = ((uint32_t)s * PC_SLICE_STRIDE) >> 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, c0 + (uint32_t)c, uu[2 * c], uu[2 * c + 1]);
+            };
+            auto publish = [&](const double (&nh)[D], double w, const double (&uu)[8]) __attribute__((always_inline)) {
+                double *pn = sNh + (size_t)lane * (D + 1);
 #pragma unroll
                 for (int d = 0; d < D; ++d) pn[d] = nh[d];
                 pn[D] = w;
-                double *pu = sU + ((size_t)(s & 1) * 64 + lane) * 9;
-                const uint32_t c0 = ((uint32_t)s * PC_SLICE_STRIDE) >> 1;
+                double *pu = sU + (size_t)lane * 9;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { double ua, ub; pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, c0 + (uint32_t)c, ua, ub); pu[2 * c] = ua; pu[2 * c + 1] = ub; }
+                for (int c = 0; c < 8; ++c) pu[c] = uu[c];
             };
             auto ship = [&](int s) __attribute__((always_inline)) {
                 double *mine = sRow + (size_t)lane * RS;
@@ -264,11 +270,13 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             if (wv == 1) {
-                produce(0);
+                double nh[D], w, uu[8];
+                compute(0, nh, w, uu); publish(nh, w, uu);
                 pc_lds_barrier();
                 for (int s = 0; s < nr; ++s) {
-                    if (s + 1 < nr) produce(s + 1);
+                    if (s + 1 < nr) compute(s + 1, nh, w, uu);
                     pc_lds_barrier();                      // X
+                    if (s + 1 < nr) publish(nh, w, uu);
                     pc_lds_barrier();                      // Y
                 }
             } else {
@@ -297,7 +305,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 #endif
         if constexpr (!HELP) whiten(vv, nh, w);
         else {                                              // made by the other wavefront, a slice ahead
-            const double *pn = sNh + ((size_t)(s & 1) * 64 + lane) * (D + 1);
+            const double *pn = sNh + (size_t)lane * (D + 1);
 #pragma unroll
             for (int d = 0; d < D; ++d) nh[d] = pn[d];
             w = pn[D];
@@ -342,7 +350,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
         const uint32_t idx0 = (uint32_t)s * PC_SLICE_STRIDE;
         uint32_t have_call = 0xFFFFFFFFu; double ua = 0.0, ub = 0.0;
         auto draw = [&](uint32_t k) -> double {
-            if constexpr (HELP) { if (k < 8u) return sU[((size_t)(s & 1) * 64 + lane) * 9 + k]; }
+            if constexpr (HELP) { if (k < 8u) return sU[(size_t)lane * 9 + k]; }
             const uint32_t call = (idx0 + k) >> 1;
             if (call != have_call) { pc_uniform2(k0, k1, PC_DOM_SLICE, batch, (uint32_t)chain, call, ua, ub); have_call = call; }
             return (k & 1u) ? ub : ua;
@@ -476,11 +484,14 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
     constexpr int FW = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
     const int nrp = deck_stride(S->nr), grid = (nchains + 63) / 64;
     const size_t sh = sizeof(double) * ((size_t)DT * DT + 2 * FW) + (size_t)64 * nrp + sizeof(double) * 64 * (size_t)(S->nT | 1);
-    const size_t shh = sh + sizeof(double) * (size_t)2 * 64 * (DT + 1 + 9);      // + two buffers of directions and uniforms
+    const size_t shh = sh + sizeof(double) * (size_t)64 * (DT + 1 + 9);      // + the buffer of the next slice's direction and uniforms
     const bool unit = S->prior.lo == nullptr && S->prior.hi == nullptr;
     static const bool help_off = std::getenv("PC_SLICE_T_HELP_OFF") != nullptr;
     // (worth it while the helpers find SIMDs of their own: 16 runs 66 ms against 75, 32 runs 102.5 against 106, 64 runs 201 against 184)
-    static const long long help_max = std::getenv("PC_SLICE_T_HELP_MAX") ? std::atoll(std::getenv("PC_SLICE_T_HELP_MAX")) : 512;
+    // (the helping wavefronts while a CU has at most two workgroups of the launch: with three -- the LDS would hold them -- the chains'
+    //  own wavefronts share SIMDs with the helpers of their neighbours, and forty-eight runs were no faster than without: 132 ms against 130)
+    static const long long help_env = std::getenv("PC_SLICE_T_HELP_MAX") ? std::atoll(std::getenv("PC_SLICE_T_HELP_MAX")) : -1;
+    const long long help_max = help_env >= 0 ? help_env : 256LL * std::max<long long>(1, std::min<long long>(2, (long long)(156 * 1024) / (long long)shh));
     if (dR && !help_off && shh <= 64 * 1024 && (long long)grid * R <= help_max) {      // runs in step: a second wavefront per 64 chains works a slice ahead
         if (shh > 48 * 1024) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); }
         if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, true>), dim3(grid, R), dim3(192), shh, st, dR, nchains, nrp);
