@@ -2524,6 +2524,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         }
         catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); (void)hipGetLastError(); if (!worst) worst = e.code; }
         catch (const std::bad_alloc &) { std::fprintf(stderr, "polychord_hip: out of host memory\n"); if (!worst) worst = PC_RC_MEMORY; }
+        catch (const std::exception &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.what()); if (!worst) worst = PC_RC_DEVICE; }      // (a thread that could not be started: nothing leaves through the C interface)
         {   // the endings under way
             const auto e0 = nowc();
             for (auto &eb : endings) {
