@@ -138,7 +138,7 @@ __device__ void block_identify_all(const PcState &S, const ConsumeShared &H, int
 // ------------------------------------------------------------------------------------------
 #define NNL_G 32
 #define NNL_P 8
-__global__ __launch_bounds__(256) void k_nn_lists(PcState S, int nleft, int tile_pts)
+__device__ __forceinline__ void nn_lists_body(const PcState &S, int nleft, int tile_pts)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, D = S.D, nr = S.nr, nT = S.nT, Ncap = S.Ncap;
@@ -238,16 +238,39 @@ __global__ __launch_bounds__(256) void k_nn_lists(PcState S, int nleft, int tile
         }
     }
 }
+__global__ __launch_bounds__(256) void k_nn_lists(PcState S, int nleft, int tile_pts) { nn_lists_body(S, nleft, tile_pts); }
+// several runs in step (blockIdx.y = run): each run its own number of chains left in the nursery (PcManyRec::ia[1])
+__global__ __launch_bounds__(256) void k_nn_lists_many(const PcManyRec *__restrict__ R, int tile_pts)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    if ((int)blockIdx.x >= r.ia[1]) return;
+    nn_lists_body(r.S, r.ia[1], tile_pts);
+}
 
+static size_t nn_lists_lds(const PcState *S, int &tile)
+{
+    tile = (int)(24576 / (sizeof(double) * S->D));            // ~24 KB of coordinates per tile
+    tile = tile < 16 ? 16 : (tile > 512 ? 512 : tile);
+    return sizeof(double) * ((size_t)NNL_G * S->D + (size_t)tile * S->D + 256 * PC_NN_K) + sizeof(int) * (256 * PC_NN_K + tile) + 64;
+}
 extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, hipStream_t st)
 {
     if (nleft <= 0) return;
-    int tile = (int)(24576 / (sizeof(double) * S->D));            // ~24 KB of coordinates per tile
-    tile = tile < 16 ? 16 : (tile > 512 ? 512 : tile);
-    const size_t sh = sizeof(double) * ((size_t)NNL_G * S->D + (size_t)tile * S->D + 256 * PC_NN_K) + sizeof(int) * (256 * PC_NN_K + tile) + 64;
+    int tile;
+    const size_t sh = nn_lists_lds(S, tile);
     static size_t done = 0;
     if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
     hipLaunchKernelGGL(k_nn_lists, dim3(nleft), dim3(256), sh, st, *S, nleft, tile);
+}
+extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, int R, int nleft_max, hipStream_t st)
+{
+    if (nleft_max <= 0) return 0;
+    int tile;
+    const size_t sh = nn_lists_lds(S, tile);
+    static size_t done = 0;
+    if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    hipLaunchKernelGGL(k_nn_lists_many, dim3(nleft_max, R), dim3(256), sh, st, dR, tile);
+    return 0;
 }
 
 // dynamic nlive target (run_time_info.f90:766-771)
@@ -924,7 +947,7 @@ __device__ __forceinline__ int wave_copy_masked(const double *src0, unsigned lon
 // four waves per consumed chain: wave 0 also moves the dead row; the phantoms of a mask word are shared out among the
 // waves by runs of bits (a wave's rows go to consecutive rows behind those of the waves before it)
 #define PC_APPLY_WAVES 4
-__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S, unsigned batch)
+__device__ __forceinline__ void apply_dead_ph_body(const PcState &S, unsigned batch)
 {
     const PcCtl *ctl = S.ctl;
     const int w = ctl->seg_lo + blockIdx.x;
@@ -992,6 +1015,8 @@ __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S
         base += __popcll(mask);
     }
 }
+__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S, unsigned batch) { apply_dead_ph_body(S, batch); }
+__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph_many(const PcManyRec *__restrict__ R) { apply_dead_ph_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0]); }
 
 // pool mode: both of the above in ONE launch (a kernel boundary on the main stream costs 6 us, 79 times per run at the metric
 // configuration).  No row is copied to become a phantom, so a chain's workgroup only writes the side arrays of its region and,
@@ -1059,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_apply_pool_many(const PcManyRec *R, int
 
 
 // new live rows: every slot now owned by a chain's last baby
-__global__ __launch_bounds__(64) void k_apply_live(PcState S)
+__device__ __forceinline__ void apply_live_body(const PcState &S)
 {
     const int slot = blockIdx.x, lane = threadIdx.x, nT = S.nT, nr = S.nr;
     const int src = S.slot_src[slot];
@@ -1070,6 +1095,8 @@ __global__ __launch_bounds__(64) void k_apply_live(PcState S)
     __syncthreads();
     if (lane == 0) { S.slot_src[slot] = -1; S.live_entry[slot] = S.plan[src].contour; }
 }
+__global__ __launch_bounds__(64) void k_apply_live(PcState S) { apply_live_body(S); }
+__global__ __launch_bounds__(64) void k_apply_live_many(const PcManyRec *__restrict__ R) { apply_live_body(R[blockIdx.y].S); }
 
 // ------------------------------------------------------------------------------------------
 // install the initial live set: rows -> slots, labels, contour (generate.F90:291-320)
@@ -1733,7 +1760,11 @@ extern "C" void pc_launch_apply(const PcState *S, unsigned batch, int nchains, h
 
 extern "C" int pc_launch_apply_many(const PcState *S, const PcManyRec *dR, int R, unsigned batch, int nchains, hipStream_t st)
 {
-    if (!S->pool) return 1;
+    if (!S->pool) {      // (the runs of a launch share the layout: Cohort::flush groups them by it)
+        hipLaunchKernelGGL(k_apply_dead_ph_many, dim3(nchains, R), dim3(64 * PC_APPLY_WAVES), 0, st, dR);
+        hipLaunchKernelGGL(k_apply_live_many, dim3(S->Ncap, R), dim3(64), 0, st, dR);
+        return 0;
+    }
     static const int wpg = std::getenv("PC_APPLY_WAVES") ? std::max(1, std::min(4, std::atoi(std::getenv("PC_APPLY_WAVES")))) : 4;
     hipLaunchKernelGGL(k_apply_pool_many, dim3((nchains + S->Ncap + wpg - 1) / wpg, R), dim3(64 * wpg), 0, st, dR, nchains);      // (the nursery's number: each run's own, PcManyRec::ia[0])
     return 0;

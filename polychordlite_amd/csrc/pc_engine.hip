@@ -33,6 +33,10 @@ int pc_launch_slice(const PcState *, unsigned, int, hipStream_t);
 int pc_slice_fusable(const PcState *);
 int pc_launch_slice_fused(const PcState *, unsigned, int, hipStream_t);
 int pc_slice_t_ok(const PcState *, int);
+int pc_launch_slice_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
+int pc_launch_nhats_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
+int pc_launch_nn_lists_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
+int pc_launch_consume_cl_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
 int pc_launch_slice_t(const PcState *, unsigned, int, hipStream_t);
 int pc_bases_t_ok(const PcState *);
 int pc_launch_slice_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
@@ -394,7 +398,8 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
 //      ONE stream and go round by round together: what each engine would launch in a phase of the round it writes down here, and
 //      every kernel of the phase is launched ONCE for all of them (blockIdx.y = run, PcManyRec).  The same kernels' bodies on
 //      the same states: the numbers of a run do not know whether it ran alone.
-enum { CK_COMPACT = 0, CK_BASES, CK_SLICE, CK_BASES_NEXT, CK_SORT, CK_CONSUME, CK_APPLY, CK_UPDATE, CK_FINAL, CK_N };      // (in the order they are launched)
+enum { CK_COMPACT = 0, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_FINAL, CK_N };      // (in the order they are launched)
+// (_G: any device likelihood, the wavefront-per-chain kernels of a run on its own with the run in the grid; NN / CONSUME_CL: runs with several clusters)
 struct Cohort {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // the bases of the NEXT nursery, next to this one's sampling and contraction
@@ -403,8 +408,16 @@ struct Cohort {
     std::vector<Rec> pend;
     static constexpr int RING = 4;
     PcManyRec *h_stage[RING] = {}, *d_recs[RING] = {};
-    hipEvent_t ev[RING] = {}; bool ev_used[RING] = {};
+    // a slot's records are read by the kernels launched from it: its events are recorded behind the LAST of them, on both streams
+    hipEvent_t ev[RING] = {}, ev2[RING] = {}; bool ev_used[RING] = {}, ev2_used[RING] = {};
     size_t cap = 0; int ring = 0;
+    void slot_wait(int k)
+    {
+        if (ev_used[k]) { HIPCHK(hipEventSynchronize(ev[k])); ev_used[k] = false; }
+        if (ev2_used[k]) { HIPCHK(hipEventSynchronize(ev2[k])); ev2_used[k] = false; }
+    }
+    // the bases of this nursery were drawn on the second stream: whatever reads them on the main stream comes behind them
+    void wait_next() { if (next_pending) { HIPCHK(hipStreamWaitEvent(st, ev_next, 0)); next_pending = false; } }
     long n_fused = 0, n_single = 0;
     // the runs' copies to the host (dead rows, results) share two streams of the cohort, on hardware queues other than the two its
     // kernels use: a copy stream per run came from the pool, on whatever queue -- and where copies are shader blits (the HIP runtime
@@ -425,6 +438,10 @@ struct Cohort {
         case CK_COMPACT: pc_launch_clean(&r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], (int *)r.p[2], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5], (unsigned long long *)r.p[6], nullptr, st); break;
         case CK_BASES: case CK_BASES_NEXT: (void)pc_launch_nhats_part(&r.S, (unsigned)r.ia[0], (int)r.a[0], 1, st, 1); break;
         case CK_SLICE: (void)pc_launch_slice_t(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
+        case CK_NHATS_G: (void)pc_launch_nhats(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
+        case CK_SLICE_G: if (r.a[1]) (void)pc_launch_slice_fused(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); else (void)pc_launch_slice(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
+        case CK_NN: pc_launch_nn_lists(&r.S, r.ia[1], st); break;
+        case CK_CONSUME_CL: (void)pc_launch_consume_cl(&r.S, r.a[0] ? 65 : 2, st); break;
         case CK_SORT: (void)pc_launch_sort_live(&r.S, st); break;
         case CK_CONSUME: (void)pc_launch_consume_par(&r.S, st); break;
         case CK_FINAL: (void)pc_launch_final_par(&r.S, st); break;
@@ -439,18 +456,19 @@ struct Cohort {
         const size_t n = pend.size();
         if (n > cap) {
             for (int k = 0; k < RING; ++k) {
-                if (ev_used[k]) { (void)hipEventSynchronize(ev[k]); ev_used[k] = false; }
+                slot_wait(k);      // (kernels of earlier flushes may still be reading the old records, on either stream)
                 // (from the block caches and the event pool: asking the driver -- and giving back to it at the end -- was 2 ms per call)
                 if (h_stage[k]) hfree(h_stage[k]);
                 if (d_recs[k]) dfree(d_recs[k]);
                 h_stage[k] = halloc<PcManyRec>(2 * n);
                 d_recs[k] = dalloc<PcManyRec>(2 * n);
                 if (!ev[k]) ev[k] = hpool().get_sync_event();
+                if (!ev2[k] && st2) ev2[k] = hpool().get_sync_event();
             }
             cap = 2 * n;
         }
         const int slot = ring++ % RING;
-        if (ev_used[slot]) { HIPCHK(hipEventSynchronize(ev[slot])); ev_used[slot] = false; }
+        slot_wait(slot);
         PcManyRec *hs = h_stage[slot], *dr = d_recs[slot];
         // records in launch order: by kind, and inside a kind by the arguments all runs of a launch must share
         std::vector<const Rec *> ord; ord.reserve(n);
@@ -461,13 +479,13 @@ struct Cohort {
             if (c != 0) return c < 0;
             if (x->S.Ncap != y->S.Ncap) return x->S.Ncap < y->S.Ncap;
             if (x->S.B != y->S.B) return x->S.B < y->S.B;
+            if (x->S.pool != y->S.pool) return x->S.pool < y->S.pool;
             return (x->S.prior.lo == nullptr) < (y->S.prior.lo == nullptr);
         };
         std::stable_sort(ord.begin(), ord.end(), shape_less);
         for (size_t i = 0; i < n; ++i) { hs[i].S = ord[i]->S; std::memcpy(hs[i].p, ord[i]->p, sizeof(ord[i]->p)); std::memcpy(hs[i].ia, ord[i]->ia, sizeof(ord[i]->ia)); }
         HIPCHK(hipMemcpyAsync(dr, hs, sizeof(PcManyRec) * n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipEventRecord(ev[slot], st)); ev_used[slot] = true;
-        bool up_marked = false;
+        bool up_marked = false, used_st2 = false;
         for (size_t i = 0; i < n;) {
             size_t j = i + 1;
             while (j < n && !shape_less(ord[i], ord[j]) && !shape_less(ord[j], ord[i])) ++j;
@@ -478,14 +496,18 @@ struct Cohort {
             if (k == CK_BASES_NEXT && st2) {         // on the second stream, behind the upload of the records
                 if (!up_marked) { HIPCHK(hipEventRecord(ev_up, st)); up_marked = true; }
                 HIPCHK(hipStreamWaitEvent(st2, ev_up, 0));
-                q = st2;
+                q = st2; used_st2 = true;
             }
-            if (k == CK_SLICE && next_pending) { HIPCHK(hipStreamWaitEvent(st, ev_next, 0)); next_pending = false; }   // (its bases were drawn over there)
+            if (k == CK_SLICE || k == CK_SLICE_G) wait_next();   // (its bases were drawn over there)
             int rc = 1;
             switch (k) {
             case CK_COMPACT: { int nbm = 0; for (size_t x = i; x < j; ++x) nbm = std::max(nbm, ord[x]->ia[2]); rc = pc_launch_clean_many(d, cnt, nbm, q); } break;
             case CK_BASES: case CK_BASES_NEXT: rc = pc_launch_bases_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
             case CK_SLICE: rc = pc_launch_slice_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
+            case CK_NHATS_G: rc = pc_launch_nhats_many(&f.S, d, cnt, (int)f.a[0], q); break;
+            case CK_SLICE_G: rc = pc_launch_slice_many(&f.S, d, cnt, (int)f.a[0], (int)f.a[1], q); break;
+            case CK_NN: { int nl = 0; for (size_t x = i; x < j; ++x) nl = std::max(nl, ord[x]->ia[1]); rc = pc_launch_nn_lists_many(&f.S, d, cnt, nl, q); } break;
+            case CK_CONSUME_CL: rc = pc_launch_consume_cl_many(&f.S, d, cnt, (int)f.a[0], q); break;
             case CK_SORT: rc = pc_launch_sort_live_many(&f.S, d, cnt, q); break;
             case CK_CONSUME: rc = pc_launch_consume_par_many(&f.S, d, cnt, q); break;
             case CK_FINAL: rc = pc_launch_final_par_many(d, cnt, q); break;
@@ -497,13 +519,18 @@ struct Cohort {
             if (k == CK_BASES_NEXT && st2) { HIPCHK(hipEventRecord(ev_next, st2)); next_pending = true; }
             i = j;
         }
+        HIPCHK(hipEventRecord(ev[slot], st)); ev_used[slot] = true;
+        if (used_st2 && ev2[slot]) { HIPCHK(hipEventRecord(ev2[slot], st2)); ev2_used[slot] = true; }
         pend.clear();
     }
     void destroy()
     {
         for (int k = 0; k < RING; ++k) {
             if (ev_used[k]) (void)hipEventSynchronize(ev[k]);
+            if (ev2_used[k]) (void)hipEventSynchronize(ev2[k]);
             if (ev[k]) hpool().put_sync_event(ev[k]);
+            if (ev2[k]) hpool().put_sync_event(ev2[k]);
+            ev2[k] = nullptr; ev2_used[k] = false;
             if (h_stage[k]) hfree(h_stage[k]);
             if (d_recs[k]) dfree(d_recs[k]);
             ev[k] = nullptr; h_stage[k] = nullptr; d_recs[k] = nullptr; ev_used[k] = false;
@@ -847,6 +874,7 @@ struct Engine {
 
     void grow_dead(int nd)
     {
+        if (co) co->flush();      // (what the runs in step have written down is launched before an array moves)
         HIPCHK(hipStreamSynchronize(st_copy));        // rows still travelling from the old array
         auto grow = [&](auto *&p, size_t per) {
             using T = std::remove_reference_t<decltype(*p)>;
@@ -867,6 +895,7 @@ struct Engine {
     // so a small compression_factor needs far more than the initial estimate.
     void grow_phantoms(long long need)
     {
+        if (co) co->flush();      // (what the runs in step have written down is launched before an array moves)
         const long long hard = 1LL << 30;             // rows; Pcap and the phantom counters are ints
         if (need > hard) engine_fail(PC_RC_LIMIT, "more than %lld phantom points (%lld needed)", hard, need);
         long long np = std::max<long long>(need, 2LL * S.Pcap);
@@ -929,6 +958,7 @@ struct Engine {
 
     void grow_dead_clusters(int nd)
     {
+        if (co) co->flush();      // (what the runs in step have written down is launched before an array moves)
         HIPCHK(hipStreamSynchronize(st));
         const size_t used = (size_t)std::min(h_ctl->ncluster_dead, S.maxc_dead);
         auto grow = [&](auto *&p) {
@@ -947,6 +977,7 @@ struct Engine {
     {
         const int mo = S.maxc, mn = std::max(need, 2 * mo), Ncap = S.Ncap, DD = S.D * S.D;
         if (mn > 16384) engine_fail(PC_RC_LIMIT, "more than 16384 clusters");
+        if (co) co->flush();
         HIPCHK(hipStreamSynchronize(st));
         auto grow_d = [&](double *&p, double fill) {
             std::vector<double> v = dl(p, (size_t)mo); v.resize(mn, fill);
@@ -1136,6 +1167,7 @@ struct Engine {
             else pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
             kt.end(KT_CLEAN, e0);
             if (cfg.resume_write || dumper || on_update || seq_post) {
+                if (co) co->flush();      // (in step with other runs the update was only written down: launched now, before its count is read)
                 int total = nph;
                 HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
@@ -1822,6 +1854,12 @@ struct Engine {
     // nurseries to come.  spec: enqueued BEHIND the previous nursery's contraction before the host has seen its outcome; the
     // kernel starts by asking the device whether that nursery was consumed whole with neither an update nor the end of the
     // run in its way (PcCtl::spec_ok, left by k_consume_par) and returns at once if not.
+    // what the cohort's launches for any device likelihood take (else the run launches for itself in between)
+    bool cohort_general_ok() const
+    {
+        static const bool off = std::getenv("PC_COHORT_GENERAL") && std::atoi(std::getenv("PC_COHORT_GENERAL")) == 0;
+        return !off && S.ngrade <= 1 && !S.seq_mode && S.like.kind != PC_LIKE_CORR_GAUSSIAN && S.like.kind != PC_LIKE_CALLBACK;
+    }
     bool enqueue_nursery(bool spec)
     {
         unsigned &batch = r_batch; int &nursery_left = r_nursery_left;
@@ -1854,8 +1892,9 @@ struct Engine {
                 }
                 rs.valid = false;
                 fused_slice = !callback_mode && pc_slice_fusable(&S) != 0;       // seeds + whitening inside k_slice
-                if (!fused_slice) { if (co) co->flush(); (void)pc_launch_nhats_part(&S, batch, B, 2, st, 0); }
+                if (!fused_slice) { if (co) { co->flush(); co->wait_next(); } (void)pc_launch_nhats_part(&S, batch, B, 2, st, 0); }
             }
+            else if (co && !callback_mode && cohort_general_ok() && S.D >= 25 && S.D <= 64) co->rec(CK_NHATS_G, S, {}, {(long long)B}, {(int)batch});
             else if ((co ? (co->flush(), 0) : 0) || pc_launch_nhats(&S, batch, B, st)) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             kt.end(KT_NHATS, e0);
             hipEvent_t e1 = spec ? nullptr : kt.begin(KT_SLICE);
@@ -1874,7 +1913,18 @@ struct Engine {
                     rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true;
                 }
             }
-            else if ((co ? (co->flush(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            else if (co && !callback_mode && !spec && cohort_general_ok() && (fused_slice || !splittable)) {
+                // in step with other runs, any device likelihood / several clusters: the one-run kernel with the run in the grid
+                co->rec(CK_SLICE_G, S, {}, {(long long)B, fused_slice ? 1LL : 0LL}, {(int)batch});
+                if (fused_slice && co->st2 && raw_depth >= 2 && pc_bases_t_ok(&S)) {
+                    const unsigned x = batch + 1;
+                    RawSlot &rn = ring[x % raw_depth];
+                    PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+                    co->rec(CK_BASES_NEXT, S1, {}, {(long long)B}, {(int)x});
+                    rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true;
+                }
+            }
+            else if ((co ? (co->flush(), co->wait_next(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             S.spec_guard = 0;
             kt.end(KT_SLICE, e1);
             if (split && !spec) side_prefetch(batch);      // (speculative: only once the device is known to have taken the nursery)
@@ -1966,28 +2016,38 @@ struct Engine {
             }
             else if (use_fast) { if (co) co->flush(); sort_valid = false; S.nn_valid = 0; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else {
-                if (co) co->flush();
                 sort_valid = false;
                 // several clusters: rank the possible nearest neighbours of every baby still in the nursery once, on
                 // the whole chip; the serial contraction then walks short lists instead of searching the live set
                 static const bool nn_off = std::getenv("PC_NN_LISTS_OFF") != nullptr;
-                if (h_ctl->ncluster > 1 && S.nn_list && !S.nn_valid && !nn_off && !S.seq_mode && nursery_left > 1) {
-                    pc_launch_nn_lists(&S, nursery_left, st);
-                    S.nn_valid = 1;
-                }
+                const bool want_nn = h_ctl->ncluster > 1 && S.nn_list && !S.nn_valid && !nn_off && !S.seq_mode && nursery_left > 1;
                 // several clusters, static number of live points, lists in place: the one-wave contraction (pc_clus.hip); everything
                 // else -- and every launch when settings.ablate bit 5 is set -- goes to the general kernel, which is its arbiter
                 static const bool cl_off = std::getenv("PC_CONSUME_CL_OFF") != nullptr;
-                if (static_ok && cfg.force_general == 0 && !cl_off && !(cfg.ablate & 32) && S.nn_valid && !S.seq_mode && h_ctl->ncluster > 1 &&
-                    pc_consume_cl_fits(&S, h_ctl->ncluster)) {
+                const bool use_cl = static_ok && cfg.force_general == 0 && !cl_off && !(cfg.ablate & 32) && (S.nn_valid || want_nn) && !S.seq_mode && h_ctl->ncluster > 1 &&
+                                    pc_consume_cl_fits(&S, h_ctl->ncluster);
+                if (co && use_cl && cohort_general_ok()) {
+                    // in step with other runs: lists, sort and the one-wave contraction once for all runs with several clusters
+                    if (want_nn) { co->rec(CK_NN, S, {}, {}, {0, nursery_left}); S.nn_valid = 1; }
+                    co->rec(CK_SORT, S, {}, {}, {});
+                    co->rec(CK_CONSUME_CL, S, {}, {h_ctl->ncluster > 64 ? 1LL : 0LL}, {});
+                    rc2 = 0;
+                } else {
+                if (co) co->flush();
+                if (want_nn) {
+                    pc_launch_nn_lists(&S, nursery_left, st);
+                    S.nn_valid = 1;
+                }
+                if (use_cl) {
                     rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
                 } else
                 rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
+                }
             }
             if (rc2) { std::fprintf(stderr, "polychord_hip: nlive too large for the LDS-resident contraction\n"); r_rc = 4; return false; }
             kt.end(KT_CONSUME, e2);
             hipEvent_t e3 = kt.begin(KT_APPLY);
-            if (co && S.pool) co->rec(CK_APPLY, S, {}, {(long long)B}, {(int)(batch - 1)}); else { if (co) co->flush(); pc_launch_apply(&S, batch - 1, B, st); }
+            if (co) co->rec(CK_APPLY, S, {}, {(long long)B}, {(int)(batch - 1)}); else pc_launch_apply(&S, batch - 1, B, st);
             kt.end(KT_APPLY, e3);
             // the main stream's wait for the next nursery's bases is enqueued now, behind this round's kernels (long
             // satisfied when the next k_slice gets there), not between the stamp and the next launch

@@ -598,345 +598,14 @@ __device__ __forceinline__ double quad_sum(double v)
 template <int HV, int PART = 0>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
-    constexpr int DP = 4 * HV, NTQ = 16 * HV;
-    // LDS rows are stored as four coordinate blocks of HV + 2 doubles: the four threads of a vector read their blocks
-    // at the same time, and blocks exactly HV doubles (a multiple of 256 B) apart would all start in the same bank
-    constexpr int HP = HV + 2, DPP = 4 * HP;
-    extern __shared__ __attribute__((aligned(16))) char smem_q[];
-    double (*Qb)[DPP] = (double (*)[DPP])smem_q;                      // [2][DPP] pivot, double buffered
-    double (*Lt)[DPP] = (double (*)[DPP])(smem_q + sizeof(double) * 2 * DPP);   // [HV][DPP] HV rows of the Cholesky factor (HV < 32)
-    __shared__ int sh[2];
-    const int D = S.D, nr = S.nr;
-    const int tid = threadIdx.x, chain = blockIdx.y;
-    const int i = tid >> 2, h = tid & 3, d0 = HV * h, p0 = HP * h;    // my vector, my coordinate block (p0: in LDS rows)
-    int grade, basis;                                                 // chordal_sampling.f90:119-130, see k_nhats
-    pc_grade_of_basis(S, blockIdx.x, grade, basis);
-    const int off = pc_sel(S.g_off, grade), Dg = D - off, nrg = pc_sel(S.g_nr, grade), col0 = pc_sel(S.g_col0, grade);
-    const bool active = i < Dg;
-#ifdef NHATSQ_DBG
-    long long qc[6]; qc[0] = clock64();
-#endif
-    if (PART != 1 && tid == 0) {
-        int sel, slot;
-        select_seed(S, batch, chain, sel, slot);
-        sh[0] = sel; sh[1] = slot;
-        if (blockIdx.x == 0) {
-            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = slot;
-            S.ch_contour[chain] = S.logLp[sel];          // nested_sampling.F90:270
-            S.ch_epoch[chain] = S.ctl->admin_epoch;
-            if (chain == 0) { S.ctl->i_nursery = gridDim.y; S.ctl->batch_id = batch; }
-        }
-    }
-    double *rawb = (PART != 0) ? S.nhat_raw + ((size_t)chain * S.nb_total + blockIdx.x) * (size_t)(HV * NTQ) : nullptr;
-    // gaussian deviates of my 32 coordinates: element (basis*D + i)*D + d of stream (batch, chain) in PC_DOM_NHAT,
-    // two per Philox call
-    double v[HV];
-#pragma unroll
-    for (int e = 0; e < HV; ++e) v[e] = 0.0;
-    double lpre[(HV * DP + NTQ - 1) / NTQ];
-    {
-    if (active) {
-        // stream element of my register 0 (coordinate d0); registers [r_lo, r_hi) hold coordinates that exist and move
-        const long long e0 = (long long)(S.seq_mode ? (uint32_t)S.ctl->seq + 2u : 0u) + pc_sel(S.g_e0, grade)
-                             + ((long long)basis * Dg + i) * Dg + (d0 - off);
-        const int r_lo = max(0, off - d0), r_hi = min(HV, D - d0);
-        if (r_hi > r_lo) {
-            // Philox call number cbase + cc holds stream elements 2 (cbase + cc) and + 1, i.e. my registers 2 cc - par and
-            // 2 cc - par + 1 with par = parity of e0: every call lands in one of two fixed register pairs
-            const long long cbase = e0 >> 1;
-            const bool par = (e0 & 1ll) != 0;
-#pragma unroll
-            for (int cc = 0; cc < HV / 2 + 1; ++cc) {
-                const int ea = 2 * cc - (par ? 1 : 0), eb = ea + 1;
-                if (eb >= r_lo && ea < r_hi) {
-                    const uint32_t call = (uint32_t)(cbase + cc);
-                    double ua, ub;
-                    if (S.seq_mode) pc_uniform2(S.k0, S.k1, PC_DOM_SEQ, 0u, 0u, call, ua, ub);
-                    else pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
-                    const double ga = pc_inv_normal_cdf(ua), gb = pc_inv_normal_cdf(ub);
-                    if (2 * cc - 1 >= 0 && 2 * cc - 1 < HV) v[(2 * cc - 1 >= 0 && 2 * cc - 1 < HV) ? 2 * cc - 1 : 0] = par ? ga : v[(2 * cc - 1 >= 0 && 2 * cc - 1 < HV) ? 2 * cc - 1 : 0];
-                    if (2 * cc < HV) v[2 * cc < HV ? 2 * cc : 0] = par ? gb : ga;
-                    if (2 * cc + 1 < HV) v[2 * cc + 1 < HV ? 2 * cc + 1 : 0] = par ? v[2 * cc + 1 < HV ? 2 * cc + 1 : 0] : gb;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < HV; ++e) v[e] = (e >= r_lo && e < r_hi) ? v[e] : 0.0;   // coordinates that do not exist / do not move
-        }
-    }
-#ifdef NHATSQ_DBG
-    qc[1] = clock64();
-#endif
-#define PC_DOT32(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
-        _Pragma("unroll") for (int e = 0; e < HV; e += 4) { \
-            p0_ += (A)[e] * (B)[e]; p1_ += (A)[e + 1] * (B)[e + 1]; p2_ += (A)[e + 2] * (B)[e + 2]; p3_ += (A)[e + 3] * (B)[e + 3]; } \
-        RES = quad_sum((p0_ + p1_) + (p2_ + p3_)); }
-    {   // random_direction (random_utils.F90:276-298)
-        double n2;
-        PC_DOT32(n2, v, v)
-        const double inrm = active ? 1.0 / sqrt(n2) : 0.0;
-#pragma unroll
-        for (int e = 0; e < HV; ++e) v[e] *= inrm;
-    }
-    if (i == 0) {
-#pragma unroll
-        for (int e = 0; e < HV; ++e) Qb[0][p0 + e] = v[e];
-    }
-    __syncthreads();
-    // first tile of the Cholesky factor: requested now, consumed after the loop
-    if constexpr (HV < 32) {
-        const double *Lc0 = S.chol + (size_t)sh[0] * D * D;
-#pragma unroll
-        for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) {
-            const int y = tid + x * NTQ, r = y / DP, b = y % DP;
-            lpre[x] = (y < HV * DP && r < D && b < D) ? Lc0[(size_t)r * D + b] : 0.0;
-        }
-    }
-#ifdef NHATSQ_DBG
-    qc[2] = clock64();
-#endif
-    // Gram-Schmidt (random_utils.F90:391-399): same projections as before, pivot unnormalised
-    for (int j = 0; j < Dg; ++j) {
-        // a wave whose sixteen vectors are all finished (i < j) only keeps the barrier company
-        if ((((tid >> 6) + 1) << 4) <= j) { __syncthreads(); continue; }
-        double q[HV];
-#pragma unroll
-        for (int e = 0; e < HV; ++e) q[e] = Qb[j & 1][p0 + e];
-        double qq, dv;
-        PC_DOT32(qq, q, q)
-        PC_DOT32(dv, q, v)
-        if (i == j) {
-            const double inrm = 1.0 / sqrt(qq);
-#pragma unroll
-            for (int e = 0; e < HV; ++e) v[e] *= inrm;
-        } else if (active && i > j) {
-            const double cproj = dv / qq;
-#pragma unroll
-            for (int e = 0; e < HV; ++e) v[e] -= cproj * q[e];
-            if (i == j + 1) {
-#pragma unroll
-                for (int e = 0; e < HV; ++e) Qb[(j + 1) & 1][p0 + e] = v[e];
-            }
-        }
-        __syncthreads();
-    }
-#ifdef NHATSQ_DBG
-    qc[3] = clock64();
-#endif
-    }
-    if constexpr (PART == 1) {
-        // the layout k_whiten reads as its B operand: [n][group of sixteen vectors][lk][vector in group], coordinate
-        // 32 h + e = 8 (n >> 1) + 2 lk + (n & 1)
-#pragma unroll
-        for (int e = 0; e < HV; ++e) {
-            const int n = 8 * h + 2 * (e >> 3) + (e & 1), lkk = (e & 7) >> 1;
-            rawb[((size_t)n * 8 + (i >> 4)) * 64 + lkk * 16 + (i & 15)] = v[e];
-        }
-        return;
-    }
-    // whitening  w = L.n  (chordal_sampling.f90:73): tile k holds rows 32k..32k+31 of L, i.e. exactly the output
-    // coordinates of block h = k
-    const int col = col0 + basis * Dg + i;
-    const bool wanted = basis * Dg + i < nrg;
-    const double *Lc = S.chol + (size_t)sh[0] * D * D;
-    if constexpr (HV == 32) {
-        // nDims 65..128: W = L.N on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  The basis goes to LDS (row = vector,
-        // odd row stride), L passes through LDS sixteen rows at a time (lower triangle only), wave tj owns the sixteen
-        // output columns (vectors) 16 tj ..: it keeps their tiles in registers, normalises, and writes whole rows.
-        // Operand maps as in k_cov_partial: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D row = (lane>>4)+4 reg.
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        constexpr int NS = 129;
-        const int nt = (D + 15) >> 4, NR = nt * 16;
-        double *Nl = (double *)smem_q + 2 * DPP;                       // [NR][NS]
-        double *L16 = Nl + (size_t)NR * NS;                            // [2][16][NS]: the tile in use and the next one
-        const bool dbuf = NR <= 112;                                   // (beyond: one buffer, and a barrier before it is refilled)
-        // tiles of L (and of M below) travel global -> registers -> LDS one tile ahead of the matrix cores: one barrier per tile
-        double pre[4];
-        auto load_L = [&](int ti) __attribute__((always_inline)) {
-            const int kmax = min(NR, 16 * (ti + 1));                   // L(a, b) = 0 for b > a
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int x = tid + q * NTQ, r = x / kmax, bcol = x - r * kmax, arow = 16 * ti + r;
-                pre[q] = (x < 16 * kmax && arow < D && bcol < D) ? Lc[(size_t)arow * D + bcol] : 0.0;
-            }
-        };
-        auto store_L = [&](int ti) __attribute__((always_inline)) {
-            const int kmax = min(NR, 16 * (ti + 1));
-            double *buf = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
-            if (!dbuf) __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int x = tid + q * NTQ, r = x / kmax, bcol = x - r * kmax;
-                if (x < 16 * kmax) buf[(size_t)r * NS + bcol] = pre[q];
-            }
-        };
-        load_L(0);
-        if (i < NR) {
-#pragma unroll
-            for (int e = 0; e < HV; ++e) Nl[(size_t)i * NS + d0 + e] = v[e];    // zero beyond nDims and beyond the basis
-        }
-        const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
-        v4d acc[8];
-#pragma unroll
-        for (int ti = 0; ti < 8; ++ti) acc[ti] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ti = 0; ti < 8; ++ti) {
-            if (ti < nt) {
-                store_L(ti);
-                if (ti + 1 < nt) load_L(ti + 1);
-                __syncthreads();                                       // tile ti (and, the first time, the basis) complete
-                if (wv < nt) {
-                    const int kmax = min(NR, 16 * (ti + 1));
-                    const double *pa = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS + (size_t)li * NS + lk;
-                    const double *pb = Nl + (size_t)(16 * wv + li) * NS + lk;
-                    v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
-                    for (int k0 = 0; k0 < kmax; k0 += 4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], a4, 0, 0, 0);
-                    acc[ti] = a4;
-                }
-            }
-        }
-        if (wv < nt) {
-            // |w| of my column (chordal_sampling.f90:80-82): my four row groups, then the other three lane groups
-            double n2 = 0.0;
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) n2 += acc[ti][r] * acc[ti][r];
-            n2 += __shfl_xor(n2, 16); n2 += __shfl_xor(n2, 32);
-            const double wn = sqrt(n2), iw = 1.0 / wn;
-            const int ivec = 16 * wv + li;                             // vector of this basis = column
-            double *mine = Nl + (size_t)ivec * NS;                     // the basis rows of this wave are no longer read
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (ti < nt) mine[16 * ti + lk + 4 * r] = acc[ti][r] * iw;
-            if (lk == 0 && ivec < Dg && basis * Dg + ivec < nrg) S.nhat_w[(size_t)chain * nr + col0 + basis * Dg + ivec] = wn * 3.0;
-            // rows leave coalesced
-            for (int cc = 0; cc < 16; ++cc) {
-                const int iv = 16 * wv + cc;
-                if (iv < Dg && basis * Dg + iv < nrg) {
-                    double *out = S.nhat + ((size_t)chain * nr + col0 + basis * Dg + iv) * D;
-                    const double *src = Nl + (size_t)iv * NS;
-                    for (int a2 = lane; a2 < D; a2 += 64) out[a2] = src[a2];
-                }
-            }
-        }
-        if (S.nhat_Ms != nullptr) {
-            // correlated Gaussian (random_gaussian.f90:17-30): along a chord the exponent is quadratic (see ChainCtx) and all a
-            // slice needs of the matrix is M.s, s = span o n^.  Every direction of the chain is known HERE: the products are
-            // one more [D x D] x [D x 16] pass per wave on the matrix cores (rows of M streamed through the tile buffer of L)
-            // instead of a matrix-vector product per slice inside the chain.  Wave 0 of the chain's first basis also forms
-            // M.(theta_seed - mean), the one product the chain needs for its start point.
-            double *spn = (double *)smem_q, *y0s = spn + 128;           // the pivot buffers are free now (2 x 136 doubles)
-            const double *Mt = S.like.invcov;                           // Mt[b * D + a] = M(a, b)
-            auto load_M = [&](int ti) __attribute__((always_inline)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int x = tid + q * NTQ, r = x & 15, bcol = x >> 4, arow = 16 * ti + r;
-                    pre[q] = (x < 16 * NR && arow < D && bcol < D) ? Mt[(size_t)bcol * D + arow] : 0.0;
-                }
-            };
-            auto store_M = [&](int ti) __attribute__((always_inline)) {
-                double *buf = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
-                if (!dbuf) __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int x = tid + q * NTQ, r = x & 15, bcol = x >> 4;
-                    if (x < 16 * NR) buf[(size_t)r * NS + bcol] = pre[q];
-                }
-            };
-            __syncthreads();
-            if (tid < NR) {
-                const bool on = tid < D;
-                const double lo = (on && S.prior.lo) ? S.prior.lo[tid] : 0.0, hi = (on && S.prior.hi) ? S.prior.hi[tid] : 1.0;
-                spn[tid] = on ? hi - lo : 0.0;
-                const double c0 = on ? S.live[(size_t)sh[1] * S.nT + tid] : 0.0;
-                y0s[tid] = on ? (lo + (hi - lo) * c0) - (S.like.mean ? S.like.mean[tid] : 0.0) : 0.0;
-            }
-            load_M(0);
-            __syncthreads();
-            if (wv < nt) {                                              // my sixteen rows: n^ -> s
-                for (int x = lane; x < 16 * NR; x += 64) { const int r = x / NR, a2 = x % NR; Nl[(size_t)(16 * wv + r) * NS + a2] *= spn[a2]; }
-            }
-            v4d ac2[8];
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti) ac2[ti] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti) {
-                if (ti < nt) {
-                    store_M(ti);
-                    if (ti + 1 < nt) load_M(ti + 1);
-                    __syncthreads();
-                    const double *tile = L16 + (size_t)(dbuf ? (ti & 1) : 0) * 16 * NS;
-                    if (wv < nt) {
-                        const double *pa = tile + (size_t)li * NS + lk;
-                        const double *pb = Nl + (size_t)(16 * wv + li) * NS + lk;
-                        v4d a4 = v4d{0.0, 0.0, 0.0, 0.0};
-                        for (int k0 = 0; k0 < NR; k0 += 4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], a4, 0, 0, 0);
-                        ac2[ti] = a4;
-                    }
-                    if (wv == 7 && blockIdx.x == 0) {                  // M.y0, rows of this tile: lane = (row, quarter of the columns)
-                        double t = 0.0;
-                        for (int b = lk; b < NR; b += 4) t += tile[(size_t)li * NS + b] * y0s[b];
-                        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-                        if (lk == 0 && 16 * ti + li < D) S.ch_My[(size_t)chain * D + 16 * ti + li] = t;
-                    }
-                }
-            }
-            if (wv < nt) {
-                double *mine = Nl + (size_t)(16 * wv + li) * NS;
-#pragma unroll
-                for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (ti < nt) mine[16 * ti + lk + 4 * r] = ac2[ti][r];
-                for (int cc = 0; cc < 16; ++cc) {
-                    const int iv = 16 * wv + cc;
-                    if (iv < Dg && basis * Dg + iv < nrg) {
-                        double *out = S.nhat_Ms + ((size_t)chain * nr + col0 + basis * Dg + iv) * D;
-                        const double *src = Nl + (size_t)iv * NS;
-                        for (int a2 = lane; a2 < D; a2 += 64) out[a2] = src[a2];
-                    }
-                }
-            }
-        }
-        return;
-    }
-    double w[HV];
-#pragma unroll
-    for (int e = 0; e < HV; ++e) w[e] = 0.0;
-    for (int k = 0; k * HV < D; ++k) {
-        __syncthreads();
-        if (k == 0) {
-            // the first tile was requested before the Gram-Schmidt loop (registers lpre): its latency is hidden
-#pragma unroll
-            for (int x = 0; x < (HV * DP + NTQ - 1) / NTQ; ++x) { const int y = tid + x * NTQ, b = y % DP; if (y < HV * DP) Lt[y / DP][(b / HV) * HP + b % HV] = lpre[x]; }
-        } else {
-            for (int x = tid; x < HV * DP; x += NTQ) {
-                const int r = x / DP, b = x % DP, a = HV * k + r;
-                Lt[r][(b / HV) * HP + b % HV] = (a < D && b < D) ? Lc[(size_t)a * D + b] : 0.0;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < HV; ++r) {
-            double t;
-            PC_DOT32(t, (&Lt[r][p0]), v)
-            if (h == k) w[r] = t;
-        }
-    }
-    if (active && wanted) {
-        double n2;
-        PC_DOT32(n2, w, w)
-        const double wn = sqrt(n2), iw = 1.0 / wn;              // chordal_sampling.f90:80-82
-        double *out = S.nhat + ((size_t)chain * nr + col) * D + d0;
-#pragma unroll
-        for (int e = 0; e < HV; ++e) if (d0 + e < D) out[e] = w[e] * iw;
-        if (h == 0) S.nhat_w[(size_t)chain * nr + col] = wn * 3.0;
-    }
-#undef PC_DOT32
-#ifdef NHATSQ_DBG
-    qc[4] = clock64();
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int x = 0; x < 4; ++x) S.ctl->gen_cyc[x] += qc[x + 1] - qc[x];
-#endif
+#include "pc_nhats_q_body.inc"
+}
+template <int HV, int PART = 0>
+__global__ __launch_bounds__(16 * HV) void k_nhats_q_many(const PcManyRec *__restrict__ R)
+{
+    const PcState S = R[blockIdx.z].S;
+    const unsigned batch = (unsigned)R[blockIdx.z].ia[0];
+#include "pc_nhats_q_body.inc"
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1443,499 +1112,18 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // enqueued before the host knew how the previous nursery ended: only if the contraction left its go-ahead for THIS nursery
-    if (S.spec_guard && S.ctl->spec_ok != (int)batch) return;
-    __builtin_amdgcn_s_setprio(3);                 // a chain is one long dependent instruction stream: it goes first on its SIMD
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    const long long kc0 = clock64(), kw0 = wall_clock64();
-#endif
-    const int lane = threadIdx.x & 63, wv = (WPB > 1) ? (int)(threadIdx.x >> 6) : 0, chain = blockIdx.x * WPB + wv;
-    const size_t per_wave = ((size_t)S.D + S.nr + (phi_lds ? (size_t)S.nr * (S.D + 1) : 0) + 1) & ~(size_t)1;   // doubles
-    double *ybuf = (double *)smem + (size_t)wv * per_wave;   // [D] (corr gaussian only)
-    int *sdeck = (int *)(ybuf + S.D);              // [nr] deck, only used when nr > 64
-    int *sj = sdeck + S.nr;                        // [nr]
-    double *tbuf = ybuf + S.D + S.nr;              // [nr][D+1] theta of every baby (when it fits: phi_lds)
-    double *Mlds = (double *)smem + (size_t)WPB * per_wave;  // [D][D] inverse covariance, transposed (mat_lds), shared
-    const int D = S.D, nr = S.nr, nT = S.nT;
-    const double logzero = S.logzero;
-    const bool seq_mode = SPECIAL && S.seq_mode != 0, graded = SPECIAL && S.ngrade > 1;
+#include "pc_slice_body.inc"
+}
 
-    LaneDims<DPL> ld;
-    int slot, seed_cluster = 0;
-    double contour;
-    // FW: the loads of the whitening prologue are issued first -- raw direction `lane` (+64, ...) and the Cholesky factor of
-    // cluster 0 (the seed's cluster unless there are several) -- and travel while the seed is chosen and the deck shuffled
-    constexpr int FWN = FW > 0 ? FW : 1;
-    constexpr int FWL = FW > 0 ? (FW * FW + 63) / 64 : 1;
-    double vv0[FWN], Lpre[FWL];
-    if constexpr (FW > 0) {
-        const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;
-#pragma unroll
-        for (int d = 0; d < FWN; ++d) vv0[d] = (d < D && lane < nr) ? rawc[(size_t)lane * D + d] : 0.0;
-#pragma unroll
-        for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; Lpre[q] = (e < D * D) ? S.chol[e] : 0.0; }
-    }
-    if constexpr (FW > 0) {
-        int sel = 0, sl = 0;
-        if (lane == 0) {                          // GenerateSeed (generate.F90:19-55), nested_sampling.F90:267-273
-            select_seed(S, batch, chain, sel, sl);
-            S.ch_cluster[chain] = sel; S.ch_seed_slot[chain] = sl;
-            S.ch_contour[chain] = S.logLp[sel];                      // nested_sampling.F90:270
-            S.ch_epoch[chain] = S.ctl->admin_epoch;
-            if (chain == 0) { S.ctl->i_nursery = gridDim.x * WPB; S.ctl->batch_id = batch; }
-        }
-        seed_cluster = __builtin_amdgcn_readfirstlane(sel); slot = __builtin_amdgcn_readfirstlane(sl);
-        contour = S.logLp[seed_cluster];
-    } else { slot = S.ch_seed_slot[chain]; contour = S.ch_contour[chain]; }
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    const long long kp1 = clock64();
-#endif
-    double x0[DPL];
-    {
-        const double *seed = S.live + (size_t)slot * nT;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            const int dim = lane + 64 * k;
-            ld.on[k] = dim < D;
-            const double lo = (ld.on[k] && S.prior.lo) ? S.prior.lo[dim] : 0.0;
-            const double hi = (ld.on[k] && S.prior.hi) ? S.prior.hi[dim] : 1.0;
-            ld.lo[k] = lo; ld.span[k] = hi - lo;
-            ld.mean[k] = (ld.on[k] && S.like.mean) ? S.like.mean[dim] : 0.0;
-            x0[k] = ld.on[k] ? seed[dim] : 0.5;
-        }
-    }
-    // pool mode: the babies land in this chain's rows of the phantom array; none of them is a phantom before the chain is consumed
-    if (S.pool) for (int i = lane; i < nr; i += 64) S.ph_cuid[(size_t)S.pool_base + (size_t)chain * nr + i] = PC_CUID_NONE;
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    const long long kp2 = clock64();
-#endif
-    ChainCtx<DPL, NROWS> C{S, ld, lane, ybuf, 0, false, 0.0, 0.0, 0.0, 0.0};
-    const bool corr = S.like.kind == PC_LIKE_CORR_GAUSSIAN;
-    C.quad = (corr || S.like.kind == PC_LIKE_GAUSSIAN) && !(S.ablate & 1);
-    C.qnorm = corr ? -((double)D * PC_LOG_TWO_PI + S.like.logdetcov) / 2.0 : S.like.norm;
-    // correlated Gaussian: y = theta - mean and M.y travel with the chain (updated, not recomputed, at every
-    // accepted point); the matrix is read from LDS when it fits
-    const double *Mt = S.like.invcov;             // transposed: Mt[b*D + a] = M(a,b), lanes read consecutive a
-    double yv[DPL], My[DPL], sv[DPL], Ms[DPL];
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) { yv[k] = 0.0; My[k] = 0.0; sv[k] = 0.0; Ms[k] = 0.0; }
-    auto matvec = [&](const double (&vec)[DPL], double (&out)[DPL]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) if (ld.on[k]) ybuf[lane + 64 * k] = vec[k];
-        __syncthreads();                             // one wave per workgroup
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            const int a = lane + 64 * k;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            if (ld.on[k]) {
-                int b = 0;
-                for (; b + 3 < D; b += 4) {
-                    t0 += Mt[(size_t)b * D + a] * ybuf[b]; t1 += Mt[(size_t)(b + 1) * D + a] * ybuf[b + 1];
-                    t2 += Mt[(size_t)(b + 2) * D + a] * ybuf[b + 2]; t3 += Mt[(size_t)(b + 3) * D + a] * ybuf[b + 3];
-                }
-                for (; b < D; ++b) t0 += Mt[(size_t)b * D + a] * ybuf[b];
-            }
-            out[k] = (t0 + t1) + (t2 + t3);
-        }
-        __syncthreads();
-    };
-    // msp: M.s of every direction and M.y of the start point were formed by k_nhats_q on the matrix cores (nhat_Ms, ch_My):
-    // no matrix here at all; y and M.y are carried along the chords for the whole chain (a rounding error per slice, the
-    // size of the one a direct evaluation makes)
-    const bool msp = corr && S.nhat_Ms != nullptr && C.quad;
-    double Ms_next[DPL];
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) Ms_next[k] = 0.0;
-    if (corr) {
-        if (mat_lds) {
-            for (int e = threadIdx.x; e < D * D; e += 64 * WPB) Mlds[e] = S.like.invcov[e];
-            __syncthreads();
-            Mt = Mlds;
-        }
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) yv[k] = ld.on[k] ? (ld.lo[k] + ld.span[k] * x0[k]) - ld.mean[k] : 0.0;
-        if (msp) {
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) My[k] = ld.on[k] ? S.ch_My[(size_t)chain * D + lane + 64 * k] : 0.0;
-        } else matvec(yv, My);
-        double pa = 0.0;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) pa += yv[k] * My[k];
-        C.qa = wsum<DPL, NROWS>(pa);
-    }
-
-    // ---- deck: first direction stays, the others are Fisher-Yates shuffled (chordal_sampling.f90:135-142,
-    //      random_utils.F90:505-532).  deck value for position p lives in lane p when nr <= 64.
-    // seq_mode: stream positions of the shuffle draws (after the seed draws and every basis) and of the slice draws
-    const unsigned long long seq_g0 = seq_mode ? S.ctl->seq + 2ull + (unsigned long long)S.n_dev : 0ull;
-    unsigned long long seq_run = seq_g0 + (unsigned long long)(nr - 1);
-    int deck = lane;
-    const bool deck_in_regs = nr <= 64;
-    if (deck_in_regs) {
-        int jv = 0;
-        if (lane >= 1 && lane < nr) {
-            const double u = seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - lane))
-                                        : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
-            int j = (int)ceil(u * lane);
-            jv = j < 1 ? 1 : (j > lane ? lane : j);
-        }
-        for (int i = nr - 1; i >= 1; --i) {
-            const int j = __builtin_amdgcn_readlane(jv, i);
-            const int di = __builtin_amdgcn_readlane(deck, i), dj = __builtin_amdgcn_readlane(deck, j);
-            deck = (lane == i) ? dj : ((lane == j) ? di : deck);
-        }
-    } else {
-        for (int i = lane; i < nr; i += 64) {
-            sdeck[i] = i;
-            if (i >= 1) {
-                const double u = seq_mode ? pc_seq_uniform(S, seq_g0 + (unsigned long long)(nr - 1 - i))
-                                            : pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)i);
-                int j = (int)ceil(u * i);
-                sj[i] = j < 1 ? 1 : (j > i ? i : j);
-            }
-        }
-        __syncthreads();
-        if (lane == 0)
-            for (int i = nr - 1; i >= 1; --i) { const int j = sj[i], t = sdeck[i]; sdeck[i] = sdeck[j]; sdeck[j] = t; }
-        __syncthreads();
-    }
-
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    const long long kp3 = clock64();
-#endif
-    double ua = 0.0, ub = 0.0;                     // uniforms of 4 consecutive slices, 32 each
-    double nh[DPL], nh_next[DPL], w_next;
-    // ---- FW: all directions of the chain whitened up front, lane = direction (what a thread of k_nhats did for its
-    //      vector, same loops): w = L n (chordal_sampling.f90:73), |w|, n^ = w / |w|, width 3 |w| (:80-82); results in LDS
-    double *nhs = nullptr, *wsh = nullptr;
-    if constexpr (FW > 0) {
-        double *Lsh = tbuf + (phi_lds ? (size_t)nr * (D + 1) : 0);     // [FW][D] Cholesky factor, rows past D zero
-        nhs = Lsh + (size_t)FW * D;                                      // [nr][D + 1]
-        wsh = nhs + (size_t)nr * (D + 1);                               // [nr]
-        if (seed_cluster != 0) {                                         // (uniform) several clusters: the seed's factor
-            const double *Lg = S.chol + (size_t)seed_cluster * D * D;
-#pragma unroll
-            for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; Lpre[q] = (e < D * D) ? Lg[e] : 0.0; }
-        }
-#pragma unroll
-        for (int q = 0; q < FWL; ++q) { const int e = lane + 64 * q; if (e < FW * D) Lsh[e] = Lpre[q]; }
-        __syncthreads();                                                // one wave per workgroup
-        const double *rawc = S.nhat_raw + (size_t)chain * S.nb_total * D * D;   // direction v (generation order) at + v * D
-        for (int v0 = 0; v0 < nr; v0 += 64) {
-            const int v = v0 + lane;
-            if (v < nr) {
-                double vv[FWN], t[FWN];
-#pragma unroll
-                for (int d = 0; d < FWN; ++d) { vv[d] = (v0 == 0) ? vv0[d] : ((d < D) ? rawc[(size_t)v * D + d] : 0.0); t[d] = 0.0; }
-#pragma unroll
-                for (int bb = 0; bb < FWN; ++bb)
-#pragma unroll
-                    for (int aa = bb; aa < FWN; ++aa) t[aa] += Lsh[(size_t)aa * D + bb] * vv[bb];
-#pragma unroll
-                for (int aa = 0; aa < FWN; ++aa) if (aa >= D) t[aa] = 0.0;
-                double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-                for (int d = 0; d < FWN; d += 4) { p0 += t[d] * t[d]; p1 += t[d + 1] * t[d + 1]; p2 += t[d + 2] * t[d + 2]; p3 += t[d + 3] * t[d + 3]; }
-                const double wn = sqrt((p0 + p1) + (p2 + p3)), iw = 1.0 / wn;
-#pragma unroll
-                for (int d = 0; d < FWN; ++d) if (d < D) nhs[(size_t)v * (D + 1) + d] = t[d] * iw;
-                wsh[v] = wn * 3.0;
-            }
-        }
-        __syncthreads();
-        const int v0 = deck_in_regs ? __builtin_amdgcn_readlane(deck, 0) : sdeck[0];
-        nh_next[0] = (lane < D) ? nhs[(size_t)v0 * (D + 1) + lane] : 0.0;
-        w_next = wsh[v0];
-    } else
-    {   // prefetch the first direction
-        const int v0 = deck_in_regs ? __builtin_amdgcn_readlane(deck, 0) : sdeck[0];
-        const double *p = S.nhat + ((size_t)chain * nr + v0) * D;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[lane + 64 * k] : 0.0;
-        w_next = S.nhat_w[(size_t)chain * nr + v0];
-        if (msp) {
-            const double *pm = S.nhat_Ms + ((size_t)chain * nr + v0) * D;
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) Ms_next[k] = ld.on[k] ? pm[lane + 64 * k] : 0.0;
-        }
-    }
-
-#ifdef SLICE_DBG
-    long long scy[6] = {0, 0, 0, 0, 0, 0}; long long nev = 0, ev2 = 0;
-#if SLICE_DBG == 2
-    const long long kc1 = clock64();
-#endif
-#endif
-    double w = w_next;
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) nh[k] = nh_next[k];
-    // loop-invariant addresses (the per-slice address arithmetic was a third of the slice's instructions)
-    const double *nh_base = S.nhat + (size_t)chain * nr * D + lane;
-    const double *nw_base = S.nhat_w + (size_t)chain * nr;
-    const double *nm_base = msp ? S.nhat_Ms + (size_t)chain * nr * D + lane : nh_base;
-    if (msp) {
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) Ms[k] = Ms_next[k];
-    }
-    double *row = S.babies + (size_t)chain * nr * nT;
-    double *bl_row = S.baby_logL + (size_t)chain * nr;
-    double *bl_col = S.baby_logL_T + chain;
-    double *tb_row = tbuf + lane;
-    const int o_p0 = S.p0, o_d0 = S.d0, o_b0 = S.b0, o_l0 = S.l0, nDer = S.nDer, Bstride = S.B;
-    int nl_grade[PC_MAX_GRADE];                    // evaluations per grade (chordal_sampling.f90:84), static indices only
-#pragma unroll
-    for (int g = 0; g < PC_MAX_GRADE; ++g) nl_grade[g] = 0;
-    for (int s = 0; s < nr; ++s, row += nT, bl_col += Bstride, tb_row += D + 1) {
-#ifdef SLICE_DBG
-        const long long c0 = clock64();
-#endif
-        const int nl_before = C.nlike;
-        int my_grade = 0;
-        if (graded) my_grade = pc_grade_of(S, deck_in_regs ? __builtin_amdgcn_readlane(deck, s) : sdeck[s]);
-        if constexpr (FW > 0) {
-            if (s + 1 < nr) {
-                const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
-                nh_next[0] = (lane < D) ? nhs[(size_t)v1 * (D + 1) + lane] : 0.0;
-                w_next = wsh[v1];
-            }
-        } else
-        if (s + 1 < nr) {                           // prefetch the next direction (hidden under this slice)
-            const int v1 = deck_in_regs ? __builtin_amdgcn_readlane(deck, s + 1) : sdeck[s + 1];
-            const double *p = nh_base + v1 * D;
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) nh_next[k] = ld.on[k] ? p[64 * k] : 0.0;
-            w_next = nw_base[v1];
-            if (msp) {
-                const double *pm = nm_base + v1 * D;
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) Ms_next[k] = ld.on[k] ? pm[64 * k] : 0.0;
-            }
-        }
-        if ((s & 3) == 0 && !seq_mode) {          // one Philox call per lane covers 4 slices x 32 uniforms
-            const uint32_t sl = (uint32_t)s + (uint32_t)(lane >> 4);
-            pc_uniform2(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain,
-                        (sl * PC_SLICE_STRIDE) / 2 + (uint32_t)(lane & 15), ua, ub);
-        }
-        uint32_t kdraw = 0;
-        auto next_u = [&]() -> double {
-            if (seq_mode) return pc_seq_uniform(S, seq_run++);
-            const uint32_t k = kdraw++;
-            if (k < 32u) {
-                const int src = ((s & 3) << 4) + (int)(k >> 1);
-                return (k & 1u) ? readlane_f64(ub, src) : readlane_f64(ua, src);
-            }
-            return pc_uniform(S.k0, S.k1, PC_DOM_SLICE, batch, (uint32_t)chain, (uint32_t)s * PC_SLICE_STRIDE + k);
-        };
-
-#ifdef SLICE_DBG
-        const long long c1 = clock64();
-#endif
-        double cube[DPL], th[DPL];
-        if (C.quad) {
-            double pa = 0.0, pb = 0.0, pc = 0.0;
-            if (!corr) {
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) {
-                    const double zA = ((ld.lo[k] + ld.span[k] * x0[k]) - S.like.mu) * S.like.inv_sigma;
-                    const double zB = (ld.span[k] * nh[k]) * S.like.inv_sigma;
-                    if (ld.on[k]) { pa += zA * zA; pb += zA * zB; pc += zB * zB; }
-                }
-                C.qa = wsum<DPL, NROWS>(pa);
-            } else {
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) sv[k] = ld.on[k] ? ld.span[k] * nh[k] : 0.0;
-                if (!msp) matvec(sv, Ms);
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) { pb += sv[k] * My[k]; pc += sv[k] * Ms[k]; }
-            }
-            C.qb = wsum<DPL, NROWS>(pb); C.qc = wsum<DPL, NROWS>(pc);
-        }
-        // initial bracket (chordal_sampling.f90:213-219)
-        const double u0 = next_u();
-        double tR = (1 - u0) * w, tL = -(u0 * w);
-        double lR, lL;
-        eval_pair<DPL, NROWS>(C, x0, nh, tR, tL, lR, lL);
-#ifdef SLICE_DBG
-        const long long c2 = clock64();
-#endif
-        // stepping out (:223-236)
-        int istep = 0;
-        while (lR >= contour && lR > logzero) { istep++; tR = w * istep; lR = eval_at<DPL, NROWS>(C, x0, nh, tR, cube, th); }
-        istep = 0;
-        while (lL >= contour && lL > logzero) { istep++; tL = -(w * istep); lL = eval_at<DPL, NROWS>(C, x0, nh, tL, cube, th); }
-#ifdef SLICE_DBG
-        const long long c3 = clock64();
-#endif
-        // shrinkage (:240-271)
-        double lnew = logzero, t_last = 0.0;
-        bool ok = false;
-        int it0 = 0;
-        if (C.quad && !seq_mode) {
-            // The first four trial points at once.  Where trial q lands does not depend on the likelihood of the trials
-            // before it, only on their positions (a rejected trial becomes the bracket end on its side of x0), and the
-            // uniforms are known: so the four positions "if everything before was rejected" are computed up front and
-            // their likelihoods -- closed form along the chord, a handful of dependent fp64 operations of ~32 cycles each
-            // on a wave that has its SIMD to itself -- are evaluated side by side instead of one after the other.  The
-            // first accepted one is the baby; the trials after it never happened (not counted, their draws given back):
-            // the same result and the same likelihood count as the loop, a third of its latency.
-            constexpr int NSP = 4;
-            const uint32_t kd0 = kdraw;
-            double tc[NSP], lc[NSP], tLb[NSP], tRb[NSP];
-            bool oc[NSP];
-            double tLc = tL, tRc = tR;
-#pragma unroll
-            for (int q = 0; q < NSP; ++q) {
-                const double dl = fabs(tLc), dr = fabs(tRc);
-                const double t = next_u() * (dr + dl) - dl;
-                tc[q] = t;
-                if (t > 0.0) tRc = t; else tLc = t;
-                tLb[q] = tLc; tRb[q] = tRc;                         // the bracket after rejecting trial q
-                bool outside = false;
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) {
-                    const double cb = x0[k] + t * nh[k];
-                    if (ld.on[k]) outside |= (cb < 0.0) | (cb > 1.0);
-                }
-                oc[q] = __ballot(outside) != 0ull;
-                lc[q] = C.qnorm - (C.qa + t * (2.0 * C.qb + t * C.qc)) / 2.0;
-            }
-            int acc = -1;
-#pragma unroll
-            for (int q = 0; q < NSP; ++q) {
-                if (acc < 0) {
-                    const double lg = oc[q] ? logzero : lc[q];     // calculate.f90:36-38
-                    if (!oc[q] && lg > logzero) C.nlike++;
-                    t_last = tc[q]; lnew = lg;
-                    if (lg < contour || lg <= logzero) { tL = tLb[q]; tR = tRb[q]; }
-                    else acc = q;
-                }
-            }
-            if (acc >= 0) {
-                ok = true; kdraw = kd0 + (uint32_t)acc + 1u;
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) { cube[k] = x0[k] + t_last * nh[k]; th[k] = ld.lo[k] + ld.span[k] * cube[k]; }
-            }
-            it0 = NSP;
-        }
-        for (int it = it0; it <= 100 && !ok; ++it) {
-            const double dl = fabs(tL), dr = fabs(tR);
-            const double t = next_u() * (dr + dl) - dl;
-            t_last = t;
-            lnew = eval_at<DPL, NROWS>(C, x0, nh, t, cube, th);
-#ifdef SLICE_DBG
-            nev++;
-#endif
-            if (lnew < contour || lnew <= logzero) { if (t > 0.0) tR = t; else tL = t; }
-            else ok = true;
-        }
-        if (!ok) lnew = logzero;                    // "Non deterministic loglikelihood"
-        if (corr) {                                 // the next start point: y and M.y move along the chord
-            C.qa = C.qa + t_last * (2.0 * C.qb + t_last * C.qc);
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) { yv[k] += t_last * sv[k]; My[k] += t_last * Ms[k]; }
-            if ((s & 15) == 15 && !msp) {            // resynchronise the carried products now and then
-                matvec(yv, My);
-                double pa = 0.0;
-#pragma unroll
-                for (int k = 0; k < DPL; ++k) pa += yv[k] * My[k];
-                C.qa = wsum<DPL, NROWS>(pa);
-            }
-        }
-#ifdef SLICE_DBG
-        const long long c4 = clock64();
-#endif
-        // the baby becomes the next start point (chordal_sampling.f90:85-88)
-        // The prefetched direction is taken over BEFORE this slice's stores are issued: its loads were
-        // issued a whole slice ago, whereas a wait placed after the stores (vmcnt counts them too on
-        // gfx9) would stall every slice for a full store round trip.
-        w = w_next;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) { nh[k] = nh_next[k]; asm volatile("" : "+v"(nh[k])); }
-        asm volatile("" : "+v"(w));
-        if (msp) {
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) { Ms[k] = Ms_next[k]; asm volatile("" : "+v"(Ms[k])); }
-        }
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            x0[k] = cube[k];
-            if (ld.on[k]) { row[lane + 64 * k] = cube[k]; row[o_p0 + lane + 64 * k] = th[k]; }
-        }
-        if (phi_lds) {
-#pragma unroll
-            for (int k = 0; k < DPL; ++k) if (ld.on[k]) tb_row[64 * k] = th[k];
-        } else if (nDer > 0) {
-            double phi0, phi1;
-            like_phi<DPL, NROWS>(S, th, ld, lane, phi0, phi1);
-            if (lane == 0) {
-                row[o_d0] = phi0;
-                if (nDer >= 2) row[o_d0 + 1] = phi1;
-                for (int e = 2; e < nDer; ++e) row[o_d0 + e] = 0.0;
-            }
-        }
-        if (lane == 0) {
-            row[o_b0] = contour;                    // nested_sampling.F90:260
-            row[o_l0] = lnew;
-            bl_row[s] = lnew; *bl_col = lnew;
-        }
-        if (graded) {
-#pragma unroll
-            for (int g = 0; g < PC_MAX_GRADE; ++g) nl_grade[g] += (my_grade == g) ? C.nlike - nl_before : 0;
-        }
-#ifdef SLICE_DBG
-        const long long c5 = clock64();
-        scy[0] += c1 - c0; scy[1] += c2 - c1; scy[2] += c3 - c2; scy[3] += c4 - c3; scy[4] += c5 - c4;
-#endif
-    }
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    const long long kc2 = clock64();
-#elif defined(SLICE_DBG)
-    if (lane == 0 && chain == 0) { for (int x = 0; x < 5; ++x) S.ctl->dbg[x] += scy[x]; S.ctl->dbg[5] += nev; S.ctl->dbg[6] += scy[5]; S.ctl->dbg[7] += ev2; }
-#endif
-    if (lane == 0) S.ch_nlike[chain] = C.nlike;
-    if (graded) {
-        if (lane == 0) {
-#pragma unroll
-            for (int g = 0; g < PC_MAX_GRADE; ++g) S.ch_nlike_g[(size_t)chain * PC_MAX_GRADE + g] = nl_grade[g];
-        }
-    }
-    if (seq_mode && lane == 0 && chain == 0) S.ctl->seq = seq_run;
-    // derived parameters of all the babies at once, lane = slice (gaussian.f90:36-37, twin_gaussian.f90:48-52):
-    // one sqrt / log per chain instead of one per slice on the chain's critical path
-    if (S.nDer > 0 && phi_lds) {
-        __syncthreads();                            // one wave per workgroup: orders the LDS writes above
-        for (int s0 = 0; s0 < nr; s0 += 64) {
-            const int s = s0 + lane;
-            if (s >= nr) continue;
-            double *row = S.babies + ((size_t)chain * nr + s) * nT;
-            const double *tt = tbuf + (size_t)s * (D + 1);
-            double phi0 = 0.0, phi1 = 0.0;
-            if (S.like.kind == PC_LIKE_GAUSSIAN) {
-                double r2 = 0.0;
-                for (int d = 0; d < D; ++d) { const double z = tt[d] - S.like.mu; r2 += z * z; }
-                phi0 = sqrt(r2);
-                if (S.nDer >= 2) phi1 = pc_log_ball(phi0, D, S.like.log_vn);
-            } else if (S.like.kind == PC_LIKE_TWIN_GAUSSIAN) {
-                phi0 = (tt[0] > 0.5) ? 1.0 : -1.0;
-            }
-            row[S.d0] = phi0;
-            if (S.nDer >= 2) row[S.d0 + 1] = phi1;
-            for (int e = 2; e < S.nDer; ++e) row[S.d0 + e] = 0.0;
-        }
-    }
-#if defined(SLICE_DBG) && SLICE_DBG == 2
-    // whole-kernel view, all chains: cycles before / inside / after the slice loop (sums and maxima), launch-relative start
-    {
-        const long long kc3 = clock64(), kw3 = wall_clock64();
-        unsigned long long *g = (unsigned long long *)S.ctl->dbg;
-        if (lane == 0) {
-            atomicAdd(&g[0], (unsigned long long)(kp1 - kc0)); atomicAdd(&g[1], (unsigned long long)(kp2 - kp1)); atomicAdd(&g[2], (unsigned long long)(kp3 - kp2));
-            atomicAdd(&g[3], (unsigned long long)(kc1 - kp3)); atomicAdd(&g[4], (unsigned long long)(kc2 - kc1)); atomicAdd(&g[5], (unsigned long long)(kc3 - kc2));
-            atomicMax(&g[6], (unsigned long long)(kw3 - kw0));       // longest chain, 100 MHz ticks
-        }
-    }
-#endif
+// several runs of a device in step (Cohort, pc_engine.hip): the same statements on each run's own state, blockIdx.y = run.  (Included, not
+// called: handing the state to a function by reference moved fused multiply-adds in the one-run kernel -- -ffp-contract=fast works on
+// whatever the optimiser has made of the code -- and the lane-per-chain kernel of pc_slice_t.hip is matched to that kernel's ISA.)
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
+__global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice_many(const PcManyRec *__restrict__ R, int phi_lds, int mat_lds)
+{
+    const PcState S = R[blockIdx.y].S;
+    const unsigned batch = (unsigned)R[blockIdx.y].ia[0];
+#include "pc_slice_body.inc"
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2056,6 +1244,53 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     else if (D <= 16) PC_SLICE_FUSED(1, 16)
     else PC_SLICE_FUSED(2, 24)
 #undef PC_SLICE_FUSED
+    return 0;
+}
+
+// Several runs of a device in step: the sampling kernel of any device likelihood launched once for all of them (grid.y = run; every
+// run the same shape: nDims, num_repeats, chains, likelihood kind).  fused: k_slice with the seed choice and the whitening inside
+// (pc_launch_slice_fused); else the plain kernel behind k_nhats*.  1: a shape only the one-run launchers take.
+extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R, int nchains, int fused, hipStream_t st)
+{
+    const int D = S->D;
+    const size_t sh0 = sizeof(double) * ((size_t)D + S->nr) + 16;
+    const size_t tb = sizeof(double) * (size_t)S->nr * (D + 1);
+    const int phi_lds = (S->nDer > 0 && sh0 + tb <= 48 * 1024) ? 1 : 0;
+    if (fused) {
+        if (!pc_slice_fusable(S)) return 1;
+        const int FWv = D <= 8 ? 8 : (D <= 16 ? 16 : 24);
+        const size_t sh = sh0 + (phi_lds ? tb : 0) + sizeof(double) * ((size_t)FWv * D + (size_t)S->nr * (D + 2));
+        if (sh > 150 * 1024) return 1;
+#define PC_SLICE_FUSED_M(NROWS, FW) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice_many<1, NROWS, false, 1, FW>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+        if (D <= 8) PC_SLICE_FUSED_M(1, 8)
+        else if (D <= 16) PC_SLICE_FUSED_M(1, 16)
+        else PC_SLICE_FUSED_M(2, 24)
+#undef PC_SLICE_FUSED_M
+        return 0;
+    }
+    if (S->like.kind == PC_LIKE_CORR_GAUSSIAN || S->ngrade > 1 || S->seq_mode || D > 64) return 1;
+    const size_t sh = sh0 + (phi_lds ? tb : 0);
+#define PC_SLICE_M(DPL, NROWS) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<DPL, NROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice_many<DPL, NROWS, false>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+    if (D <= 16) PC_SLICE_M(1, 1)
+    else if (D <= 32) PC_SLICE_M(1, 2)
+    else PC_SLICE_M(1, 4)
+#undef PC_SLICE_M
+    return 0;
+}
+
+// ... and the directions (bases, seeds, whitening in one kernel: pc_launch_nhats) for the shapes that do not split: 24 < nDims <= 64
+extern "C" int pc_launch_nhats_many(const PcState *S, const PcManyRec *dR, int R, int nchains, hipStream_t st)
+{
+    const int D = S->D, nb = S->nb_total;
+    if (D < 25 || D > 64 || S->seq_mode || std::getenv("PC_NHATS_QUAD_MIN")) return 1;
+    dim3 grid(nb, nchains, R);
+    auto lds_q = [](int HV) { return sizeof(double) * (size_t)(2 + HV) * 4 * (HV + 2); };
+    if (D <= 32) hipLaunchKernelGGL((k_nhats_q_many<8>), grid, dim3(128), lds_q(8), st, dR);
+    else hipLaunchKernelGGL((k_nhats_q_many<16>), grid, dim3(256), lds_q(16), st, dR);
     return 0;
 }
 

@@ -307,12 +307,17 @@ def test_lived_records_follow_the_runs_logzero(engine):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,nDer,nlive,nr,clus,box", [("gaussian", 20, 2, 400, 20, 0, None), ("gaussian", 7, 1, 300, 14, 0, (-0.25, 1.5)),
                                                             ("rastrigin", 3, 0, 200, 9, 1, (-5.12, 5.12)), ("twin_gaussian", 6, 1, 250, 12, 0, (-1.0, 1.0)),
-                                                            ("gaussian", 24, 0, 256, 24, 0, None), ("gaussian", 3, 4, 200, 6, 0, (0.1, 0.9))])
+                                                            ("gaussian", 24, 0, 256, 24, 0, None), ("gaussian", 3, 4, 200, 6, 0, (0.1, 0.9)),
+                                                            # the clustered BASELINE shapes, smaller: 10-D Rastrigin (dozens of clusters), 30-D twin Gaussian
+                                                            # (k_nhats_q + the plain k_slice), twin Gaussian with a split, Rastrigin without clustering
+                                                            ("rastrigin", 10, 0, 300, 30, 1, (-5.12, 5.12)), ("twin_gaussian", 30, 1, 120, 40, 1, (-1.0, 1.0)),
+                                                            ("twin_gaussian", 6, 1, 250, 12, 1, (-1.0, 1.0)), ("rastrigin", 4, 0, 200, 12, 0, (-5.12, 5.12))])
 def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus, box):
     """pchip_run_repeats with all runs of the device in flight: they go round by round together on one stream, every kernel of a
     round launched once for all of them (Gaussian: the lane-per-chain kernels, fused update, pool compaction for all at once;
-    the other likelihoods and clustered runs: the engines' ordinary launches in between the common ones) -- each run bit for
-    bit the run it is alone, whatever round the others update, compact or end in"""
+    the other likelihoods and clustered runs: k_slice / k_nhats_q / k_nn_lists / k_consume_cl / the row copies with the run in the
+    grid, the updates with clustering by each engine in between) -- each run bit for bit the run it is alone, whatever round the
+    others update, split, compact or end in.  The first seed is also the ORACLE's run of these settings (tests.oracle_api)."""
     from polychordlite_amd.repeats import run_repeats
     api = engine
     lib = api.load()
@@ -332,6 +337,25 @@ def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus
         assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
         assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
     assert merged["n_runs"] == len(seeds)
+    # one of the runs in step next to the oracle (same Philox keys: the same trajectory; nDims <= 7 whole runs, beyond that the first
+    # generations -- round-off grows with every covariance update, and clusters of fewer points than dimensions hang on the sign of
+    # a 1e-19 Cholesky pivot: DESIGN section 7)
+    from tests import oracle_api as orc
+    g = runs[0]
+    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=seeds[0], batch=g["batch"], do_clustering=clus)
+    Lo, Po, keep2 = orc.make_problem(kind, D, *(box if box else (None, None)))
+    o = orc.run(so, Lo, Po)
+    if D <= 7:
+        for k in ("ndead", "nlike", "niter", "nbatches", "ncluster", "ncluster_dead"):
+            assert g[k] == o[k], (k, g[k], o[k])
+        assert abs(g["logZ"] - o["logZ"]) < 1e-8 and abs(g["logZerr"] - o["logZerr"]) < 1e-8
+        rel = np.abs(g["dead"] - o["dead"]) / np.maximum(1.0, np.abs(o["dead"]))
+        assert rel.max() < 1e-7
+    else:
+        n0 = min(6 * nlive, int(g["ndead"]), int(o["ndead"]))
+        rel = np.abs(g["dead"][:n0] - o["dead"][:n0]) / np.maximum(1.0, np.abs(o["dead"][:n0]))
+        assert rel.max() < 1e-7
+        assert abs(g["logZ"] - o["logZ"]) < 3.0 * (g["logZerr"] + o["logZerr"])
 
 
 @pytest.mark.gpu

@@ -10,13 +10,32 @@ import os
 import sys
 
 
+def kernel_name(raw):
+    """'void (anonymous namespace)::k_slice_t_many<20, true, true>(PcManyRec const*, int, int)' -> 'k_slice_t_many<20, true, true>':
+    the return type, namespaces written with parentheses and the argument list go; template arguments stay."""
+    s = raw.strip()
+    if s.startswith("void "):
+        s = s[5:].strip()
+    s = s.replace("(anonymous namespace)::", "")
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):          # the argument list opens at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return s[:cut].strip()
+
+
 def per_kernel(d, counter):
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            name = kernel_name(r["Kernel_Name"])
             a = acc.setdefault(name, [0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
