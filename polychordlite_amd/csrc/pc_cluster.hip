@@ -298,7 +298,54 @@ __global__ __launch_bounds__(256) void k_ph_count(PcState S, int nph, int nc, in
     (void)nc;
 }
 
+// add_cluster: the Cholesky factors and covariances of the clusters behind cluster p move up a block (run_time_info.f90:371-376); one
+// workgroup, block after block (the blocks overlap in the order of the move)
+__global__ __launch_bounds__(256) void k_shift_mats(PcState S, int p, int nc)
+{
+    const int DD = S.D * S.D;
+    for (int c = p; c < nc - 1; ++c) {
+        for (int e = threadIdx.x; e < DD; e += 256) {
+            S.chol[(size_t)c * DD + e] = S.chol[(size_t)(c + 1) * DD + e];
+            S.cov[(size_t)c * DD + e] = S.cov[(size_t)(c + 1) * DD + e];
+        }
+        __syncthreads();
+    }
+}
+
+// the first pass for several runs in step: blockIdx.z = run, every run its own descriptors and scratch (PcManyRec::p: 0 descriptors,
+// 1 similarity blocks, 2 neighbour lists, 3 labels, 4 verdicts; ia[1] = clusters looked at)
+__global__ __launch_bounds__(256) void k_similarity_b_many(const PcManyRec *__restrict__ R)
+{
+    const PcManyRec &r = R[blockIdx.z];
+    if ((int)blockIdx.y >= r.ia[1]) return;
+    const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.y];
+    if ((int)blockIdx.x >= d.n) return;
+    similarity_body(r.S, r.S.cl_list + (size_t)d.c * r.S.Ncap, d.n, (double *)r.p[1] + d.off2, 0, 256);
+}
+__global__ __launch_bounds__(256) void k_knn_sort_b_many(const PcManyRec *__restrict__ R)
+{
+    const PcManyRec &r = R[blockIdx.z];
+    if ((int)blockIdx.y >= r.ia[1]) return;
+    const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.y];
+    if ((int)blockIdx.x >= d.n) return;
+    int npow2 = 2;
+    while (npow2 < d.n) npow2 <<= 1;
+    knn_sort_body((const double *)r.p[1] + d.off2, d.n, nullptr, d.n, npow2, (int *)r.p[2] + d.off2);
+}
+__global__ __launch_bounds__(1024) void k_nn_cluster_b_many(const PcManyRec *__restrict__ R)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    if ((int)blockIdx.x >= r.ia[1]) return;
+    const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.x];
+    nn_cluster_body((const int *)r.p[2] + d.off2, d.n, (int *)r.p[3] + d.off1, (int *)r.p[4] + blockIdx.x);
+}
+
 extern "C" {
+
+void pc_launch_shift_mats(const PcState *S, int p, int nc, hipStream_t st)
+{
+    if (p < nc - 1) hipLaunchKernelGGL(k_shift_mats, dim3(1), dim3(256), 0, st, *S, p, nc);
+}
 
 void pc_launch_similarity(const PcState *S, const int *pts, int n, double *Sm, hipStream_t st)
 {
@@ -337,6 +384,39 @@ int pc_launch_knn_cluster_batch(const PcState *S, const int *h_desc, const int *
     hipLaunchKernelGGL(k_similarity_b, dim3(nmax, nd), dim3(256), 0, st, *S, dd, Sm);
     hipLaunchKernelGGL(k_knn_sort_b, dim3(nmax, nd), dim3(256), sh, st, (const double *)Sm, dd, knn);
     hipLaunchKernelGGL(k_nn_cluster_b, dim3(nd), dim3(1024), sh2, st, (const int *)knn, dd, labels, out);
+    return 0;
+}
+
+// the same with the largest cluster given (no host copy of the descriptors at hand: a record of the runs in step launched on its own)
+int pc_launch_knn_cluster_batch_dev(const PcState *S, const int *d_desc, int nd, int nmax, double *Sm, int *knn, int *labels, int *out, hipStream_t st)
+{
+    if (nd <= 0) return 0;
+    int npow2 = 2;
+    while (npow2 < nmax) npow2 <<= 1;
+    const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
+    if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
+    (void)hipFuncSetAttribute((const void *)k_knn_sort_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    (void)hipFuncSetAttribute((const void *)k_nn_cluster_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+    const ClusDesc *dd = (const ClusDesc *)d_desc;
+    hipLaunchKernelGGL(k_similarity_b, dim3(nmax, nd), dim3(256), 0, st, *S, dd, Sm);
+    hipLaunchKernelGGL(k_knn_sort_b, dim3(nmax, nd), dim3(256), sh, st, (const double *)Sm, dd, knn);
+    hipLaunchKernelGGL(k_nn_cluster_b, dim3(nd), dim3(1024), sh2, st, (const int *)knn, dd, labels, out);
+    return 0;
+}
+int pc_launch_knn_cluster_batch_many(const PcState *S, const PcManyRec *dR, int R, int nd_max, int nmax, hipStream_t st)
+{
+    (void)S;
+    if (nd_max <= 0) return 0;
+    int npow2 = 2;
+    while (npow2 < nmax) npow2 <<= 1;
+    const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
+    if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
+    static size_t d1 = 0, d2 = 0;
+    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_b_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
+    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_b_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    hipLaunchKernelGGL(k_similarity_b_many, dim3(nmax, nd_max, R), dim3(256), 0, st, dR);
+    hipLaunchKernelGGL(k_knn_sort_b_many, dim3(nmax, nd_max, R), dim3(256), sh, st, dR);
+    hipLaunchKernelGGL(k_nn_cluster_b_many, dim3(nd_max, R), dim3(1024), sh2, st, dR);
     return 0;
 }
 

@@ -12,6 +12,7 @@
 //               threshold test + deterministic stream compaction, calculate_covmats (:601-641) as a
 //               two-pass mean / centred SYRK with fixed-order reduction, calc_cholesky (utils.F90:621-649).
 #include "pc_state.h"
+#include <atomic>
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
@@ -247,6 +248,203 @@ __global__ __launch_bounds__(256) void k_nn_lists_many(const PcManyRec *__restri
     nn_lists_body(r.S, r.ia[1], tile_pts);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_nn_lists_d<D> (nDims <= 32): the same lists from registers.  The kernel above reads both operands of every (x - y)^2 from LDS
+// and fills 32 x 8 threads with the babies of a chain in groups of 32 (num_repeats = 40: 62 % of the slots); with several runs of a
+// device in step it is the heaviest kernel of a round (1.6 ms for sixteen runs at BASELINE configs[3]).  Here a thread holds TWO
+// babies' coordinates in registers (the loop over d is unrolled: one instantiation per nDims), the pairs of a chain share the
+// workgroup with as many scanners each as fit (num_repeats 40: 20 pairs x 12 scanners = 240 threads), a staged point is read
+// from LDS once for two babies, and a thread walks two points at a time (four independent sums in flight: a dependent fp64
+// operation issues every 32 cycles on a wave).  The same sums in the same order (d ascending, fused multiply-add of the
+// difference), the same lists: ties between different points -- exact duplicates only -- go to the lower scanner, then the
+// lower point, as above.
+// ------------------------------------------------------------------------------------------
+// the candidates of a nursery, once: every workgroup of k_nn_lists_d stages its tiles from this array with plain consecutive loads
+// (resolving slot -> occupant -> row per workgroup was a chain of three dependent global loads per staged point: at nDims = 10 a
+// workgroup spent four fifths of its time there)
+__device__ __forceinline__ void nn_gather_body(const PcState &S, int nleft)
+{
+    const int D = S.D, nr = S.nr, nT = S.nT, Ncap = S.Ncap;
+    const int e = blockIdx.x * 256 + threadIdx.x, n = (Ncap + nleft) * D;
+    if (e >= n) return;
+    const int gi = e / D, d = e - gi * D;
+    int code = PC_NN_NONE; double v = 0.0;
+    if (gi < Ncap) {
+        if (S.live_cluster[gi] >= 0) { code = gi; const int src = S.slot_src[gi]; v = (src >= 0) ? S.babies[((size_t)src * nr + (nr - 1)) * nT + d] : S.live[(size_t)gi * nT + d]; }
+    } else { const int c = gi - Ncap; code = -(1 + c); v = S.babies[((size_t)c * nr + (nr - 1)) * nT + d]; }
+    S.nn_pts[e] = v;
+    if (d == 0) S.nn_code[gi] = code;
+}
+__global__ __launch_bounds__(256) void k_nn_gather(PcState S, int nleft) { nn_gather_body(S, nleft); }
+__global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R) { const PcManyRec &r = R[blockIdx.y]; nn_gather_body(r.S, r.ia[1]); }
+
+#define NND_SC 16                                   /* at most this many scanners per pair of babies */
+template <int D>
+__device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int tile_pts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DP = D | 1;                         // odd row stride: the scanners of a wave read different banks
+    const int tid = threadIdx.x, nr = S.nr, nT = S.nT, Ncap = S.Ncap;
+    const int w = blockIdx.x;                         // chain, w < nleft = entries still in the nursery
+    double *pts = (double *)smem;                     // [tile_pts][DP]
+    int *pcode = (int *)(pts + (size_t)tile_pts * DP);   // [tile_pts] code of each staged point, PC_NN_NONE = skip
+    double *md = (double *)smem;                      // [256][2][PC_NN_K] merge buffer: over the tile, once the last one has been scanned
+    int *mc = (int *)(md + 256 * 2 * PC_NN_K);        // [256][2][PC_NN_K]
+    if (w == 0) {                                     // liveness bookkeeping starts now
+        for (int s = tid; s < Ncap; s += 256) S.nn_slot_owner[s] = -1;
+        for (int c = tid; c < S.B; c += 256) S.nn_chain_slot[c] = -1;
+    }
+    const int nc = S.ctl->ncluster;
+    double Lg0 = S.logLp[0];
+    for (int c = 1; c < nc; ++c) Lg0 = fmin(Lg0, S.logLp[c]);
+    const double *blog = S.baby_logL + (size_t)w * nr;
+    const int ncand = nleft - 1 - w;                  // chains w+1 .. nleft-1 are consumed before w
+    const int npts = Ncap + ncand;
+    const int npair = (nr + 1) / 2;
+    const int PG = npair < 256 ? npair : 256;         // pairs per pass
+    const int nscan = (256 / PG) < NND_SC ? (256 / PG) : NND_SC;
+    const int pi = tid / nscan, p = tid - pi * nscan;
+    for (int pg0 = 0; pg0 < npair; pg0 += PG) {
+        const bool act = pi < PG && pg0 + pi < npair;
+        const int ia = 2 * (pg0 + pi), ib = ia + 1;
+        double xa[D], xb[D];
+        {
+            const double *ra = S.babies + ((size_t)w * nr + (act ? ia : 0)) * nT, *rb = S.babies + ((size_t)w * nr + ((act && ib < nr) ? ib : 0)) * nT;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { xa[d] = ra[d]; xb[d] = rb[d]; }
+        }
+        const bool minea = act && blog[ia] > Lg0;                 // the contour only rises: others never need a cluster
+        const bool mineb = act && ib < nr && blog[ib] > Lg0;
+        double bda[PC_NN_K], bdb[PC_NN_K]; int bca[PC_NN_K], bcb[PC_NN_K];
+#pragma unroll
+        for (int k = 0; k < PC_NN_K; ++k) { bda[k] = PC_HUGE; bdb[k] = PC_HUGE; bca[k] = PC_NN_NONE; bcb[k] = PC_NN_NONE; }
+        auto insert = [&](double (&bd)[PC_NN_K], int (&bc)[PC_NN_K], double d2, int code) __attribute__((always_inline)) {
+            if (d2 < bd[PC_NN_K - 1]) {                           // sorted insertion, registers only
+                double cd = d2; int cc = code;
+#pragma unroll
+                for (int k = 0; k < PC_NN_K; ++k) {
+                    const bool sw = cd < bd[k];
+                    const double td = sw ? bd[k] : cd; const int tc = sw ? bc[k] : cc;
+                    bd[k] = sw ? cd : bd[k]; bc[k] = sw ? cc : bc[k];
+                    cd = td; cc = tc;
+                }
+            }
+        };
+        for (int t0 = 0; t0 < npts; t0 += tile_pts) {
+            const int tn = min(tile_pts, npts - t0);
+            __syncthreads();
+            // point t0 + q of this chain's candidates = entry t0 + q of the gathered array, the chains up to w skipped
+            for (int q = tid; q < tn; q += 256) { const int gi = t0 + q; pcode[q] = S.nn_code[gi < Ncap ? gi : gi + w + 1]; }
+            for (int e = tid; e < tn * D; e += 256) {
+                const int q = e / D, d = e - q * D, gi = t0 + q;
+                pts[(size_t)q * DP + d] = S.nn_pts[(size_t)(gi < Ncap ? gi : gi + w + 1) * D + d];
+            }
+            __syncthreads();
+            if (minea || mineb) {
+                int q = p;
+                for (; q + nscan < tn; q += 2 * nscan) {          // two points at a time: four sums in flight
+                    const int c0 = pcode[q], c1 = pcode[q + nscan];
+                    const double *y0 = pts + (size_t)q * DP, *y1 = pts + (size_t)(q + nscan) * DP;
+                    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const double u0 = y0[d], u1 = y1[d];
+                        const double ta0 = xa[d] - u0, tb0 = xb[d] - u0, ta1 = xa[d] - u1, tb1 = xb[d] - u1;
+                        a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); a1 = fma(ta1, ta1, a1); b1 = fma(tb1, tb1, b1);
+                    }
+                    if (c0 != PC_NN_NONE) { if (minea) insert(bda, bca, a0, c0); if (mineb) insert(bdb, bcb, b0, c0); }
+                    if (c1 != PC_NN_NONE) { if (minea) insert(bda, bca, a1, c1); if (mineb) insert(bdb, bcb, b1, c1); }
+                }
+                if (q < tn) {
+                    const int c0 = pcode[q];
+                    const double *y0 = pts + (size_t)q * DP;
+                    double a0 = 0.0, b0 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) { const double u0 = y0[d]; const double ta0 = xa[d] - u0, tb0 = xb[d] - u0; a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); }
+                    if (c0 != PC_NN_NONE) { if (minea) insert(bda, bca, a0, c0); if (mineb) insert(bdb, bcb, b0, c0); }
+                }
+            }
+        }
+        // merge the partial lists of a baby: each is sorted, nscan-way pick by the pair's first scanner
+        __syncthreads();                              // (the merge buffer lies over the tile)
+#pragma unroll
+        for (int k = 0; k < PC_NN_K; ++k) {
+            md[(tid * 2 + 0) * PC_NN_K + k] = bda[k]; mc[(tid * 2 + 0) * PC_NN_K + k] = bca[k];
+            md[(tid * 2 + 1) * PC_NN_K + k] = bdb[k]; mc[(tid * 2 + 1) * PC_NN_K + k] = bcb[k];
+        }
+        __syncthreads();
+        if (act && p == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = ia + h;
+                if (i >= nr) continue;
+                const bool mine = h ? mineb : minea;
+                int head[NND_SC];
+#pragma unroll
+                for (int q = 0; q < NND_SC; ++q) head[q] = 0;
+                int out[PC_NN_K];
+#pragma unroll
+                for (int k = 0; k < PC_NN_K; ++k) {
+                    double best = PC_HUGE; int bq = -1;
+#pragma unroll
+                    for (int q = 0; q < NND_SC; ++q) {
+                        const double v = (q < nscan && head[q] < PC_NN_K) ? md[((tid + q) * 2 + h) * PC_NN_K + head[q]] : PC_HUGE;
+                        if (v < best) { best = v; bq = q; }
+                    }
+                    int code = PC_NN_NONE;
+#pragma unroll
+                    for (int q = 0; q < NND_SC; ++q) if (q == bq) { code = mc[((tid + q) * 2 + h) * PC_NN_K + head[q]]; head[q]++; }
+                    out[k] = mine ? code : PC_NN_NONE;
+                }
+                int4 *dst = (int4 *)(S.nn_list + ((size_t)w * nr + i) * PC_NN_K);
+                dst[0] = make_int4(out[0], out[1], out[2], out[3]);
+                dst[1] = make_int4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();
+    }
+}
+template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d(PcState S, int nleft, int tile_pts) { nn_lists_d_body<D>(S, nleft, tile_pts); }
+template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d_many(const PcManyRec *__restrict__ R, int tile_pts)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    if ((int)blockIdx.x >= r.ia[1]) return;
+    nn_lists_d_body<D>(r.S, r.ia[1], tile_pts);
+}
+static size_t nn_lists_d_lds(const PcState *S, int &tile)
+{
+    const int DP = S->D | 1;
+    const size_t merge = (sizeof(double) + sizeof(int)) * 256 * 2 * PC_NN_K;      // 48 KB, over the tile: three workgroups to a compute unit
+    tile = (int)((merge - 64) / (sizeof(double) * DP + sizeof(int)));
+    tile = tile < 32 ? 32 : (tile > 1024 ? 1024 : tile);
+    const size_t t = (sizeof(double) * DP + sizeof(int)) * (size_t)tile;
+    return (t > merge ? t : merge) + 64;
+}
+// nDims <= 32: the register kernel; dR == null: one run
+static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int nleft, hipStream_t st)
+{
+    static const bool off = std::getenv("PC_NN_LISTS_OLD") != nullptr;
+    if (off || S->D > 32 || S->D < 1) return 1;
+    int tile;
+    const size_t sh = nn_lists_d_lds(S, tile);
+    static std::atomic<size_t> done1[33], donem[33];
+    if (!S->nn_pts) return 1;
+    if (dR) hipLaunchKernelGGL(k_nn_gather_many, dim3(((S->Ncap + nleft) * S->D + 255) / 256, R), dim3(256), 0, st, dR);
+    else hipLaunchKernelGGL(k_nn_gather, dim3(((S->Ncap + nleft) * S->D + 255) / 256), dim3(256), 0, st, *S, nleft);
+    switch (S->D) {
+#define PC_NND(n) case n: \
+        if (dR) { if (sh > donem[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d_many<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donem[n].store(sh); } \
+                  hipLaunchKernelGGL(k_nn_lists_d_many<n>, dim3(nleft, R), dim3(256), sh, st, dR, tile); } \
+        else { if (sh > done1[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1[n].store(sh); } \
+               hipLaunchKernelGGL(k_nn_lists_d<n>, dim3(nleft), dim3(256), sh, st, *S, nleft, tile); } \
+        return 0;
+        PC_NND(1) PC_NND(2) PC_NND(3) PC_NND(4) PC_NND(5) PC_NND(6) PC_NND(7) PC_NND(8) PC_NND(9) PC_NND(10) PC_NND(11) PC_NND(12) PC_NND(13) PC_NND(14) PC_NND(15) PC_NND(16)
+        PC_NND(17) PC_NND(18) PC_NND(19) PC_NND(20) PC_NND(21) PC_NND(22) PC_NND(23) PC_NND(24) PC_NND(25) PC_NND(26) PC_NND(27) PC_NND(28) PC_NND(29) PC_NND(30) PC_NND(31) PC_NND(32)
+#undef PC_NND
+    }
+    return 1;
+}
+
 static size_t nn_lists_lds(const PcState *S, int &tile)
 {
     tile = (int)(24576 / (sizeof(double) * S->D));            // ~24 KB of coordinates per tile
@@ -256,6 +454,7 @@ static size_t nn_lists_lds(const PcState *S, int &tile)
 extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, hipStream_t st)
 {
     if (nleft <= 0) return;
+    if (nn_lists_d_dispatch(S, nullptr, 0, nleft, st) == 0) return;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
     static size_t done = 0;
@@ -265,6 +464,7 @@ extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, hipStream_t st)
 extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, int R, int nleft_max, hipStream_t st)
 {
     if (nleft_max <= 0) return 0;
+    if (nn_lists_d_dispatch(S, dR, R, nleft_max, st) == 0) return 0;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
     static size_t done = 0;
@@ -1225,7 +1425,8 @@ __global__ __launch_bounds__(256) void k_clean_scatter_many(const PcManyRec *R)
 }
 
 
-__global__ void k_reset_thresholds(PcState S) { if (threadIdx.x < S.maxc) S.death_thr[threadIdx.x] = -PC_HUGE; }
+__global__ void k_reset_thresholds(PcState S) { for (int c = threadIdx.x; c < S.maxc; c += blockDim.x) S.death_thr[c] = -PC_HUGE; }
+__global__ void k_reset_thresholds_many(const PcManyRec *__restrict__ R) { const PcState &S = R[blockIdx.y].S; for (int c = threadIdx.x; c < S.maxc; c += blockDim.x) S.death_thr[c] = -PC_HUGE; }
 
 // ------------------------------------------------------------------------------------------
 // update step 2: calculate_covmats (run_time_info.f90:601-641), two passes, fixed-order sums
@@ -1804,6 +2005,13 @@ extern "C" void pc_launch_clean(const PcState *S, int nph, unsigned char *keep, 
 extern "C" void pc_launch_reset_thresholds(const PcState *S, hipStream_t st)
 {
     hipLaunchKernelGGL(k_reset_thresholds, dim3(1), dim3(S->maxc <= 1024 ? ((S->maxc + 63) / 64) * 64 : 1024), 0, st, *S);
+}
+
+extern "C" int pc_launch_reset_thresholds_many(const PcState *S, const PcManyRec *dR, int R, hipStream_t st)
+{
+    (void)S;
+    hipLaunchKernelGGL(k_reset_thresholds_many, dim3(1, R), dim3(256), 0, st, dR);
+    return 0;
 }
 
 static int cov_use_mfma(const PcState *S) { return S->D >= 32; }

@@ -23,6 +23,9 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <functional>
+#include <exception>
+#include <ucontext.h>
 
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
@@ -37,6 +40,9 @@ int pc_launch_slice_many(const PcState *, const PcManyRec *, int, int, int, hipS
 int pc_launch_nhats_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
 int pc_launch_nn_lists_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
 int pc_launch_consume_cl_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
+int pc_launch_reset_thresholds_many(const PcState *, const PcManyRec *, int, hipStream_t);
+int pc_launch_knn_cluster_batch_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
+int pc_launch_knn_cluster_batch_dev(const PcState *, const int *, int, int, double *, int *, int *, int *, hipStream_t);
 int pc_launch_slice_t(const PcState *, unsigned, int, hipStream_t);
 int pc_bases_t_ok(const PcState *);
 int pc_launch_slice_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
@@ -50,6 +56,7 @@ int pc_launch_apply_many(const PcState *, const PcManyRec *, int, unsigned, int,
 int pc_launch_update_fused_many(const PcState *, const PcManyRec *, int, int, int, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
+void pc_launch_shift_mats(const PcState *, int, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
 int pc_fast_fits(const PcState *);
 int pc_par_fits(const PcState *);
@@ -398,7 +405,40 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
 //      ONE stream and go round by round together: what each engine would launch in a phase of the round it writes down here, and
 //      every kernel of the phase is launched ONCE for all of them (blockIdx.y = run, PcManyRec).  The same kernels' bodies on
 //      the same states: the numbers of a run do not know whether it ran alone.
-enum { CK_COMPACT = 0, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_FINAL, CK_N };      // (in the order they are launched)
+// ---- a run's host work that has to WAIT for the device in the middle (an update with clustering: counts down, verdicts back,
+//      splits) as a fiber of the thread that drives the runs in step: where a run on its own synchronises its stream, a run in step
+//      yields (Engine::sync_point); the driver goes through all the runs that have something to wait for, launches what they
+//      wrote down ONCE for all of them, waits ONCE, and resumes them.  The waits of sixteen runs' updates cost what one run's do,
+//      and the kernels between two waits are launched together.  (makecontext / swapcontext: no threads, no locks; an
+//      exception inside a fiber is caught at its foot and rethrown by the driver.)
+struct Fiber {
+    ucontext_t ctx, ret;
+    void *stack = nullptr; size_t stack_sz = 0;
+    std::function<void()> fn;
+    bool started = false, done = false;
+    std::exception_ptr err;
+    static void foot(unsigned lo, unsigned hi)
+    {
+        Fiber *f = (Fiber *)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        try { f->fn(); } catch (...) { f->err = std::current_exception(); }
+        f->done = true;
+        swapcontext(&f->ctx, &f->ret);
+    }
+    void resume()
+    {
+        if (!started) {
+            getcontext(&ctx);
+            ctx.uc_stack.ss_sp = stack; ctx.uc_stack.ss_size = stack_sz; ctx.uc_link = nullptr;
+            const uintptr_t a = (uintptr_t)this;
+            makecontext(&ctx, (void (*)())foot, 2, (unsigned)(a & 0xFFFFFFFFu), (unsigned)(a >> 32));
+            started = true;
+        }
+        swapcontext(&ret, &ctx);
+    }
+    void yield() { swapcontext(&ctx, &ret); }
+};
+
+enum { CK_COMPACT = 0, CK_RESET, CK_CLUS1, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_COV, CK_FINAL, CK_N };      // (in the order they are launched)
 // (_G: any device likelihood, the wavefront-per-chain kernels of a run on its own with the run in the grid; NN / CONSUME_CL: runs with several clusters)
 struct Cohort {
     hipStream_t st = nullptr;
@@ -423,6 +463,8 @@ struct Cohort {
     // kernels use: a copy stream per run came from the pool, on whatever queue -- and where copies are shader blits (the HIP runtime
     // PyTorch ships: 48 us each) a round's kernels queued behind them
     hipStream_t stc[2] = {nullptr, nullptr}; int n_stc = 0;
+    // copies to the host that belong behind what has been written down: made at the end of flush(), in the order they were asked for
+    std::vector<std::function<void()>> post;
     void rec(int kind, const PcState &S, std::initializer_list<void *> p, std::initializer_list<long long> a, std::initializer_list<int> ia)
     {
         pend.emplace_back();
@@ -441,6 +483,8 @@ struct Cohort {
         case CK_NHATS_G: (void)pc_launch_nhats(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_SLICE_G: if (r.a[1]) (void)pc_launch_slice_fused(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); else (void)pc_launch_slice(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_NN: pc_launch_nn_lists(&r.S, r.ia[1], st); break;
+        case CK_RESET: pc_launch_reset_thresholds(&r.S, st); break;
+        case CK_CLUS1: (void)pc_launch_knn_cluster_batch_dev(&r.S, (const int *)r.p[0], r.ia[1], r.ia[2], (double *)r.p[1], (int *)r.p[2], (int *)r.p[3], (int *)r.p[4], st); break;
         case CK_CONSUME_CL: (void)pc_launch_consume_cl(&r.S, r.a[0] ? 65 : 2, st); break;
         case CK_SORT: (void)pc_launch_sort_live(&r.S, st); break;
         case CK_CONSUME: (void)pc_launch_consume_par(&r.S, st); break;
@@ -450,9 +494,10 @@ struct Cohort {
                                                (unsigned *)r.p[5], (unsigned long long *)r.p[6], (double *)r.p[7], (double *)r.p[8], (int)r.a[1], st); break;
         }
     }
+    void run_post() { if (post.empty()) return; std::vector<std::function<void()>> p; p.swap(post); for (auto &f : p) f(); }
     void flush()
     {
-        if (pend.empty()) return;
+        if (pend.empty()) { run_post(); return; }
         const size_t n = pend.size();
         if (n > cap) {
             for (int k = 0; k < RING; ++k) {
@@ -508,6 +553,8 @@ struct Cohort {
             case CK_SLICE_G: rc = pc_launch_slice_many(&f.S, d, cnt, (int)f.a[0], (int)f.a[1], q); break;
             case CK_NN: { int nl = 0; for (size_t x = i; x < j; ++x) nl = std::max(nl, ord[x]->ia[1]); rc = pc_launch_nn_lists_many(&f.S, d, cnt, nl, q); } break;
             case CK_CONSUME_CL: rc = pc_launch_consume_cl_many(&f.S, d, cnt, (int)f.a[0], q); break;
+            case CK_RESET: rc = pc_launch_reset_thresholds_many(&f.S, d, cnt, q); break;
+            case CK_CLUS1: { int ndm = 0, nmx = 0; for (size_t x = i; x < j; ++x) { ndm = std::max(ndm, ord[x]->ia[1]); nmx = std::max(nmx, ord[x]->ia[2]); } rc = pc_launch_knn_cluster_batch_many(&f.S, d, cnt, ndm, nmx, q); } break;
             case CK_SORT: rc = pc_launch_sort_live_many(&f.S, d, cnt, q); break;
             case CK_CONSUME: rc = pc_launch_consume_par_many(&f.S, d, cnt, q); break;
             case CK_FINAL: rc = pc_launch_final_par_many(d, cnt, q); break;
@@ -522,6 +569,7 @@ struct Cohort {
         HIPCHK(hipEventRecord(ev[slot], st)); ev_used[slot] = true;
         if (used_st2 && ev2[slot]) { HIPCHK(hipEventRecord(ev2[slot], st2)); ev2_used[slot] = true; }
         pend.clear();
+        run_post();
     }
     void destroy()
     {
@@ -542,6 +590,7 @@ struct Cohort {
 static std::atomic<long long> g_dbg_compact_ns{0}, g_dbg_nursery_ns{0}, g_dbg_capacity_ns{0}, g_dbg_endb_ns{0}, g_dbg_destroy_ns{0}, g_dbg_evwait_ns{0}, g_dbg_d1{0}, g_dbg_d2{0};      // (PC_DEBUG=5: where round_enqueue's time goes)
 struct Engine {
     Cohort *co = nullptr;               // not null: this run goes in step with others of its device, on their common stream
+    Fiber *fib = nullptr;               // not null: this call runs as a fiber of the thread that drives the runs in step (waits are shared)
     pchip_settings cfg{};
     std::atomic<int> stop{0};                   // polychord_hip_request_stop reached this run
     polychord_batch_fn batch_fn = nullptr; void *batch_user = nullptr;     // the batch callback registered when the run was set up
@@ -753,9 +802,10 @@ struct Engine {
             upload(d_logn, ln.data(), sizeof(double) * ln.size());
             S.logn = d_logn;
         }
-        S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_valid = 0;
+        S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_pts = nullptr; S.nn_code = nullptr; S.nn_valid = 0;
         if (c.do_clustering) {      // candidate lists of the nearest-cluster search (k_nn_lists)
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
+            S.nn_pts = dalloc<double>((size_t)(Ncap + B) * D); S.nn_code = dalloc<int>((size_t)Ncap + B);
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         static const bool ms_off = std::getenv("PC_MS_PRE_OFF") != nullptr;
@@ -816,17 +866,62 @@ struct Engine {
             for (int g = 0; g < PC_MAX_GRADE; ++g) nlike_g[g] += h_nlike_g[(size_t)w * PC_MAX_GRADE + g];
     }
 
-    void read_ctl()
+    // ---- waiting for the device.  A run on its own synchronises its stream; a run in step, inside a fiber, yields to the driver,
+    //      which launches what all runs have written down, waits once for all of them and resumes them (pc_run_cohort)
+    void sync_point()
     {
+        if (fib) { fib->yield(); return; }
         if (co) co->flush();
-        HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));
         // (polling the stream wakes the host a few microseconds after the copy; the blocking wait sleeps on an interrupt)
         for (int spins = 0; spins < 200000; ++spins) { const hipError_t q = hipStreamQuery(st); if (q != hipErrorNotReady) { HIPCHK(q); break; } __builtin_ia32_pause(); }
         HIPCHK(hipStreamSynchronize(st));
+    }
+    // something launched here and now, behind whatever the runs in step have written down so far
+    void direct_op() { if (co) co->flush(); }
+    // device -> host, through a pinned block, in stream order behind everything asked for so far; the values are there after fetch_wait()
+    struct Fetch { void *h; void *dst; size_t bytes; };
+    std::vector<Fetch> fetching;
+    void fetch_raw(void *dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return;
+        void *h = halloc<char>(bytes);
+        fetching.push_back({h, dst, bytes});
+        hipStream_t q = st;
+        if (co) co->post.push_back([h, src, bytes, q] { HIPCHK(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, q)); });
+        else HIPCHK(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, st));
+    }
+    template <class T> void fetch(std::vector<T> &v, const T *p, size_t n) { v.resize(n); fetch_raw(v.data(), p, sizeof(T) * n); }
+    void fetch_wait()
+    {
+        sync_point();
+        for (const Fetch &f : fetching) { std::memcpy(f.dst, f.h, f.bytes); hfree(f.h); }
+        fetching.clear();
+        for (void *h : staged_up) hfree(h);
+        staged_up.clear();
+    }
+    // host -> device, through a pinned block, in stream order (the block goes back at the next wait)
+    std::vector<void *> staged_up;
+    void send_raw(void *dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return;
+        direct_op();
+        void *h = halloc<char>(bytes);
+        staged_up.push_back(h);
+        std::memcpy(h, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st));
+    }
+
+    void read_ctl()
+    {
+        fetch_raw(h_ctl_in(), S.ctl, sizeof(PcCtl));
+        fetch_wait();
+        *h_ctl = ctl_in;
         HIPCHK(hipGetLastError());                    // a kernel that could not be launched must not go unnoticed
         nph_stale = false;
         kt.collect();                                 // (the stream is idle: every open span is complete)
     }
+    PcCtl ctl_in;
+    PcCtl *h_ctl_in() { return &ctl_in; }
 
     // The outcome of a round without a copy and without a stream synchronisation: the contraction kernel stamps the
     // host mirror when it is done.  The row copies of the round (k_apply_*) may still be running when this returns;
@@ -1148,7 +1243,9 @@ struct Engine {
         tm.updates += deferred ? std::max(1, h_ctl->upd_marks) : 1;
         // the round loop only sees the compact notification; whoever looks at evidences, counters or cluster ids gets the block
         const bool seq_post = S.seq_mode && (cfg.posteriors || cfg.equals);
-        if (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
+        // (clustering alone: the block comes with the counts below, in the same wait)
+        const bool ctl_late = cfg.do_clustering && !(dumper || on_update || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post);
+        if (!ctl_late && (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post)) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
         call_dumper();
         const int nph = S.pool ? (int)pool_cursor : h_ctl->nphantom;
         static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
@@ -1167,10 +1264,11 @@ struct Engine {
             else pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
             kt.end(KT_CLEAN, e0);
             if (cfg.resume_write || dumper || on_update || seq_post) {
-                if (co) co->flush();      // (in step with other runs the update was only written down: launched now, before its count is read)
-                int total = nph;
-                HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                // (in step with other runs the update was only written down: the copy of its count comes behind its launch)
+                std::vector<int> tot;
+                fetch(tot, (const int *)d_total, 1);
+                fetch_wait();
+                const int total = tot[0];
                 h_ctl->nphantom = total;
                 if (seq_post) seq_consume((unsigned long long)(nph - total));
             } else nph_stale = true;
@@ -1180,7 +1278,9 @@ struct Engine {
         }
         if (deferred) engine_fail(PC_RC_DEVICE, "deferred update without the fused update path");
         hipEvent_t e0 = kt.begin(KT_CLEAN);
-        pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st);
+        // (in step with other runs: the clean of all runs that update in this round is one launch, like the pool compaction)
+        if (co && nph > 0) co->rec(CK_COMPACT, S, {keep, blk, d_total, ph2, phL2, phC2, phU2}, {}, {0, nph, (nph + 255) / 256});
+        else { direct_op(); pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st); }
         kt.end(KT_CLEAN, e0);
         if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals)) collect_phantom_posteriors(nph);
         // The surviving count is written to the control block on the device.  Without clustering / resume files
@@ -1188,15 +1288,22 @@ struct Engine {
         // covariance grid is sized with the pre-clean count and the kernels clamp to the device value.
         const bool need_count = cfg.do_clustering || cfg.resume_write || dumper || on_update || cfg.boost_posterior != 0.0 || seq_post;
         int total = nph;
+        std::vector<int> tot, cn;
         if (need_count) {
-            HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            h_ctl->nphantom = total;
-            if (seq_post) seq_consume((unsigned long long)(nph - total));
+            fetch(tot, (const int *)d_total, 1);
+            if (cfg.do_clustering) fetch(cn, (const int *)S.cl_n, (size_t)h_ctl->ncluster);      // (the clusters' sizes for do_clustering: the same wait)
+            if (ctl_late) fetch_raw(&ctl_in, S.ctl, sizeof(PcCtl));
         } else nph_stale = true;
         std::swap(S.phantom, ph2); std::swap(S.ph_logL, phL2); std::swap(S.ph_cuid, phC2); std::swap(S.ph_uid, phU2);
-        pc_launch_reset_thresholds(&S, st);
-        if (cfg.do_clustering) { HIPCHK(hipStreamSynchronize(st)); do_clustering(); }
+        if (co) co->rec(CK_RESET, S, {}, {}, {}); else pc_launch_reset_thresholds(&S, st);
+        if (need_count) {
+            fetch_wait();
+            if (ctl_late) { const int st_keep = h_ctl->status; *h_ctl = ctl_in; h_ctl->status = st_keep; nph_stale = false; }
+            total = tot[0];
+            h_ctl->nphantom = total;
+            if (seq_post) seq_consume((unsigned long long)(nph - total));
+        }
+        if (cfg.do_clustering) do_clustering(cn);
         hipEvent_t e1 = kt.begin(KT_COV);
         covmats(total, h_ctl->ncluster);
         kt.end(KT_COV, e1);
@@ -1224,12 +1331,14 @@ struct Engine {
         const int m = (int)gidx.size();
         labels.assign(m, 1);
         if (m <= 1) return 1;
-        HIPCHK(hipMemcpyAsync(c_gidx, gidx.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+        send_raw(c_gidx, gidx.data(), sizeof(int) * m);
+        direct_op();
         if (pc_launch_knn_cluster(c_Sm, nroot, c_gidx, m, c_knn, c_lab, c_out, st)) engine_fail(PC_RC_LDS, "cluster of %d points too large for the LDS kNN sort", m);
-        int num = 0;
-        HIPCHK(hipMemcpyAsync(labels.data(), c_lab, sizeof(int) * m, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&num, c_out, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> numv;
+        fetch_raw(labels.data(), c_lab, sizeof(int) * m);
+        fetch(numv, (const int *)c_out, 1);
+        fetch_wait();
+        int num = numv[0];
         if (num > 1) {
             int ic = 1;
             while (ic <= num) {
@@ -1254,13 +1363,15 @@ struct Engine {
         c_cnt = dalloc<int>(S.maxc); c_olduid = dalloc<unsigned>(S.maxc);
     }
 
+    // (in stream order, through pinned blocks: a run in step shares the wait with the others)
     template <class T> std::vector<T> dl(const T *p, size_t n)
     {
-        std::vector<T> v(n);
-        HIPCHK(hipMemcpy(v.data(), p, sizeof(T) * n, hipMemcpyDeviceToHost));
+        std::vector<T> v;
+        fetch(v, p, n);
+        fetch_wait();
         return v;
     }
-    template <class T> void ul(T *p, const std::vector<T> &v) { if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice)); }
+    template <class T> void ul(T *p, const std::vector<T> &v) { send_raw(p, v.data(), sizeof(T) * v.size()); }
 
     // add_cluster (run_time_info.f90:303-505): cluster p splits into nnew clusters appended at the end
     void add_cluster(int p, const std::vector<int> &labels, int nnew)
@@ -1270,7 +1381,13 @@ struct Engine {
         if (ncn > S.maxc) grow_clusters(ncn);
         const int maxc = S.maxc;
         nsplits++;
-        auto lc = dl(S.live_cluster, Ncap); auto lp = dl(S.live_pos, Ncap);
+        // everything the host's half of the split reads, in ONE wait (a run in step shares it with the others)
+        std::vector<int> lc, lp; std::vector<double> Xp, ZXp, Zp, Zp2, ZpXp, thr, XQ; std::vector<unsigned> uid;
+        fetch(lc, (const int *)S.live_cluster, Ncap); fetch(lp, (const int *)S.live_pos, Ncap);
+        fetch(Xp, (const double *)S.logXp, maxc); fetch(ZXp, (const double *)S.logZXp, maxc); fetch(Zp, (const double *)S.logZp, maxc); fetch(Zp2, (const double *)S.logZp2, maxc);
+        fetch(ZpXp, (const double *)S.logZpXp, maxc); fetch(thr, (const double *)S.death_thr, maxc); fetch(XQ, (const double *)S.XpXq, (size_t)maxc * maxc);
+        fetch(uid, (const unsigned *)S.cl_uid, maxc);
+        fetch_wait();
         // position of every split point inside its new cluster = rank among equal labels in list order
         std::vector<int> posnew(labels.size()), cnt(nnew, 0);
         for (size_t a = 0; a < labels.size(); ++a) posnew[a] = cnt[labels[a] - 1]++;
@@ -1282,11 +1399,8 @@ struct Engine {
         }
         ul(S.live_cluster, lc); ul(S.live_pos, lp);
         // per-cluster state: old clusters keep their order at 0..nold-1 (old_save/old_target, :371-376)
-        auto Xp = dl(S.logXp, maxc), ZXp = dl(S.logZXp, maxc), Zp = dl(S.logZp, maxc), Zp2 = dl(S.logZp2, maxc),
-             ZpXp = dl(S.logZpXp, maxc), thr = dl(S.death_thr, maxc), XQ = dl(S.XpXq, (size_t)maxc * maxc);
-        auto uid = dl(S.cl_uid, maxc);
         std::vector<unsigned> olduid(uid.begin(), uid.begin() + nc);
-        HIPCHK(hipMemcpy(c_olduid, olduid.data(), sizeof(unsigned) * nc, hipMemcpyHostToDevice));
+        send_raw(c_olduid, olduid.data(), sizeof(unsigned) * nc);
         const double logXp = Xp[p], logXp2 = XQ[(size_t)p * maxc + p], logZp = Zp[p], logZp2 = Zp2[p], logZXp = ZXp[p], logZpXp = ZpXp[p];
         std::vector<double> rowpq;
         for (int q = 0; q < nc; ++q) if (q != p) rowpq.push_back(XQ[(size_t)p * maxc + q]);
@@ -1297,18 +1411,18 @@ struct Engine {
             std::vector<double> t(XQ);
             for (int a = 0, na = 0; a < nc; ++a) { if (a == p) continue; for (int b = 0, nb = 0; b < nc; ++b) { if (b == p) continue; XQ[(size_t)na * maxc + nb] = t[(size_t)a * maxc + b]; nb++; } na++; }
         }
-        const int DD = S.D * S.D;
-        for (int c = p; c < nc - 1; ++c) {
-            HIPCHK(hipMemcpy(S.chol + (size_t)c * DD, S.chol + (size_t)(c + 1) * DD, sizeof(double) * DD, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(S.cov + (size_t)c * DD, S.cov + (size_t)(c + 1) * DD, sizeof(double) * DD, hipMemcpyDeviceToDevice));
-        }
+        // (the Cholesky factors and covariances of the clusters behind p move up a block: one launch, not two copies per cluster)
+        direct_op();
+        pc_launch_shift_mats(&S, p, nc, st);
         for (int k = 0; k < nnew; ++k) { uid[nold + k] = h_ctl->next_cluster_uid++; thr[nold + k] = -PC_HUGE; }
         ul(S.cl_uid, uid); ul(S.death_thr, thr);
         // lists, contours, live log-sum-exp of every cluster; then the phantoms find their new homes
+        direct_op();
         pc_launch_rebuild(&S, ncn, st);
         pc_launch_ph_rehome(&S, h_ctl->nphantom, ncn, c_olduid, nc, c_cnt, st);
-        HIPCHK(hipStreamSynchronize(st));
-        auto nph = dl(c_cnt, ncn); auto nlv = dl(S.cl_n, ncn);
+        std::vector<int> nph, nlv;
+        fetch(nph, (const int *)c_cnt, ncn); fetch(nlv, (const int *)S.cl_n, ncn);
+        fetch_wait();
         // 5) evidences and volumes split in proportion to nlive + nphantom (:458-503)
         std::vector<double> logni(nnew), logni1(nnew);
         for (int k = 0; k < nnew; ++k) { logni[k] = std::log((double)(nlv[nold + k] + nph[nold + k]) + 0.0); logni1[k] = std::log((double)(nlv[nold + k] + nph[nold + k]) + 1.0); }
@@ -1338,13 +1452,14 @@ struct Engine {
     // counts down and the verdicts back: two host waits per update); a cluster in which the pass finds more than one group
     // goes through the per-cluster path with its recursion and add_cluster, in the reference's order
     int *c_desc = nullptr, *c_bout = nullptr; int c_desc_cap = 0;
-    bool do_clustering()
+    bool do_clustering(std::vector<int> cn = std::vector<int>())
     {
         ensure_cluster_scratch();
         bool found = false;
         const int nold = h_ctl->ncluster;
         if (c_desc_cap < nold) { dfree(c_desc); dfree(c_bout); c_desc_cap = std::max(2 * nold, 64); c_desc = dalloc<int>((size_t)4 * c_desc_cap); c_bout = dalloc<int>(c_desc_cap); }
-        std::vector<int> cn = dl(S.cl_n, (size_t)nold), desc, verdict(nold, 1);
+        if ((int)cn.size() != nold) cn = dl(S.cl_n, (size_t)nold);
+        std::vector<int> desc, verdict(nold, 1);
         {
             int o1 = 0; long long o2 = 0;
             std::vector<int> which;
@@ -1353,11 +1468,15 @@ struct Engine {
             const int nd = (int)which.size();
             static const bool batch_off = std::getenv("PC_CLUSTER_BATCH_OFF") != nullptr;
             if (nd > 0 && !batch_off && o2 <= (long long)c_cap * c_cap) {
-                HIPCHK(hipMemcpyAsync(c_desc, desc.data(), sizeof(int) * desc.size(), hipMemcpyHostToDevice, st));
-                if (pc_launch_knn_cluster_batch(&S, desc.data(), c_desc, nd, c_Sm, c_knn, c_lab, c_bout, st)) engine_fail(PC_RC_LDS, "a cluster too large for the LDS kNN sort");
-                std::vector<int> out(nd);
-                HIPCHK(hipMemcpyAsync(out.data(), c_bout, sizeof(int) * nd, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                send_raw(c_desc, desc.data(), sizeof(int) * desc.size());
+                int nmax1 = 0;
+                for (int k = 0; k < nd; ++k) nmax1 = std::max(nmax1, desc[4 * k + 1]);
+                // (in step with other runs: the first pass of all runs that update in this round in three launches)
+                if (co) co->rec(CK_CLUS1, S, {c_desc, c_Sm, c_knn, c_lab, c_bout}, {}, {0, nd, nmax1});
+                else if (pc_launch_knn_cluster_batch(&S, desc.data(), c_desc, nd, c_Sm, c_knn, c_lab, c_bout, st)) engine_fail(PC_RC_LDS, "a cluster too large for the LDS kNN sort");
+                std::vector<int> out;
+                fetch(out, (const int *)c_bout, (size_t)nd);
+                fetch_wait();
                 for (int k = 0; k < nd; ++k) verdict[which[k]] = out[k];
             } else for (int c = 0; c < nold; ++c) verdict[c] = cn[c] > 2 ? 2 : 1;      // (no first pass: look at every cluster)
         }
@@ -1366,6 +1485,7 @@ struct Engine {
             if (ic >= h_ctl->ncluster) break;
             const int n = cn[j];
             if (n > 2 && verdict[j] > 1) {
+                direct_op();
                 HIPCHK(hipMemcpyAsync(c_pts, S.cl_list + (size_t)ic * S.Ncap, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
                 pc_launch_similarity(&S, c_pts, n, c_Sm, st);
                 std::vector<int> gidx(n), labels;
@@ -1378,7 +1498,7 @@ struct Engine {
         if (found) {
             h_ctl->admin_epoch++;
             h_ctl->status = PC_ST_RUNNING;
-            HIPCHK(hipMemcpy(S.ctl, h_ctl, sizeof(PcCtl), hipMemcpyHostToDevice));
+            send_raw(S.ctl, h_ctl, sizeof(PcCtl));
         }
         return found;
     }
@@ -1393,6 +1513,7 @@ struct Engine {
             pcov = dalloc<double>(cov_chunks_cap * S.D * S.D);
             mean = dalloc<double>((size_t)S.maxc * S.D); count = dalloc<int>(S.maxc);
         }
+        direct_op();
         if (pc_launch_covmats(&S, nph, nc, psum, pcnt, mean, count, pcov, st)) {
             engine_fail(PC_RC_LDS, "covariance tile exceeds LDS (nDims too large)");
         }
@@ -2074,6 +2195,13 @@ struct Engine {
         return true;
     }
 
+    // will round_finish wait for the device (an update that is not merely written down)?
+    bool finish_may_wait() const
+    {
+        const bool upd = h_ctl->status == PC_ST_UPDATE || (h_ctl->upd_pending && h_ctl->status == PC_ST_RUNNING);
+        return upd && (cfg.do_clustering || dumper || on_update || cfg.resume_write || cfg.boost_posterior != 0.0 || S.seq_mode || h_ctl->ncluster > 1 ||
+                       !pc_update_fused_ok(&S, h_ctl->ncluster));
+    }
     // what the round did, once its stamp is in; false: the loop is over
     bool round_finish()
     {
@@ -2266,7 +2394,11 @@ struct Engine {
         if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
         dfree(upd_part); dfree(upd_shift); upd_part_cap = 0;
         dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
-        dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot);
+        for (void *h : staged_up) hfree(h);
+        staged_up.clear();
+        for (const Fetch &f : fetching) hfree(f.h);
+        fetching.clear();
+        dfree(d_logn); dfree(S.ch_nlike_g); dfree(S.nn_list); dfree(S.nn_slot_owner); dfree(S.nn_chain_slot); dfree(S.nn_pts); dfree(S.nn_code);
         unsigned **uu[] = { &S.cl_uid, &S.ph_cuid, &S.dead_cuid, &phC2, &S.cl_uid_dead };
         for (auto p : uu) dfree(*p);
         dfree(S.ph_uid); dfree(S.sort_key); dfree(S.plan); dfree(phU2); dfree(keep); dfree(S.ctl);
@@ -2439,7 +2571,9 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         std::vector<Engine *> E((size_t)n, nullptr);
         std::vector<char> live((size_t)n, 0), enq((size_t)n, 0);
         const auto T0 = std::chrono::steady_clock::now();
-        long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0;
+        long rounds = 0; double t_begin = 0, t_end = 0, t_wait = 0, t_enq = 0, t_fin = 0, t_fl = 0, t_comp = 0, t_end_dev = 0, t_fwait = 0; long n_fwait = 0;
+        static const bool fibers_on = !(std::getenv("PC_COHORT_FIBERS") && std::atoi(std::getenv("PC_COHORT_FIBERS")) == 0);
+        std::vector<Fiber> fibs;
         int *h_totals = nullptr; size_t totals_cap = 0;
         double t_setup_max = 0; int n_comp_pass = 0;
         struct EndBatch { std::vector<int> fin, rcs; hipEvent_t ev = nullptr, ev2 = nullptr; int dev = 0; std::thread th; };
@@ -2522,7 +2656,48 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 { const auto a0 = nowc(); for (int k = 0; k < n; ++k) enq[k] = (live[k] && E[k]->round_enqueue()) ? 1 : 0; const auto a1 = nowc(); t_enq += secc(a0, a1);
                   co.flush(); t_fl += secc(a1, nowc()); }
                 { const auto w0 = nowc(); for (int k = 0; k < n; ++k) if (enq[k]) while (!E[k]->round_ready()) __builtin_ia32_pause(); t_wait += secc(w0, nowc()); }
-                { const auto a0 = nowc(); for (int k = 0; k < n; ++k) if (enq[k] && !E[k]->round_finish()) enq[k] = 0; const auto a1 = nowc(); t_fin += secc(a0, a1);
+                { const auto a0 = nowc();
+                  // what the round did: a run whose update has to wait for the device in the middle (clustering, files, hooks) makes it as a
+                  // fiber of this thread; the others at once
+                  std::vector<int> wk;
+                  for (int k = 0; k < n; ++k) {
+                      if (!enq[k]) continue;
+                      if (fibers_on && E[k]->finish_may_wait()) wk.push_back(k);
+                      else if (!E[k]->round_finish()) enq[k] = 0;
+                  }
+                  if (!wk.empty()) {
+                      if (fibs.size() < wk.size()) fibs.resize(wk.size());
+                      std::vector<char> ok(wk.size(), 1);
+                      for (size_t a = 0; a < wk.size(); ++a) {
+                          Fiber &f = fibs[a];
+                          if (!f.stack) { f.stack_sz = (size_t)1 << 20; f.stack = std::malloc(f.stack_sz); if (!f.stack) throw std::bad_alloc(); }
+                          f.started = false; f.done = false; f.err = nullptr;
+                          Engine *e = E[wk[a]]; char *okp = &ok[a];
+                          f.fn = [e, okp] { *okp = e->round_finish() ? 1 : 0; };
+                          e->fib = &f;
+                      }
+                      std::exception_ptr first_err;
+                      for (;;) {
+                          bool waiting = false;
+                          for (size_t a = 0; a < wk.size(); ++a) {
+                              Fiber &f = fibs[a];
+                              if (f.done) continue;
+                              f.resume();
+                              if (f.err && !first_err) first_err = f.err;
+                              if (!f.done) waiting = true;
+                          }
+                          if (first_err || !waiting) break;
+                          // one launch of what they all wrote down, one wait for all of them
+                          const auto w0 = nowc();
+                          co.flush();
+                          for (int spins = 0; spins < 200000; ++spins) { const hipError_t q = hipStreamQuery(co.st); if (q != hipErrorNotReady) { HIPCHK(q); break; } __builtin_ia32_pause(); }
+                          HIPCHK(hipStreamSynchronize(co.st));
+                          t_fwait += secc(w0, nowc()); n_fwait++;
+                      }
+                      for (size_t a = 0; a < wk.size(); ++a) { E[wk[a]]->fib = nullptr; if (!ok[a]) enq[wk[a]] = 0; }
+                      if (first_err) std::rethrow_exception(first_err);      // (the fibers still suspended are dropped with their stacks)
+                  }
+                  const auto a1 = nowc(); t_fin += secc(a0, a1);
                   co.flush(); t_fl += secc(a1, nowc()); }
                 rounds++;
                 bool any_done = false;
@@ -2602,6 +2777,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f in %d passes, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, n_comp_pass, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
+        for (Fiber &f : fibs) { std::free(f.stack); f.stack = nullptr; }
+        if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: of finish: %ld shared waits, %.2f ms\n", n_fwait, t_fwait * 1e3);
         co.destroy();
         if (h_totals) hfree(h_totals);
         (void)hipStreamSynchronize(co.st);

@@ -153,6 +153,9 @@ struct PcState {
     int *nn_list;                // [B][nr][PC_NN_K]
     int *nn_slot_owner;          // [Ncap] -1: occupant of T0 still there; -2: emptied since; w >= 0: last baby of chain w
     int *nn_chain_slot;          // [B] slot the chain's last baby went to since T0, or -1
+    double *nn_pts;              // [Ncap + B][D] the points a baby can be nearest to, gathered once per nursery (k_nn_gather): live slots as occupied at T0,
+                                 //   then the last baby of every chain still in the nursery
+    int *nn_code;                // [Ncap + B] their codes (slot, -(1 + chain), PC_NN_NONE for an empty slot)
     int nn_valid;                // set by the host for the launches after T0 of the same nursery
     int ablate;                  // developer / bench switches (bit mask), 0 in production: bit 0 = the built-in quadratic-form
                                  // likelihoods are evaluated like any device functor (one reduction per trial) instead of in closed form
