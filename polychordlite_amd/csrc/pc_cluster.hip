@@ -340,7 +340,76 @@ __global__ __launch_bounds__(1024) void k_nn_cluster_b_many(const PcManyRec *__r
     nn_cluster_body((const int *)r.p[2] + d.off2, d.n, (int *)r.p[3] + d.off1, (int *)r.p[4] + blockIdx.x);
 }
 
+// One level of NN_clustering's recursion for many parts at once (Engine::refine_partitions): part b = m points of a cluster, given by
+// their positions in the cluster's point order (pool + ioff), clustered on the sub-matrix of the cluster's similarity block the first
+// pass left at Sm + off2 (n x n).  Descriptor: {off2, n, ioff, m, koff}: its neighbour lists go to knn + koff (m x m), its labels to
+// labels + ioff, the number of clusters found to out[b].
+struct SubDesc { int off2, n, ioff, m, koff; };
+__global__ __launch_bounds__(256) void k_knn_sort_sub(const SubDesc *desc, const double *Sm, const int *pool, int *knn)
+{
+    const SubDesc d = desc[blockIdx.y];
+    if ((int)blockIdx.x >= d.m) return;
+    int npow2 = 2;
+    while (npow2 < d.m) npow2 <<= 1;
+    knn_sort_body(Sm + d.off2, d.n, pool + d.ioff, d.m, npow2, knn + d.koff);
+}
+__global__ __launch_bounds__(1024) void k_nn_cluster_sub(const SubDesc *desc, const int *knn, int *labels, int *out)
+{
+    const SubDesc d = desc[blockIdx.x];
+    nn_cluster_body(knn + d.koff, d.m, labels + d.ioff, out + blockIdx.x);
+}
+// ... for several runs in step (PcManyRec::p: 0 descriptors, 1 similarity blocks, 2 pool, 3 neighbour lists, 4 labels, 5 verdicts; ia[1] parts)
+__global__ __launch_bounds__(256) void k_knn_sort_sub_many(const PcManyRec *__restrict__ R)
+{
+    const PcManyRec &r = R[blockIdx.z];
+    if ((int)blockIdx.y >= r.ia[1]) return;
+    const SubDesc d = ((const SubDesc *)r.p[0])[blockIdx.y];
+    if ((int)blockIdx.x >= d.m) return;
+    int npow2 = 2;
+    while (npow2 < d.m) npow2 <<= 1;
+    knn_sort_body((const double *)r.p[1] + d.off2, d.n, (const int *)r.p[2] + d.ioff, d.m, npow2, (int *)r.p[3] + d.koff);
+}
+__global__ __launch_bounds__(1024) void k_nn_cluster_sub_many(const PcManyRec *__restrict__ R)
+{
+    const PcManyRec &r = R[blockIdx.y];
+    if ((int)blockIdx.x >= r.ia[1]) return;
+    const SubDesc d = ((const SubDesc *)r.p[0])[blockIdx.x];
+    nn_cluster_body((const int *)r.p[3] + d.koff, d.m, (int *)r.p[4] + d.ioff, (int *)r.p[5] + blockIdx.x);
+}
+
 extern "C" {
+
+static int sub_lds(int mmax, size_t &sh, size_t &sh2)
+{
+    int npow2 = 2;
+    while (npow2 < mmax) npow2 <<= 1;
+    sh = (size_t)npow2 * 12; sh2 = (size_t)mmax * 12 + 64;
+    return (sh > 160 * 1024 || sh2 > 150 * 1024) ? 1 : 0;
+}
+int pc_launch_knn_cluster_sub(const int *d_desc, int nb, int mmax, const double *Sm, const int *pool, int *knn, int *labels, int *out, hipStream_t st)
+{
+    if (nb <= 0) return 0;
+    size_t sh, sh2;
+    if (sub_lds(mmax, sh, sh2)) return 1;
+    static size_t d1 = 0, d2 = 0;
+    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
+    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    hipLaunchKernelGGL(k_knn_sort_sub, dim3(mmax, nb), dim3(256), sh, st, (const SubDesc *)d_desc, Sm, pool, knn);
+    hipLaunchKernelGGL(k_nn_cluster_sub, dim3(nb), dim3(1024), sh2, st, (const SubDesc *)d_desc, (const int *)knn, labels, out);
+    return 0;
+}
+int pc_launch_knn_cluster_sub_many(const PcManyRec *dR, int R, int nb_max, int mmax, hipStream_t st)
+{
+    if (nb_max <= 0) return 0;
+    size_t sh, sh2;
+    if (sub_lds(mmax, sh, sh2)) return 1;
+    static size_t d1 = 0, d2 = 0;
+    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_sub_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
+    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_sub_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    hipLaunchKernelGGL(k_knn_sort_sub_many, dim3(mmax, nb_max, R), dim3(256), sh, st, dR);
+    hipLaunchKernelGGL(k_nn_cluster_sub_many, dim3(nb_max, R), dim3(1024), sh2, st, dR);
+    return 0;
+}
 
 void pc_launch_shift_mats(const PcState *S, int p, int nc, hipStream_t st)
 {

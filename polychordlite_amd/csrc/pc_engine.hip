@@ -43,6 +43,8 @@ int pc_launch_consume_cl_many(const PcState *, const PcManyRec *, int, int, hipS
 int pc_launch_reset_thresholds_many(const PcState *, const PcManyRec *, int, hipStream_t);
 int pc_launch_knn_cluster_batch_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
 int pc_launch_knn_cluster_batch_dev(const PcState *, const int *, int, int, double *, int *, int *, int *, hipStream_t);
+int pc_launch_knn_cluster_sub(const int *, int, int, const double *, const int *, int *, int *, int *, hipStream_t);
+int pc_launch_knn_cluster_sub_many(const PcManyRec *, int, int, int, hipStream_t);
 int pc_launch_slice_t(const PcState *, unsigned, int, hipStream_t);
 int pc_bases_t_ok(const PcState *);
 int pc_launch_slice_t_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
@@ -438,7 +440,7 @@ struct Fiber {
     void yield() { swapcontext(&ctx, &ret); }
 };
 
-enum { CK_COMPACT = 0, CK_RESET, CK_CLUS1, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_COV, CK_FINAL, CK_N };      // (in the order they are launched)
+enum { CK_COMPACT = 0, CK_RESET, CK_CLUS1, CK_CLUSG, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_COV, CK_FINAL, CK_N };      // (in the order they are launched)
 // (_G: any device likelihood, the wavefront-per-chain kernels of a run on its own with the run in the grid; NN / CONSUME_CL: runs with several clusters)
 struct Cohort {
     hipStream_t st = nullptr;
@@ -465,6 +467,8 @@ struct Cohort {
     hipStream_t stc[2] = {nullptr, nullptr}; int n_stc = 0;
     // copies to the host that belong behind what has been written down: made at the end of flush(), in the order they were asked for
     std::vector<std::function<void()>> post;
+    // ... and copies to the device that what is written down reads: made at the start of flush()
+    std::vector<std::function<void()>> pre;
     void rec(int kind, const PcState &S, std::initializer_list<void *> p, std::initializer_list<long long> a, std::initializer_list<int> ia)
     {
         pend.emplace_back();
@@ -484,6 +488,7 @@ struct Cohort {
         case CK_SLICE_G: if (r.a[1]) (void)pc_launch_slice_fused(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); else (void)pc_launch_slice(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_NN: pc_launch_nn_lists(&r.S, r.ia[1], st); break;
         case CK_RESET: pc_launch_reset_thresholds(&r.S, st); break;
+        case CK_CLUSG: (void)pc_launch_knn_cluster_sub((const int *)r.p[0], r.ia[1], r.ia[2], (const double *)r.p[1], (const int *)r.p[2], (int *)r.p[3], (int *)r.p[4], (int *)r.p[5], st); break;
         case CK_CLUS1: (void)pc_launch_knn_cluster_batch_dev(&r.S, (const int *)r.p[0], r.ia[1], r.ia[2], (double *)r.p[1], (int *)r.p[2], (int *)r.p[3], (int *)r.p[4], st); break;
         case CK_CONSUME_CL: (void)pc_launch_consume_cl(&r.S, r.a[0] ? 65 : 2, st); break;
         case CK_SORT: (void)pc_launch_sort_live(&r.S, st); break;
@@ -495,8 +500,10 @@ struct Cohort {
         }
     }
     void run_post() { if (post.empty()) return; std::vector<std::function<void()>> p; p.swap(post); for (auto &f : p) f(); }
+    void run_pre() { if (pre.empty()) return; std::vector<std::function<void()>> p; p.swap(pre); for (auto &f : p) f(); }
     void flush()
     {
+        run_pre();
         if (pend.empty()) { run_post(); return; }
         const size_t n = pend.size();
         if (n > cap) {
@@ -554,6 +561,7 @@ struct Cohort {
             case CK_NN: { int nl = 0; for (size_t x = i; x < j; ++x) nl = std::max(nl, ord[x]->ia[1]); rc = pc_launch_nn_lists_many(&f.S, d, cnt, nl, q); } break;
             case CK_CONSUME_CL: rc = pc_launch_consume_cl_many(&f.S, d, cnt, (int)f.a[0], q); break;
             case CK_RESET: rc = pc_launch_reset_thresholds_many(&f.S, d, cnt, q); break;
+            case CK_CLUSG: { int nbm = 0, nmx = 0; for (size_t x = i; x < j; ++x) { nbm = std::max(nbm, ord[x]->ia[1]); nmx = std::max(nmx, ord[x]->ia[2]); } rc = pc_launch_knn_cluster_sub_many(d, cnt, nbm, nmx, q); } break;
             case CK_CLUS1: { int ndm = 0, nmx = 0; for (size_t x = i; x < j; ++x) { ndm = std::max(ndm, ord[x]->ia[1]); nmx = std::max(nmx, ord[x]->ia[2]); } rc = pc_launch_knn_cluster_batch_many(&f.S, d, cnt, ndm, nmx, q); } break;
             case CK_SORT: rc = pc_launch_sort_live_many(&f.S, d, cnt, q); break;
             case CK_CONSUME: rc = pc_launch_consume_par_many(&f.S, d, cnt, q); break;
@@ -909,6 +917,19 @@ struct Engine {
         staged_up.push_back(h);
         std::memcpy(h, src, bytes);
         HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st));
+    }
+
+    // host -> device for kernels that are WRITTEN DOWN after this call (runs in step: the copy is made at the start of the common launch,
+    // so the runs' kernels stay together; the destination must not be read by anything this run wrote down before)
+    void send_pre(void *dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return;
+        if (!co) { send_raw(dst, src, bytes); return; }
+        void *h = halloc<char>(bytes);
+        staged_up.push_back(h);
+        std::memcpy(h, src, bytes);
+        hipStream_t q = st;
+        co->pre.push_back([dst, h, bytes, q] { HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, q)); });
     }
 
     void read_ctl()
@@ -1452,6 +1473,73 @@ struct Engine {
     // counts down and the verdicts back: two host waits per update); a cluster in which the pass finds more than one group
     // goes through the per-cluster path with its recursion and add_cluster, in the reference's order
     int *c_desc = nullptr, *c_bout = nullptr; int c_desc_cap = 0;
+    int *c_gdesc = nullptr, *c_gpool = nullptr, *c_glab = nullptr, *c_gout = nullptr; int c_g_cap = 0;
+    // NN_clustering's recursion (clustering.f90:80-95) level by level.  The reference re-clusters every cluster it finds, alone, until one
+    // pass over it finds a single cluster; the labels it returns are the final parts numbered by first appearance (relabel after every
+    // step, utils.F90:713-749).  A part's own clustering depends on its points only, so the order in which the parts are looked at does
+    // not matter: all parts of all clusters of this update that are still open are clustered in ONE launch per level (and, in step
+    // with other runs, together with theirs), on the similarity blocks the first pass left behind -- two or three waits per update
+    // instead of one per part.  desc: the first pass' descriptors {cluster, n, off2, off1}; out: clusters it found; lab0: its labels.
+    bool refine_partitions(const std::vector<int> &desc, const std::vector<int> &which, const std::vector<int> &out, const std::vector<int> &lab0,
+                           std::vector<std::vector<int>> &final_labels, std::vector<int> &final_num)
+    {
+        struct Part { int k; std::vector<int> idx; };              // k: descriptor; idx: positions in the cluster's point order
+        const int nd = (int)which.size();
+        std::vector<std::vector<std::vector<int>>> done((size_t)nd);       // final parts of every split cluster
+        std::vector<Part> work;
+        auto split_by = [&](int k, const std::vector<int> &idx, const int *lab /* 1-based, one per entry of idx */, int num) {
+            std::vector<std::vector<int>> parts((size_t)num);
+            for (size_t a = 0; a < idx.size(); ++a) parts[(size_t)lab[a] - 1].push_back(idx[a]);
+            for (auto &pt : parts) { if (pt.size() > 1) work.push_back(Part{k, std::move(pt)}); else if (!pt.empty()) done[(size_t)k].push_back(std::move(pt)); }
+        };
+        for (int k = 0; k < nd; ++k) {
+            if (out[k] <= 1) continue;
+            const int n = desc[4 * k + 1], o1 = desc[4 * k + 3];
+            std::vector<int> all((size_t)n);
+            for (int i = 0; i < n; ++i) all[i] = i;
+            split_by(k, all, lab0.data() + o1, out[k]);
+        }
+        while (!work.empty()) {
+            std::vector<Part> cur; cur.swap(work);
+            const int nb = (int)cur.size();
+            std::vector<int> gdesc((size_t)5 * nb), pool;
+            int mmax = 0; long long koff = 0;
+            for (int b = 0; b < nb; ++b) {
+                const int k = cur[b].k, m = (int)cur[b].idx.size();
+                gdesc[5 * b + 0] = desc[4 * k + 2]; gdesc[5 * b + 1] = desc[4 * k + 1]; gdesc[5 * b + 2] = (int)pool.size(); gdesc[5 * b + 3] = m; gdesc[5 * b + 4] = (int)koff;
+                pool.insert(pool.end(), cur[b].idx.begin(), cur[b].idx.end());
+                mmax = std::max(mmax, m); koff += (long long)m * m;
+            }
+            if (koff > (long long)c_cap * c_cap) return false;           // (cannot happen: the parts of a cluster are disjoint)
+            if (c_g_cap < std::max(nb, (int)pool.size())) {
+                dfree(c_gdesc); dfree(c_gpool); dfree(c_glab); dfree(c_gout);
+                c_g_cap = std::max(2 * std::max(nb, (int)pool.size()), S.Ncap);
+                c_gdesc = dalloc<int>((size_t)5 * c_g_cap); c_gpool = dalloc<int>(c_g_cap); c_glab = dalloc<int>(c_g_cap); c_gout = dalloc<int>(c_g_cap);
+            }
+            send_pre(c_gdesc, gdesc.data(), sizeof(int) * gdesc.size());
+            send_pre(c_gpool, pool.data(), sizeof(int) * pool.size());
+            if (co) co->rec(CK_CLUSG, S, {c_gdesc, c_Sm, c_gpool, c_knn, c_glab, c_gout}, {}, {0, nb, mmax});
+            else if (pc_launch_knn_cluster_sub(c_gdesc, nb, mmax, c_Sm, c_gpool, c_knn, c_glab, c_gout, st)) engine_fail(PC_RC_LDS, "cluster of %d points too large for the LDS kNN sort", mmax);
+            std::vector<int> labs, nums;
+            fetch(labs, (const int *)c_glab, pool.size()); fetch(nums, (const int *)c_gout, (size_t)nb);
+            fetch_wait();
+            for (int b = 0; b < nb; ++b) {
+                if (nums[b] > 1) split_by(cur[b].k, cur[b].idx, labs.data() + gdesc[5 * b + 2], nums[b]);
+                else done[(size_t)cur[b].k].push_back(std::move(cur[b].idx));
+            }
+        }
+        for (int k = 0; k < nd; ++k) {
+            if (out[k] <= 1) continue;
+            const int n = desc[4 * k + 1], j = which[k];
+            std::vector<int> part_of((size_t)n, -1), newlab(done[(size_t)k].size(), 0);
+            for (size_t q = 0; q < done[(size_t)k].size(); ++q) for (int i : done[(size_t)k][q]) part_of[(size_t)i] = (int)q;
+            int next = 0;
+            final_labels[(size_t)j].assign((size_t)n, 0);
+            for (int i = 0; i < n; ++i) { int &l = newlab[(size_t)part_of[(size_t)i]]; if (l == 0) l = ++next; final_labels[(size_t)j][(size_t)i] = l; }
+            final_num[(size_t)j] = next;
+        }
+        return true;
+    }
     bool do_clustering(std::vector<int> cn = std::vector<int>())
     {
         ensure_cluster_scratch();
@@ -1460,6 +1548,8 @@ struct Engine {
         if (c_desc_cap < nold) { dfree(c_desc); dfree(c_bout); c_desc_cap = std::max(2 * nold, 64); c_desc = dalloc<int>((size_t)4 * c_desc_cap); c_bout = dalloc<int>(c_desc_cap); }
         if ((int)cn.size() != nold) cn = dl(S.cl_n, (size_t)nold);
         std::vector<int> desc, verdict(nold, 1);
+        std::vector<std::vector<int>> final_labels((size_t)nold); std::vector<int> final_num((size_t)nold, 1);
+        bool refined = false;
         {
             int o1 = 0; long long o2 = 0;
             std::vector<int> which;
@@ -1468,23 +1558,29 @@ struct Engine {
             const int nd = (int)which.size();
             static const bool batch_off = std::getenv("PC_CLUSTER_BATCH_OFF") != nullptr;
             if (nd > 0 && !batch_off && o2 <= (long long)c_cap * c_cap) {
-                send_raw(c_desc, desc.data(), sizeof(int) * desc.size());
+                send_pre(c_desc, desc.data(), sizeof(int) * desc.size());
                 int nmax1 = 0;
                 for (int k = 0; k < nd; ++k) nmax1 = std::max(nmax1, desc[4 * k + 1]);
                 // (in step with other runs: the first pass of all runs that update in this round in three launches)
                 if (co) co->rec(CK_CLUS1, S, {c_desc, c_Sm, c_knn, c_lab, c_bout}, {}, {0, nd, nmax1});
                 else if (pc_launch_knn_cluster_batch(&S, desc.data(), c_desc, nd, c_Sm, c_knn, c_lab, c_bout, st)) engine_fail(PC_RC_LDS, "a cluster too large for the LDS kNN sort");
-                std::vector<int> out;
+                std::vector<int> out, lab0;
                 fetch(out, (const int *)c_bout, (size_t)nd);
+                fetch(lab0, (const int *)c_lab, (size_t)o1);       // (the first pass' labels of every cluster: a few KB, the same wait)
                 fetch_wait();
                 for (int k = 0; k < nd; ++k) verdict[which[k]] = out[k];
+                refined = refine_partitions(desc, which, out, lab0, final_labels, final_num);
             } else for (int c = 0; c < nold; ++c) verdict[c] = cn[c] > 2 ? 2 : 1;      // (no first pass: look at every cluster)
         }
         int ic = 0;
         for (int j = 0; j < nold; ++j) {                 // j: the cluster's number when the update began; ic: its number now
             if (ic >= h_ctl->ncluster) break;
             const int n = cn[j];
-            if (n > 2 && verdict[j] > 1) {
+            if (refined && n > 2 && verdict[j] > 1) {
+                // (the recursion of clustering.f90:80-95 was made for all clusters and all runs level by level: refine_partitions)
+                if (final_num[j] > 1) { found = true; add_cluster(ic, final_labels[j], final_num[j]); }
+                else ic++;
+            } else if (n > 2 && verdict[j] > 1) {
                 direct_op();
                 HIPCHK(hipMemcpyAsync(c_pts, S.cl_list + (size_t)ic * S.Ncap, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
                 pc_launch_similarity(&S, c_pts, n, c_Sm, st);
@@ -2393,7 +2489,7 @@ struct Engine {
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);
         if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
         dfree(upd_part); dfree(upd_shift); upd_part_cap = 0;
-        dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
+        dfree(c_gdesc); dfree(c_gpool); dfree(c_glab); dfree(c_gout); c_g_cap = 0; dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
         for (void *h : staged_up) hfree(h);
         staged_up.clear();
         for (const Fetch &f : fetching) hfree(f.h);

@@ -609,7 +609,10 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
     if (device_like) {
         // seeds dealt round-robin to the devices: run k on devs[k % ndev] (what the merge below assumes)
         // (a device's runs may be shared out among a few scheduler threads: one thread's launch path saturates at about eight runs)
-        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : 1;
+        // (runs with clustering: two groups going round by round side by side -- while one group's contractions hold a wavefront each, the
+        //  other samples or updates; measured at BASELINE configs[2] / [3], sixteen runs: 969 -> ~780 ms, 541 -> ~400 ms.  One-cluster
+        //  Gaussian runs fill the chip with one group, and two were slower: DESIGN section 5f)
+        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : ((s->do_clustering && per_dev >= 8) ? 2 : 1);
         const int nd = (int)devs.size();
         auto work = [&](int wi) {
             const int di = wi % nd, part = wi / nd;
