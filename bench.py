@@ -36,15 +36,17 @@ BYTES_PER_EVAL = 258.0
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # BASELINE.json configs through this harness: kind, nDims, nDerived, nlive, num_repeats, clustering, box, analytic logZ
 WORKLOADS = {
-    "c2": dict(kind="gaussian", D=20, nDer=2, nlive=2000, nr=40, clustering=0, box=None, truth=0.0,
+    "c2": dict(kind="gaussian", D=20, nDer=2, nlive=2000, nr=40, clustering=0, box=None, truth=0.0, ref_evals_per_dead=173.9,
                name="BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, num_repeats=40"),
-    "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.263,
+    "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.263, ref_evals_per_dead=155.5,
                name="BASELINE configs[2]: 10-D Rastrigin, U(-5.12,5.12)^10, nlive=%d, num_repeats=30 (= 3 nDims, the ini's ratio), kNN clustering"),
-    "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.794,
+    "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.794, ref_evals_per_dead=177.3,
                name="BASELINE configs[3]: 30-D twin Gaussian (sigma=0.1), U(-1,1)^30, nlive=%d, num_repeats=40, kNN clustering"),
-    "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=0.0,
+    "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=0.0, ref_evals_per_dead=None,
                name="BASELINE configs[4]: 100-D correlated Gaussian (random eigenbasis, eigen-sigma 0.1 .. 0.001), U(0,1)^100, nlive=%d, num_repeats=200"),
 }
+# ref_evals_per_dead: likelihood evaluations per dead point of the REFERENCE BINARY at this configuration (its linear mode, one chain at a
+# time: tests/golden/ref_c3_seeds.json, ref_c4_seeds.json; configs[1]: the cpu_baseline leg of this script on the GPU box, 11.45 M / 65.8 k)
 METRIC = {"c2": "likelihood evals/sec, 20D Gaussian nlive=%d", "c3": "likelihood evals/sec, 10D Rastrigin nlive=%d",
           "c4": "likelihood evals/sec, 30D twin Gaussian nlive=%d", "c5": "likelihood evals/sec, 100D correlated Gaussian nlive=%d"}
 
@@ -240,6 +242,8 @@ def main():
     ap.add_argument("--concurrent", default="4,8,16,32,64",
                     help="after the timed steps (N = 1): R independent runs in flight on this GPU for each R of the list "
                          "(polychordlite_amd.repeats.run_repeats; reported separately, never part of `value`); '' or 0 = skip")
+    ap.add_argument("--concurrent-configs", default="c3,c4", help="after the timed steps (N = 1): these clustered BASELINE configurations with R runs in step, R from --concurrent-clustered; '' = skip")
+    ap.add_argument("--concurrent-clustered", default="16,32")
     ap.add_argument("--other-configs", default="c3,c4,c5",
                     help="after the timed steps of the default workload (N = 1): one step each of these BASELINE configurations, reported "
                          "as `other_configs`; '' = skip")
@@ -406,6 +410,43 @@ def main():
                          "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
         lib.polychord_hip_set_option(b"trim_cache", 0.0)      # (the blocks of 64 engines: the next configurations size their buffers by what is free)
         sync()
+    # the configurations north_star shards over the GPUs (Rastrigin, twin Gaussian: clustered runs) in step on this one
+    conc_other = {}
+    if extras and Rs and args.workload == "c2" and args.concurrent_configs:
+        from polychordlite_amd.repeats import run_repeats
+        for name in [x for x in args.concurrent_configs.split(",") if x.strip()]:
+            w3 = WORKLOADS[name]
+            s3, L3, P3, keep3 = problem(w3, w3["nlive"])
+            s3.seed = 6999; api.run(s3, L3, P3)
+            ts0 = time.perf_counter(); solo = []
+            for i in range(3):
+                s3.seed = 7000 + i; g3 = api.run(s3, L3, P3); solo.append((g3["nlike"], int((g3["logweights"] > g3["logzero"]).sum()))); g3 = None
+            tsolo = (time.perf_counter() - ts0) / 3
+            solo_v = float(np.mean([x[0] for x in solo]) / tsolo); solo_ld = float(np.mean([x[1] for x in solo]) / tsolo)
+            rows = []
+            for R in [int(x) for x in args.concurrent_clustered.split(",") if x.strip()]:
+                for w in range(2):
+                    _, held = run_repeats(s3, L3, P3, [400000 + 1000 * w + j for j in range(R)], max_in_flight=R); held = None
+                samples = []
+                for k in range(3):
+                    mc, held = run_repeats(s3, L3, P3, [500000 + 1000 * k + j for j in range(R)], max_in_flight=R)
+                    lived = sum(int((h["logweights"] > h["logzero"]).sum()) for h in held); held = None
+                    samples.append((mc["nlike"] / mc["t_runs_s"], mc, lived))
+                v, mc, lived = sorted(samples, key=lambda t: t[0])[1]
+                bpe3 = algorithmic_bytes_per_iteration(w3["D"], w3["nDer"], w3["nr"], w3["nlive"]) * lived / mc["nlike"]
+                rows.append({"runs": R, "wall_ms": mc["t_runs_s"] * 1e3, "value": v, "value_min": min(t[0] for t in samples), "value_max": max(t[0] for t in samples),
+                             "unit": "likelihood evals/s", "x_solo": v / solo_v, "lived_dead_per_s": lived / mc["t_runs_s"], "x_solo_lived_dead": lived / mc["t_runs_s"] / solo_ld,
+                             "evals_per_lived_dead": mc["nlike"] / lived, "evals_per_lived_dead_reference": w3["ref_evals_per_dead"],
+                             "value_reference_equivalent": lived / mc["t_runs_s"] * w3["ref_evals_per_dead"],
+                             "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "logZ_truth": w3["truth"],
+                             "whole_run_frac": mc["nlike"] * bpe3 / mc["t_runs_s"] / 1e9 / HBM_PEAK_GBS})
+            conc_other[name] = {"workload": w3["name"] % w3["nlive"], "solo": {"value": solo_v, "lived_dead_per_s": solo_ld, "ms_per_run": tsolo * 1e3,
+                                                                              "evals_per_lived_dead": float(np.sum([x[0] for x in solo]) / np.sum([x[1] for x in solo]))},
+                                "in_step": rows,
+                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; value_reference_equivalent = "
+                                        "dead points that lived per second x the reference binary's evaluations per dead point"}
+        lib.polychord_hip_set_option(b"trim_cache", 0.0)
+        sync()
     # the other BASELINE configurations through the same engine, one timed step each (after two untimed steps that size the
     # block cache): reported next to the headline, never part of `value`
     others = None
@@ -432,7 +473,12 @@ def main():
             kt2 = r2["kernel_time"]
             dom2 = max(kt2, key=lambda n: kt2[n]["total_s"]) if kt2 else None
             bpe2 = algorithmic_bytes_per_iteration(w2["D"], w2["nDer"], w2["nr"], w2["nlive"]) * r2["niter"] / r2["nlike"]
+            lived2 = int((r2["logweights"] > r2["logzero"]).sum())
             others[name] = {"workload": w2["name"] % w2["nlive"], "value": r2["nlike"] / to, "unit": "likelihood evals/s", "ms_per_step": to * 1e3,
+                            # evaluations of the chains that put a point into the live set (what the reference's one-chain loop would have
+                            # needed for these dead points) / wall; all evaluations per dead point that lived, next to the reference binary's
+                            "value_reference_equivalent": (r2["nlike"] - r2["nlike_failed"]) / to, "lived_dead": lived2, "lived_dead_per_s": lived2 / to,
+                            "evals_per_lived_dead": r2["nlike"] / lived2, "evals_per_lived_dead_reference": w2["ref_evals_per_dead"], "batch_chains": int(r2["batch"]),
                             "engine_ms": r2["t_total"] * 1e3, "logZ": r2["logZ"], "logZerr": r2["logZerr"], "logZ_truth": w2["truth"],
                             "ndead": int(r2["ndead"]), "nlike": int(r2["nlike"]), "clusters_peak": int(r2["ncluster_peak"]),
                             "dominant_kernel": dom2, "dominant_share_of_kernel_time": (kt2[dom2]["total_s"] / sum(v["total_s"] for v in kt2.values())) if dom2 else None,
@@ -493,19 +539,27 @@ def main():
                             "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
         if roof and args.workload == "c2":
             roof["latency"] = latency_model(runs, kern)
+        if roof and conc:
+            # the GPU's best mode: R runs of the metric configuration in step (never part of `value`; `--gpus N` ranks run ONE run at a time each)
+            roof["in_step"] = [{"runs": c_["runs"], "value": c_["value"], "ms_per_run": c_["per_run_ms"], "whole_run_frac": c_["whole_run_frac"]} for c_ in conc if c_["runs"] in (16, 64)]
+            for nm, v_ in conc_other.items():
+                roof["in_step"] += [{"config": nm, "runs": r_["runs"], "value": r_["value"], "x_solo": r_["x_solo"], "value_reference_equivalent": r_["value_reference_equivalent"],
+                                     "whole_run_frac": r_["whole_run_frac"]} for r_ in v_["in_step"]]
         out = {"metric": METRIC[args.workload] % nlive, "value": value,
                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
-                          "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world},
+                          "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world,
+                          "mode": "one run at a time per GPU (a step = one run; every rank of --gpus N runs this mode).  R runs of a GPU in step -- its best "
+                                  "mode, `concurrent*` and roofline.in_step -- are reported beside it, never in `value`"},
                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
                "logZ_truth": wl["truth"], "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
                # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
                # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
                "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
                "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "records", "post_mean", "t_merge_s")} if merged else None,
-               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "other_configs": others, "roofline": roof,
+               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
                "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (comm.library, world)) if comm is not None else "one rank: no exchange",
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},

@@ -141,6 +141,12 @@ typedef struct {
        grade_repeats[g] directions per chain, drawn in the subspace of its own and all faster parameters;
        num_repeats is then ignored (the total is the sum).  At most 8 grades. */
     int nGrade; const int *grade_dims; const int *grade_repeats;
+    int epoch_discard;  /* chains in flight when the list of clusters changes (batch > 1 only).  The reference's farm discards every baby
+                           seeded before the change (nested_sampling.F90:313, :339-341: its workers' messages carry positional cluster
+                           indices).  0 (default): only the chains seeded in the cluster that ended -- it died or was split -- are lost;
+                           the others are samples as good after the change as before and stay in the nursery, their cluster index following
+                           the list (BASELINE configs[2] at batch = nlive/2: 199 instead of 338 evaluations per dead point, the reference's
+                           linear mode 155).  1: the reference's rule.  Option "epoch_discard" for polychord_c_interface callers. */
 } pchip_settings;
 
 typedef struct {

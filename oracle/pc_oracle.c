@@ -428,6 +428,8 @@ typedef struct {
     int ncluster_dead; double *logZp_dead, *logZp2_dead;
     long nposterior_dead_tot, nequals_dead_tot;
     int nlive_target_static;
+    /* chains in flight (keyed mode, B > 1): cluster index and epoch of every chain still in the nursery; see remap_chains */
+    int *w_cluster, *w_epoch, w_n;
 } rti_t;
 
 #define XQ(R, p, q) ((R)->XpXq[(size_t)(p) * (R)->ccap + (q)])
@@ -717,6 +719,21 @@ static void update_posteriors(rti_t *R)
     free(ep);
 }
 
+/* ENGINE RULE (settings.epoch_discard = 0, the default; B > 1 only -- at B = 1 no chain is in flight when a cluster ends).
+ * The reference's farm discards every baby seeded before a change of the cluster list (nested_sampling.F90:313: the workers'
+ * messages carry positional cluster indices).  A chain seeded in a cluster the change did not touch is as good a sample after it
+ * as before: when cluster p ends -- it died (delete_cluster) or was split (add_cluster) -- only the chains seeded in p are lost;
+ * the clusters behind p move up one place and the chains seeded in them follow.  epoch_discard = 1 restores the reference's rule. */
+static void remap_chains(rti_t *R, int p)
+{
+    if (!R->w_cluster || R->s->epoch_discard) return;
+    for (int w = 0; w < R->w_n; ++w) {
+        const int c = R->w_cluster[w];
+        if (c == p) { R->w_cluster[w] = -1; R->w_epoch[w] = -1; }
+        else if (c > p) R->w_cluster[w] = c - 1;
+    }
+}
+
 static int delete_cluster(rti_t *R)
 {   /* run_time_info.f90:507-598 */
     int p = -1;
@@ -745,6 +762,7 @@ static int delete_cluster(rti_t *R)
         na++;
     }
     R->ncluster--;
+    remap_chains(R, p);
     return 1;
 }
 
@@ -774,6 +792,7 @@ static void add_cluster(rti_t *R, int p, const int *labels, int nnew)
     for (int q = 0, k = 0; q < R->ncluster; ++q) if (q != p) rowpq[k++] = XQ(R, p, q);
     /* old clusters keep their order at 0..nold-1 */
     for (int c = p; c < R->ncluster - 1; ++c) R->cl[c] = R->cl[c + 1];
+    remap_chains(R, p);
     {
         int n = R->ncluster;
         double *tmp = (double *)malloc(sizeof(double) * (size_t)n * n);
@@ -1187,6 +1206,7 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
             i_nursery = B; batch++; out->nbatches++;
         }
         int w = i_nursery - 1; i_nursery--;
+        R->w_cluster = wcluster; R->w_epoch = wepoch; R->w_n = i_nursery;
         R->nlike += wnlike[w];
         for (int g = 0; g < 8; ++g) R->nlike_g[g] += wnlike_g[(size_t)w * 8 + g];
         niter++;
@@ -1199,14 +1219,15 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
                 R->logX_last_update = lx;
                 update_posteriors(R);
             }
-            if (delete_cluster(R)) admin_epoch++;
+            if (delete_cluster(R) && s->epoch_discard) admin_epoch++;
             if (R->ncluster == 0) break;
             if (update) {
-                if (s->do_clustering && do_clustering(R)) admin_epoch++;
+                if (s->do_clustering && do_clustering(R) && s->epoch_discard) admin_epoch++;
                 calculate_covmats(R);
             }
         }
     }
+    R->w_cluster = NULL; R->w_epoch = NULL; R->w_n = 0;
     /* final live points (before kill-off) */
     out->nlive_final = total_live(R);
     out->live = (double *)malloc(sizeof(double) * (size_t)(out->nlive_final > 0 ? out->nlive_final : 1) * nT);

@@ -105,6 +105,8 @@ typedef struct {
      * Only the deterministic branch of generate.F90:303-309 is restated: every grade_frac > 1 is the number of
      * repeats of that grade (the other branch times the likelihood with the wall clock). */
     int nGrade; const int *grade_dims; const double *grade_frac;
+    int epoch_discard;  /* 1: nested_sampling.F90:313 as written (every chain in flight is lost when the cluster list changes); 0: the engine's
+                           rule (pc_oracle.c remap_chains: only the chains of the cluster that ended are lost) */
 } pc_settings;
 
 typedef struct {

@@ -32,7 +32,8 @@ class Settings(C.Structure):
                 ("batch", C.c_int), ("device", C.c_int), ("feedback", C.c_int), ("profile", C.c_int),
                 ("force_general", C.c_int), ("ablate", C.c_int),
                 ("resume_write", C.c_char_p), ("sequential_rng", C.c_int), ("resume_read", C.c_char_p),
-                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_repeats", C.POINTER(C.c_int))]
+                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_repeats", C.POINTER(C.c_int)),
+                ("epoch_discard", C.c_int)]
 
 
 class Like(C.Structure):

@@ -27,7 +27,7 @@ struct Builtins {
     double g_mu = 0.5, g_sigma = 0.1;                 // likelihoods/examples/gaussian.f90:25-26
     int cg_D = 0; std::vector<double> cg_invcov, cg_mean; double cg_logdet = 0.0;
     int up_D = 0; std::vector<double> up_lo, up_hi;
-    int batch = 0, device = -1;
+    int batch = 0, device = -1, epoch_discard = 0;
     bool halt_returns = false;                        // fatal conditions return to the caller instead of `stop 1` (language bindings)
     std::string last_error;
 } G;
@@ -427,6 +427,7 @@ void polychord_hip_set_option(const char *name, double value)
     else if (!std::strcmp(name, "phantom_capacity")) pchip_set_capacity(-1, (int)value);
     else if (!std::strcmp(name, "trim_cache")) pchip_trim_cache();
     else if (!std::strcmp(name, "halt_returns")) G.halt_returns = value != 0.0;
+    else if (!std::strcmp(name, "epoch_discard")) G.epoch_discard = value != 0.0 ? 1 : 0;
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }
 
@@ -613,7 +614,7 @@ static void c_interface_impl(
     s.boost_posterior = boost_posterior; s.posteriors = posteriors; s.equals = equals; s.cluster_posteriors = cluster_posteriors;
     s.compression_factor = compression_factor; s.n_nlives = n_nlives; s.loglikes = loglikes; s.nlives = nlives;
     s.seed = seed >= 0 ? seed : (int)(std::chrono::system_clock::now().time_since_epoch().count() & 0x7fffffff); // random_utils.F90:62-79
-    s.batch = G.batch; s.device = G.device;
+    s.batch = G.batch; s.device = G.device; s.epoch_discard = G.epoch_discard;
     // tests: the engine's sequential-stream mode through the reference's entry point (draw order of the reference binary;
     // with the RNG shim of oracle/ the two programs then write the same files)
     if (const char *e = std::getenv("PC_SEQUENTIAL_RNG")) s.sequential_rng = std::atoi(e) != 0;

@@ -411,6 +411,22 @@ int pc_launch_knn_cluster_sub_many(const PcManyRec *dR, int R, int nb_max, int m
     return 0;
 }
 
+// The chains still in the nursery follow the list of clusters through an update that split some of them (settings.epoch_discard
+// = 0; oracle: remap_chains): map[c] = the place of the update's cluster c in the new list, -1 if it was split -- its chains are lost.
+__global__ __launch_bounds__(256) void k_remap_chains(PcState S, const int *map, int nold, int n)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= n) return;
+    const int c = S.ch_cluster[w];
+    const int m = (c >= 0 && c < nold) ? map[c] : -1;
+    S.ch_cluster[w] = m;
+    if (m < 0) S.ch_epoch[w] = -1;
+}
+void pc_launch_remap_chains(const PcState *S, const int *map, int nold, int n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_remap_chains, dim3((n + 255) / 256), dim3(256), 0, st, *S, map, nold, n);
+}
+
 void pc_launch_shift_mats(const PcState *S, int p, int nc, hipStream_t st)
 {
     if (p < nc - 1) hipLaunchKernelGGL(k_shift_mats, dim3(1), dim3(256), 0, st, *S, p, nc);

@@ -796,6 +796,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     };
 
     // delete_cluster (run_time_info.f90:507-598): drop the first empty cluster, keep the others' order
+    int dropped_p = -1;
     auto drop_empty_cluster = [&]() -> bool {
         int p = -1;                                    // first empty cluster: one cluster per lane, every wave for itself
         for (int c0 = 0; c0 < nc && p < 0; c0 += 64) {
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         for (int s = tid; s < Ncap; s += NT) if (H.sC[s] > p) H.sC[s] -= 1;
         nc--;
         cluster_deleted = 1;
+        dropped_p = p;
         __syncthreads();
         return true;
     };
@@ -1081,7 +1083,21 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         // nested_sampling.F90:321  logsumexp(logXp) <= logX_last_update + log(compression_factor), in linear space
         const bool update = lx_s <= exp(lx_last + S.log_cf - lx_m);
         if (update) lx_last = lx_m + log(lx_s);
-        if (drop_empty_cluster()) epoch++;
+        if (drop_empty_cluster()) {
+            if (S.epoch_discard) epoch++;          // nested_sampling.F90:339-341 as written: every chain in flight fails the guard of :313
+            else {
+                // the engine's rule (oracle: remap_chains): only the chains seeded in the cluster that ended are lost; the clusters behind
+                // it moved up one place and the chains seeded in them follow
+                const int p = dropped_p;
+                for (int w2 = tid; w2 < i_nursery; w2 += NT) {
+                    const int c = S.ch_cluster[w2];
+                    if (c == p) { S.ch_cluster[w2] = -1; S.ch_epoch[w2] = -1; }
+                    else if (c > p) S.ch_cluster[w2] = c - 1;
+                }
+                if (pf_ca == p) { pf_ca = -1; pf_epoch = -1; } else if (pf_ca > p) pf_ca -= 1;      // (the next chain's record is in registers already)
+                __syncthreads();
+            }
+        }
         cyE += clock64() - q3;
         if (nc == 0) { status = PC_ST_DONE; break; }
         if (update) { status = PC_ST_UPDATE; break; }

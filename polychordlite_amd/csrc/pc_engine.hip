@@ -59,6 +59,7 @@ int pc_launch_update_fused_many(const PcState *, const PcManyRec *, int, int, in
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
 void pc_launch_nn_lists(const PcState *, int, hipStream_t);
 void pc_launch_shift_mats(const PcState *, int, int, hipStream_t);
+void pc_launch_remap_chains(const PcState *, const int *, int, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
 int pc_fast_fits(const PcState *);
 int pc_par_fits(const PcState *);
@@ -745,6 +746,7 @@ struct Engine {
         S.log_cf = std::log(c.compression_factor);
         S.max_ndead = c.max_ndead; S.nfail = c.nfail <= 0 ? c.nlive : c.nfail;
         S.seed_override = 0; S.ablate = c.ablate; S.seq_mode = c.sequential_rng ? 1 : 0;
+        S.epoch_discard = c.epoch_discard ? 1 : 0;
         if (S.seq_mode) { cfg.batch = 1; cfg.force_general = 1; }
         // dynamic nlive tables
         S.n_nlives = c.n_nlives;
@@ -1473,6 +1475,7 @@ struct Engine {
     // counts down and the verdicts back: two host waits per update); a cluster in which the pass finds more than one group
     // goes through the per-cluster path with its recursion and add_cluster, in the reference's order
     int *c_desc = nullptr, *c_bout = nullptr; int c_desc_cap = 0;
+    int *c_map = nullptr; int c_map_cap = 0;
     int *c_gdesc = nullptr, *c_gpool = nullptr, *c_glab = nullptr, *c_gout = nullptr; int c_g_cap = 0;
     // NN_clustering's recursion (clustering.f90:80-95) level by level.  The reference re-clusters every cluster it finds, alone, until one
     // pass over it finds a single cluster; the labels it returns are the final parts numbered by first appearance (relabel after every
@@ -1573,12 +1576,15 @@ struct Engine {
             } else for (int c = 0; c < nold; ++c) verdict[c] = cn[c] > 2 ? 2 : 1;      // (no first pass: look at every cluster)
         }
         int ic = 0;
+        std::vector<int> cmap((size_t)nold);             // where the update's cluster j is in the list now; -1: it was split
+        for (int j = 0; j < nold; ++j) cmap[(size_t)j] = j;
+        auto split_at = [&](int p) { for (int &m : cmap) { if (m == p) m = -1; else if (m > p) m -= 1; } };
         for (int j = 0; j < nold; ++j) {                 // j: the cluster's number when the update began; ic: its number now
             if (ic >= h_ctl->ncluster) break;
             const int n = cn[j];
             if (refined && n > 2 && verdict[j] > 1) {
                 // (the recursion of clustering.f90:80-95 was made for all clusters and all runs level by level: refine_partitions)
-                if (final_num[j] > 1) { found = true; add_cluster(ic, final_labels[j], final_num[j]); }
+                if (final_num[j] > 1) { found = true; add_cluster(ic, final_labels[j], final_num[j]); split_at(ic); }
                 else ic++;
             } else if (n > 2 && verdict[j] > 1) {
                 direct_op();
@@ -1587,12 +1593,19 @@ struct Engine {
                 std::vector<int> gidx(n), labels;
                 for (int i = 0; i < n; ++i) gidx[i] = i;
                 const int num = nn_clustering(n, gidx, labels);
-                if (num > 1) { found = true; add_cluster(ic, labels, num); }
+                if (num > 1) { found = true; add_cluster(ic, labels, num); split_at(ic); }
                 else ic++;
             } else ic++;
         }
         if (found) {
-            h_ctl->admin_epoch++;
+            if (cfg.epoch_discard) h_ctl->admin_epoch++;         // nested_sampling.F90:331-333 as written: every chain in flight is lost
+            else if (h_ctl->i_nursery > 0) {
+                // the engine's rule: the chains seeded in clusters this update left alone stay in the nursery, under their new numbers
+                if (c_map_cap < nold) { dfree(c_map); c_map_cap = std::max(2 * nold, 64); c_map = dalloc<int>(c_map_cap); }
+                send_raw(c_map, cmap.data(), sizeof(int) * (size_t)nold);
+                direct_op();
+                pc_launch_remap_chains(&S, c_map, nold, h_ctl->i_nursery, st);
+            }
             h_ctl->status = PC_ST_RUNNING;
             send_raw(S.ctl, h_ctl, sizeof(PcCtl));
         }
@@ -2489,7 +2502,7 @@ struct Engine {
         dfree(d_x0s); dfree(d_prop); dfree(d_ans); dfree(d_decks);
         if (hp_prop) { hfree(hp_prop); hp_prop = nullptr; } if (hp_ans) { hfree(hp_ans); hp_ans = nullptr; } if (hp_need) { hfree(hp_need); hp_need = nullptr; }
         dfree(upd_part); dfree(upd_shift); upd_part_cap = 0;
-        dfree(c_gdesc); dfree(c_gpool); dfree(c_glab); dfree(c_gout); c_g_cap = 0; dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
+        dfree(c_gdesc); dfree(c_gpool); dfree(c_glab); dfree(c_gout); c_g_cap = 0; dfree(c_map); c_map_cap = 0; dfree(c_desc); dfree(c_bout); dfree(c_Sm); dfree(c_pts); dfree(c_gidx); dfree(c_knn); dfree(c_lab); dfree(c_out); dfree(c_cnt); dfree(c_olduid); c_cap = 0; c_desc_cap = 0;   // (the clustering scratch used to stay behind: 12 MB per clustered run)
         for (void *h : staged_up) hfree(h);
         staged_up.clear();
         for (const Fetch &f : fetching) hfree(f.h);

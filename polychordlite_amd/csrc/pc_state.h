@@ -164,6 +164,7 @@ struct PcState {
                                  // scans only (no linear-space path); bit 5 = several clusters: the general contraction kernel for every launch (not
                                  // the one-wave kernel of pc_clus.hip); bit 30 = trace of Cholesky fallbacks
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
+    int epoch_discard;           // 1: nested_sampling.F90:313 as written (a change of the cluster list loses every chain in flight); 0: only the ended cluster's
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     int spec_guard;              // k_slice: enqueued ahead of the host's decision -- return unless ctl->spec_ok names this nursery

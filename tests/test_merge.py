@@ -385,6 +385,13 @@ def test_runs_in_step_at_every_width(engine, D):
         assert one["logZ"] == r["logZ"] and one["logZerr"] == r["logZerr"]
         assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
         assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
+    # the first of the runs in step next to the ORACLE's run of these settings
+    from tests import oracle_api as orc
+    from tests.test_gpu_parity import _next_to_the_oracle
+    g = runs[0]
+    so = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=seeds[0], batch=g["batch"])
+    Lo, Po, keep2 = orc.make_problem("gaussian", D, *(box if box else (None, None)))
+    _next_to_the_oracle(g, orc.run(so, Lo, Po), D, nlive)
 
 
 @pytest.mark.gpu

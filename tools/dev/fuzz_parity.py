@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = api.load(); olib = orc.load()
 bad = 0
 for case in range(ncases):
-    kind = rng.choice(["gaussian", "gaussian", "corr_gaussian", "rastrigin", "twin_gaussian"])
+    kind = rng.choice(["gaussian", "gaussian", "corr_gaussian", "rastrigin", "twin_gaussian"] if not os.environ.get("FUZZ_CLUSTERED") else ["rastrigin", "rastrigin", "twin_gaussian"])
     D = int(rng.choice([2, 3, 5, 8, 13, 20, 24, 25, 31, 32, 33, 40, 64, 65, 70, 100])) if kind != "twin_gaussian" else int(rng.choice([2, 4, 10, 30]))
     if kind == "rastrigin": D = min(D, 10)
     nlive = int(rng.choice([25, 50, 100, 200, 400])); nr = int(rng.choice([1, 2, 5, D, 2 * D])) if D <= 20 else int(rng.choice([2, 5, 10]))
@@ -29,6 +29,7 @@ for case in range(ncases):
     s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
     for k, v in kw.items(): setattr(s, k, v)
     s.batch = B
+    s.ablate = int(os.environ.get("FUZZ_ABLATE", "0")); s.epoch_discard = int(os.environ.get("FUZZ_DISCARD", "0"))
     lo, hi = (-5.12, 5.12) if kind == "rastrigin" else ((-1.0, 1.0) if kind == "twin_gaussian" else (None, None))
     extra = {}
     if kind == "corr_gaussian":
@@ -38,7 +39,7 @@ for case in range(ncases):
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != case: continue     # (the draws above keep the sequence)
     L, P, keep = api.make_problem(kind, D, nDer, lo, hi, **extra)
     t0 = time.time(); g = api.run(s, L, P); tg = time.time() - t0
-    so = orc.settings(D, nDer, batch=g["batch"], **kw)
+    so = orc.settings(D, nDer, batch=g["batch"], epoch_discard=int(os.environ.get("FUZZ_DISCARD", "0")), **kw)
     Lo, Po, keep2 = orc.make_problem(kind, D, *(() if lo is None else (lo, hi)), **extra)
     t0 = time.time(); o = orc.run(so, Lo, Po); to = time.time() - t0
     ok = all(g[k] == o[k] for k in ("ndead", "nlike", "niter", "ncluster_dead"))
