@@ -2350,11 +2350,24 @@ struct Engine {
         double *hlive = nullptr; int *hcl = nullptr; double *d_pmax = nullptr, *h_part = nullptr, *h_zp = nullptr;
         int nc_end = 0, ncd_max = 0, pmD = 0, pm_nb = 0, pm_pw = 0; clk::time_point t2;
     } es;
+    // A run in step that ends with several clusters: its kill-off is the general contraction kernel, one workgroup for ~4 ms
+    // (BASELINE configs[2]: a thousand deaths one after the other), and on the cohort's stream the other runs' next round waited
+    // behind it -- sixteen endings 70 ms of a 670 ms call.  It goes to the run's copy stream, behind everything the run has had.
+    hipStream_t st_fin = nullptr; hipEvent_t ev_fin = nullptr;
     void end_a(bool fused_final = false)
     {
         if (co && !fused_final) co->flush();      // (fused: the caller has launched what was pending, and launches the kill-offs together)
         const bool par_ok = r_par_ok; bool &sort_valid = r_sort_valid;
         es.t2 = clk::now();
+        st_fin = st;
+        static const bool fin_off = std::getenv("PC_COHORT_FINAL_ASIDE") && std::atoi(std::getenv("PC_COHORT_FINAL_ASIDE")) == 0;
+        if (co && fused_final && !fin_off && st_copy && st_copy != st && h_ctl->ncluster > 1) {
+            ev_fin = hpool().get_sync_event();
+            HIPCHK(hipEventRecord(ev_fin, st));
+            HIPCHK(hipStreamWaitEvent(st_copy, ev_fin, 0));
+            st_fin = st_copy;
+        }
+        hipStream_t st = st_fin;                  // (what follows is this run's alone)
         // snapshot of the live set at termination, then nested_sampling.F90:381-384
         const int nT = S.nT;
         // (pinned buffers, copies in stream order in front of the kill-off: the host does not stop here)
@@ -2375,6 +2388,7 @@ struct Engine {
     }
     void end_a2()
     {
+        hipStream_t st = st_fin ? st_fin : this->st;
         // what the results need from the device is requested here, behind the kill-off and before the host waits for it: the
         // posterior moments of theta over the dead points (device reduction, fixed order; the kernels take the count from the
         // control block) and the evidences of the retired clusters -- one wait instead of four
@@ -2391,8 +2405,10 @@ struct Engine {
             HIPCHK(hipMemcpyAsync(es.h_zp + es.ncd_max, S.logZp2_dead, sizeof(double) * es.ncd_max, hipMemcpyDeviceToHost, st));
         }
         HIPCHK(hipMemcpyAsync(h_ctl, S.ctl, sizeof(PcCtl), hipMemcpyDeviceToHost, st));       // (read_ctl without its wait: end_b's caller waits)
+        if (ev_fin) HIPCHK(hipEventRecord(ev_fin, st));      // (a kill-off beside the cohort's stream: end_b's caller waits for this one too)
     }
-    int end(pchip_result *out) { end_a(); HIPCHK(hipStreamSynchronize(st)); return end_b(out); }
+    void end_wait_aside() { if (ev_fin) { HIPCHK(hipEventSynchronize(ev_fin)); hpool().put_sync_event(ev_fin); ev_fin = nullptr; } }
+    int end(pchip_result *out) { end_a(); HIPCHK(hipStreamSynchronize(st)); end_wait_aside(); return end_b(out); }
     int end_b(pchip_result *out)
     {
         struct HostBuf { EndState &e; ~HostBuf() { if (e.hlive) hfree(e.hlive); if (e.hcl) hfree(e.hcl); e.hlive = nullptr; e.hcl = nullptr; } } hb{es};
@@ -2840,7 +2856,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                             if (!r && (w1 != hipSuccess || w2 != hipSuccess)) r = PC_RC_DEVICE;
                             const auto q0 = std::chrono::steady_clock::now();
                             if (!r) {
-                                try { r = E[k]->end_b(&results[base + k]); }
+                                try { E[k]->end_wait_aside(); r = E[k]->end_b(&results[base + k]); }
                                 catch (const EngineError &e) { std::fprintf(stderr, "polychord_hip: %s\n", e.msg.c_str()); r = e.code; }
                                 catch (const std::bad_alloc &) { r = PC_RC_MEMORY; }
                             }

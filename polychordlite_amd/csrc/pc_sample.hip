@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 #else
 #define PC_SLICE_ATTR
 #endif
-template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, bool LEAN = false>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
 #include "pc_slice_body.inc"
@@ -1121,6 +1121,7 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice_many(const PcManyRec *__restrict__ R, int phi_lds, int mat_lds)
 {
+    constexpr bool LEAN = false;
     const PcState S = R[blockIdx.y].S;
     const unsigned batch = (unsigned)R[blockIdx.y].ia[0];
 #include "pc_slice_body.inc"
@@ -1237,9 +1238,14 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     const int D = S->D, FWv = D <= 8 ? 8 : (D <= 16 ? 16 : 24);
     const size_t sh = sh0 + (phi_lds ? tb : 0) + sizeof(double) * ((size_t)FWv * D + (size_t)S->nr * (D + 2));   // + L, directions, widths
     if (sh > 150 * 1024) return 1;
+    static const bool lean_off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
+    const bool lean = !lean_off && S->like.kind == PC_LIKE_GAUSSIAN && !(S->ablate & 1) && phi_lds && S->nr <= 64 && !S->seq_mode && S->ngrade <= 1;
 #define PC_SLICE_FUSED(NROWS, FW) { \
+        if (lean) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, true>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } }
     if (D <= 8) PC_SLICE_FUSED(1, 8)
     else if (D <= 16) PC_SLICE_FUSED(1, 16)
     else PC_SLICE_FUSED(2, 24)
