@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 #else
 #define PC_SLICE_ATTR
 #endif
-template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, bool LEAN = false>
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, int LEAN = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
 #include "pc_slice_body.inc"
@@ -1121,7 +1121,7 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice_many(const PcManyRec *__restrict__ R, int phi_lds, int mat_lds)
 {
-    constexpr bool LEAN = false;
+    constexpr int LEAN = 0;
     const PcState S = R[blockIdx.y].S;
     const unsigned batch = (unsigned)R[blockIdx.y].ia[0];
 #include "pc_slice_body.inc"
@@ -1242,8 +1242,8 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     const bool lean = !lean_off && S->like.kind == PC_LIKE_GAUSSIAN && !(S->ablate & 1) && phi_lds && S->nr <= 64 && !S->seq_mode && S->ngrade <= 1;
 #define PC_SLICE_FUSED(NROWS, FW) { \
         if (lean) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, true>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } }
     if (D <= 8) PC_SLICE_FUSED(1, 8)
@@ -1320,6 +1320,14 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
         return 0;
     }
     if (mat_lds) sh += mb;
+    static const bool lean2_off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
+    if (!lean2_off && S->like.kind == PC_LIKE_CORR_GAUSSIAN && S->nhat_Ms != nullptr && !(S->ablate & 1) && S->nDer == 0 && S->nr > 64 && D > 64 && D <= 128 &&
+        S->ngrade <= 1 && !S->seq_mode && !mat_lds) {
+        // BASELINE configs[4]'s shape: the kernel without its other variants (LEAN = 2)
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<2, 4, false, 1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((k_slice<2, 4, false, 1, 0, 2>), dim3(nchains), dim3(64), sh, st, *S, batch, 0, 0);
+        return 0;
+    }
 #define PC_SLICE_LAUNCH1(DPL, NROWS, GR) { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, GR>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
