@@ -101,7 +101,7 @@ void pchip_inject_fault(int kind);
 /* initial capacities of the per-cluster arrays (default 128) and of the phantom array (rows; 0 = estimate); both grow on
    demand like the reference's reallocating arrays (run_time_info.f90:392-418), options "cluster_capacity" / "phantom_capacity" */
 void pchip_set_capacity(int clusters, int phantom_rows);
-/* The engine keeps the device and pinned blocks of finished runs for the next ones (up to 48 GB / 4 GB); this gives them back
+/* The engine keeps the device and pinned blocks of finished runs for the next ones (up to 64 GB / 12 GB); this gives them back
  * to the driver -- e.g. after many runs in flight, before a run that sizes its buffers by the memory that is free.
  * polychord_hip_set_option("trim_cache", 0) does the same. */
 void pchip_trim_cache(void);
@@ -128,7 +128,8 @@ typedef struct {
     int ablate;         /* developer / test switches, 0 = product: bit 0 = built-in quadratic likelihoods evaluated like a general functor;
                            bits 1, 2, 3 = no pool mode, no deferred update, no fused update (identical results by the older kernels);
                            bit 4 = evidence prefixes of the parallel contraction by pair scans only; bit 5 = several clusters: every
-                           launch by the general contraction kernel (no one-wave kernel) */
+                           launch by the general contraction kernel (no one-wave kernel); bits 6, 7 = a run on its own by the kernels it uses
+                           next to other runs of its device (bit 6: lane-per-chain sampling, pc_slice_t.hip; bit 7: lane-per-vector bases) */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

@@ -214,7 +214,9 @@ struct FileSink {
     void thin_equals_round(const pchip_update &u)
     {
         auto draw = [&]() { const unsigned long long n = eq_draws++; return polychord_hip_keyed_uniform(seed, 6u, (unsigned)(n >> 32), 0u, (unsigned)n); };
-        for (long i = eq_done; i < u.ndead; ++i) if (u.logpost[i] > -1e29) eq_max = std::max(eq_max, u.logpost[i]);
+        // a failed spawn carries logweight = the run's own logzero (run_time_info.f90:781-785): logpost - logL <= logzero
+        auto lived = [&](long i) { return u.logpost[i] - u.dead[(size_t)i * u.npars + u.npars - 1] > logzero; };
+        for (long i = eq_done; i < u.ndead; ++i) if (lived(i)) eq_max = std::max(eq_max, u.logpost[i]);
         for (long i = eq_xdone; i < u.n_extra; ++i) eq_max = std::max(eq_max, u.extra_logpost[i]);
         for (size_t i = 0; i < eq_w.size();) {
             if (eq_w[i] < eq_max) {
@@ -223,7 +225,7 @@ struct FileSink {
             } else ++i;
         }
         for (long i = eq_done; i < u.ndead; ++i) {
-            if (!(u.logpost[i] > -1e29)) continue;              // failed spawns never entered the stack
+            if (!lived(i)) continue;                            // failed spawns never entered the stack
             if (draw() < std::exp(u.logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(0); }
         }
         for (long i = eq_xdone; i < u.n_extra; ++i)

@@ -744,7 +744,11 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     const auto t0 = clk::now();
     std::memset(out, 0, sizeof(*out));
     const int R = c ? c->nranks : 1, nT = 2 * nDims + nDerived + 2;
-    if (run->ndead > 0 && run->nTotal != nT) { std::fprintf(stderr, "polychord_hip: comm merge: the run's rows have %d columns, not %d\n", run->nTotal, nT); return 1; }
+    // A rank that fails on its own (its records, its memory) still takes part in the exchange and says so there: the counts' all-gather
+    // carries -1 for it, a one-word all-gather behind the second phase's allocations its status, and every rank returns the error
+    // together -- a rank that left early would leave the others waiting in ncclAllGather for ever.
+    int local_err = 0;
+    if (run->ndead > 0 && run->nTotal != nT) { std::fprintf(stderr, "polychord_hip: comm merge: the run's rows have %d columns, not %d\n", run->nTotal, nT); local_err = 1; }
     int device = 0;
     if (c) device = c->device; else if (hipGetDevice(&device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
     if (hipSetDevice(device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
@@ -754,17 +758,33 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     auto nfail = [&](const char *what, ncclResult_t e) { std::fprintf(stderr, "polychord_hip: comm merge: %s: %s\n", what, rccl().GetErrorString(e)); return 2; };
     PackJob J;
     J.r = run; J.logzero = logzero; J.device = device;
-    if (!J.count_records(B, st)) return fail("packing the run's records", 7);
+    if (!local_err && !J.count_records(B, st)) local_err = fail("packing the run's records", 7);
+    if (local_err && !(c && c->comm)) return local_err;
     // counts (and the runs' totals) of every rank
     std::vector<long long> meta((size_t)3 * R, 0);
-    meta[0] = J.count; meta[1] = run->nlike; meta[2] = run->ndead;
+    meta[0] = local_err ? -1 : (long long)J.count; meta[1] = run->nlike; meta[2] = run->ndead;
+    long long *d_status = nullptr;
+    auto agree = [&](int mine) -> int {        // the ranks' status words, all-gathered: 0 if every rank is fine
+        std::vector<long long> w((size_t)R + 1, 0); w[0] = mine;
+        if (hipMemcpyAsync(d_status, w.data(), sizeof(long long), hipMemcpyHostToDevice, st) != hipSuccess) return 2;
+        if (rccl().AllGather(d_status, d_status + 1, 1, ncclInt64, c->comm, st) != ncclSuccess) return 2;
+        if (hipMemcpyAsync(w.data() + 1, d_status + 1, sizeof(long long) * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 2;
+        int worst = 0;
+        for (int q = 0; q < R; ++q) if (w[(size_t)q + 1] != 0) { if (!worst) { worst = (int)w[(size_t)q + 1]; if (q != c->rank) std::fprintf(stderr, "polychord_hip: comm merge: rank %d failed (code %d)\n", q, worst); } }
+        return worst;
+    };
     if (c && c->comm) {
         long long *d_meta = B.get<long long>((size_t)3 * (R + 1));
-        if (!d_meta) return fail("out of device memory", 7);
+        d_status = B.get<long long>((size_t)R + 1);
+        if (!d_meta || !d_status) return fail("out of device memory", 7);      // (a few hundred bytes: a device in this state serves no collective either)
         if (hipMemcpyAsync(d_meta, meta.data(), sizeof(long long) * 3, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
         const ncclResult_t e = rccl().AllGather(d_meta, d_meta + 3, 3, ncclInt64, c->comm, st);
         if (e != ncclSuccess) return nfail("ncclAllGather (counts)", e);
         if (hipMemcpyAsync(meta.data(), d_meta + 3, sizeof(long long) * 3 * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("counts", 2);
+        for (int q = 0; q < R; ++q) if (meta[(size_t)3 * q] < 0) {
+            if (q != c->rank) std::fprintf(stderr, "polychord_hip: comm merge: rank %d could not pack its records\n", q);
+            return local_err ? local_err : 7;
+        }
     }
     std::vector<long> counts(R);
     std::vector<long long> off(R + 1, 0);
@@ -772,15 +792,17 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     for (int q = 0; q < R; ++q) { counts[q] = (long)meta[(size_t)3 * q]; off[q + 1] = off[q] + counts[q]; nmax = std::max(nmax, meta[(size_t)3 * q]); nlike += meta[(size_t)3 * q + 1]; ndead_all += meta[(size_t)3 * q + 2]; }
     const size_t per = (size_t)nmax * (nT + 1);                 // one rank's block: rows [nmax][nT], then entry [nmax]
     double *send = B.get<double>(per);
-    if (!send) return fail("out of device memory", 7);
-    if (!J.scatter(B, send, send + (size_t)nmax * nT, st)) return fail("packing the run's records", 7);
+    if (!send) local_err = fail("out of device memory", 7);
+    else if (!J.scatter(B, send, send + (size_t)nmax * nT, st)) local_err = fail("packing the run's records", 7);
+    if (local_err && !(c && c->comm)) return local_err;
     const double *rows_all = send, *entry_all = send + (size_t)nmax * nT;
     if (c && c->comm) {
-        double *recv = B.get<double>(per * R);
-        long long *d_off = B.get<long long>(R + 1);
+        double *recv = local_err ? nullptr : B.get<double>(per * R);
+        long long *d_off = local_err ? nullptr : B.get<long long>(R + 1);
         const long long ntot = off[R];
-        double *ra = B.get<double>((size_t)std::max<long long>(ntot, 1) * nT), *ea = B.get<double>(std::max<long long>(ntot, 1));
-        if (!recv || !d_off || !ra || !ea) return fail("out of device memory", 7);
+        double *ra = local_err ? nullptr : B.get<double>((size_t)std::max<long long>(ntot, 1) * nT), *ea = local_err ? nullptr : B.get<double>(std::max<long long>(ntot, 1));
+        if (!local_err && (!recv || !d_off || !ra || !ea)) local_err = fail("out of device memory", 7);
+        { const int w = agree(local_err); if (w) return local_err ? local_err : w; }
         const ncclResult_t e = rccl().AllGather(send, recv, per, ncclDouble, c->comm, st);       // the exchange: one padded block per rank over xGMI
         if (e != ncclSuccess) return nfail("ncclAllGather (records)", e);
         if (hipMemcpyAsync(d_off, off.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);

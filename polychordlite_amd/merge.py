@@ -115,8 +115,8 @@ class Comm:
         lib = _lib()
         self.lib, self.rank, self.world, self.device, self.h = lib, rank, world, device, C.c_void_p()
         ident = C.create_string_buffer(128)
-        if rank == 0 and lib.pchip_comm_get_id(ident) != 0:
-            raise RuntimeError("pchip_comm_get_id failed (librccl.so not loadable?)")
+        # (rank 0 tells the others when it has no id to give: they must not wait in the broadcast / ncclCommInitRank for ever)
+        failed = rank == 0 and lib.pchip_comm_get_id(ident) != 0
         if exchange is None:
             import torch.distributed as dist
 
@@ -124,7 +124,9 @@ class Comm:
                 box = [b]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-        raw = exchange(ident.raw if rank == 0 else None) if world > 1 else ident.raw
+        raw = exchange((b"" if failed else ident.raw) if rank == 0 else None) if world > 1 else (b"" if failed else ident.raw)
+        if not raw:
+            raise RuntimeError("pchip_comm_get_id failed on rank 0 (librccl.so not loadable?)")
         if lib.pchip_comm_create(raw, world, rank, device, C.byref(self.h)) != 0:
             raise RuntimeError("pchip_comm_create failed")
 
