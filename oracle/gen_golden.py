@@ -160,7 +160,45 @@ def posterior_cases(inj):
     json.dump(meta, open(os.path.join(GOLD, "ref_posteriors.json"), "w"), indent=1)
 
 
+FARM_CASES = [  # like nDims nDerived nlive nrepeats seed clustering workers (= nprocs - 1)
+    ("gaussian", 4, 1, 60, 8, 3, 0, 4), ("gaussian", 20, 2, 100, 20, 1, 0, 8), ("rastrigin", 2, 0, 100, 6, 7, 1, 2),
+    ("rastrigin", 2, 0, 300, 6, 2, 1, 8), ("rastrigin", 4, 0, 200, 12, 5, 1, 4), ("twin_gaussian", 6, 1, 150, 12, 4, 1, 8),
+    ("rastrigin", 3, 0, 200, 9, 8, 1, 16),
+]
+
+
+def farm_cases():
+    """the reference's own FARM in its synchronous mode (nested_sampling.F90:262-286; mpi_utils.F90:376-600), built with -DMPI against
+    the container's mpich (oracle/Makefile ref_mpi) and run under mpiexec with workers + 1 ranks, every rank's `random_number` fed
+    from its own sequential Philox stream (ref_rng_shim.c pc_shim_set_rank).  The farm stores a worker's babies at the worker's index:
+    the run does not depend on the order of arrival (each case is run twice here to show it).  Numbers only; the oracle's farm mode
+    (pc_settings.farm) must reproduce them draw for draw: tests/test_oracle_pinned.py."""
+    exe = os.path.join(HERE, "_ref", "ref_driver_mpi_inject")
+    out = []
+    for c in FARM_CASES:
+        runs = []
+        for rep in range(2):
+            r = sh(f"rm -rf {TMP}/farm; /opt/conda/bin/mpiexec -n {c[7] + 1} {exe} {c[0]} {c[1]} {c[2]} {c[3]} {c[4]} {c[5]} {c[6]} {TMP}/farm f 1")
+            j = last_json(r)
+            rows = [[float(x) for x in l.split()] for l in open(f"{TMP}/farm/f_dead-birth.txt")]
+            j["dead_logL_sum"] = sum(x[-2] for x in rows); j["dead_birth_sum"] = sum(x[-1] for x in rows if x[-1] > -1e29)
+            j["dead_first_row"] = rows[0]; j["dead_last_row"] = rows[-1]
+            runs.append(j)
+        a, b = runs
+        assert all(a[k] == b[k] for k in ("logZ", "logZerr", "ndead", "nlike", "dead_logL_sum")), (a, b)
+        a.update(nDerived=c[2], clustering=c[6], workers=c[7])
+        for k in ("wall", "nlike_grades", "calls", "nposterior", "nequals"):
+            a.pop(k, None)
+        out.append(a)
+        print("farm", {k: a[k] for k in ("like", "nDims", "workers", "logZ", "ndead", "nlike", "ncluster")})
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "farm":       # only tests/golden/ref_farm.json
+        os.makedirs(TMP, exist_ok=True)
+        json.dump(farm_cases(), open(os.path.join(GOLD, "ref_farm.json"), "w"), indent=1)
+        return
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "posteriors":
         os.makedirs(TMP, exist_ok=True)

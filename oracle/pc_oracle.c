@@ -726,7 +726,7 @@ static void update_posteriors(rti_t *R)
  * the clusters behind p move up one place and the chains seeded in them follow.  epoch_discard = 1 restores the reference's rule. */
 static void remap_chains(rti_t *R, int p)
 {
-    if (!R->w_cluster || R->s->epoch_discard) return;
+    if (!R->w_cluster || R->s->epoch_discard || R->s->farm) return;
     for (int w = 0; w < R->w_n; ++w) {
         const int c = R->w_cluster[w];
         if (c == p) { R->w_cluster[w] = -1; R->w_epoch[w] = -1; }
@@ -1157,6 +1157,12 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
 
     /* ---- GenerateLivePoints, linear mode (generate.F90:150-183) ---- */
     int nprior = s->nprior <= 0 ? s->nlive : s->nprior;
+    const int farm = s->farm && s->sequential_rng && B > 1;
+    /* The farm's administrator (generate.F90:187-252) draws the coordinates itself and has one request out to every worker: when the
+     * nprior-th point comes back B - 1 more are on their way, and they are added as well (the points are put in the order they were
+     * drawn in, :236; what exceeds nlive dies before the first chain, nested_sampling.F90:201-205).  Restated for likelihoods that
+     * accept every prior sample (all of the built-in ones): with rejections the count would depend on the order of arrival. */
+    if (farm) nprior += B - 1;
     long nlike = 0; uint32_t attempt = 0;
     double *pt = (double *)calloc(nT, sizeof(double));
     while (R->cl[0].live.n < nprior) {
@@ -1188,6 +1194,21 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
     int i_nursery = 0, admin_epoch = 0;
     uint32_t batch = 0;
     long niter = 0;
+    pc_rng *wrng = NULL;
+    if (farm) {
+        /* worker w = rank w + 1 of the farm: its own running stream (ref_rng_shim.c pc_shim_set_rank), of which time_speeds has taken
+         * one prior sample on every rank before the first chain (generate.F90:388-393) */
+        wrng = (pc_rng *)malloc(sizeof(pc_rng) * B);
+        for (int w = 0; w < B; ++w) {
+            wrng[w] = R->rng; wrng[w].key[1] = 0x504F4C59u ^ ((uint32_t)(w + 1) * 0x9E3779B9u); wrng[w].seq = 0;
+            if (s->time_speeds_draw) {
+                pc_rng keep_rng = R->rng; long dummy = 0;
+                R->rng = wrng[w];
+                do { for (int d = 0; d < D; ++d) pt[d] = pc_rng_u(&R->rng, PC_DOM_LIVEGEN, 1, 0, (uint32_t)d); calculate_point(R, pt, &dummy); } while (!(pt[R->l0] > s->logzero));
+                wrng[w] = R->rng; R->rng = keep_rng;
+            }
+        }
+    }
 
     while (more_samples_needed(R) && failures <= nfail) {
         int cluster_id; const double *seedpt;
@@ -1199,8 +1220,11 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
                 if (!(R->rng.sequential && B == 1)) generate_seed(R, batch, (uint32_t)w, &cluster_id, &seedpt);
                 wcluster[w] = cluster_id; wepoch[w] = admin_epoch;
                 for (int g = 0; g < 8; ++g) wnlike_g[(size_t)w * 8 + g] = 0;
+                pc_rng admin_rng = R->rng;
+                if (farm) R->rng = wrng[w];                 /* (the chain is worker w's: its draws come from its stream) */
                 wnlike[w] = slice_sampling(R, batch, (uint32_t)w, seedpt, R->cl[cluster_id].chol,
                                            R->cl[cluster_id].logLp, nursery + (size_t)w * nr * nT, NULL, wnlike_g + (size_t)w * 8);
+                if (farm) { wrng[w] = R->rng; R->rng = admin_rng; }
                 for (int i = 0; i < nr; ++i) uids[(size_t)w * nr + i] = ((uint64_t)batch << 32) | (uint32_t)(w * nr + i);
             }
             i_nursery = B; batch++; out->nbatches++;
@@ -1219,10 +1243,10 @@ int pc_oracle_run(const pc_settings *s, const pc_like *like, const pc_prior *pri
                 R->logX_last_update = lx;
                 update_posteriors(R);
             }
-            if (delete_cluster(R) && s->epoch_discard) admin_epoch++;
+            if (delete_cluster(R) && (s->epoch_discard || s->farm)) admin_epoch++;
             if (R->ncluster == 0) break;
             if (update) {
-                if (s->do_clustering && do_clustering(R) && s->epoch_discard) admin_epoch++;
+                if (s->do_clustering && do_clustering(R) && (s->epoch_discard || s->farm)) admin_epoch++;
                 calculate_covmats(R);
             }
         }

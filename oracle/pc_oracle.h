@@ -105,6 +105,10 @@ typedef struct {
      * Only the deterministic branch of generate.F90:303-309 is restated: every grade_frac > 1 is the number of
      * repeats of that grade (the other branch times the likelihood with the wall clock). */
     int nGrade; const int *grade_dims; const double *grade_frac;
+    int farm;           /* 1 (with sequential_rng = 1, batch = B): the reference's synchronous FARM, nprocs - 1 = B (nested_sampling.F90:262-286,
+                           generate.F90:187-252, :388-393): the administrator's running stream for the prior samples, every seed, the
+                           posterior thinning; worker w's own running stream for its chains -- what oracle/_ref/ref_driver_mpi_inject
+                           consumes under mpiexec -n B+1 (ref_rng_shim.c pc_shim_set_rank).  Forces epoch_discard = 1 (its rule). */
     int epoch_discard;  /* 1: nested_sampling.F90:313 as written (every chain in flight is lost when the cluster list changes); 0: the engine's
                            rule (pc_oracle.c remap_chains: only the chains of the cluster that ended are lost) */
 } pc_settings;

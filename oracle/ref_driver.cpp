@@ -30,6 +30,10 @@ extern "C" void polychord_c_interface(
     int, int, int, int, bool, int, double, double, int, double, bool, bool, bool, bool, bool, bool, bool,
     bool, bool, bool, bool, double, bool, int, int, char *, char *, int, double *, int *, int, double *,
     int *, int, int &);
+#ifdef REF_MPI
+#include <mpi.h>
+extern "C" void pc_shim_set_rank(unsigned) __attribute__((weak));
+#endif
 extern "C" void pc_shim_reset(unsigned) __attribute__((weak));
 extern "C" unsigned long pc_shim_consumed(void) __attribute__((weak));
 
@@ -147,8 +151,16 @@ int main(int argc, char **argv)
             n_nlives++; pos = k + 1;
         }
     }
-    int comm = 0;
+    int comm = 0, rank = 0;
     if (pc_shim_reset) pc_shim_reset((unsigned)seed);
+#ifdef REF_MPI
+    // the reference's farm: rank 0 administers, ranks 1 .. nprocs-1 sample (REF_SYNC=0: its asynchronous mode, not reproducible)
+    MPI_Init(&argc, &argv);
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    comm = (int)MPI_Comm_c2f(MPI_COMM_WORLD);
+    if (pc_shim_set_rank) pc_shim_set_rank((unsigned)rank);
+#endif
+    const bool synchronous = !(std::getenv("REF_SYNC") && atoi(std::getenv("REF_SYNC")) == 0);
     auto t0 = std::chrono::steady_clock::now();
     const bool maximise = std::getenv("REF_MAXIMISE") != nullptr;       // optional: <root>.maximum (maximiser.F90)
     // optional: REF_POSTERIORS = "pe" / "p" / "e" (weighted and / or equally weighted posterior files, update_posteriors
@@ -160,9 +172,20 @@ int main(int argc, char **argv)
     const int max_ndead = std::getenv("REF_MAX_NDEAD") ? atoi(std::getenv("REF_MAX_NDEAD")) : -1;
     polychord_c_interface(fn, prior, dumper, nlive, nrep, nprior, -1, clustering, 0, 0.001, -1e30, max_ndead, boost,
                           posteriors, equals, cluster_post, write_resume, false, false, true, false, write_dead, false, maximise,
-                          0.36787944117144233, true, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
+                          0.36787944117144233, synchronous, nDims, nDer, (char *)base.c_str(), (char *)root.c_str(),
                           nGrade, grade_frac, grade_dims, n_nlives, loglikes, nlives, seed, comm);
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+#ifdef REF_MPI
+    {
+        long calls_all = 0;
+        MPI_Reduce(&g_calls, &calls_all, 1, MPI_LONG, MPI_SUM, 0, MPI_COMM_WORLD);
+        g_calls = calls_all;
+        unsigned long used = pc_shim_consumed ? pc_shim_consumed() : 0ul;
+        if (std::getenv("REF_RNG_TRACE")) std::fprintf(stderr, "rank %d consumed %lu draws\n", rank, used);
+        MPI_Finalize();
+        if (rank != 0) return 0;
+    }
+#endif
     // parse <base>/<root>.stats (read_write.F90:842-889)
     std::string fn_stats = base + "/" + root + ".stats";
     FILE *f = std::fopen(fn_stats.c_str(), "r");

@@ -32,6 +32,9 @@ static uint64_t g_seq = 0;
 /* called by the driver before each run */
 void pc_shim_reset(uint32_t seed) { g_key[0] = seed; g_key[1] = 0x504F4C59u; g_seq = 0; }
 uint64_t pc_shim_consumed(void) { return g_seq; }
+/* the farm (oracle/Makefile ref_mpi): every rank draws from a stream of its own -- the administrator's is the run's, worker w's
+ * (rank w) carries w in the second key word, as pc_oracle.c's farm mode expects */
+void pc_shim_set_rank(uint32_t rank) { g_key[1] = 0x504F4C59u ^ (rank * 0x9E3779B9u); g_seq = 0; }
 
 static double next_u(void)
 {

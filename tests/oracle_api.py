@@ -35,7 +35,7 @@ class Settings(C.Structure):
                 ("cluster_posteriors", C.c_int), ("compression_factor", C.c_double), ("n_nlives", C.c_int),
                 ("loglikes", C.POINTER(C.c_double)), ("nlives", C.POINTER(C.c_int)), ("seed", C.c_int),
                 ("batch", C.c_int), ("sequential_rng", C.c_int), ("time_speeds_draw", C.c_int),
-                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_frac", C.POINTER(C.c_double)), ("epoch_discard", C.c_int)]
+                ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_frac", C.POINTER(C.c_double)), ("farm", C.c_int), ("epoch_discard", C.c_int)]
 
 
 class Result(C.Structure):

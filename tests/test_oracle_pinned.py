@@ -43,6 +43,32 @@ def test_oracle_reproduces_injected_reference(golden):
         assert abs(o["logZerr"] - c["logZerr"]) < 1e-10, c
 
 
+def test_oracle_farm_mode_reproduces_the_reference_farm(golden):
+    """B > 1 pinned to the reference itself.  tests/golden/ref_farm.json: full runs of the reference binary built with -DMPI
+    (oracle/Makefile ref_mpi, the container's mpich) under mpiexec with workers + 1 ranks in its synchronous mode
+    (nested_sampling.F90:262-286: seeds for all workers from one snapshot, the babies stored at the worker's index, consumed from the
+    last worker down, the epoch guard of :313, the updates in the middle of a nursery), every rank's generator fed from its own
+    Philox stream.  The oracle's farm mode -- the SAME nursery loop its keyed mode runs for the engine, with the streams arranged as
+    the farm's ranks consume them -- must give the same run: integers exact, logZ to round-off, the dead file's columns."""
+    cases = golden["ref_farm"]
+    assert len(cases) >= 6 and {c["workers"] for c in cases} >= {2, 4, 8} and any(c["clustering"] for c in cases)
+    for c in cases:
+        lo, hi = BOX[c["like"]]
+        s = orc.settings(c["nDims"], c["nDerived"], nlive=c["nlive"], num_repeats=c["num_repeats"], seed=c["seed"], batch=c["workers"],
+                         sequential_rng=1, time_speeds_draw=1, do_clustering=c["clustering"], farm=1)
+        L, P, keep = orc.make_problem(c["like"], c["nDims"], lo, hi)
+        o = orc.run(s, L, P)
+        assert o["ndead"] == c["ndead"] and o["nlike"] == c["nlike"], (c["like"], c["workers"], o["ndead"], c["ndead"], o["nlike"], c["nlike"])
+        assert abs(o["logZ"] - c["logZ"]) < 1e-10 and abs(o["logZerr"] - c["logZerr"]) < 1e-10, c
+        D, nDer = c["nDims"], c["nDerived"]
+        logL = o["dead"][:, -1]; birth = o["dead"][:, -2]
+        assert abs(logL.sum() - c["dead_logL_sum"]) < 1e-9 * max(1.0, abs(c["dead_logL_sum"]))
+        assert abs(birth[birth > -1e29].sum() - c["dead_birth_sum"]) < 1e-9 * max(1.0, abs(c["dead_birth_sum"]))
+        for row, ref in ((o["dead"][0], c["dead_first_row"]), (o["dead"][-1], c["dead_last_row"])):    # theta, phi, logL, birth
+            mine = np.concatenate([row[D:2 * D + nDer], [row[-1], row[-2]]])
+            assert np.allclose(mine, np.array(ref), rtol=1e-12, atol=1e-12), (mine, ref)
+
+
 def test_oracle_keyed_mode_statistics_against_native_reference(golden):
     """keyed RNG (the engine's layout): logZ is statistically compatible with the untouched
     reference over its 8 seeds (mean within 3 standard errors) and with the analytic truth 0"""
