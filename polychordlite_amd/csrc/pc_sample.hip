@@ -30,26 +30,28 @@ template <int DPL, int NROWS>
 __device__ __forceinline__ double wsum(double v) { return (DPL > 1) ? wave_sum<4>(v) : wave_sum<NROWS>(v); }
 
 // returns logL of theta (uniform over the wave).  ybuf: per-wave LDS scratch of >= D doubles.
-template <int DPL, int NROWS>
+// (KIND >= 0: the likelihood is known when the kernel is compiled -- k_slice's LEAN variants -- and the other branches are not there)
+template <int DPL, int NROWS, int KIND = -1>
 __device__ __forceinline__ double like_eval(const PcState &S, const double (&th)[DPL], const LaneDims<DPL> &ld,
                                             int lane, double *ybuf)
 {
     const int D = S.D;
     const PcLike &L = S.like;
-    if (L.kind == PC_LIKE_GAUSSIAN) {            // gaussian.f90:25-34
+    const int kind = KIND >= 0 ? KIND : L.kind;
+    if (kind == PC_LIKE_GAUSSIAN) {            // gaussian.f90:25-34
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) if (ld.on[k]) { const double z = (th[k] - L.mu) * L.inv_sigma; s += z * z; }
         s = wsum<DPL, NROWS>(s);
         return L.norm - s / 2.0;
-    } else if (L.kind == PC_LIKE_RASTRIGIN) {    // rastrigin.f90:33
+    } else if (kind == PC_LIKE_RASTRIGIN) {    // rastrigin.f90:33
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k)
             if (ld.on[k]) s += 8.515435146961291 /* log(4991.21750) */ + th[k] * th[k] - 10.0 * cos(PC_TWO_PI * th[k]);
         s = wsum<DPL, NROWS>(s);
         return -s;
-    } else if (L.kind == PC_LIKE_TWIN_GAUSSIAN) {  // twin_gaussian.f90:29-46
+    } else if (kind == PC_LIKE_TWIN_GAUSSIAN) {  // twin_gaussian.f90:29-46
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k)
@@ -82,20 +84,21 @@ __device__ __forceinline__ double like_eval(const PcState &S, const double (&th)
 }
 
 // derived parameters of an accepted point (lane-uniform results)
-template <int DPL, int NROWS>
+template <int DPL, int NROWS, int KIND = -1>
 __device__ __forceinline__ void like_phi(const PcState &S, const double (&th)[DPL], const LaneDims<DPL> &ld,
                                          int lane, double &phi0, double &phi1)
 {
     phi0 = 0.0; phi1 = 0.0;
     if (S.nDer == 0) return;
-    if (S.like.kind == PC_LIKE_GAUSSIAN) {        // gaussian.f90:36-37
+    const int kind = KIND >= 0 ? KIND : S.like.kind;
+    if (kind == PC_LIKE_GAUSSIAN) {        // gaussian.f90:36-37
         double r2 = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) if (ld.on[k]) r2 += (th[k] - S.like.mu) * (th[k] - S.like.mu);
         r2 = wsum<DPL, NROWS>(r2);
         phi0 = sqrt(r2);
         if (S.nDer >= 2) phi1 = pc_log_ball(phi0, S.D, S.like.log_vn);
-    } else if (S.like.kind == PC_LIKE_TWIN_GAUSSIAN) {   // twin_gaussian.f90:48-52
+    } else if (kind == PC_LIKE_TWIN_GAUSSIAN) {   // twin_gaussian.f90:48-52
         const double t0 = readlane_f64(th[0], 0);
         phi0 = (t0 > 0.5) ? 1.0 : -1.0;
     }
@@ -1002,7 +1005,7 @@ struct ChainCtx {
 };
 
 // calculate_point (calculate.f90:6-50) at x0 + t*nh; leaves cube/theta of the trial in registers
-template <int DPL, int NROWS>
+template <int DPL, int NROWS, int KIND = -1>
 __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double (&x0)[DPL], const double (&nh)[DPL],
                                           double t, double (&cube)[DPL], double (&th)[DPL])
 {
@@ -1034,7 +1037,7 @@ __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double 
     }
 #pragma unroll
     for (int k = 0; k < DPL; ++k) th[k] = C.ld.lo[k] + C.ld.span[k] * cube[k];
-    const double logL = like_eval<DPL, NROWS>(C.S, th, C.ld, C.lane, C.ybuf);
+    const double logL = like_eval<DPL, NROWS, KIND>(C.S, th, C.ld, C.lane, C.ybuf);
     if (logL > C.S.logzero) C.nlike++;
     return logL;
 }
@@ -1042,11 +1045,12 @@ __device__ __forceinline__ double eval_at(ChainCtx<DPL, NROWS> &C, const double 
 // Two independent trial points at once (the two ends of the initial bracket): the per-point work is a
 // dependent chain (FMA -> compare -> reduction), so the second evaluation rides in the shadow of the first.
 // Straight-line code: both likelihoods are computed unconditionally and masked afterwards.
-template <int DPL, int NROWS>
+template <int DPL, int NROWS, int KIND = -1>
 __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double (&x0)[DPL], const double (&nh)[DPL],
                                           double tA, double tB, double &lA, double &lB)
 {
     const PcLike &L = C.S.like;
+    const int kind = KIND >= 0 ? KIND : L.kind;
     if (C.quad) {
         bool oA = false, oB = false;
 #pragma unroll
@@ -1068,7 +1072,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
         if (C.ld.on[k]) { outA |= (cA < 0.0) | (cA > 1.0); outB |= (cB < 0.0) | (cB > 1.0); }
         const double thA = C.ld.lo[k] + C.ld.span[k] * cA, thB = C.ld.lo[k] + C.ld.span[k] * cB;
         if (C.ld.on[k]) {
-            if (L.kind == PC_LIKE_RASTRIGIN) {
+            if (kind == PC_LIKE_RASTRIGIN) {
                 sA += 8.515435146961291 + thA * thA - 10.0 * cos(PC_TWO_PI * thA);
                 sB += 8.515435146961291 + thB * thB - 10.0 * cos(PC_TWO_PI * thB);
             } else {
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
     }
     const bool oa = __ballot(outA) != 0ull, ob = __ballot(outB) != 0ull;
     sA = wsum<DPL, NROWS>(sA); sB = wsum<DPL, NROWS>(sB);
-    if (L.kind == PC_LIKE_RASTRIGIN) { lA = -sA; lB = -sB; }
+    if (kind == PC_LIKE_RASTRIGIN) { lA = -sA; lB = -sB; }
     else {
         s2A = wsum<DPL, NROWS>(s2A); s2B = wsum<DPL, NROWS>(s2B);
         lA = pc_logaddexp(L.norm - sA / 2.0, L.norm - s2A / 2.0) - 0.6931471805599453;
@@ -1118,10 +1122,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
 // several runs of a device in step (Cohort, pc_engine.hip): the same statements on each run's own state, blockIdx.y = run.  (Included, not
 // called: handing the state to a function by reference moved fused multiply-adds in the one-run kernel -- -ffp-contract=fast works on
 // whatever the optimiser has made of the code -- and the lane-per-chain kernel of pc_slice_t.hip is matched to that kernel's ISA.)
-template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0>
+template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, int LEAN = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice_many(const PcManyRec *__restrict__ R, int phi_lds, int mat_lds)
 {
-    constexpr int LEAN = 0;
     const PcState S = R[blockIdx.y].S;
     const unsigned batch = (unsigned)R[blockIdx.y].ia[0];
 #include "pc_slice_body.inc"
@@ -1229,6 +1232,14 @@ extern "C" int pc_slice_fusable(const PcState *S)
     return !off && S->D <= 24 && pc_nhats_splittable(S) && S->ngrade <= 1 && S->like.kind != PC_LIKE_CORR_GAUSSIAN && S->nr <= 1024;
 }
 
+// the functor variants of k_slice (LEAN = 3 Rastrigin, 4 twin Gaussian): one grade, keyed draws
+static int slice_lean_functor(const PcState *S)
+{
+    static const bool off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
+    if (off || S->ngrade > 1 || S->seq_mode) return 0;
+    return S->like.kind == PC_LIKE_RASTRIGIN ? 3 : (S->like.kind == PC_LIKE_TWIN_GAUSSIAN ? 4 : 0);
+}
+
 extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchains, hipStream_t st)
 {
     if (!pc_slice_fusable(S)) return 1;
@@ -1240,7 +1251,12 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     if (sh > 150 * 1024) return 1;
     static const bool lean_off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
     const bool lean = !lean_off && S->like.kind == PC_LIKE_GAUSSIAN && !(S->ablate & 1) && phi_lds && S->nr <= 64 && !S->seq_mode && S->ngrade <= 1;
+    const int leanf = slice_lean_functor(S);
+#define PC_SLICE_FUSED_L(NROWS, FW, LN) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
 #define PC_SLICE_FUSED(NROWS, FW) { \
+        if (leanf == 3) PC_SLICE_FUSED_L(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_L(NROWS, FW, 4) else \
         if (lean) { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
@@ -1250,6 +1266,7 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     else if (D <= 16) PC_SLICE_FUSED(1, 16)
     else PC_SLICE_FUSED(2, 24)
 #undef PC_SLICE_FUSED
+#undef PC_SLICE_FUSED_L
     return 0;
 }
 
@@ -1267,24 +1284,30 @@ extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R
         const int FWv = D <= 8 ? 8 : (D <= 16 ? 16 : 24);
         const size_t sh = sh0 + (phi_lds ? tb : 0) + sizeof(double) * ((size_t)FWv * D + (size_t)S->nr * (D + 2));
         if (sh > 150 * 1024) return 1;
-#define PC_SLICE_FUSED_M(NROWS, FW) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_slice_many<1, NROWS, false, 1, FW>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+        const int leanf = slice_lean_functor(S);
+#define PC_SLICE_FUSED_ML(NROWS, FW, LN) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<1, NROWS, false, 1, FW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice_many<1, NROWS, false, 1, FW, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+#define PC_SLICE_FUSED_M(NROWS, FW) { if (leanf == 3) PC_SLICE_FUSED_ML(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_ML(NROWS, FW, 4) else PC_SLICE_FUSED_ML(NROWS, FW, 0) }
         if (D <= 8) PC_SLICE_FUSED_M(1, 8)
         else if (D <= 16) PC_SLICE_FUSED_M(1, 16)
         else PC_SLICE_FUSED_M(2, 24)
 #undef PC_SLICE_FUSED_M
+#undef PC_SLICE_FUSED_ML
         return 0;
     }
     if (S->like.kind == PC_LIKE_CORR_GAUSSIAN || S->ngrade > 1 || S->seq_mode || D > 64) return 1;
     const size_t sh = sh0 + (phi_lds ? tb : 0);
-#define PC_SLICE_M(DPL, NROWS) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<DPL, NROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_slice_many<DPL, NROWS, false>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+    const int leanf = slice_lean_functor(S);
+#define PC_SLICE_ML(DPL, NROWS, LN) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<DPL, NROWS, false, 1, 0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice_many<DPL, NROWS, false, 1, 0, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
+#define PC_SLICE_M(DPL, NROWS) { if (leanf == 3) PC_SLICE_ML(DPL, NROWS, 3) else if (leanf == 4) PC_SLICE_ML(DPL, NROWS, 4) else PC_SLICE_ML(DPL, NROWS, 0) }
     if (D <= 16) PC_SLICE_M(1, 1)
     else if (D <= 32) PC_SLICE_M(1, 2)
     else PC_SLICE_M(1, 4)
 #undef PC_SLICE_M
+#undef PC_SLICE_ML
     return 0;
 }
 
@@ -1331,7 +1354,12 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
 #define PC_SLICE_LAUNCH1(DPL, NROWS, GR) { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, GR>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
-#define PC_SLICE_LAUNCH(DPL, NROWS) { if (S->ngrade > 1 || S->seq_mode) PC_SLICE_LAUNCH1(DPL, NROWS, true) else PC_SLICE_LAUNCH1(DPL, NROWS, false) }
+    const int leanf = (D <= 64 && !mat_lds) ? slice_lean_functor(S) : 0;
+#define PC_SLICE_LAUNCHL(DPL, NROWS, LN) { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, false, 1, 0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((k_slice<DPL, NROWS, false, 1, 0, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
+#define PC_SLICE_LAUNCH(DPL, NROWS) { if (DPL == 1 && leanf == 3) PC_SLICE_LAUNCHL(1, NROWS, 3) else if (DPL == 1 && leanf == 4) PC_SLICE_LAUNCHL(1, NROWS, 4) else \
+        if (S->ngrade > 1 || S->seq_mode) PC_SLICE_LAUNCH1(DPL, NROWS, true) else PC_SLICE_LAUNCH1(DPL, NROWS, false) }
     if (D <= 16) PC_SLICE_LAUNCH(1, 1)
     else if (D <= 32) PC_SLICE_LAUNCH(1, 2)
     else if (D <= 64) PC_SLICE_LAUNCH(1, 4)
@@ -1339,6 +1367,7 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     else if (D <= 256) PC_SLICE_LAUNCH(4, 4)
     else return 1;
 #undef PC_SLICE_LAUNCH
+#undef PC_SLICE_LAUNCHL
 #undef PC_SLICE_LAUNCH1
     return 0;
 }
