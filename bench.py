@@ -81,7 +81,7 @@ def random_correlated_gaussian(D, seed=12345, sigma0=0.1):
 # ---- latency model of the dominant kernel (the path is latency bound, not bandwidth bound: SURVEY 8d).  k_slice runs one
 # wavefront per chain with one cube coordinate per lane; a slice is a chain of DEPENDENT fp64 operations, and on a wave that has
 # its SIMD to itself a dependent fp64 operation issues every 32 cycles (tools/ubench.hip on this hardware: fma 32, LDS round
-# trip 70, exp 140, log 480, div 100 cycles at 2.4 GHz; profiles/r03_slice_cycles.json).  Dependent operations per slice of the
+# trip 70, exp 140, log 480, div 100 cycles at 2.4 GHz; profiles/r04_slice_cycles.json).  Dependent operations per slice of the
 # closed-form Gaussian chord (pc_sample.hip k_slice), section by section:
 SLICE_CHAIN = {  # section: (dependent fp64 ops, LDS round trips, what)
     "take_over_and_philox": (2, 1, "next direction from LDS; one Philox4x32-10 call per four slices (10 rounds x ~3 integer ops / 4)"),
@@ -107,11 +107,11 @@ def latency_model(runs, kern):
     out = {"unit": "shader cycles per slice (one wavefront = one chain, 2.4 GHz)", "model_min_by_section": model, "model_min": sum(model.values()),
            "dependent_fp64_cycles": DEP_FP64_CYCLES, "lds_round_trip_cycles": LDS_CYCLES, "evaluations_per_slice": evals_per_slice,
            "chain": {k: v[2] for k, v in SLICE_CHAIN.items()}}
-    pth = os.path.join(ROOT, "profiles", "r03_slice_cycles.json")
-    if os.path.exists(pth):
+    pth = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_slice_cycles.json", "r03_slice_cycles.json")) if os.path.exists(q)), None)
+    if pth:
         m = json.load(open(pth))
         out["measured_by_section"] = m["cycles_per_slice"]; out["measured"] = m["cycles_per_slice_total"]
-        out["measured_source"] = "profiles/r03_slice_cycles.json (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)"
+        out["measured_source"] = "profiles/%s (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)" % os.path.basename(pth)
         out["frac_of_model"] = out["model_min"] / m["cycles_per_slice_total"]
     if ks:
         out["launch_cycles_per_slice_this_run"] = ks[0]["avg_launch_us"] * CLOCK_MHZ / nr      # whole launch / slices: includes seed choice, shuffle, whitening, derived parameters
@@ -501,7 +501,7 @@ def main():
             if lp:
                 pmc, pmc_src = lp, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each, over 3 runs of this workload"
         if not pmc:
-            for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+            for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth) and args.workload == "c2":
                     pmc = json.load(open(pth))["kernels"]; pmc_src = "profiles/" + name
