@@ -640,7 +640,16 @@ __device__ __forceinline__ void consume_par_body(const PcState &S)
         marks_sh[0] = Kl; marks_sh[1] = marks;
         const unsigned err = (pri == 2) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
         note_early[0] = (unsigned)status | (err << 8) | ((unsigned)(marks > 0) << 17) | ((unsigned)(marks > 0x3FFF ? 0x3FFF : marks) << 18);
-        note_early[1] = (unsigned)(T - ts); note_early[2] = (unsigned)(ndead0 + vps);
+        // lived deaths until the next update trigger, as the state stands after this launch (PcCtl::upd_in: the host decides by it
+        // whether to enqueue the next nursery's sampling before it has seen that round's outcome)
+        int upd_in_e;
+        {
+            const double Xe = Xp0 + (double)Kp * d01, lastu = marks > 0 ? Xp0 + (double)Kl * d01 : ((pri == 0) ? Xe : ctl->logX_last_update);
+            const double left = (Xe - (lastu + S.log_cf)) / (-d01);
+            upd_in_e = left > 0.0 ? (left < 65535.0 ? (int)ceil(left) : 65535) : 1;
+        }
+        note_early[5] = (unsigned)upd_in_e;
+        note_early[1] = ((unsigned)(T - ts) & 0xFFFFu) | ((unsigned)upd_in_e << 16); note_early[2] = (unsigned)(ndead0 + vps);
         note_early[3] = (unsigned)(S.pool ? S.pool_base + S.pool_rows : nph0 + ts * nr);
         note_early[4] = 1u | ((unsigned)(ctl->ncluster_dead & 0xFFFF) << 16);
     }
@@ -751,6 +760,7 @@ __device__ __forceinline__ void consume_par_body(const PcState &S)
             ctl->upd_thr = key2d(uKey[Kl - 1]); ctl->upd_keep_thr = (Kp > Kl) ? 1 : 0;
             ctl->logX_last_update = Xp0 + (double)Kl * d01;
         }
+        ctl->upd_in = (int)note_early[5];
         if (S.use_prec) ctl->live_logZ = (Kp ? sLse[Kp - 1] : lseRef0 + ulog[3]) - l0 + Xp;   // (= lse_m + log(lse_s), taken in phase 7)
         cyc[ncy++] = clock64();
 #ifdef PAR_NO_DBG

@@ -47,7 +47,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     int upd_keep_thr, upd_pad;          // deaths after the mark: death_thr stays the last death's logL
     double upd_thr;                     // logL of the death that triggered the mark (clean_phantoms' threshold)
     int chol_suspect, chol_pad;         // the blocked factorisation met a pivot it does not trust: the reference-order kernel behind it decides
-    int spec_ok, spec_pad;              // parallel contraction: number of the nursery that may be sampled at once (this one was consumed whole, no
+    int spec_ok, upd_in;                // upd_in: lived deaths until the next update trigger, as the state stands after this launch (0 = not known); spec_ok: parallel contraction: number of the nursery that may be sampled at once (this one was consumed whole, no
                                         // update is due, the run goes on), or -1: what a speculatively enqueued k_slice asks first
 };
 
@@ -196,7 +196,8 @@ __device__ __forceinline__ void pc_publish_ctl(const PcState &S)
         const PcCtl *c = S.ctl;
         pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16) |
                         ((unsigned)(c->upd_pending != 0) << 17) | ((unsigned)(c->upd_marks > 0x3FFF ? 0x3FFF : c->upd_marks) << 18);   // (a launch consumes <= 1024 chains: <= 1024 marks)
-        pc_note_sh[1] = (unsigned)c->i_nursery; pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
+        pc_note_sh[1] = ((unsigned)c->i_nursery & 0xFFFFu) | ((unsigned)(c->upd_in < 0 ? 0 : (c->upd_in > 0xFFFF ? 0xFFFF : c->upd_in)) << 16);   // (a nursery holds <= 1024 chains)
+        pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
         pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (ncluster <= 16384: Engine::grow_clusters; the full dead count comes with the block)
     }
     __syncthreads();
