@@ -831,7 +831,11 @@ struct Engine {
         // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read
         // (nDims > 64: the bases cost more than the rest of a nursery's round -- they are drawn up to three nurseries ahead,
         //  through the updates as well)
-        raw_depth = split_q ? RAW_RING : 2;
+        // (nDims <= 24: three -- the bases of nursery b + 2 are drawn under nursery b's contraction.  With two, nursery b + 1's were drawn
+        //  there and k_slice(b + 1) waited for them across streams: kernel 39 us + ~10 us for the event to cross, a path as long as
+        //  contraction + row copies + the host's look at the stamp, which is why enqueueing k_slice ahead changed nothing)
+        static const int depth_env = std::getenv("PC_RAW_DEPTH") ? std::max(2, std::min(RAW_RING, std::atoi(std::getenv("PC_RAW_DEPTH")))) : 3;
+        raw_depth = split_q ? RAW_RING : depth_env;
         raw_buf[0] = S.nhat_raw;
         for (int r = 1; r < raw_depth; ++r) raw_buf[r] = ((D <= 24 || split_q) && S.nhat_raw) ? dalloc<double>(raw_n) : nullptr;
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.slot_dead = dalloc<int>(Ncap); HIPCHK(hipMemsetAsync(S.slot_dead, 0xFF, sizeof(int) * Ncap, st)); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
