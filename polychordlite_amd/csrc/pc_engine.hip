@@ -447,6 +447,11 @@ struct Cohort {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // the bases of the NEXT nursery, next to this one's sampling and contraction
     hipEvent_t ev_up = nullptr, ev_next = nullptr; bool next_pending = false;
+    // bases drawn TWO nurseries ahead: a sampling launch waits for the launch that drew ITS bases (numbered), not for the second stream's
+    // latest -- with one event for the latest, sixteen runs' k_slice_t waited 140 us per round without an update for the 250 us of
+    // deviates + bases launched a round before
+    hipEvent_t ev_seq[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long seq_launched = 0, seq_waited = 0; bool seq_open = false;
+    int seq_for_next() const { return (int)(seq_launched + 1); }      // (the number the bases written down now will be launched under)
     struct Rec { int kind; PcState S; void *p[10]; long long a[4]; int ia[6]; };      // a: what the runs of one launch must share; ia: each run's own (PcManyRec::ia)
     std::vector<Rec> pend;
     static constexpr int RING = 4;
@@ -551,7 +556,13 @@ struct Cohort {
                 HIPCHK(hipStreamWaitEvent(st2, ev_up, 0));
                 q = st2; used_st2 = true;
             }
-            if (k == CK_SLICE || k == CK_SLICE_G) wait_next();   // (its bases were drawn over there)
+            if (k == CK_SLICE || k == CK_SLICE_G) {             // (its bases were drawn over there)
+                int need = 0; bool numbered = st2 != nullptr;
+                for (size_t x = i; x < j; ++x) { numbered = numbered && ord[x]->ia[3] > 0; need = std::max(need, ord[x]->ia[3]); }
+                if (numbered && (unsigned long long)need <= seq_launched) {
+                    if ((unsigned long long)need > seq_waited) { HIPCHK(hipStreamWaitEvent(st, ev_seq[need & 3], 0)); seq_waited = (unsigned long long)need; }
+                } else wait_next();
+            }
             int rc = 1;
             switch (k) {
             case CK_COMPACT: { int nbm = 0; for (size_t x = i; x < j; ++x) nbm = std::max(nbm, ord[x]->ia[2]); rc = pc_launch_clean_many(d, cnt, nbm, q); } break;
@@ -572,16 +583,23 @@ struct Cohort {
             }
             if (rc == 0) n_fused += cnt;
             else for (size_t x = i; x < j; ++x) { single(*ord[x], q); n_single++; }
-            if (k == CK_BASES_NEXT && st2) { HIPCHK(hipEventRecord(ev_next, st2)); next_pending = true; }
+            if (k == CK_BASES_NEXT && st2) {
+                HIPCHK(hipEventRecord(ev_next, st2)); next_pending = true;
+                if (!seq_open) { seq_launched++; seq_open = true; }
+                if (!ev_seq[seq_launched & 3]) ev_seq[seq_launched & 3] = hpool().get_sync_event();
+                HIPCHK(hipEventRecord(ev_seq[seq_launched & 3], st2));
+            }
             i = j;
         }
         HIPCHK(hipEventRecord(ev[slot], st)); ev_used[slot] = true;
         if (used_st2 && ev2[slot]) { HIPCHK(hipEventRecord(ev2[slot], st2)); ev2_used[slot] = true; }
         pend.clear();
+        seq_open = false;
         run_post();
     }
     void destroy()
     {
+        for (int k = 0; k < 4; ++k) if (ev_seq[k]) { hpool().put_sync_event(ev_seq[k]); ev_seq[k] = nullptr; }
         for (int k = 0; k < RING; ++k) {
             if (ev_used[k]) (void)hipEventSynchronize(ev[k]);
             if (ev2_used[k]) (void)hipEventSynchronize(ev2[k]);
@@ -634,7 +652,7 @@ struct Engine {
     hipEvent_t ev_main = nullptr;
     // ring of bases drawn ahead on the side stream: nursery b's live in raw_buf[b % raw_depth]
     static constexpr int RAW_RING = 4;
-    struct RawSlot { hipEvent_t ready = nullptr, consumed = nullptr; unsigned batch = 0; int B = 0; bool valid = false, waited = false, used = false; };
+    struct RawSlot { hipEvent_t ready = nullptr, consumed = nullptr; unsigned batch = 0; int B = 0; bool valid = false, waited = false, used = false; int co_seq = 0; };
     RawSlot ring[RAW_RING];
     int raw_depth = 2;
     double *h_dead = nullptr; size_t h_dead_cap = 0, h_dead_copied = 0;
@@ -2113,12 +2131,13 @@ struct Engine {
             const bool multi = co != nullptr || g_active_dev[dev & 63].load(std::memory_order_relaxed) > 1;
             const bool split = splittable && !multi;
             bool fused_slice = false;
+            int bases_seq = 0;                        // in step with other runs: the number of the launch that drew this nursery's bases (0: in line)
             if (splittable) {
                 // the bases of this nursery were drawn on the side stream while earlier ones were sampled and consumed (or
                 // are drawn now)
                 RawSlot &rs = ring[batch % raw_depth];
                 S.nhat_raw = raw_buf[batch % raw_depth];
-                if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); }      // (in step with other runs: their common wait, Cohort::flush)
+                if (rs.valid && rs.batch == batch && rs.B == B) { if (!rs.waited) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0)); bases_seq = rs.co_seq; }      // (in step with other runs: the wait for the launch that drew them, Cohort::flush)
                 else {
                     if (rs.valid) HIPCHK(hipStreamWaitEvent(st, rs.ready, 0));       // (a stale job may still be writing there)
                     if (co && pc_bases_t_ok(&S)) co->rec(CK_BASES, S, {}, {(long long)B}, {(int)batch});
@@ -2137,26 +2156,14 @@ struct Engine {
             // next to other runs of this device (or settings.ablate bit 6): the lane = chain kernel (pc_slice_t.hip), the same
             // numbers from 1/60 of the wavefronts
             else if (fused_slice && !spec && (multi || (cfg.ablate & 64)) && pc_slice_t_ok(&S, h_ctl->ncluster)) {
-                if (co) co->rec(CK_SLICE, S, {}, {(long long)B}, {(int)batch}); else (void)pc_launch_slice_t(&S, batch, B, st);
-                // in step with other runs: the bases of the next nursery on the runs' second stream, next to this round's kernels
-                if (co && co->st2 && splittable && raw_depth >= 2 && pc_bases_t_ok(&S)) {
-                    const unsigned x = batch + 1;
-                    RawSlot &rn = ring[x % raw_depth];
-                    PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
-                    co->rec(CK_BASES_NEXT, S1, {}, {(long long)B}, {(int)x});
-                    rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true;
-                }
+                if (co) co->rec(CK_SLICE, S, {}, {(long long)B}, {(int)batch, 0, 0, bases_seq}); else (void)pc_launch_slice_t(&S, batch, B, st);
+                // in step with other runs: the bases of the next nurseries on the runs' second stream, next to this round's kernels
+                if (co && co->st2 && splittable && raw_depth >= 2 && pc_bases_t_ok(&S)) bases_ahead(batch);
             }
             else if (co && !callback_mode && !spec && cohort_general_ok() && (fused_slice || !splittable)) {
                 // in step with other runs, any device likelihood / several clusters: the one-run kernel with the run in the grid
-                co->rec(CK_SLICE_G, S, {}, {(long long)B, fused_slice ? 1LL : 0LL}, {(int)batch});
-                if (fused_slice && co->st2 && raw_depth >= 2 && pc_bases_t_ok(&S)) {
-                    const unsigned x = batch + 1;
-                    RawSlot &rn = ring[x % raw_depth];
-                    PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
-                    co->rec(CK_BASES_NEXT, S1, {}, {(long long)B}, {(int)x});
-                    rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true;
-                }
+                co->rec(CK_SLICE_G, S, {}, {(long long)B, fused_slice ? 1LL : 0LL}, {(int)batch, 0, 0, fused_slice ? bases_seq : 0});
+                if (fused_slice && co->st2 && raw_depth >= 2 && pc_bases_t_ok(&S)) bases_ahead(batch);
             }
             else if ((co ? (co->flush(), co->wait_next(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             S.spec_guard = 0;
@@ -2167,6 +2174,20 @@ struct Engine {
             S.nn_valid = 0; nursery_left = B;
         }
         return true;
+    }
+
+    // in step with other runs: the bases of the nurseries after `cur` that are not drawn yet (two ahead with a ring of three) written down for
+    // the cohort's second stream
+    void bases_ahead(unsigned cur)
+    {
+        const unsigned ahead = raw_depth >= 3 ? 2u : 1u;
+        for (unsigned x = cur + 1; x <= cur + ahead; ++x) {
+            RawSlot &rn = ring[x % raw_depth];
+            if (rn.valid && rn.batch == x && rn.B == B) continue;
+            PcState S1 = S; S1.nhat_raw = raw_buf[x % raw_depth];
+            co->rec(CK_BASES_NEXT, S1, {}, {(long long)B}, {(int)x});
+            rn.valid = true; rn.batch = x; rn.B = B; rn.waited = true; rn.co_seq = co->seq_for_next();
+        }
     }
 
     // the bases of the nurseries after `cur`, on the side stream (behind cur's sampling kernel on the main stream)

@@ -8,7 +8,7 @@ for r in csv.DictReader(open(fn)):
 rows.sort()
 t_end = max(r[1] for r in rows); t0 = t_end - int(win * 1e6)
 W = [r for r in rows if r[0] >= t0]
-short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n)).replace("(anonymous namespace)::", "")[:44]
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n).replace("(anonymous namespace)::", ""))[:44]
 tot = collections.Counter(); cnt = collections.Counter()
 for s, e, n, q, gx, gy in W: tot[short(n)] += e - s; cnt[short(n)] += 1
 ev = sorted([(s, 1) for s, e, *_ in W] + [(e, -1) for s, e, *_ in W]); busy = 0; depth = 0; last = None
