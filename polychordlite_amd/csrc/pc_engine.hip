@@ -2180,7 +2180,11 @@ struct Engine {
     // the cohort's second stream
     void bases_ahead(unsigned cur)
     {
-        const unsigned ahead = raw_depth >= 3 ? 2u : 1u;
+        // (two ahead -- PC_COHORT_AHEAD=2 -- takes the wait for the bases out of a round without an update, but the bases kernels then run
+        //  next to k_slice_t: in a process of the engine's own sixteen runs take as long as with one ahead and 32 / 64 runs 2 % less, in
+        //  bench.py's process (the HIP runtime PyTorch brings) 8-10 % MORE: one ahead)
+        static const unsigned ahead_env = std::getenv("PC_COHORT_AHEAD") ? (unsigned)std::max(1, std::min(2, std::atoi(std::getenv("PC_COHORT_AHEAD")))) : 1u;
+        const unsigned ahead = raw_depth >= 3 ? ahead_env : 1u;
         for (unsigned x = cur + 1; x <= cur + ahead; ++x) {
             RawSlot &rn = ring[x % raw_depth];
             if (rn.valid && rn.batch == x && rn.B == B) continue;

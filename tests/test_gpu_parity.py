@@ -504,12 +504,18 @@ def test_twin_gaussian_evidence_statistics_match_the_reference(engine, golden):
     s.batch = 0                                         # the engine's default nursery
     lo, hi = BOX["twin_gaussian"]
     L, P, keep = api.make_problem("twin_gaussian", c["nDims"], c["nDerived"], lo, hi)
-    z, nd = [], []
+    z, nd, per, per_all = [], [], [], []
     for i in range(32):
         s.seed = 900 + i
         g = api.run(s, L, P)
         z.append(g["logZ"]); nd.append(int((g["logweights"] > -1e29).sum()))   # dead points proper, without the failed spawns of a nursery
+        per.append((g["nlike"] - g["nlike_failed"]) / nd[-1]); per_all.append(g["nlike"] / nd[-1])
     z = np.array(z)
+    # likelihood evaluations per dead point: the chains that placed a point cost what the reference's cost (177.3); with the babies born
+    # below the contour by the time a nursery of nlive/2 gets to them, 1.23 times that
+    ref_per = np.mean([r["nlike"] / r["ndead"] for r in ref["runs"]])
+    assert abs(np.mean(per) / ref_per - 1.0) < 0.05, (np.mean(per), ref_per)
+    assert np.mean(per_all) / ref_per < 1.3, (np.mean(per_all), ref_per)
     sem = np.sqrt(z.var(ddof=1) / z.size + zr.var(ddof=1) / zr.size)
     assert abs(z.mean() - zr.mean()) < 3.0 * sem, (z.mean(), zr.mean(), sem)
     assert 0.6 < z.std(ddof=1) / zr.std(ddof=1) < 1.6
