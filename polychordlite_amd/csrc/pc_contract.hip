@@ -279,8 +279,16 @@ __global__ __launch_bounds__(256) void k_nn_gather(PcState S, int nleft) { nn_ga
 __global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R) { const PcManyRec &r = R[blockIdx.y]; nn_gather_body(r.S, r.ia[1]); }
 
 #define NND_SC 16                                   /* at most this many scanners per pair of babies */
+// Round 4: most of the candidates cannot die before the chain is looked at.  The deaths of a nursery take the snapshot's points in
+// ascending logL (k_sort_live's order); before chain w is consumed at most ncand = nleft - 1 - w chains were, so a snapshot point of
+// rank >= ncand is CERTAINLY alive then ("safe").  The nearest safe point ends every walk of a list: what the contraction needs is the
+// candidates that may be dead by then ("uncertain": the ncand lowest snapshot points, the last babies of the chains before) that are
+// NEARER than the nearest safe point, ascending, and then that point -- the old list of the eight nearest, cut off behind its first safe
+// entry.  So a safe point costs a comparison (running minimum), and an uncertain one is inserted only if it beats that minimum: the
+// sorted insertion, three quarters of the kernel's instructions while every candidate went through it, is now rare.  use_rank = 0 (no
+// sorted order at hand): every candidate is uncertain, the old lists.
 template <int D>
-__device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int tile_pts)
+__device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int tile_pts, int use_rank)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DP = D | 1;                         // odd row stride: the scanners of a wave read different banks
@@ -288,8 +296,11 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
     const int w = blockIdx.x;                         // chain, w < nleft = entries still in the nursery
     double *pts = (double *)smem;                     // [tile_pts][DP]
     int *pcode = (int *)(pts + (size_t)tile_pts * DP);   // [tile_pts] code of each staged point, PC_NN_NONE = skip
+    int *psafe = pcode + tile_pts;                    // [tile_pts] 1: certainly alive when this chain is consumed
     double *md = (double *)smem;                      // [256][2][PC_NN_K] merge buffer: over the tile, once the last one has been scanned
     int *mc = (int *)(md + 256 * 2 * PC_NN_K);        // [256][2][PC_NN_K]
+    double *msd = (double *)smem;                     // [256][2] the scanners' nearest safe points (before the lists are laid down)
+    int *msc = (int *)(msd + 256 * 2);                // [256][2]
     if (w == 0) {                                     // liveness bookkeeping starts now
         for (int s = tid; s < Ncap; s += 256) S.nn_slot_owner[s] = -1;
         for (int c = tid; c < S.B; c += 256) S.nn_chain_slot[c] = -1;
@@ -300,6 +311,7 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
     const double *blog = S.baby_logL + (size_t)w * nr;
     const int ncand = nleft - 1 - w;                  // chains w+1 .. nleft-1 are consumed before w
     const int npts = Ncap + ncand;
+    const int *nn_rank = S.nn_code + (size_t)Ncap + S.B;      // [Ncap] rank of a slot's point in the snapshot's death order (k_sort_live)
     const int npair = (nr + 1) / 2;
     const int PG = npair < 256 ? npair : 256;         // pairs per pass
     const int nscan = (256 / PG) < NND_SC ? (256 / PG) : NND_SC;
@@ -318,23 +330,36 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
         double bda[PC_NN_K], bdb[PC_NN_K]; int bca[PC_NN_K], bcb[PC_NN_K];
 #pragma unroll
         for (int k = 0; k < PC_NN_K; ++k) { bda[k] = PC_HUGE; bdb[k] = PC_HUGE; bca[k] = PC_NN_NONE; bcb[k] = PC_NN_NONE; }
+        double sa = PC_HUGE, sb = PC_HUGE; int sca = PC_NN_NONE, scb = PC_NN_NONE;      // nearest safe point of this scanner
         auto insert = [&](double (&bd)[PC_NN_K], int (&bc)[PC_NN_K], double d2, int code) __attribute__((always_inline)) {
-            if (d2 < bd[PC_NN_K - 1]) {                           // sorted insertion, registers only
-                double cd = d2; int cc = code;
+            double cd = d2; int cc = code;                        // sorted insertion, registers only (the caller has compared with the last entry)
 #pragma unroll
-                for (int k = 0; k < PC_NN_K; ++k) {
-                    const bool sw = cd < bd[k];
-                    const double td = sw ? bd[k] : cd; const int tc = sw ? bc[k] : cc;
-                    bd[k] = sw ? cd : bd[k]; bc[k] = sw ? cc : bc[k];
-                    cd = td; cc = tc;
-                }
+            for (int k = 0; k < PC_NN_K; ++k) {
+                const bool sw = cd < bd[k];
+                const double td = sw ? bd[k] : cd; const int tc = sw ? bc[k] : cc;
+                bd[k] = sw ? cd : bd[k]; bc[k] = sw ? cc : bc[k];
+                cd = td; cc = tc;
+            }
+        };
+        auto take = [&](double a0, double b0, int c0, int safe) __attribute__((always_inline)) {
+            if (c0 == PC_NN_NONE) return;
+            if (safe) {
+                if (a0 < sa) { sa = a0; sca = c0; }
+                if (b0 < sb) { sb = b0; scb = c0; }
+            } else {
+                if (minea && a0 < bda[PC_NN_K - 1] && a0 < sa) insert(bda, bca, a0, c0);
+                if (mineb && b0 < bdb[PC_NN_K - 1] && b0 < sb) insert(bdb, bcb, b0, c0);
             }
         };
         for (int t0 = 0; t0 < npts; t0 += tile_pts) {
             const int tn = min(tile_pts, npts - t0);
             __syncthreads();
             // point t0 + q of this chain's candidates = entry t0 + q of the gathered array, the chains up to w skipped
-            for (int q = tid; q < tn; q += 256) { const int gi = t0 + q; pcode[q] = S.nn_code[gi < Ncap ? gi : gi + w + 1]; }
+            for (int q = tid; q < tn; q += 256) {
+                const int gi = t0 + q;
+                pcode[q] = S.nn_code[gi < Ncap ? gi : gi + w + 1];
+                psafe[q] = (use_rank && gi < Ncap && nn_rank[gi] >= ncand) ? 1 : 0;
+            }
             for (int e = tid; e < tn * D; e += 256) {
                 const int q = e / D, d = e - q * D, gi = t0 + q;
                 pts[(size_t)q * DP + d] = S.nn_pts[(size_t)(gi < Ncap ? gi : gi + w + 1) * D + d];
@@ -343,7 +368,7 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
             if (minea || mineb) {
                 int q = p;
                 for (; q + nscan < tn; q += 2 * nscan) {          // two points at a time: four sums in flight
-                    const int c0 = pcode[q], c1 = pcode[q + nscan];
+                    const int c0 = pcode[q], c1 = pcode[q + nscan], f0 = psafe[q], f1 = psafe[q + nscan];
                     const double *y0 = pts + (size_t)q * DP, *y1 = pts + (size_t)(q + nscan) * DP;
                     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
 #pragma unroll
@@ -352,21 +377,30 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
                         const double ta0 = xa[d] - u0, tb0 = xb[d] - u0, ta1 = xa[d] - u1, tb1 = xb[d] - u1;
                         a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); a1 = fma(ta1, ta1, a1); b1 = fma(tb1, tb1, b1);
                     }
-                    if (c0 != PC_NN_NONE) { if (minea) insert(bda, bca, a0, c0); if (mineb) insert(bdb, bcb, b0, c0); }
-                    if (c1 != PC_NN_NONE) { if (minea) insert(bda, bca, a1, c1); if (mineb) insert(bdb, bcb, b1, c1); }
+                    take(a0, b0, c0, f0); take(a1, b1, c1, f1);
                 }
                 if (q < tn) {
-                    const int c0 = pcode[q];
+                    const int c0 = pcode[q], f0 = psafe[q];
                     const double *y0 = pts + (size_t)q * DP;
                     double a0 = 0.0, b0 = 0.0;
 #pragma unroll
                     for (int d = 0; d < D; ++d) { const double u0 = y0[d]; const double ta0 = xa[d] - u0, tb0 = xb[d] - u0; a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); }
-                    if (c0 != PC_NN_NONE) { if (minea) insert(bda, bca, a0, c0); if (mineb) insert(bdb, bcb, b0, c0); }
+                    take(a0, b0, c0, f0);
                 }
             }
         }
-        // merge the partial lists of a baby: each is sorted, nscan-way pick by the pair's first scanner
-        __syncthreads();                              // (the merge buffer lies over the tile)
+        // the pair's nearest safe point: the scanners' minima meet (equal distances -- exact duplicates only -- go to the lower scanner)
+        __syncthreads();                              // (the buffers lie over the tile)
+        msd[tid * 2 + 0] = sa; msc[tid * 2 + 0] = sca; msd[tid * 2 + 1] = sb; msc[tid * 2 + 1] = scb;
+        __syncthreads();
+        double fs[2] = {PC_HUGE, PC_HUGE}; int fc[2] = {PC_NN_NONE, PC_NN_NONE};
+        if (act && p == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                for (int q = 0; q < nscan; ++q) { const double v = msd[(tid + q) * 2 + h]; if (v < fs[h]) { fs[h] = v; fc[h] = msc[(tid + q) * 2 + h]; } }
+        }
+        // merge the partial lists of a baby: each is sorted, nscan-way pick by the pair's first scanner, up to the nearest safe point
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < PC_NN_K; ++k) {
             md[(tid * 2 + 0) * PC_NN_K + k] = bda[k]; mc[(tid * 2 + 0) * PC_NN_K + k] = bca[k];
@@ -383,6 +417,7 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
 #pragma unroll
                 for (int q = 0; q < NND_SC; ++q) head[q] = 0;
                 int out[PC_NN_K];
+                bool closed = false;                              // the safe point has been written: nothing behind it matters
 #pragma unroll
                 for (int k = 0; k < PC_NN_K; ++k) {
                     double best = PC_HUGE; int bq = -1;
@@ -392,8 +427,10 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
                         if (v < best) { best = v; bq = q; }
                     }
                     int code = PC_NN_NONE;
+                    if (!closed && best < fs[h]) {
 #pragma unroll
-                    for (int q = 0; q < NND_SC; ++q) if (q == bq) { code = mc[((tid + q) * 2 + h) * PC_NN_K + head[q]]; head[q]++; }
+                        for (int q = 0; q < NND_SC; ++q) if (q == bq) { code = mc[((tid + q) * 2 + h) * PC_NN_K + head[q]]; head[q]++; }
+                    } else if (!closed) { code = fc[h]; closed = true; }
                     out[k] = mine ? code : PC_NN_NONE;
                 }
                 int4 *dst = (int4 *)(S.nn_list + ((size_t)w * nr + i) * PC_NN_K);
@@ -404,24 +441,24 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
         __syncthreads();
     }
 }
-template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d(PcState S, int nleft, int tile_pts) { nn_lists_d_body<D>(S, nleft, tile_pts); }
-template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d_many(const PcManyRec *__restrict__ R, int tile_pts)
+template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d(PcState S, int nleft, int tile_pts, int use_rank) { nn_lists_d_body<D>(S, nleft, tile_pts, use_rank); }
+template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d_many(const PcManyRec *__restrict__ R, int tile_pts, int use_rank)
 {
     const PcManyRec &r = R[blockIdx.y];
     if ((int)blockIdx.x >= r.ia[1]) return;
-    nn_lists_d_body<D>(r.S, r.ia[1], tile_pts);
+    nn_lists_d_body<D>(r.S, r.ia[1], tile_pts, use_rank);
 }
 static size_t nn_lists_d_lds(const PcState *S, int &tile)
 {
     const int DP = S->D | 1;
     const size_t merge = (sizeof(double) + sizeof(int)) * 256 * 2 * PC_NN_K;      // 48 KB, over the tile: three workgroups to a compute unit
-    tile = (int)((merge - 64) / (sizeof(double) * DP + sizeof(int)));
+    tile = (int)((merge - 64) / (sizeof(double) * DP + 2 * sizeof(int)));
     tile = tile < 32 ? 32 : (tile > 1024 ? 1024 : tile);
-    const size_t t = (sizeof(double) * DP + sizeof(int)) * (size_t)tile;
+    const size_t t = (sizeof(double) * DP + 2 * sizeof(int)) * (size_t)tile;
     return (t > merge ? t : merge) + 64;
 }
 // nDims <= 32: the register kernel; dR == null: one run
-static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int nleft, hipStream_t st)
+static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int nleft, int use_rank, hipStream_t st)
 {
     static const bool off = std::getenv("PC_NN_LISTS_OLD") != nullptr;
     if (off || S->D > 32 || S->D < 1) return 1;
@@ -434,9 +471,9 @@ static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int
     switch (S->D) {
 #define PC_NND(n) case n: \
         if (dR) { if (sh > donem[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d_many<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donem[n].store(sh); } \
-                  hipLaunchKernelGGL(k_nn_lists_d_many<n>, dim3(nleft, R), dim3(256), sh, st, dR, tile); } \
+                  hipLaunchKernelGGL(k_nn_lists_d_many<n>, dim3(nleft, R), dim3(256), sh, st, dR, tile, use_rank); } \
         else { if (sh > done1[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1[n].store(sh); } \
-               hipLaunchKernelGGL(k_nn_lists_d<n>, dim3(nleft), dim3(256), sh, st, *S, nleft, tile); } \
+               hipLaunchKernelGGL(k_nn_lists_d<n>, dim3(nleft), dim3(256), sh, st, *S, nleft, tile, use_rank); } \
         return 0;
         PC_NND(1) PC_NND(2) PC_NND(3) PC_NND(4) PC_NND(5) PC_NND(6) PC_NND(7) PC_NND(8) PC_NND(9) PC_NND(10) PC_NND(11) PC_NND(12) PC_NND(13) PC_NND(14) PC_NND(15) PC_NND(16)
         PC_NND(17) PC_NND(18) PC_NND(19) PC_NND(20) PC_NND(21) PC_NND(22) PC_NND(23) PC_NND(24) PC_NND(25) PC_NND(26) PC_NND(27) PC_NND(28) PC_NND(29) PC_NND(30) PC_NND(31) PC_NND(32)
@@ -451,20 +488,21 @@ static size_t nn_lists_lds(const PcState *S, int &tile)
     tile = tile < 16 ? 16 : (tile > 512 ? 512 : tile);
     return sizeof(double) * ((size_t)NNL_G * S->D + (size_t)tile * S->D + 256 * PC_NN_K) + sizeof(int) * (256 * PC_NN_K + tile) + 64;
 }
-extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, hipStream_t st)
+// use_rank: k_sort_live has run on this state in front of this launch (its order tells which candidates cannot die before a chain is looked at)
+extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, int use_rank, hipStream_t st)
 {
     if (nleft <= 0) return;
-    if (nn_lists_d_dispatch(S, nullptr, 0, nleft, st) == 0) return;
+    if (nn_lists_d_dispatch(S, nullptr, 0, nleft, use_rank, st) == 0) return;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
     static size_t done = 0;
     if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
     hipLaunchKernelGGL(k_nn_lists, dim3(nleft), dim3(256), sh, st, *S, nleft, tile);
 }
-extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, int R, int nleft_max, hipStream_t st)
+extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, int R, int nleft_max, int use_rank, hipStream_t st)
 {
     if (nleft_max <= 0) return 0;
-    if (nn_lists_d_dispatch(S, dR, R, nleft_max, st) == 0) return 0;
+    if (nn_lists_d_dispatch(S, dR, R, nleft_max, use_rank, st) == 0) return 0;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
     static size_t done = 0;

@@ -38,7 +38,7 @@ int pc_launch_slice_fused(const PcState *, unsigned, int, hipStream_t);
 int pc_slice_t_ok(const PcState *, int);
 int pc_launch_slice_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
 int pc_launch_nhats_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
-int pc_launch_nn_lists_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
+int pc_launch_nn_lists_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
 int pc_launch_consume_cl_many(const PcState *, const PcManyRec *, int, int, hipStream_t);
 int pc_launch_reset_thresholds_many(const PcState *, const PcManyRec *, int, hipStream_t);
 int pc_launch_knn_cluster_batch_many(const PcState *, const PcManyRec *, int, int, int, hipStream_t);
@@ -57,7 +57,7 @@ int pc_launch_consume_par_many(const PcState *, const PcManyRec *, int, hipStrea
 int pc_launch_apply_many(const PcState *, const PcManyRec *, int, unsigned, int, hipStream_t);
 int pc_launch_update_fused_many(const PcState *, const PcManyRec *, int, int, int, int, hipStream_t);
 int pc_launch_consume(const PcState *, int, int, hipStream_t);
-void pc_launch_nn_lists(const PcState *, int, hipStream_t);
+void pc_launch_nn_lists(const PcState *, int, int, hipStream_t);
 void pc_launch_shift_mats(const PcState *, int, int, hipStream_t);
 void pc_launch_remap_chains(const PcState *, const int *, int, int, hipStream_t);
 int pc_launch_consume_fast(const PcState *, int, hipStream_t);
@@ -441,7 +441,7 @@ struct Fiber {
     void yield() { swapcontext(&ctx, &ret); }
 };
 
-enum { CK_COMPACT = 0, CK_RESET, CK_CLUS1, CK_CLUSG, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_NN, CK_SORT, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_COV, CK_FINAL, CK_N };      // (in the order they are launched)
+enum { CK_COMPACT = 0, CK_RESET, CK_CLUS1, CK_CLUSG, CK_BASES, CK_NHATS_G, CK_SLICE, CK_SLICE_G, CK_BASES_NEXT, CK_SORT, CK_NN, CK_CONSUME, CK_CONSUME_CL, CK_APPLY, CK_UPDATE, CK_COV, CK_FINAL, CK_N };      // (in the order they are launched)
 // (_G: any device likelihood, the wavefront-per-chain kernels of a run on its own with the run in the grid; NN / CONSUME_CL: runs with several clusters)
 struct Cohort {
     hipStream_t st = nullptr;
@@ -492,7 +492,7 @@ struct Cohort {
         case CK_SLICE: (void)pc_launch_slice_t(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_NHATS_G: (void)pc_launch_nhats(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
         case CK_SLICE_G: if (r.a[1]) (void)pc_launch_slice_fused(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); else (void)pc_launch_slice(&r.S, (unsigned)r.ia[0], (int)r.a[0], st); break;
-        case CK_NN: pc_launch_nn_lists(&r.S, r.ia[1], st); break;
+        case CK_NN: pc_launch_nn_lists(&r.S, r.ia[1], 1, st); break;      // (the run's CK_SORT of this round has been launched: kinds go in order)
         case CK_RESET: pc_launch_reset_thresholds(&r.S, st); break;
         case CK_CLUSG: (void)pc_launch_knn_cluster_sub((const int *)r.p[0], r.ia[1], r.ia[2], (const double *)r.p[1], (const int *)r.p[2], (int *)r.p[3], (int *)r.p[4], (int *)r.p[5], st); break;
         case CK_CLUS1: (void)pc_launch_knn_cluster_batch_dev(&r.S, (const int *)r.p[0], r.ia[1], r.ia[2], (double *)r.p[1], (int *)r.p[2], (int *)r.p[3], (int *)r.p[4], st); break;
@@ -570,7 +570,7 @@ struct Cohort {
             case CK_SLICE: rc = pc_launch_slice_t_many(&f.S, d, cnt, 0u, (int)f.a[0], q); break;
             case CK_NHATS_G: rc = pc_launch_nhats_many(&f.S, d, cnt, (int)f.a[0], q); break;
             case CK_SLICE_G: rc = pc_launch_slice_many(&f.S, d, cnt, (int)f.a[0], (int)f.a[1], q); break;
-            case CK_NN: { int nl = 0; for (size_t x = i; x < j; ++x) nl = std::max(nl, ord[x]->ia[1]); rc = pc_launch_nn_lists_many(&f.S, d, cnt, nl, q); } break;
+            case CK_NN: { int nl = 0; for (size_t x = i; x < j; ++x) nl = std::max(nl, ord[x]->ia[1]); rc = pc_launch_nn_lists_many(&f.S, d, cnt, nl, 1, q); } break;
             case CK_CONSUME_CL: rc = pc_launch_consume_cl_many(&f.S, d, cnt, (int)f.a[0], q); break;
             case CK_RESET: rc = pc_launch_reset_thresholds_many(&f.S, d, cnt, q); break;
             case CK_CLUSG: { int nbm = 0, nmx = 0; for (size_t x = i; x < j; ++x) { nbm = std::max(nbm, ord[x]->ia[1]); nmx = std::max(nmx, ord[x]->ia[2]); } rc = pc_launch_knn_cluster_sub_many(d, cnt, nbm, nmx, q); } break;
@@ -833,7 +833,7 @@ struct Engine {
         S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_pts = nullptr; S.nn_code = nullptr; S.nn_valid = 0;
         if (c.do_clustering) {      // candidate lists of the nearest-cluster search (k_nn_lists)
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
-            S.nn_pts = dalloc<double>((size_t)(Ncap + B) * D); S.nn_code = dalloc<int>((size_t)Ncap + B);
+            S.nn_pts = dalloc<double>((size_t)(Ncap + B) * D); S.nn_code = dalloc<int>((size_t)2 * Ncap + B);      // (codes of the candidates, then the ranks of the live points: k_sort_live)
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         static const bool ms_off = std::getenv("PC_MS_PRE_OFF") != nullptr;
@@ -2295,12 +2295,15 @@ struct Engine {
                     rc2 = 0;
                 } else {
                 if (co) co->flush();
+                bool sorted_now = false;
                 if (want_nn) {
-                    pc_launch_nn_lists(&S, nursery_left, st);
+                    // (the sorted order first: its ranks tell the lists' kernel which candidates cannot die before a chain is looked at)
+                    sorted_now = pc_launch_sort_live(&S, st) == 0;
+                    pc_launch_nn_lists(&S, nursery_left, sorted_now ? 1 : 0, st);
                     S.nn_valid = 1;
                 }
                 if (use_cl) {
-                    rc2 = pc_launch_sort_live(&S, st) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
+                    rc2 = (sorted_now ? 0 : pc_launch_sort_live(&S, st)) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
                 } else
                 rc2 = pc_launch_consume(&S, 0, (h_ctl->ncluster > 1) ? 1 : wide, st);
                 }

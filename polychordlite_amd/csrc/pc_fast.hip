@@ -87,6 +87,12 @@ __device__ __forceinline__ void sort_live_body(const PcState &S, int npow2)
         }
     const int NS = (S.Ncap + 63) & ~63;
     for (int i = tid; i < NS; i += 1024) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
+    // the rank of every live point in this order = how many deaths of the snapshot come before its own: k_nn_lists_d tells by it which
+    // candidates are certainly alive when a chain is looked at (behind the candidates' codes: [Ncap + B] codes, [Ncap] ranks)
+    if (S.nn_code) {
+        int *rank = S.nn_code + (size_t)S.Ncap + S.B;
+        for (int i = tid; i < npow2; i += 1024) { const int sl = ks[i]; if (sl >= 0 && sl < S.Ncap) rank[sl] = (kv[i] < PC_HUGE) ? i : 0x7fffffff; }
+    }
 }
 __global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2) { sort_live_body(S, npow2); }
 __global__ __launch_bounds__(1024) void k_sort_live_many(const PcManyRec *R, int npow2) { sort_live_body(R[blockIdx.y].S, npow2); }
