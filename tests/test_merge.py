@@ -101,6 +101,14 @@ def test_merge_has_no_cpu_path():
         mg.merge_records(6, 0, [rows.shape[0]], rows, entry)
 
 
+def test_a_rank_learns_that_rank_0_has_no_communicator_id():
+    """rank 0 could not make the RCCL id (library not loadable): what it broadcasts is empty, and every other rank raises instead of
+    waiting in ncclCommInitRank for a peer that will never come"""
+    from polychordlite_amd import merge as mg
+    with pytest.raises(RuntimeError, match="rank 0"):
+        mg.Comm(1, 2, 0, exchange=lambda b: b"")
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _engine_runs(api, seeds, D=6, nDer=1, nlive=150, nr=12, batch=50, kind="gaussian", clustering=0, box=(None, None)):
     lib = api.load()
