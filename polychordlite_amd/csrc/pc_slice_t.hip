@@ -611,21 +611,45 @@ template <int DMAX>
 __global__ __launch_bounds__(64) void k_bases_packed_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX>(R[blockIdx.y].S, nbases); }
 
 // step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
+// Four stream calls (eight deviates) a thread.  AS241's central branch is two polynomials and a division; the tails (15 % of the
+// arguments) cost a log and a square root on top, and a wavefront that calls the whole function pays for both on every call because
+// some lane is always in a tail.  So: the central branch in line, the tail arguments of a wavefront collected in LDS (ballot + prefix
+// count: no atomics) and finished together -- two passes of the tail branch per wavefront instead of eight, the same arithmetic
+// (pc_dev.h: the function in two halves): 118 -> ~70 us for sixteen runs of the metric configuration.
+#define DEVT_CALLS 4
 __device__ __forceinline__ void deviates_t_body(const PcState &S, unsigned batch, int nbases, int NC)
 {
-    const int D = S.D, DD = D * D;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)nbases * NC) return;
-    const int g = (int)(t / NC), m = (int)(t - (long long)g * NC);
-    const int chain = g / S.nb_total, basis = g - chain * S.nb_total;
-    const uint32_t e0 = (uint32_t)pc_sel(S.g_e0, 0) + (uint32_t)basis * DD, e1 = e0 + (uint32_t)DD;
-    const uint32_t call = (e0 >> 1) + (uint32_t)m;
-    double ua, ub;
-    pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
-    const uint32_t ia = 2 * call, ib = ia + 1;
-    double *G = S.nhat_raw + (size_t)g * DD;
-    if (ia >= e0 && ia < e1) G[ia - e0] = pc_inv_normal_cdf(ua);
-    if (ib >= e0 && ib < e1) G[ib - e0] = pc_inv_normal_cdf(ub);
+    __shared__ double qU[4][2 * DEVT_CALLS * 64];
+    __shared__ int qA[4][2 * DEVT_CALLS * 64];
+    const int D = S.D, DD = D * D, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ncalls = (long long)nbases * NC;
+    int qn = 0;                                              // (wave-uniform) tail arguments queued so far
+    auto put = [&](bool want, double u, int dst) {
+        bool t = false;
+        double x = 0.0;
+        if (want) x = pc_inv_normal_central(u, t);
+        if (want && !t) S.nhat_raw[dst] = x;
+        const unsigned long long m = __ballot(want && t);
+        if (want && t) { const int pos = qn + __popcll(m & ((1ull << lane) - 1ull)); qU[wv][pos] = u; qA[wv][pos] = dst; }
+        qn += __popcll(m);
+    };
+#pragma unroll
+    for (int k = 0; k < DEVT_CALLS; ++k) {
+        const long long t = ((long long)blockIdx.x * DEVT_CALLS + k) * 256 + threadIdx.x;
+        const bool in = t < ncalls;
+        const int g = in ? (int)(t / NC) : 0, m = in ? (int)(t - (long long)g * NC) : 0;
+        const int chain = g / S.nb_total, basis = g - chain * S.nb_total;
+        const uint32_t e0 = (uint32_t)pc_sel(S.g_e0, 0) + (uint32_t)basis * DD, e1 = e0 + (uint32_t)DD;
+        const uint32_t call = (e0 >> 1) + (uint32_t)m;
+        double ua = 0.5, ub = 0.5;
+        if (in) pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, call, ua, ub);
+        const uint32_t ia = 2 * call, ib = ia + 1;
+        const int base = g * DD;                             // (nbases * nDims^2 < 2^31: 64 runs x 1024 chains are launched run by run in the grid's y)
+        put(in && ia >= e0 && ia < e1, ua, base + (int)(ia - e0));
+        put(in && ib >= e0 && ib < e1, ub, base + (int)(ib - e0));
+    }
+    __syncthreads();
+    for (int k = lane; k < qn; k += 64) S.nhat_raw[qA[wv][k]] = pc_inv_normal_tail(qU[wv][k]);
 }
 __global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, int nbases, int NC) { deviates_t_body(S, batch, nbases, NC); }
 __global__ __launch_bounds__(256) void k_deviates_t_many(const PcManyRec *R, int nbases, int NC) { deviates_t_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, NC); }
@@ -637,7 +661,7 @@ static int launch_bases_t(const PcState *S, const PcManyRec *dR, int R, unsigned
     constexpr int DD = DT * DT, NC = (DD + 1) / 2, DM = DT <= 8 ? 8 : (DT <= 16 ? 16 : 24);
     const int nbases = nchains * S->nb_total;
     const long long ncalls = (long long)nbases * NC;
-    const unsigned gdev = (unsigned)((ncalls + 255) / 256);
+    const unsigned gdev = (unsigned)((ncalls + 256 * DEVT_CALLS - 1) / (256 * DEVT_CALLS));
     const int perw = 64 / DT, blocksw = (nbases + perw - 1) / perw;
     const size_t shw = sizeof(double) * (size_t)perw * 2 * DM;
     if (dR) {
