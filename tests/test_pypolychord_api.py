@@ -872,6 +872,29 @@ def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nli
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("discard", [0, 1])
+def test_epoch_rule_through_the_front_door(engine, tmp_path, discard):
+    """polychord_hip_set_option("epoch_discard", 1) gives polychord_c_interface callers the reference farm's rule for chains in flight
+    when the list of clusters changes (nested_sampling.F90:313); the default keeps the chains of the clusters the change left alone.
+    Either way the run pypolychord.run_polychord makes is the oracle's run under that rule."""
+    from tests import oracle_api as orc
+    lib = engine.load(); lib.polychord_hip_set_option(b"batch", 120.0); lib.polychord_hip_set_option(b"epoch_discard", float(discard))
+    D, nlive, nr = 3, 300, 9
+    try:
+        s = pypolychord.PolyChordSettings(D, 0, nlive=nlive, num_repeats=nr, seed=23, do_clustering=True, read_resume=False,
+                                          write_resume=False, write_dead=False, write_stats=True, posteriors=False, equals=False,
+                                          write_prior=False, write_live=False, base_dir=str(tmp_path), file_root="e", feedback=0)
+        out = pypolychord.run_polychord(dl.Rastrigin(), D, 0, s, dl.UniformPrior(-5.12, 5.12))
+    finally:
+        lib.polychord_hip_set_option(b"batch", 0.0); lib.polychord_hip_set_option(b"epoch_discard", 0.0)
+    so = orc.settings(D, 0, nlive=nlive, num_repeats=nr, seed=23, batch=120, do_clustering=1, epoch_discard=discard)
+    Lo, Po, keep = orc.make_problem("rastrigin", D, -5.12, 5.12)
+    o = orc.run(so, Lo, Po)
+    assert o["ncluster"] + o["ncluster_dead"] > 3
+    assert out.ndead == o["ndead"] and abs(out.logZ - o["logZ"]) < 1e-8 and abs(out.logZerr - o["logZerr"]) < 1e-8
+
+
+@pytest.mark.gpu
 def test_resumed_run_keeps_its_posterior_bookkeeping(engine, tmp_path):
     """a clustered run restarted from a .resume file written while it was under way (a copy taken from the dumper): the
     cluster every earlier dead point died in, the genealogy of the splits and the phantoms kept by boost_posterior travel
