@@ -438,12 +438,12 @@ def main():
                              "unit": "likelihood evals/s", "x_solo": v / solo_v, "lived_dead_per_s": lived / mc["t_runs_s"], "x_solo_lived_dead": lived / mc["t_runs_s"] / solo_ld,
                              "evals_per_lived_dead": mc["nlike"] / lived, "evals_per_lived_dead_reference": w3["ref_evals_per_dead"],
                              "value_reference_equivalent": lived / mc["t_runs_s"] * w3["ref_evals_per_dead"],
-                             "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "logZ_truth": w3["truth"],
+                             "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "runs_logZ_mean": mc["runs_logZ_mean"], "runs_logZ_sem": mc["runs_logZ_sem"], "logZ_truth": w3["truth"],
                              "whole_run_frac": mc["nlike"] * bpe3 / mc["t_runs_s"] / 1e9 / HBM_PEAK_GBS})
             conc_other[name] = {"workload": w3["name"] % w3["nlive"], "solo": {"value": solo_v, "lived_dead_per_s": solo_ld, "ms_per_run": tsolo * 1e3,
                                                                               "evals_per_lived_dead": float(np.sum([x[0] for x in solo]) / np.sum([x[1] for x in solo]))},
                                 "in_step": rows,
-                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; value_reference_equivalent = "
+                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; merged_logZ = the replay of the union by ranks and live counts (it does not know the clusters' own volumes: biased low where a run has dozens of clusters, DESIGN section 8), runs_logZ_mean = the runs' own evidences; value_reference_equivalent = "
                                         "dead points that lived per second x the reference binary's evaluations per dead point"}
         lib.polychord_hip_set_option(b"trim_cache", 0.0)
         sync()
