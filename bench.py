@@ -558,7 +558,7 @@ def main():
                # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
                # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
                "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
-               "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "records", "post_mean", "t_merge_s")} if merged else None,
+               "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "runs_logZ_mean", "runs_logZ_sem", "records", "post_mean", "t_merge_s")} if merged else None,
                "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
                "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (comm.library, world)) if comm is not None else "one rank: no exchange",
                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},

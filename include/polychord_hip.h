@@ -252,6 +252,10 @@ typedef struct {
     double *post_mean, *post_var;  /* [nDims + nDerived] posterior moments of theta, phi */
     double t_merge_s, t_runs_s;    /* wall clock of the merge / of the runs (pchip_run_repeats) */
     long nlike, ndead_all;         /* totals over the runs (pchip_run_repeats) */
+    double runs_logZ_mean, runs_logZ_sem;   /* mean of the runs' OWN log Z and its standard error (one run: that run's own error).  The
+                                      union's logZ is replayed from ranks and live counts; a run with clusters weighs its dead points by
+                                      its clusters' volumes, which the replay does not know (10-D Rastrigin: the replay sits 0.46 below
+                                      a run's own log Z): for clustered problems this is the evidence to quote */
 } pchip_merged;
 /* Merge `nruns` runs on the device.  rows = the lived records (logweight > logzero) of run 0, then run 1, ...: counts[q]
  * rows of nTotal doubles each, every run ascending in logL (the order in which they died); entry[i] = contour at which

@@ -590,6 +590,18 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
 // each run a complete engine on its own stream of its own device), merged on devices[0].  This is the front door of the
 // repeat-sharded mode for a single process; between processes (one per GPU, torch.distributed / RCCL) the same merge
 // is fed by an all-gather (polychordlite_amd/merge.py).
+// mean of the runs' own log Z and its standard error (pchip_merged::runs_logZ_mean / _sem); one run: its own reported error
+static void runs_evidence(const double *z, int n, double err_one, pchip_merged *out)
+{
+    double m = 0.0;
+    for (int k = 0; k < n; ++k) m += z[k];
+    m /= (double)(n > 0 ? n : 1);
+    double v = 0.0;
+    for (int k = 0; k < n; ++k) v += (z[k] - m) * (z[k] - m);
+    out->runs_logZ_mean = m;
+    out->runs_logZ_sem = n > 1 ? std::sqrt(v / (double)(n - 1) / (double)n) : err_one;
+}
+
 int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
                       int ndevices, const int *devices, int max_in_flight, pchip_result *results, pchip_merged *merged)
 {
@@ -693,7 +705,12 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
         if (rc == 0) rc = pchip_merge_records(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, 1, 1, merged);
         else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
     }
-    if (rc == 0) { merged->t_runs_s = t_runs; for (int k = 0; k < nseeds; ++k) { merged->nlike += results[k].nlike; merged->ndead_all += results[k].ndead; } }
+    if (rc == 0) {
+        merged->t_runs_s = t_runs;
+        std::vector<double> zs((size_t)nseeds);
+        for (int k = 0; k < nseeds; ++k) { merged->nlike += results[k].nlike; merged->ndead_all += results[k].ndead; zs[(size_t)k] = results[k].logZ; }
+        runs_evidence(zs.data(), nseeds, std::sqrt(std::fabs(results[0].varlogZ)), merged);
+    }
     else { for (int k = 0; k < nseeds; ++k) pchip_result_free(&results[k]); }        // (nothing is left for the caller to free on failure)
     return rc;
 }
@@ -761,8 +778,11 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     if (!local_err && !J.count_records(B, st)) local_err = fail("packing the run's records", 7);
     if (local_err && !(c && c->comm)) return local_err;
     // counts (and the runs' totals) of every rank
-    std::vector<long long> meta((size_t)3 * R, 0);
-    meta[0] = local_err ? -1 : (long long)J.count; meta[1] = run->nlike; meta[2] = run->ndead;
+    std::vector<long long> meta((size_t)4 * R, 0);
+    {   // (the 4th word: the run's own log Z, for the mean of the runs' evidences beside the union's)
+        const double zown = run->logZ; long long zb; std::memcpy(&zb, &zown, sizeof zb);
+        meta[0] = local_err ? -1 : (long long)J.count; meta[1] = run->nlike; meta[2] = run->ndead; meta[3] = zb;
+    }
     long long *d_status = nullptr;
     auto agree = [&](int mine) -> int {        // the ranks' status words, all-gathered: 0 if every rank is fine
         std::vector<long long> w((size_t)R + 1, 0); w[0] = mine;
@@ -774,14 +794,14 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
         return worst;
     };
     if (c && c->comm) {
-        long long *d_meta = B.get<long long>((size_t)3 * (R + 1));
+        long long *d_meta = B.get<long long>((size_t)4 * (R + 1));
         d_status = B.get<long long>((size_t)R + 1);
         if (!d_meta || !d_status) return fail("out of device memory", 7);      // (a few hundred bytes: a device in this state serves no collective either)
-        if (hipMemcpyAsync(d_meta, meta.data(), sizeof(long long) * 3, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
-        const ncclResult_t e = rccl().AllGather(d_meta, d_meta + 3, 3, ncclInt64, c->comm, st);
+        if (hipMemcpyAsync(d_meta, meta.data(), sizeof(long long) * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
+        const ncclResult_t e = rccl().AllGather(d_meta, d_meta + 4, 4, ncclInt64, c->comm, st);
         if (e != ncclSuccess) return nfail("ncclAllGather (counts)", e);
-        if (hipMemcpyAsync(meta.data(), d_meta + 3, sizeof(long long) * 3 * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("counts", 2);
-        for (int q = 0; q < R; ++q) if (meta[(size_t)3 * q] < 0) {
+        if (hipMemcpyAsync(meta.data(), d_meta + 4, sizeof(long long) * 4 * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("counts", 2);
+        for (int q = 0; q < R; ++q) if (meta[(size_t)4 * q] < 0) {
             if (q != c->rank) std::fprintf(stderr, "polychord_hip: comm merge: rank %d could not pack its records\n", q);
             return local_err ? local_err : 7;
         }
@@ -789,7 +809,7 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     std::vector<long> counts(R);
     std::vector<long long> off(R + 1, 0);
     long long nmax = 1, nlike = 0, ndead_all = 0;
-    for (int q = 0; q < R; ++q) { counts[q] = (long)meta[(size_t)3 * q]; off[q + 1] = off[q] + counts[q]; nmax = std::max(nmax, meta[(size_t)3 * q]); nlike += meta[(size_t)3 * q + 1]; ndead_all += meta[(size_t)3 * q + 2]; }
+    for (int q = 0; q < R; ++q) { counts[q] = (long)meta[(size_t)4 * q]; off[q + 1] = off[q] + counts[q]; nmax = std::max(nmax, meta[(size_t)4 * q]); nlike += meta[(size_t)4 * q + 1]; ndead_all += meta[(size_t)4 * q + 2]; }
     const size_t per = (size_t)nmax * (nT + 1);                 // one rank's block: rows [nmax][nT], then entry [nmax]
     double *send = B.get<double>(per);
     if (!send) local_err = fail("out of device memory", 7);
@@ -811,7 +831,12 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail("exchange", 2);
     const int rc = pchip_merge_records(nDims, nDerived, R, counts.data(), rows_all, entry_all, 1, want_rows, out);
-    if (rc == 0) { out->nlike = (long)nlike; out->ndead_all = (long)ndead_all; out->t_merge_s = std::chrono::duration<double>(clk::now() - t0).count(); }
+    if (rc == 0) {
+        out->nlike = (long)nlike; out->ndead_all = (long)ndead_all; out->t_merge_s = std::chrono::duration<double>(clk::now() - t0).count();
+        std::vector<double> zs((size_t)R);
+        for (int q = 0; q < R; ++q) std::memcpy(&zs[(size_t)q], &meta[(size_t)4 * q + 3], sizeof(double));
+        runs_evidence(zs.data(), R, std::sqrt(std::fabs(run->varlogZ)), out);
+    }
     return rc;
 }
 

@@ -23,7 +23,8 @@ class Merged(C.Structure):
     _fields_ = [("logZ", C.c_double), ("varlogZ", C.c_double), ("n", C.c_long), ("nTotal", C.c_int), ("nruns", C.c_int),
                 ("rows", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("nlive", C.POINTER(C.c_int)),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
-                ("t_merge_s", C.c_double), ("t_runs_s", C.c_double), ("nlike", C.c_long), ("ndead_all", C.c_long)]
+                ("t_merge_s", C.c_double), ("t_runs_s", C.c_double), ("nlike", C.c_long), ("ndead_all", C.c_long),
+                ("runs_logZ_mean", C.c_double), ("runs_logZ_sem", C.c_double)]
 
 
 def _lib():
@@ -76,7 +77,8 @@ def merged_dict(m, nDims, nDerived, want_rows):
            "post_var": np.ctypeslib.as_array(m.post_var, shape=(nP,)).copy(),
            "logweights": arr(m.logweights, n, np.float64),
            "nlive": arr(m.nlive, n, np.int32),
-           "t_merge_s": m.t_merge_s, "t_runs_s": m.t_runs_s, "nlike": int(m.nlike), "ndead_all": int(m.ndead_all)}
+           "t_merge_s": m.t_merge_s, "t_runs_s": m.t_runs_s, "nlike": int(m.nlike), "ndead_all": int(m.ndead_all),
+           "runs_logZ_mean": m.runs_logZ_mean, "runs_logZ_sem": m.runs_logZ_sem}
     if want_rows and n > 0:
         out["rows"] = np.ctypeslib.as_array(m.rows, shape=(n, nT)).copy()
     return out

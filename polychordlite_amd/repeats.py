@@ -50,12 +50,5 @@ def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, wan
         r = api.Result()
         C.memmove(C.byref(r), C.byref(res[k]), C.sizeof(r))          # each dict owns (and frees) its own result block
         runs.append(api.result_dict(r, settings))
-    # The runs' OWN evidences next to the union's.  The union is replayed from ranks and live counts alone; a run with clustering
-    # weighs its dead points by its clusters' own volumes (run_time_info.f90:211-296), which the replay does not know: at 10-D Rastrigin
-    # (dozens of clusters, volumes apportioned by live + phantom counts at every split) the replay of a run sits 0.46 +- 0.06 below the
-    # run's own log Z, at the twin Gaussian 0.04, with one cluster they coincide.  For clustered problems quote these:
-    z = np.array([r["logZ"] for r in runs])
-    merged["runs_logZ"] = z.tolist()
-    merged["runs_logZ_mean"] = float(z.mean())
-    merged["runs_logZ_sem"] = float(z.std(ddof=1) / np.sqrt(z.size)) if z.size > 1 else float(runs[0]["logZerr"])
+    merged["runs_logZ"] = [r["logZ"] for r in runs]      # (their mean and its error: merged["runs_logZ_mean"], ["runs_logZ_sem"], from the library)
     return merged, runs

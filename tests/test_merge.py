@@ -293,6 +293,7 @@ def test_library_rccl_exchange_one_rank(engine):
     assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["logweights"], b["logweights"]) and np.array_equal(a["nlive"], b["nlive"])
     assert a["nlike"] == run["nlike"] and a["ndead_all"] == run["ndead"]
     assert abs(a["logZ"] - run["logZ"]) < 1e-7
+    assert a["runs_logZ_mean"] == run["logZ"] and abs(a["runs_logZ_sem"] - run["logZerr"]) < 1e-12      # (the run's own evidence travelled with the counts)
 
 
 @pytest.mark.gpu
@@ -345,6 +346,9 @@ def test_runs_in_step_are_their_solo_runs(engine, kind, D, nDer, nlive, nr, clus
         assert np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"], equal_nan=True)
         assert np.array_equal(one["post_mean"], r["post_mean"], equal_nan=True)
     assert merged["n_runs"] == len(seeds)
+    # the runs' own evidences beside the union's (the one to quote where runs have many clusters: DESIGN section 8)
+    zs = np.array([r["logZ"] for r in runs])
+    assert abs(merged["runs_logZ_mean"] - zs.mean()) < 1e-12 and abs(merged["runs_logZ_sem"] - zs.std(ddof=1) / np.sqrt(zs.size)) < 1e-12
     # one of the runs in step next to the oracle (same Philox keys: the same trajectory; nDims <= 7 whole runs, beyond that the first
     # generations -- round-off grows with every covariance update, and clusters of fewer points than dimensions hang on the sign of
     # a 1e-19 Cholesky pivot: DESIGN section 7)
