@@ -8,16 +8,17 @@ Contract (DESIGN.md "Measurement"):
   * metric = likelihood evals/sec = sum of the reference's own counter RTI%nlike (calculate.f90:44) over the timed steps
     / wall time (barrier + device sync on both sides, max over ranks).  The exchange step is inside the timed region.
   * N > 1 GPUs: repeat-sharded: every rank runs independent runs with its own seeds; the dead points of the
-    last step's runs -- full rows + entry contours -- are all-gathered over RCCL (torch.distributed "nccl", one padded
-    buffer per rank) and merged on every rank by the device merge of the library (evidence + posterior of the union);
-    scaling is "weak".  N = 1 goes through the same merge code.
-  * roofline: the kernel class with the largest HIP-event time (no thumb on the scale); `achieved` = SURVEY 8(d)'s
-    algorithmic bytes per evaluation x evaluations of one launch / its measured launch duration; `kernels` carries the
-    two heaviest classes each with its OWN algorithmic bytes; `whole_run_frac` = nlike x bytes / wall / peak.
+    last step's runs are all-gathered over RCCL inside the library and merged on every rank; scaling is "weak".
+    N = 1 goes through the same merge code.  `--runs-per-gpu R`: behind the timed steps every rank also runs R runs IN STEP
+    (pchip_run_repeats), the N R runs are exchanged the same way, reported as `roofline.in_step_multi`, never in `value`.
+  * roofline: the kernel class with the largest HIP-event time; `achieved` = SURVEY 8(d)'s algorithmic bytes per
+    evaluation x evaluations of one launch / its measured launch duration.
   * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by oracle/Makefile; else the C
     restatement oracle/liboracle.so) on one host core, one full run of the same workload, and `all_cores`: one
-    independent run per host core at the same time (the reference's MPI farm does not speed this likelihood up,
-    BASELINE.md), aggregate evals/s, core count and CPU model stated.
+    independent bounded run per host core at the same time.
+  * OUTPUT: the LAST stdout line is ONE compact JSON record (< 6 KB: `compact_record`); the full record (per-step lists,
+    every kernel class, the sweeps' details, notes) goes to gpurun_out/bench_full_<workload>.json (`--full-out`), never to
+    stdout.  Round 4's 18.9-KB line was not parsed by the driver; tests/test_bench_line.py holds the size.
 """
 import argparse
 import ctypes as C
@@ -34,21 +35,27 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_EVAL = 258.0
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+COMPACT_LIMIT = 6000        # bytes of the last stdout line (the driver parsed 6.5 KB and 13 KB, not 18.9 KB)
 # BASELINE.json configs through this harness: kind, nDims, nDerived, nlive, num_repeats, clustering, box, analytic logZ
 WORKLOADS = {
     "c2": dict(kind="gaussian", D=20, nDer=2, nlive=2000, nr=40, clustering=0, box=None, truth=0.0, ref_evals_per_dead=173.9,
+               short="configs[1]: 20-D Gaussian, nlive=%d, num_repeats=40",
                name="BASELINE configs[1]: 20-D Gaussian (mu=0.5, sigma=0.1, U(0,1)^20), nlive=%d, num_repeats=40"),
     "c3": dict(kind="rastrigin", D=10, nDer=0, nlive=1000, nr=30, clustering=1, box=(-5.12, 5.12), truth=-23.263, ref_evals_per_dead=155.5,
+               short="configs[2]: 10-D Rastrigin, nlive=%d, num_repeats=30, kNN clustering",
                name="BASELINE configs[2]: 10-D Rastrigin, U(-5.12,5.12)^10, nlive=%d, num_repeats=30 (= 3 nDims, the ini's ratio), kNN clustering"),
     "c4": dict(kind="twin_gaussian", D=30, nDer=1, nlive=500, nr=40, clustering=1, box=(-1.0, 1.0), truth=-20.794, ref_evals_per_dead=177.3,
+               short="configs[3]: 30-D twin Gaussian, nlive=%d, num_repeats=40, kNN clustering",
                name="BASELINE configs[3]: 30-D twin Gaussian (sigma=0.1), U(-1,1)^30, nlive=%d, num_repeats=40, kNN clustering"),
     "c5": dict(kind="corr_gaussian", D=100, nDer=0, nlive=5000, nr=200, clustering=0, box=None, truth=0.0, ref_evals_per_dead=None,
+               short="configs[4]: 100-D correlated Gaussian, nlive=%d, num_repeats=200",
                name="BASELINE configs[4]: 100-D correlated Gaussian (random eigenbasis, eigen-sigma 0.1 .. 0.001), U(0,1)^100, nlive=%d, num_repeats=200"),
 }
 # ref_evals_per_dead: likelihood evaluations per dead point of the REFERENCE BINARY at this configuration (its linear mode, one chain at a
 # time: tests/golden/ref_c3_seeds.json, ref_c4_seeds.json; configs[1]: the cpu_baseline leg of this script on the GPU box, 11.45 M / 65.8 k)
 METRIC = {"c2": "likelihood evals/sec, 20D Gaussian nlive=%d", "c3": "likelihood evals/sec, 10D Rastrigin nlive=%d",
           "c4": "likelihood evals/sec, 30D twin Gaussian nlive=%d", "c5": "likelihood evals/sec, 100D correlated Gaussian nlive=%d"}
+HOST_PHASES = ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")
 
 
 def algorithmic_bytes_per_iteration(D, nDer, nr, N):
@@ -92,6 +99,8 @@ SLICE_CHAIN = {  # section: (dependent fp64 ops, LDS round trips, what)
     "stores": (2, 1, "cube -> theta: 2; LDS hop for the derived parameters' row"),
 }
 DEP_FP64_CYCLES, LDS_CYCLES, PHILOX_CYCLES_PER_SLICE, CLOCK_MHZ = 32.0, 70.0, 60.0, 2400.0
+SLICE_CYCLE_FILES = ("r05_slice_cycles.json", "r04_slice_cycles.json", "r03_slice_cycles.json")
+PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")
 
 
 def latency_model(runs, kern):
@@ -107,7 +116,7 @@ def latency_model(runs, kern):
     out = {"unit": "shader cycles per slice (one wavefront = one chain, 2.4 GHz)", "model_min_by_section": model, "model_min": sum(model.values()),
            "dependent_fp64_cycles": DEP_FP64_CYCLES, "lds_round_trip_cycles": LDS_CYCLES, "evaluations_per_slice": evals_per_slice,
            "chain": {k: v[2] for k, v in SLICE_CHAIN.items()}}
-    pth = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_slice_cycles.json", "r03_slice_cycles.json")) if os.path.exists(q)), None)
+    pth = next((q for q in (os.path.join(ROOT, "profiles", n) for n in SLICE_CYCLE_FILES) if os.path.exists(q)), None)
     if pth:
         m = json.load(open(pth))
         out["measured_by_section"] = m["cycles_per_slice"]; out["measured"] = m["cycles_per_slice_total"]
@@ -136,7 +145,8 @@ def live_pmc(workload):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                            os.path.abspath(__file__), "--workload", workload, "--no-cpu", "--no-extras", "--steps", "2", "--warmup", "1"],
+                            os.path.abspath(__file__), "--workload", workload, "--no-cpu", "--no-extras", "--steps", "2", "--warmup", "1",
+                            "--full-out", ""],
                            cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             acc[counter] = pmc_summary.per_kernel(d, counter)
         shutil.rmtree(tmp, ignore_errors=True)
@@ -162,73 +172,177 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(wl, nlive, all_cores=True):
-    """the reference (preferred) or the restatement on ONE host core, then one run per core at the same time"""
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    visible = ncores
-    try:    # the cores this container may actually use (cgroup v2 quota), not the threads the host shows
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            ncores = max(1, min(ncores, int(float(q) / float(per))))
-    except (OSError, ValueError):
-        pass
-    ncores = min(ncores, 32)         # bounded sample: at most 32 runs at a time
-    sample = "the workload itself (%s), one full run per measurement, seed 7 (all_cores: seeds 7 .. 7 + cores - 1, one run per core in parallel)" % (wl["name"] % nlive)
-    kind, D, nDer, nr, clus = wl["kind"], wl["D"], wl["nDer"], wl["nr"], wl["clustering"]
+class CpuBaseline:
+    """the reference (preferred) or the restatement on ONE host core -- one full run of the workload (bounded for c5) -- and
+    `all_cores`: one BOUNDED run per host core at the same time (the first ALL_CORES_NDEAD deaths: the same evaluations and the
+    same bookkeeping early in the run; ~3 s instead of a second full run's 11 s).  start() launches the one-core run in the
+    background (it keeps ONE of the box's cores busy while the figures behind the timed region are taken on the GPU);
+    finish() waits for it and then runs the all-cores leg."""
+    ALL_CORES_NDEAD = 16000
 
-    # Long configurations get a BOUNDED sample: the reference stops after max_ndead deaths (settings%max_ndead), ~10-30 s of
-    # one core; its evals/s is the cost of the same evaluations and the same bookkeeping, early in the run.
-    env, bounded = "", None
-    if kind == "corr_gaussian":
-        covf = "/tmp/pc_ref_bench_cov%d.bin" % D
-        ic, mean, logdet = random_correlated_gaussian(D)
-        with open(covf, "wb") as f:
-            f.write(np.ascontiguousarray(ic).tobytes()); f.write(np.ascontiguousarray(mean).tobytes()); f.write(np.float64(logdet).tobytes())
-        bounded = 2500
-        env = "REF_COV_FILE=%s REF_MAX_NDEAD=%d " % (covf, bounded)
-        sample = ("the first %d deaths of the workload (%s; the reference stopped by max_ndead: a full run takes it hours), seed 7 "
-                  "(all_cores: seeds 7 .. 7 + cores - 1, one run per core in parallel)" % (bounded, wl["name"] % nlive))
+    def __init__(self, wl, nlive, all_cores=True):
+        self.wl, self.nlive, self.all_cores = wl, nlive, all_cores
+        self.ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        self.visible = ncores
+        try:    # the cores this container may actually use (cgroup v2 quota), not the threads the host shows
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                ncores = max(1, min(ncores, int(float(q) / float(per))))
+        except (OSError, ValueError):
+            pass
+        self.ncores = min(ncores, 32)         # bounded sample: at most 32 runs at a time
+        self.env, self.bounded, self.proc = "", None, None
+        self.sample = "%s, one full run, seed 7" % (wl["short"] % nlive)
+        if wl["kind"] == "corr_gaussian":
+            # long configurations get a BOUNDED sample: the reference stops after max_ndead deaths (settings%max_ndead)
+            covf = "/tmp/pc_ref_bench_cov%d.bin" % wl["D"]
+            ic, mean, logdet = random_correlated_gaussian(wl["D"])
+            with open(covf, "wb") as f:
+                f.write(np.ascontiguousarray(ic).tobytes()); f.write(np.ascontiguousarray(mean).tobytes()); f.write(np.float64(logdet).tobytes())
+            self.bounded = 2500
+            self.env = "REF_COV_FILE=%s REF_MAX_NDEAD=%d " % (covf, self.bounded)
+            self.sample = "%s, the first %d deaths (a full run takes the reference hours), seed 7" % (wl["short"] % nlive, self.bounded)
 
-    def ref_run(seed, tag):
+    def _ref_run(self, seed, tag, max_ndead=None):
+        wl = self.wl
         tmp = "/tmp/pc_ref_bench_%s" % tag
         os.makedirs(tmp, exist_ok=True)
-        cmd = f"ulimit -s unlimited; {env}{ref} {kind} {D} {nDer} {nlive} {nr} {seed} {clus} {tmp} ref 0"
+        env = self.env + ("REF_MAX_NDEAD=%d " % max_ndead if (max_ndead and not self.bounded) else "")
+        cmd = f"ulimit -s unlimited; {env}{self.ref} {wl['kind']} {wl['D']} {wl['nDer']} {self.nlive} {wl['nr']} {seed} {wl['clustering']} {tmp} ref 0"
         return subprocess.Popen(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=tmp)
 
-    def parse(p):
+    @staticmethod
+    def _parse(p):
         out = p.communicate()[0]
         line = [l for l in out.splitlines() if l.startswith("{")]
         return json.loads(line[-1]) if line else None
 
-    if os.path.exists(ref):
-        j = parse(ref_run(7, "one"))
-        if j:
-            res = {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
-                   "sample": sample + "; PolyChordLite Fortran built with amdflang -O2, file output off", "cpu_model": cpu_model(),
-                   "logZ": j["logZ"] if not bounded else None, "logZerr": j["logZerr"] if not bounded else None, "ndead": j["ndead"], "nlike": j["nlike"],
-                   "wall_s": j["wall"], "bounded_max_ndead": bounded}
-            if all_cores and ncores > 1:
-                t0 = time.time()
-                js = [parse(p) for p in [ref_run(7 + c, "c%d" % c) for c in range(ncores)]]
-                wall = time.time() - t0
-                js = [x for x in js if x]
-                res["all_cores"] = {"value": sum(x["nlike"] for x in js) / wall, "unit": "likelihood evals/s", "cores": ncores, "runs": len(js),
-                                    "wall_s": wall, "mean_run_wall_s": float(np.mean([x["wall"] for x in js])),
-                                    "hardware_threads_visible": visible,
-                                    "note": "independent runs, one per host core this container may use (cgroup cpu.max quota, at most 32), started together; aggregate nlike / wall of the slowest"}
-            return res
-    from tests import oracle_api as orc
-    s = orc.settings(D, nDer, nlive=nlive, num_repeats=nr, seed=7, batch=1, do_clustering=clus)
-    lo, hi = wl["box"] if wl["box"] else (None, None)
-    L, P, keep = orc.make_problem(kind, D, lo, hi)
-    t0 = time.time(); o = orc.run(s, L, P); dt = time.time() - t0
-    return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-            "sample": sample + "; oracle/liboracle.so (C restatement, gcc -O2)", "logZ": o["logZ"],
-            "logZerr": o["logZerr"], "ndead": int(o["ndead"]), "nlike": int(o["nlike"]), "wall_s": dt}
+    def start(self):
+        if os.path.exists(self.ref):
+            self.proc = self._ref_run(7, "one")
+
+    def finish(self):
+        if os.path.exists(self.ref):
+            if self.proc is None:
+                self.start()
+            j = self._parse(self.proc)
+            if j:
+                res = {"value": j["nlike"] / j["wall"], "unit": "likelihood evals/s", "cores": 1, "kind": "reference",
+                       "sample": self.sample + "; PolyChordLite Fortran, amdflang -O2, no file output", "cpu_model": cpu_model(),
+                       "logZ": j["logZ"] if not self.bounded else None, "logZerr": j["logZerr"] if not self.bounded else None,
+                       "ndead": j["ndead"], "nlike": j["nlike"], "wall_s": j["wall"], "bounded_max_ndead": self.bounded}
+                if self.all_cores and self.ncores > 1:
+                    t0 = time.time()
+                    js = [self._parse(p) for p in [self._ref_run(7 + c, "c%d" % c, self.ALL_CORES_NDEAD) for c in range(self.ncores)]]
+                    wall = time.time() - t0
+                    js = [x for x in js if x]
+                    res["all_cores"] = {"value": sum(x["nlike"] for x in js) / wall, "unit": "likelihood evals/s", "cores": self.ncores, "runs": len(js),
+                                        "wall_s": wall, "mean_run_wall_s": float(np.mean([x["wall"] for x in js])),
+                                        "hardware_threads_visible": self.visible,
+                                        "sample": "one run per core the cgroup grants (<= 32), started together, each stopped after %d deaths; "
+                                                  "sum nlike / wall of the slowest" % (self.bounded or self.ALL_CORES_NDEAD)}
+                return res
+        from tests import oracle_api as orc
+        wl = self.wl
+        s = orc.settings(wl["D"], wl["nDer"], nlive=self.nlive, num_repeats=wl["nr"], seed=7, batch=1, do_clustering=wl["clustering"])
+        lo, hi = wl["box"] if wl["box"] else (None, None)
+        L, P, keep = orc.make_problem(wl["kind"], wl["D"], lo, hi)
+        t0 = time.time(); o = orc.run(s, L, P); dt = time.time() - t0
+        return {"value": o["nlike"] / dt, "unit": "likelihood evals/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                "sample": self.sample + "; oracle/liboracle.so (C restatement, gcc -O2)", "logZ": o["logZ"],
+                "logZerr": o["logZerr"], "ndead": int(o["ndead"]), "nlike": int(o["nlike"]), "wall_s": dt}
 
 
-def main():
+# ---- the record the driver parses --------------------------------------------------------------------------------------
+def _num(x, digits=6):
+    """floats to `digits` significant figures (the line is read by a parser and a judge, not by a solver)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if np.isfinite(x) else None
+    if isinstance(x, (np.floating, np.integer)):
+        return _num(x.item(), digits)
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_record(full, full_path=None):
+    """The ONE line the driver parses: BASELINE's metric, `roofline`, `cpu_baseline` and a handful of scalars -- no per-step lists,
+    no paragraphs; every string < 120 characters; < COMPACT_LIMIT bytes (asserted).  Everything else is in the full record."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = full.get("vs_baseline")
+    out.update(_pick(full, ("dtype", "data")))
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": str(cfg.get("workload_short", cfg.get("workload", "")))[:110], "batch_chains": cfg.get("batch_chains"),
+                     "parallelism": cfg.get("parallelism"), "mode": "one run at a time per GPU; R runs in step: roofline.in_step"}
+    roof = full.get("roofline")
+    if roof:
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "bytes_per_launch", "bytes_per_eval",
+                         "whole_run_frac", "stream"))
+        r["traffic_source"] = "live rocprofv3 --pmc" if str(roof.get("traffic_source", "")).startswith("live") else roof.get("traffic_source")
+        lat = roof.get("latency")
+        if lat and "frac_of_model" in lat:
+            r["latency"] = _pick(lat, ("frac_of_model", "measured", "model_min"))
+        # the two heaviest classes with their OWN algorithmic bytes, short
+        r["kernels"] = [_pick(k, ("kernel", "avg_launch_us", "own_frac", "traffic")) for k in (roof.get("kernels") or [])[:2]]
+        ins = []
+        for e in (roof.get("in_step") or [])[:6]:
+            ins.append(_pick(e, ("config", "runs", "value", "x_solo", "ms_per_run", "whole_run_frac")))
+        if ins:
+            r["in_step"] = ins
+        if roof.get("in_step_multi"):
+            r["in_step_multi"] = _pick(roof["in_step_multi"], ("runs_per_gpu", "n_gpus", "runs", "value", "wall_ms", "merged_logZ", "merged_logZerr", "exchange_ms"))
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "wall_s", "logZ", "logZerr", "ndead", "nlike", "bounded_max_ndead"))
+        c["sample"] = str(cb.get("sample", ""))[:118]
+        if cb.get("all_cores"):
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "runs", "wall_s"))
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    lz, le = full.get("logZ") or [], full.get("logZerr") or []
+    if lz:
+        out["logZ_mean"] = float(np.mean(lz)); out["logZ_sem"] = float(np.std(lz, ddof=1) / np.sqrt(len(lz))) if len(lz) > 1 else None
+        out["logZerr_mean"] = float(np.mean(le)) if le else None
+    out.update(_pick(full, ("logZ_truth", "value_reference_equivalent", "speedup_wall_per_run", "speedup_evals_per_s", "merge_ms", "exchange")))
+    mg = full.get("merged")
+    if mg:
+        out["merged"] = _pick(mg, ("n_runs", "logZ", "logZerr", "evidence_rule", "records"))
+    gf = full.get("general_functor")
+    if gf:
+        out["general_functor"] = _pick(gf, ("value", "ms_per_step"))
+    oc = full.get("other_configs")
+    if oc:
+        out["other_configs"] = {n: (_pick(v, ("value", "ms_per_step", "logZ", "logZerr", "logZ_truth", "evals_per_lived_dead", "dominant_kernel", "whole_run_frac"))
+                                    if "error" not in v else {"error": str(v["error"])[:80]}) for n, v in oc.items()}
+    if full_path:
+        out["full_record"] = full_path
+    out = _num(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:          # never print a line the driver cannot parse: drop the optional blocks, largest first
+        for k in ("other_configs", "general_functor", "merged"):
+            out.pop(k, None)
+        if out.get("roofline"):
+            out["roofline"].pop("kernels", None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, "bench.py: the compact record is %d bytes" % len(line)
+    return out
+
+
+# ---- ranks ----------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -239,6 +353,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = BASELINE configs[1], the metric configuration (default, what the driver runs); c3 / c4 / c5 = "
                          "BASELINE configs[2..4] through the same harness, also with --gpus N (their lines are kept under profiles/)")
+    ap.add_argument("--runs-per-gpu", type=int, default=16,
+                    help="behind the timed steps: every rank runs this many runs of the workload IN STEP (pchip_run_repeats), the N x R runs are "
+                         "exchanged over RCCL and merged; reported as roofline.in_step_multi, never part of `value`; 0 = skip")
     ap.add_argument("--concurrent", default="4,8,16,32,64",
                     help="after the timed steps (N = 1): R independent runs in flight on this GPU for each R of the list "
                          "(polychordlite_amd.repeats.run_repeats; reported separately, never part of `value`); '' or 0 = skip")
@@ -249,16 +366,24 @@ def main():
                          "as `other_configs`; '' = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/ instead of two profiled runs now")
     ap.add_argument("--no-extras", action="store_true", help="skip the figures after the timed region (general functor, concurrent sweep)")
-    args = ap.parse_args()
+    ap.add_argument("--full-out", default=None, help="where the full record goes (default gpurun_out/bench_full_<workload>.json; '' = nowhere)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="process-group backend of the ranks (gloo: the launcher test on CPU)")
+    ap.add_argument("--bootstrap-only", action="store_true", help="start the ranks, form the process group, reduce one number over it, print and stop "
+                                                                   "(before the library's communicator): tests/test_bench_line.py")
+    return ap.parse_args(argv)
 
+
+def bootstrap(args):
+    """One process per GPU.  `python bench.py --gpus N` on its own starts the N ranks here, the way the driver does (torch.distributed.run,
+    127.0.0.1); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Returns (rank, local_rank, world, dist, torch)."""
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) here, the way the driver does
-        from polychordlite_amd import _ctypes_api as api0
-        ndev = api0.load().pchip_device_count()
-        if ndev < args.gpus:
-            raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible -- one rank per GPU, no oversubscription" % (args.gpus, ndev))
+        if args.backend == "nccl":
+            from polychordlite_amd import _ctypes_api as api0
+            ndev = api0.load().pchip_device_count()
+            if ndev < args.gpus:
+                raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible -- one rank per GPU, no oversubscription" % (args.gpus, ndev))
         import socket
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
@@ -273,20 +398,50 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     import torch
-    if torch.cuda.device_count() <= local_rank:
+    if args.backend == "nccl" and torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    return rank, local_rank, world, dist, torch
+
+
+def reduce_over_ranks(dist, torch, device, dt, sums):
+    """(max over ranks of dt, sums added over ranks) -- what turns the ranks' clocks and counters into the job's"""
+    if dist is None:
+        return dt, list(sums)
+    t = torch.tensor([dt] + list(sums), dtype=torch.float64, device=device)
+    tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return float(tm[0]), [float(x) for x in ts[1:]]
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world, dist, torch = bootstrap(args)
+    if args.bootstrap_only:
+        dev = "cpu" if args.backend == "gloo" else f"cuda:{local_rank}"
+        if dist is not None:
+            dist.barrier()
+        tmax, (total,) = reduce_over_ranks(dist, torch, dev, 1.0 + rank, [10.0 * (rank + 1)])
+        if rank == 0:
+            print(json.dumps({"bootstrap": "ok", "world": world, "backend": args.backend, "max": tmax, "sum": total}))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     from polychordlite_amd import _ctypes_api as api
     from polychordlite_amd.merge import merge_runs, Comm
     lib = api.load()
     if lib.pchip_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
+    dev = f"cuda:{local_rank}"
     # the exchange step's communicator: RCCL inside the library (its id travels through the process group the ranks were
     # started with); one rank needs none
     comm = Comm(rank, world, local_rank) if world > 1 else None
@@ -354,14 +509,42 @@ def main():
     merge_ms = (time.perf_counter() - tm0) * 1e3
     sync()
     dt = time.perf_counter() - t0
-    tmax = dt
-    nlike = float(sum(r["nlike"] for r in runs))
-    nfailed = float(sum(r["nlike_failed"] for r in runs))
-    if dist is not None:
-        t = torch.tensor([dt, nlike, nfailed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); tmax = float(tm[0])
-        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM); nlike = float(ts[1]); nfailed = float(ts[2])
+    tmax, (nlike, nfailed) = reduce_over_ranks(dist, torch, dev, dt, [float(sum(r["nlike"] for r in runs)), float(sum(r["nlike_failed"] for r in runs))])
     last = None
+
+    # the one-core reference run goes on in the background while the figures behind the timed region are taken
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = CpuBaseline(wl, nlive)
+        cpu.start()
+
+    # ---- R runs of every GPU in step + the exchange of all N R runs (its own barrier-bracketed region; never part of `value`)
+    multi = None
+    if args.runs_per_gpu > 1 and args.steps > 0 and not args.no_extras and args.workload != "c5":
+        from polychordlite_amd.repeats import run_repeats
+        R = args.runs_per_gpu
+        s_m = api.Settings(); C.memmove(C.byref(s_m), C.byref(s), C.sizeof(s)); s_m.profile = 0
+        for w in range(2):              # untimed: the block cache for R engines, the kernels' first launches
+            _, held = run_repeats(s_m, L, P, [300000 + 100003 * rank + 1000 * w + j for j in range(R)], max_in_flight=R, comm=comm)
+            held = None
+        samples = []
+        for k in range(3):
+            sync()
+            tq0 = time.perf_counter()
+            mm, held = run_repeats(s_m, L, P, [310000 + 100003 * rank + 1000 * k + j for j in range(R)], max_in_flight=R, comm=comm)
+            held = None
+            sync()
+            tq, (nl_all,) = reduce_over_ranks(dist, torch, dev, time.perf_counter() - tq0, [float(mm["nlike_local"])])
+            samples.append((nl_all / tq, tq, mm))
+        v, tq, mm = sorted(samples, key=lambda t_: t_[0])[1]
+        multi = {"runs_per_gpu": R, "n_gpus": world, "runs": int(mm["n_runs"]), "value": v, "value_min": min(t_[0] for t_ in samples),
+                 "value_max": max(t_[0] for t_ in samples), "unit": "likelihood evals/s", "wall_ms": tq * 1e3, "exchange_ms": mm["t_merge_s"] * 1e3,
+                 "merged_logZ": mm["logZ"], "merged_logZerr": mm["logZerr"], "evidence_rule": mm.get("evidence_rule"),
+                 "runs_logZ_mean": mm["runs_logZ_mean"], "runs_logZ_sem": mm["runs_logZ_sem"],
+                 "note": "every rank: R runs in step (pchip_run_repeats), then ONE exchange of all N R runs' lived records (RCCL all-gather inside the "
+                         "library; N = 1: none) and the device merge on every rank; barrier + sync on both sides, max over ranks; median of 3"}
+        lib.polychord_hip_set_option(b"trim_cache", 0.0)
+        sync()
 
     extras = rank == 0 and world == 1 and not args.no_extras and args.steps > 0
     general = None
@@ -438,13 +621,16 @@ def main():
                              "unit": "likelihood evals/s", "x_solo": v / solo_v, "lived_dead_per_s": lived / mc["t_runs_s"], "x_solo_lived_dead": lived / mc["t_runs_s"] / solo_ld,
                              "evals_per_lived_dead": mc["nlike"] / lived, "evals_per_lived_dead_reference": w3["ref_evals_per_dead"],
                              "value_reference_equivalent": lived / mc["t_runs_s"] * w3["ref_evals_per_dead"],
-                             "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "runs_logZ_mean": mc["runs_logZ_mean"], "runs_logZ_sem": mc["runs_logZ_sem"], "logZ_truth": w3["truth"],
+                             "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "evidence_rule": mc.get("evidence_rule"), "merged_logZ_replay": mc.get("logZ_replay"),
+                             "runs_logZ_mean": mc["runs_logZ_mean"], "runs_logZ_sem": mc["runs_logZ_sem"], "logZ_truth": w3["truth"],
                              "whole_run_frac": mc["nlike"] * bpe3 / mc["t_runs_s"] / 1e9 / HBM_PEAK_GBS})
             conc_other[name] = {"workload": w3["name"] % w3["nlive"], "solo": {"value": solo_v, "lived_dead_per_s": solo_ld, "ms_per_run": tsolo * 1e3,
                                                                               "evals_per_lived_dead": float(np.sum([x[0] for x in solo]) / np.sum([x[1] for x in solo]))},
                                 "in_step": rows,
-                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; merged_logZ = the replay of the union by ranks and live counts (it does not know the clusters' own volumes: biased low where a run has dozens of clusters, DESIGN section 8), runs_logZ_mean = the runs' own evidences; value_reference_equivalent = "
-                                        "dead points that lived per second x the reference binary's evaluations per dead point"}
+                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; merged_logZ = the union's "
+                                        "evidence by the rule in evidence_rule (clustered runs: the runs' own evidences combined in linear space; merged_logZ_replay = the replay "
+                                        "of the union by ranks and live counts, DESIGN section 8); value_reference_equivalent = dead points that lived per second x the "
+                                        "reference binary's evaluations per dead point"}
         lib.polychord_hip_set_option(b"trim_cache", 0.0)
         sync()
     # the other BASELINE configurations through the same engine, one timed step each (after two untimed steps that size the
@@ -501,7 +687,7 @@ def main():
             if lp:
                 pmc, pmc_src = lp, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each, over 3 runs of this workload"
         if not pmc:
-            for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+            for name in PMC_FILES:
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth) and args.workload == "c2":
                     pmc = json.load(open(pth))["kernels"]; pmc_src = "profiles/" + name
@@ -532,50 +718,66 @@ def main():
                     "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe, "traffic_source": pmc_src,
                     "whole_run_frac": evals * bpe / dt / 1e9 / HBM_PEAK_GBS,
                     "kernels": kern,
-                    "stream": "side (drawn ahead of the nursery that uses them, next to the main stream's kernels)" if dom["kernel"] == "k_bases_side" else "main",
+                    "stream": "side" if dom["kernel"] == "k_bases_side" else "main",
                     "note": "latency/parallelism bound path (SURVEY 8d): <= B chains x nDims lanes are live.  achieved = SURVEY 8(d) algorithmic "
                             "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
                             "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
                             "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
         if roof and args.workload == "c2":
             roof["latency"] = latency_model(runs, kern)
+        if roof and multi:
+            roof["in_step_multi"] = multi
         if roof and conc:
             # the GPU's best mode: R runs of the metric configuration in step (never part of `value`; `--gpus N` ranks run ONE run at a time each)
             roof["in_step"] = [{"runs": c_["runs"], "value": c_["value"], "ms_per_run": c_["per_run_ms"], "whole_run_frac": c_["whole_run_frac"]} for c_ in conc if c_["runs"] in (16, 64)]
             for nm, v_ in conc_other.items():
                 roof["in_step"] += [{"config": nm, "runs": r_["runs"], "value": r_["value"], "x_solo": r_["x_solo"], "value_reference_equivalent": r_["value_reference_equivalent"],
                                      "whole_run_frac": r_["whole_run_frac"]} for r_ in v_["in_step"]]
-        out = {"metric": METRIC[args.workload] % nlive, "value": value,
-               "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
-                          "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world,
-                          "mode": "one run at a time per GPU (a step = one run; every rank of --gpus N runs this mode).  R runs of a GPU in step -- its best "
-                                  "mode, `concurrent*` and roofline.in_step -- are reported beside it, never in `value`"},
-               "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
-               "logZ_truth": wl["truth"], "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
-               # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
-               # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
-               "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
-               "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in ("n_runs", "logZ", "logZerr", "runs_logZ_mean", "runs_logZ_sem", "records", "post_mean", "t_merge_s")} if merged else None,
-               "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
-               "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (comm.library, world)) if comm is not None else "one rank: no exchange",
-               "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
-               "host_time_s": {k: runs[-1][k] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
-               "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in ("t_setup", "t_generate", "t_loop", "t_final", "t_results", "t_teardown")},
-               "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
-               "reference_cpu_evals_per_s_survey_container": 357e3}
-        if not args.no_cpu and world == 1:
-            cb = cpu_baseline(wl, nlive)
-            out["cpu_baseline"] = cb
+        full = {"metric": METRIC[args.workload] % nlive, "value": value,
+                "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
+                           "workload_short": wl["short"] % nlive + ", one full run per step",
+                           "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world,
+                           "mode": "one run at a time per GPU (a step = one run; every rank of --gpus N runs this mode).  R runs of a GPU in step -- its best "
+                                   "mode, `concurrent*`, roofline.in_step and roofline.in_step_multi -- are reported beside it, never in `value`"},
+                "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
+                "logZ_truth": wl["truth"], "ndead": [int(r["ndead"]) for r in runs], "nlike": [int(r["nlike"]) for r in runs],
+                # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
+                # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
+                "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
+                "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items()
+                           if k in ("n_runs", "logZ", "logZerr", "logZ_replay", "logZerr_replay", "evidence_rule", "runs_logZ_mean", "runs_logZ_sem", "records", "post_mean", "t_merge_s")} if merged else None,
+                "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
+                "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (os.path.basename(comm.library or "?"), world)) if comm is not None else "one rank: no exchange",
+                "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
+                "host_time_s": {k: runs[-1][k] for k in HOST_PHASES},
+                "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in HOST_PHASES},
+                "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
+                "reference_cpu_evals_per_s_survey_container": 357e3}
+        if cpu is not None:
+            cb = cpu.finish()
+            full["cpu_baseline"] = cb
             # wall clock of one run of the reference / of the engine: what a user waits for (the evals/s ratio also counts the
             # engine's failed spawns as work)
-            out["speedup_wall_per_run"] = cb["wall_s"] / (tmax / max(args.steps, 1)) if not cb.get("bounded_max_ndead") else None
-            out["speedup_evals_per_s"] = value / cb["value"]
+            full["speedup_wall_per_run"] = cb["wall_s"] / (tmax / max(args.steps, 1)) if not cb.get("bounded_max_ndead") else None
+            full["speedup_evals_per_s"] = value / cb["value"]
         else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+            full["cpu_baseline"] = None
+        full_path = None
+        dest = args.full_out if args.full_out is not None else os.path.join("gpurun_out", "bench_full_%s.json" % args.workload)
+        if dest:
+            try:
+                os.makedirs(os.path.dirname(os.path.join(ROOT, dest)) or ".", exist_ok=True)
+                with open(os.path.join(ROOT, dest), "w") as f:
+                    json.dump(full, f)
+                full_path = dest
+            except OSError:
+                full_path = None
+        sys.stdout.flush()
+        print(json.dumps(compact_record(full, full_path), separators=(",", ":")))
+        sys.stdout.flush()
     if comm is not None:
         comm.close()
     if dist is not None:

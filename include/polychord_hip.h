@@ -252,10 +252,19 @@ typedef struct {
     double *post_mean, *post_var;  /* [nDims + nDerived] posterior moments of theta, phi */
     double t_merge_s, t_runs_s;    /* wall clock of the merge / of the runs (pchip_run_repeats) */
     long nlike, ndead_all;         /* totals over the runs (pchip_run_repeats) */
-    double runs_logZ_mean, runs_logZ_sem;   /* mean of the runs' OWN log Z and its standard error (one run: that run's own error).  The
-                                      union's logZ is replayed from ranks and live counts; a run with clusters weighs its dead points by
-                                      its clusters' volumes, which the replay does not know (10-D Rastrigin: the replay sits 0.46 below
-                                      a run's own log Z): for clustered problems this is the evidence to quote */
+    double runs_logZ_mean, runs_logZ_sem;   /* mean of the runs' OWN log Z and its standard error (one run: that run's own error) */
+    /* Which evidence `logZ, varlogZ` (and `logweights`, `post_mean`, `post_var`) are: evidence_rule
+     *   0 -- every run ended with ONE cluster: the replay of the union from ranks and live counts (the sharper estimator, and what
+     *        anesthetic computes from <root>_dead-birth.txt); logZ_replay == logZ;
+     *   1 -- at least one run ended with more than one cluster, alive or dead (`nclustered` of them).  Such a run weighs a dead point by
+     *        its CLUSTER's volume over the cluster's live count (run_time_info.f90:211-296, volumes apportioned at a split :458-503), which
+     *        the replay does not know (10-D Rastrigin, dozens of clusters: the replay sits 0.46 below the runs' own log Z, twenty of its own
+     *        error bars).  Then logZ, varlogZ = the runs' own evidences combined in linear space -- log-normal moments of each run,
+     *        mean of the Z_r, variance the larger of the propagated one and the scatter between the runs -- and record i of a run keeps its
+     *        OWN log weight minus log(nruns): the union is the equal-weight mixture of the runs' posteriors.  The replay stays in
+     *        logZ_replay, varlogZ_replay; `nlive` is the replay's live count either way. */
+    double logZ_replay, varlogZ_replay;
+    int evidence_rule, nclustered;
 } pchip_merged;
 /* Merge `nruns` runs on the device.  rows = the lived records (logweight > logzero) of run 0, then run 1, ...: counts[q]
  * rows of nTotal doubles each, every run ascending in logL (the order in which they died); entry[i] = contour at which
@@ -263,6 +272,13 @@ typedef struct {
  * RCCL all-gather filled), else host memory that is uploaded first.  Returns 0, or a pchip_run code; no CPU path. */
 int  pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
                          int on_device, int want_rows, pchip_merged *out);
+/* The same with what each run knows about itself: ownw[i] = the log prior-volume weight record i had in its own run
+ * (pchip_result.logweights of the lived records, laid out like `entry`), run_logZ / run_varlogZ / run_clustered[q] = the run's own
+ * evidence and whether it ended with more than one cluster (ncluster + ncluster_dead > 1).  If any run did, the union's evidence and
+ * weights follow pchip_merged.evidence_rule 1; all four NULL = pchip_merge_records. */
+int  pchip_merge_records_ex(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
+                            const double *ownw, const double *run_logZ, const double *run_varlogZ, const int *run_clustered,
+                            int on_device, int want_rows, pchip_merged *out);
 void pchip_merged_free(pchip_merged *m);
 /* <root>.stats (global evidence, counters, posterior means), <root>_dead-birth.txt and <root>.txt of a merged result in
  * the reference's formats (read_write.F90:809-910, :707-716, :479-617), so that PolyChordOutput / anesthetic read the
@@ -281,7 +297,7 @@ int  pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pc
  *       file, MPI_Bcast, a torch.distributed store: the library does not care;
  *   pchip_comm_create: collective over the nranks processes (ncclCommInitRank), `device` = this rank's HIP ordinal;
  *   pchip_comm_merge: picks the points of `run` that entered a live set (logweight > logzero) on the device, all-gathers
- *       the counts and then one padded block [nmax][nTotal] | [nmax] per rank (ncclAllGather over xGMI), and merges the
+ *       the counts and then one padded block [nmax][nTotal] | [nmax] | [nmax] per rank (ncclAllGather over xGMI), and merges the
  *       union on every rank with pchip_merge_records; nlike / ndead_all of the result are the totals over the ranks.
  *       c = NULL: this process alone (no collective library is touched).
  * All return 0 or a pchip_run code; nothing has a CPU path. */
@@ -292,6 +308,12 @@ int  pchip_comm_create(const char *id128, int nranks, int rank, int device, pchi
 void pchip_comm_destroy(pchip_comm *c);
 int  pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int nDims, int nDerived, int want_rows,
                       pchip_merged *out);
+/* the same for a rank that holds `nruns` runs (pchip_run_repeats with merged = NULL: the runs of a GPU in step): the ranks' run
+ * counts travel first, then six words per run (count, nlike, ndead, log Z, var log Z, clustered?), then ONE padded block per rank
+ * [nmax][nTotal] | entry [nmax] | own log weight [nmax] with the rank's runs one after the other; the union of all ranks' runs is
+ * merged on every rank (pchip_merge_records_ex).  Ranks may hold different numbers of runs. */
+int  pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, double logzero, int nDims, int nDerived, int want_rows,
+                           pchip_merged *out);
 const char *pchip_comm_library(void);   /* the RCCL that was resolved (path or soname), NULL if none could be loaded */
 
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */

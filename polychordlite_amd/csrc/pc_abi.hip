@@ -483,6 +483,16 @@ int pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const cha
         std::fprintf(fs, "%3d%s +/- %s\n", k + 1, fmt_e24(m->post_mean[k]).c_str(), fmt_e24(std::sqrt(std::fabs(m->post_var[k]))).c_str());
     }
     if (nDerived == 0) std::fprintf(fs, "-------------------------------\n");
+    // behind everything the reference's readers look at (pypolychord/output.py:57-99 stops at <nlike>): what kind of evidence this is
+    std::fprintf(fs, "\n\nUnion of %d independent runs:\n-----------------------------\n\n", m->nruns);
+    if (m->evidence_rule == 1)
+        std::fprintf(fs, " evidence rule 1: %d of the runs ended with more than one cluster; the global evidence above is the mean of the runs' own Z\n"
+                         "   (log-normal moments, error = the larger of the propagated one and the scatter between runs), posterior weights are the\n"
+                         "   runs' own over the number of runs.  A replay of the union from ranks and live counts does not know the clusters' volumes:\n", m->nclustered);
+    else
+        std::fprintf(fs, " evidence rule 0: every run ended with one cluster; the global evidence above is the replay of the union from ranks and live counts\n");
+    std::fprintf(fs, "   replay of the union: %s +/- %s\n", fmt_e24(m->logZ_replay).c_str(), fmt_e24(std::sqrt(std::fabs(m->varlogZ_replay))).c_str());
+    std::fprintf(fs, "   mean of the runs' own log Z: %s +/- %s\n", fmt_e24(m->runs_logZ_mean).c_str(), fmt_e24(m->runs_logZ_sem).c_str());
     std::fclose(fs);
     return 0;
 }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_pack_scan(int *blk, int nb, long long 
 // surviving row i of block b -> rows_out[off_b + rank in block]; entry contour next to it.  One wave per row of the block
 // in turn (4 waves), lane = column
 __global__ __launch_bounds__(PK_ROWS) void k_pack_scatter(const double *dead, const double *logw, const double *entry, long long nd, int nT,
-                                                        double logzero, const int *blk_off, double *rows_out, double *entry_out)
+                                                        double logzero, const int *blk_off, double *rows_out, double *entry_out, double *ownw_out)
 {
     __shared__ int dst[PK_ROWS];
     __shared__ int wc[PK_ROWS / 64];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(PK_ROWS) void k_pack_scatter(const double *dead, co
     int pre = blk_off[blockIdx.x];
     for (int w = 0; w < wv; ++w) pre += wc[w];
     dst[tid] = keep ? pre + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-    if (keep) entry_out[dst[tid]] = entry[i];
+    if (keep) { entry_out[dst[tid]] = entry[i]; if (ownw_out) ownw_out[dst[tid]] = logw[i]; }
     __syncthreads();
     for (int r = wv; r < PK_ROWS; r += PK_ROWS / 64) {
         const int d = dst[r];
@@ -375,18 +375,35 @@ __global__ __launch_bounds__(PK_ROWS) void k_pack_scatter(const double *dead, co
         for (int e = lane; e < nT; e += 64) o[e] = src[e];
     }
 }
-// gathered blocks [rank][rows nmax x nT | entry nmax] -> the runs one after the other
-__global__ __launch_bounds__(64) void k_unpad(const double *recv, long long nmax, int nT, int R, const long long *off, double *rows, double *entry)
+// gathered blocks [rank][rows nmax x nT | entry nmax | own log weight nmax] -> the ranks' records one after the other (a rank's
+// records: its runs one after the other); off = first record of each RANK
+__global__ __launch_bounds__(64) void k_unpad(const double *recv, long long nmax, int nT, int R, const long long *off, double *rows, double *entry, double *ownw)
 {
     const long long g = blockIdx.x;                // merged record index
     int q = 0;
     for (int r = 1; r < R; ++r) q = (g >= off[r]) ? r : q;
     const long long k = g - off[q];
-    const double *blk = recv + (size_t)q * (size_t)nmax * (nT + 1);
+    const double *blk = recv + (size_t)q * (size_t)nmax * (nT + 2);
     const double *src = blk + (size_t)k * nT;
     double *dst = rows + (size_t)g * nT;
     for (int e = threadIdx.x; e < nT; e += 64) dst[e] = src[e];
-    if (threadIdx.x == 0) entry[g] = blk[(size_t)nmax * nT + k];
+    if (threadIdx.x == 0) { entry[g] = blk[(size_t)nmax * nT + k]; ownw[g] = blk[(size_t)nmax * (nT + 1) + k]; }
+}
+// the union's weights when a run had clusters (pchip_merged::evidence_rule 1): record i keeps the prior-volume weight its OWN run gave
+// it -- its cluster's volume over the cluster's live count, run_time_info.f90:211-296 -- over the number of runs; per chunk of 1024 the
+// largest posterior log-weight
+__global__ __launch_bounds__(1024) void k_merge_ownw(const long long *perm, const double *ownw, const double *Ls, long long n, double logR,
+                                                     double *logw, double *partM)
+{
+    __shared__ double sm[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long i = (long long)blockIdx.x * 1024 + tid;
+    double pm = NEGBIG;
+    if (i < n) { const double w = ownw[perm[i]] - logR; logw[i] = w; pm = w + Ls[i]; }
+    for (int s = 32; s > 0; s >>= 1) pm = fmax(pm, __shfl_xor(pm, s));
+    if (lane == 0) sm[wv] = pm;
+    __syncthreads();
+    if (tid == 0) { for (int x = 1; x < 16; ++x) pm = fmax(pm, sm[x]); partM[blockIdx.x] = pm; }
 }
 
 // ---- RCCL, resolved at run time: the engine has no link-time dependency on a collective library (a single-GPU user needs
@@ -467,7 +484,7 @@ struct PackJob {
         if (hipMemcpyAsync(&count, d_total, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
         return hipStreamSynchronize(st) == hipSuccess;
     }
-    bool scatter(DevBuf &B, double *rows_out, double *entry_out, hipStream_t st)
+    bool scatter(DevBuf &B, double *rows_out, double *entry_out, double *ownw_out, hipStream_t st)
     {
         if (nd <= 0 || count <= 0) return true;
         if (hipSetDevice(device) != hipSuccess) return false;
@@ -476,7 +493,7 @@ struct PackJob {
         if (hipMemcpyAsync(d_dead, r->dead, sizeof(double) * (size_t)nd * nT, hipMemcpyHostToDevice, st) != hipSuccess) return false;
         if (hipMemcpyAsync(d_entry, r->entry, sizeof(double) * nd, hipMemcpyHostToDevice, st) != hipSuccess) return false;
         hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(PK_ROWS), 0, st, (const double *)d_dead, (const double *)d_logw, (const double *)d_entry,
-                           nd, nT, logzero, (const int *)d_blk, rows_out, entry_out);
+                           nd, nT, logzero, (const int *)d_blk, rows_out, entry_out, ownw_out);
         return hipGetLastError() == hipSuccess;
     }
 };
@@ -495,8 +512,44 @@ void pchip_merged_free(pchip_merged *m)
     std::memset(m, 0, sizeof(*m));
 }
 
+// The evidence of R independent runs from the runs' OWN evidences (pchip_merged::evidence_rule 1).  Each run reports a log-normal
+// Z_r: log<Z_r> = logZ_r + v_r / 2, log<Z_r^2> = 2 logZ_r + 2 v_r (run_time_info.f90:652-678 read backwards).  The mean of the runs'
+// Z in linear space, Zbar = sum Z_r / R, has <Zbar> = sum <Z_r> / R and <Zbar^2> = (sum <Z_r^2> + (sum <Z_r>)^2 - sum <Z_r>^2) / R^2
+// (independent runs); its variance in the log is the larger of that propagated one and of the scatter BETWEEN the runs (what a run does
+// not know about itself: which modes it found), log(1 + s^2 / (R <Zbar>^2)) with s^2 the sample variance of the <Z_r>.  One run gives
+// its own logZ and variance back.
+static void runs_combined_evidence(const double *lz, const double *var, int R, double *logZ, double *varlogZ)
+{
+    double mx = -1.7e308;
+    for (int r = 0; r < R; ++r) mx = std::max(mx, lz[r] + 0.5 * var[r]);
+    double s1 = 0.0, s2 = 0.0, sq = 0.0;            // sums of <Z_r>, <Z_r>^2, <Z_r^2>, all relative to exp(mx)
+    for (int r = 0; r < R; ++r) {
+        const double m = std::exp(lz[r] + 0.5 * var[r] - mx);
+        s1 += m; s2 += m * m; sq += std::exp(2.0 * lz[r] + 2.0 * var[r] - 2.0 * mx);
+    }
+    const double mean = s1 / R;
+    const double second = (sq + s1 * s1 - s2) / ((double)R * R);
+    double v = std::log(second) - 2.0 * std::log(mean);
+    if (R > 1) {
+        double ss = 0.0;
+        for (int r = 0; r < R; ++r) { const double d = std::exp(lz[r] + 0.5 * var[r] - mx) - mean; ss += d * d; }
+        const double between = std::log1p(ss / (double)(R - 1) / (double)R / (mean * mean));
+        v = std::max(v, between);
+    }
+    if (!(v > 0.0)) v = 0.0;
+    *logZ = std::log(mean) + mx - 0.5 * v;           // location of the log-normal with this mean and this variance of the log
+    *varlogZ = v;
+}
+
 int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
                         int on_device, int want_rows, pchip_merged *out)
+{
+    return pchip_merge_records_ex(nDims, nDerived, nruns, counts, rows, entry, nullptr, nullptr, nullptr, nullptr, on_device, want_rows, out);
+}
+
+int pchip_merge_records_ex(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
+                           const double *ownw, const double *run_logZ, const double *run_varlogZ, const int *run_clustered,
+                           int on_device, int want_rows, pchip_merged *out)
 {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
@@ -518,13 +571,25 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
     hipStream_t st = nullptr;
     DevBuf B;
     auto fail = [&](const char *what) { std::fprintf(stderr, "polychord_hip: merge: %s (%s)\n", what, hipGetErrorString(hipGetLastError())); pchip_merged_free(out); return 7; };
-    const double *d_rows = rows, *d_entry = entry;
+    // which evidence the union quotes: a run that ended with more than one cluster (alive or dead) weighed its dead points by its
+    // clusters' volumes, which a replay of the union from ranks and live counts does not know (10-D Rastrigin, dozens of clusters: the
+    // replay sits 0.46 below the runs' own log Z, twenty of its own error bars) -- then the runs' own evidences and weights are used
+    int nclustered = 0;
+    if (run_clustered && ownw && run_logZ && run_varlogZ) for (int q = 0; q < nruns; ++q) nclustered += run_clustered[q] != 0;
+    const bool own_rule = nclustered > 0;
+    const double *d_rows = rows, *d_entry = entry, *d_ownw = ownw;
     if (!on_device) {
         double *r = B.get<double>((size_t)n * nT), *e = B.get<double>(n);
         if (!r || !e) return fail("out of device memory");
         if (hipMemcpy(r, rows, sizeof(double) * (size_t)n * nT, hipMemcpyHostToDevice) != hipSuccess) return fail("upload");
         if (hipMemcpy(e, entry, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return fail("upload");
         d_rows = r; d_entry = e;
+        if (own_rule) {
+            double *w = B.get<double>(n);
+            if (!w) return fail("out of device memory");
+            if (hipMemcpy(w, ownw, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return fail("upload");
+            d_ownw = w;
+        }
     }
     const int nbs = (int)((n + SC_CHUNK - 1) / SC_CHUNK), nbt = (int)((n + 1023) / 1024), nbm = (int)((n + MM_CHUNK - 1) / MM_CHUNK);
     MergeDev M{};
@@ -555,6 +620,15 @@ int pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts, 
     for (int k = 1; k < nbt; ++k) { a = comb(a, hA[k]); b = comb(b, hB[k]); wmax = std::max(wmax, hM[k]); }
     const double lZ = a.a + std::log(a.b), lZ2 = b.a + std::log(b.b);       // log <Z>, log <Z^2>
     out->logZ = 2.0 * lZ - 0.5 * lZ2; out->varlogZ = lZ2 - 2.0 * lZ;       // run_time_info.f90:652-678
+    out->logZ_replay = out->logZ; out->varlogZ_replay = out->varlogZ; out->evidence_rule = 0; out->nclustered = nclustered;
+    if (own_rule) {
+        runs_combined_evidence(run_logZ, run_varlogZ, nruns, &out->logZ, &out->varlogZ);
+        out->evidence_rule = 1;
+        hipLaunchKernelGGL(k_merge_ownw, dim3(nbt), dim3(1024), 0, st, (const long long *)M.perm, d_ownw, (const double *)M.Ls, n, std::log((double)nruns), d_logw, pM);
+        if (hipMemcpy(hM.data(), pM, sizeof(double) * nbt, hipMemcpyDeviceToHost) != hipSuccess) return fail("weight kernel");
+        wmax = hM[0];
+        for (int k = 1; k < nbt; ++k) wmax = std::max(wmax, hM[k]);
+    }
     hipLaunchKernelGGL(k_merge_moments, dim3(nbm), dim3(256), 0, st, M, (const double *)d_logw, wmax, p0, nP, pmom);
     PinBuf<double> hm((size_t)nbm * (2 * nP + 1));
     if (!hm.p) return fail("out of pinned memory");
@@ -679,30 +753,36 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
             counts[k] = (long)J.count; ntot += (size_t)J.count;
         }
         DevBuf U;
-        double *rows_all = nullptr, *entry_all = nullptr;
+        double *rows_all = nullptr, *entry_all = nullptr, *ownw_all = nullptr;
         if (rc == 0) {
             (void)hipSetDevice(devs[0]);
-            rows_all = U.get<double>(ntot * nT); entry_all = U.get<double>(ntot);
-            if (!rows_all || !entry_all) rc = 7;
+            rows_all = U.get<double>(ntot * nT); entry_all = U.get<double>(ntot); ownw_all = U.get<double>(ntot);
+            if (!rows_all || !entry_all || !ownw_all) rc = 7;
         }
         size_t o = 0;
         for (int k = 0; k < nseeds && rc == 0; ++k) {
             PackJob &J = jobs[k];
             DevBuf &B = scratch[k % devs.size()];
-            if (J.device == devs[0]) { if (!J.scatter(B, rows_all + o * nT, entry_all + o, nullptr)) rc = 7; }
+            if (J.device == devs[0]) { if (!J.scatter(B, rows_all + o * nT, entry_all + o, ownw_all + o, nullptr)) rc = 7; }
             else if (J.count > 0) {
                 (void)hipSetDevice(J.device);
-                double *tr = B.get<double>((size_t)J.count * nT), *te = B.get<double>(J.count);
-                if (!tr || !te || !J.scatter(B, tr, te, nullptr)) { rc = 7; break; }
+                double *tr = B.get<double>((size_t)J.count * nT), *te = B.get<double>(2 * (size_t)J.count);
+                if (!tr || !te || !J.scatter(B, tr, te, te + J.count, nullptr)) { rc = 7; break; }
                 if (hipMemcpyPeerAsync(rows_all + o * nT, devs[0], tr, J.device, sizeof(double) * (size_t)J.count * nT, nullptr) != hipSuccess ||
-                    hipMemcpyPeerAsync(entry_all + o, devs[0], te, J.device, sizeof(double) * J.count, nullptr) != hipSuccess) rc = 2;
+                    hipMemcpyPeerAsync(entry_all + o, devs[0], te, J.device, sizeof(double) * J.count, nullptr) != hipSuccess ||
+                    hipMemcpyPeerAsync(ownw_all + o, devs[0], te + J.count, J.device, sizeof(double) * J.count, nullptr) != hipSuccess) rc = 2;
             }
             o += (size_t)J.count;
         }
         for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); if (hipDeviceSynchronize() != hipSuccess) rc = rc ? rc : 2; }
         for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); std::vector<void *> v; v.swap(scratch[d].v); for (void *p : v) pc_cache_dev_free(p); }
         (void)hipSetDevice(devs[0]);
-        if (rc == 0) rc = pchip_merge_records(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, 1, 1, merged);
+        if (rc == 0) {
+            std::vector<double> lz((size_t)nseeds), vz((size_t)nseeds);
+            std::vector<int> cl((size_t)nseeds);
+            for (int k = 0; k < nseeds; ++k) { lz[(size_t)k] = results[k].logZ; vz[(size_t)k] = results[k].varlogZ; cl[(size_t)k] = results[k].ncluster + results[k].ncluster_dead > 1; }
+            rc = pchip_merge_records_ex(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, ownw_all, lz.data(), vz.data(), cl.data(), 1, 1, merged);
+        }
         else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
     }
     if (rc == 0) {
@@ -757,15 +837,27 @@ const char *pchip_comm_library(void) { return rccl().load() ? rccl().where.c_str
 
 int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int nDims, int nDerived, int want_rows, pchip_merged *out)
 {
+    return pchip_comm_merge_many(c, run, 1, logzero, nDims, nDerived, want_rows, out);
+}
+
+// words a rank sends about each of its runs ahead of the records: count, nlike, ndead, log Z, var log Z, ended with clusters?
+#define META_W 6
+
+int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, double logzero, int nDims, int nDerived, int want_rows,
+                          pchip_merged *out)
+{
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     std::memset(out, 0, sizeof(*out));
-    const int R = c ? c->nranks : 1, nT = 2 * nDims + nDerived + 2;
-    // A rank that fails on its own (its records, its memory) still takes part in the exchange and says so there: the counts' all-gather
+    if (nruns < 1 || !runs) return 1;
+    const int R = c ? c->nranks : 1, nT = 2 * nDims + nDerived + 2, me = c ? c->rank : 0;
+    const bool coll = c && c->comm;
+    // A rank that fails on its own (its records, its memory) still takes part in the exchange and says so there: the header's all-gather
     // carries -1 for it, a one-word all-gather behind the second phase's allocations its status, and every rank returns the error
     // together -- a rank that left early would leave the others waiting in ncclAllGather for ever.
     int local_err = 0;
-    if (run->ndead > 0 && run->nTotal != nT) { std::fprintf(stderr, "polychord_hip: comm merge: the run's rows have %d columns, not %d\n", run->nTotal, nT); local_err = 1; }
+    for (int j = 0; j < nruns; ++j)
+        if (runs[j].ndead > 0 && runs[j].nTotal != nT) { std::fprintf(stderr, "polychord_hip: comm merge: the run's rows have %d columns, not %d\n", runs[j].nTotal, nT); local_err = 1; }
     int device = 0;
     if (c) device = c->device; else if (hipGetDevice(&device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
     if (hipSetDevice(device) != hipSuccess) { std::fprintf(stderr, "polychord_hip: no HIP device available -- the merge has no CPU path\n"); return 2; }
@@ -773,69 +865,106 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     DevBuf B;
     auto fail = [&](const char *what, int code) { std::fprintf(stderr, "polychord_hip: comm merge: %s (%s)\n", what, hipGetErrorString(hipGetLastError())); return code; };
     auto nfail = [&](const char *what, ncclResult_t e) { std::fprintf(stderr, "polychord_hip: comm merge: %s: %s\n", what, rccl().GetErrorString(e)); return 2; };
-    PackJob J;
-    J.r = run; J.logzero = logzero; J.device = device;
-    if (!local_err && !J.count_records(B, st)) local_err = fail("packing the run's records", 7);
-    if (local_err && !(c && c->comm)) return local_err;
-    // counts (and the runs' totals) of every rank
-    std::vector<long long> meta((size_t)4 * R, 0);
-    {   // (the 4th word: the run's own log Z, for the mean of the runs' evidences beside the union's)
-        const double zown = run->logZ; long long zb; std::memcpy(&zb, &zown, sizeof zb);
-        meta[0] = local_err ? -1 : (long long)J.count; meta[1] = run->nlike; meta[2] = run->ndead; meta[3] = zb;
+    std::vector<PackJob> J((size_t)nruns);
+    long long mine_total = 0;
+    for (int j = 0; j < nruns && !local_err; ++j) {
+        J[(size_t)j].r = &runs[j]; J[(size_t)j].logzero = logzero; J[(size_t)j].device = device;
+        if (!J[(size_t)j].count_records(B, st)) local_err = fail("packing the run's records", 7);
+        mine_total += J[(size_t)j].count;
     }
+    if (local_err && !coll) return local_err;
     long long *d_status = nullptr;
-    auto agree = [&](int mine) -> int {        // the ranks' status words, all-gathered: 0 if every rank is fine
-        std::vector<long long> w((size_t)R + 1, 0); w[0] = mine;
-        if (hipMemcpyAsync(d_status, w.data(), sizeof(long long), hipMemcpyHostToDevice, st) != hipSuccess) return 2;
-        if (rccl().AllGather(d_status, d_status + 1, 1, ncclInt64, c->comm, st) != ncclSuccess) return 2;
-        if (hipMemcpyAsync(w.data() + 1, d_status + 1, sizeof(long long) * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 2;
-        int worst = 0;
-        for (int q = 0; q < R; ++q) if (w[(size_t)q + 1] != 0) { if (!worst) { worst = (int)w[(size_t)q + 1]; if (q != c->rank) std::fprintf(stderr, "polychord_hip: comm merge: rank %d failed (code %d)\n", q, worst); } }
-        return worst;
+    auto gather_words = [&](const long long *mine, int nw, std::vector<long long> &all, long long *d_buf, const char *what) -> int {
+        // every rank's nw words -> all [R][nw]
+        if (hipMemcpyAsync(d_buf, mine, sizeof(long long) * nw, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
+        const ncclResult_t e = rccl().AllGather(d_buf, d_buf + nw, (size_t)nw, ncclInt64, c->comm, st);
+        if (e != ncclSuccess) return nfail(what, e);
+        all.assign((size_t)nw * R, 0);
+        if (hipMemcpyAsync(all.data(), d_buf + nw, sizeof(long long) * nw * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(what, 2);
+        return 0;
     };
-    if (c && c->comm) {
-        long long *d_meta = B.get<long long>((size_t)4 * (R + 1));
+    // runs per rank (header), then META_W words per run
+    std::vector<long long> hdr(1, local_err ? -1 : (long long)nruns), hdr_all;
+    int nr_max = nruns;
+    if (coll) {
         d_status = B.get<long long>((size_t)R + 1);
-        if (!d_meta || !d_status) return fail("out of device memory", 7);      // (a few hundred bytes: a device in this state serves no collective either)
-        if (hipMemcpyAsync(d_meta, meta.data(), sizeof(long long) * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
-        const ncclResult_t e = rccl().AllGather(d_meta, d_meta + 4, 4, ncclInt64, c->comm, st);
-        if (e != ncclSuccess) return nfail("ncclAllGather (counts)", e);
-        if (hipMemcpyAsync(meta.data(), d_meta + 4, sizeof(long long) * 4 * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("counts", 2);
-        for (int q = 0; q < R; ++q) if (meta[(size_t)4 * q] < 0) {
-            if (q != c->rank) std::fprintf(stderr, "polychord_hip: comm merge: rank %d could not pack its records\n", q);
-            return local_err ? local_err : 7;
+        if (!d_status) return fail("out of device memory", 7);      // (a few hundred bytes: a device in this state serves no collective either)
+        if (const int e = gather_words(hdr.data(), 1, hdr_all, d_status, "ncclAllGather (header)")) return e;
+        for (int q = 0; q < R; ++q) {
+            if (hdr_all[(size_t)q] < 0) {
+                if (q != me) std::fprintf(stderr, "polychord_hip: comm merge: rank %d could not pack its records\n", q);
+                return local_err ? local_err : 7;
+            }
+            nr_max = std::max(nr_max, (int)hdr_all[(size_t)q]);
         }
+    } else hdr_all = hdr;
+    std::vector<long long> meta((size_t)META_W * nr_max, 0), meta_all;
+    for (int j = 0; j < nruns; ++j) {
+        long long *m = &meta[(size_t)META_W * j];
+        const double z = runs[j].logZ, v = runs[j].varlogZ;
+        m[0] = J[(size_t)j].count; m[1] = runs[j].nlike; m[2] = runs[j].ndead;
+        std::memcpy(&m[3], &z, sizeof z); std::memcpy(&m[4], &v, sizeof v);
+        m[5] = runs[j].ncluster + runs[j].ncluster_dead > 1;
     }
-    std::vector<long> counts(R);
-    std::vector<long long> off(R + 1, 0);
+    if (coll) {
+        long long *d_meta = B.get<long long>((size_t)META_W * nr_max * (R + 1));
+        if (!d_meta) return fail("out of device memory", 7);
+        if (const int e = gather_words(meta.data(), META_W * nr_max, meta_all, d_meta, "ncclAllGather (counts)")) return e;
+    } else meta_all = meta;
+    // the union's runs: rank 0's, then rank 1's, ...
+    std::vector<long> counts;
+    std::vector<double> lz, vz;
+    std::vector<int> cl;
+    std::vector<long long> off_rank(R + 1, 0);
     long long nmax = 1, nlike = 0, ndead_all = 0;
-    for (int q = 0; q < R; ++q) { counts[q] = (long)meta[(size_t)4 * q]; off[q + 1] = off[q] + counts[q]; nmax = std::max(nmax, meta[(size_t)4 * q]); nlike += meta[(size_t)4 * q + 1]; ndead_all += meta[(size_t)4 * q + 2]; }
-    const size_t per = (size_t)nmax * (nT + 1);                 // one rank's block: rows [nmax][nT], then entry [nmax]
+    for (int q = 0; q < R; ++q) {
+        long long tot = 0;
+        for (int j = 0; j < (int)hdr_all[(size_t)q]; ++j) {
+            const long long *m = &meta_all[((size_t)q * nr_max + j) * META_W];
+            counts.push_back((long)m[0]); tot += m[0]; nlike += m[1]; ndead_all += m[2];
+            double z, v; std::memcpy(&z, &m[3], sizeof z); std::memcpy(&v, &m[4], sizeof v);
+            lz.push_back(z); vz.push_back(v); cl.push_back((int)m[5]);
+        }
+        off_rank[q + 1] = off_rank[q] + tot; nmax = std::max(nmax, tot);
+    }
+    const int nruns_all = (int)counts.size();
+    const size_t per = (size_t)nmax * (nT + 2);                 // one rank's block: rows [nmax][nT], entry [nmax], own log weight [nmax]
     double *send = B.get<double>(per);
     if (!send) local_err = fail("out of device memory", 7);
-    else if (!J.scatter(B, send, send + (size_t)nmax * nT, st)) local_err = fail("packing the run's records", 7);
-    if (local_err && !(c && c->comm)) return local_err;
-    const double *rows_all = send, *entry_all = send + (size_t)nmax * nT;
-    if (c && c->comm) {
+    else {
+        long long o = 0;
+        for (int j = 0; j < nruns && !local_err; ++j) {
+            if (!J[(size_t)j].scatter(B, send + (size_t)o * nT, send + (size_t)nmax * nT + o, send + (size_t)nmax * (nT + 1) + o, st)) local_err = fail("packing the run's records", 7);
+            o += J[(size_t)j].count;
+        }
+    }
+    if (local_err && !coll) return local_err;
+    const double *rows_all = send, *entry_all = send + (size_t)nmax * nT, *ownw_all = send + (size_t)nmax * (nT + 1);
+    if (coll) {
         double *recv = local_err ? nullptr : B.get<double>(per * R);
         long long *d_off = local_err ? nullptr : B.get<long long>(R + 1);
-        const long long ntot = off[R];
-        double *ra = local_err ? nullptr : B.get<double>((size_t)std::max<long long>(ntot, 1) * nT), *ea = local_err ? nullptr : B.get<double>(std::max<long long>(ntot, 1));
+        const long long ntot = off_rank[R];
+        const size_t na = (size_t)std::max<long long>(ntot, 1);
+        double *ra = local_err ? nullptr : B.get<double>(na * nT), *ea = local_err ? nullptr : B.get<double>(2 * na);
         if (!local_err && (!recv || !d_off || !ra || !ea)) local_err = fail("out of device memory", 7);
-        { const int w = agree(local_err); if (w) return local_err ? local_err : w; }
+        {   // the ranks' status words, all-gathered: go on only if every rank is fine
+            std::vector<long long> w(1, local_err), all;
+            if (const int e = gather_words(w.data(), 1, all, d_status, "ncclAllGather (status)")) return e;
+            int worst = 0;
+            for (int q = 0; q < R; ++q) if (all[(size_t)q] != 0 && !worst) { worst = (int)all[(size_t)q]; if (q != me) std::fprintf(stderr, "polychord_hip: comm merge: rank %d failed (code %d)\n", q, worst); }
+            if (worst) return local_err ? local_err : worst;
+        }
         const ncclResult_t e = rccl().AllGather(send, recv, per, ncclDouble, c->comm, st);       // the exchange: one padded block per rank over xGMI
         if (e != ncclSuccess) return nfail("ncclAllGather (records)", e);
-        if (hipMemcpyAsync(d_off, off.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
-        if (ntot > 0) hipLaunchKernelGGL(k_unpad, dim3((unsigned)ntot), dim3(64), 0, st, (const double *)recv, nmax, nT, R, (const long long *)d_off, ra, ea);
-        rows_all = ra; entry_all = ea;
+        if (hipMemcpyAsync(d_off, off_rank.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
+        if (ntot > 0) hipLaunchKernelGGL(k_unpad, dim3((unsigned)ntot), dim3(64), 0, st, (const double *)recv, nmax, nT, R, (const long long *)d_off, ra, ea, ea + na);
+        rows_all = ra; entry_all = ea; ownw_all = ea + na;
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail("exchange", 2);
-    const int rc = pchip_merge_records(nDims, nDerived, R, counts.data(), rows_all, entry_all, 1, want_rows, out);
+    const int rc = pchip_merge_records_ex(nDims, nDerived, nruns_all, counts.data(), rows_all, entry_all, ownw_all, lz.data(), vz.data(), cl.data(), 1, want_rows, out);
     if (rc == 0) {
         out->nlike = (long)nlike; out->ndead_all = (long)ndead_all; out->t_merge_s = std::chrono::duration<double>(clk::now() - t0).count();
-        std::vector<double> zs((size_t)R);
-        for (int q = 0; q < R; ++q) std::memcpy(&zs[(size_t)q], &meta[(size_t)4 * q + 3], sizeof(double));
-        runs_evidence(zs.data(), R, std::sqrt(std::fabs(run->varlogZ)), out);
+        runs_evidence(lz.data(), nruns_all, std::sqrt(std::fabs(vz[0])), out);
     }
     return rc;
 }

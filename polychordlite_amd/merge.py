@@ -24,7 +24,8 @@ class Merged(C.Structure):
                 ("rows", C.POINTER(C.c_double)), ("logweights", C.POINTER(C.c_double)), ("nlive", C.POINTER(C.c_int)),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
                 ("t_merge_s", C.c_double), ("t_runs_s", C.c_double), ("nlike", C.c_long), ("ndead_all", C.c_long),
-                ("runs_logZ_mean", C.c_double), ("runs_logZ_sem", C.c_double)]
+                ("runs_logZ_mean", C.c_double), ("runs_logZ_sem", C.c_double),
+                ("logZ_replay", C.c_double), ("varlogZ_replay", C.c_double), ("evidence_rule", C.c_int), ("nclustered", C.c_int)]
 
 
 def _lib():
@@ -33,6 +34,9 @@ def _lib():
         lib.pchip_merge_records.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.POINTER(Merged)]
         lib.pchip_merge_records.restype = C.c_int
+        lib.pchip_merge_records_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(Merged)]
+        lib.pchip_merge_records_ex.restype = C.c_int
         lib.pchip_merged_free.argtypes = [C.POINTER(Merged)]
         lib.pchip_merged_free.restype = None
         lib.pchip_merged_write.argtypes = [C.POINTER(Merged), C.c_int, C.c_int, C.c_char_p, C.c_char_p]
@@ -45,6 +49,8 @@ def _lib():
         lib.pchip_comm_destroy.restype = None
         lib.pchip_comm_merge.argtypes = [C.c_void_p, C.POINTER(api.Result), C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Merged)]
         lib.pchip_comm_merge.restype = C.c_int
+        lib.pchip_comm_merge_many.argtypes = [C.c_void_p, C.POINTER(api.Result), C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Merged)]
+        lib.pchip_comm_merge_many.restype = C.c_int
         lib.pchip_comm_library.argtypes = []
         lib.pchip_comm_library.restype = C.c_char_p
         lib._merge_bound = True
@@ -78,25 +84,46 @@ def merged_dict(m, nDims, nDerived, want_rows):
            "logweights": arr(m.logweights, n, np.float64),
            "nlive": arr(m.nlive, n, np.int32),
            "t_merge_s": m.t_merge_s, "t_runs_s": m.t_runs_s, "nlike": int(m.nlike), "ndead_all": int(m.ndead_all),
-           "runs_logZ_mean": m.runs_logZ_mean, "runs_logZ_sem": m.runs_logZ_sem}
+           "runs_logZ_mean": m.runs_logZ_mean, "runs_logZ_sem": m.runs_logZ_sem,
+           # which evidence logZ is (include/polychord_hip.h pchip_merged): 0 = the replay of the union (every run ended with one cluster),
+           # 1 = the runs' own evidences combined in linear space + the runs' own weights (a run had clusters); the replay beside it
+           "evidence_rule": int(m.evidence_rule), "nclustered": int(m.nclustered), "logZ_replay": m.logZ_replay,
+           "varlogZ_replay": m.varlogZ_replay, "logZerr_replay": float(np.sqrt(abs(m.varlogZ_replay)))}
     if want_rows and n > 0:
         out["rows"] = np.ctypeslib.as_array(m.rows, shape=(n, nT)).copy()
     return out
 
 
-def merge_records(nDims, nDerived, counts, rows, entry, on_device=False, want_rows=False, write=None):
-    """pchip_merge_records -> dict.  rows / entry: host numpy arrays (uploaded by the library), or -- on_device -- integer
-    device addresses of the gathered buffers.  write = (base_dir, file_root): also <root>.stats / _dead-birth.txt / .txt."""
+def clustered(run):
+    """did this run end with more than one cluster, alive or dead?  (then its dead points carry cluster-volume weights the union's replay
+    does not know: pchip_merged.evidence_rule)"""
+    return int(run["ncluster"] + run["ncluster_dead"] > 1)
+
+
+def merge_records(nDims, nDerived, counts, rows, entry, on_device=False, want_rows=False, write=None, ownw=None, run_logZ=None,
+                  run_varlogZ=None, run_clustered=None):
+    """pchip_merge_records[_ex] -> dict.  rows / entry (/ ownw): host numpy arrays (uploaded by the library), or -- on_device -- integer
+    device addresses of the gathered buffers.  ownw + run_logZ + run_varlogZ + run_clustered: what each run knows about itself (the
+    records' own log weights, the runs' evidences, did it end with clusters) -- with them a union that holds a clustered run quotes the
+    runs' own evidences and weights (evidence_rule 1).  write = (base_dir, file_root): also <root>.stats / _dead-birth.txt / .txt."""
     lib = _lib()
     cnt = (C.c_long * len(counts))(*[int(c) for c in counts])
     m = Merged()
     if on_device:
-        rp, ep = C.c_void_p(int(rows)), C.c_void_p(int(entry))
+        rp, ep, wp = C.c_void_p(int(rows)), C.c_void_p(int(entry)), (C.c_void_p(int(ownw)) if ownw is not None else None)
     else:
         rows = np.ascontiguousarray(rows, dtype=np.float64); entry = np.ascontiguousarray(entry, dtype=np.float64)
-        rp, ep = rows.ctypes.data_as(C.c_void_p), entry.ctypes.data_as(C.c_void_p)
+        rp, ep, wp = rows.ctypes.data_as(C.c_void_p), entry.ctypes.data_as(C.c_void_p), None
+        if ownw is not None:
+            ownw = np.ascontiguousarray(ownw, dtype=np.float64); wp = ownw.ctypes.data_as(C.c_void_p)
     want = 1 if (want_rows or write) else 0
-    rc = lib.pchip_merge_records(nDims, nDerived, len(counts), cnt, rp, ep, 1 if on_device else 0, want, C.byref(m))
+    if ownw is not None and run_logZ is not None:
+        R = len(counts)
+        lz = (C.c_double * R)(*[float(x) for x in run_logZ]); vz = (C.c_double * R)(*[float(x) for x in run_varlogZ])
+        cl = (C.c_int * R)(*[int(x) for x in run_clustered])
+        rc = lib.pchip_merge_records_ex(nDims, nDerived, R, cnt, rp, ep, wp, lz, vz, cl, 1 if on_device else 0, want, C.byref(m))
+    else:
+        rc = lib.pchip_merge_records(nDims, nDerived, len(counts), cnt, rp, ep, 1 if on_device else 0, want, C.byref(m))
     if rc != 0:
         raise RuntimeError(f"pchip_merge_records failed with code {rc}")
     try:
@@ -170,14 +197,43 @@ def comm_merge(run, comm, nDims, nDerived, want_rows=False, write=None, logzero=
         lib.pchip_merged_free(C.byref(m))
 
 
-def gather_records(run, dist, torch, device, logzero=None):
+def comm_merge_many(runs, comm, nDims, nDerived, want_rows=False, write=None, logzero=None):
+    """this rank's runs (e.g. the R runs it made in step) + everybody else's -> the merged result of all of them (pchip_comm_merge_many)"""
+    lib = _lib()
+    n = len(runs)
+    res = (api.Result * n)()
+    for k, run in enumerate(runs):
+        own = run.get("_owner")
+        if own is None:
+            raise ValueError("comm_merge_many needs results of _ctypes_api.run / run_repeats (the pchip_result travels with them)")
+        C.memmove(C.byref(res[k]), C.byref(own.res), C.sizeof(api.Result))       # (a view: the blocks stay the owners')
+    m = Merged()
+    want = 1 if (want_rows or write) else 0
+    rc = lib.pchip_comm_merge_many(comm.h if comm is not None else None, res, n, _logzero(runs[0], logzero), nDims, nDerived, want, C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"pchip_comm_merge_many failed with code {rc}")
+    try:
+        if write:
+            if lib.pchip_merged_write(C.byref(m), nDims, nDerived, str(write[0]).encode(), str(write[1]).encode()) != 0:
+                raise RuntimeError("pchip_merged_write failed")
+        return merged_dict(m, nDims, nDerived, want_rows)
+    finally:
+        lib.pchip_merged_free(C.byref(m))
+
+
+def gather_records(run, dist, torch, device, logzero=None, with_own=False):
     """The exchange on torch tensors (tests: gloo between ranks that share a GPU, or CPU only): counts first, then ONE padded
     [nmax][nTotal + 1] buffer per rank (rows | entry contour).  Returns (gathered [sum counts][nTotal + 1] tensor on
-    `device`, counts).  dist = None: this rank's records alone.  The product path between GPUs is comm_merge."""
+    `device`, counts).  dist = None: this rank's records alone.  with_own: one more column, the records' own log weights, and a third
+    return value [(logZ, varlogZ, clustered)] per rank -- what pchip_merge_records_ex wants.  The product path between GPUs is comm_merge."""
     rows, entry = lived_records(run, logzero)
-    rec = torch.cat([torch.from_numpy(rows), torch.from_numpy(entry)[:, None]], dim=1).to(device)
+    cols = [torch.from_numpy(rows), torch.from_numpy(entry)[:, None]]
+    if with_own:
+        cols.append(torch.from_numpy(np.ascontiguousarray(run["logweights"][run["logweights"] > _logzero(run, logzero)]))[:, None])
+    rec = torch.cat(cols, dim=1).to(device)
+    mine = (float(run["logZ"]), float(run["varlogZ"]), clustered(run)) if with_own else None
     if dist is None:
-        return rec.contiguous(), [int(rec.shape[0])]
+        return (rec.contiguous(), [int(rec.shape[0])], [mine]) if with_own else (rec.contiguous(), [int(rec.shape[0])])
     world = dist.get_world_size()
     cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=device)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
@@ -188,7 +244,13 @@ def gather_records(run, dist, torch, device, logzero=None):
     pad[:rec.shape[0]] = rec
     bufs = torch.empty((world * nmax, rec.shape[1]), dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(bufs, pad)
-    return torch.cat([bufs[r * nmax:r * nmax + k] for r, k in enumerate(ks)]).contiguous(), ks
+    g = torch.cat([bufs[r * nmax:r * nmax + k] for r, k in enumerate(ks)]).contiguous()
+    if not with_own:
+        return g, ks
+    ev = torch.tensor(list(mine), dtype=torch.float64, device=device)
+    evs = [torch.zeros_like(ev) for _ in range(world)]
+    dist.all_gather(evs, ev)
+    return g, ks, [(float(e[0]), float(e[1]), int(e[2])) for e in evs]
 
 
 def merge_runs(run, comm, nDims, nDerived, want_rows=False, write=None):

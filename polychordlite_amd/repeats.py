@@ -15,12 +15,14 @@ from . import _ctypes_api as api
 from . import merge as mg
 
 
-def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, want_rows=False, write=None):
+def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, want_rows=False, write=None, comm=None):
     """One nested-sampling run per seed, at most `max_in_flight` at a time per device, on `devices` (HIP ordinals of this
-    process; None = the device of `settings`), merged.
+    process; None = the device of `settings`), merged.  comm (merge.Comm, one rank per GPU): every rank makes its own seeds' runs and
+    the union of ALL ranks' runs is merged on every rank (pchip_comm_merge_many: one RCCL all-gather of the lived records).
 
-    Returns (merged, runs): merged = {"n_runs", "logZ", "logZerr", "post_mean", "post_var", "logweights", "nlive", "records",
-    "nlike", "t_runs_s", "t_merge_s"[, "rows"]}; runs = the per-seed result dicts of `_ctypes_api.run`."""
+    Returns (merged, runs): merged = {"n_runs", "logZ", "logZerr", "evidence_rule", "logZ_replay", "post_mean", "post_var", "logweights",
+    "nlive", "records", "nlike", "nlike_local", "t_runs_s", "t_merge_s"[, "rows"]}; runs = the per-seed result dicts of `_ctypes_api.run`
+    (this rank's)."""
     seeds = [int(s) for s in seeds]
     if not seeds:
         raise ValueError("run_repeats needs at least one seed")
@@ -35,20 +37,28 @@ def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, wan
     dv = (C.c_int * max(len(devs), 1))(*devs) if devs else None
     res = (api.Result * n)()
     m = mg.Merged()
-    rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), res, C.byref(m))
+    import time
+    t0 = time.perf_counter()
+    rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), res, C.byref(m) if comm is None else None)
     if rc != 0:
         raise RuntimeError(f"pchip_run_repeats failed with code {rc}")
-    try:
-        if write:
-            if lib.pchip_merged_write(C.byref(m), settings.nDims, settings.nDerived, str(write[0]).encode(), str(write[1]).encode()) != 0:
-                raise RuntimeError("pchip_merged_write failed")
-        merged = mg.merged_dict(m, settings.nDims, settings.nDerived, want_rows)
-    finally:
-        lib.pchip_merged_free(C.byref(m))
+    t_runs = time.perf_counter() - t0
     runs = []
     for k in range(n):
         r = api.Result()
         C.memmove(C.byref(r), C.byref(res[k]), C.sizeof(r))          # each dict owns (and frees) its own result block
         runs.append(api.result_dict(r, settings))
+    if comm is None:
+        try:
+            if write:
+                if lib.pchip_merged_write(C.byref(m), settings.nDims, settings.nDerived, str(write[0]).encode(), str(write[1]).encode()) != 0:
+                    raise RuntimeError("pchip_merged_write failed")
+            merged = mg.merged_dict(m, settings.nDims, settings.nDerived, want_rows)
+        finally:
+            lib.pchip_merged_free(C.byref(m))
+    else:
+        merged = mg.comm_merge_many(runs, comm, settings.nDims, settings.nDerived, want_rows=want_rows, write=write)
+        merged["t_runs_s"] = t_runs
+    merged["nlike_local"] = int(sum(r["nlike"] for r in runs))
     merged["runs_logZ"] = [r["logZ"] for r in runs]      # (their mean and its error: merged["runs_logZ_mean"], ["runs_logZ_sem"], from the library)
     return merged, runs

@@ -46,3 +46,19 @@ def lived_records(run):
     keep = lw > -1e29
     entry = run["entry"] if "entry" in run else dead[:, -2]
     return dead[keep, -1], entry[keep]
+
+
+def combined_evidence(run_logZ, run_varlogZ):
+    """evidence of R independent runs from the runs' own log-normal evidences (pchip_merged.evidence_rule 1): mean of the Z_r in linear
+    space; variance of its log = the larger of the propagated one and the scatter between the runs.  -> (logZ, varlogZ)"""
+    lz = np.asarray(run_logZ, dtype=np.float64); v = np.asarray(run_varlogZ, dtype=np.float64)
+    R = lz.size
+    m = np.exp(lz + 0.5 * v)                 # <Z_r>
+    q = np.exp(2.0 * lz + 2.0 * v)           # <Z_r^2>
+    mean = m.mean()
+    second = (q.sum() + m.sum() ** 2 - (m ** 2).sum()) / R ** 2
+    var = np.log(second) - 2.0 * np.log(mean)
+    if R > 1:
+        var = max(var, np.log1p(m.var(ddof=1) / R / mean ** 2))
+    var = max(var, 0.0)
+    return float(np.log(mean) - 0.5 * var), float(var)

@@ -1,0 +1,91 @@
+"""bench.py's last stdout line is what the driver parses: it must stay small, valid and complete.
+
+Round 4's line (profiles/r04_bench.json, 18.9 KB: per-step lists, every sweep's detail, paragraph-long notes) was not parsed and
+the round's measurement did not count.  `compact_record` makes the line from the full record; these tests feed it that very record
+(and a clustered one) and hold its size, its JSON round trip and the fields SURVEY 8(d) asks for.  The second test starts bench.py's
+own rank bootstrap with two processes over gloo (no GPU) up to, not including, the library's communicator.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _canned(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
+@pytest.mark.parametrize("name", ["r04_bench.json", "r04_bench_c3.json", "r04_bench_c5.json", "r03_bench.json"])
+def test_compact_record_is_small_valid_and_complete(name):
+    full = _canned(name)
+    # what round 5 adds to the full record
+    if full.get("roofline"):
+        full["roofline"]["in_step_multi"] = {"runs_per_gpu": 16, "n_gpus": 1, "runs": 16, "value": 4.4e9, "wall_ms": 52.1, "exchange_ms": 3.3,
+                                             "merged_logZ": 0.01, "merged_logZerr": 0.023, "note": "x" * 500}
+    full.setdefault("config", {})["workload_short"] = "configs[1]: 20-D Gaussian, nlive=2000, num_repeats=40, one full run per step"
+    out = bench.compact_record(full, "gpurun_out/bench_full_c2.json")
+    line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < bench.COMPACT_LIMIT <= 6000, len(line)
+    back = json.loads(line)
+    assert back == out
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+        assert k in back, k
+    assert back["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert back["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert set(back["config"]) >= {"workload", "batch_chains", "parallelism", "mode"}
+    roof = back["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    for k in ("kernel", "achieved", "avg_launch_us", "bytes_per_launch", "bytes_per_eval", "whole_run_frac"):
+        assert k in roof, k
+    cb = back["cpu_baseline"]
+    assert cb["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-5)
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["unit"] and cb["sample"]
+    # nothing a parser chokes on: no lists of more than six entries, no string of more than 120 characters, no NaN
+    def walk(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                walk(v)
+        elif isinstance(x, list):
+            assert len(x) <= 6
+            for v in x:
+                walk(v)
+        elif isinstance(x, str):
+            assert len(x) <= 120, x
+        elif isinstance(x, float):
+            assert x == x and abs(x) != float("inf")
+    walk(back)
+    assert "NaN" not in line and "Infinity" not in line
+
+
+def test_compact_record_sheds_optional_blocks_rather_than_grow():
+    full = _canned("r04_bench.json")
+    full["other_configs"] = {("c%d" % k): dict(full["other_configs"]["c3"]) for k in range(40)}       # absurdly many
+    out = bench.compact_record(full)
+    assert len(json.dumps(out, separators=(",", ":"))) < bench.COMPACT_LIMIT
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+
+
+def test_rank_bootstrap_two_processes_over_gloo():
+    """`python bench.py --gpus 2` starts its two ranks itself (torch.distributed.run, 127.0.0.1), forms the process group and reduces
+    the ranks' clocks and counters the way the timed region does -- here over gloo, stopping before the library's communicator"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bootstrap-only"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j == {"bootstrap": "ok", "world": 2, "backend": "gloo", "max": 2.0, "sum": 30.0}
+    # a launcher whose world size disagrees with --gpus is refused
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bootstrap-only"],
+                        cwd=ROOT, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE=3" in p2.stderr

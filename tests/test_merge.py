@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_api as orc
-from tests.replay_oracle import replay, evidence_replay, lived_records
+from tests.replay_oracle import replay, evidence_replay, lived_records, combined_evidence
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -41,6 +41,21 @@ def test_merged_runs_shrink_the_error():
     single = np.mean([r["varlogZ"] for r in runs])
     assert var < 0.4 * single                      # ~ 1/4
     assert abs(lz) < 4 * np.sqrt(var) + 0.2        # truth ~ 0 (6-D Gaussian inside the unit box)
+
+
+def test_combined_evidence_of_runs():
+    """the checker of evidence_rule 1: one run gives its own evidence back; equal runs shrink the error like 1/sqrt(R); runs that scatter
+    more than they say get the scatter as their error and the LINEAR mean as their evidence"""
+    lz, var = combined_evidence([-3.2], [0.04])
+    assert abs(lz + 3.2) < 1e-12 and abs(var - 0.04) < 1e-12
+    lz, var = combined_evidence([-3.2] * 9, [0.04] * 9)
+    assert abs(var - np.log1p(np.expm1(0.04) / 9)) < 1e-12 and abs(lz + 0.5 * var - (-3.2 + 0.02)) < 1e-12
+    zs = np.array([-23.9, -23.1, -22.6, -23.4, -22.9, -24.2])
+    lz, var = combined_evidence(zs, [0.03] * 6)
+    m = np.exp(zs + 0.015)
+    assert abs(lz + 0.5 * var - np.log(m.mean())) < 1e-12
+    assert abs(var - np.log1p(m.var(ddof=1) / 6 / m.mean() ** 2)) < 1e-12 and var > 0.03 / 6
+    assert lz > zs.mean()                            # the mean of the Z, not of the log Z
 
 
 WORKER = r"""
@@ -73,6 +88,13 @@ assert m["logZ"] == ref["logZ"] and np.array_equal(m["post_mean"], ref["post_mea
 singles = [replay(*[a for a in (lived_records(x)[0][:, -1], lived_records(x)[1])]) for x in runs]
 assert m["varlogZ"] < 0.75 * np.mean([s["varlogZ"] for s in singles])
 assert np.all(np.abs(m["post_mean"] - 0.5) < 0.05)                                   # posterior of the union: theta ~ N(0.5, 0.1)
+# with the runs' own weights and evidences behind the records (what pchip_merge_records_ex wants for clustered runs)
+g2, ks2, ev = gather_records(mine, dist, torch, torch.device("cpu"), with_own=True)
+g2 = g2.numpy()
+assert ks2 == ks and np.array_equal(g2[:, :-1], g) and len(ev) == world
+own = np.concatenate([x["logweights"][x["logweights"] > -1e29] for x in runs])
+assert np.array_equal(g2[:, -1], own)
+assert ev == [(float(x["logZ"]), float(x["varlogZ"]), int(x["ncluster"] + x["ncluster_dead"] > 1)) for x in runs], ev
 if rank == 0:
     print("GATHER_OK", ks, m["logZ"], m["post_mean"][:2])
 dist.barrier(); dist.destroy_process_group()
@@ -174,6 +196,72 @@ def test_device_merge_of_clustered_and_ragged_runs(engine):
 
 
 @pytest.mark.gpu
+def test_union_of_clustered_runs_quotes_the_runs_own_evidence(engine, tmp_path):
+    """sixteen 10-D Rastrigin runs (nlive 300, kNN clustering: dozens of clusters each).  A run with clusters weighs a dead point by its
+    CLUSTER's volume (run_time_info.f90:211-296, :458-503); the replay of the union from ranks and live counts does not know them and sits
+    far below the runs' own evidences (round 4: 0.46 at BASELINE configs[2], twenty of its own error bars).  The union must quote the runs'
+    own evidences combined in linear space (evidence_rule 1), weigh every record by its own weight over the number of runs, say so in its
+    .stats file, and keep the replay beside it."""
+    from polychordlite_amd import merge as mg
+    from polychordlite_amd.repeats import run_repeats
+    from polychordlite_amd.pypolychord.output import PolyChordOutput
+    api = engine
+    lib = api.load()
+    D, R = 10, 16
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, 0)
+    s.nlive, s.num_repeats, s.do_clustering = 300, 30, 1
+    L, P, keep = api.make_problem("rastrigin", D, 0, -5.12, 5.12)
+    merged, runs = run_repeats(s, L, P, [600 + k for k in range(R)], max_in_flight=R, want_rows=True, write=(str(tmp_path), "u"))
+    assert merged["n_runs"] == R and merged["evidence_rule"] == 1 and merged["nclustered"] == sum(mg.clustered(r) for r in runs) >= R // 2
+    lz, var = combined_evidence([r["logZ"] for r in runs], [r["varlogZ"] for r in runs])
+    assert abs(merged["logZ"] - lz) < 1e-10 and abs(merged["varlogZ"] - var) < 1e-10
+    zs = np.array([r["logZ"] for r in runs])
+    assert abs(merged["runs_logZ_mean"] - zs.mean()) < 1e-12
+    # within 3 sigma of the runs' own mean -- and the replay is not (that is what this rule is for)
+    assert abs(merged["logZ"] - merged["runs_logZ_mean"]) < 3.0 * np.hypot(merged["logZerr"], merged["runs_logZ_sem"])
+    assert merged["logZerr"] >= np.sqrt(np.mean([r["varlogZ"] for r in runs]) / R) * 0.99          # never below the propagated error
+    recs = [mg.lived_records(r) for r in runs]
+    rows = np.concatenate([a for a, _ in recs]); entry = np.concatenate([b for _, b in recs])
+    ref = replay(rows[:, -1], entry, rows=rows, p0=D, nP=D)
+    assert abs(merged["logZ_replay"] - ref["logZ"]) < 1e-9 and abs(merged["varlogZ_replay"] - ref["varlogZ"]) < 1e-9
+    assert np.array_equal(merged["nlive"], ref["nlive"])
+    assert merged["logZ_replay"] < merged["runs_logZ_mean"] - 3.0 * merged["logZerr_replay"]
+    # weights: the runs' own, over the number of runs, in merged death order
+    own = np.concatenate([r["logweights"][r["logweights"] > -1e29] for r in runs]) - np.log(R)
+    order = ref["order"]
+    assert np.array_equal(merged["rows"][:, -1], rows[order, -1])
+    assert np.abs(merged["logweights"] - own[order]).max() < 1e-12
+    lp = merged["logweights"] + merged["rows"][:, -1]
+    # sum of the posterior weights = mean over the runs of <Z_r>
+    assert abs(np.logaddexp.reduce(lp) - np.log(np.mean(np.exp(zs + 0.5 * np.array([r["varlogZ"] for r in runs]))))) < 1e-6
+    w = np.exp(lp - lp.max())
+    x = merged["rows"][:, D:2 * D]
+    mean = (w[:, None] * x).sum(0) / w.sum()
+    assert np.allclose(merged["post_mean"], mean, atol=1e-11) and np.allclose(merged["post_var"], (w[:, None] * x * x).sum(0) / w.sum() - mean ** 2, atol=1e-11)
+    assert np.all(np.abs(merged["post_mean"]) < 0.35)             # Rastrigin: symmetric about 0
+    # the files: PolyChordOutput reads the quoted evidence, the file says which it is and keeps the replay
+    out = PolyChordOutput(str(tmp_path), "u")
+    assert abs(out.logZ - merged["logZ"]) < 1e-12 and abs(out.logZerr - merged["logZerr"]) < 1e-12
+    txt = open(tmp_path / "u.stats").read()
+    assert "evidence rule 1" in txt and "replay of the union" in txt and ("%d of the runs" % merged["nclustered"]) in txt
+    post = np.loadtxt(tmp_path / "u.txt")
+    assert np.allclose((post[:, 0][:, None] * post[:, 2:2 + D]).sum(0) / post[:, 0].sum(), merged["post_mean"], atol=1e-9)
+    # the same union through the records interface (what a gloo / MPI transport feeds): identical
+    m2 = mg.merge_records(D, 0, [a.shape[0] for a, _ in recs], rows, entry, ownw=own + np.log(R), run_logZ=zs,
+                          run_varlogZ=[r["varlogZ"] for r in runs], run_clustered=[mg.clustered(r) for r in runs])
+    assert m2["logZ"] == merged["logZ"] and m2["evidence_rule"] == 1 and np.array_equal(m2["logweights"], merged["logweights"])
+    # and without what the runs know about themselves it is the replay, as before
+    m3 = mg.merge_records(D, 0, [a.shape[0] for a, _ in recs], rows, entry)
+    assert m3["evidence_rule"] == 0 and m3["logZ"] == merged["logZ_replay"]
+    # one clustered run merged alone gives its own evidence back
+    one = mg.comm_merge(runs[0], None, D, 0)
+    if mg.clustered(runs[0]):
+        assert one["evidence_rule"] == 1 and abs(one["logZ"] - runs[0]["logZ"]) < 1e-12 and abs(one["varlogZ"] - runs[0]["varlogZ"]) < 1e-12
+        lw = runs[0]["logweights"]
+        assert np.array_equal(one["logweights"], lw[lw > -1e29])
+
+
+@pytest.mark.gpu
 def test_run_repeats_front_door_and_files(engine, tmp_path):
     """polychordlite_amd.repeats.run_repeats(devices=[...]): the repeats are the runs they would be one after the other, the
     union comes from the device merge, and its files read like a single run's (PolyChordOutput parses <root>.stats)"""
@@ -188,6 +276,7 @@ def test_run_repeats_front_door_and_files(engine, tmp_path):
         assert one["ndead"] == r["ndead"] and one["nlike"] == r["nlike"] and one["logZ"] == r["logZ"]
         assert np.array_equal(one["dead"], r["dead"]) and np.array_equal(one["logweights"], r["logweights"]) and np.array_equal(one["live"], r["live"])
     assert merged["n_runs"] == 6 and merged["nlike"] == sum(r["nlike"] for r in runs)
+    assert merged["evidence_rule"] == 0 and merged["logZ_replay"] == merged["logZ"]     # one-cluster runs: the replay of the union, as before
     rows = np.concatenate([r["dead"][r["logweights"] > -1e29] for r in runs]); entry = np.concatenate([r["entry"][r["logweights"] > -1e29] for r in runs])
     ref = replay(rows[:, -1], entry, rows=rows, p0=6, nP=7)
     assert abs(merged["logZ"] - ref["logZ"]) < 1e-9 and np.allclose(merged["post_mean"], ref["post_mean"], atol=1e-11)
@@ -248,6 +337,24 @@ box = [None] * world
 dist.all_gather_object(box, dig)
 assert all(b == box[0] for b in box), box
 dist.barrier()
+# clustered runs on both ranks: the records travel with their own weights and the runs' evidences, the union follows evidence_rule 1
+from tests.replay_oracle import combined_evidence
+s2 = api.Settings(); lib.pchip_settings_default(C.byref(s2), 3, 0)
+s2.nlive, s2.num_repeats, s2.do_clustering, s2.seed, s2.device = 200, 9, 1, 90 + rank, 0
+L2, P2, keep2 = api.make_problem("rastrigin", 3, 0, -5.12, 5.12)
+mine2 = api.run(s2, L2, P2)
+assert mg.clustered(mine2)
+g2, ks2, ev = mg.gather_records(mine2, dist, torch, torch.device("cpu"), with_own=True)
+g2 = g2.numpy()
+m2 = mg.merge_records(3, 0, ks2, np.ascontiguousarray(g2[:, :-2]), np.ascontiguousarray(g2[:, -2]), ownw=np.ascontiguousarray(g2[:, -1]),
+                      run_logZ=[e[0] for e in ev], run_varlogZ=[e[1] for e in ev], run_clustered=[e[2] for e in ev])
+lz, var = combined_evidence([e[0] for e in ev], [e[1] for e in ev])
+assert m2["evidence_rule"] == 1 and m2["nclustered"] == 2 and abs(m2["logZ"] - lz) < 1e-10 and abs(m2["varlogZ"] - var) < 1e-10
+assert ev[rank][0] == mine2["logZ"]
+box2 = [None] * world
+dist.all_gather_object(box2, (m2["logZ"], m2["varlogZ"], m2["logZ_replay"], m2["post_mean"].tolist(), hashlib.sha256(m2["logweights"].tobytes()).hexdigest()))
+assert all(b == box2[0] for b in box2), box2
+dist.barrier()
 if rank == 0:
     a, b = PolyChordOutput(out_dir, "u0"), PolyChordOutput(out_dir, "u1")
     assert a.logZ == b.logZ and abs(a.logZ - m["logZ"]) < 1e-12
@@ -294,6 +401,20 @@ def test_library_rccl_exchange_one_rank(engine):
     assert a["nlike"] == run["nlike"] and a["ndead_all"] == run["ndead"]
     assert abs(a["logZ"] - run["logZ"]) < 1e-7
     assert a["runs_logZ_mean"] == run["logZ"] and abs(a["runs_logZ_sem"] - run["logZerr"]) < 1e-12      # (the run's own evidence travelled with the counts)
+    # a rank that holds several runs (the runs of a GPU in step): header, six words per run, one padded block with the runs one after the other
+    s3, L3, P3, keep3, runs3 = _engine_runs(engine, [32, 33, 34], nlive=120)
+    comm = mg.Comm(0, 1, 0)
+    try:
+        c = mg.comm_merge_many(runs3, comm, 6, 1, want_rows=True)
+    finally:
+        comm.close()
+    recs = [mg.lived_records(r) for r in runs3]
+    d = mg.merge_records(6, 1, [x.shape[0] for x, _ in recs], np.concatenate([x for x, _ in recs]), np.concatenate([e for _, e in recs]), want_rows=True)
+    assert c["n_runs"] == 3 and c["records"] == d["records"] and c["logZ"] == d["logZ"] and c["varlogZ"] == d["varlogZ"]
+    assert np.array_equal(c["rows"], d["rows"]) and np.array_equal(c["logweights"], d["logweights"]) and np.array_equal(c["nlive"], d["nlive"])
+    assert c["nlike"] == sum(r["nlike"] for r in runs3) and abs(c["runs_logZ_mean"] - np.mean([r["logZ"] for r in runs3])) < 1e-12
+    e = mg.comm_merge_many(runs3, None, 6, 1, want_rows=True)              # no communicator: the same code without the collective
+    assert e["logZ"] == c["logZ"] and np.array_equal(e["rows"], c["rows"])
 
 
 @pytest.mark.gpu
