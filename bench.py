@@ -15,7 +15,7 @@ Contract (DESIGN.md "Measurement"):
     evaluation x evaluations of one launch / its measured launch duration.
   * cpu_baseline: the REFERENCE itself (oracle/_ref/ref_driver, built from /root/reference by oracle/Makefile; else the C
     restatement oracle/liboracle.so) on one host core, one full run of the same workload, and `all_cores`: one
-    independent bounded run per host core at the same time.
+    independent run per host core at the same time (both legs after every GPU figure, alone).
   * OUTPUT: the LAST stdout line is ONE compact JSON record (< 6 KB: `compact_record`); the full record (per-step lists,
     every kernel class, the sweeps' details, notes) goes to gpurun_out/bench_full_<workload>.json (`--full-out`), never to
     stdout.  Round 4's 18.9-KB line was not parsed by the driver; tests/test_bench_line.py holds the size.
@@ -174,11 +174,10 @@ def cpu_model():
 
 class CpuBaseline:
     """the reference (preferred) or the restatement on ONE host core -- one full run of the workload (bounded for c5) -- and
-    `all_cores`: one BOUNDED run per host core at the same time (the first ALL_CORES_NDEAD deaths: the same evaluations and the
-    same bookkeeping early in the run; ~3 s instead of a second full run's 11 s).  start() launches the one-core run in the
-    background (it keeps ONE of the box's cores busy while the figures behind the timed region are taken on the GPU);
-    finish() waits for it and then runs the all-cores leg."""
-    ALL_CORES_NDEAD = 16000
+    `all_cores`: one full run per host core at the same time.  Both legs run AFTER every GPU figure has been taken, with nothing else
+    going on (tried in round 5: the one-core run in the background of the GPU sweeps measured 6 % low, an all-cores leg bounded to
+    the first 16000 deaths 30 % low -- a baseline must not be flattered by the harness)."""
+    ALL_CORES_NDEAD = None
 
     def __init__(self, wl, nlive, all_cores=True):
         self.wl, self.nlive, self.all_cores = wl, nlive, all_cores
@@ -240,8 +239,7 @@ class CpuBaseline:
                     res["all_cores"] = {"value": sum(x["nlike"] for x in js) / wall, "unit": "likelihood evals/s", "cores": self.ncores, "runs": len(js),
                                         "wall_s": wall, "mean_run_wall_s": float(np.mean([x["wall"] for x in js])),
                                         "hardware_threads_visible": self.visible,
-                                        "sample": "one run per core the cgroup grants (<= 32), started together, each stopped after %d deaths; "
-                                                  "sum nlike / wall of the slowest" % (self.bounded or self.ALL_CORES_NDEAD)}
+                                        "sample": "one run per core the cgroup grants (<= 32), started together; sum nlike / wall of the slowest"}
                 return res
         from tests import oracle_api as orc
         wl = self.wl
@@ -512,11 +510,7 @@ def main():
     tmax, (nlike, nfailed) = reduce_over_ranks(dist, torch, dev, dt, [float(sum(r["nlike"] for r in runs)), float(sum(r["nlike_failed"] for r in runs))])
     last = None
 
-    # the one-core reference run goes on in the background while the figures behind the timed region are taken
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = CpuBaseline(wl, nlive)
-        cpu.start()
+    cpu = CpuBaseline(wl, nlive) if (rank == 0 and world == 1 and not args.no_cpu) else None      # (runs at the very end, alone)
 
     # ---- R runs of every GPU in step + the exchange of all N R runs (its own barrier-bracketed region; never part of `value`)
     multi = None

@@ -184,6 +184,8 @@ typedef struct {
     long nlike_failed;             /* of nlike: evaluations spent on chains whose spawn failed (their last point fell below the
                                       contour that had risen since the nursery was seeded; batch = 1 has almost none) */
     int ncluster_peak;             /* largest number of clusters alive at the same time */
+    int epoch_discard;             /* the rule this run followed for chains in flight when the cluster list changed (pchip_settings.epoch_discard:
+                                      0 = the engine's, 1 = the reference farm's); it only matters with batch > 1 and several clusters */
 } pchip_result;
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
@@ -223,6 +225,13 @@ typedef struct {
     void *user;
 } pchip_hooks;
 
+/* The structs of this header grow at their END from release to release and carry no size member (their first members are what existing
+ * bindings rely on).  A binding that mirrors them (ctypes, ISO_C_BINDING, cgo ...) checks itself against the library it loaded:
+ * pchip_abi_version() == PCHIP_ABI_VERSION of the header it was written against, and pchip_sizeof("settings" | "result" | "merged" |
+ * "like" | "prior" | "update") == the size of its own mirror (0 for an unknown name). */
+#define PCHIP_ABI_VERSION 5
+int  pchip_abi_version(void);
+unsigned long pchip_sizeof(const char *struct_name);
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
 int  pchip_device_count(void);
 /* full run; returns 0 on success, else (message on stderr, nothing to free, the process goes on): 1 settings, 2 HIP /
@@ -254,9 +263,9 @@ typedef struct {
     long nlike, ndead_all;         /* totals over the runs (pchip_run_repeats) */
     double runs_logZ_mean, runs_logZ_sem;   /* mean of the runs' OWN log Z and its standard error (one run: that run's own error) */
     /* Which evidence `logZ, varlogZ` (and `logweights`, `post_mean`, `post_var`) are: evidence_rule
-     *   0 -- every run ended with ONE cluster: the replay of the union from ranks and live counts (the sharper estimator, and what
+     *   0 -- no run ever held more than ONE cluster: the replay of the union from ranks and live counts (the sharper estimator, and what
      *        anesthetic computes from <root>_dead-birth.txt); logZ_replay == logZ;
-     *   1 -- at least one run ended with more than one cluster, alive or dead (`nclustered` of them).  Such a run weighs a dead point by
+     *   1 -- at least one run held several clusters at some time (pchip_result.ncluster_peak > 1; `nclustered` of them).  Such a run weighs a dead point by
      *        its CLUSTER's volume over the cluster's live count (run_time_info.f90:211-296, volumes apportioned at a split :458-503), which
      *        the replay does not know (10-D Rastrigin, dozens of clusters: the replay sits 0.46 below the runs' own log Z, twenty of its own
      *        error bars).  Then logZ, varlogZ = the runs' own evidences combined in linear space -- log-normal moments of each run,
@@ -274,7 +283,7 @@ int  pchip_merge_records(int nDims, int nDerived, int nruns, const long *counts,
                          int on_device, int want_rows, pchip_merged *out);
 /* The same with what each run knows about itself: ownw[i] = the log prior-volume weight record i had in its own run
  * (pchip_result.logweights of the lived records, laid out like `entry`), run_logZ / run_varlogZ / run_clustered[q] = the run's own
- * evidence and whether it ended with more than one cluster (ncluster + ncluster_dead > 1).  If any run did, the union's evidence and
+ * evidence and whether it ever held more than one cluster (pchip_result.ncluster_peak > 1).  If any run did, the union's evidence and
  * weights follow pchip_merged.evidence_rule 1; all four NULL = pchip_merge_records. */
 int  pchip_merge_records_ex(int nDims, int nDerived, int nruns, const long *counts, const double *rows, const double *entry,
                             const double *ownw, const double *run_logZ, const double *run_varlogZ, const int *run_clustered,

@@ -57,7 +57,7 @@ class Result(C.Structure):
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
                 ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int)),
-                ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int)]
+                ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int), ("epoch_discard", C.c_int)]
 
 
 _lib = None
@@ -87,6 +87,13 @@ def load():
     lib.polychord_hip_set_uniform_prior.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.polychord_hip_set_corr_gaussian.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
     lib.polychord_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    # this mirror against the library that was loaded (the structs grow at their end: include/polychord_hip.h PCHIP_ABI_VERSION)
+    lib.pchip_sizeof.argtypes = [C.c_char_p]
+    lib.pchip_sizeof.restype = C.c_ulong
+    for name, cls in (("settings", Settings), ("result", Result), ("like", Like), ("prior", Prior)):
+        if lib.pchip_sizeof(name.encode()) != C.sizeof(cls):
+            raise ImportError(f"{LIB_PATH}: pchip_{name} is {lib.pchip_sizeof(name.encode())} bytes, this binding's mirror {C.sizeof(cls)} "
+                              f"(library ABI version {lib.pchip_abi_version()}): rebuild with `python -m polychordlite_amd.build`")
     _lib = lib
     return lib
 
@@ -183,7 +190,7 @@ def result_dict(r, settings):
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
-               nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak,
+               nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak, epoch_discard=r.epoch_discard,
                varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                logzero=settings.logzero,
                _owner=own)          # the pchip_result itself (merge.comm_merge hands it back to the library)

@@ -85,6 +85,7 @@ struct FileSink {
     std::vector<long> nlike_last_g;
     std::vector<double> mu, sig;
     int feedback = 0, nlive_set = 1;
+    int epoch_note = -1;          // >= 0: the run's epoch_discard rule goes to the end of <root>.stats (clustered runs with a nursery of several chains)
 
     // progress block of an update, in the layout of feedback.f90:221-315 (the rows this engine keeps on the host:
     // live points per cluster, counters, evidences -- per cluster in order of decreasing evidence)
@@ -201,6 +202,11 @@ struct FileSink {
             }
             if (nDer == 0) std::fprintf(f, "-------------------------------\n");
         }
+        // behind everything the reference's readers look at: the one engine-specific sampling rule a clustered run with a nursery of
+        // several chains follows (include/polychord_hip.h pchip_settings.epoch_discard); batch = 1 and unclustered runs have none
+        if (epoch_note >= 0)
+            std::fprintf(f, "\n\npolychord_hip: chains in flight when the list of clusters changes: epoch_discard = %d (%s)\n", epoch_note,
+                         epoch_note ? "all discarded: the reference farm's rule, nested_sampling.F90:313" : "only those seeded in the cluster that ended are lost");
         std::fclose(f);
     }
     // weighted / equally weighted posteriors from the dead points (update_posteriors, run_time_info.f90:955-1066;
@@ -433,6 +439,19 @@ void polychord_hip_set_option(const char *name, double value)
     else std::fprintf(stderr, "polychord_hip: unknown option %s\n", name);
 }
 
+int pchip_abi_version(void) { return PCHIP_ABI_VERSION; }
+unsigned long pchip_sizeof(const char *n)
+{
+    if (!n) return 0;
+    if (!std::strcmp(n, "settings")) return sizeof(pchip_settings);
+    if (!std::strcmp(n, "result")) return sizeof(pchip_result);
+    if (!std::strcmp(n, "merged")) return sizeof(pchip_merged);
+    if (!std::strcmp(n, "like")) return sizeof(pchip_like);
+    if (!std::strcmp(n, "prior")) return sizeof(pchip_prior);
+    if (!std::strcmp(n, "update")) return sizeof(pchip_update);
+    return 0;
+}
+
 // Files of a merged result (pchip_merge_records / pchip_run_repeats) in the reference's formats: <root>.stats
 // (read_write.F90:809-910; no local evidences: the union has one volume), <root>_dead-birth.txt (theta, phi, logL, birth;
 // :707-716) and <root>.txt (weight, -2 logL, theta, phi; :479-617, weights relative to the largest).
@@ -486,11 +505,11 @@ int pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const cha
     // behind everything the reference's readers look at (pypolychord/output.py:57-99 stops at <nlike>): what kind of evidence this is
     std::fprintf(fs, "\n\nUnion of %d independent runs:\n-----------------------------\n\n", m->nruns);
     if (m->evidence_rule == 1)
-        std::fprintf(fs, " evidence rule 1: %d of the runs ended with more than one cluster; the global evidence above is the mean of the runs' own Z\n"
+        std::fprintf(fs, " evidence rule 1: %d of the runs held more than one cluster; the global evidence above is the mean of the runs' own Z\n"
                          "   (log-normal moments, error = the larger of the propagated one and the scatter between runs), posterior weights are the\n"
                          "   runs' own over the number of runs.  A replay of the union from ranks and live counts does not know the clusters' volumes:\n", m->nclustered);
     else
-        std::fprintf(fs, " evidence rule 0: every run ended with one cluster; the global evidence above is the replay of the union from ranks and live counts\n");
+        std::fprintf(fs, " evidence rule 0: no run ever held more than one cluster; the global evidence above is the replay of the union from ranks and live counts\n");
     std::fprintf(fs, "   replay of the union: %s +/- %s\n", fmt_e24(m->logZ_replay).c_str(), fmt_e24(std::sqrt(std::fabs(m->varlogZ_replay))).c_str());
     std::fprintf(fs, "   mean of the runs' own log Z: %s +/- %s\n", fmt_e24(m->runs_logZ_mean).c_str(), fmt_e24(m->runs_logZ_sem).c_str());
     std::fclose(fs);
@@ -669,6 +688,7 @@ static void c_interface_impl(
     sink.write_stats = write_stats_f; sink.write_live = write_live; sink.write_dead = write_dead;
     sink.posteriors = posteriors; sink.equals = equals; sink.write_prior = write_prior; sink.cluster_posteriors = cluster_posteriors; sink.seed = (unsigned)s.seed; sink.logzero = logzero;
     sink.compression = compression_factor; sink.num_repeats = num_repeats;
+    sink.epoch_note = (do_clustering && s.batch != 1 && !s.sequential_rng) ? s.epoch_discard : -1;
     sink.feedback = feedback; sink.nlive_set = nlive > 0 ? nlive : 1;
     const bool files = write_stats_f || write_dead || write_live || posteriors || equals || write_prior;
     pchip_result r;
@@ -677,6 +697,10 @@ static void c_interface_impl(
         std::printf("\nPolyChord interface on polychord_hip (MI355X engine)\n");
         std::printf("nlive      : %8d\nnDims      : %8d\nnDerived   : %8d\n", nlive, nDims, nDerived);
         if (do_clustering) std::printf("Doing Clustering\n");
+        if (do_clustering && s.batch != 1)
+            std::printf("chains in flight when the list of clusters changes: %s\n",
+                        s.epoch_discard ? "all discarded (epoch_discard = 1: the reference farm's rule, nested_sampling.F90:313)"
+                                        : "only those seeded in the cluster that ended are lost (epoch_discard = 0, this engine's default; option \"epoch_discard\" = 1: the reference farm's rule)");
         if (write_resume || read_resume) std::printf("Resume file: %s/%s.resume\n", base.c_str(), root.c_str());
         std::printf("\nnum_repeats:");
         if (g_reps.size()) for (int v : g_reps) std::printf("%8d", v); else std::printf("%8d", num_repeats);

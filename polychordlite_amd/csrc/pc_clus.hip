@@ -112,12 +112,11 @@ extern "C" int pc_consume_cl_fits(const PcState *S, int nc)
 extern "C" int pc_launch_consume_cl_many(const PcState *S, const PcManyRec *dR, int R, int wide, hipStream_t st)
 {
     const size_t sh = cl_layout(S->Ncap, S->B, S->nr).total;
-    static size_t done1 = 0, done2 = 0;
     if (!wide) {
-        if (sh > done1) { (void)hipFuncSetAttribute((const void *)k_consume_cl_many<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1 = sh; }
+        pc_need_dyn_lds((const void *)k_consume_cl_many<1>, sh);
         hipLaunchKernelGGL(k_consume_cl_many<1>, dim3(1, R), dim3(CL_NT), sh, st, dR);
     } else {
-        if (sh > done2) { (void)hipFuncSetAttribute((const void *)k_consume_cl_many<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done2 = sh; }
+        pc_need_dyn_lds((const void *)k_consume_cl_many<2>, sh);
         hipLaunchKernelGGL(k_consume_cl_many<2>, dim3(1, R), dim3(CL_NT), sh, st, dR);
     }
     return 0;
@@ -126,12 +125,11 @@ extern "C" int pc_launch_consume_cl_many(const PcState *S, const PcManyRec *dR, 
 extern "C" int pc_launch_consume_cl(const PcState *S, int nc, hipStream_t st)
 {
     const size_t sh = cl_layout(S->Ncap, S->B, S->nr).total;
-    static size_t done1 = 0, done2 = 0;
     if (nc <= 64) {
-        if (sh > done1) { (void)hipFuncSetAttribute((const void *)k_consume_cl<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1 = sh; }
+        pc_need_dyn_lds((const void *)k_consume_cl<1>, sh);
         hipLaunchKernelGGL(k_consume_cl<1>, dim3(1), dim3(CL_NT), sh, st, *S);
     } else {
-        if (sh > done2) { (void)hipFuncSetAttribute((const void *)k_consume_cl<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done2 = sh; }
+        pc_need_dyn_lds((const void *)k_consume_cl<2>, sh);
         hipLaunchKernelGGL(k_consume_cl<2>, dim3(1), dim3(CL_NT), sh, st, *S);
     }
     return 0;

@@ -391,9 +391,8 @@ int pc_launch_knn_cluster_sub(const int *d_desc, int nb, int mmax, const double 
     if (nb <= 0) return 0;
     size_t sh, sh2;
     if (sub_lds(mmax, sh, sh2)) return 1;
-    static size_t d1 = 0, d2 = 0;
-    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
-    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    pc_need_dyn_lds((const void *)k_knn_sort_sub, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster_sub, sh2);
     hipLaunchKernelGGL(k_knn_sort_sub, dim3(mmax, nb), dim3(256), sh, st, (const SubDesc *)d_desc, Sm, pool, knn);
     hipLaunchKernelGGL(k_nn_cluster_sub, dim3(nb), dim3(1024), sh2, st, (const SubDesc *)d_desc, (const int *)knn, labels, out);
     return 0;
@@ -403,9 +402,8 @@ int pc_launch_knn_cluster_sub_many(const PcManyRec *dR, int R, int nb_max, int m
     if (nb_max <= 0) return 0;
     size_t sh, sh2;
     if (sub_lds(mmax, sh, sh2)) return 1;
-    static size_t d1 = 0, d2 = 0;
-    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_sub_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
-    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_sub_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    pc_need_dyn_lds((const void *)k_knn_sort_sub_many, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster_sub_many, sh2);
     hipLaunchKernelGGL(k_knn_sort_sub_many, dim3(mmax, nb_max, R), dim3(256), sh, st, dR);
     hipLaunchKernelGGL(k_nn_cluster_sub_many, dim3(nb_max, R), dim3(1024), sh2, st, dR);
     return 0;
@@ -444,9 +442,8 @@ int pc_launch_knn_cluster(const double *Sm, int nroot, const int *gidx, int m, i
     const size_t sh = (size_t)npow2 * 12;
     const size_t sh2 = (size_t)m * 12 + 64;
     if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
-    static size_t d1 = 0, d2 = 0;
-    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
-    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    pc_need_dyn_lds((const void *)k_knn_sort, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster, sh2);
     hipLaunchKernelGGL(k_knn_sort, dim3(m), dim3(256), sh, st, Sm, nroot, gidx, m, npow2, knn);
     hipLaunchKernelGGL(k_nn_cluster, dim3(1), dim3(1024), sh2, st, knn, m, labels, out);
     return 0;
@@ -462,9 +459,8 @@ int pc_launch_knn_cluster_batch(const PcState *S, const int *h_desc, const int *
     while (npow2 < nmax) npow2 <<= 1;
     const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
     if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
-    static size_t d1 = 0, d2 = 0;
-    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
-    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    pc_need_dyn_lds((const void *)k_knn_sort_b, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster_b, sh2);
     const ClusDesc *dd = (const ClusDesc *)d_desc;
     hipLaunchKernelGGL(k_similarity_b, dim3(nmax, nd), dim3(256), 0, st, *S, dd, Sm);
     hipLaunchKernelGGL(k_knn_sort_b, dim3(nmax, nd), dim3(256), sh, st, (const double *)Sm, dd, knn);
@@ -480,8 +476,8 @@ int pc_launch_knn_cluster_batch_dev(const PcState *S, const int *d_desc, int nd,
     while (npow2 < nmax) npow2 <<= 1;
     const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
     if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
-    (void)hipFuncSetAttribute((const void *)k_knn_sort_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    (void)hipFuncSetAttribute((const void *)k_nn_cluster_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+    pc_need_dyn_lds((const void *)k_knn_sort_b, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster_b, sh2);
     const ClusDesc *dd = (const ClusDesc *)d_desc;
     hipLaunchKernelGGL(k_similarity_b, dim3(nmax, nd), dim3(256), 0, st, *S, dd, Sm);
     hipLaunchKernelGGL(k_knn_sort_b, dim3(nmax, nd), dim3(256), sh, st, (const double *)Sm, dd, knn);
@@ -496,9 +492,8 @@ int pc_launch_knn_cluster_batch_many(const PcState *S, const PcManyRec *dR, int 
     while (npow2 < nmax) npow2 <<= 1;
     const size_t sh = (size_t)npow2 * 12, sh2 = (size_t)nmax * 12 + 64;
     if (sh > 160 * 1024 || sh2 > 150 * 1024) return 1;
-    static size_t d1 = 0, d2 = 0;
-    if (sh > d1) { (void)hipFuncSetAttribute((const void *)k_knn_sort_b_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d1 = sh; }
-    if (sh2 > d2) { (void)hipFuncSetAttribute((const void *)k_nn_cluster_b_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); d2 = sh2; }
+    pc_need_dyn_lds((const void *)k_knn_sort_b_many, sh);
+    pc_need_dyn_lds((const void *)k_nn_cluster_b_many, sh2);
     hipLaunchKernelGGL(k_similarity_b_many, dim3(nmax, nd_max, R), dim3(256), 0, st, dR);
     hipLaunchKernelGGL(k_knn_sort_b_many, dim3(nmax, nd_max, R), dim3(256), sh, st, dR);
     hipLaunchKernelGGL(k_nn_cluster_b_many, dim3(nd_max, R), dim3(1024), sh2, st, dR);
@@ -517,8 +512,7 @@ void pc_launch_ph_rehome(const PcState *S, int nph, int nc, const unsigned *old_
     if (nph > 0) {
         const int DP = S->D | 1;
         const size_t sh = sizeof(double) * ((size_t)(PHR_P + PHR_T) * DP + 256) + sizeof(int) * (PHR_T + 256 + PHR_P);
-        static size_t done = 0;
-        if (sh > done) { (void)hipFuncSetAttribute((const void *)k_ph_rehome, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+        pc_need_dyn_lds((const void *)k_ph_rehome, sh);
         hipLaunchKernelGGL(k_ph_rehome, dim3((nph + PHR_P - 1) / PHR_P), dim3(256), sh, st, *S, nph, nc, old_uids, nold_uids);
     }
     hipLaunchKernelGGL(k_ph_count, dim3(nc), dim3(256), 0, st, *S, nph, nc, counts);

@@ -464,15 +464,14 @@ static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int
     if (off || S->D > 32 || S->D < 1) return 1;
     int tile;
     const size_t sh = nn_lists_d_lds(S, tile);
-    static std::atomic<size_t> done1[33], donem[33];
     if (!S->nn_pts) return 1;
     if (dR) hipLaunchKernelGGL(k_nn_gather_many, dim3(((S->Ncap + nleft) * S->D + 255) / 256, R), dim3(256), 0, st, dR);
     else hipLaunchKernelGGL(k_nn_gather, dim3(((S->Ncap + nleft) * S->D + 255) / 256), dim3(256), 0, st, *S, nleft);
     switch (S->D) {
 #define PC_NND(n) case n: \
-        if (dR) { if (sh > donem[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d_many<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donem[n].store(sh); } \
+        if (dR) { pc_need_dyn_lds((const void *)k_nn_lists_d_many<n>, sh); \
                   hipLaunchKernelGGL(k_nn_lists_d_many<n>, dim3(nleft, R), dim3(256), sh, st, dR, tile, use_rank); } \
-        else { if (sh > done1[n].load()) { (void)hipFuncSetAttribute((const void *)k_nn_lists_d<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1[n].store(sh); } \
+        else { pc_need_dyn_lds((const void *)k_nn_lists_d<n>, sh); \
                hipLaunchKernelGGL(k_nn_lists_d<n>, dim3(nleft), dim3(256), sh, st, *S, nleft, tile, use_rank); } \
         return 0;
         PC_NND(1) PC_NND(2) PC_NND(3) PC_NND(4) PC_NND(5) PC_NND(6) PC_NND(7) PC_NND(8) PC_NND(9) PC_NND(10) PC_NND(11) PC_NND(12) PC_NND(13) PC_NND(14) PC_NND(15) PC_NND(16)
@@ -495,8 +494,7 @@ extern "C" void pc_launch_nn_lists(const PcState *S, int nleft, int use_rank, hi
     if (nn_lists_d_dispatch(S, nullptr, 0, nleft, use_rank, st) == 0) return;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
-    static size_t done = 0;
-    if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    pc_need_dyn_lds((const void *)k_nn_lists, sh);
     hipLaunchKernelGGL(k_nn_lists, dim3(nleft), dim3(256), sh, st, *S, nleft, tile);
 }
 extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, int R, int nleft_max, int use_rank, hipStream_t st)
@@ -505,8 +503,7 @@ extern "C" int pc_launch_nn_lists_many(const PcState *S, const PcManyRec *dR, in
     if (nn_lists_d_dispatch(S, dR, R, nleft_max, use_rank, st) == 0) return 0;
     int tile;
     const size_t sh = nn_lists_lds(S, tile);
-    static size_t done = 0;
-    if (sh > done) { (void)hipFuncSetAttribute((const void *)k_nn_lists_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done = sh; }
+    pc_need_dyn_lds((const void *)k_nn_lists_many, sh);
     hipLaunchKernelGGL(k_nn_lists_many, dim3(nleft_max, R), dim3(256), sh, st, dR, tile);
     return 0;
 }
@@ -1973,8 +1970,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
             while (xq_n > 8 && consume_lds(S, NTV, cache_x, xq_n, sgl) > 158 * 1024) xq_n -= 8; \
             const size_t sh = consume_lds(S, NTV, cache_x, xq_n, sgl); \
             if (sh > 160 * 1024) return 1; \
-            static size_t done_ = 0; \
-            if (sh > done_) { hipFuncSetAttribute((const void *)k_consume<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done_ = sh; } \
+            pc_need_dyn_lds((const void *)k_consume<NTV>, sh); \
             hipLaunchKernelGGL((k_consume<NTV>), dim3(1), dim3(NTV), sh, st, *S, final_mode, cache_x, xq_n, sgl); \
             return 0; }
         if (wide_nt == 64) PC_CONSUME_LAUNCH(64)
@@ -1990,8 +1986,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         while (cache_x > 32 && consume_lds(S, 1024, cache_x, 0, sgl) > 158 * 1024) cache_x = (cache_x + 1) / 2;
         const size_t sh = consume_lds(S, 1024, cache_x, 0, sgl);
         if (sh > 160 * 1024) return 1;
-        static size_t done1024 = 0;
-        if (sh > done1024) { hipFuncSetAttribute((const void *)k_consume<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done1024 = sh; }
+        pc_need_dyn_lds((const void *)k_consume<1024>, sh);
         hipLaunchKernelGGL((k_consume<1024>), dim3(1), dim3(1024), sh, st, *S, final_mode, cache_x, 0, sgl);
     } else {
         const int sgl = consume_slots_global(S, 64);
@@ -1999,8 +1994,7 @@ extern "C" int pc_launch_consume(const PcState *S, int final_mode, int wide, hip
         while (xr > 32 && consume_lds(S, 64, xr, 0, sgl) > 158 * 1024) xr = (xr + 1) / 2;
         const size_t sh = consume_lds(S, 64, xr, 0, sgl);
         if (sh > 160 * 1024) return 1;
-        static size_t done64 = 0;
-        if (sh > done64) { hipFuncSetAttribute((const void *)k_consume<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); done64 = sh; }
+        pc_need_dyn_lds((const void *)k_consume<64>, sh);
         hipLaunchKernelGGL((k_consume<64>), dim3(1), dim3(64), sh, st, *S, final_mode, xr, 0, sgl);
     }
     return 0;
@@ -2093,8 +2087,7 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     const int TS = cov_tile_stride(S);
     const size_t sh = sizeof(double) * ((size_t)CR * TS + D + 256) + sizeof(int) * CR;
     if (sh > 160 * 1024) return 1;
-    static size_t donep = 0;
-    if (sh > donep) { hipFuncSetAttribute((const void *)k_cov_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); donep = sh; }
+    pc_need_dyn_lds((const void *)k_cov_partial, sh);
     int ncov = nred;                                             // partial matrices the Cholesky kernel adds up
     if (cov_use_mfma(S)) {
         // persistent workgroups (one per CU at nDims = 100), each walks its share of the chunks and writes one partial matrix
@@ -2109,8 +2102,7 @@ extern "C" int pc_launch_covmats(const PcState *S, int nph, int nc, double *psum
     int a_global = 0;
     if (sh2 > 160 * 1024) { a_global = 1; sh2 = sizeof(double) * ((size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT)); }
     if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
-    static size_t donec = 0;
-    if (sh2 > donec) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec = sh2; }
+    pc_need_dyn_lds((const void *)k_cov_final_chol, sh2);
     hipLaunchKernelGGL(k_cov_final_chol, dim3(nc), dim3(PC_CHOL_NT), sh2, st, *S, ncov, pcov, count, a_global, 0);
     return 0;
 }
@@ -2221,14 +2213,13 @@ extern "C" void pc_launch_chol_only(const PcState *S, const double *ncov, const 
     int a_global = 0;
     if (sh2 > 160 * 1024) { a_global = 1; sh2 = sizeof(double) * ((size_t)D * D + ((size_t)D * D >= PC_CHOL_NT ? 0 : PC_CHOL_NT)); }
     if (sh2 > 160 * 1024) { a_global = 2; sh2 = sizeof(double) * PC_CHOL_NT; }
-    static size_t donec1 = 0;
-    if (sh2 > donec1) { hipFuncSetAttribute((const void *)k_cov_final_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2); donec1 = sh2; }
+    pc_need_dyn_lds((const void *)k_cov_final_chol, sh2);
     static const bool blocked_off = std::getenv("PC_CHOL_BLOCKED_OFF") != nullptr;
     int guard = 0;
     if (!blocked_off && D >= 32 && D <= 128) {
         const int nt = (D + 15) / 16;
         const size_t shb = sizeof(double) * (size_t)(16 * nt) * (16 * nt + 1);
-#define PC_CHOLB(NT) { static bool done_ = false; if (!done_) { (void)hipFuncSetAttribute((const void *)k_chol_blocked<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb); done_ = true; } \
+#define PC_CHOLB(NT) { pc_need_dyn_lds((const void *)k_chol_blocked<NT>, shb); \
             hipLaunchKernelGGL((k_chol_blocked<NT>), dim3(1), dim3(256), shb, st, *S, ncov, count); }
         switch (nt) { case 2: PC_CHOLB(2) break; case 3: PC_CHOLB(3) break; case 4: PC_CHOLB(4) break; case 5: PC_CHOLB(5) break;
                       case 6: PC_CHOLB(6) break; case 7: PC_CHOLB(7) break; default: PC_CHOLB(8) break; }

@@ -26,6 +26,8 @@
 #include <functional>
 #include <exception>
 #include <ucontext.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
@@ -414,12 +416,26 @@ static double h_uniform(uint32_t k0, uint32_t k1, uint32_t dom, uint32_t shi, ui
 //      wrote down ONCE for all of them, waits ONCE, and resumes them.  The waits of sixteen runs' updates cost what one run's do,
 //      and the kernels between two waits are launched together.  (makecontext / swapcontext: no threads, no locks; an
 //      exception inside a fiber is caught at its foot and rethrown by the driver.)
+struct FiberCancelled {};      // thrown inside a suspended fiber that is resumed only to unwind (another run's update failed)
 struct Fiber {
     ucontext_t ctx, ret;
-    void *stack = nullptr; size_t stack_sz = 0;
+    void *stack = nullptr; size_t stack_sz = 0;      // usable part; one PROT_NONE page below it (stacks grow down): an overflow faults
+    void *map = nullptr; size_t map_sz = 0;          // instead of running into the heap
     std::function<void()> fn;
-    bool started = false, done = false;
+    bool started = false, done = false, cancel = false;
     std::exception_ptr err;
+    // round_finish with clustering goes deep (update, kNN passes, add_cluster, the resume file's writer, HIP runtime calls): 8 MB of
+    // address space, committed as touched
+    void make_stack()
+    {
+        if (stack) return;
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE), want = (size_t)8 << 20;
+        void *m = mmap(nullptr, want + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        (void)mprotect(m, page, PROT_NONE);
+        map = m; map_sz = want + page; stack = (char *)m + page; stack_sz = want;
+    }
+    void free_stack() { if (map) munmap(map, map_sz); map = stack = nullptr; map_sz = stack_sz = 0; }
     static void foot(unsigned lo, unsigned hi)
     {
         Fiber *f = (Fiber *)(((uintptr_t)hi << 32) | (uintptr_t)lo);
@@ -745,6 +761,8 @@ struct Engine {
         const int nprior = c.nprior <= 0 ? c.nlive : c.nprior;
         S.Ncap = std::max(nmax, nprior);
         B = c.batch > 0 ? c.batch : std::max(1, std::min(1024, c.nlive / 2));
+        // (the contraction kernels stamp the nursery position into 16 bits of the host mirror, pc_state.h pc_note: never truncate silently)
+        if (B > 65535) engine_fail(PC_RC_LIMIT, "batch = %d chains per nursery: at most 65535", B);
         if (c.sequential_rng) B = 1;
         // Host callbacks: every chain of a nursery is seeded from one snapshot, so about B / (2 nlive) of the evaluations
         // are spent on spawns that fail -- cheap for a compiled likelihood (then the round trips per nursery dominate and
@@ -902,7 +920,17 @@ struct Engine {
     //      which launches what all runs have written down, waits once for all of them and resumes them (pc_run_cohort)
     void sync_point()
     {
-        if (fib) { fib->yield(); return; }
+        if (fib) {
+            fib->yield();
+            if (fib->cancel) {      // resumed to unwind: give back what this wait was for, then out through the frames of round_finish
+                for (const Fetch &f : fetching) hfree(f.h);
+                fetching.clear();
+                for (void *h : staged_up) hfree(h);
+                staged_up.clear();
+                throw FiberCancelled{};
+            }
+            return;
+        }
         if (co) co->flush();
         // (polling the stream wakes the host a few microseconds after the copy; the blocking wait sleeps on an interrupt)
         for (int spins = 0; spins < 200000; ++spins) { const hipError_t q = hipStreamQuery(st); if (q != hipErrorNotReady) { HIPCHK(q); break; } __builtin_ia32_pause(); }
@@ -2488,7 +2516,7 @@ struct Engine {
         out->logZ = std::max(-PC_HUGE, 2 * h_ctl->logZ - 0.5 * h_ctl->logZ2);
         out->varlogZ = h_ctl->logZ2 - 2 * h_ctl->logZ;
         out->ndead = h_ctl->ndead; out->nlike = h_ctl->nlike; out->niter = h_ctl->niter;
-        out->nlike_failed = h_ctl->nlike_failed; out->ncluster_peak = ncluster_peak;
+        out->nlike_failed = h_ctl->nlike_failed; out->ncluster_peak = ncluster_peak; out->epoch_discard = S.epoch_discard;
         grade_counts(out->nlike_grade);
         out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
@@ -2849,8 +2877,8 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                       std::vector<char> ok(wk.size(), 1);
                       for (size_t a = 0; a < wk.size(); ++a) {
                           Fiber &f = fibs[a];
-                          if (!f.stack) { f.stack_sz = (size_t)1 << 20; f.stack = std::malloc(f.stack_sz); if (!f.stack) throw std::bad_alloc(); }
-                          f.started = false; f.done = false; f.err = nullptr;
+                          f.make_stack();
+                          f.started = false; f.done = false; f.cancel = false; f.err = nullptr;
                           Engine *e = E[wk[a]]; char *okp = &ok[a];
                           f.fn = [e, okp] { *okp = e->round_finish() ? 1 : 0; };
                           e->fib = &f;
@@ -2873,8 +2901,18 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                           HIPCHK(hipStreamSynchronize(co.st));
                           t_fwait += secc(w0, nowc()); n_fwait++;
                       }
+                      if (first_err) {
+                          // the fibers still suspended hold locals, pinned blocks and copies written down for a flush that will not come: what
+                          // they wrote down is dropped, and each is resumed once more with the cancel flag -- its wait throws, its frames unwind
+                          co.pre.clear(); co.post.clear(); co.pend.clear();
+                          for (size_t a = 0; a < wk.size(); ++a) {
+                              Fiber &f = fibs[a];
+                              if (f.started && !f.done) { f.cancel = true; f.resume(); }
+                          }
+                          co.pre.clear(); co.post.clear(); co.pend.clear();
+                      }
                       for (size_t a = 0; a < wk.size(); ++a) { E[wk[a]]->fib = nullptr; if (!ok[a]) enq[wk[a]] = 0; }
-                      if (first_err) std::rethrow_exception(first_err);      // (the fibers still suspended are dropped with their stacks)
+                      if (first_err) std::rethrow_exception(first_err);
                   }
                   const auto a1 = nowc(); t_fin += secc(a0, a1);
                   co.flush(); t_fl += secc(a1, nowc()); }
@@ -2956,7 +2994,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: trips to the driver: %lld device blocks (%.2f ms), %lld pinned blocks (%.2f ms), %lld streams (%.2f ms)\n", g_dbg_miss_n[0].exchange(0), g_dbg_miss_ns[0].exchange(0) * 1e-6, g_dbg_miss_n[1].exchange(0), g_dbg_miss_ns[1].exchange(0) * 1e-6, g_dbg_mk_stream_n.exchange(0), g_dbg_mk_stream_ns.exchange(0) * 1e-6);
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: %d runs, %ld rounds, streams %.2f ms, wall %.2f ms (setup + begin %.2f, compactions %.2f in %d passes, enqueue %.2f, finish %.2f, launches %.2f, waiting for the device %.2f, the endings' requests %.2f, waiting for the endings %.2f); %ld records launched together, %ld one by one\n", n, rounds, std::chrono::duration<double>(T0 - Tpre).count() * 1e3,
                                std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3, t_begin * 1e3, t_comp * 1e3, n_comp_pass, t_enq * 1e3, t_fin * 1e3, t_fl * 1e3, t_wait * 1e3, t_end_dev * 1e3, t_end * 1e3, co.n_fused, co.n_single);
-        for (Fiber &f : fibs) { std::free(f.stack); f.stack = nullptr; }
+        for (Fiber &f : fibs) f.free_stack();
         if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: of finish: %ld shared waits, %.2f ms\n", n_fwait, t_fwait * 1e3);
         co.destroy();
         if (h_totals) hfree(h_totals);

@@ -469,8 +469,7 @@ extern "C" int pc_launch_sort_live(const PcState *S, hipStream_t st)
     while (npow2 < S->Ncap) npow2 <<= 1;
     const size_t shs = (size_t)npow2 * 16;
     if (shs > 160 * 1024) return 1;
-    static size_t d1 = 0;
-    if (shs > d1) { (void)hipFuncSetAttribute((const void *)k_sort_live, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs); d1 = shs; }
+    pc_need_dyn_lds((const void *)k_sort_live, shs);
     hipLaunchKernelGGL(k_sort_live, dim3(1), dim3(1024), shs, st, *S, npow2);
     return 0;
 }
@@ -481,8 +480,7 @@ extern "C" int pc_launch_sort_live_many(const PcState *S, const PcManyRec *dR, i
     while (npow2 < S->Ncap) npow2 <<= 1;
     const size_t shs = (size_t)npow2 * 16;
     if (shs > 160 * 1024) return 1;
-    static size_t d1 = 0;
-    if (shs > d1) { (void)hipFuncSetAttribute((const void *)k_sort_live_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs); d1 = shs; }
+    pc_need_dyn_lds((const void *)k_sort_live_many, shs);
     hipLaunchKernelGGL(k_sort_live_many, dim3(1, R), dim3(1024), shs, st, dR, npow2);
     return 0;
 }
@@ -491,8 +489,7 @@ extern "C" int pc_launch_consume_fast(const PcState *S, int final_mode, hipStrea
 {
     const size_t sh = fast_lds(S);
     if (sh > 160 * 1024) return 1;
-    static size_t d2 = 0;
-    if (sh > d2) { (void)hipFuncSetAttribute((const void *)k_consume_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d2 = sh; }
+    pc_need_dyn_lds((const void *)k_consume_fast, sh);
     if (pc_launch_sort_live(S, st)) return 1;
     hipLaunchKernelGGL(k_consume_fast, dim3(1), dim3(64), sh, st, *S, final_mode);
     return 0;

@@ -571,7 +571,7 @@ int pchip_merge_records_ex(int nDims, int nDerived, int nruns, const long *count
     hipStream_t st = nullptr;
     DevBuf B;
     auto fail = [&](const char *what) { std::fprintf(stderr, "polychord_hip: merge: %s (%s)\n", what, hipGetErrorString(hipGetLastError())); pchip_merged_free(out); return 7; };
-    // which evidence the union quotes: a run that ended with more than one cluster (alive or dead) weighed its dead points by its
+    // which evidence the union quotes: a run that held more than one cluster at some time (pchip_result.ncluster_peak > 1) weighed its dead points by its
     // clusters' volumes, which a replay of the union from ranks and live counts does not know (10-D Rastrigin, dozens of clusters: the
     // replay sits 0.46 below the runs' own log Z, twenty of its own error bars) -- then the runs' own evidences and weights are used
     int nclustered = 0;
@@ -780,7 +780,7 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
         if (rc == 0) {
             std::vector<double> lz((size_t)nseeds), vz((size_t)nseeds);
             std::vector<int> cl((size_t)nseeds);
-            for (int k = 0; k < nseeds; ++k) { lz[(size_t)k] = results[k].logZ; vz[(size_t)k] = results[k].varlogZ; cl[(size_t)k] = results[k].ncluster + results[k].ncluster_dead > 1; }
+            for (int k = 0; k < nseeds; ++k) { lz[(size_t)k] = results[k].logZ; vz[(size_t)k] = results[k].varlogZ; cl[(size_t)k] = results[k].ncluster_peak > 1; }
             rc = pchip_merge_records_ex(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, ownw_all, lz.data(), vz.data(), cl.data(), 1, 1, merged);
         }
         else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
@@ -840,7 +840,7 @@ int pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, int
     return pchip_comm_merge_many(c, run, 1, logzero, nDims, nDerived, want_rows, out);
 }
 
-// words a rank sends about each of its runs ahead of the records: count, nlike, ndead, log Z, var log Z, ended with clusters?
+// words a rank sends about each of its runs ahead of the records: count, nlike, ndead, log Z, var log Z, did it ever hold several clusters?
 #define META_W 6
 
 int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, double logzero, int nDims, int nDerived, int want_rows,
@@ -904,7 +904,7 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
         const double z = runs[j].logZ, v = runs[j].varlogZ;
         m[0] = J[(size_t)j].count; m[1] = runs[j].nlike; m[2] = runs[j].ndead;
         std::memcpy(&m[3], &z, sizeof z); std::memcpy(&m[4], &v, sizeof v);
-        m[5] = runs[j].ncluster + runs[j].ncluster_dead > 1;
+        m[5] = runs[j].ncluster_peak > 1;
     }
     if (coll) {
         long long *d_meta = B.get<long long>((size_t)META_W * nr_max * (R + 1));

@@ -882,8 +882,7 @@ extern "C" int pc_launch_consume_par(const PcState *S, hipStream_t st)
 {
     const size_t sh = par_lds(S);
     if (sh + PAR_STATIC_LDS > 160 * 1024 || S->B > PAR_NT) return 1;
-    static size_t d = 0;
-    if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
+    pc_need_dyn_lds((const void *)k_consume_par, sh);
     hipLaunchKernelGGL(k_consume_par, dim3(1), dim3(PAR_NT), sh, st, *S);
     return 0;
 }
@@ -893,8 +892,7 @@ extern "C" int pc_launch_consume_par_many(const PcState *S, const PcManyRec *dR,
 {
     const size_t sh = par_lds(S);
     if (sh + PAR_STATIC_LDS > 160 * 1024 || S->B > PAR_NT) return 1;
-    static size_t d = 0;
-    if (sh > d) { (void)hipFuncSetAttribute((const void *)k_consume_par_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); d = sh; }
+    pc_need_dyn_lds((const void *)k_consume_par_many, sh);
     hipLaunchKernelGGL(k_consume_par_many, dim3(1, R), dim3(PAR_NT), sh, st, dR);
     return 0;
 }

@@ -1207,8 +1207,7 @@ extern "C" int pc_launch_nhats(const PcState *S, unsigned batch, int nchains, hi
         else if (D <= 64) hipLaunchKernelGGL((k_nhats_q<16>), grid, dim3(256), lds_q(16), st, *S, batch);
         else if (D <= 128) {
             const size_t shq = pc_nhats_q32_lds(D);
-            static size_t doneq = 0;
-            if (shq > doneq) { (void)hipFuncSetAttribute((const void *)k_nhats_q<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shq); doneq = shq; }
+            pc_need_dyn_lds((const void *)k_nhats_q<32>, shq);
             hipLaunchKernelGGL((k_nhats_q<32>), grid, dim3(512), shq, st, *S, batch);
         }
         else if (D <= 256 && S->nhat_raw) hipLaunchKernelGGL(k_nhats_big, grid, dim3(PC_BIG_NT), 0, st, *S, batch);
@@ -1253,14 +1252,14 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     const bool lean = !lean_off && S->like.kind == PC_LIKE_GAUSSIAN && !(S->ablate & 1) && phi_lds && S->nr <= 64 && !S->seq_mode && S->ngrade <= 1;
     const int leanf = slice_lean_functor(S);
 #define PC_SLICE_FUSED_L(NROWS, FW, LN) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, LN>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
 #define PC_SLICE_FUSED(NROWS, FW) { \
         if (leanf == 3) PC_SLICE_FUSED_L(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_L(NROWS, FW, 4) else \
         if (lean) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, 1>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<1, NROWS, false, 1, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } }
     if (D <= 8) PC_SLICE_FUSED(1, 8)
     else if (D <= 16) PC_SLICE_FUSED(1, 16)
@@ -1286,7 +1285,7 @@ extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R
         if (sh > 150 * 1024) return 1;
         const int leanf = slice_lean_functor(S);
 #define PC_SLICE_FUSED_ML(NROWS, FW, LN) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<1, NROWS, false, 1, FW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice_many<1, NROWS, false, 1, FW, LN>, sh); \
         hipLaunchKernelGGL((k_slice_many<1, NROWS, false, 1, FW, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
 #define PC_SLICE_FUSED_M(NROWS, FW) { if (leanf == 3) PC_SLICE_FUSED_ML(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_ML(NROWS, FW, 4) else PC_SLICE_FUSED_ML(NROWS, FW, 0) }
         if (D <= 8) PC_SLICE_FUSED_M(1, 8)
@@ -1300,7 +1299,7 @@ extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R
     const size_t sh = sh0 + (phi_lds ? tb : 0);
     const int leanf = slice_lean_functor(S);
 #define PC_SLICE_ML(DPL, NROWS, LN) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice_many<DPL, NROWS, false, 1, 0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice_many<DPL, NROWS, false, 1, 0, LN>, sh); \
         hipLaunchKernelGGL((k_slice_many<DPL, NROWS, false, 1, 0, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
 #define PC_SLICE_M(DPL, NROWS) { if (leanf == 3) PC_SLICE_ML(DPL, NROWS, 3) else if (leanf == 4) PC_SLICE_ML(DPL, NROWS, 4) else PC_SLICE_ML(DPL, NROWS, 0) }
     if (D <= 16) PC_SLICE_M(1, 1)
@@ -1338,7 +1337,7 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     static const bool wpb_off = std::getenv("PC_SLICE_WPB_OFF") != nullptr;
     if (mat_lds && D > 64 && D <= 128 && nchains % 4 == 0 && S->ngrade <= 1 && !S->seq_mode && !wpb_off && 4 * sh + mb <= 150 * 1024) {
         const size_t sh4 = 4 * sh + mb;
-        if (sh4 > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<2, 4, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+        if (sh4 > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<2, 4, false, 4>, sh4);
         hipLaunchKernelGGL((k_slice<2, 4, false, 4>), dim3(nchains / 4), dim3(256), sh4, st, *S, batch, phi_lds, mat_lds);
         return 0;
     }
@@ -1347,16 +1346,16 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
     if (!lean2_off && S->like.kind == PC_LIKE_CORR_GAUSSIAN && S->nhat_Ms != nullptr && !(S->ablate & 1) && S->nDer == 0 && S->nr > 64 && D > 64 && D <= 128 &&
         S->ngrade <= 1 && !S->seq_mode && !mat_lds) {
         // BASELINE configs[4]'s shape: the kernel without its other variants (LEAN = 2)
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<2, 4, false, 1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<2, 4, false, 1, 0, 2>, sh);
         hipLaunchKernelGGL((k_slice<2, 4, false, 1, 0, 2>), dim3(nchains), dim3(64), sh, st, *S, batch, 0, 0);
         return 0;
     }
 #define PC_SLICE_LAUNCH1(DPL, NROWS, GR) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<DPL, NROWS, GR>, sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, GR>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
     const int leanf = (D <= 64 && !mat_lds) ? slice_lean_functor(S) : 0;
 #define PC_SLICE_LAUNCHL(DPL, NROWS, LN) { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_slice<DPL, NROWS, false, 1, 0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<DPL, NROWS, false, 1, 0, LN>, sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, false, 1, 0, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
 #define PC_SLICE_LAUNCH(DPL, NROWS) { if (DPL == 1 && leanf == 3) PC_SLICE_LAUNCHL(1, NROWS, 3) else if (DPL == 1 && leanf == 4) PC_SLICE_LAUNCHL(1, NROWS, 4) else \
         if (S->ngrade > 1 || S->seq_mode) PC_SLICE_LAUNCH1(DPL, NROWS, true) else PC_SLICE_LAUNCH1(DPL, NROWS, false) }

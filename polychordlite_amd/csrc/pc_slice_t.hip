@@ -493,14 +493,14 @@ static void launch_t(const PcState *S, const PcManyRec *dR, int R, unsigned batc
     static const long long help_env = std::getenv("PC_SLICE_T_HELP_MAX") ? std::atoll(std::getenv("PC_SLICE_T_HELP_MAX")) : -1;
     const long long help_max = help_env >= 0 ? help_env : 256LL * std::max<long long>(1, std::min<long long>(2, (long long)(156 * 1024) / (long long)shh));
     if (dR && !help_off && shh <= 64 * 1024 && (long long)grid * R <= help_max) {      // runs in step: a second wavefront per 64 chains works a slice ahead
-        if (shh > 48 * 1024) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shh); }
+        if (shh > 48 * 1024) { if (unit) pc_need_dyn_lds((const void *)k_slice_t_many<DT, true, true>, shh); else pc_need_dyn_lds((const void *)k_slice_t_many<DT, false, true>, shh); }
         if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, true>), dim3(grid, R), dim3(192), shh, st, dR, nchains, nrp);
         else hipLaunchKernelGGL((k_slice_t_many<DT, false, true>), dim3(grid, R), dim3(192), shh, st, dR, nchains, nrp);
         return;
     }
     if (sh > 48 * 1024) {                                         // (long decks and wide records: pc_slice_t_ok keeps it under 64 KB)
-        if (dR) { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t_many<DT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
-        else { if (unit) (void)hipFuncSetAttribute((const void *)k_slice_t<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); else (void)hipFuncSetAttribute((const void *)k_slice_t<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
+        if (dR) { if (unit) pc_need_dyn_lds((const void *)k_slice_t_many<DT, true, false>, sh); else pc_need_dyn_lds((const void *)k_slice_t_many<DT, false, false>, sh); }
+        else { if (unit) pc_need_dyn_lds((const void *)k_slice_t<DT, true>, sh); else pc_need_dyn_lds((const void *)k_slice_t<DT, false>, sh); }
     }
     if (dR) {
         if (unit) hipLaunchKernelGGL((k_slice_t_many<DT, true, false>), dim3(grid, R), dim3(64), sh, st, dR, nchains, nrp);

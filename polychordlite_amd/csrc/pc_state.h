@@ -164,8 +164,8 @@ struct PcState {
                                  // scans only (no linear-space path); bit 5 = several clusters: the general contraction kernel for every launch (not
                                  // the one-wave kernel of pc_clus.hip); bit 30 = trace of Cholesky fallbacks
     int seq_mode;                // tests: ONE running Philox stream consumed in the reference's program order
-    int epoch_discard;           // 1: nested_sampling.F90:313 as written (a change of the cluster list loses every chain in flight); 0: only the ended cluster's
                                  // (B = 1 only; PcCtl::seq is the position), cf. oracle `sequential` mode
+    int epoch_discard;           // 1: nested_sampling.F90:313 as written (a change of the cluster list loses every chain in flight); 0: only the ended cluster's
     int seed_override;           // test hook: chain c starts from slot c instead of a random seed
     int spec_guard;              // k_slice: enqueued ahead of the host's decision -- return unless ctl->spec_ok names this nursery
     PcCtl *ctl;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void pc_publish_ctl(const PcState &S)
         const PcCtl *c = S.ctl;
         pc_note_sh[0] = (unsigned)c->status | ((unsigned)c->error << 8) | ((unsigned)(c->cluster_deleted != 0) << 16) |
                         ((unsigned)(c->upd_pending != 0) << 17) | ((unsigned)(c->upd_marks > 0x3FFF ? 0x3FFF : c->upd_marks) << 18);   // (a launch consumes <= 1024 chains: <= 1024 marks)
-        pc_note_sh[1] = ((unsigned)c->i_nursery & 0xFFFFu) | ((unsigned)(c->upd_in < 0 ? 0 : (c->upd_in > 0xFFFF ? 0xFFFF : c->upd_in)) << 16);   // (a nursery holds <= 1024 chains)
+        pc_note_sh[1] = ((unsigned)c->i_nursery & 0xFFFFu) | ((unsigned)(c->upd_in < 0 ? 0 : (c->upd_in > 0xFFFF ? 0xFFFF : c->upd_in)) << 16);   // (a nursery holds <= 65535 chains: Engine::setup refuses a larger batch)
         pc_note_sh[2] = (unsigned)c->ndead; pc_note_sh[3] = (unsigned)c->nphantom;
         pc_note_sh[4] = (unsigned)c->ncluster | ((unsigned)(c->ncluster_dead & 0xFFFF) << 16);   // (ncluster <= 16384: Engine::grow_clusters; the full dead count comes with the block)
     }
@@ -234,3 +234,27 @@ __device__ __forceinline__ double pc_seq_uniform(const PcState &S, unsigned long
 {
     return pc_uniform(S.k0, S.k1, PC_DOM_SEQ, (uint32_t)(n >> 32), 0u, (uint32_t)n);
 }
+// ---- host side: dynamic LDS beyond the default limit.  hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE) and
+// only ever has to grow.  Launch helpers are called from several host threads (the scheduler groups of pchip_run_repeats, runs on several
+// devices): a guard that is a plain function-local static races (one thread lowers the limit between another's check and its launch, and a
+// mark set for one device hides the need on the next).  One mutex, one high-water mark per (kernel, device); never lowered.
+#include <mutex>
+#include <map>
+#include <utility>
+inline void pc_need_dyn_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mtx;
+    static std::map<std::pair<const void *, int>, size_t> mark;
+    thread_local std::map<std::pair<const void *, int>, size_t> seen;      // what this thread knows to be set already (marks only grow)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(kernel, dev);
+    size_t &mine = seen[key];
+    if (bytes <= mine) return;
+    std::lock_guard<std::mutex> g(mtx);
+    size_t &m = mark[key];
+    if (bytes > m) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); m = bytes; }
+    mine = m;
+}
+
+

@@ -650,9 +650,8 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     }
     int devi = 0; (void)hipGetDevice(&devi); devi &= 63;
 #define UPDG_LAUNCH(NT) { \
-        static std::atomic<size_t> done_##NT[64];      /* largest size asked for so far, per device (shw grows with D inside one NT) */ \
-        if (shw > done_##NT[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); \
-                          (void)hipFuncSetAttribute((const void *)k_upd_gather<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); done_##NT[devi].store(shw); } \
+        pc_need_dyn_lds((const void *)k_upd_gather<NT, false>, shw); \
+                          pc_need_dyn_lds((const void *)k_upd_gather<NT, true>, shw); \
         /* pool mode: the alternate id buffer is free between compactions and holds the index list, *d_total its length */ \
         if (S->pool) hipLaunchKernelGGL((k_upd_gather<NT, true>), dim3(G), dim3(256), shw, st, *S, nph, nblk, (const unsigned char *)keep, (const int *)blk, \
                            ph2, phL2, phC2, phU2, (const int *)phC2, (const int *)d_total, (const double *)shift, part, E, deferred, nlb, ndb); \
@@ -667,8 +666,7 @@ extern "C" void pc_launch_update_fused(const PcState *S, int nph, unsigned char 
     double *ncov = part2 + (size_t)ng * E;
     int *count = (int *)(ncov + (size_t)D * D);
     const size_t shf = sizeof(double) * (size_t)(D * (D + 1) / 2 + D + 1);
-    static std::atomic<size_t> donef[64];
-    if (shf > donef[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_final_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shf); donef[devi].store(shf); }
+    pc_need_dyn_lds((const void *)k_upd_final_w, shf);
     hipLaunchKernelGGL(k_upd_final_w, dim3(1), dim3(1024), shf, st, *S, ng, (const double *)part2, E, shift, deferred, ncov, count);
     pc_launch_chol_only(S, ncov, count, st);
 }
@@ -690,8 +688,7 @@ extern "C" int pc_launch_update_fused_many(const PcState *S, const PcManyRec *dR
     hipLaunchKernelGGL(k_upd_index_self_many, dim3((nblk_max + 15) / 16, R), dim3(UPD_IDX_NT), 0, st, dR);
     int devi = 0; (void)hipGetDevice(&devi); devi &= 63;
 #define UPDM_LAUNCH(NT) { \
-        static std::atomic<size_t> donem_##NT[64]; \
-        if (shw > donem_##NT[devi].load()) { (void)hipFuncSetAttribute((const void *)k_upd_gather_many<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw); donem_##NT[devi].store(shw); } \
+        pc_need_dyn_lds((const void *)k_upd_gather_many<NT>, shw); \
         hipLaunchKernelGGL((k_upd_gather_many<NT>), dim3(G, R), dim3(256), shw, st, dR, E, deferred, nlb, ndb); }
     if (NTv == 1) UPDM_LAUNCH(1) else UPDM_LAUNCH(2)
 #undef UPDM_LAUNCH

@@ -13,7 +13,7 @@ def _declared():
             continue
         src = open(os.path.join(ROOT, "include", fn)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        for m in re.finditer(r"^\s*(?:void|int|double)\s+\*?\s*((?:polychord|pchip)_\w+)\s*\(", src, flags=re.M):
+        for m in re.finditer(r"^\s*(?:void|int|double|unsigned long|const char)\s+\*?\s*((?:polychord|pchip)_\w+)\s*\(", src, flags=re.M):
             names.add(m.group(1))
     return names
 
@@ -25,6 +25,19 @@ def test_library_exports_declared_symbols():
     assert {"polychord_c_interface", "polychord_c_interface_ini", "pchip_run", "pchip_slice_chains"} <= names
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+
+
+def test_bindings_check_themselves_against_the_library():
+    """the structs grow at their end from round to round: the ctypes mirrors are held against pchip_sizeof at load time (a stale mirror of
+    pchip_merged read garbage for the fields behind its end), and the header's version is the library's"""
+    from polychordlite_amd import _ctypes_api as api
+    from polychordlite_amd import merge as mg
+    lib = mg._lib()
+    src = open(os.path.join(ROOT, "include", "polychord_hip.h")).read()
+    assert lib.pchip_abi_version() == int(re.search(r"#define PCHIP_ABI_VERSION (\d+)", src).group(1))
+    for name, cls in (("settings", api.Settings), ("result", api.Result), ("like", api.Like), ("prior", api.Prior), ("merged", mg.Merged)):
+        assert lib.pchip_sizeof(name.encode()) == C.sizeof(cls) > 0, name
+    assert lib.pchip_sizeof(b"no such struct") == 0 and lib.pchip_sizeof(b"update") > 0
 
 
 def test_reference_boundary_signature_has_38_args():

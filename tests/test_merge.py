@@ -94,7 +94,8 @@ g2 = g2.numpy()
 assert ks2 == ks and np.array_equal(g2[:, :-1], g) and len(ev) == world
 own = np.concatenate([x["logweights"][x["logweights"] > -1e29] for x in runs])
 assert np.array_equal(g2[:, -1], own)
-assert ev == [(float(x["logZ"]), float(x["varlogZ"]), int(x["ncluster"] + x["ncluster_dead"] > 1)) for x in runs], ev
+from polychordlite_amd.merge import clustered
+assert ev == [(float(x["logZ"]), float(x["varlogZ"]), clustered(x)) for x in runs] and not any(e[2] for e in ev), ev
 if rank == 0:
     print("GATHER_OK", ks, m["logZ"], m["post_mean"][:2])
 dist.barrier(); dist.destroy_process_group()
@@ -238,12 +239,12 @@ def test_union_of_clustered_runs_quotes_the_runs_own_evidence(engine, tmp_path):
     x = merged["rows"][:, D:2 * D]
     mean = (w[:, None] * x).sum(0) / w.sum()
     assert np.allclose(merged["post_mean"], mean, atol=1e-11) and np.allclose(merged["post_var"], (w[:, None] * x * x).sum(0) / w.sum() - mean ** 2, atol=1e-11)
-    assert np.all(np.abs(merged["post_mean"]) < 0.35)             # Rastrigin: symmetric about 0
+    assert np.all(np.abs(merged["post_mean"]) < 1.0)              # Rastrigin: symmetric about 0, modes one unit apart
     # the files: PolyChordOutput reads the quoted evidence, the file says which it is and keeps the replay
     out = PolyChordOutput(str(tmp_path), "u")
     assert abs(out.logZ - merged["logZ"]) < 1e-12 and abs(out.logZerr - merged["logZerr"]) < 1e-12
     txt = open(tmp_path / "u.stats").read()
-    assert "evidence rule 1" in txt and "replay of the union" in txt and ("%d of the runs" % merged["nclustered"]) in txt
+    assert "evidence rule 1" in txt and "replay of the union" in txt and ("%d of the runs held" % merged["nclustered"]) in txt
     post = np.loadtxt(tmp_path / "u.txt")
     assert np.allclose((post[:, 0][:, None] * post[:, 2:2 + D]).sum(0) / post[:, 0].sum(), merged["post_mean"], atol=1e-9)
     # the same union through the records interface (what a gloo / MPI transport feeds): identical
@@ -543,3 +544,27 @@ def test_a_failing_run_ends_the_runs_in_step_cleanly(engine):
         run_repeats(s, L, P, [71, 72, 73, 74], max_in_flight=4)
     again, runs = run_repeats(s, L, P, [71, 72, 73, 74], max_in_flight=4)
     assert again["logZ"] == good["logZ"] and again["nlike"] == good["nlike"] and len(runs) == 4
+
+
+@pytest.mark.gpu
+def test_a_failing_update_inside_a_fiber_unwinds_the_others(engine):
+    """clustered runs in step make their updates as fibers of the driving thread (shared waits).  One of them fails in the middle of its
+    update (injected: cluster capacity at the next split): the fibers still suspended are resumed with the cancel flag and unwind their
+    frames (their pinned blocks go back to the cache, what they wrote down for the next flush is dropped), the call reports the failure,
+    and the next call -- the same seeds -- makes the runs as if nothing had happened"""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    L, P, keep = api.make_problem("rastrigin", 3, 0, -5.12, 5.12)
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), 3, 0)
+    s.nlive, s.num_repeats, s.do_clustering = 200, 9, 1
+    seeds = [81, 82, 83, 84, 85, 86]
+    good, gruns = run_repeats(s, L, P, seeds, max_in_flight=len(seeds))
+    assert good["nclustered"] >= 4
+    lib.polychord_hip_set_option(b"inject_fault", 2.0)
+    with pytest.raises(RuntimeError):
+        run_repeats(s, L, P, seeds, max_in_flight=len(seeds))
+    again, runs = run_repeats(s, L, P, seeds, max_in_flight=len(seeds))
+    assert again["logZ"] == good["logZ"] and again["nlike"] == good["nlike"] and len(runs) == len(seeds)
+    for a, b in zip(gruns, runs):
+        assert a["logZ"] == b["logZ"] and np.array_equal(a["dead"], b["dead"], equal_nan=True)

@@ -892,6 +892,9 @@ def test_epoch_rule_through_the_front_door(engine, tmp_path, discard):
     o = orc.run(so, Lo, Po)
     assert o["ncluster"] + o["ncluster_dead"] > 3
     assert out.ndead == o["ndead"] and abs(out.logZ - o["logZ"]) < 1e-8 and abs(out.logZerr - o["logZerr"]) < 1e-8
+    # a caller of the reference's interface can see which rule the run followed: the last line of <root>.stats (behind everything the
+    # reference's readers parse)
+    assert ("epoch_discard = %d" % discard) in open(tmp_path / "e.stats").read().splitlines()[-1]
 
 
 @pytest.mark.gpu

@@ -129,3 +129,18 @@ def test_python_front_door_raises_instead_of_exiting(engine, capacities, tmp_pat
         pypolychord.run_polychord(dl.Gaussian(), 3, 0, st, dl.UniformPrior(0.0, 1.0))
     out = pypolychord.run_polychord(dl.Gaussian(), 3, 0, st, dl.UniformPrior(0.0, 1.0))      # and the next run is fine
     assert abs(out.logZ) < 5 * out.logZerr + 1.0
+
+
+@pytest.mark.gpu
+def test_a_nursery_of_more_than_65535_chains_is_refused(engine):
+    """the contraction kernels stamp the nursery position into 16 bits of the host mirror: a larger batch must be refused (code 8, a
+    message), not truncated"""
+    api = engine
+    lib = api.load()
+    s = api.Settings(); lib.pchip_settings_default(C.byref(s), 4, 0)
+    s.nlive, s.num_repeats, s.batch = 200, 8, 70000
+    L, P, keep = api.make_problem("gaussian", 4, 0)
+    r = api.Result()
+    assert lib.pchip_run(C.byref(s), C.byref(L), C.byref(P), C.byref(r)) == 8
+    s.batch = 0
+    assert api.run(s, L, P)["ndead"] > 0          # the process goes on
