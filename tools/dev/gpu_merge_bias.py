@@ -16,7 +16,7 @@ s.nlive, s.num_repeats, s.do_clustering = nlive, nr, 1
 L, P, keep = api.make_problem(kind, D, nDer, *box)
 m, runs = run_repeats(s, L, P, [8000 + j for j in range(R)], max_in_flight=min(R, 32))
 own = np.array([r["logZ"] for r in runs]); err = np.array([r["logZerr"] for r in runs])
-alone = np.array([mg.merge_runs(r, None, D, nDer)["logZ"] for r in runs])
+alone = np.array([mg.merge_runs(r, None, D, nDer)["logZ_replay"] for r in runs])
 sem = lambda x: x.std(ddof=1) / np.sqrt(x.size)
 lme = lambda x: float(np.log(np.mean(np.exp(x - x.max()))) + x.max())
 print(json.dumps({"config": cfg, "runs": R, "truth": float(truth),
@@ -24,4 +24,6 @@ print(json.dumps({"config": cfg, "runs": R, "truth": float(truth),
                   "own_log_mean_Z": lme(own),
                   "replay_alone_mean": float(alone.mean()), "replay_alone_sem": float(sem(alone)), "replay_minus_own_mean": float((alone - own).mean()), "replay_minus_own_sd": float((alone - own).std(ddof=1)),
                   "replay_alone_log_mean_Z": lme(alone),
-                  "union": float(m["logZ"]), "union_err": float(m["logZerr"])}))
+                  "union": float(m["logZ"]), "union_err": float(m["logZerr"]), "union_evidence_rule": m["evidence_rule"], "union_nclustered": m["nclustered"],
+                  "union_replay": float(m["logZ_replay"]), "union_replay_err": float(m["logZerr_replay"]),
+                  "union_post_mean_absmax": float(np.abs(m["post_mean"]).max())}))
