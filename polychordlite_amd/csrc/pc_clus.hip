@@ -89,6 +89,39 @@ __device__ __forceinline__ double cl_log(double ref, double v, double logzero)
     return x > logzero ? x : logzero;
 }
 
+// the live slots by (logL, list position), free slots last -- k_sort_live's order (pc_fast.hip sort_live_body: the same comparator, a
+// bitonic network over the next power of two), by this workgroup, in LDS that holds nothing any more; sort_slot / sort_key as that kernel
+// leaves them (the ranks it also writes serve the candidate lists of the NEXT nursery, which the host sorts for)
+__device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem)
+{
+    int npow2 = 2;
+    while (npow2 < S.Ncap) npow2 <<= 1;
+    double *kv = (double *)smem;            // [npow2]
+    int *kp = (int *)(kv + npow2);          // [npow2] list position
+    int *ks = kp + npow2;                   // [npow2] slot
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npow2; i += CL_NT) {
+        const bool used = i < S.Ncap && S.live_cluster[i] >= 0;
+        kv[i] = used ? S.live_logL[i] : PC_HUGE; kp[i] = used ? S.live_pos[i] : 0x7fffffff; ks[i] = i < S.Ncap ? i : -1;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += CL_NT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double a = kv[i], b = kv[l]; const int pa = kp[i], pb = kp[l];
+                    const bool gt = (a > b) || (a == b && pa > pb);
+                    if (gt == up) { kv[i] = b; kv[l] = a; kp[i] = pb; kp[l] = pa; const int t = ks[i]; ks[i] = ks[l]; ks[l] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    const int NS = (S.Ncap + 63) & ~63;
+    for (int i = tid; i < NS; i += CL_NT) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
+}
+
 template <int J>
 __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
 {
@@ -98,7 +131,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
 template <int J>
 __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__restrict__ R)
 {
-    const PcState S = R[blockIdx.y].S;
+    const PcState S = pc_many_state(R, blockIdx.y);
 #include "pc_consume_cl_body.inc"
 }
 

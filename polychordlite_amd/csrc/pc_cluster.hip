@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_shift_mats(PcState S, int p, int nc)
 // 1 similarity blocks, 2 neighbour lists, 3 labels, 4 verdicts; ia[1] = clusters looked at)
 __global__ __launch_bounds__(256) void k_similarity_b_many(const PcManyRec *__restrict__ R)
 {
-    const PcManyRec &r = R[blockIdx.z];
+    const PcManyView r = pc_many_view(R, blockIdx.z);
     if ((int)blockIdx.y >= r.ia[1]) return;
     const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.y];
     if ((int)blockIdx.x >= d.n) return;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_similarity_b_many(const PcManyRec *__re
 }
 __global__ __launch_bounds__(256) void k_knn_sort_b_many(const PcManyRec *__restrict__ R)
 {
-    const PcManyRec &r = R[blockIdx.z];
+    const PcManyView r = pc_many_view(R, blockIdx.z);
     if ((int)blockIdx.y >= r.ia[1]) return;
     const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.y];
     if ((int)blockIdx.x >= d.n) return;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_knn_sort_b_many(const PcManyRec *__rest
 }
 __global__ __launch_bounds__(1024) void k_nn_cluster_b_many(const PcManyRec *__restrict__ R)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     if ((int)blockIdx.x >= r.ia[1]) return;
     const ClusDesc d = ((const ClusDesc *)r.p[0])[blockIdx.x];
     nn_cluster_body((const int *)r.p[2] + d.off2, d.n, (int *)r.p[3] + d.off1, (int *)r.p[4] + blockIdx.x);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_nn_cluster_sub(const SubDesc *desc, co
 // ... for several runs in step (PcManyRec::p: 0 descriptors, 1 similarity blocks, 2 pool, 3 neighbour lists, 4 labels, 5 verdicts; ia[1] parts)
 __global__ __launch_bounds__(256) void k_knn_sort_sub_many(const PcManyRec *__restrict__ R)
 {
-    const PcManyRec &r = R[blockIdx.z];
+    const PcManyView r = pc_many_view(R, blockIdx.z);
     if ((int)blockIdx.y >= r.ia[1]) return;
     const SubDesc d = ((const SubDesc *)r.p[0])[blockIdx.y];
     if ((int)blockIdx.x >= d.m) return;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_knn_sort_sub_many(const PcManyRec *__re
 }
 __global__ __launch_bounds__(1024) void k_nn_cluster_sub_many(const PcManyRec *__restrict__ R)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     if ((int)blockIdx.x >= r.ia[1]) return;
     const SubDesc d = ((const SubDesc *)r.p[0])[blockIdx.x];
     nn_cluster_body((const int *)r.p[3] + d.koff, d.m, (int *)r.p[4] + d.ioff, (int *)r.p[5] + blockIdx.x);

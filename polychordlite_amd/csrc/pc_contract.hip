@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_nn_lists(PcState S, int nleft, int tile
 // several runs in step (blockIdx.y = run): each run its own number of chains left in the nursery (PcManyRec::ia[1])
 __global__ __launch_bounds__(256) void k_nn_lists_many(const PcManyRec *__restrict__ R, int tile_pts)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     if ((int)blockIdx.x >= r.ia[1]) return;
     nn_lists_body(r.S, r.ia[1], tile_pts);
 }
@@ -276,7 +276,7 @@ __device__ __forceinline__ void nn_gather_body(const PcState &S, int nleft)
     if (d == 0) S.nn_code[gi] = code;
 }
 __global__ __launch_bounds__(256) void k_nn_gather(PcState S, int nleft) { nn_gather_body(S, nleft); }
-__global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R) { const PcManyRec &r = R[blockIdx.y]; nn_gather_body(r.S, r.ia[1]); }
+__global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R) { const PcManyView r = pc_many_view(R, blockIdx.y); nn_gather_body(r.S, r.ia[1]); }
 
 #define NND_SC 16                                   /* at most this many scanners per pair of babies */
 // Round 4: most of the candidates cannot die before the chain is looked at.  The deaths of a nursery take the snapshot's points in
@@ -444,7 +444,7 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
 template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d(PcState S, int nleft, int tile_pts, int use_rank) { nn_lists_d_body<D>(S, nleft, tile_pts, use_rank); }
 template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d_many(const PcManyRec *__restrict__ R, int tile_pts, int use_rank)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     if ((int)blockIdx.x >= r.ia[1]) return;
     nn_lists_d_body<D>(r.S, r.ia[1], tile_pts, use_rank);
 }
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void apply_dead_ph_body(const PcState &S, unsigned ba
     }
 }
 __global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph(PcState S, unsigned batch) { apply_dead_ph_body(S, batch); }
-__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph_many(const PcManyRec *__restrict__ R) { apply_dead_ph_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0]); }
+__global__ __launch_bounds__(64 * PC_APPLY_WAVES) void k_apply_dead_ph_many(const PcManyRec *__restrict__ R) { apply_dead_ph_body(pc_many_state(R, blockIdx.y), (unsigned)R[blockIdx.y].ia[0]); }
 
 // pool mode: both of the above in ONE launch (a kernel boundary on the main stream costs 6 us, 79 times per run at the metric
 // configuration).  No row is copied to become a phantom, so a chain's workgroup only writes the side arrays of its region and,
@@ -1331,7 +1331,7 @@ __device__ __forceinline__ void apply_pool_body(const PcState &S, unsigned batch
     if (lane == 0) { S.slot_src[slot] = -1; S.slot_dead[slot] = -1; if (src >= 0) S.live_entry[slot] = S.plan[src].contour; }
 }
 __global__ __launch_bounds__(256) void k_apply_pool(PcState S, unsigned batch, int nchains) { apply_pool_body(S, batch, nchains); }
-__global__ __launch_bounds__(256) void k_apply_pool_many(const PcManyRec *R, int nchains) { apply_pool_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains); }
+__global__ __launch_bounds__(256) void k_apply_pool_many(const PcManyRec *R, int nchains) { apply_pool_body(pc_many_state(R, blockIdx.y), (unsigned)R[blockIdx.y].ia[0], nchains); }
 
 
 // new live rows: every slot now owned by a chain's last baby
@@ -1347,7 +1347,7 @@ __device__ __forceinline__ void apply_live_body(const PcState &S)
     if (lane == 0) { S.slot_src[slot] = -1; S.live_entry[slot] = S.plan[src].contour; }
 }
 __global__ __launch_bounds__(64) void k_apply_live(PcState S) { apply_live_body(S); }
-__global__ __launch_bounds__(64) void k_apply_live_many(const PcManyRec *__restrict__ R) { apply_live_body(R[blockIdx.y].S); }
+__global__ __launch_bounds__(64) void k_apply_live_many(const PcManyRec *__restrict__ R) { apply_live_body(pc_many_state(R, blockIdx.y)); }
 
 // ------------------------------------------------------------------------------------------
 // install the initial live set: rows -> slots, labels, contour (generate.F90:291-320)
@@ -1415,7 +1415,7 @@ __device__ __forceinline__ void clean_flag_body(const PcState &S, int nph, unsig
     if (threadIdx.x == 0) blk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 __global__ __launch_bounds__(256) void k_clean_flag(PcState S, int nph, unsigned char *keep, int *blk_count) { clean_flag_body(S, nph, keep, blk_count); }
-__global__ __launch_bounds__(256) void k_clean_flag_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x >= r.ia[2]) return; clean_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1]); }
+__global__ __launch_bounds__(256) void k_clean_flag_many(const PcManyRec *R) { const PcManyView r = pc_many_view(R, blockIdx.y); if ((int)blockIdx.x >= r.ia[2]) return; clean_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1]); }
 
 
 __device__ __forceinline__ void scan_blocks_body(int *blk_count, int nblk, int *total, int *total2)
@@ -1443,7 +1443,7 @@ __device__ __forceinline__ void scan_blocks_body(int *blk_count, int nblk, int *
     if (threadIdx.x == 0) { *total = carry; if (total2) *total2 = carry; }   // total2: the control block's phantom count
 }
 __global__ __launch_bounds__(256) void k_scan_blocks(int *blk_count, int nblk, int *total, int *total2) { scan_blocks_body(blk_count, nblk, total, total2); }
-__global__ __launch_bounds__(256) void k_scan_blocks_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; scan_blocks_body((int *)r.p[1], r.ia[2], (int *)r.p[2], &r.S.ctl->nphantom); }
+__global__ __launch_bounds__(256) void k_scan_blocks_many(const PcManyRec *R) { const PcManyView r = pc_many_view(R, blockIdx.y); scan_blocks_body((int *)r.p[1], r.ia[2], (int *)r.p[2], &r.S.ctl->nphantom); }
 
 
 __device__ __forceinline__ void clean_scatter_body(const PcState &S, int nph, const unsigned char *keep, const int *blk_off,
@@ -1470,14 +1470,14 @@ __global__ __launch_bounds__(256) void k_clean_scatter(PcState S, int nph, const
 { clean_scatter_body(S, nph, keep, blk_off, ph2, phL2, phC2, phU2, dst_index); }
 __global__ __launch_bounds__(256) void k_clean_scatter_many(const PcManyRec *R)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     if ((int)blockIdx.x >= r.ia[2]) return;
     clean_scatter_body(r.S, r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5], (unsigned long long *)r.p[6], nullptr);
 }
 
 
 __global__ void k_reset_thresholds(PcState S) { for (int c = threadIdx.x; c < S.maxc; c += blockDim.x) S.death_thr[c] = -PC_HUGE; }
-__global__ void k_reset_thresholds_many(const PcManyRec *__restrict__ R) { const PcState &S = R[blockIdx.y].S; for (int c = threadIdx.x; c < S.maxc; c += blockDim.x) S.death_thr[c] = -PC_HUGE; }
+__global__ void k_reset_thresholds_many(const PcManyRec *__restrict__ R) { const PcState S = pc_many_state(R, blockIdx.y); for (int c = threadIdx.x; c < S.maxc; c += blockDim.x) S.death_thr[c] = -PC_HUGE; }
 
 // ------------------------------------------------------------------------------------------
 // update step 2: calculate_covmats (run_time_info.f90:601-641), two passes, fixed-order sums

@@ -95,7 +95,7 @@ __device__ __forceinline__ void sort_live_body(const PcState &S, int npow2)
     }
 }
 __global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2) { sort_live_body(S, npow2); }
-__global__ __launch_bounds__(1024) void k_sort_live_many(const PcManyRec *R, int npow2) { sort_live_body(R[blockIdx.y].S, npow2); }
+__global__ __launch_bounds__(1024) void k_sort_live_many(const PcManyRec *R, int npow2) { sort_live_body(pc_many_state(R, blockIdx.y), npow2); }
 
 
 // ------------------------------------------------------------------------------------------

@@ -776,7 +776,7 @@ __device__ __forceinline__ void consume_par_body(const PcState &S)
     }
 }
 __global__ __launch_bounds__(PAR_NT) void k_consume_par(PcState S) { consume_par_body(S); }
-__global__ __launch_bounds__(PAR_NT) void k_consume_par_many(const PcManyRec *R) { consume_par_body(R[blockIdx.y].S); }
+__global__ __launch_bounds__(PAR_NT) void k_consume_par_many(const PcManyRec *R) { consume_par_body(pc_many_state(R, blockIdx.y)); }
 
 
 // ------------------------------------------------------------------------------------------
@@ -866,7 +866,7 @@ __device__ __forceinline__ void final_par_body(const PcState &S)
     }
 }
 __global__ __launch_bounds__(PAR_NT) void k_final_par(PcState S) { final_par_body(S); }
-__global__ __launch_bounds__(PAR_NT) void k_final_par_many(const PcManyRec *R) { final_par_body(R[blockIdx.y].S); }
+__global__ __launch_bounds__(PAR_NT) void k_final_par_many(const PcManyRec *R) { final_par_body(pc_many_state(R, blockIdx.y)); }
 
 
 static size_t par_lds(const PcState *S)

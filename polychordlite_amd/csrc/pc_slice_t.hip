@@ -473,7 +473,7 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
 template <int DT, bool UNIT>
 __global__ __launch_bounds__(64) void k_slice_t(PcState S, unsigned batch, int nchains, int nrp) { slice_t_body<DT, UNIT, false>(S, batch, nchains, nrp); }
 template <int DT, bool UNIT, bool HELP>
-__global__ __launch_bounds__(HELP ? 192 : 64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT, HELP>(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
+__global__ __launch_bounds__(HELP ? 192 : 64) void k_slice_t_many(const PcManyRec *R, int nchains, int nrp) { slice_t_body<DT, UNIT, HELP>(pc_many_state(R, blockIdx.y), (unsigned)R[blockIdx.y].ia[0], nchains, nrp); }
 
 
 static int deck_stride(int nr) { int q = (nr + 3) / 4; if ((q & 1) == 0) q++; return 4 * q; }   // bytes, an odd number of words: lanes on different banks
@@ -608,7 +608,7 @@ __device__ __forceinline__ void bases_packed_body(const PcState &S, int nbases)
 template <int DMAX>
 __global__ __launch_bounds__(64) void k_bases_packed(PcState S, int nbases) { bases_packed_body<DMAX>(S, nbases); }
 template <int DMAX>
-__global__ __launch_bounds__(64) void k_bases_packed_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX>(R[blockIdx.y].S, nbases); }
+__global__ __launch_bounds__(64) void k_bases_packed_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX>(pc_many_state(R, blockIdx.y), nbases); }
 
 // step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
 // Four stream calls (eight deviates) a thread.  AS241's central branch is two polynomials and a division; the tails (15 % of the
@@ -652,7 +652,7 @@ __device__ __forceinline__ void deviates_t_body(const PcState &S, unsigned batch
     for (int k = lane; k < qn; k += 64) S.nhat_raw[qA[wv][k]] = pc_inv_normal_tail(qU[wv][k]);
 }
 __global__ __launch_bounds__(256) void k_deviates_t(PcState S, unsigned batch, int nbases, int NC) { deviates_t_body(S, batch, nbases, NC); }
-__global__ __launch_bounds__(256) void k_deviates_t_many(const PcManyRec *R, int nbases, int NC) { deviates_t_body(R[blockIdx.y].S, (unsigned)R[blockIdx.y].ia[0], nbases, NC); }
+__global__ __launch_bounds__(256) void k_deviates_t_many(const PcManyRec *R, int nbases, int NC) { deviates_t_body(pc_many_state(R, blockIdx.y), (unsigned)R[blockIdx.y].ia[0], nbases, NC); }
 
 
 template <int DT>

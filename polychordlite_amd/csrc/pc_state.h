@@ -180,6 +180,54 @@ struct PcState {
 // kernel takes as arguments (update: 0 keep, 1 block counts, 2 total, 3-6 the alternate phantom arrays, 7 partial sums, 8 shift).
 struct PcManyRec { PcState S; void *p[10]; int ia[6]; int pad[2]; };      // ia: 0 the nursery's number, 1 phantom rows in use (update), 2 its blocks
 
+#ifdef __HIPCC__
+// ---- kernels that take their state from a record in memory (the runs of a device in step, blockIdx.y = run) --------------------------
+// A pointer that a kernel READS FROM MEMORY is a generic pointer to the compiler (only kernel arguments are known to be global), and
+// every access through it becomes a flat_load / flat_store.  FLAT instructions count on lgkmcnt as well as on vmcnt: every wait for an
+// LDS read or a scalar load then also waits for the global loads and stores in flight -- the prefetches a serial loop lives on
+// (k_consume_cl_many averaged 958 us per launch against 498 us for the one-run kernel with the SAME body: round 4's open question;
+// its ISA: 210 flat_load + 170 flat_store where the one-run kernel has global_load / global_store).  Sent through an integer into the
+// global address space a pointer is global again (free: the bits are the same; null stays null AND stays testable -- rebuilt as
+// known_global_base + offset it was global too, but a GEP from a non-null base "cannot" be null, the compiler dropped the `p ? p[i] : ..`
+// tests and the kernels read address 0).  Casts through address_space(1) and straight back, and __builtin_assume(!is_shared &
+// !is_private), are folded away before the address-space inference sees them (ROCm 7.2).
+template <class T, class B> __device__ __forceinline__ T *pc_as_global(T *p, const B * /* (the kernel's argument: not needed) */)
+{
+    typedef __attribute__((address_space(1))) char gchar;
+    return (T *)(gchar *)(uintptr_t)p;
+}
+// the state of run blockIdx.y with every pointer member global (a member added to PcState must be added here: the size is checked)
+static_assert(sizeof(PcState) == 944, "PcState changed: add the new pointer members to pc_many_state, then update this size");
+__device__ __forceinline__ PcState pc_many_state(const PcManyRec *R, int run)
+{
+    PcState S = R[run].S;
+#define G(f) S.f = pc_as_global(S.f, R)
+    G(like.invcov); G(like.mean); G(prior.lo); G(prior.hi); G(dyn_loglikes); G(dyn_nlives); G(live); G(live_logL);
+    G(live_cluster); G(live_pos); G(live_entry); G(cl_list); G(cl_n); G(logZp); G(logXp); G(logZXp);
+    G(logZp2); G(logZpXp); G(logLp); G(XpXq); G(imin_slot); G(lse_ref); G(lse_sum); G(death_thr);
+    G(cl_uid); G(chol); G(cov); G(logZp_dead); G(logZp2_dead); G(cl_uid_dead); G(phantom); G(ph_logL);
+    G(ph_cuid); G(ph_uid); G(dead); G(dead_logw); G(dead_postX); G(dead_postZ); G(dead_cuid); G(dead_entry);
+    G(babies); G(baby_logL); G(baby_logL_T); G(ch_cluster); G(ch_epoch); G(ch_nlike); G(ch_seed_slot); G(ch_contour);
+    G(nhat); G(nhat_w); G(nhat_raw); G(nhat_Ms); G(ch_My); G(plan); G(sort_slot); G(sort_key);
+    G(slot_src); G(slot_dead); G(slot_step); G(ch_nlike_g); G(logn); G(nn_list); G(nn_slot_owner); G(nn_chain_slot);
+    G(nn_pts); G(nn_code); G(ctl); G(ctl_host);
+#undef G
+    return S;
+}
+// ... and the whole record: the state, the buffers (global too) and the integers; the members a kernel does not touch are never loaded
+struct PcManyView { PcState S; void *p[10]; int ia[6]; };
+__device__ __forceinline__ PcManyView pc_many_view(const PcManyRec *R, int run)
+{
+    PcManyView v;
+    v.S = pc_many_state(R, run);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v.p[i] = pc_as_global(R[run].p[i], R);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v.ia[i] = R[run].ia[i];
+    return v;
+}
+#endif
+
 // Called by EVERY thread of the (single) workgroup at the end of a contraction kernel, after thread 0 has stored the new
 // control block to *S.ctl.  The host mirror is fine-grained host memory over PCIe; a system-scope release (fence + L2
 // write-back) in front of a stamp costs the kernel ~15 us, and a dozen dependent stores by one thread ~6 us, so: no

@@ -114,7 +114,7 @@ __device__ __forceinline__ void upd_flag_body(const PcState &S, int nph, unsigne
     if (lane == 0) blk_count[sb] = cnt;
 }
 __global__ __launch_bounds__(UPD_NT) void k_upd_flag(PcState S, int nph, unsigned char *keep, int *blk_count, int def, int nblk) { upd_flag_body(S, nph, keep, blk_count, def, nblk); }
-__global__ __launch_bounds__(UPD_NT) void k_upd_flag_many(const PcManyRec *R, int def) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x * 4 >= r.ia[2]) return; upd_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], def, r.ia[2]); }
+__global__ __launch_bounds__(UPD_NT) void k_upd_flag_many(const PcManyRec *R, int def) { const PcManyView r = pc_many_view(R, blockIdx.y); if ((int)blockIdx.x * 4 >= r.ia[2]) return; upd_flag_body(r.S, r.ia[1], (unsigned char *)r.p[0], (int *)r.p[1], def, r.ia[2]); }
 
 
 // exclusive scan of the block counts in place, one workgroup, 4096 counts at a time (four per thread, coalesced)
@@ -209,7 +209,7 @@ __device__ __forceinline__ void upd_index_self_body(int nph, const unsigned char
     }
 }
 __global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self(int nph, const unsigned char *keep, const int *blk_count, int nblk, int *idx, int *total) { upd_index_self_body(nph, keep, blk_count, nblk, idx, total); }
-__global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyRec &r = R[blockIdx.y]; if ((int)blockIdx.x * 16 >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
+__global__ __launch_bounds__(UPD_IDX_NT) void k_upd_index_self_many(const PcManyRec *R) { const PcManyView r = pc_many_view(R, blockIdx.y); if ((int)blockIdx.x * 16 >= r.ia[2]) return; upd_index_self_body(r.ia[1], (const unsigned char *)r.p[0], (const int *)r.p[1], r.ia[2], (int *)r.p[5], (int *)r.p[2]); }
 
 
 // sixteen rows given by index, coordinates minus shift and a one, to consecutive tile rows; lane = element, the loads of
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_upd_gather(PcState S, int nph, int nblk
 template <int NT>
 __global__ __launch_bounds__(256) void k_upd_gather_many(const PcManyRec *R, int E, int def, int nlb, int ndb)
 {
-    const PcManyRec &r = R[blockIdx.y];
+    const PcManyView r = pc_many_view(R, blockIdx.y);
     upd_gather_body<NT, true>(r.S, r.ia[1], r.ia[2], (const unsigned char *)r.p[0], (const int *)r.p[1], (double *)r.p[3], (double *)r.p[4], (unsigned *)r.p[5],
                               (unsigned long long *)r.p[6], (const int *)r.p[5], (const int *)r.p[2], (const double *)r.p[8], (double *)r.p[7], E, def, nlb, ndb);
 }
@@ -480,7 +480,7 @@ __device__ __forceinline__ void upd_fold_body(const double *part, int nb, int E,
     }
 }
 __global__ __launch_bounds__(256) void k_upd_fold(const double *part, int nb, int E, double *part2) { upd_fold_body(part, nb, E, part2); }
-__global__ __launch_bounds__(256) void k_upd_fold_many(const PcManyRec *R, int nb, int E) { double *part = (double *)R[blockIdx.y].p[7]; upd_fold_body(part, nb, E, part + (size_t)nb * E); }
+__global__ __launch_bounds__(256) void k_upd_fold_many(const PcManyRec *R, int nb, int E) { double *part = pc_as_global((double *)R[blockIdx.y].p[7], R); upd_fold_body(part, nb, E, part + (size_t)nb * E); }
 
 
 // fold + mean + covariance + Cholesky; one workgroup of 1024 threads
@@ -572,7 +572,7 @@ __device__ __forceinline__ void upd_final_body(const PcState &S, int nb, const d
 #endif
 }
 __global__ __launch_bounds__(1024) void k_upd_final(PcState S, int nb, const double *part, int E, double *shift, int def) { upd_final_body(S, nb, part, E, shift, def); }
-__global__ __launch_bounds__(1024) void k_upd_final_many(const PcManyRec *R, int nb, int E, int def, int G) { const PcManyRec &r = R[blockIdx.y]; upd_final_body(r.S, nb, (const double *)r.p[7] + (size_t)G * E, E, (double *)r.p[8], def); }
+__global__ __launch_bounds__(1024) void k_upd_final_many(const PcManyRec *R, int nb, int E, int def, int G) { const PcManyView r = pc_many_view(R, blockIdx.y); upd_final_body(r.S, nb, (const double *)r.p[7] + (size_t)G * E, E, (double *)r.p[8], def); }
 
 
 // records added up; delta = mean - shift; n cov = M2 - n delta delta^T for k_cov_final_chol (which divides by n, stores the
