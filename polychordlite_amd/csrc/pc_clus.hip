@@ -48,9 +48,19 @@ struct ClSorted { double L, e; int slot, pad; };             // logL, exp(logL -
 struct ClCand { double L, e; int w, pad; };
 struct ClHead { double logw, postXs, zl, contour; int dead_idx, dead_src; unsigned dead_cuid, ph_cuid; int ph_base, pad; };
 struct ClOwn { double zp, zp2, zpx, kzp, kp2a, kp2b, kzpx, rzp, rzp2, rzpx; int touched, pad; };   // a cluster's own accumulators (linear) and their scales
+// what wave 0 (the decisions) leaves for the waves behind it about a consumed chain, 16 bytes (the LDS block is full: 150 KB at nlive
+// 1000 / 500 chains): kind 0 = nothing died; 1 = the point of cluster cd (nd live points before) in `slot` died with exp(L - Lhi) = eL
+// and the chain's last baby joined ITS cluster (ClChain::ca; na points there after the death); predC = the cluster expected to lose the
+// next point (-1: a newcomer).  a = kind | cd << 1 | (predC + 1) << 8 | slot << 16, b = nd | na << 16 (pc_consume_cl_fits: nlive < 65536)
+struct ClEvt { double eL; unsigned a, b; };
+__device__ __forceinline__ ClEvt cl_evt(int cd, int predC, int slot, int nd, int na, double eL)
+{
+    return ClEvt{eL, 1u | ((unsigned)cd << 1) | ((unsigned)(predC + 1) << 8) | ((unsigned)slot << 16), (unsigned)nd | ((unsigned)na << 16)};
+}
+#define CL_NO_LIMIT (-0x7fffffff)
 
 struct ClLayout {                 // byte offsets into the dynamic LDS block; the same function sizes it on the host
-    size_t slot, sL, sorted, cand, chain, head, own, logn, rcp, fg, masks, kmin, sCS, lst, lstOff, tag, total;
+    size_t slot, sL, sorted, cand, chain, head, own, logn, rcp, fg, masks, kmin, sCS, lst, lstOff, tag, evt, total;
 };
 __host__ __device__ inline ClLayout cl_layout(int Ncap, int B, int nr)
 {
@@ -63,6 +73,7 @@ __host__ __device__ inline ClLayout cl_layout(int Ncap, int B, int nr)
     take(o.own, sizeof(ClOwn) * CL_MAXC); take(o.logn, 8 * ((size_t)Ncap + 4)); take(o.rcp, 8 * ((size_t)Ncap + 4)); take(o.fg, 8 * 2 * CL_MAXC);
     take(o.masks, 8 * (size_t)B * nw); take(o.kmin, 8 * CL_MAXC);
     take(o.sCS, 4 * (size_t)B); take(o.lst, 4 * ((size_t)Ncap + B)); take(o.lstOff, 4 * (CL_MAXC + 1)); take(o.tag, 4 * ((size_t)Ncap + B + 1));
+    take(o.evt, sizeof(ClEvt) * (size_t)B);
     o.total = p;
     return o;
 }
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__re
 
 extern "C" int pc_consume_cl_fits(const PcState *S, int nc)
 {
-    if (nc < 2 || nc > CL_MAXC || S->B > 1024 || S->nr > 64 * PC_MASK_WORDS) return 0;
+    if (nc < 2 || nc > CL_MAXC || S->B > 1024 || S->nr > 64 * PC_MASK_WORDS || S->Ncap >= 65536) return 0;
     return cl_layout(S->Ncap, S->B, S->nr).total + 1024 <= (size_t)160 * 1024;
 }
 
