@@ -136,6 +136,7 @@ __device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem)
 template <int J>
 __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
 {
+#pragma clang fp contract(on)
 #include "pc_consume_cl_body.inc"
 }
 // several runs in step: R one-wave contractions on R compute units (blockIdx.y = run).  (The body is included, not called: see k_slice_many)
@@ -143,7 +144,10 @@ template <int J>
 __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__restrict__ R)
 {
     const PcState S = pc_many_state(R, blockIdx.y);
+    {
+#pragma clang fp contract(on)
 #include "pc_consume_cl_body.inc"
+    }
 }
 
 extern "C" int pc_consume_cl_fits(const PcState *S, int nc)

@@ -606,7 +606,9 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 template <int HV, int PART = 0>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q_many(const PcManyRec *__restrict__ R)
 {
-    const PcState S = pc_many_state(R, blockIdx.z);
+    // (pointers left generic here: with them made global -- pc_many_state -- the compiler fused other multiply-adds than in the one-run
+    //  kernel, the same statements, and a run in step was no longer bit for bit the run alone)
+    const PcState S = R[blockIdx.z].S;
     const unsigned batch = (unsigned)R[blockIdx.z].ia[0];
 #include "pc_nhats_q_body.inc"
 }
@@ -1125,7 +1127,9 @@ __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, uns
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, int LEAN = 0>
 __global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice_many(const PcManyRec *__restrict__ R, int phi_lds, int mat_lds)
 {
-    const PcState S = pc_many_state(R, blockIdx.y);
+    // (pointers left generic here: with them made global -- pc_many_state -- the compiler fused other multiply-adds than in the one-run
+    //  kernel, the same statements, and a run in step was no longer bit for bit the run alone)
+    const PcState S = R[blockIdx.y].S;
     const unsigned batch = (unsigned)R[blockIdx.y].ia[0];
 #include "pc_slice_body.inc"
 }

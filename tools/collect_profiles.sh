@@ -16,6 +16,6 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$o
 python tools/pmc_summary.py "$out/fetch" "$out/write" "profiles/${tag}_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $BENCH (one pass per counter)"
 cp "profiles/${tag}_pmc.json" "profiles/${tag}_kernel_stats.csv" gpurun_out/
 # the bench line itself (same command plus the CPU baseline and the concurrent-runs capacity figure), with the PMC file in place
-timeout 400 python bench.py > "profiles/${tag}_bench.json" 2> "$out/bench.log"
-cp "profiles/${tag}_bench.json" gpurun_out/
+timeout 600 python bench.py --steps 20 --warmup 5 --full-out "gpurun_out/${tag}_bench_full.json" > "profiles/${tag}_bench.json" 2> "$out/bench.log"      # (the compact record the driver parses; the full one beside it)
+cp "profiles/${tag}_bench.json" gpurun_out/; cp "gpurun_out/${tag}_bench_full.json" profiles/ 2>/dev/null
 head -5 "profiles/${tag}_kernel_stats.csv"

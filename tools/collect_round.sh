@@ -22,5 +22,5 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$o
 python tools/pmc_summary.py "$out/fetch" "$out/write" "gpurun_out/${tag}_concurrent16_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $CMD (one pass per counter)"
 tail -3 "$out/stats.log"
 bash tools/collect_slice_dbg.sh $tag > /dev/null 2>&1
-for w in c3 c4 c5; do timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-extras > gpurun_out/${tag}_bench_$w.json 2> /dev/null; done
+for w in c3 c4 c5; do timeout 400 python bench.py --workload $w --steps 3 --warmup 1 --no-extras --full-out gpurun_out/${tag}_bench_${w}_full.json > gpurun_out/${tag}_bench_$w.json 2> /dev/null; done
 ls gpurun_out | grep "^$tag" 
