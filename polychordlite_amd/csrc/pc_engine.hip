@@ -26,6 +26,7 @@
 #include <functional>
 #include <exception>
 #include <ucontext.h>
+#include <array>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -286,6 +287,41 @@ HandlePool &hpool() { static HandlePool *p = new HandlePool; return *p; }
 // queues (GPU_MAX_HW_QUEUES, four by default), and two streams of one queue take turns -- after a sweep of sixty-four runs in
 // step the pool held dozens of streams, and a single run that drew two of one queue was 2.3 ms (16 %) slower.  So a side stream
 // is tried against its main stream once (two 40-us spinning kernels: together or one after the other?) and the verdict kept.
+// ---- the small copies of runs in step, many at a time.  An update with clustering reads a dozen small arrays back and sends a dozen
+// down (add_cluster: counts, evidences, the cross-volume matrix, labels); as hipMemcpyAsync calls that was 49 000 copies for sixteen
+// 10-D Rastrigin runs (round 4) -- ~6 us of the driving thread each, and on the stream one after the other, ~4 us each, in front of
+// every shared wait.  Pinned host memory is mapped into the device's address space (hipHostMalloc), so ONE kernel makes up to PC_COPY_N
+// of them, either way, a workgroup per piece of at most 4 KB: its arguments are the (source, destination, bytes) of the pieces.
+#define PC_COPY_N 96
+#define PC_COPY_PIECE 4096u
+struct PcCopyBatch { const void *src[PC_COPY_N]; void *dst[PC_COPY_N]; unsigned bytes[PC_COPY_N]; };
+__global__ __launch_bounds__(256) void k_copy_batch(PcCopyBatch b)
+{
+    const int i = blockIdx.x;
+    const unsigned n = b.bytes[i];
+    const char *s = (const char *)b.src[i]; char *d = (char *)b.dst[i];
+    if ((((uintptr_t)s | (uintptr_t)d) & 7u) == 0u) {
+        const unsigned n8 = n >> 3;
+        for (unsigned k = threadIdx.x; k < n8; k += 256) ((unsigned long long *)d)[k] = ((const unsigned long long *)s)[k];
+        for (unsigned k = (n8 << 3) + threadIdx.x; k < n; k += 256) d[k] = s[k];
+    } else for (unsigned k = threadIdx.x; k < n; k += 256) d[k] = s[k];
+}
+static void pc_copy_many(const std::vector<std::array<uintptr_t, 3>> &reqs, hipStream_t q)      // {dst, src, bytes}
+{
+    PcCopyBatch b; int n = 0;
+    auto go = [&] { if (n) { hipLaunchKernelGGL(k_copy_batch, dim3(n), dim3(256), 0, q, b); n = 0; } };
+    for (const auto &r : reqs) {
+        size_t left = r[2]; uintptr_t d = r[0], s = r[1];
+        while (left) {
+            const unsigned c = (unsigned)std::min<size_t>(left, PC_COPY_PIECE);
+            b.dst[n] = (void *)d; b.src[n] = (const void *)s; b.bytes[n] = c; ++n;
+            d += c; s += c; left -= c;
+            if (n == PC_COPY_N) go();
+        }
+    }
+    go();
+}
+
 __global__ void k_engine_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) {} }
 static bool streams_overlap_test(hipStream_t a, hipStream_t b)
 {
@@ -521,8 +557,20 @@ struct Cohort {
                                                (unsigned *)r.p[5], (unsigned long long *)r.p[6], (double *)r.p[7], (double *)r.p[8], (int)r.a[1], st); break;
         }
     }
-    void run_post() { if (post.empty()) return; std::vector<std::function<void()>> p; p.swap(post); for (auto &f : p) f(); }
-    void run_pre() { if (pre.empty()) return; std::vector<std::function<void()>> p; p.swap(pre); for (auto &f : p) f(); }
+    // ... the copies among them as (destination, source, bytes): one kernel for all of them (k_copy_batch), not a hipMemcpyAsync each
+    std::vector<std::array<uintptr_t, 3>> post_copies, pre_copies;
+    void run_post()
+    {
+        if (!post_copies.empty()) { std::vector<std::array<uintptr_t, 3>> c; c.swap(post_copies); pc_copy_many(c, st); }
+        if (post.empty()) return;
+        std::vector<std::function<void()>> p; p.swap(post); for (auto &f : p) f();
+    }
+    void run_pre()
+    {
+        if (!pre_copies.empty()) { std::vector<std::array<uintptr_t, 3>> c; c.swap(pre_copies); pc_copy_many(c, st); }
+        if (pre.empty()) return;
+        std::vector<std::function<void()>> p; p.swap(pre); for (auto &f : p) f();
+    }
     void flush()
     {
         run_pre();
@@ -947,7 +995,8 @@ struct Engine {
         void *h = halloc<char>(bytes);
         fetching.push_back({h, dst, bytes});
         hipStream_t q = st;
-        if (co) co->post.push_back([h, src, bytes, q] { HIPCHK(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, q)); });
+        if (co && batch_copies()) co->post_copies.push_back({(uintptr_t)h, (uintptr_t)src, (uintptr_t)bytes});
+        else if (co) co->post.push_back([h, src, bytes, q] { HIPCHK(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, q)); });
         else HIPCHK(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, st));
     }
     template <class T> void fetch(std::vector<T> &v, const T *p, size_t n) { v.resize(n); fetch_raw(v.data(), p, sizeof(T) * n); }
@@ -968,7 +1017,10 @@ struct Engine {
         void *h = halloc<char>(bytes);
         staged_up.push_back(h);
         std::memcpy(h, src, bytes);
-        HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st));
+        // (runs in step: with the other copies at the head of the next launch -- what was written down before this call has been launched
+        //  by direct_op(), and whatever is launched behind it, here and now or written down, goes through the same door)
+        if (co && batch_copies()) co->pre_copies.push_back({(uintptr_t)dst, (uintptr_t)h, (uintptr_t)bytes});
+        else HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st));
     }
 
     // host -> device for kernels that are WRITTEN DOWN after this call (runs in step: the copy is made at the start of the common launch,
@@ -981,8 +1033,10 @@ struct Engine {
         staged_up.push_back(h);
         std::memcpy(h, src, bytes);
         hipStream_t q = st;
-        co->pre.push_back([dst, h, bytes, q] { HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, q)); });
+        if (batch_copies()) co->pre_copies.push_back({(uintptr_t)dst, (uintptr_t)h, (uintptr_t)bytes});
+        else co->pre.push_back([dst, h, bytes, q] { HIPCHK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, q)); });
     }
+    static bool batch_copies() { static const bool off = std::getenv("PC_COPY_BATCH_OFF") != nullptr; return !off; }
 
     void read_ctl()
     {
@@ -2904,12 +2958,12 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                       if (first_err) {
                           // the fibers still suspended hold locals, pinned blocks and copies written down for a flush that will not come: what
                           // they wrote down is dropped, and each is resumed once more with the cancel flag -- its wait throws, its frames unwind
-                          co.pre.clear(); co.post.clear(); co.pend.clear();
+                          co.pre.clear(); co.post.clear(); co.pend.clear(); co.pre_copies.clear(); co.post_copies.clear();
                           for (size_t a = 0; a < wk.size(); ++a) {
                               Fiber &f = fibs[a];
                               if (f.started && !f.done) { f.cancel = true; f.resume(); }
                           }
-                          co.pre.clear(); co.post.clear(); co.pend.clear();
+                          co.pre.clear(); co.post.clear(); co.pend.clear(); co.pre_copies.clear(); co.post_copies.clear();
                       }
                       for (size_t a = 0; a < wk.size(); ++a) { E[wk[a]]->fib = nullptr; if (!ok[a]) enq[wk[a]] = 0; }
                       if (first_err) std::rethrow_exception(first_err);
