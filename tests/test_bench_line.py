@@ -21,7 +21,7 @@ def _canned(name):
     return json.load(open(os.path.join(ROOT, "profiles", name)))
 
 
-@pytest.mark.parametrize("name", ["r04_bench.json", "r04_bench_c3.json", "r04_bench_c5.json", "r03_bench.json"])
+@pytest.mark.parametrize("name", ["r05_bench_full.json", "r05_bench_c3_full.json", "r05_bench_c5_full.json", "r04_bench.json", "r04_bench_c3.json", "r03_bench.json"])
 def test_compact_record_is_small_valid_and_complete(name):
     full = _canned(name)
     # what round 5 adds to the full record
@@ -89,3 +89,16 @@ def test_rank_bootstrap_two_processes_over_gloo():
     p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bootstrap-only"],
                         cwd=ROOT, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p2.returncode != 0 and "WORLD_SIZE=3" in p2.stderr
+
+
+@pytest.mark.parametrize("name", ["r05_bench.json", "r05_bench_c3.json", "r05_bench_c4.json", "r05_bench_c5.json"])
+def test_the_lines_bench_py_printed_on_the_gpu_box(name):
+    """the committed last lines of `python bench.py [--workload cN]` as they came off the MI355X: one line, < 6 KB, the driver's fields"""
+    text = open(os.path.join(ROOT, "profiles", name)).read().strip()
+    assert "\n" not in text and len(text) < bench.COMPACT_LIMIT
+    j = json.loads(text)
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["bound"] == "hbm" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "reference"
+    assert j["unit"] == "likelihood evals/s" and j["dtype"] == "f64" and j["scaling"] == "weak" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    if name == "r05_bench.json":
+        assert j["metric"].startswith("likelihood evals/sec, 20D Gaussian nlive=2000") and j["config"]["batch_chains"] == 1000
+        assert len(j["roofline"]["in_step"]) == 6 and j["roofline"]["in_step_multi"]["runs"] == 16
