@@ -150,6 +150,9 @@ typedef struct {
                            the others are samples as good after the change as before and stay in the nursery, their cluster index following
                            the list (BASELINE configs[2] at batch = nlive/2: 199 instead of 338 evaluations per dead point, the reference's
                            linear mode 155).  1: the reference's rule.  Option "epoch_discard" for polychord_c_interface callers. */
+    int device_records; /* 1: the run also leaves the records of its points that entered the live set ON THE DEVICE (pchip_result.d_records:
+                           what the exchange step of repeat-sharded runs sends; pchip_run_repeats sets it itself).  The dead points of a run
+                           are made on the device; without this the merge uploads them again from the host arrays of the result */
 } pchip_settings;
 
 typedef struct {
@@ -188,6 +191,10 @@ typedef struct {
     int ncluster_peak;             /* largest number of clusters alive at the same time */
     int epoch_discard;             /* the rule this run followed for chains in flight when the cluster list changed (pchip_settings.epoch_discard:
                                       0 = the engine's, 1 = the reference farm's); it only matters with batch > 1 and several clusters */
+    /* settings.device_records: the lived records (logweight > logzero) in death order, in DEVICE memory of device `records_device`, owned
+       by the result (pchip_result_free): rows [n_records][nTotal] at d_records, their entry contours at d_records + records_cap * nTotal,
+       their own log weights at d_records + records_cap * (nTotal + 1).  NULL when not asked for. */
+    double *d_records; long n_records, records_cap; int records_device;
 } pchip_result;
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
@@ -231,7 +238,7 @@ typedef struct {
  * bindings rely on).  A binding that mirrors them (ctypes, ISO_C_BINDING, cgo ...) checks itself against the library it loaded:
  * pchip_abi_version() == PCHIP_ABI_VERSION of the header it was written against, and pchip_sizeof("settings" | "result" | "merged" |
  * "like" | "prior" | "update") == the size of its own mirror (0 for an unknown name). */
-#define PCHIP_ABI_VERSION 5
+#define PCHIP_ABI_VERSION 6
 int  pchip_abi_version(void);
 unsigned long pchip_sizeof(const char *struct_name);
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
@@ -300,6 +307,10 @@ int  pchip_merged_write(const pchip_merged *m, int nDims, int nDerived, const ch
  * (free each with pchip_result_free), merged (may be NULL) = their union with rows.  0 on success. */
 int  pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
                        int ndevices, const int *devices, int max_in_flight, pchip_result *results, pchip_merged *merged);
+/* the same; want_rows = 0: the union without its merged rows (evidence, weights, live counts, moments only: 370 MB less to bring back
+   for sixteen runs of the metric configuration) */
+int  pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
+                          int ndevices, const int *devices, int max_in_flight, int want_rows, pchip_result *results, pchip_merged *merged);
 
 /* ---- between processes: one rank per GPU, RCCL inside the library (dlopen of librccl.so at first use, none at link time).
  * Replaces the reference's MPI exchange (mpi_utils.F90:376-463 throw_baby / catch_babies, nested_sampling.F90:262-301) for

@@ -33,7 +33,7 @@ class Settings(C.Structure):
                 ("force_general", C.c_int), ("ablate", C.c_int),
                 ("resume_write", C.c_char_p), ("sequential_rng", C.c_int), ("resume_read", C.c_char_p),
                 ("nGrade", C.c_int), ("grade_dims", C.POINTER(C.c_int)), ("grade_repeats", C.POINTER(C.c_int)),
-                ("epoch_discard", C.c_int)]
+                ("epoch_discard", C.c_int), ("device_records", C.c_int)]
 
 
 class Like(C.Structure):
@@ -57,7 +57,8 @@ class Result(C.Structure):
                 ("logZp", C.POINTER(C.c_double)), ("varlogZp", C.POINTER(C.c_double)), ("nZp", C.c_int),
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
                 ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int)),
-                ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int), ("epoch_discard", C.c_int)]
+                ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int), ("epoch_discard", C.c_int),
+                ("d_records", C.c_void_p), ("n_records", C.c_long), ("records_cap", C.c_long), ("records_device", C.c_int)]
 
 
 _lib = None
@@ -190,7 +191,7 @@ def result_dict(r, settings):
                logZp=np.ctypeslib.as_array(r.logZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
-               nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak, epoch_discard=r.epoch_discard,
+               nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak, epoch_discard=r.epoch_discard, n_records=int(r.n_records) if r.d_records else None,
                varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                logzero=settings.logzero,
                _owner=own)          # the pchip_result itself (merge.comm_merge hands it back to the library)

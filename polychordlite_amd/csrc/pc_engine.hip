@@ -30,6 +30,10 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+extern "C" size_t pc_records_block_bytes(long long cap, int nT);
+extern "C" int pc_pack_lived_device(const double *, const double *, const double *, long long, int, double, double *, long long, long long *, hipStream_t);
+extern "C" void *pc_cache_dev_alloc(size_t bytes);
+extern "C" void pc_cache_dev_free(void *p);
 extern "C" {
 int pc_launch_generate_live(const PcState *, int, int, double *, double *, hipStream_t);
 int pc_launch_nhats(const PcState *, unsigned, int, hipStream_t);
@@ -2616,7 +2620,19 @@ struct Engine {
         }
         for (int d = 0; d < D; ++d) { out->post_mean[d] /= sw; out->post_var[d] = out->post_var[d] / sw - out->post_mean[d] * out->post_mean[d]; }
         dfree(d_pmax); hfree(h_part);
+        // settings.device_records: the lived records picked here, on the device that made them (what the exchange step of repeat-sharded
+        // runs sends); their count comes back with the wait below
+        long long *h_nrec = nullptr;
+        if (cfg.device_records && h_ctl->ndead > 0) {
+            const long long cap = h_ctl->ndead;
+            double *blk_rec = (double *)pc_cache_dev_alloc(pc_records_block_bytes(cap, nT));
+            if (!blk_rec) engine_fail(PC_RC_MEMORY, "no device memory for the run's records (%lld rows)", cap);
+            h_nrec = halloc<long long>(1);
+            if (pc_pack_lived_device(S.dead, S.dead_logw, S.dead_entry, cap, nT, cfg.logzero, blk_rec, cap, h_nrec, st_copy) != 0) { pc_cache_dev_free(blk_rec); hfree(h_nrec); engine_fail(PC_RC_DEVICE, "packing the run's records"); }
+            out->d_records = blk_rec; out->records_cap = (long)cap; out->records_device = dev;
+        }
         HIPCHK(hipStreamSynchronize(st_copy));
+        if (h_nrec) { out->n_records = (long)*h_nrec; hfree(h_nrec); }
         active_run.reset();
         return 0;
     }
@@ -3125,6 +3141,7 @@ int pc_run_many(const pchip_settings *s, const pchip_like *like, const pchip_pri
 void pchip_result_free(pchip_result *r)
 {
     hfree(r->dead); hfree(r->logweights); hfree(r->entry); std::free(r->live); std::free(r->logZp); std::free(r->varlogZp);
+    if (r->d_records) pc_cache_dev_free(r->d_records);
     std::free(r->post_mean); std::free(r->post_var); std::free(r->live_cluster);
     std::memset(r, 0, sizeof(*r));
 }

@@ -502,6 +502,30 @@ struct PackJob {
 
 struct pchip_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
 
+// The lived records of a run picked where they were made (settings.device_records; called by the engine at the end of a run, on the
+// run's device, behind everything that wrote the arrays): flags, offsets, scatter into `block` -- rows [cap][nT] | entry [cap] | own log
+// weight [cap] | scratch (block counts and the total) -- and the count into *h_count (pinned) by a copy in stream order.
+extern "C" size_t pc_records_block_bytes(long long cap, int nT)
+{
+    const long long nb = (cap + PK_ROWS - 1) / PK_ROWS;
+    return sizeof(double) * (size_t)cap * (nT + 2) + sizeof(long long) * (size_t)(nb + 4);
+}
+extern "C" int pc_pack_lived_device(const double *dead, const double *logw, const double *entry, long long nd, int nT, double logzero,
+                                    double *block, long long cap, long long *h_count, hipStream_t st)
+{
+    *h_count = 0;
+    if (nd <= 0) return 0;
+    const int nb = (int)((nd + PK_ROWS - 1) / PK_ROWS);
+    double *rows = block, *ent = block + (size_t)cap * nT, *own = block + (size_t)cap * (nT + 1);
+    long long *d_total = (long long *)(block + (size_t)cap * (nT + 2));
+    int *d_blk = (int *)(d_total + 2);
+    hipLaunchKernelGGL(k_pack_flag, dim3(nb), dim3(PK_ROWS), 0, st, logw, nd, logzero, d_blk);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, d_blk, nb, d_total);
+    hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(PK_ROWS), 0, st, dead, logw, entry, nd, nT, logzero, (const int *)d_blk, rows, ent, own);
+    if (hipMemcpyAsync(h_count, d_total, sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess) return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" {
 
 void pchip_merged_free(pchip_merged *m)
@@ -679,6 +703,12 @@ static void runs_evidence(const double *z, int n, double err_one, pchip_merged *
 int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
                       int ndevices, const int *devices, int max_in_flight, pchip_result *results, pchip_merged *merged)
 {
+    return pchip_run_repeats_ex(s, like, prior, nseeds, seeds, ndevices, devices, max_in_flight, 1, results, merged);
+}
+
+int pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const pchip_prior *prior, int nseeds, const int *seeds,
+                         int ndevices, const int *devices, int max_in_flight, int want_rows, pchip_result *results, pchip_merged *merged)
+{
     using clk = std::chrono::steady_clock;
     if (nseeds < 1) return 1;
     int ndev_all = 0;
@@ -692,6 +722,10 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
     std::atomic<int> next{0}, worst{0};
     const auto t0 = clk::now();
     const bool device_like = like->kind != PCHIP_LIKE_CALLBACK && prior->kind == 1 && !std::getenv("PC_REPEATS_THREADS");
+    // (the runs leave their lived records on the device for the merge below: no second trip over the host link)
+    pchip_settings s_loc = *s;
+    if (merged && !std::getenv("PC_DEVICE_RECORDS_OFF")) s_loc.device_records = 1;
+    s = &s_loc;
     if (device_like) {
         // seeds dealt round-robin to the devices: run k on devs[k % ndev] (what the merge below assumes)
         // (a device's runs may be shared out among a few scheduler threads: one thread's launch path saturates at about eight runs)
@@ -749,7 +783,8 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
         for (int k = 0; k < nseeds && rc == 0; ++k) {
             PackJob &J = jobs[k];
             J.r = &results[k]; J.logzero = s->logzero; J.device = devs[k % devs.size()];
-            if (!J.count_records(scratch[k % devs.size()], nullptr)) rc = 7;
+            if (results[k].d_records) J.count = results[k].n_records;                 // (picked on the device when the run ended)
+            else if (!J.count_records(scratch[k % devs.size()], nullptr)) rc = 7;
             counts[k] = (long)J.count; ntot += (size_t)J.count;
         }
         DevBuf U;
@@ -763,7 +798,25 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
         for (int k = 0; k < nseeds && rc == 0; ++k) {
             PackJob &J = jobs[k];
             DevBuf &B = scratch[k % devs.size()];
-            if (J.device == devs[0]) { if (!J.scatter(B, rows_all + o * nT, entry_all + o, ownw_all + o, nullptr)) rc = 7; }
+            if (results[k].d_records) {
+                // device to device (a peer copy when the run was made on another device): rows, entry contours, own weights
+                const pchip_result &r = results[k];
+                const double *rr = r.d_records, *re = r.d_records + (size_t)r.records_cap * nT, *rw = r.d_records + (size_t)r.records_cap * (nT + 1);
+                if (J.count > 0) {
+                    if (r.records_device == devs[0]) {
+                        (void)hipSetDevice(devs[0]);
+                        if (hipMemcpyAsync(rows_all + o * nT, rr, sizeof(double) * (size_t)J.count * nT, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+                            hipMemcpyAsync(entry_all + o, re, sizeof(double) * J.count, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+                            hipMemcpyAsync(ownw_all + o, rw, sizeof(double) * J.count, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = 2;
+                    } else {
+                        (void)hipSetDevice(r.records_device);
+                        if (hipMemcpyPeerAsync(rows_all + o * nT, devs[0], rr, r.records_device, sizeof(double) * (size_t)J.count * nT, nullptr) != hipSuccess ||
+                            hipMemcpyPeerAsync(entry_all + o, devs[0], re, r.records_device, sizeof(double) * J.count, nullptr) != hipSuccess ||
+                            hipMemcpyPeerAsync(ownw_all + o, devs[0], rw, r.records_device, sizeof(double) * J.count, nullptr) != hipSuccess) rc = 2;
+                    }
+                }
+            }
+            else if (J.device == devs[0]) { if (!J.scatter(B, rows_all + o * nT, entry_all + o, ownw_all + o, nullptr)) rc = 7; }
             else if (J.count > 0) {
                 (void)hipSetDevice(J.device);
                 double *tr = B.get<double>((size_t)J.count * nT), *te = B.get<double>(2 * (size_t)J.count);
@@ -781,7 +834,7 @@ int pchip_run_repeats(const pchip_settings *s, const pchip_like *like, const pch
             std::vector<double> lz((size_t)nseeds), vz((size_t)nseeds);
             std::vector<int> cl((size_t)nseeds);
             for (int k = 0; k < nseeds; ++k) { lz[(size_t)k] = results[k].logZ; vz[(size_t)k] = results[k].varlogZ; cl[(size_t)k] = results[k].ncluster_peak > 1; }
-            rc = pchip_merge_records_ex(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, ownw_all, lz.data(), vz.data(), cl.data(), 1, 1, merged);
+            rc = pchip_merge_records_ex(s->nDims, s->nDerived, nseeds, counts.data(), rows_all, entry_all, ownw_all, lz.data(), vz.data(), cl.data(), 1, want_rows ? 1 : 0, merged);
         }
         else std::fprintf(stderr, "polychord_hip: run_repeats: packing the runs' records failed (%s)\n", hipGetErrorString(hipGetLastError()));
     }
@@ -869,7 +922,8 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
     long long mine_total = 0;
     for (int j = 0; j < nruns && !local_err; ++j) {
         J[(size_t)j].r = &runs[j]; J[(size_t)j].logzero = logzero; J[(size_t)j].device = device;
-        if (!J[(size_t)j].count_records(B, st)) local_err = fail("packing the run's records", 7);
+        if (runs[j].d_records && runs[j].records_device == device) J[(size_t)j].count = runs[j].n_records;      // (picked on the device when the run ended)
+        else if (!J[(size_t)j].count_records(B, st)) local_err = fail("packing the run's records", 7);
         mine_total += J[(size_t)j].count;
     }
     if (local_err && !coll) return local_err;
@@ -934,8 +988,16 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
     else {
         long long o = 0;
         for (int j = 0; j < nruns && !local_err; ++j) {
-            if (!J[(size_t)j].scatter(B, send + (size_t)o * nT, send + (size_t)nmax * nT + o, send + (size_t)nmax * (nT + 1) + o, st)) local_err = fail("packing the run's records", 7);
-            o += J[(size_t)j].count;
+            const pchip_result &r = runs[j];
+            const long long cj = J[(size_t)j].count;
+            if (r.d_records && r.records_device == device) {
+                if (cj > 0 && (hipMemcpyAsync(send + (size_t)o * nT, r.d_records, sizeof(double) * (size_t)cj * nT, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                               hipMemcpyAsync(send + (size_t)nmax * nT + o, r.d_records + (size_t)r.records_cap * nT, sizeof(double) * cj, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                               hipMemcpyAsync(send + (size_t)nmax * (nT + 1) + o, r.d_records + (size_t)r.records_cap * (nT + 1), sizeof(double) * cj, hipMemcpyDeviceToDevice, st) != hipSuccess))
+                    local_err = fail("copying the run's records", 2);
+            }
+            else if (!J[(size_t)j].scatter(B, send + (size_t)o * nT, send + (size_t)nmax * nT + o, send + (size_t)nmax * (nT + 1) + o, st)) local_err = fail("packing the run's records", 7);
+            o += cj;
         }
     }
     if (local_err && !coll) return local_err;

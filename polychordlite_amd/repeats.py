@@ -27,10 +27,10 @@ def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, wan
     if not seeds:
         raise ValueError("run_repeats needs at least one seed")
     lib = mg._lib()
-    f = lib.pchip_run_repeats
+    f = lib.pchip_run_repeats_ex
     f.restype = C.c_int
     f.argtypes = [C.POINTER(api.Settings), C.POINTER(api.Like), C.POINTER(api.Prior), C.c_int, C.POINTER(C.c_int), C.c_int,
-                  C.POINTER(C.c_int), C.c_int, C.POINTER(api.Result), C.POINTER(mg.Merged)]
+                  C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(api.Result), C.POINTER(mg.Merged)]
     n = len(seeds)
     sd = (C.c_int * n)(*seeds)
     devs = list(devices) if devices else []
@@ -39,7 +39,12 @@ def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, wan
     m = mg.Merged()
     import time
     t0 = time.perf_counter()
-    rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), res, C.byref(m) if comm is None else None)
+    if comm is not None and not settings.device_records:
+        # (the runs leave their lived records on the device for the exchange: no second trip over the host link)
+        s2 = api.Settings(); C.memmove(C.byref(s2), C.byref(settings), C.sizeof(settings)); s2.device_records = 1
+        settings = s2
+    rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), 1 if (want_rows or write) else 0, res,
+           C.byref(m) if comm is None else None)
     if rc != 0:
         raise RuntimeError(f"pchip_run_repeats failed with code {rc}")
     t_runs = time.perf_counter() - t0

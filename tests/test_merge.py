@@ -568,3 +568,40 @@ def test_a_failing_update_inside_a_fiber_unwinds_the_others(engine):
     assert again["logZ"] == good["logZ"] and again["nlike"] == good["nlike"] and len(runs) == len(seeds)
     for a, b in zip(gruns, runs):
         assert a["logZ"] == b["logZ"] and np.array_equal(a["dead"], b["dead"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_lived_records_left_on_the_device(engine):
+    """settings.device_records: a run leaves the records of its points that entered the live set on the device that made them (what the
+    exchange step sends), picked by the same kernels the merge uses on uploaded host arrays: the merge that reads them there must be, bit
+    for bit, the merge of the host arrays -- for a run with failed spawns (batch > 1) and for a clustered one -- and pchip_run_repeats
+    (which asks for them itself) must give the union it gave before"""
+    from polychordlite_amd import merge as mg
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    for kind, D, nDer, nlive, nr, clus, box in (("gaussian", 6, 1, 150, 12, 0, (None, None)), ("rastrigin", 3, 0, 200, 9, 1, (-5.12, 5.12))):
+        s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+        s.nlive, s.num_repeats, s.batch, s.seed, s.do_clustering, s.device_records = nlive, nr, nlive // 2, 5, clus, 1
+        L, P, keep = api.make_problem(kind, D, nDer, *box)
+        run = api.run(s, L, P)
+        lived = int((run["logweights"] > run["logzero"]).sum())
+        assert run["n_records"] == lived < run["ndead"]
+        a = mg.comm_merge(run, None, D, nDer, want_rows=True)                      # reads the device block
+        s.device_records = 0
+        run0 = api.run(s, L, P)
+        assert run0["n_records"] is None and np.array_equal(run0["dead"], run["dead"], equal_nan=True)
+        b = mg.comm_merge(run0, None, D, nDer, want_rows=True)                     # uploads the host arrays
+        assert a["records"] == b["records"] == lived and a["logZ"] == b["logZ"] and a["evidence_rule"] == b["evidence_rule"] == clus
+        assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["logweights"], b["logweights"]) and np.array_equal(a["nlive"], b["nlive"])
+        seeds = [5, 6, 7]
+        m1, r1 = run_repeats(s, L, P, seeds, max_in_flight=3, want_rows=True)       # (device records asked for by the library itself)
+        os.environ["PC_DEVICE_RECORDS_OFF"] = "1"
+        try:
+            m0, r0 = run_repeats(s, L, P, seeds, max_in_flight=3, want_rows=True)
+        finally:
+            del os.environ["PC_DEVICE_RECORDS_OFF"]
+        assert all(x["n_records"] is not None for x in r1) and all(x["n_records"] is None for x in r0)
+        assert m1["logZ"] == m0["logZ"] and np.array_equal(m1["rows"], m0["rows"]) and np.array_equal(m1["logweights"], m0["logweights"])
+        m2, _ = run_repeats(s, L, P, seeds, max_in_flight=3)                        # without the merged rows: the same evidence
+        assert m2["logZ"] == m1["logZ"] and "rows" not in m2 and np.array_equal(m2["post_mean"], m1["post_mean"])
