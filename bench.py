@@ -421,37 +421,34 @@ def reduce_over_ranks(dist, torch, device, dt, sums):
     return float(tm[0]), [float(x) for x in ts[1:]]
 
 
-def main():
-    args = parse_args()
-    rank, local_rank, world, dist, torch = bootstrap(args)
-    if args.bootstrap_only:
-        dev = "cpu" if args.backend == "gloo" else f"cuda:{local_rank}"
-        if dist is not None:
-            dist.barrier()
-        tmax, (total,) = reduce_over_ranks(dist, torch, dev, 1.0 + rank, [10.0 * (rank + 1)])
-        if rank == 0:
-            print(json.dumps({"bootstrap": "ok", "world": world, "backend": args.backend, "max": tmax, "sum": total}))
-        if dist is not None:
-            dist.barrier(); dist.destroy_process_group()
-        return
-    from polychordlite_amd import _ctypes_api as api
-    from polychordlite_amd.merge import merge_runs, Comm
-    lib = api.load()
-    if lib.pchip_device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
-    dev = f"cuda:{local_rank}"
-    # the exchange step's communicator: RCCL inside the library (its id travels through the process group the ranks were
-    # started with); one rank needs none
-    comm = Comm(rank, world, local_rank) if world > 1 else None
+class Bench:
+    """one rank of the harness: the problem, the engine's library, the process group"""
+    BIG = ("dead", "logweights", "entry", "live", "_owner")      # result arrays that are views of pinned engine buffers: not kept across steps
+    TIMED_STRIDE = 8
 
-    wl = WORKLOADS[args.workload]
-    nlive = args.nlive if args.nlive > 0 else wl["nlive"]
-    nDims, nDer, nr = wl["D"], wl["nDer"], wl["nr"]
-    cls_bit = lambda name: 1 << (api.KERNEL_CLASSES.index(name) + 1)
+    def __init__(self, args, rank, local_rank, world, dist, torch):
+        from polychordlite_amd import _ctypes_api as api
+        from polychordlite_amd.merge import Comm
+        self.args, self.rank, self.local_rank, self.world, self.dist, self.torch, self.api = args, rank, local_rank, world, dist, torch, api
+        self.lib = api.load()
+        if self.lib.pchip_device_count() < 1:
+            raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
+        self.dev = f"cuda:{local_rank}"
+        # the exchange step's communicator: RCCL inside the library (its id travels through the process group the ranks were
+        # started with); one rank needs none
+        self.comm = Comm(rank, world, local_rank) if world > 1 else None
+        self.wl = WORKLOADS[args.workload]
+        self.nlive = args.nlive if args.nlive > 0 else self.wl["nlive"]
+        self.s, self.L, self.P, self.keep = self.problem(self.wl, self.nlive, args.batch)
+        self.extras = rank == 0 and world == 1 and not args.no_extras and args.steps > 0
 
-    def problem(w, nl, batch=0):
-        s_ = api.Settings(); lib.pchip_settings_default(C.byref(s_), w["D"], w["nDer"])
-        s_.nlive = nl; s_.num_repeats = w["nr"]; s_.batch = batch; s_.device = local_rank
+    def cls_bit(self, name):
+        return 1 << (self.api.KERNEL_CLASSES.index(name) + 1)
+
+    def problem(self, w, nl, batch=0):
+        api = self.api
+        s_ = api.Settings(); self.lib.pchip_settings_default(C.byref(s_), w["D"], w["nDer"])
+        s_.nlive = nl; s_.num_repeats = w["nr"]; s_.batch = batch; s_.device = self.local_rank
         s_.do_clustering = w["clustering"]
         s_.ablate = int(os.environ.get("PC_ABLATE", "0"))      # developer switches of the engine (A/B timing of a code path), 0 in production
         if w["kind"] == "corr_gaussian":
@@ -462,120 +459,129 @@ def main():
             L_, P_, keep_ = api.make_problem(w["kind"], w["D"], w["nDer"], lo, hi)
         return s_, L_, P_, keep_
 
-    s, L, P, keep = problem(wl, nlive, args.batch)
-    # HIP-event stopwatch on the run's own stream.  Warm-up: the four kernel classes a round consists of, every launch
-    # (picks the two heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream
-    # ~6 us, every launch of two classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
-    s.profile = cls_bit("k_nhats") | cls_bit("k_slice") | cls_bit("k_consume") | cls_bit("k_apply") | cls_bit("k_bases_side")
+    def one(self, i):
+        self.s.seed = 1000 + i + 100003 * self.rank
+        return self.api.run(self.s, self.L, self.P)
 
-    def one(i):
-        s.seed = 1000 + i + 100003 * rank
-        return api.run(s, L, P)
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def reduce(self, dt, sums):
+        return reduce_over_ranks(self.dist, self.torch, self.dev, dt, sums)
 
-    top2 = ["k_slice", "k_consume"]
-    for i in range(args.warmup):
-        w = one(-1 - i)
-        merge_runs(w, comm, nDims, nDer)
-        kw = w["kernel_time"]
-        if kw:
-            top2 = sorted(kw, key=lambda n: -kw[n]["total_s"])[:2]
-        w = None
-    TIMED_STRIDE = 8
-    s.profile = sum(cls_bit(n) for n in top2) | (TIMED_STRIDE << 8)
-    sync()
-    t0 = time.perf_counter()
-    # Every step hands back its dead points in pinned host memory (zero-copy views).  Only the last step's arrays are
-    # kept (for the merge); of the earlier ones the numbers: holding all of them made every later run allocate a fresh
-    # 45 MB pinned buffer (~3 ms) instead of getting the previous one back from the engine's block cache.
-    BIG = ("dead", "logweights", "entry", "live", "_owner")
-    runs, step_ms, last = [], [], None
-    for i in range(args.steps):
-        ts0 = time.perf_counter()
-        last = None                                 # releases the previous step's result buffers
-        last = one(i)
-        runs.append({k: v for k, v in last.items() if k not in BIG})
-        step_ms.append((time.perf_counter() - ts0) * 1e3)
-    # the exchange step: all-gather of the last step's dead points (rows + entry contours) over RCCL, merged on the device
-    tm0 = time.perf_counter()
-    merged = merge_runs(last, comm, nDims, nDer) if args.steps > 0 else None
-    merge_ms = (time.perf_counter() - tm0) * 1e3
-    sync()
-    dt = time.perf_counter() - t0
-    tmax, (nlike, nfailed) = reduce_over_ranks(dist, torch, dev, dt, [float(sum(r["nlike"] for r in runs)), float(sum(r["nlike_failed"] for r in runs))])
-    last = None
-
-    cpu = CpuBaseline(wl, nlive) if (rank == 0 and world == 1 and not args.no_cpu) else None      # (runs at the very end, alone)
+    # ---- the timed region: K steps (one full run each) + the exchange of the last step's runs, barrier + sync on both sides
+    def timed_steps(self):
+        from polychordlite_amd.merge import merge_runs
+        args, s, wl = self.args, self.s, self.wl
+        nDims, nDer = wl["D"], wl["nDer"]
+        # HIP-event stopwatch on the run's own stream.  Warm-up: the kernel classes a round consists of, every launch (picks the two
+        # heaviest).  Timed steps: those two, every 8th launch of each -- an event pair costs the stream ~6 us, every launch of two
+        # classes would be ~2.5 ms of a 22 ms run, every 8th is ~0.3 ms.
+        s.profile = sum(self.cls_bit(n) for n in ("k_nhats", "k_slice", "k_consume", "k_apply", "k_bases_side"))
+        top2 = ["k_slice", "k_consume"]
+        for i in range(args.warmup):
+            w = self.one(-1 - i)
+            merge_runs(w, self.comm, nDims, nDer)
+            kw = w["kernel_time"]
+            if kw:
+                top2 = sorted(kw, key=lambda n: -kw[n]["total_s"])[:2]
+            w = None
+        s.profile = sum(self.cls_bit(n) for n in top2) | (self.TIMED_STRIDE << 8)
+        self.sync()
+        t0 = time.perf_counter()
+        # Every step hands back its dead points in pinned host memory (zero-copy views).  Only the last step's arrays are
+        # kept (for the merge); of the earlier ones the numbers: holding all of them made every later run allocate a fresh
+        # 45 MB pinned buffer (~3 ms) instead of getting the previous one back from the engine's block cache.
+        runs, step_ms, last = [], [], None
+        for i in range(args.steps):
+            ts0 = time.perf_counter()
+            last = None                                 # releases the previous step's result buffers
+            last = self.one(i)
+            runs.append({k: v for k, v in last.items() if k not in self.BIG})
+            step_ms.append((time.perf_counter() - ts0) * 1e3)
+        # the exchange step: all-gather of the last step's dead points (rows + entry contours) over RCCL, merged on the device
+        tm0 = time.perf_counter()
+        merged = merge_runs(last, self.comm, nDims, nDer) if args.steps > 0 else None
+        merge_ms = (time.perf_counter() - tm0) * 1e3
+        self.sync()
+        dt = time.perf_counter() - t0
+        tmax, (nlike, nfailed) = self.reduce(dt, [float(sum(r["nlike"] for r in runs)), float(sum(r["nlike_failed"] for r in runs))])
+        last = None
+        return dict(runs=runs, step_ms=step_ms, merged=merged, merge_ms=merge_ms, dt=dt, tmax=tmax, nlike=nlike, nfailed=nfailed)
 
     # ---- R runs of every GPU in step + the exchange of all N R runs (its own barrier-bracketed region; never part of `value`)
-    multi = None
-    if args.runs_per_gpu > 1 and args.steps > 0 and not args.no_extras and args.workload != "c5":
+    def in_step_multi(self):
+        args = self.args
+        if not (args.runs_per_gpu > 1 and args.steps > 0 and not args.no_extras and args.workload != "c5"):
+            return None
         from polychordlite_amd.repeats import run_repeats
-        R = args.runs_per_gpu
-        s_m = api.Settings(); C.memmove(C.byref(s_m), C.byref(s), C.sizeof(s)); s_m.profile = 0
+        R, api = args.runs_per_gpu, self.api
+        s_m = api.Settings(); C.memmove(C.byref(s_m), C.byref(self.s), C.sizeof(self.s)); s_m.profile = 0
+        seeds = lambda base, k: [base + 100003 * self.rank + 1000 * k + j for j in range(R)]
         for w in range(2):              # untimed: the block cache for R engines, the kernels' first launches
-            _, held = run_repeats(s_m, L, P, [300000 + 100003 * rank + 1000 * w + j for j in range(R)], max_in_flight=R, comm=comm)
+            _, held = run_repeats(s_m, self.L, self.P, seeds(300000, w), max_in_flight=R, comm=self.comm)
             held = None
         samples = []
         for k in range(3):
-            sync()
+            self.sync()
             tq0 = time.perf_counter()
-            mm, held = run_repeats(s_m, L, P, [310000 + 100003 * rank + 1000 * k + j for j in range(R)], max_in_flight=R, comm=comm)
+            mm, held = run_repeats(s_m, self.L, self.P, seeds(310000, k), max_in_flight=R, comm=self.comm)
             held = None
-            sync()
-            tq, (nl_all,) = reduce_over_ranks(dist, torch, dev, time.perf_counter() - tq0, [float(mm["nlike_local"])])
+            self.sync()
+            tq, (nl_all,) = self.reduce(time.perf_counter() - tq0, [float(mm["nlike_local"])])
             samples.append((nl_all / tq, tq, mm))
         v, tq, mm = sorted(samples, key=lambda t_: t_[0])[1]
-        multi = {"runs_per_gpu": R, "n_gpus": world, "runs": int(mm["n_runs"]), "value": v, "value_min": min(t_[0] for t_ in samples),
-                 "value_max": max(t_[0] for t_ in samples), "unit": "likelihood evals/s", "wall_ms": tq * 1e3, "exchange_ms": mm["t_merge_s"] * 1e3,
-                 "merged_logZ": mm["logZ"], "merged_logZerr": mm["logZerr"], "evidence_rule": mm.get("evidence_rule"),
-                 "runs_logZ_mean": mm["runs_logZ_mean"], "runs_logZ_sem": mm["runs_logZ_sem"],
-                 "note": "every rank: R runs in step (pchip_run_repeats), then ONE exchange of all N R runs' lived records (RCCL all-gather inside the "
-                         "library; N = 1: none) and the device merge on every rank; barrier + sync on both sides, max over ranks; median of 3"}
-        lib.polychord_hip_set_option(b"trim_cache", 0.0)
-        sync()
+        self.lib.polychord_hip_set_option(b"trim_cache", 0.0)
+        self.sync()
+        return {"runs_per_gpu": R, "n_gpus": self.world, "runs": int(mm["n_runs"]), "value": v, "value_min": min(t_[0] for t_ in samples),
+                "value_max": max(t_[0] for t_ in samples), "unit": "likelihood evals/s", "wall_ms": tq * 1e3, "exchange_ms": mm["t_merge_s"] * 1e3,
+                "merged_logZ": mm["logZ"], "merged_logZerr": mm["logZerr"], "evidence_rule": mm.get("evidence_rule"),
+                "runs_logZ_mean": mm["runs_logZ_mean"], "runs_logZ_sem": mm["runs_logZ_sem"],
+                "note": "every rank: R runs in step (pchip_run_repeats, their lived records left on the device), then ONE exchange of all N R runs' records "
+                        "(RCCL all-gather inside the library; N = 1: none) and the device merge on every rank; barrier + sync on both sides, max over ranks; median of 3"}
 
-    extras = rank == 0 and world == 1 and not args.no_extras and args.steps > 0
-    general = None
-    if extras and wl["kind"] in ("gaussian", "corr_gaussian") and args.workload != "c5":
-        # the same workload with the closed-form chord evaluation of the built-in quadratic likelihoods switched off: every
-        # trial point pays a wave reduction like any other device functor would (same trajectory up to round-off)
+    # ---- figures behind the timed region (N = 1 only; never part of `value`)
+    def general_functor(self):
+        """the same workload with the closed-form chord evaluation of the built-in quadratic likelihoods switched off: every trial point pays
+        a wave reduction like any other device functor would (same trajectory up to round-off)"""
+        if not (self.extras and self.wl["kind"] in ("gaussian", "corr_gaussian") and self.args.workload != "c5"):
+            return None
+        s = self.s
         s.ablate = 1; s.profile = 0
-        one(-100)
+        self.one(-100)
         tg0 = time.perf_counter()
-        gr = [one(-101 - k) for k in range(3)]
-        torch.cuda.synchronize()
+        gr = [self.one(-101 - k) for k in range(3)]
+        self.torch.cuda.synchronize()
         tg = time.perf_counter() - tg0
-        general = {"value": sum(r["nlike"] for r in gr) / tg, "unit": "likelihood evals/s", "ms_per_step": tg / 3 * 1e3,
-                   "logZ": [r["logZ"] for r in gr],
-                   "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
-        gr = None
         s.ablate = int(os.environ.get("PC_ABLATE", "0"))
-    conc = None
-    Rs = [int(x) for x in args.concurrent.split(",") if x.strip() and int(x) > 1] if args.concurrent else []
-    if extras and Rs:
+        return {"value": sum(r["nlike"] for r in gr) / tg, "unit": "likelihood evals/s", "ms_per_step": tg / 3 * 1e3, "logZ": [r["logZ"] for r in gr],
+                "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
+
+    def concurrent(self, Rs):
+        """R independent runs of the metric configuration in step on this GPU, for each R of the list"""
+        if not (self.extras and Rs):
+            return None
         from polychordlite_amd.repeats import run_repeats
-        s_c = api.Settings(); C.memmove(C.byref(s_c), C.byref(s), C.sizeof(s)); s_c.profile = 0
+        api, wl, nlive = self.api, self.wl, self.nlive
+        s_c = api.Settings(); C.memmove(C.byref(s_c), C.byref(self.s), C.sizeof(self.s)); s_c.profile = 0
         conc = []
         for R in Rs:
-            if R * nlive * (4 * nr + 64) * (2 * nDims + nDer + 2) * 8 * 5 > 200e9:      # phantom buffers of R engines (pool mode: twice the rows, two buffers)
+            if R * nlive * (4 * wl["nr"] + 64) * (2 * wl["D"] + wl["nDer"] + 2) * 8 * 5 > 200e9:      # phantom buffers of R engines (pool mode: twice the rows, two buffers)
                 continue
             # (untimed: the block cache for R engines, then two more calls -- on the HIP runtime PyTorch brings into this process
             #  the host phases of the calls after the first are slow now and then, 60 -> 72 ms for sixteen runs, with no trip to
             #  the driver in them; value_min / value_max keep what the timed ones saw)
             for w in range(3):
-                _, held = run_repeats(s_c, L, P, [400000 + 1000 * w + j for j in range(R)], max_in_flight=R)
+                _, held = run_repeats(s_c, self.L, self.P, [400000 + 1000 * w + j for j in range(R)], max_in_flight=R)
                 held = None
             samples = []
             for k in range(3):
                 # (the runs' result arrays are views of pinned buffers of the engine: given back before the next call, or every
                 #  run of it pins a fresh 45 MB -- 7 ms each, on the one thread that drives them all)
-                mc, held = run_repeats(s_c, L, P, [500000 + 1000 * k + j for j in range(R)], max_in_flight=R)
+                mc, held = run_repeats(s_c, self.L, self.P, [500000 + 1000 * k + j for j in range(R)], max_in_flight=R)
                 held = None
                 samples.append(mc)
             vals = sorted(m["nlike"] / m["t_runs_s"] for m in samples)
@@ -584,16 +590,22 @@ def main():
                          "unit": "likelihood evals/s", "merge_ms": mc["t_merge_s"] * 1e3, "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"],
                          "per_run_ms": mc["t_runs_s"] * 1e3 / R,
                          "whole_run_frac": mc["nlike"] * 258.0 / mc["t_runs_s"] / 8e12,      # algorithmic bytes (258 B per evaluation) / wall / 8 TB/s
-                         "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
-        lib.polychord_hip_set_option(b"trim_cache", 0.0)      # (the blocks of 64 engines: the next configurations size their buffers by what is free)
-        sync()
-    # the configurations north_star shards over the GPUs (Rastrigin, twin Gaussian: clustered runs) in step on this one
-    conc_other = {}
-    if extras and Rs and args.workload == "c2" and args.concurrent_configs:
+                         "note": "R independent runs of this GPU going round by round together (pchip_run_repeats: one stream, every kernel of a round "
+                                 "launched once for all runs, the lane-per-chain sampling kernel); each run bit for bit its solo run; median of 3 samples"})
+        self.lib.polychord_hip_set_option(b"trim_cache", 0.0)      # (the blocks of 64 engines: the next configurations size their buffers by what is free)
+        self.sync()
+        return conc
+
+    def concurrent_clustered(self, names, Rs):
+        """the configurations north_star shards over the GPUs (Rastrigin, twin Gaussian: clustered runs) in step on this one"""
+        out = {}
+        if not (self.extras and Rs and self.args.workload == "c2" and names):
+            return out
         from polychordlite_amd.repeats import run_repeats
-        for name in [x for x in args.concurrent_configs.split(",") if x.strip()]:
+        api = self.api
+        for name in names:
             w3 = WORKLOADS[name]
-            s3, L3, P3, keep3 = problem(w3, w3["nlive"])
+            s3, L3, P3, keep3 = self.problem(w3, w3["nlive"])
             s3.seed = 6999; api.run(s3, L3, P3)
             ts0 = time.perf_counter(); solo = []
             for i in range(3):
@@ -601,7 +613,7 @@ def main():
             tsolo = (time.perf_counter() - ts0) / 3
             solo_v = float(np.mean([x[0] for x in solo]) / tsolo); solo_ld = float(np.mean([x[1] for x in solo]) / tsolo)
             rows = []
-            for R in [int(x) for x in args.concurrent_clustered.split(",") if x.strip()]:
+            for R in Rs:
                 for w in range(2):
                     _, held = run_repeats(s3, L3, P3, [400000 + 1000 * w + j for j in range(R)], max_in_flight=R); held = None
                 samples = []
@@ -618,23 +630,28 @@ def main():
                              "merged_logZ": mc["logZ"], "merged_logZerr": mc["logZerr"], "evidence_rule": mc.get("evidence_rule"), "merged_logZ_replay": mc.get("logZ_replay"),
                              "runs_logZ_mean": mc["runs_logZ_mean"], "runs_logZ_sem": mc["runs_logZ_sem"], "logZ_truth": w3["truth"],
                              "whole_run_frac": mc["nlike"] * bpe3 / mc["t_runs_s"] / 1e9 / HBM_PEAK_GBS})
-            conc_other[name] = {"workload": w3["name"] % w3["nlive"], "solo": {"value": solo_v, "lived_dead_per_s": solo_ld, "ms_per_run": tsolo * 1e3,
-                                                                              "evals_per_lived_dead": float(np.sum([x[0] for x in solo]) / np.sum([x[1] for x in solo]))},
-                                "in_step": rows,
-                                "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; merged_logZ = the union's "
-                                        "evidence by the rule in evidence_rule (clustered runs: the runs' own evidences combined in linear space; merged_logZ_replay = the replay "
-                                        "of the union by ranks and live counts, DESIGN section 8); value_reference_equivalent = dead points that lived per second x the "
-                                        "reference binary's evaluations per dead point"}
-        lib.polychord_hip_set_option(b"trim_cache", 0.0)
-        sync()
-    # the other BASELINE configurations through the same engine, one timed step each (after two untimed steps that size the
-    # block cache): reported next to the headline, never part of `value`
-    others = None
-    if extras and args.workload == "c2" and args.other_configs:
+            out[name] = {"workload": w3["name"] % w3["nlive"],
+                         "solo": {"value": solo_v, "lived_dead_per_s": solo_ld, "ms_per_run": tsolo * 1e3,
+                                  "evals_per_lived_dead": float(np.sum([x[0] for x in solo]) / np.sum([x[1] for x in solo]))},
+                         "in_step": rows,
+                         "note": "R independent runs of this GPU in step (pchip_run_repeats), each bit for bit its solo run; median of 3 calls; merged_logZ = the union's "
+                                 "evidence by the rule in evidence_rule (clustered runs: the runs' own evidences combined in linear space; merged_logZ_replay = the replay "
+                                 "of the union by ranks and live counts, DESIGN section 8); value_reference_equivalent = dead points that lived per second x the "
+                                 "reference binary's evaluations per dead point"}
+        self.lib.polychord_hip_set_option(b"trim_cache", 0.0)
+        self.sync()
+        return out
+
+    def other_configs(self, names):
+        """the other BASELINE configurations through the same engine, one timed step each (after two untimed steps that size the block
+        cache): reported next to the headline, never part of `value`"""
+        if not (self.extras and self.args.workload == "c2" and names):
+            return None
+        api, torch = self.api, self.torch
         others = {}
-        for name in [x for x in args.other_configs.split(",") if x.strip()]:
+        for name in names:
             w2 = WORKLOADS[name]
-            s2, L2, P2, keep2 = problem(w2, w2["nlive"])
+            s2, L2, P2, keep2 = self.problem(w2, w2["nlive"])
             s2.profile = 1
             s2.seed = 2000
             try:
@@ -666,9 +683,14 @@ def main():
                             "bytes_per_eval": bpe2, "whole_run_frac": r2["nlike"] * bpe2 / to / 1e9 / HBM_PEAK_GBS,
                             "note": "HIP-event stopwatch around every kernel class of the run's main stream (profile = 1: a few percent slower than an untimed run)"}
             r2 = None
-        sync()
-    if rank == 0:
-        value = nlike / tmax
+        self.sync()
+        return others
+
+    # ---- the roofline block: the kernel class with the largest HIP-event time over the timed steps
+    def roofline(self, T):
+        args, wl, nlive = self.args, self.wl, self.nlive
+        nDims, nDer, nr = wl["D"], wl["nDer"], wl["nr"]
+        runs = T["runs"]
         B_ = runs[-1]["batch"]
         evals = float(sum(r["nlike"] for r in runs)); niter = float(sum(r["niter"] for r in runs))
         nurseries = float(sum(r["nbatches"] for r in runs))
@@ -676,7 +698,7 @@ def main():
         # HBM traffic per launch (PMC counters): measured now when the profiler is at hand (two short profiled runs of this
         # script behind the timed region), else the committed passes of profiles/ for the metric configuration
         pmc, pmc_src = {}, None
-        if extras and not args.no_live_pmc:
+        if self.extras and not args.no_live_pmc:
             lp = live_pmc(args.workload)
             if lp:
                 pmc, pmc_src = lp, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each, over 3 runs of this workload"
@@ -697,28 +719,58 @@ def main():
             pmc_name = {"k_consume": "k_consume_par" if wl["clustering"] == 0 else "k_consume_cl", "k_bases_side": "k_basis" if nDims > 64 else "k_nhats",
                         "k_nhats": "k_whiten" if nDims > 64 else "k_nhats"}.get(name, name)
             hit = sorted([v for k, v in pmc.items() if k.startswith(pmc_name)], key=lambda v: -v["launches"])
-            kern.append({"kernel": name, "avg_launch_us": avg * 1e6, "launches_timed": kl, "timed_every": TIMED_STRIDE,
+            kern.append({"kernel": name, "avg_launch_us": avg * 1e6, "launches_timed": kl, "timed_every": self.TIMED_STRIDE,
                          "own_bytes_per_launch": own, "own_achieved_GBs": own / avg / 1e9 if own else None,
                          "own_frac": own / avg / 1e9 / HBM_PEAK_GBS if own else None,
                          "traffic": hit[0]["hbm_bytes_per_launch"] if hit else None})
-        roof = None
-        if kern:
-            # launches of the dominant class per run: nurseries (k_slice, k_nhats) or rounds (k_consume, k_apply)
-            dom = kern[0]
-            per_launch_evals = evals / (nurseries if dom["kernel"] in ("k_slice", "k_nhats", "k_bases_side") else float(sum(r["nrounds"] for r in runs)))
-            achieved = per_launch_evals * bpe / (dom["avg_launch_us"] * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
-                    "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe, "traffic_source": pmc_src,
-                    "whole_run_frac": evals * bpe / dt / 1e9 / HBM_PEAK_GBS,
-                    "kernels": kern,
-                    "stream": "side" if dom["kernel"] == "k_bases_side" else "main",
-                    "note": "latency/parallelism bound path (SURVEY 8d): <= B chains x nDims lanes are live.  achieved = SURVEY 8(d) algorithmic "
-                            "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
-                            "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
-                            "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
-        if roof and args.workload == "c2":
+        if not kern:
+            return None
+        # launches of the dominant class per run: nurseries (k_slice, k_nhats) or rounds (k_consume, k_apply)
+        dom = kern[0]
+        per_launch_evals = evals / (nurseries if dom["kernel"] in ("k_slice", "k_nhats", "k_bases_side") else float(sum(r["nrounds"] for r in runs)))
+        achieved = per_launch_evals * bpe / (dom["avg_launch_us"] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
+                "bytes_per_launch": per_launch_evals * bpe, "bytes_per_eval": bpe, "traffic_source": pmc_src,
+                "whole_run_frac": evals * bpe / T["dt"] / 1e9 / HBM_PEAK_GBS,
+                "kernels": kern,
+                "stream": "side" if dom["kernel"] == "k_bases_side" else "main",
+                "note": "latency/parallelism bound path (SURVEY 8d): <= B chains x nDims lanes are live.  achieved = SURVEY 8(d) algorithmic "
+                        "bytes per likelihood evaluation (whole path) x evaluations of one launch / that launch's HIP-event time, for the "
+                        "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
+                        "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
+        if args.workload == "c2":
             roof["latency"] = latency_model(runs, kern)
+        return roof
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world, dist, torch = bootstrap(args)
+    if args.bootstrap_only:
+        dev = "cpu" if args.backend == "gloo" else f"cuda:{local_rank}"
+        if dist is not None:
+            dist.barrier()
+        tmax, (total,) = reduce_over_ranks(dist, torch, dev, 1.0 + rank, [10.0 * (rank + 1)])
+        if rank == 0:
+            print(json.dumps({"bootstrap": "ok", "world": world, "backend": args.backend, "max": tmax, "sum": total}))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+    b = Bench(args, rank, local_rank, world, dist, torch)
+    wl, nlive = b.wl, b.nlive
+    T = b.timed_steps()                                         # `value` comes from here and from nowhere else
+    multi = b.in_step_multi()
+    ints = lambda txt: [int(x) for x in txt.split(",") if x.strip() and int(x) > 1] if txt else []
+    names = lambda txt: [x for x in txt.split(",") if x.strip()] if txt else []
+    general = b.general_functor()
+    conc = b.concurrent(ints(args.concurrent))
+    conc_other = b.concurrent_clustered(names(args.concurrent_configs), ints(args.concurrent_clustered) if ints(args.concurrent) else [])
+    others = b.other_configs(names(args.other_configs))
+    if rank == 0:
+        runs, tmax, nlike, nfailed, merged = T["runs"], T["tmax"], T["nlike"], T["nfailed"], T["merged"]
+        value = nlike / tmax
+        roof = b.roofline(T)
         if roof and multi:
             roof["in_step_multi"] = multi
         if roof and conc:
@@ -727,13 +779,14 @@ def main():
             for nm, v_ in conc_other.items():
                 roof["in_step"] += [{"config": nm, "runs": r_["runs"], "value": r_["value"], "x_solo": r_["x_solo"], "value_reference_equivalent": r_["value_reference_equivalent"],
                                      "whole_run_frac": r_["whole_run_frac"]} for r_ in v_["in_step"]]
+        keep_merged = ("n_runs", "logZ", "logZerr", "logZ_replay", "logZerr_replay", "evidence_rule", "runs_logZ_mean", "runs_logZ_sem", "records", "post_mean", "t_merge_s")
         full = {"metric": METRIC[args.workload] % nlive, "value": value,
                 "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
                            "workload_short": wl["short"] % nlive + ", one full run per step",
-                           "batch_chains": B_, "parallelism": "repeat-sharded x%d" % world,
+                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world,
                            "mode": "one run at a time per GPU (a step = one run; every rank of --gpus N runs this mode).  R runs of a GPU in step -- its best "
                                    "mode, `concurrent*`, roofline.in_step and roofline.in_step_multi -- are reported beside it, never in `value`"},
                 "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
@@ -741,17 +794,17 @@ def main():
                 # evaluations spent on chains whose spawn failed (a nursery of B chains is seeded from ONE snapshot; the
                 # reference's one-chain loop has none): what is left is what the reference would have needed for this evidence
                 "evals_reference_equivalent": nlike - nfailed, "value_reference_equivalent": (nlike - nfailed) / tmax,
-                "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items()
-                           if k in ("n_runs", "logZ", "logZerr", "logZ_replay", "logZerr_replay", "evidence_rule", "runs_logZ_mean", "runs_logZ_sem", "records", "post_mean", "t_merge_s")} if merged else None,
-                "step_ms": step_ms, "merge_ms": merge_ms, "general_functor": general, "concurrent": conc, "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
-                "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (os.path.basename(comm.library or "?"), world)) if comm is not None else "one rank: no exchange",
+                "merged": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in merged.items() if k in keep_merged} if merged else None,
+                "step_ms": T["step_ms"], "merge_ms": T["merge_ms"], "general_functor": general, "concurrent": conc,
+                "concurrent_c3": conc_other.get("c3"), "concurrent_c4": conc_other.get("c4"), "other_configs": others, "roofline": roof,
+                "exchange": ("RCCL all-gather inside the library (%s), %d ranks" % (os.path.basename(b.comm.library or "?"), world)) if b.comm is not None else "one rank: no exchange",
                 "kernel_time": {n: v for n, v in runs[-1]["kernel_time"].items()},
                 "host_time_s": {k: runs[-1][k] for k in HOST_PHASES},
                 "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in HOST_PHASES},
                 "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                 "reference_cpu_evals_per_s_survey_container": 357e3}
-        if cpu is not None:
-            cb = cpu.finish()
+        if world == 1 and not args.no_cpu:
+            cb = CpuBaseline(wl, nlive).finish()                 # (both legs now, alone: every GPU figure has been taken)
             full["cpu_baseline"] = cb
             # wall clock of one run of the reference / of the engine: what a user waits for (the evals/s ratio also counts the
             # engine's failed spawns as work)
@@ -772,8 +825,8 @@ def main():
         sys.stdout.flush()
         print(json.dumps(compact_record(full, full_path), separators=(",", ":")))
         sys.stdout.flush()
-    if comm is not None:
-        comm.close()
+    if b.comm is not None:
+        b.comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
