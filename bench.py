@@ -297,7 +297,7 @@ def compact_record(full, full_path=None):
         if ins:
             r["in_step"] = ins
         if roof.get("in_step_multi"):
-            r["in_step_multi"] = _pick(roof["in_step_multi"], ("runs_per_gpu", "n_gpus", "runs", "value", "wall_ms", "merged_logZ", "merged_logZerr", "exchange_ms"))
+            r["in_step_multi"] = _pick(roof["in_step_multi"], ("runs_per_gpu", "n_gpus", "runs", "value", "wall_ms", "merged_logZ", "merged_logZerr", "exchange_ms", "error"))
         out["roofline"] = r
     else:
         out["roofline"] = None
@@ -760,7 +760,18 @@ def main():
     b = Bench(args, rank, local_rank, world, dist, torch)
     wl, nlive = b.wl, b.nlive
     T = b.timed_steps()                                         # `value` comes from here and from nowhere else
-    multi = b.in_step_multi()
+    if world > 1 and rank == 0:
+        # N > 1: the record of the timed region leaves BEFORE the optional legs -- R runs per GPU in step and their exchange have never run
+        # on more than one GPU, and a line that is already out survives whatever happens there.  The LAST line is the complete record.
+        early = {"metric": METRIC[args.workload] % nlive, "value": T["nlike"] / T["tmax"], "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps,
+                 "warmup": args.warmup, "ms_per_step": T["tmax"] / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                 "dtype": "f64", "data": "synthetic", "config": {"workload": wl["short"] % nlive + ", one full run per step", "parallelism": "repeat-sharded x%d" % world},
+                 "roofline": None, "cpu_baseline": None, "partial": "timed region only; the complete record follows"}
+        print(json.dumps(_num(early), separators=(",", ":")), flush=True)
+    try:
+        multi = b.in_step_multi()
+    except RuntimeError as e:                                   # (never the reason to lose the timed region's record)
+        multi = {"error": str(e)[:100], "runs_per_gpu": args.runs_per_gpu, "n_gpus": world}
     ints = lambda txt: [int(x) for x in txt.split(",") if x.strip() and int(x) > 1] if txt else []
     names = lambda txt: [x for x in txt.split(",") if x.strip()] if txt else []
     general = b.general_functor()
