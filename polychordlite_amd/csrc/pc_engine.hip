@@ -366,12 +366,18 @@ struct StreamClasses {
 static StreamClasses &sclasses() { static StreamClasses *p = new StreamClasses; return *p; }
 // a pooled (or new) stream that runs next to all of `others` (null entries ignored): one whose class is known first, then the
 // pool's unknown ones, classed as they come; the ones found wanting go back to the pool
+static hipStream_t stream_avoiding(std::vector<int> avoid);
 static hipStream_t stream_beside(std::initializer_list<hipStream_t> others)
 {
     static const bool off = std::getenv("PC_SIDE_PICK_OFF") != nullptr;
     if (off) return hpool().get_stream();
     std::vector<int> avoid;
     for (hipStream_t o : others) if (o) avoid.push_back(sclasses().classify(o));
+    return stream_avoiding(avoid);
+}
+// ... next to every stream of the hardware-queue classes in `avoid`
+static hipStream_t stream_avoiding(std::vector<int> avoid)
+{
     auto fits = [&](int c) { return c >= 0 && std::find(avoid.begin(), avoid.end(), c) == avoid.end(); };
     if (hipStream_t k = hpool().take_stream_if([&](hipStream_t x) { return fits(sclasses().known(x)); })) return k;
     std::vector<hipStream_t> tried;
@@ -392,6 +398,19 @@ static hipStream_t stream_beside(std::initializer_list<hipStream_t> others)
     return pick;
 }
 static hipStream_t side_stream_for(hipStream_t main_st) { return stream_beside({main_st}); }
+// The hardware-queue classes the scheduler groups at work on a device have taken for their main and side streams.  Two groups side by
+// side (clustered runs: pchip_run_repeats) each picked their streams from the pool on their own, and now and then both main streams sat
+// on ONE hardware queue: their kernels took turns, sixteen twin-Gaussian runs 590 ms instead of 370 -- which of the two a process got
+// depended on what it had done before (a merge, a torch.cuda.synchronize: whatever moved the pool's order).  A group now takes streams
+// of classes no other group of its device holds, while there are any.
+struct CohortStreams {
+    std::mutex m;
+    std::vector<std::pair<int, int>> used;      // (device, class)
+    std::vector<int> busy(int dev) { std::vector<int> b; for (auto &u : used) if (u.first == dev) b.push_back(u.second); return b; }
+    void take(int dev, int c) { if (c >= 0) used.emplace_back(dev, c); }
+    void give(int dev, int c) { for (size_t i = 0; i < used.size(); ++i) if (used[i].first == dev && used[i].second == c) { used.erase(used.begin() + (long)i); return; } }
+};
+static CohortStreams &cstreams() { static CohortStreams *p = new CohortStreams; return *p; }
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
 std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
@@ -2828,17 +2847,25 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         //  launch is then there -- a call's first wait was 10 ... 24 ms now and then while the pair changed from call to call)
         static std::mutex last_m; static hipStream_t last_st[64] = {nullptr}, last_st2[64] = {nullptr};
         int devq = 0; (void)hipGetDevice(&devq); devq &= 63;
+        int cls_main = -1, cls_side = -1;
         if (prio_off || plo == phi) {
             hipStream_t want, want2;
             { std::lock_guard<std::mutex> g(last_m); want = last_st[devq]; want2 = last_st2[devq]; }
-            if (want) co.st = hpool().take_stream_if([&](hipStream_t x) { return x == want; });
-            if (!co.st) co.st = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) >= 0; });
-            if (!co.st) co.st = hpool().get_stream();
+            std::lock_guard<std::mutex> gq(cstreams().m);             // (one group at a time picks: what it takes the next one avoids)
+            std::vector<int> busy = cstreams().busy(devq);
+            auto free_cls = [&](hipStream_t x) { const int c = sclasses().known(x); return c >= 0 && std::find(busy.begin(), busy.end(), c) == busy.end(); };
+            if (want) co.st = hpool().take_stream_if([&](hipStream_t x) { return x == want && (busy.empty() || free_cls(x)); });
+            if (!co.st) co.st = hpool().take_stream_if([&](hipStream_t x) { return busy.empty() ? sclasses().known(x) >= 0 : free_cls(x); });
+            if (!co.st) co.st = busy.empty() ? hpool().get_stream() : stream_avoiding(busy);
             const auto Tp2 = std::chrono::steady_clock::now();
+            if (!busy.empty() || !side_off) cls_main = sclasses().classify(co.st);
             if (!side_off) {
-                if (co.st == want && want2) co.st2 = hpool().take_stream_if([&](hipStream_t x) { return x == want2; });
-                if (!co.st2) co.st2 = side_stream_for(co.st);
+                busy.push_back(cls_main);
+                if (co.st == want && want2) co.st2 = hpool().take_stream_if([&](hipStream_t x) { return x == want2 && free_cls(x); });
+                if (!co.st2) co.st2 = stream_avoiding(busy);
+                cls_side = sclasses().classify(co.st2);
             }
+            cstreams().take(devq, cls_main); cstreams().take(devq, cls_side);
             { std::lock_guard<std::mutex> g(last_m); last_st[devq] = co.st; last_st2[devq] = co.st2; }
             if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
@@ -3069,6 +3096,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         co.destroy();
         if (h_totals) hfree(h_totals);
         (void)hipStreamSynchronize(co.st);
+        { std::lock_guard<std::mutex> gq(cstreams().m); cstreams().give(devq, cls_main); cstreams().give(devq, cls_side); }
         if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
         if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
         for (int q = 0; q < 2; ++q) if (co.stc[q]) { (void)hipStreamSynchronize(co.stc[q]); hpool().put_stream(co.stc[q]); co.stc[q] = nullptr; }
