@@ -366,20 +366,26 @@ struct StreamClasses {
 static StreamClasses &sclasses() { static StreamClasses *p = new StreamClasses; return *p; }
 // a pooled (or new) stream that runs next to all of `others` (null entries ignored): one whose class is known first, then the
 // pool's unknown ones, classed as they come; the ones found wanting go back to the pool
-static hipStream_t stream_avoiding(std::vector<int> avoid);
-static hipStream_t stream_beside(std::initializer_list<hipStream_t> others)
+static hipStream_t stream_avoiding(std::vector<int> avoid, bool known_only = false);
+static hipStream_t stream_beside(std::initializer_list<hipStream_t> others, bool known_only = false)
 {
     static const bool off = std::getenv("PC_SIDE_PICK_OFF") != nullptr;
     if (off) return hpool().get_stream();
     std::vector<int> avoid;
-    for (hipStream_t o : others) if (o) avoid.push_back(sclasses().classify(o));
-    return stream_avoiding(avoid);
+    for (hipStream_t o : others) if (o) { const int c = known_only ? sclasses().known(o) : sclasses().classify(o); if (c >= 0) avoid.push_back(c); }
+    return stream_avoiding(avoid, known_only);
 }
-// ... next to every stream of the hardware-queue classes in `avoid`
-static hipStream_t stream_avoiding(std::vector<int> avoid)
+// ... next to every stream of the hardware-queue classes in `avoid`.  known_only: the device is at work (another scheduler group's runs):
+// a class test now -- two spin kernels timed side by side -- would say "one queue" for whatever pair it is given, and the wrong class would
+// stay with the stream; only streams classed earlier (pc_prepare_streams) are looked at, the best of them taken
+static hipStream_t stream_avoiding(std::vector<int> avoid, bool known_only)
 {
     auto fits = [&](int c) { return c >= 0 && std::find(avoid.begin(), avoid.end(), c) == avoid.end(); };
     if (hipStream_t k = hpool().take_stream_if([&](hipStream_t x) { return fits(sclasses().known(x)); })) return k;
+    if (known_only) {
+        if (hipStream_t k = hpool().take_stream_if([&](hipStream_t x) { return sclasses().known(x) >= 0; })) return k;
+        return hpool().get_stream();
+    }
     std::vector<hipStream_t> tried;
     hipStream_t pick = nullptr;
     for (int k = 0; k < 8 && !pick; ++k) {
@@ -405,12 +411,34 @@ static hipStream_t side_stream_for(hipStream_t main_st) { return stream_beside({
 // of classes no other group of its device holds, while there are any.
 struct CohortStreams {
     std::mutex m;
-    std::vector<std::pair<int, int>> used;      // (device, class)
-    std::vector<int> busy(int dev) { std::vector<int> b; for (auto &u : used) if (u.first == dev) b.push_back(u.second); return b; }
-    void take(int dev, int c) { if (c >= 0) used.emplace_back(dev, c); }
-    void give(int dev, int c) { for (size_t i = 0; i < used.size(); ++i) if (used[i].first == dev && used[i].second == c) { used.erase(used.begin() + (long)i); return; } }
+    std::vector<std::pair<int, int>> used;      // (device, class; main streams' classes carry + 1000)
+    std::vector<int> busy(int dev, bool mains_only = false)
+    {
+        std::vector<int> b;
+        for (auto &u : used) if (u.first == dev && (!mains_only || u.second >= 1000)) b.push_back(u.second % 1000);
+        return b;
+    }
+    void take(int dev, int c, bool main_stream = false) { if (c >= 0) used.emplace_back(dev, c + (main_stream ? 1000 : 0)); }
+    void give(int dev, int c) { for (size_t i = 0; i < used.size(); ++i) if (used[i].first == dev && used[i].second % 1000 == c) { used.erase(used.begin() + (long)i); return; } }
 };
 static CohortStreams &cstreams() { static CohortStreams *p = new CohortStreams; return *p; }
+// called before several scheduler groups start on a device, while it is idle: the pool gets at least `want` streams whose hardware-queue
+// class is known (a group takes four: main, side, two for copies), so that no group has to class a stream while another group's kernels run
+extern "C" void pc_prepare_streams(int dev, int want)
+{
+    if (hipSetDevice(dev) != hipSuccess) return;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> gq(cstreams().m);
+    std::vector<hipStream_t> have;
+    while (hipStream_t k = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) >= 0; })) have.push_back(k);
+    for (int tries = 0; (int)have.size() < want && tries < 4 * want; ++tries) {
+        hipStream_t c = hpool().take_stream_if([](hipStream_t x) { return sclasses().known(x) < 0; });
+        if (!c && hipStreamCreate(&c) != hipSuccess) break;
+        (void)sclasses().classify(c);
+        have.push_back(c);
+    }
+    for (hipStream_t k : have) hpool().put_stream(k);
+}
 std::atomic<int> g_active_runs{0};         // runs in flight in this process (pchip_run_repeats: one thread each)
 std::atomic<int> g_active_dev[64];         // ... per HIP device (zero-initialised: static storage)
 
@@ -2848,30 +2876,35 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         static std::mutex last_m; static hipStream_t last_st[64] = {nullptr}, last_st2[64] = {nullptr};
         int devq = 0; (void)hipGetDevice(&devq); devq &= 63;
         int cls_main = -1, cls_side = -1;
+        bool cohort_loaded = false;
         if (prio_off || plo == phi) {
             hipStream_t want, want2;
             { std::lock_guard<std::mutex> g(last_m); want = last_st[devq]; want2 = last_st2[devq]; }
             std::lock_guard<std::mutex> gq(cstreams().m);             // (one group at a time picks: what it takes the next one avoids)
             std::vector<int> busy = cstreams().busy(devq);
+            const bool loaded = !busy.empty();                    // another group is at work on this device: no class tests now
+            // (more groups than hardware queues can keep apart: at least not on another group's MAIN stream's queue)
+            if (busy.size() >= 4) busy = cstreams().busy(devq, true);
             auto free_cls = [&](hipStream_t x) { const int c = sclasses().known(x); return c >= 0 && std::find(busy.begin(), busy.end(), c) == busy.end(); };
             if (want) co.st = hpool().take_stream_if([&](hipStream_t x) { return x == want && (busy.empty() || free_cls(x)); });
             if (!co.st) co.st = hpool().take_stream_if([&](hipStream_t x) { return busy.empty() ? sclasses().known(x) >= 0 : free_cls(x); });
-            if (!co.st) co.st = busy.empty() ? hpool().get_stream() : stream_avoiding(busy);
+            if (!co.st) co.st = busy.empty() ? hpool().get_stream() : stream_avoiding(busy, loaded);
             const auto Tp2 = std::chrono::steady_clock::now();
-            if (!busy.empty() || !side_off) cls_main = sclasses().classify(co.st);
+            if (!busy.empty() || !side_off) cls_main = loaded ? sclasses().known(co.st) : sclasses().classify(co.st);
             if (!side_off) {
-                busy.push_back(cls_main);
+                if (cls_main >= 0) busy.push_back(cls_main);
                 if (co.st == want && want2) co.st2 = hpool().take_stream_if([&](hipStream_t x) { return x == want2 && free_cls(x); });
-                if (!co.st2) co.st2 = stream_avoiding(busy);
-                cls_side = sclasses().classify(co.st2);
+                if (!co.st2) co.st2 = stream_avoiding(busy, loaded);
+                cls_side = loaded ? sclasses().known(co.st2) : sclasses().classify(co.st2);
             }
-            cstreams().take(devq, cls_main); cstreams().take(devq, cls_side);
+            cohort_loaded = loaded;
+            cstreams().take(devq, cls_main, true); cstreams().take(devq, cls_side);
             { std::lock_guard<std::mutex> g(last_m); last_st[devq] = co.st; last_st2[devq] = co.st2; }
             if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
         if (co.st2) { co.ev_up = hpool().get_sync_event(); co.ev_next = hpool().get_sync_event(); }
         static const bool stc_off = std::getenv("PC_COHORT_COPY_STREAMS") && std::atoi(std::getenv("PC_COHORT_COPY_STREAMS")) == 0;
-        if (!stc_off && !own_streams) { co.stc[0] = stream_beside({co.st, co.st2}); co.stc[1] = stream_beside({co.st, co.st2, co.stc[0]}); }
+        if (!stc_off && !own_streams) { co.stc[0] = stream_beside({co.st, co.st2}, cohort_loaded); co.stc[1] = stream_beside({co.st, co.st2, co.stc[0]}, cohort_loaded); }
         std::vector<Engine *> E((size_t)n, nullptr);
         std::vector<char> live((size_t)n, 0), enq((size_t)n, 0);
         const auto T0 = std::chrono::steady_clock::now();

@@ -34,6 +34,7 @@
 #include <rccl/rccl.h>          // types and enums only: the library is dlopen'ed (no link-time dependency on RCCL)
 
 extern "C" int pc_run_many(const pchip_settings *, const pchip_like *, const pchip_prior *, int, const int *, int, int, pchip_result *);
+extern "C" void pc_prepare_streams(int dev, int want);
 
 namespace {
 
@@ -732,8 +733,13 @@ int pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const 
         // (runs with clustering: two groups going round by round side by side -- while one group's contractions hold a wavefront each, the
         //  other samples or updates; measured at BASELINE configs[2] / [3], sixteen runs: 969 -> ~780 ms, 541 -> ~400 ms.  One-cluster
         //  Gaussian runs fill the chip with one group, and two were slower: DESIGN section 5f)
-        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : ((s->do_clustering && per_dev >= 8) ? 2 : 1);
+        // (round 5: four groups of at least four runs each -- one main stream per hardware queue, which the groups now keep apart
+        //  (CohortStreams, pc_engine.hip); sixteen runs of configs[2] / [3]: 495 / 386 ms with two groups, 430 / 340 with four; with six or
+        //  eight groups main streams share queues again and the call takes twice as long)
+        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : ((s->do_clustering && per_dev >= 8) ? std::min(4, per_dev / 4) : 1);
         const int nd = (int)devs.size();
+        // (several groups on a device: streams of known hardware-queue classes for all of them, classed now, while the device is idle)
+        if (sched > 1) for (int d : devs) pc_prepare_streams(d, 4 * sched);
         auto work = [&](int wi) {
             const int di = wi % nd, part = wi / nd;
             std::vector<int> mine, idx;
