@@ -19,8 +19,15 @@ for q, L in sorted(byq.items()):
     tot = collections.Counter(); cnt = collections.Counter()
     for s, e, n, *_ in L: tot[short(n)] += e - s; cnt[short(n)] += 1
     print("queue %d: %d launches, busy %.1f ms (%.0f%% of window); first +%.1f ms, last +%.1f ms" % (q, len(L), busy / 1e6, 100.0 * busy / span, (L[0][0] - W[0][0]) / 1e6, (L[-1][1] - W[0][0]) / 1e6))
-    for n, t in tot.most_common(9): print("    %-42s %6d x %8.1f us = %8.2f ms" % (n, cnt[n], t / cnt[n] / 1e3, t / 1e6))
+    for n, t in tot.most_common(int(sys.argv[4]) if len(sys.argv) > 4 else 9): print("    %-42s %6d x %8.1f us = %8.2f ms" % (n, cnt[n], t / cnt[n] / 1e3, t / 1e6))
     if main_q is None and any("consume" in short(n) for n in tot): main_q = q
+    # idle time of the queue by what ran in front of the gap / behind it (gaps of more than 3 us)
+    gb = collections.Counter(); ga = collections.Counter(); gn = collections.Counter(); idle = 0
+    for (s0, e0, n0, *_), (s1, e1, n1, *_) in zip(L, L[1:]):
+        g = s1 - e0
+        if g > 3000: gb[short(n0)] += g; ga[short(n1)] += g; gn[short(n0)] += 1; idle += g
+    print("    idle in gaps > 3 us: %.1f ms; by the kernel in front: %s" % (idle / 1e6, ", ".join("%s %.1f ms/%d" % (k, v / 1e6, gn[k]) for k, v in gb.most_common(8))))
+    print("    by the kernel behind: %s" % ", ".join("%s %.1f ms" % (k, v / 1e6) for k, v in ga.most_common(8)))
 if main_q is not None:
     L = byq[main_q]; mid = L[len(L) // 2][0]
     print("queue %d, %.1f ms from the middle (gap in front, duration, grid):" % (main_q, stretch))
