@@ -283,6 +283,58 @@ __global__ __launch_bounds__(256) void k_ph_rehome(PcState S, int nph, int nc, c
     (void)nc;
 }
 
+// The same for nDims <= 32 (round 5): lane = phantom with its coordinates in registers, two wavefronts to 64 phantoms that take every
+// other live point of a tile -- all lanes read the SAME live point, one LDS broadcast per two coordinates.  The kernel above reads both
+// operands of every difference from LDS (two reads per multiply-add: 150-190 us a split at configs[2], the LDS pipe's time; this one
+// 35).  Rows are padded with zeros to DM coordinates on both sides: (0 - 0)^2 adds +0 to the same sum, term for term in the same order.
+template <int DM>
+__global__ __launch_bounds__(128) void k_ph_rehome_r(PcState S, int nph, const unsigned *old_uids, int nold_uids)
+{
+    constexpr int T = 128;
+    __shared__ __attribute__((aligned(16))) double ys[T * DM];
+    __shared__ int ykey[T];
+    __shared__ double bd[64];
+    __shared__ int bk[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, D = S.D, nT = S.nT, Ncap = S.Ncap;
+    const int j = blockIdx.x * 64 + lane;
+    double x[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) x[d] = (j < nph && d < D) ? S.phantom[(size_t)j * nT + d] : 0.0;
+    double best = PC_HUGE; int bkey = 0x7fffffff;
+    for (int t0 = 0; t0 < Ncap; t0 += T) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < DM; ++u) {
+            const int e = tid + 128 * u, q = e / DM, d = e - q * DM, s = t0 + q;
+            ys[e] = (s < Ncap && d < D) ? S.live[(size_t)s * nT + d] : 0.0;
+        }
+        { const int s = t0 + tid; const int c = (s < Ncap) ? S.live_cluster[s] : -1; ykey[tid] = (c >= 0) ? c * Ncap + S.live_pos[s] : -1; }
+        __syncthreads();
+#pragma unroll 2
+        for (int q = wv; q < T; q += 2) {
+            const int key = ykey[q];
+            if (key < 0) continue;
+            const double *y = ys + q * DM;
+            double d2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DM; ++d) { const double t = x[d] - y[d]; d2 += t * t; }
+            if (d2 < best || (d2 == best && key < bkey)) { best = d2; bkey = key; }
+        }
+    }
+    if (wv == 1) { bd[lane] = best; bk[lane] = bkey; }
+    __syncthreads();
+    if (wv == 0 && j < nph) {
+        const double v = bd[lane]; const int kk = bk[lane];
+        if (v < best || (v == best && kk < bkey)) { best = v; bkey = kk; }
+        // phantoms of clusters that no longer exist are gone (run_time_info.f90:367-368 saves live clusters only)
+        const unsigned u = S.ph_cuid[j];
+        bool ok = false;
+        for (int q = 0; q < nold_uids; ++q) ok |= (old_uids[q] == u);
+        if (!ok) S.ph_cuid[j] = 0xFFFFFFFFu;
+        else { const int c = bkey / Ncap; S.ph_cuid[j] = (S.ph_logL[j] > S.logLp[c]) ? S.cl_uid[c] : 0xFFFFFFFFu; }
+    }
+}
+
 // number of phantoms per cluster uid (fixed order: one workgroup, serial accumulation per cluster)
 __global__ __launch_bounds__(256) void k_ph_count(PcState S, int nph, int nc, int *counts)
 {
@@ -509,7 +561,14 @@ void pc_launch_rebuild(const PcState *S, int nc, hipStream_t st)
 
 void pc_launch_ph_rehome(const PcState *S, int nph, int nc, const unsigned *old_uids, int nold_uids, int *counts, hipStream_t st)
 {
-    if (nph > 0) {
+    if (nph > 0 && S->D <= 32) {
+        const dim3 g((nph + 63) / 64), b(128);
+        switch ((S->D + 3) / 4) {
+#define PC_R(n) case n: hipLaunchKernelGGL((k_ph_rehome_r<4 * n>), g, b, 0, st, *S, nph, old_uids, nold_uids); break;
+            PC_R(1) PC_R(2) PC_R(3) PC_R(4) PC_R(5) PC_R(6) PC_R(7) PC_R(8)
+#undef PC_R
+        }
+    } else if (nph > 0) {
         const int DP = S->D | 1;
         const size_t sh = sizeof(double) * ((size_t)(PHR_P + PHR_T) * DP + 256) + sizeof(int) * (PHR_T + 256 + PHR_P);
         pc_need_dyn_lds((const void *)k_ph_rehome, sh);

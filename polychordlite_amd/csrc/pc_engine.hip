@@ -1551,21 +1551,42 @@ struct Engine {
     }
     template <class T> void ul(T *p, const std::vector<T> &v) { send_raw(p, v.data(), sizeof(T) * v.size()); }
 
+    // What the host's half of a split reads: the points' (cluster, position) labels and the clusters' volumes, evidences, thresholds,
+    // ids, cross-volume rows -- the first nc entries / rows; what lies behind them stays what it is on the device.  Asked for with the
+    // verdicts of the update's first clustering pass (do_clustering: the same wait), it serves every split of the update: a split
+    // leaves on the host exactly what it sends up, so the splits of an update cost one wait each (the phantoms' counts), not two.
+    struct ClusterMirror {
+        bool valid = false; int maxc = 0;
+        std::vector<int> lc, lp; std::vector<double> Xp, ZXp, Zp, Zp2, ZpXp, thr, XQ; std::vector<unsigned> uid;
+    } cmir;
+    void cmir_ask()
+    {
+        const int nc = h_ctl->ncluster, maxc = S.maxc, Ncap = S.Ncap;
+        cmir.lc.resize(Ncap); cmir.lp.resize(Ncap);
+        for (std::vector<double> *v : {&cmir.Xp, &cmir.ZXp, &cmir.Zp, &cmir.Zp2, &cmir.ZpXp, &cmir.thr}) v->resize(maxc);
+        cmir.XQ.resize((size_t)maxc * maxc); cmir.uid.resize(maxc);
+        fetch_raw(cmir.lc.data(), S.live_cluster, sizeof(int) * Ncap); fetch_raw(cmir.lp.data(), S.live_pos, sizeof(int) * Ncap);
+        fetch_raw(cmir.Xp.data(), S.logXp, sizeof(double) * nc); fetch_raw(cmir.ZXp.data(), S.logZXp, sizeof(double) * nc);
+        fetch_raw(cmir.Zp.data(), S.logZp, sizeof(double) * nc); fetch_raw(cmir.Zp2.data(), S.logZp2, sizeof(double) * nc);
+        fetch_raw(cmir.ZpXp.data(), S.logZpXp, sizeof(double) * nc); fetch_raw(cmir.thr.data(), S.death_thr, sizeof(double) * nc);
+        fetch_raw(cmir.XQ.data(), S.XpXq, sizeof(double) * (size_t)nc * maxc); fetch_raw(cmir.uid.data(), S.cl_uid, sizeof(unsigned) * nc);
+        cmir.maxc = maxc;
+    }
+
     // add_cluster (run_time_info.f90:303-505): cluster p splits into nnew clusters appended at the end
     void add_cluster(int p, const std::vector<int> &labels, int nnew)
     {
         const int nc = h_ctl->ncluster, nold = nc - 1, ncn = nc + nnew - 1, Ncap = S.Ncap;
         if (g_inject_fault.load() == 2) { g_inject_fault = 0; engine_fail(PC_RC_LIMIT, "more than %d clusters (injected)", nc); }
-        if (ncn > S.maxc) grow_clusters(ncn);
+        if (ncn > S.maxc) { grow_clusters(ncn); cmir.valid = false; }
         const int maxc = S.maxc;
         nsplits++;
-        // everything the host's half of the split reads, in ONE wait (a run in step shares it with the others)
-        std::vector<int> lc, lp; std::vector<double> Xp, ZXp, Zp, Zp2, ZpXp, thr, XQ; std::vector<unsigned> uid;
-        fetch(lc, (const int *)S.live_cluster, Ncap); fetch(lp, (const int *)S.live_pos, Ncap);
-        fetch(Xp, (const double *)S.logXp, maxc); fetch(ZXp, (const double *)S.logZXp, maxc); fetch(Zp, (const double *)S.logZp, maxc); fetch(Zp2, (const double *)S.logZp2, maxc);
-        fetch(ZpXp, (const double *)S.logZpXp, maxc); fetch(thr, (const double *)S.death_thr, maxc); fetch(XQ, (const double *)S.XpXq, (size_t)maxc * maxc);
-        fetch(uid, (const unsigned *)S.cl_uid, maxc);
-        fetch_wait();
+        // everything the host's half of the split reads: there since the update's first pass, or asked for now in ONE wait (a run in step
+        // shares it with the others)
+        if (!cmir.valid || cmir.maxc != maxc) { cmir_ask(); fetch_wait(); cmir.valid = true; }
+        std::vector<int> &lc = cmir.lc, &lp = cmir.lp; std::vector<double> &Xp = cmir.Xp, &ZXp = cmir.ZXp, &Zp = cmir.Zp, &Zp2 = cmir.Zp2, &ZpXp = cmir.ZpXp, &thr = cmir.thr, &XQ = cmir.XQ;
+        std::vector<unsigned> &uid = cmir.uid;
+        auto uln = [&](auto *dst, const auto &v, size_t n) { send_raw(dst, v.data(), sizeof(v[0]) * n); };
         // position of every split point inside its new cluster = rank among equal labels in list order
         std::vector<int> posnew(labels.size()), cnt(nnew, 0);
         for (size_t a = 0; a < labels.size(); ++a) posnew[a] = cnt[labels[a] - 1]++;
@@ -1593,7 +1614,7 @@ struct Engine {
         direct_op();
         pc_launch_shift_mats(&S, p, nc, st);
         for (int k = 0; k < nnew; ++k) { uid[nold + k] = h_ctl->next_cluster_uid++; thr[nold + k] = -PC_HUGE; }
-        ul(S.cl_uid, uid); ul(S.death_thr, thr);
+        uln(S.cl_uid, uid, (size_t)ncn); uln(S.death_thr, thr, (size_t)ncn);
         // lists, contours, live log-sum-exp of every cluster; then the phantoms find their new homes
         direct_op();
         pc_launch_rebuild(&S, ncn, st);
@@ -1621,7 +1642,8 @@ struct Engine {
             for (int b = 0; b < nnew; ++b)
                 XQ[(size_t)(nold + a) * maxc + nold + b] = (a == b) ? logXp2 + logni[a] + logni1[a] - logn - logn1
                                                                      : logXp2 + logni[a] + logni[b] - logn - logn1;
-        ul(S.logXp, Xp); ul(S.logZXp, ZXp); ul(S.logZp, Zp); ul(S.logZp2, Zp2); ul(S.logZpXp, ZpXp); ul(S.XpXq, XQ);
+        uln(S.logXp, Xp, (size_t)ncn); uln(S.logZXp, ZXp, (size_t)ncn); uln(S.logZp, Zp, (size_t)ncn); uln(S.logZp2, Zp2, (size_t)ncn); uln(S.logZpXp, ZpXp, (size_t)ncn);
+        uln(S.XpXq, XQ, (size_t)ncn * maxc);
         h_ctl->ncluster = ncn;
         ncluster_peak = std::max(ncluster_peak, ncn);
     }
@@ -1702,6 +1724,8 @@ struct Engine {
     {
         ensure_cluster_scratch();
         bool found = false;
+        cmir.valid = false;                              // (the contraction has moved volumes and evidences since the last update)
+        struct MirrorEnds { ClusterMirror &m; ~MirrorEnds() { m.valid = false; } } mirror_ends{cmir};
         const int nold = h_ctl->ncluster;
         if (c_desc_cap < nold) { dfree(c_desc); dfree(c_bout); c_desc_cap = std::max(2 * nold, 64); c_desc = dalloc<int>((size_t)4 * c_desc_cap); c_bout = dalloc<int>(c_desc_cap); }
         if ((int)cn.size() != nold) cn = dl(S.cl_n, (size_t)nold);
@@ -1725,7 +1749,9 @@ struct Engine {
                 std::vector<int> out, lab0;
                 fetch(out, (const int *)c_bout, (size_t)nd);
                 fetch(lab0, (const int *)c_lab, (size_t)o1);       // (the first pass' labels of every cluster: a few KB, the same wait)
+                cmir_ask();                                        // (and what a split will read, should the pass find one)
                 fetch_wait();
+                cmir.valid = true;
                 for (int k = 0; k < nd; ++k) verdict[which[k]] = out[k];
                 refined = refine_partitions(desc, which, out, lab0, final_labels, final_num);
             } else for (int c = 0; c < nold; ++c) verdict[c] = cn[c] > 2 ? 2 : 1;      // (no first pass: look at every cluster)
