@@ -103,6 +103,20 @@ SLICE_CYCLE_FILES = ("r05_slice_cycles.json", "r04_slice_cycles.json", "r03_slic
 PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")
 
 
+def committed_record(names, need):
+    """the first of profiles/<names> that is there, parses and holds the keys `need`: (record, name) or (None, None).  A profile that a
+    failed collection left empty or half-written must not take the bench line down with it"""
+    for n in names:
+        pth = os.path.join(ROOT, "profiles", n)
+        try:
+            rec = json.load(open(pth))
+        except (OSError, ValueError):
+            continue
+        if isinstance(rec, dict) and all(k in rec for k in need):
+            return rec, n
+    return None, None
+
+
 def latency_model(runs, kern):
     """modelled minimum cycles per slice (dependent-operation count x measured single-wave latencies) next to the measured ones"""
     ks = [k for k in kern if k["kernel"] == "k_slice"]
@@ -116,11 +130,10 @@ def latency_model(runs, kern):
     out = {"unit": "shader cycles per slice (one wavefront = one chain, 2.4 GHz)", "model_min_by_section": model, "model_min": sum(model.values()),
            "dependent_fp64_cycles": DEP_FP64_CYCLES, "lds_round_trip_cycles": LDS_CYCLES, "evaluations_per_slice": evals_per_slice,
            "chain": {k: v[2] for k, v in SLICE_CHAIN.items()}}
-    pth = next((q for q in (os.path.join(ROOT, "profiles", n) for n in SLICE_CYCLE_FILES) if os.path.exists(q)), None)
-    if pth:
-        m = json.load(open(pth))
+    m, src = committed_record(SLICE_CYCLE_FILES, ("cycles_per_slice", "cycles_per_slice_total"))
+    if m:
         out["measured_by_section"] = m["cycles_per_slice"]; out["measured"] = m["cycles_per_slice_total"]
-        out["measured_source"] = "profiles/%s (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)" % os.path.basename(pth)
+        out["measured_source"] = "profiles/%s (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)" % src
         out["frac_of_model"] = out["model_min"] / m["cycles_per_slice_total"]
     if ks:
         out["launch_cycles_per_slice_this_run"] = ks[0]["avg_launch_us"] * CLOCK_MHZ / nr      # whole launch / slices: includes seed choice, shuffle, whitening, derived parameters
@@ -325,6 +338,8 @@ def compact_record(full, full_path=None):
     if oc:
         out["other_configs"] = {n: (_pick(v, ("value", "ms_per_step", "logZ", "logZerr", "logZ_truth", "evals_per_lived_dead", "dominant_kernel", "whole_run_frac"))
                                     if "error" not in v else {"error": str(v["error"])[:80]}) for n, v in oc.items()}
+    if full.get("leg_errors"):
+        out["leg_errors"] = {k: str(v)[:80] for k, v in list(full["leg_errors"].items())[:6]}
     if full_path:
         out["full_record"] = full_path
     out = _num(out)
@@ -430,6 +445,7 @@ class Bench:
         from polychordlite_amd import _ctypes_api as api
         from polychordlite_amd.merge import Comm
         self.args, self.rank, self.local_rank, self.world, self.dist, self.torch, self.api = args, rank, local_rank, world, dist, torch, api
+        self.leg_errors = {}
         self.lib = api.load()
         if self.lib.pchip_device_count() < 1:
             raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
@@ -686,6 +702,15 @@ class Bench:
         self.sync()
         return others
 
+    # ---- a leg behind the timed region: whatever goes wrong in it is written into the record, and the record still leaves
+    def leg(self, name, fn, default):
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001 -- the line the driver parses must not depend on an optional figure
+            self.leg_errors[name] = ("%s: %s" % (type(e).__name__, e))[:160]
+            sys.stderr.write("bench.py: leg %s failed: %s\n" % (name, self.leg_errors[name]))
+            return default
+
     # ---- the roofline block: the kernel class with the largest HIP-event time over the timed steps
     def roofline(self, T):
         args, wl, nlive = self.args, self.wl, self.nlive
@@ -699,15 +724,13 @@ class Bench:
         # script behind the timed region), else the committed passes of profiles/ for the metric configuration
         pmc, pmc_src = {}, None
         if self.extras and not args.no_live_pmc:
-            lp = live_pmc(args.workload)
+            lp = self.leg("live_pmc", lambda: live_pmc(args.workload), None)
             if lp:
                 pmc, pmc_src = lp, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, one pass each, over 3 runs of this workload"
-        if not pmc:
-            for name in PMC_FILES:
-                pth = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(pth) and args.workload == "c2":
-                    pmc = json.load(open(pth))["kernels"]; pmc_src = "profiles/" + name
-                    break
+        if not pmc and args.workload == "c2":
+            rec, name = committed_record(PMC_FILES, ("kernels",))
+            if rec:
+                pmc, pmc_src = rec["kernels"], "profiles/" + name
         kern = []
         k_last = runs[-1]["kernel_time"]
         for name in sorted(k_last, key=lambda n: -sum(r["kernel_time"][n]["total_s"] for r in runs)):
@@ -740,7 +763,7 @@ class Bench:
                         "class with the largest total time; kernels[] = the two heaviest classes with their OWN algorithmic bytes per launch "
                         "and the PMC traffic of profiles/ (per launch); whole_run_frac = all algorithmic bytes of the timed steps / wall / peak"}
         if args.workload == "c2":
-            roof["latency"] = latency_model(runs, kern)
+            roof["latency"] = self.leg("latency_model", lambda: latency_model(runs, kern), None)
         return roof
 
 
@@ -768,20 +791,20 @@ def main():
                  "dtype": "f64", "data": "synthetic", "config": {"workload": wl["short"] % nlive + ", one full run per step", "parallelism": "repeat-sharded x%d" % world},
                  "roofline": None, "cpu_baseline": None, "partial": "timed region only; the complete record follows"}
         print(json.dumps(_num(early), separators=(",", ":")), flush=True)
-    try:
-        multi = b.in_step_multi()
-    except RuntimeError as e:                                   # (never the reason to lose the timed region's record)
-        multi = {"error": str(e)[:100], "runs_per_gpu": args.runs_per_gpu, "n_gpus": world}
+    # (none of the legs below is ever the reason to lose the timed region's record: Bench.leg)
+    multi = b.leg("in_step_multi", b.in_step_multi, None)
+    if multi is None and "in_step_multi" in b.leg_errors:
+        multi = {"error": b.leg_errors["in_step_multi"][:100], "runs_per_gpu": args.runs_per_gpu, "n_gpus": world}
     ints = lambda txt: [int(x) for x in txt.split(",") if x.strip() and int(x) > 1] if txt else []
     names = lambda txt: [x for x in txt.split(",") if x.strip()] if txt else []
-    general = b.general_functor()
-    conc = b.concurrent(ints(args.concurrent))
-    conc_other = b.concurrent_clustered(names(args.concurrent_configs), ints(args.concurrent_clustered) if ints(args.concurrent) else [])
-    others = b.other_configs(names(args.other_configs))
+    general = b.leg("general_functor", b.general_functor, None)
+    conc = b.leg("concurrent", lambda: b.concurrent(ints(args.concurrent)), [])
+    conc_other = b.leg("concurrent_clustered", lambda: b.concurrent_clustered(names(args.concurrent_configs), ints(args.concurrent_clustered) if ints(args.concurrent) else []), {})
+    others = b.leg("other_configs", lambda: b.other_configs(names(args.other_configs)), {})
     if rank == 0:
         runs, tmax, nlike, nfailed, merged = T["runs"], T["tmax"], T["nlike"], T["nfailed"], T["merged"]
         value = nlike / tmax
-        roof = b.roofline(T)
+        roof = b.leg("roofline", lambda: b.roofline(T), None)
         if roof and multi:
             roof["in_step_multi"] = multi
         if roof and conc:
@@ -814,8 +837,8 @@ def main():
                 "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in HOST_PHASES},
                 "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
                 "reference_cpu_evals_per_s_survey_container": 357e3}
-        if world == 1 and not args.no_cpu:
-            cb = CpuBaseline(wl, nlive).finish()                 # (both legs now, alone: every GPU figure has been taken)
+        cb = b.leg("cpu_baseline", lambda: CpuBaseline(wl, nlive).finish(), None) if world == 1 and not args.no_cpu else None      # (both legs now, alone: every GPU figure has been taken)
+        if cb:
             full["cpu_baseline"] = cb
             # wall clock of one run of the reference / of the engine: what a user waits for (the evals/s ratio also counts the
             # engine's failed spawns as work)
@@ -823,6 +846,8 @@ def main():
             full["speedup_evals_per_s"] = value / cb["value"]
         else:
             full["cpu_baseline"] = None
+        if b.leg_errors:
+            full["leg_errors"] = dict(b.leg_errors)
         full_path = None
         dest = args.full_out if args.full_out is not None else os.path.join("gpurun_out", "bench_full_%s.json" % args.workload)
         if dest:

@@ -2353,6 +2353,29 @@ struct Engine {
         }
     }
 
+    void ensure_side()
+    {
+        if (st_side) return;
+        st_side = stream_beside({st, st_copy}); ev_main = hpool().get_sync_event();
+        for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
+    }
+    // Several clusters, a run on its own: the sorted order of the live set (k_sort_live: one workgroup, 17-26 us + a launch) is what the
+    // candidate lists and the one-wave contraction start from, and it depends on the live set only -- which the sampling of a fresh
+    // nursery does not touch.  It is made on the side stream while k_slice runs; the main stream waits for it in front of the lists.
+    hipEvent_t ev_presort_a = nullptr, ev_presort_b = nullptr;
+    bool presorted = false;
+    void presort_live()
+    {
+        static const bool off = std::getenv("PC_PRESORT_OFF") != nullptr;
+        presorted = false;
+        if (off || co || callback_mode || S.seq_mode || !S.nn_list || h_ctl->ncluster < 2 || g_active_dev[dev & 63].load(std::memory_order_relaxed) != 1) return;
+        ensure_side();
+        if (!ev_presort_a) { ev_presort_a = hpool().get_sync_event(); ev_presort_b = hpool().get_sync_event(); }
+        HIPCHK(hipEventRecord(ev_presort_a, st)); HIPCHK(hipStreamWaitEvent(st_side, ev_presort_a, 0));      // (behind the row copies of the round before)
+        if (pc_launch_sort_live(&S, st_side) != 0) return;
+        HIPCHK(hipEventRecord(ev_presort_b, st_side));
+        presorted = true;
+    }
     // the bases of the nurseries after `cur`, on the side stream (behind cur's sampling kernel on the main stream)
     void side_prefetch(unsigned cur)
     {
@@ -2360,10 +2383,7 @@ struct Engine {
         {
                 // drawn while the one-CU contraction of this nursery runs: next to k_slice (one wave per SIMD) the
         // 2000 workgroups of the bases kernel cost it 10 us, next to the contraction nothing
-        if (!st_side) {
-            st_side = stream_beside({st, st_copy}); ev_main = hpool().get_sync_event();
-            for (int r = 0; r < raw_depth; ++r) { ring[r].ready = hpool().get_sync_event(); ring[r].consumed = hpool().get_sync_event(); }
-        }
+        ensure_side();
         // (nDims > 64: the bases take longer than the contraction and the slice kernel is one wave per SIMD for
         //  half a millisecond: there they run next to it from the start)
         static const bool side_free_env = std::getenv("PC_SIDE_FREE") != nullptr, side_ord_env = std::getenv("PC_SIDE_ORDERED") != nullptr;
@@ -2418,13 +2438,14 @@ struct Engine {
                 const bool have = spec_pending;                 // (still pending here = the device took it: round_finish undid the others)
                 spec_pending = false;
                 if (have) side_prefetch(batch - 1);
-                else { const auto n0 = std::chrono::steady_clock::now(); const bool okn = enqueue_nursery(false); g_dbg_nursery_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n0).count(); if (!okn) return false; }
+                else { const auto n0 = std::chrono::steady_clock::now(); if (r_static_ok && cfg.force_general == 0 && !(cfg.ablate & 32)) presort_live(); const bool okn = enqueue_nursery(false); g_dbg_nursery_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n0).count(); if (!okn) return false; }
             }
             if (fresh_nursery) { const auto n0 = std::chrono::steady_clock::now(); ensure_capacity(); g_dbg_capacity_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n0).count(); }
             hipEvent_t e2 = kt.begin(KT_CONSUME);
             int rc2;
             const bool use_fast = fast_ok && h_ctl->ncluster == 1;
             launch_stamp();
+            if (presorted && (co || !(h_ctl->ncluster > 1) || use_fast)) { HIPCHK(hipStreamWaitEvent(st, ev_presort_b, 0)); presorted = false; }
             if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0; S.nn_valid = 0;                     // (the one-cluster kernels do not keep the list bookkeeping)
@@ -2455,9 +2476,10 @@ struct Engine {
                 } else {
                 if (co) co->flush();
                 bool sorted_now = false;
+                if (presorted) { HIPCHK(hipStreamWaitEvent(st, ev_presort_b, 0)); sorted_now = fresh_nursery; presorted = false; }      // (made beside k_slice: presort_live)
                 if (want_nn) {
                     // (the sorted order first: its ranks tell the lists' kernel which candidates cannot die before a chain is looked at)
-                    sorted_now = pc_launch_sort_live(&S, st) == 0;
+                    if (!sorted_now) sorted_now = pc_launch_sort_live(&S, st) == 0;
                     pc_launch_nn_lists(&S, nursery_left, sorted_now ? 1 : 0, st);
                     S.nn_valid = 1;
                 }
@@ -2766,6 +2788,7 @@ struct Engine {
         if (st_copy) { if (!streams_idle) (void)hipStreamSynchronize(st_copy); if (!st_copy_shared) hpool().put_stream(st_copy); } st_copy = nullptr;
         if (st_side) {
             if (!streams_idle) (void)hipStreamSynchronize(st_side); hpool().put_stream(st_side); hpool().put_sync_event(ev_main);
+            if (ev_presort_a) { hpool().put_sync_event(ev_presort_a); hpool().put_sync_event(ev_presort_b); ev_presort_a = ev_presort_b = nullptr; }
             for (int r = 0; r < RAW_RING; ++r) { if (ring[r].ready) hpool().put_sync_event(ring[r].ready); if (ring[r].consumed) hpool().put_sync_event(ring[r].consumed); ring[r] = RawSlot(); }
         }
         st_side = nullptr; ev_main = nullptr;

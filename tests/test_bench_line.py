@@ -102,3 +102,56 @@ def test_the_lines_bench_py_printed_on_the_gpu_box(name):
     if name == "r05_bench.json":
         assert j["metric"].startswith("likelihood evals/sec, 20D Gaussian nlive=2000") and j["config"]["batch_chains"] == 1000
         assert len(j["roofline"]["in_step"]) == 6 and j["roofline"]["in_step_multi"]["runs"] == 16
+
+
+def test_every_committed_profile_bench_py_reads_is_a_record():
+    """round 5 committed an EMPTY profiles/r05_slice_cycles.json (a collection that failed half way) and `python bench.py` died in
+    json.load behind its timed region -- on the GPU box only.  The files bench.py picks up must parse, and one that does not is skipped"""
+    import glob
+    for pth in glob.glob(os.path.join(ROOT, "profiles", "*.json")):
+        assert os.path.getsize(pth) > 0, pth
+        json.load(open(pth))
+    rec, name = bench.committed_record(bench.SLICE_CYCLE_FILES, ("cycles_per_slice", "cycles_per_slice_total"))
+    assert rec and rec["cycles_per_slice_total"] > 0 and name in bench.SLICE_CYCLE_FILES
+    rec, name = bench.committed_record(bench.PMC_FILES, ("kernels",))
+    assert rec and any(k.startswith("k_slice") for k in rec["kernels"])
+    # an empty or truncated file in front of a good one is passed over
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp()
+    try:
+        os.makedirs(os.path.join(d, "profiles"))
+        open(os.path.join(d, "profiles", "a.json"), "w").close()
+        open(os.path.join(d, "profiles", "b.json"), "w").write('{"cycles_per_slice": {')
+        open(os.path.join(d, "profiles", "c.json"), "w").write('{"cycles_per_slice": {"x": 1.0}, "cycles_per_slice_total": 1.0}')
+        root = bench.ROOT
+        bench.ROOT = d
+        try:
+            rec, name = bench.committed_record(("missing.json", "a.json", "b.json", "c.json"), ("cycles_per_slice", "cycles_per_slice_total"))
+        finally:
+            bench.ROOT = root
+        assert name == "c.json" and rec["cycles_per_slice_total"] == 1.0
+    finally:
+        shutil.rmtree(d)
+
+
+def test_the_latency_block_from_the_committed_cycles():
+    runs = [{"nlike": 14_000_000, "niter": 80_000, "nbatches": 79, "nrounds": 79}]
+    kern = [{"kernel": "k_slice", "avg_launch_us": 70.0}]
+    lat = bench.latency_model(runs, kern)
+    assert lat["model_min"] > 0 and 0.3 < lat["frac_of_model"] < 1.0 and lat["measured_source"].startswith("profiles/r0")
+
+
+def test_a_leg_that_fails_is_written_down_not_raised():
+    class B(bench.Bench):
+        def __init__(self):
+            self.leg_errors = {}
+    b = B()
+    assert b.leg("ok", lambda: 3, None) == 3 and not b.leg_errors
+    assert b.leg("broken", lambda: json.loads(""), "dflt") == "dflt"
+    assert "broken" in b.leg_errors and "JSONDecodeError" in b.leg_errors["broken"]
+    full = _canned("r05_bench_full.json")
+    full["leg_errors"] = b.leg_errors
+    full["roofline"] = None                                            # (the roofline leg itself lost: the line still leaves, and says so)
+    out = bench.compact_record(full)
+    assert out["roofline"] is None and "broken" in out["leg_errors"] and out["value"] > 0 and out["cpu_baseline"]["value"] > 0
