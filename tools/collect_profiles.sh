@@ -17,5 +17,6 @@ python tools/pmc_summary.py "$out/fetch" "$out/write" "profiles/${tag}_pmc.json"
 cp "profiles/${tag}_pmc.json" "profiles/${tag}_kernel_stats.csv" gpurun_out/
 # the bench line itself (same command plus the CPU baseline and the concurrent-runs capacity figure), with the PMC file in place
 timeout 600 python bench.py --steps 20 --warmup 5 --full-out "gpurun_out/${tag}_bench_full.json" > "profiles/${tag}_bench.json" 2> "$out/bench.log"      # (the compact record the driver parses; the full one beside it)
-cp "profiles/${tag}_bench.json" gpurun_out/; cp "gpurun_out/${tag}_bench_full.json" profiles/ 2>/dev/null
+[ -s "profiles/${tag}_bench.json" ] || { rm -f "profiles/${tag}_bench.json"; echo "collect_profiles.sh: bench.py printed no line:" >&2; tail -5 "$out/bench.log" >&2; }
+cp "profiles/${tag}_bench.json" gpurun_out/ 2>/dev/null; cp "gpurun_out/${tag}_bench_full.json" profiles/ 2>/dev/null
 head -5 "profiles/${tag}_kernel_stats.csv"
