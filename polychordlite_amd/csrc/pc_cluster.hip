@@ -20,6 +20,7 @@
 // The recursion over found clusters (clustering.f90:80-95) and the O(ncluster) evidence split
 // (run_time_info.f90:458-503) are driven from the host (pc_engine.hip); they touch a few integers.
 #include "pc_state.h"
+#include <cstdlib>
 
 __device__ __forceinline__ void similarity_body(const PcState &S, const int *pts /* slots in list order */, int n, double *Sm, int ybase, int ystride)
 {
@@ -561,7 +562,8 @@ void pc_launch_rebuild(const PcState *S, int nc, hipStream_t st)
 
 void pc_launch_ph_rehome(const PcState *S, int nph, int nc, const unsigned *old_uids, int nold_uids, int *counts, hipStream_t st)
 {
-    if (nph > 0 && S->D <= 32) {
+    static const bool general_only = std::getenv("PC_PH_REHOME_GENERAL") != nullptr;      // (A/B and the test that holds the two kernels together)
+    if (nph > 0 && S->D <= 32 && !general_only) {
         const dim3 g((nph + 63) / 64), b(128);
         switch ((S->D + 3) / 4) {
 #define PC_R(n) case n: hipLaunchKernelGGL((k_ph_rehome_r<4 * n>), g, b, 0, st, *S, nph, old_uids, nold_uids); break;

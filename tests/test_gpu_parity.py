@@ -577,6 +577,34 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,box,maxnd", [("rastrigin", 4, 0, 300, 8, (-5.12, 5.12), 2400), ("twin_gaussian", 30, 1, 300, 10, (-1.0, 1.0), -1)])
+def test_phantoms_find_the_same_clusters_by_both_kernels(engine, kind, D, nDer, nlive, nr, box, maxnd):
+    """a split's phantoms go to the cluster of their nearest live point (run_time_info.f90:444-453): the lane-per-phantom kernel
+    (nDims <= 32: coordinates in registers, live points by LDS broadcast) against the general one it stands in for
+    (PC_PH_REHOME_GENERAL=1, read once per process: a child process) -- the same run to the last bit"""
+    import json, subprocess, sys
+    api = engine
+    L, P, keep = api.make_problem(kind, D, nDer, *box)
+    s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=77, batch=0, do_clustering=1, max_ndead=maxnd)
+    a = api.run(s, L, P)
+    assert a["ncluster_peak"] >= 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, ctypes as C; sys.path.insert(0, %r)\n"
+            "from polychordlite_amd import _ctypes_api as api\n"
+            "lib = api.load(); L, P, keep = api.make_problem(%r, %d, %d, *%r)\n"
+            "s = api.Settings(); lib.pchip_settings_default(C.byref(s), %d, %d)\n"
+            "s.nlive, s.num_repeats, s.seed, s.batch, s.do_clustering, s.max_ndead = %d, %d, 77, 0, 1, %d\n"
+            "g = api.run(s, L, P)\n"
+            "print(json.dumps(dict(ndead=int(g['ndead']), nlike=int(g['nlike']), logZ=float(g['logZ']).hex(), peak=int(g['ncluster_peak']), sumdead=float(g['dead'][:, :-2].sum()).hex())))\n"
+            % (root, kind, D, nDer, box, D, nDer, nlive, nr, maxnd))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_PH_REHOME_GENERAL="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    b = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert (b["ndead"], b["nlike"], b["peak"]) == (int(a["ndead"]), int(a["nlike"]), int(a["ncluster_peak"]))
+    assert b["logZ"] == float(a["logZ"]).hex() and b["sumdead"] == float(a["dead"][:, :-2].sum()).hex()
+
+
+@pytest.mark.gpu
 def test_clustered_contraction_with_a_chain_that_has_no_number(engine):
     """two repeats in ten dimensions, 200 live points and a nursery of 100: clusters of fewer points than dimensions have singular
     covariances, and a chain that starts there comes back with NaN for its last logL.  Such a chain must take the same place among
