@@ -960,8 +960,10 @@ struct Engine {
         static const bool split_off = std::getenv("PC_NHATS_SPLIT_OFF") != nullptr;
         // 64 < nDims <= 128, one grade: k_nhats_q<32, 1> leaves a basis register-major, 32 x 512 doubles
         const bool split_q = D > 64 && D <= 128 && S.ngrade <= 1 && !S.seq_mode && !split_off && !callback_mode;
-        const size_t raw_n = split_q ? (size_t)B * S.nb_total * 32 * 512 : (size_t)B * S.nb_total * D * D;
-        S.nhat_raw = ((D <= 24 && !S.seq_mode && !split_off) || split_q) ? dalloc<double>(raw_n)
+        // 24 < nDims <= 64, one grade (round 5): k_nhats_q<8 / 16, 1> leaves a basis thread by thread, 16 HV^2 doubles
+        const bool split_m = D > 24 && D <= 64 && S.ngrade <= 1 && !S.seq_mode && !split_off && !callback_mode;
+        const size_t raw_n = split_q ? (size_t)B * S.nb_total * 32 * 512 : split_m ? (size_t)B * S.nb_total * (D <= 32 ? 1024 : 4096) : (size_t)B * S.nb_total * D * D;
+        S.nhat_raw = ((D <= 24 && !S.seq_mode && !split_off) || split_q || split_m) ? dalloc<double>(raw_n)
                    : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
         // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read
         // (nDims > 64: the bases cost more than the rest of a nursery's round -- they are drawn up to three nurseries ahead,
@@ -972,7 +974,7 @@ struct Engine {
         static const int depth_env = std::getenv("PC_RAW_DEPTH") ? std::max(2, std::min(RAW_RING, std::atoi(std::getenv("PC_RAW_DEPTH")))) : 3;
         raw_depth = split_q ? RAW_RING : depth_env;
         raw_buf[0] = S.nhat_raw;
-        for (int r = 1; r < raw_depth; ++r) raw_buf[r] = ((D <= 24 || split_q) && S.nhat_raw) ? dalloc<double>(raw_n) : nullptr;
+        for (int r = 1; r < raw_depth; ++r) raw_buf[r] = ((D <= 24 || split_q || split_m) && S.nhat_raw) ? dalloc<double>(raw_n) : nullptr;
         S.plan = dalloc<PcPlan>(B); S.slot_src = dalloc<int>(Ncap); S.slot_step = dalloc<int>(Ncap); S.slot_dead = dalloc<int>(Ncap); HIPCHK(hipMemsetAsync(S.slot_dead, 0xFF, sizeof(int) * Ncap, st)); S.defer_update = 0; S.sort_slot = dalloc<int>(Ncap + 64); S.sort_key = dalloc<unsigned long long>(Ncap + 64);
         S.ctl = dalloc<PcCtl>(1);
         d_total = dalloc<int>(1);
@@ -2286,8 +2288,9 @@ struct Engine {
             // (a run that has the chip to itself: next to other runs the side stream takes from them what it gives)
             // (next to other runs of this device the bases are drawn in line, in front of the sampling kernel: their side streams
             //  would take from each other what they give -- but the split itself, and with it the fused sampling kernel, stays)
-            const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1];
             const bool multi = co != nullptr || g_active_dev[dev & 63].load(std::memory_order_relaxed) > 1;
+            // (nDims 25 ... 64: the halves for a run on its own; runs in step take the whole kernel with the run in the grid, CK_NHATS_G)
+            const bool splittable = pc_nhats_splittable(&S) != 0 && raw_buf[1] && !(S.D > 24 && S.D <= 64 && multi);
             const bool split = splittable && !multi;
             bool fused_slice = false;
             int bases_seq = 0;                        // in step with other runs: the number of the launch that drew this nursery's bases (0: in line)

@@ -601,6 +601,9 @@ __device__ __forceinline__ double quad_sum(double v)
 template <int HV, int PART = 0>
 __global__ __launch_bounds__(16 * HV) void k_nhats_q(PcState S, unsigned batch)
 {
+    // (fused where ONE expression says a * b + c and nowhere else: the body is compiled as the whole kernel, as its two halves and with
+    //  the run in the grid, and what the optimiser fuses across statements differed between those -- a run in step must be the run alone)
+#pragma clang fp contract(on)
 #include "pc_nhats_q_body.inc"
 }
 template <int HV, int PART = 0>
@@ -610,7 +613,10 @@ __global__ __launch_bounds__(16 * HV) void k_nhats_q_many(const PcManyRec *__res
     //  kernel, the same statements, and a run in step was no longer bit for bit the run alone)
     const PcState S = R[blockIdx.z].S;
     const unsigned batch = (unsigned)R[blockIdx.z].ia[0];
+    {
+#pragma clang fp contract(on)
 #include "pc_nhats_q_body.inc"
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1153,6 +1159,7 @@ extern "C" int pc_nhats_splittable(const PcState *S)
 {
     const char *e = std::getenv("PC_NHATS_QUAD_MIN");
     if (S->D > 64 && S->D <= 128) return S->ngrade <= 1 && !S->seq_mode && S->nhat_raw != nullptr;    // k_nhats_q<32, 1 / 2>
+    if (S->D > 24 && S->D <= 64) return S->ngrade <= 1 && !S->seq_mode && S->nhat_raw != nullptr && (!e || std::atoi(e) <= 25);      // k_nhats_q<8 / 16, 1 / 2> (round 5)
     return S->D <= 24 && S->D < (e ? std::atoi(e) : 25) && !S->seq_mode && S->nhat_raw != nullptr;
 }
 // (two tile buffers up to nDims 112; beyond that one, with a barrier more per tile: 160 KB of LDS)
@@ -1181,6 +1188,14 @@ extern "C" int pc_launch_nhats_part(const PcState *S, unsigned batch, int nchain
             else if (nt == 7) hipLaunchKernelGGL((k_whiten<7>), g2, dim3(256), 0, st, *S, batch);
             else hipLaunchKernelGGL((k_whiten<8>), g2, dim3(256), 0, st, *S, batch);
         }
+        return 0;
+    }
+    if (D > 24) {
+        // nDims 25 ... 64: the four-threads-per-vector kernel in two halves -- deviates + Gram-Schmidt (nothing the contraction changes:
+        // drawn ahead on the side stream), then seeds + whitening in front of k_slice
+        auto lds_q = [](int HV) { return sizeof(double) * (size_t)(2 + HV) * 4 * (HV + 2); };
+        if (D <= 32) { if (part == 1) hipLaunchKernelGGL((k_nhats_q<8, 1>), grid, dim3(128), lds_q(8), st, *S, batch); else hipLaunchKernelGGL((k_nhats_q<8, 2>), grid, dim3(128), lds_q(8), st, *S, batch); }
+        else { if (part == 1) hipLaunchKernelGGL((k_nhats_q<16, 1>), grid, dim3(256), lds_q(16), st, *S, batch); else hipLaunchKernelGGL((k_nhats_q<16, 2>), grid, dim3(256), lds_q(16), st, *S, batch); }
         return 0;
     }
     const size_t sh = sizeof(double) * ((size_t)(D + 8) * (D + 8) + 2 * 128) + 16;
