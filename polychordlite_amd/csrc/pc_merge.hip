@@ -735,8 +735,9 @@ int pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const 
         //  Gaussian runs fill the chip with one group, and two were slower: DESIGN section 5f)
         // (round 5: four groups of at least four runs each -- one main stream per hardware queue, which the groups now keep apart
         //  (CohortStreams, pc_engine.hip); sixteen runs of configs[2] / [3]: 495 / 386 ms with two groups, 430 / 340 with four; with six or
-        //  eight groups main streams share queues again and the call takes twice as long)
-        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : ((s->do_clustering && per_dev >= 8) ? std::min(4, per_dev / 4) : 1);
+        //  eight groups main streams share queues again and the call takes twice as long.  And four groups whatever they hold: four runs
+        //  as four groups of one 172 ms against 274 in one group, eight as four groups of two 264 against 325 in two)
+        const int sched = std::getenv("PC_REPEATS_SCHED") ? std::max(1, std::atoi(std::getenv("PC_REPEATS_SCHED"))) : ((s->do_clustering && per_dev >= 2) ? std::min(4, per_dev) : 1);
         const int nd = (int)devs.size();
         // (several groups on a device: streams of known hardware-queue classes for all of them, classed now, while the device is idle)
         if (sched > 1) for (int d : devs) pc_prepare_streams(d, 4 * sched);
