@@ -616,6 +616,7 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
     // and the state is rewritten once, behind one barrier (two barriers per death instead of seven; measured before: jobs
     // 2.5 k cycles, scan 2.3 k, volumes 0.8 k, one after the other).
     const bool fastkill = NT >= 256 && Ncap <= 4096 && !slots_global;
+    const int ndead_kill0 = ndead;                            // (the kill-off's first death: its rows are copied behind the loop)
     auto kill_lowest = [&](int plan_w) {
         // cluster with the lowest contour (minpos: first minimum)
         const int cd = lowest_contour().k;
@@ -724,7 +725,15 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                         S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lxm; S.plan[plan_w].postXs = lxs; S.plan[plan_w].postZ = logZ;
                         S.plan[plan_w].dead_cuid = H.cUid[cd];
                     }
-                } else {   // kill-off / trimming: rows are current in live[], copy immediately
+                } else if (final_mode == 1) {
+                    // the kill-off: nothing is born any more, the rows stay what they are -- they leave together behind the loop (a copy
+                    // here is a global load and a store per death on the loop's critical path: a third of its 4.5 us)
+                    if (tid == 0) {
+                        S.sort_slot[ndead - ndead_kill0] = slot_del;
+                        S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lxm + log(lxs); S.dead_postZ[ndead] = logZ;
+                        S.dead_cuid[ndead] = H.cUid[cd];
+                    }
+                } else {   // trimming: rows are current in live[], copy immediately
                     const double *row = S.live + (size_t)slot_del * nT;
                     double *dst = S.dead + (size_t)ndead * nT;
                     for (int e = tid; e < nT; e += NT) dst[e] = row[e];
@@ -816,7 +825,13 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
                     S.plan[plan_w].logw = logweight; S.plan[plan_w].postX = lxm; S.plan[plan_w].postXs = lxs; S.plan[plan_w].postZ = logZ;
                     S.plan[plan_w].dead_cuid = H.cUid[cd];
                 }
-            } else {   // kill-off / trimming: rows are current in live[], copy immediately
+            } else if (final_mode == 1) {      // (the kill-off: the rows leave together behind the loop, see above)
+                if (tid == 0) {
+                    S.sort_slot[ndead - ndead_kill0] = slot_del;
+                    S.dead_logw[ndead] = logweight; S.dead_postX[ndead] = lxm + log(lxs); S.dead_postZ[ndead] = logZ;
+                    S.dead_cuid[ndead] = H.cUid[cd];
+                }
+            } else {   // trimming: rows are current in live[], copy immediately
                 const double *row = S.live + (size_t)slot_del * nT;
                 double *dst = S.dead + (size_t)ndead * nT;
                 for (int e = tid; e < nT; e += NT) dst[e] = row[e];
@@ -881,6 +896,23 @@ __global__ __launch_bounds__(NT) void k_consume(PcState S, int final_mode, int c
         while (nc > 0 && status == PC_ST_RUNNING) {
             kill_lowest(-1);
             drop_empty_cluster();
+        }
+        {   // the rows of the points that died here (the k-th death of the loop took slot sort_slot[k]): all threads, eight loads in flight
+            __threadfence_block();
+            __syncthreads();
+            const int nk = ndead - ndead_kill0;
+            const long long ne = (long long)nk * nT;
+            for (long long e0 = tid; e0 < ne; e0 += (long long)NT * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long long e = e0 + (long long)u * NT;
+                    if (e < ne) { const int k = (int)(e / nT), d = (int)(e - (long long)k * nT); v[u] = S.live[(size_t)((volatile int *)S.sort_slot)[k] * nT + d]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const long long e = e0 + (long long)u * NT; if (e < ne) S.dead[(size_t)ndead_kill0 * nT + e] = v[u]; }
+            }
+            for (int k = tid; k < nk; k += NT) S.dead_entry[ndead_kill0 + k] = S.live_entry[((volatile int *)S.sort_slot)[k]];
         }
         status = PC_ST_DONE;
     } else if (final_mode == 2) {
