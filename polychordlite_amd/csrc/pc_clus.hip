@@ -150,6 +150,207 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_killoff_cl -- nested_sampling.F90:381-384 for a run that ends with several clusters: every remaining live point dies,
+// lowest first (delete_outermost_point, run_time_info.f90:789-817; update_evidence :211-296; delete_cluster :507-598 when a
+// cluster has lost its last point).  The general kernel (k_consume, final_mode 1) makes a death with a workgroup: two barriers,
+// a scan of every slot for the dying cluster's next minimum, a dozen lanes of log-add-exps -- 4.5 us a death, a thousand deaths
+// at BASELINE configs[2], and with runs in step one such tail per run.  Nothing is born here, so the ORDER of the deaths is the
+// sorted order of the live set and everything a death needs but the evidence state is known beforehand:
+//   * the workgroup sorts the live set by (logL, cluster, list position) in LDS (an exact tie in logL between clusters goes to
+//     the lower cluster as in minpos; inside a cluster the general kernel's positions move with every death -- ties there are
+//     broken by the position at the start);
+//   * ONE wavefront makes the deaths, cluster q in lane q (as many lanes as clusters alive, in the list's order: a cluster's
+//     end moves the lanes behind it up, so every wave-wide sum adds the same terms in the same places as the general kernel),
+//     the six accumulations of the dying cluster and of the run in lanes 56-61: every lane one three-term log-sum-exp
+//     m + log((e^(a-m) + e^(b-m)) + e^(c-m)) -- for the two-term ones c = -huge, and the sum is then exactly pc_logaddexp's
+//     (one of its terms is e^0 = 1) -- so the wave does not diverge;
+//   * the cross-volume matrix stays in LDS under the numbers the clusters had at launch (each lane knows its own): a death
+//     rewrites the dying cluster's row and column; the row the NEXT death needs, that cluster's log n and the sorted record are
+//     requested at the end of a death;
+//   * no global LOAD inside the loop, so the per-death stores (log weight, logZ, cluster id) cost their issue slots only; the
+//     volume column's logarithm and the rows leave behind the loop, all threads.
+// The same statements in the same order as k_consume's kill_lowest: the two give the same numbers (tests/test_gpu_parity.py;
+// settings.ablate bit 9 = the general kernel).  Not here: more than 56 clusters alive, a live set beyond the LDS.
+#define KO_NT 512
+#define KO_MAXC 56
+struct KoLayout { size_t kv, kc, kp, ks, xq, lgn, os, total; int ld; };
+static __host__ __device__ inline KoLayout ko_layout(int Ncap, int npow2, int nc)
+{
+    KoLayout l; size_t o = 0;
+    l.ld = nc | 1;
+    l.kv = o; o += sizeof(double) * (size_t)npow2;
+    l.xq = o; o += sizeof(double) * (size_t)nc * l.ld;
+    l.lgn = o; o += sizeof(double) * (size_t)(Ncap + 4);
+    l.os = o; o += sizeof(double) * (size_t)npow2;
+    l.kc = o; o += sizeof(int) * (size_t)npow2;
+    l.kp = o; o += sizeof(int) * (size_t)npow2;
+    l.ks = o; o += sizeof(int) * (size_t)npow2;
+    l.total = o;
+    return l;
+}
+
+__global__ __launch_bounds__(KO_NT) void k_killoff_cl(PcState S, int npow2, int nc0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KoLayout lay = ko_layout(S.Ncap, npow2, nc0);
+    double *kv = (double *)(smem + lay.kv), *xq = (double *)(smem + lay.xq), *lgn = (double *)(smem + lay.lgn);
+    double *os = (double *)(smem + lay.os), *om = kv;      // (the volume column's maximum takes the place of the dead point's logL: entry k is read before death k)
+    int *kc = (int *)(smem + lay.kc), *kp = (int *)(smem + lay.kp), *ks = (int *)(smem + lay.ks);
+    __shared__ int sh_nk, sh_ncd;
+    const int tid = threadIdx.x, lane = tid & 63, Ncap = S.Ncap, nT = S.nT, maxc = S.maxc, ld = lay.ld;
+    PcCtl *ctl = S.ctl;
+    // ---- stage: the live set, the matrix, the table of logarithms
+    for (int i = tid; i < npow2; i += KO_NT) {
+        const int c = i < Ncap ? S.live_cluster[i] : -1;
+        const bool used = c >= 0;
+        kv[i] = used ? S.live_logL[i] : PC_HUGE; kc[i] = used ? c : 0x7fffffff; kp[i] = used ? S.live_pos[i] : 0x7fffffff; ks[i] = i < Ncap ? i : -1;
+    }
+    for (int e = tid; e < nc0 * nc0; e += KO_NT) xq[(size_t)(e / nc0) * ld + e % nc0] = S.XpXq[(size_t)(e / nc0) * maxc + e % nc0];
+    for (int i = tid; i < Ncap + 4; i += KO_NT) lgn[i] = S.logn[i];
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += KO_NT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double a = kv[i], b = kv[l]; const int ca = kc[i], cb = kc[l], pa = kp[i], pb = kp[l];
+                    const bool gt = (a > b) || (a == b && (ca > cb || (ca == cb && pa > pb)));
+                    if (gt == up) { kv[i] = b; kv[l] = a; kc[i] = cb; kc[l] = ca; kp[i] = pb; kp[l] = pa; const int t = ks[i]; ks[i] = ks[l]; ks[l] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    const int ndead0 = ctl->ndead;
+    if (tid < 64) {
+        // ---- the deaths: one wavefront, no barrier
+        int nc = nc0, nc_dead = ctl->ncluster_dead, ntot = 0;
+        const bool cl = lane < nc0;
+        double Xp = cl ? S.logXp[lane] : -PC_HUGE, ZXp = cl ? S.logZXp[lane] : 0.0, Zp = cl ? S.logZp[lane] : 0.0;
+        double Zp2 = cl ? S.logZp2[lane] : 0.0, ZpXp = cl ? S.logZpXp[lane] : 0.0;
+        int nq = cl ? S.cl_n[lane] : 0, orig = cl ? lane : -1;
+        unsigned uid = cl ? S.cl_uid[lane] : 0u;
+        for (int c = 0; c < nc0; ++c) ntot += __builtin_amdgcn_readlane(nq, c);
+        double logZ = ctl->logZ, logZ2 = ctl->logZ2;
+        const double log2v = log(2.0);
+        int room = S.Dcap - ndead0;
+        if (room < 0) room = 0;
+        const int nk = ntot < room ? ntot : room;
+        // what the first death needs
+        int cdo = __builtin_amdgcn_readfirstlane(kc[0]);
+        int cd = nk > 0 ? __ffsll((long long)__ballot(orig == cdo)) - 1 : 0;
+        int n = __builtin_amdgcn_readlane(nq, cd);
+        double l0 = lgn[n], l1 = lgn[n + 1], l2 = lgn[n + 2];
+        double row = (lane < nc) ? xq[(size_t)cdo * ld + orig] : 0.0;
+        double L = kv[0];
+        for (int k = 0; k < nk; ++k) {
+            const double Xpd = readlane_f64(Xp, cd), XX = readlane_f64(row, cd);
+            const double ZXpd = readlane_f64(ZXp, cd), Zpd = readlane_f64(Zp, cd), Zp2d = readlane_f64(Zp2, cd), ZpXpd = readlane_f64(ZpXp, cd);
+            const unsigned uidd = (unsigned)__builtin_amdgcn_readlane((int)uid, cd);
+            const double logweight = Xpd - l1;
+            // update_evidence (run_time_info.f90:211-296): every accumulation reads the state before the death
+            double a = 0.0, b = -INFINITY, c3 = -INFINITY;       // (e^-inf = 0 exactly)
+            if (lane < nc) { a = ZXp; b = row + L - l1; }
+            if (lane == 56) { a = logZ; b = Xpd + L - l1; }
+            if (lane == 57) { a = Zpd; b = Xpd + L - l1; }
+            if (lane == 58) { a = logZ2; b = log2v + ZXpd + L - l1; c3 = log2v + XX + 2 * L - l1 - l2; }
+            if (lane == 59) { a = ZXpd + l0 - l1; b = XX + L + l0 - l1 - l2; }
+            if (lane == 60) { a = Zp2d; b = log2v + ZpXpd + L - l1; c3 = log2v + XX + 2 * L - l1 - l2; }
+            if (lane == 61) { a = ZpXpd + l0 - l1; b = XX + L + l0 - l1 - l2; }
+            const double m3 = fmax(a, fmax(b, c3));
+            const double r = m3 + log(exp(a - m3) + exp(b - m3) + exp(c3 - m3));
+            logZ = readlane_f64(r, 56); logZ2 = readlane_f64(r, 58);
+            const double nZp = readlane_f64(r, 57), nZXp = readlane_f64(r, 59), nZp2 = readlane_f64(r, 60), nZpXp = readlane_f64(r, 61);
+            if (lane < nc) {
+                if (lane == cd) {
+                    Zp = nZp; ZXp = nZXp; Zp2 = nZp2; ZpXp = nZpXp; Xp = Xpd + l0 - l1; nq = n - 1;
+                    xq[(size_t)cdo * ld + cdo] = XX + l0 - l2;
+                } else {
+                    ZXp = r;
+                    const double v = row + l0 - l1;
+                    xq[(size_t)cdo * ld + orig] = v; xq[(size_t)orig * ld + cdo] = v;
+                }
+            }
+            // the posterior stack's volume column: log sum_p X_p after the death, as a (maximum, sum) pair
+            double lxm, lxs;
+            if (nc == 1) { lxm = Xpd + l0 - l1; lxs = 1.0; }
+            else {
+                lxm = wave_max(lane < nc ? Xp : -PC_HUGE);
+                lxs = wave_sum<4>(lane < nc ? exp(Xp - lxm) : 0.0);
+            }
+            if (lane == 0) {
+                const int di = ndead0 + k;
+                S.dead_logw[di] = logweight; S.dead_postZ[di] = logZ; S.dead_cuid[di] = uidd;
+                om[k] = lxm; os[k] = lxs;
+            }
+            // delete_cluster (run_time_info.f90:507-598): the cluster's evidences go to the record of the dead, the lanes behind it move up
+            if (n - 1 == 0) {
+                if (lane == 0 && nc_dead < S.maxc_dead) { S.logZp_dead[nc_dead] = nZp; S.logZp2_dead[nc_dead] = nZp2; S.cl_uid_dead[nc_dead] = uidd; }
+                nc_dead++;
+                const double tX = __shfl_down(Xp, 1), tZX = __shfl_down(ZXp, 1), tZ = __shfl_down(Zp, 1), tZ2 = __shfl_down(Zp2, 1), tZpX = __shfl_down(ZpXp, 1);
+                const int tn = __shfl_down(nq, 1), to = __shfl_down(orig, 1); const unsigned tu = (unsigned)__shfl_down((int)uid, 1);
+                if (lane >= cd && lane < nc - 1) { Xp = tX; ZXp = tZX; Zp = tZ; Zp2 = tZ2; ZpXp = tZpX; nq = tn; orig = to; uid = tu; }
+                if (lane == nc - 1) { Xp = -PC_HUGE; nq = 0; orig = -1; }
+                nc--;
+            }
+            // what the next death needs (behind this death's writes to the matrix)
+            if (k + 1 < nk) {
+                cdo = __builtin_amdgcn_readfirstlane(kc[k + 1]);
+                cd = __ffsll((long long)__ballot(orig == cdo)) - 1;
+                n = __builtin_amdgcn_readlane(nq, cd);
+                l0 = lgn[n]; l1 = lgn[n + 1]; l2 = lgn[n + 2];
+                row = (lane < nc) ? xq[(size_t)cdo * ld + orig] : 0.0;
+                L = kv[k + 1];
+            }
+        }
+        if (lane == 0) {
+            sh_nk = nk; sh_ncd = nc_dead;
+            ctl->status = PC_ST_DONE; ctl->error = (nk < ntot) ? PC_ERR_DEAD_CAP : PC_ERR_NONE;
+            ctl->ncluster = nc; ctl->ncluster_dead = nc_dead; ctl->ndead = ndead0 + nk;
+            ctl->seg_hi = ctl->i_nursery - 1; ctl->seg_lo = ctl->i_nursery; ctl->cluster_deleted = 1;
+            ctl->logZ = logZ; ctl->logZ2 = logZ2; ctl->live_logZ = S.logzero;
+        }
+    }
+    __syncthreads();
+    // ---- behind the loop, all threads: the volume column, the rows of the points that died (eight loads in flight), the slots' labels
+    const int nk = sh_nk;
+    for (int k = tid; k < nk; k += KO_NT) {
+        S.dead_postX[ndead0 + k] = om[k] + log(os[k]);
+        S.dead_entry[ndead0 + k] = S.live_entry[ks[k]];
+        S.live_cluster[ks[k]] = -1;
+    }
+    const long long ne = (long long)nk * nT;
+    for (long long e0 = tid; e0 < ne; e0 += (long long)KO_NT * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long e = e0 + (long long)u * KO_NT;
+            if (e < ne) { const int k = (int)(e / nT), d = (int)(e - (long long)k * nT); v[u] = S.live[(size_t)ks[k] * nT + d]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long long e = e0 + (long long)u * KO_NT; if (e < ne) S.dead[(size_t)ndead0 * nT + e] = v[u]; }
+    }
+    for (int c = tid; c < nc0; c += KO_NT) S.cl_n[c] = 0;
+    __syncthreads();
+    pc_publish_ctl(S);
+}
+
+// 0: launched; 1: not this way (the caller takes the general kernel)
+extern "C" int pc_launch_killoff_cl(const PcState *S, int nc, hipStream_t st)
+{
+    static const bool off = std::getenv("PC_KILLOFF_GENERAL") != nullptr;
+    if (off || (S->ablate & 512) || nc < 2 || nc > KO_MAXC || S->seq_mode) return 1;
+    int npow2 = 64;
+    while (npow2 < S->Ncap) npow2 <<= 1;
+    const size_t sh = ko_layout(S->Ncap, npow2, nc).total;
+    if (sh + 1024 > (size_t)158 * 1024) return 1;
+    pc_need_dyn_lds((const void *)k_killoff_cl, sh);
+    hipLaunchKernelGGL(k_killoff_cl, dim3(1), dim3(KO_NT), sh, st, *S, npow2, nc);
+    return 0;
+}
+
 extern "C" int pc_consume_cl_fits(const PcState *S, int nc)
 {
     if (nc < 2 || nc > CL_MAXC || S->B > 1024 || S->nr > 64 * PC_MASK_WORDS || S->Ncap >= 65536) return 0;

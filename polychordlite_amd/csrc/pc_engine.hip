@@ -75,6 +75,7 @@ int pc_launch_consume_par(const PcState *, hipStream_t);
 int pc_launch_final_par(const PcState *, hipStream_t);
 int pc_consume_cl_fits(const PcState *, int);
 int pc_launch_consume_cl(const PcState *, int, hipStream_t);
+int pc_launch_killoff_cl(const PcState *, int, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
 void pc_launch_apply(const PcState *, unsigned, int, hipStream_t);
 void pc_launch_install_live(const PcState *, const double *, int, hipStream_t);
@@ -2625,7 +2626,8 @@ struct Engine {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
             }
-        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st);   // (several clusters: four waves, a death's jobs side by side)
+        } else if (h_ctl->ncluster > 1 && pc_launch_killoff_cl(&S, h_ctl->ncluster, st) == 0) {      // (several clusters: the deaths in sorted order by one wavefront, pc_clus.hip)
+        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st);   // (the general kernel: four waves, a death's jobs side by side)
         if (!fused_final) end_a2();
     }
     void end_a2()

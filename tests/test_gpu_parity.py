@@ -577,6 +577,36 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,box,maxnd", [("rastrigin", 4, 0, 400, 12, (-5.12, 5.12), 7000),         # 11 clusters alive at the end
+                                                            ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12), 3000),          # 25
+                                                            ("twin_gaussian", 8, 1, 300, 16, (-1.0, 1.0), -1), ("twin_gaussian", 30, 1, 500, 40, (-1.0, 1.0), 20000),      # 2
+                                                            ("rastrigin", 10, 0, 1000, 30, (-5.12, 5.12), 24000),
+                                                            ("rastrigin", 3, 0, 2400, 9, (-5.12, 5.12), 12000),        # 15, a live set of 4096 sort entries
+                                                            ("rastrigin", 3, 0, 2400, 9, (-5.12, 5.12), 20000)])       # 69: more than the kernel takes, both runs by the general one
+def test_clustered_kill_off_kernels_agree(engine, kind, D, nDer, nlive, nr, box, maxnd):
+    """the end of a run with several clusters alive (nested_sampling.F90:381-384: every live point dies, lowest first; delete_cluster
+    whenever a cluster has lost its last point): the one-wave kill-off of pc_clus.hip (deaths in the sorted order, cluster = lane)
+    against the general kernel it stands in for (settings.ablate bit 9) -- the same statements in the same order: the same bits.
+    max_ndead stops some of the runs early, with more clusters alive than at a run's natural end"""
+    api = engine
+    L, P, keep = api.make_problem(kind, D, nDer, *box)
+    runs = []
+    for ab in (0, 512):
+        s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=33, batch=0, do_clustering=1, max_ndead=maxnd)
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    a, b = runs
+    assert a["ncluster"] >= 2                                           # (clusters alive when the run stopped: the kill-off's)
+    for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a["logZ"] == b["logZ"] and a["logZerr"] == b["logZerr"], (a["logZ"], b["logZ"])
+    assert np.array_equal(a["dead"], b["dead"])
+    assert np.array_equal(a["logweights"], b["logweights"])
+    assert np.array_equal(a["logZp"], b["logZp"]) and np.array_equal(a["varlogZp"], b["varlogZp"])
+    assert np.array_equal(a["post_mean"], b["post_mean"]) if "post_mean" in a else True
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,nDer,nlive,nr,box,maxnd", [("rastrigin", 4, 0, 300, 8, (-5.12, 5.12), 2400), ("twin_gaussian", 30, 1, 300, 10, (-1.0, 1.0), -1)])
 def test_phantoms_find_the_same_clusters_by_both_kernels(engine, kind, D, nDer, nlive, nr, box, maxnd):
     """a split's phantoms go to the cluster of their nearest live point (run_time_info.f90:444-453): the lane-per-phantom kernel
