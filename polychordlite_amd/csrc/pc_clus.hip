@@ -78,6 +78,12 @@ __host__ __device__ inline ClLayout cl_layout(int Ncap, int B, int nr)
     return o;
 }
 
+// LDS words that another wave of the workgroup reads or writes while the loop runs (progress words, a slot's cluster / owner / position): relaxed
+// atomics of workgroup scope = plain ds_read / ds_write that the compiler neither caches nor reorders against other memory operations.  As
+// `*(volatile int *)&x` they were FLAT instructions (the address-space inference does not rewrite volatile accesses): slower than a ds
+// operation, and counted on vmcnt -- every wait for one of them also waited for the next chain's records, requested a moment before from L2.
+__device__ __forceinline__ int cl_lld(const int *p) { return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void cl_lst(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int cl_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double cl_unid(double v)
 {
