@@ -625,7 +625,8 @@ struct Cohort {
     }
     void flush()
     {
-        if (pend.empty()) { run_pre(); run_post(); return; }
+        run_pre();
+        if (pend.empty()) { run_post(); return; }
         const size_t n = pend.size();
         if (n > cap) {
             for (int k = 0; k < RING; ++k) {
@@ -657,12 +658,7 @@ struct Cohort {
         };
         std::stable_sort(ord.begin(), ord.end(), shape_less);
         for (size_t i = 0; i < n; ++i) { hs[i].S = ord[i]->S; std::memcpy(hs[i].p, ord[i]->p, sizeof(ord[i]->p)); std::memcpy(hs[i].ia, ord[i]->ia, sizeof(ord[i]->ia)); }
-        // (the records go up with the other small copies in front of the launches, in the same kernel, not as a copy command of their own
-        //  between two kernels: one launch less per flush.  Measured: no difference in the wall of sixteen / thirty-two clustered runs in step
-        //  -- the ~60 us the queue idles either side of that point of a flush are the host's, not the copy's; PC_COHORT_REC_MEMCPY=1: as before)
-        static const bool rec_copy_cmd = std::getenv("PC_COHORT_REC_MEMCPY") != nullptr;
-        if (rec_copy_cmd) { run_pre(); HIPCHK(hipMemcpyAsync(dr, hs, sizeof(PcManyRec) * n, hipMemcpyHostToDevice, st)); }
-        else { pre_copies.push_back({(uintptr_t)dr, (uintptr_t)hs, (uintptr_t)(sizeof(PcManyRec) * n)}); run_pre(); }
+        HIPCHK(hipMemcpyAsync(dr, hs, sizeof(PcManyRec) * n, hipMemcpyHostToDevice, st));
         bool up_marked = false, used_st2 = false;
         for (size_t i = 0; i < n;) {
             size_t j = i + 1;
