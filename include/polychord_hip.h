@@ -131,7 +131,8 @@ typedef struct {
                            launch by the general contraction kernel (no one-wave kernel); bits 6, 7 = a run on its own by the kernels it uses
                            next to other runs of its device (bit 6: lane-per-chain sampling, pc_slice_t.hip; bit 7: lane-per-vector bases); bit 8 = the one-wave
                            contraction of clustered runs ends its launch at a cluster's death (the host relaunches for the rest of the nursery) instead
-                           of sorting the live set itself and going on */
+                           of sorting the live set itself and going on; bit 9 = the kill-off of a run that ends with several clusters by the general
+                           contraction kernel instead of the one-wave kernel k_killoff_cl (the same bits) */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the
