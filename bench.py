@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_EVAL = 258.0
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+GENERAL_PMC_FILES = ("r06_general_pmc.json",)      # PMC passes of the general-functor run (tools/collect_pmc.sh with PC_ABLATE=1)
 COMPACT_LIMIT = 6000        # bytes of the last stdout line (the driver parsed 6.5 KB and 13 KB, not 18.9 KB)
 # BASELINE.json configs through this harness: kind, nDims, nDerived, nlive, num_repeats, clustering, box, analytic logZ
 WORKLOADS = {
@@ -327,16 +328,19 @@ def compact_record(full, full_path=None):
     if lz:
         out["logZ_mean"] = float(np.mean(lz)); out["logZ_sem"] = float(np.std(lz, ddof=1) / np.sqrt(len(lz))) if len(lz) > 1 else None
         out["logZerr_mean"] = float(np.mean(le)) if le else None
-    out.update(_pick(full, ("logZ_truth", "value_reference_equivalent", "speedup_wall_per_run", "speedup_evals_per_s", "merge_ms", "exchange")))
+    out.update(_pick(full, ("logZ_truth", "value_reference_equivalent", "speedup_wall_per_run", "speedup_evals_per_s", "merge_ms", "exchange", "paths")))
     mg = full.get("merged")
     if mg:
         out["merged"] = _pick(mg, ("n_runs", "logZ", "logZerr", "evidence_rule", "records"))
     gf = full.get("general_functor")
     if gf:
-        out["general_functor"] = _pick(gf, ("value", "ms_per_step"))
+        # `value` is the built-in Gaussian by its closed form along the chord, failed spawns counted: the figure a user's OWN device functor gets
+        # (one reduction per trial) stands next to it at the top, and so does the reference-equivalent one (value_reference_equivalent)
+        out["value_general_functor"] = gf.get("value")
+        out["general_functor"] = _pick(gf, ("value", "ms_per_step", "frac", "avg_launch_us", "traffic"))
     oc = full.get("other_configs")
     if oc:
-        out["other_configs"] = {n: (_pick(v, ("value", "ms_per_step", "logZ", "logZerr", "logZ_truth", "evals_per_lived_dead", "dominant_kernel", "whole_run_frac"))
+        out["other_configs"] = {n: (_pick(v, ("value", "ms_per_step", "logZ", "logZerr", "logZ_truth", "evals_per_lived_dead", "dominant_kernel", "whole_run_frac", "general_kernel_launches"))
                                     if "error" not in v else {"error": str(v["error"])[:80]}) for n, v in oc.items()}
     if full.get("leg_errors"):
         out["leg_errors"] = {k: str(v)[:80] for k, v in list(full["leg_errors"].items())[:6]}
@@ -426,6 +430,9 @@ def bootstrap(args):
     return rank, local_rank, world, dist, torch
 
 
+GLOO_NOTE = " -- ranks SHARE the visible GPU(s), the exchange goes over a host all-gather (gloo) handed to the library: a test of the N > 1 code path, not a scaling figure"
+
+
 def reduce_over_ranks(dist, torch, device, dt, sums):
     """(max over ranks of dt, sums added over ranks) -- what turns the ranks' clocks and counters into the job's"""
     if dist is None:
@@ -449,10 +456,19 @@ class Bench:
         self.lib = api.load()
         if self.lib.pchip_device_count() < 1:
             raise SystemExit("bench.py: no HIP device visible; the engine has no CPU path")
-        self.dev = f"cuda:{local_rank}"
         # the exchange step's communicator: RCCL inside the library (its id travels through the process group the ranks were
-        # started with); one rank needs none
-        self.comm = Comm(rank, world, local_rank) if world > 1 else None
+        # started with); one rank needs none.  --backend gloo on a GPU box (tests, a one-GPU box): the ranks share the visible devices,
+        # the process group is gloo on host tensors and the library's exchange runs over it (merge.CallbackComm) -- every statement of
+        # pchip_comm_merge_many and of this harness with world > 1, no claim about xGMI
+        if args.backend == "gloo":
+            from polychordlite_amd.merge import CallbackComm, host_all_gather
+            local_rank = self.local_rank = local_rank % self.lib.pchip_device_count()
+            torch.cuda.set_device(local_rank)
+            self.dev = "cpu"                                        # (where the harness's own reductions live: gloo)
+            self.comm = CallbackComm(rank, world, local_rank, host_all_gather(dist, torch, local_rank)) if world > 1 else None
+        else:
+            self.dev = f"cuda:{local_rank}"
+            self.comm = Comm(rank, world, local_rank) if world > 1 else None
         self.wl = WORKLOADS[args.workload]
         self.nlive = args.nlive if args.nlive > 0 else self.wl["nlive"]
         self.s, self.L, self.P, self.keep = self.problem(self.wl, self.nlive, args.batch)
@@ -487,6 +503,15 @@ class Bench:
 
     def reduce(self, dt, sums):
         return reduce_over_ranks(self.dist, self.torch, self.dev, dt, sums)
+
+    def agree(self, ok):
+        """all ranks: did everybody's local part succeed?  (one all-reduce; what run_repeats calls between a rank's runs and their exchange, so
+        that a rank-local failure inside a leg that swallows exceptions cannot leave the other ranks waiting in the all-gather)"""
+        if self.dist is None:
+            return bool(ok)
+        t = self.torch.tensor([0.0 if ok else 1.0], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0]) == 0.0
 
     # ---- the timed region: K steps (one full run each) + the exchange of the last step's runs, barrier + sync on both sides
     def timed_steps(self):
@@ -538,13 +563,13 @@ class Bench:
         s_m = api.Settings(); C.memmove(C.byref(s_m), C.byref(self.s), C.sizeof(self.s)); s_m.profile = 0
         seeds = lambda base, k: [base + 100003 * self.rank + 1000 * k + j for j in range(R)]
         for w in range(2):              # untimed: the block cache for R engines, the kernels' first launches
-            _, held = run_repeats(s_m, self.L, self.P, seeds(300000, w), max_in_flight=R, comm=self.comm)
+            _, held = run_repeats(s_m, self.L, self.P, seeds(300000, w), max_in_flight=R, comm=self.comm, agree=self.agree)
             held = None
         samples = []
         for k in range(3):
             self.sync()
             tq0 = time.perf_counter()
-            mm, held = run_repeats(s_m, self.L, self.P, seeds(310000, k), max_in_flight=R, comm=self.comm)
+            mm, held = run_repeats(s_m, self.L, self.P, seeds(310000, k), max_in_flight=R, comm=self.comm, agree=self.agree)
             held = None
             self.sync()
             tq, (nl_all,) = self.reduce(time.perf_counter() - tq0, [float(mm["nlike_local"])])
@@ -565,16 +590,36 @@ class Bench:
         a wave reduction like any other device functor would (same trajectory up to round-off)"""
         if not (self.extras and self.wl["kind"] in ("gaussian", "corr_gaussian") and self.args.workload != "c5"):
             return None
-        s = self.s
+        s, wl = self.s, self.wl
+        prof_keep = s.profile
         s.ablate = 1; s.profile = 0
         self.one(-100)
         tg0 = time.perf_counter()
         gr = [self.one(-101 - k) for k in range(3)]
         self.torch.cuda.synchronize()
         tg = time.perf_counter() - tg0
-        s.ablate = int(os.environ.get("PC_ABLATE", "0"))
-        return {"value": sum(r["nlike"] for r in gr) / tg, "unit": "likelihood evals/s", "ms_per_step": tg / 3 * 1e3, "logZ": [r["logZ"] for r in gr],
-                "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
+        # ... and its sampling kernel under the HIP-event stopwatch (one more run, every launch timed; not part of the figure above):
+        # k_slice<.., LEAN = 0> with its OWN algorithmic bytes -- the roofline entry of the path any user functor takes
+        s.profile = self.cls_bit("k_slice")
+        pr = self.one(-110)
+        s.ablate = int(os.environ.get("PC_ABLATE", "0")); s.profile = prof_keep
+        kt = pr["kernel_time"].get("k_slice")
+        out = {"value": sum(r["nlike"] for r in gr) / tg, "unit": "likelihood evals/s", "ms_per_step": tg / 3 * 1e3, "logZ": [r["logZ"] for r in gr],
+               "value_reference_equivalent": sum(r["nlike"] - r["nlike_failed"] for r in gr) / tg,
+               "note": "built-in Gaussian evaluated like a general device functor (one wave reduction per trial, no closed form along the chord); 3 runs"}
+        if kt and kt["launches"] > 0:
+            own = own_bytes_per_launch("k_slice", wl["D"], wl["nDer"], wl["nr"], self.nlive, pr["batch"])
+            avg = kt["total_s"] / kt["launches"]
+            bpe = BYTES_PER_EVAL if self.args.workload == "c2" else algorithmic_bytes_per_iteration(wl["D"], wl["nDer"], wl["nr"], self.nlive) * pr["niter"] / pr["nlike"]
+            per_launch = pr["nlike"] / max(1, pr["nbatches"]) * bpe
+            rec, name = committed_record(GENERAL_PMC_FILES, ("kernels",))
+            hit = sorted([v for k, v in (rec["kernels"] if rec else {}).items() if k.startswith("k_slice")], key=lambda v: -v["launches"])
+            out.update({"kernel": "k_slice (general functor)", "avg_launch_us": avg * 1e6, "launches_timed": kt["launches"],
+                        "achieved": per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "frac": per_launch / avg / 1e9 / HBM_PEAK_GBS,
+                        "own_bytes_per_launch": own, "own_frac": own / avg / 1e9 / HBM_PEAK_GBS,
+                        "whole_run_frac": sum(r["nlike"] for r in gr) * bpe / tg / 1e9 / HBM_PEAK_GBS,
+                        "traffic": hit[0]["hbm_bytes_per_launch"] if hit else None, "traffic_source": ("profiles/" + name) if hit else None})
+        return out
 
     def concurrent(self, Rs):
         """R independent runs of the metric configuration in step on this GPU, for each R of the list"""
@@ -696,6 +741,8 @@ class Bench:
                             "ndead": int(r2["ndead"]), "nlike": int(r2["nlike"]), "clusters_peak": int(r2["ncluster_peak"]),
                             "dominant_kernel": dom2, "dominant_share_of_kernel_time": (kt2[dom2]["total_s"] / sum(v["total_s"] for v in kt2.values())) if dom2 else None,
                             "kernel_time_s": {n: round(v["total_s"], 6) for n, v in kt2.items()},
+                            # which kernels the run went through (pchip_result.path): a silent drop to the general serial kernel shows here
+                            "paths": {k: v for k, v in r2["path"].items() if v}, "general_kernel_launches": int(r2["path"]["consume_general"] + r2["path"]["killoff_general"]),
                             "bytes_per_eval": bpe2, "whole_run_frac": r2["nlike"] * bpe2 / to / 1e9 / HBM_PEAK_GBS,
                             "note": "HIP-event stopwatch around every kernel class of the run's main stream (profile = 1: a few percent slower than an untimed run)"}
             r2 = None
@@ -788,7 +835,7 @@ def main():
         # on more than one GPU, and a line that is already out survives whatever happens there.  The LAST line is the complete record.
         early = {"metric": METRIC[args.workload] % nlive, "value": T["nlike"] / T["tmax"], "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps,
                  "warmup": args.warmup, "ms_per_step": T["tmax"] / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                 "dtype": "f64", "data": "synthetic", "config": {"workload": wl["short"] % nlive + ", one full run per step", "parallelism": "repeat-sharded x%d" % world},
+                 "dtype": "f64", "data": "synthetic", "config": {"workload": wl["short"] % nlive + ", one full run per step", "parallelism": "repeat-sharded x%d" % world + GLOO_NOTE * (args.backend == "gloo" and world > 1)},
                  "roofline": None, "cpu_baseline": None, "partial": "timed region only; the complete record follows"}
         print(json.dumps(_num(early), separators=(",", ":")), flush=True)
     # (none of the legs below is ever the reason to lose the timed region's record: Bench.leg)
@@ -820,7 +867,7 @@ def main():
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": wl["name"] % nlive + ", precision_criterion=1e-3, one full nested-sampling run per step",
                            "workload_short": wl["short"] % nlive + ", one full run per step",
-                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world,
+                           "batch_chains": runs[-1]["batch"], "parallelism": "repeat-sharded x%d" % world + GLOO_NOTE * (args.backend == "gloo" and world > 1),
                            "mode": "one run at a time per GPU (a step = one run; every rank of --gpus N runs this mode).  R runs of a GPU in step -- its best "
                                    "mode, `concurrent*`, roofline.in_step and roofline.in_step_multi -- are reported beside it, never in `value`"},
                 "logZ": [r["logZ"] for r in runs], "logZerr": [r["logZerr"] for r in runs],
@@ -836,6 +883,7 @@ def main():
                 "host_time_s": {k: runs[-1][k] for k in HOST_PHASES},
                 "host_time_ms_steps": {k: [round(r[k] * 1e3, 3) for r in runs] for k in HOST_PHASES},
                 "rounds": int(runs[-1]["nrounds"]), "batches": int(runs[-1]["nbatches"]),
+                "paths": {k: v for k, v in runs[-1]["path"].items() if v},
                 "reference_cpu_evals_per_s_survey_container": 357e3}
         cb = b.leg("cpu_baseline", lambda: CpuBaseline(wl, nlive).finish(), None) if world == 1 and not args.no_cpu else None      # (both legs now, alone: every GPU figure has been taken)
         if cb:

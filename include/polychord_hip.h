@@ -196,7 +196,25 @@ typedef struct {
        by the result (pchip_result_free): rows [n_records][nTotal] at d_records, their entry contours at d_records + records_cap * nTotal,
        their own log weights at d_records + records_cap * (nTotal + 1).  NULL when not asked for. */
     double *d_records; long n_records, records_cap; int records_device;
+    /* Which kernels the run went through: launches per variant, counted where the host chooses (PCHIP_PATH_* below).  A shape that
+       silently leaves a fast path -- an LDS layout that no longer fits, a guard that no longer holds -- shows up here and nowhere
+       else: its numbers are the same.  tests/test_baseline_configs.py holds the BASELINE shapes to their paths. */
+    long path[16];
 } pchip_result;
+enum { PCHIP_PATH_CONSUME_PAR = 0,      /* one cluster: the parallel contraction k_consume_par (pc_par.hip) */
+       PCHIP_PATH_CONSUME_CL = 1,       /* several clusters: k_consume_cl (pc_clus.hip) */
+       PCHIP_PATH_CONSUME_GENERAL = 2,  /* the general serial kernel k_consume (pc_contract.hip): dynamic nlive, sequential test mode, shapes beyond the LDS */
+       PCHIP_PATH_CONSUME_FAST = 3,     /* one cluster, one wavefront: k_consume_fast (B > 1024) */
+       PCHIP_PATH_KILLOFF_PAR = 4, PCHIP_PATH_KILLOFF_CL = 5, PCHIP_PATH_KILLOFF_GENERAL = 6, PCHIP_PATH_KILLOFF_FAST = 7,   /* the final kill-off's kernel */
+       PCHIP_PATH_UPDATE_FUSED = 8,     /* updates by the fused kernels of pc_update.hip */
+       PCHIP_PATH_UPDATE_STEPS = 9,     /* updates by clean + covariance + Cholesky launches (clustered runs, posteriors with boost, nDims beyond the fused kernel) */
+       PCHIP_PATH_SLICE_WAVE = 10,      /* nurseries sampled by k_slice (wavefront = chain) */
+       PCHIP_PATH_SLICE_LANE = 11,      /* nurseries sampled by k_slice_t (lane = chain: runs in step) */
+       PCHIP_PATH_NN_LISTS = 12,        /* candidate-list launches (k_nn_lists) */
+       PCHIP_PATH_NN_FALLBACKS = 13,    /* chains whose candidate lists held no living entry: the full search inside the contraction */
+       PCHIP_PATH_POOL_MODE = 14,       /* 1: babies written straight into the phantom array */
+       PCHIP_PATH_DEFER_UPDATE = 15,    /* 1: the contraction runs past update triggers */
+       PCHIP_PATH_COUNT = 16 };
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
    (nested_sampling.F90:323-340, read_write.F90) -- host memory owned by the engine, valid during the call */
@@ -225,6 +243,7 @@ typedef struct {
     const double *split_logfrac;               /* log(evidence of child / evidence of parent) at the split */
     /* boost_posterior: phantom points kept as posterior samples (run_time_info.f90:845-870), same row layout */
     int n_extra; const double *extra, *extra_logpost; const unsigned *extra_cluster;
+    const unsigned long long *extra_uid;       /* [n_extra] the phantoms' ids (nursery << 32 | chain * num_repeats + baby): what keys their trials */
 } pchip_update;
 typedef void (*pchip_update_fn)(void *user, const pchip_update *u);
 
@@ -239,7 +258,7 @@ typedef struct {
  * bindings rely on).  A binding that mirrors them (ctypes, ISO_C_BINDING, cgo ...) checks itself against the library it loaded:
  * pchip_abi_version() == PCHIP_ABI_VERSION of the header it was written against, and pchip_sizeof("settings" | "result" | "merged" |
  * "like" | "prior" | "update") == the size of its own mirror (0 for an unknown name). */
-#define PCHIP_ABI_VERSION 6
+#define PCHIP_ABI_VERSION 7
 int  pchip_abi_version(void);
 unsigned long pchip_sizeof(const char *struct_name);
 void pchip_settings_default(pchip_settings *s, int nDims, int nDerived);
@@ -280,8 +299,10 @@ typedef struct {
      *        the replay does not know (10-D Rastrigin, dozens of clusters: the replay sits 0.46 below the runs' own log Z, twenty of its own
      *        error bars).  Then logZ, varlogZ = the runs' own evidences combined in linear space -- log-normal moments of each run,
      *        mean of the Z_r, variance the larger of the propagated one and the scatter between the runs -- and record i of a run keeps its
-     *        OWN log weight minus log(nruns): the union is the equal-weight mixture of the runs' posteriors.  The replay stays in
-     *        logZ_replay, varlogZ_replay; `nlive` is the replay's live count either way. */
+     *        OWN log weight minus log(nruns): sum_i w_i L_i over the union = the mean of the runs' Z_r, so the union's posterior is the
+     *        Z_r-WEIGHTED mixture of the runs' posteriors (run r carries Z_r / sum Z), not an equal-weight one.  The replay stays in
+     *        logZ_replay, varlogZ_replay; `nlive` is the replay's live count either way -- and <root>_dead-birth.txt of such a union, read
+     *        by anesthetic, reproduces logZ_replay, not the log Z written in <root>.stats. */
     double logZ_replay, varlogZ_replay;
     int evidence_rule, nclustered;
 } pchip_merged;
@@ -337,6 +358,13 @@ int  pchip_comm_merge(pchip_comm *c, const pchip_result *run, double logzero, in
  * merged on every rank (pchip_merge_records_ex).  Ranks may hold different numbers of runs. */
 int  pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, double logzero, int nDims, int nDerived, int want_rows,
                            pchip_merged *out);
+/* The same exchange over the CALLER's collective instead of RCCL: all_gather(user, send, recv, bytes) places every rank's `bytes` at `send`
+ * (device memory of `device`) into `recv` (device memory, nranks * bytes, rank after rank) on all ranks; it is called with the library's stream
+ * drained and returns 0 once `recv` is complete.  For a host that brings its own transport (a GPU-aware MPI_Allgather under the reference's
+ * MPI launcher, mpi_utils.F90:376-463; torch.distributed) and for tests with several ranks on one GPU, where RCCL forms no communicator.
+ * pchip_comm_merge / _merge_many / _destroy take the communicator like one made by pchip_comm_create. */
+typedef int (*pchip_allgather_fn)(void *user, const void *send, void *recv, unsigned long bytes);
+int  pchip_comm_create_with(pchip_allgather_fn all_gather, void *user, int nranks, int rank, int device, pchip_comm **out);
 const char *pchip_comm_library(void);   /* the RCCL that was resolved (path or soname), NULL if none could be loaded */
 
 /* kernel-level: directions + slice chains only (parity tests against oracle pc_slice_chain) */

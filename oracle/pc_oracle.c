@@ -423,6 +423,7 @@ typedef struct {
     ptarr dead; double *logweights; int lwcap;
     long nlike;
     double logX_last_update, thin_posterior, maxlogweight_global;
+    uint32_t post_round;      /* update_posteriors calls so far (keyed mode: the thinning round of bernoulli_post) */
     ptarr posterior_global, equals_global;
     /* dead clusters */
     int ncluster_dead; double *logZp_dead, *logZp2_dead;
@@ -551,7 +552,7 @@ static void delete_outermost_point(rti_t *R)
     pp[R->pos_w] = logweight;
     pp[R->pos_Z] = R->logZ;
     memcpy(pp + R->pos_p0, pt + R->p0, sizeof(double) * (R->D + R->nDer));
-    pa_add(&C->pstack, pp, 0);
+    pa_add(&C->pstack, pp, (uint64_t)(R->dead.n - 1));      /* (keyed mode: the row's id = its index in death order, see bernoulli_post) */
     double lw = pp[R->pos_w] + pp[R->pos_l];
     if (lw > C->maxlogweight) C->maxlogweight = lw;
     if (C->maxlogweight > R->maxlogweight_global) R->maxlogweight_global = C->maxlogweight;
@@ -626,7 +627,19 @@ static int replace_point(rti_t *R, const double *babies, const uint64_t *uids, i
     return replaced;
 }
 
-static int bernoulli_post(rti_t *R, double p) { return rng_post(&R->rng) < p; }
+/* A Bernoulli trial of update_posteriors (run_time_info.f90:975-1062).  Sequential mode: the next draw of the ONE stream, in the
+ * reference's program order (what the reference binary pins).  Keyed mode (the HIP engine's): the reference's trials are independent
+ * draws, and WHICH draw a row gets is an accident of its arrays' order (per-cluster stacks, delete = overwrite-with-last) -- so the
+ * trial of posterior row `uid` (a dead point: its index in death order; a phantom kept by boost_posterior: its phantom id, top bit set)
+ * in thinning round `post_round` (the number of the update_posteriors call) is the draw keyed by (round, row): the same rows survive
+ * whatever order the lists are walked in, with several clusters and with phantoms in the stack.  list: 0 the global list, 1 a
+ * cluster's own (cluster_posteriors). */
+static int bernoulli_post(rti_t *R, double p, uint64_t uid, uint32_t list)
+{
+    if (R->rng.sequential) return rng_post(&R->rng) < p;
+    const uint32_t a = (R->post_round & 0x0FFFFFFFu) | ((uid >> 63) ? 0x80000000u : 0u) | (list ? 0x40000000u : 0u);
+    return pc_uniform_keyed(R->rng.key, PC_DOM_POST, a, (uint32_t)((uid & 0x7FFFFFFFFFFFFFFFull) >> 32), (uint32_t)uid) < p;
+}
 
 static void clean_phantoms(rti_t *R)
 {   /* run_time_info.f90:820-877.  The posterior stack of a cluster holds that cluster's
@@ -659,7 +672,7 @@ static void clean_phantoms(rti_t *R)
                     pp[R->pos_w] = st[R->pos_w];
                     pp[R->pos_Z] = st[R->pos_Z];
                     memcpy(pp + R->pos_p0, pt + R->p0, sizeof(double) * (R->D + R->nDer));
-                    pa_add(&C->pstack, pp, 0);
+                    pa_add(&C->pstack, pp, uid | (1ull << 63));
                     double lw = pp[R->pos_w] + pp[R->pos_l];
                     if (lw > C->maxlogweight) C->maxlogweight = lw;
                     if (C->maxlogweight > R->maxlogweight_global) R->maxlogweight_global = C->maxlogweight;
@@ -670,13 +683,13 @@ static void clean_phantoms(rti_t *R)
     }
 }
 
-static void thin_equals(rti_t *R, ptarr *eq, double maxlw)
+static void thin_equals(rti_t *R, ptarr *eq, double maxlw, uint32_t list)
 {   /* run_time_info.f90:976-997 */
     int i = 0;
     while (i < eq->n) {
         double *row = eq->a + (size_t)i * R->np;
         if (row[0] < maxlw) {
-            if (bernoulli_post(R, exp(row[0] - maxlw))) { row[0] = maxlw; i++; }
+            if (bernoulli_post(R, exp(row[0] - maxlw), eq->uid[i], list)) { row[0] = maxlw; i++; }
             else pa_del(eq, i, NULL, NULL);
         } else i++;
     }
@@ -685,11 +698,12 @@ static void thin_equals(rti_t *R, ptarr *eq, double maxlw)
 static void update_posteriors(rti_t *R)
 {   /* run_time_info.f90:955-1066 */
     const pc_settings *s = R->s;
+    R->post_round++;
     clean_phantoms(R);
     if (s->equals) {
-        thin_equals(R, &R->equals_global, R->maxlogweight_global);
+        thin_equals(R, &R->equals_global, R->maxlogweight_global, 0);
         if (s->cluster_posteriors)
-            for (int c = 0; c < R->ncluster; ++c) thin_equals(R, &R->cl[c].equals, R->cl[c].maxlogweight);
+            for (int c = 0; c < R->ncluster; ++c) thin_equals(R, &R->cl[c].equals, R->cl[c].maxlogweight, 1);
     }
     double *ep = (double *)malloc(sizeof(double) * R->np);
     for (int c = 0; c < R->ncluster; ++c) {
@@ -697,16 +711,16 @@ static void update_posteriors(rti_t *R)
         for (int i = 0; i < C->pstack.n; ++i) {
             const double *st = C->pstack.a + (size_t)i * R->npost;
             if (s->equals) {
-                if (bernoulli_post(R, exp(st[R->pos_w] + st[R->pos_l] - R->maxlogweight_global))) {
+                if (bernoulli_post(R, exp(st[R->pos_w] + st[R->pos_l] - R->maxlogweight_global), C->pstack.uid[i], 0)) {
                     ep[0] = R->maxlogweight_global; ep[1] = -2 * st[R->pos_l];
                     memcpy(ep + 2, st + R->pos_p0, sizeof(double) * (R->D + R->nDer));
-                    pa_add(&R->equals_global, ep, 0);
+                    pa_add(&R->equals_global, ep, C->pstack.uid[i]);
                 }
                 if (s->cluster_posteriors &&
-                    bernoulli_post(R, exp(st[R->pos_w] + st[R->pos_l] - C->maxlogweight))) {
+                    bernoulli_post(R, exp(st[R->pos_w] + st[R->pos_l] - C->maxlogweight), C->pstack.uid[i], 1)) {
                     ep[0] = C->maxlogweight; ep[1] = -2 * st[R->pos_l];
                     memcpy(ep + 2, st + R->pos_p0, sizeof(double) * (R->D + R->nDer));
-                    pa_add(&C->equals, ep, 0);
+                    pa_add(&C->equals, ep, C->pstack.uid[i]);
                 }
             }
             if (s->posteriors) {
@@ -819,7 +833,7 @@ static void add_cluster(rti_t *R, int p, const int *labels, int nnew)
     for (int k = 0; k < nnew; ++k) {
         cluster_t *C = &R->cl[nold + k];
         for (int i = 0; i < oldp.posterior.n; ++i) pa_add(&C->posterior, oldp.posterior.a + (size_t)i * R->npost, 0);
-        for (int i = 0; i < oldp.equals.n; ++i) pa_add(&C->equals, oldp.equals.a + (size_t)i * R->np, 0);
+        for (int i = 0; i < oldp.equals.n; ++i) pa_add(&C->equals, oldp.equals.a + (size_t)i * R->np, oldp.equals.uid[i]);
         C->maxlogweight = oldp.maxlogweight;
     }
     /* 4b) re-home ALL phantoms (old numbering order) by nearest live point */

@@ -58,7 +58,14 @@ class Result(C.Structure):
                 ("post_mean", C.POINTER(C.c_double)), ("post_var", C.POINTER(C.c_double)),
                 ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int)),
                 ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int), ("epoch_discard", C.c_int),
-                ("d_records", C.c_void_p), ("n_records", C.c_long), ("records_cap", C.c_long), ("records_device", C.c_int)]
+                ("d_records", C.c_void_p), ("n_records", C.c_long), ("records_cap", C.c_long), ("records_device", C.c_int),
+                ("path", C.c_long * 16)]
+
+
+# pchip_result.path[]: launches per kernel variant (include/polychord_hip.h PCHIP_PATH_*)
+PATH_NAMES = ("consume_par", "consume_cl", "consume_general", "consume_fast", "killoff_par", "killoff_cl", "killoff_general",
+              "killoff_fast", "update_fused", "update_steps", "slice_wave", "slice_lane", "nn_lists", "nn_fallbacks", "pool_mode",
+              "defer_update")
 
 
 _lib = None
@@ -192,6 +199,7 @@ def result_dict(r, settings):
                post_mean=np.ctypeslib.as_array(r.post_mean, shape=(D + settings.nDerived,)).copy(),
                post_var=np.ctypeslib.as_array(r.post_var, shape=(D + settings.nDerived,)).copy(),
                nlike_grade=[int(v) for v in r.nlike_grade], nlike_failed=r.nlike_failed, ncluster_peak=r.ncluster_peak, epoch_discard=r.epoch_discard, n_records=int(r.n_records) if r.d_records else None,
+               path={n: int(r.path[i]) for i, n in enumerate(PATH_NAMES)},
                varlogZp=np.ctypeslib.as_array(r.varlogZp, shape=(max(r.nZp, 1),))[:r.nZp].copy(),
                logzero=settings.logzero,
                _owner=own)          # the pchip_result itself (merge.comm_merge hands it back to the library)

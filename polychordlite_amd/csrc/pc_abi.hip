@@ -81,7 +81,7 @@ struct FileSink {
     // the equally weighted posterior, thinned at every update like the reference's (run_time_info.f90:975-1026): entries =
     // (log weight the entry was last accepted at, index of the point: dead point, or ndead_final + phantom kept by boost)
     std::vector<double> eq_w; std::vector<long> eq_i; std::vector<char> eq_x;
-    long eq_done = 0, eq_xdone = 0; unsigned long long eq_draws = 0; double eq_max = -1.7e308;
+    long eq_done = 0, eq_xdone = 0; unsigned eq_round = 0; int eq_ncd_seen = 0; double eq_max = -1.7e308;
     std::vector<long> nlike_last_g;
     std::vector<double> mu, sig;
     int feedback = 0, nlive_set = 1;
@@ -213,30 +213,61 @@ struct FileSink {
     // write_posterior_file, read_write.F90:479-617); the equally weighted list comes from thin_equals_round.
     // One round of update_posteriors for the global equal-weight list: survivors of the earlier rounds are re-drawn against
     // the ratio of their weight to the largest weight so far and move up to it, the points that joined the posterior stack
-    // since the last round (deaths in death order, then the phantoms boost_posterior kept) are drawn against it.  The trials
-    // are the numbered draws of the posterior domain of the counter RNG, in the order the reference's loops make them
-    // (thin_equals: array order with delete = overwrite-with-last, array_utils.f90:433-458; then the stack) -- so that with
-    // one cluster the list is, entry for entry, the one the oracle (and through it the reference) builds.
+    // since the last round (deaths in death order, then the phantoms boost_posterior kept) are drawn against it.
+    // The reference's trials are independent draws of its one generator, and WHICH draw a row gets is an accident of its
+    // arrays' order (per-cluster stacks walked cluster by cluster, delete = overwrite-with-last, array_utils.f90:433-458).
+    // Here -- and in the oracle's keyed mode, oracle/pc_oracle.c bernoulli_post -- the trial of posterior row r in thinning
+    // round k is the draw keyed by (k, r): r = the dead point's index in death order, or the kept phantom's id with the top
+    // bit of the round word set.  The rows that survive are then the same whatever order the lists are walked in: with
+    // several clusters, and with phantoms in the stack, the file holds the oracle's rows (tests: sorted, row for row).
     void thin_equals_round(const pchip_update &u)
     {
-        auto draw = [&]() { const unsigned long long n = eq_draws++; return polychord_hip_keyed_uniform(seed, 6u, (unsigned)(n >> 32), 0u, (unsigned)n); };
+        // The reference makes a round at every update AND whenever a cluster has lost its last point (delete_cluster calls
+        // update_posteriors, run_time_info.f90:533-534; also for every cluster that ends in the final kill-off, nested_sampling.F90:381-386).
+        // The engine deletes clusters on the device with no host call, but the moments can be read off the records: a cluster ended with
+        // the last point that died in it.  Rounds in the reference's order: the cluster ends before this hook's death count, ascending; the
+        // update itself (the last cluster's end, when the run is over); then the ends that coincide with it (nested_sampling.F90:321-339: the
+        // update's round comes first).  Phantoms kept by boost_posterior join at the hooks only (with several clusters AND boost_posterior the
+        // rounds between differ from the reference's: its clean_phantoms runs in them too).
+        std::vector<long> ends;
+        for (int k = eq_ncd_seen; k < u.ncluster_dead; ++k) {
+            long last = -1;
+            for (long i = u.ndead - 1; i >= 0 && last < 0; --i) if (u.dead_cluster[i] == u.cluster_uid_dead[k]) last = i;
+            if (last >= 0) ends.push_back(last + 1);
+        }
+        eq_ncd_seen = u.ncluster_dead;
+        std::sort(ends.begin(), ends.end());
+        for (long b : ends) if (b < u.ndead) thin_equals_to(u, b, eq_xdone);
+        thin_equals_to(u, u.ndead, u.n_extra);
+        for (long b : ends) if (b >= u.ndead) thin_equals_to(u, u.ndead, u.n_extra);
+    }
+    // one round: the deaths before `nd` and the kept phantoms before `nx` that no round has seen yet
+    void thin_equals_to(const pchip_update &u, long nd, long nx)
+    {
+        const unsigned round = ++eq_round;
+        auto draw = [&](long i, bool extra) {
+            const unsigned long long id = extra ? (u.extra_uid ? u.extra_uid[i] : (unsigned long long)i) : (unsigned long long)i;
+            return polychord_hip_keyed_uniform(seed, 6u, (round & 0x0FFFFFFFu) | (extra ? 0x80000000u : 0u), (unsigned)((id & 0x7FFFFFFFFFFFFFFFull) >> 32), (unsigned)id);
+        };
         // a failed spawn carries logweight = the run's own logzero (run_time_info.f90:781-785): logpost - logL <= logzero
         auto lived = [&](long i) { return u.logpost[i] - u.dead[(size_t)i * u.npars + u.npars - 1] > logzero; };
-        for (long i = eq_done; i < u.ndead; ++i) if (lived(i)) eq_max = std::max(eq_max, u.logpost[i]);
-        for (long i = eq_xdone; i < u.n_extra; ++i) eq_max = std::max(eq_max, u.extra_logpost[i]);
+        if (nd < eq_done) nd = eq_done;
+        if (nx < eq_xdone) nx = eq_xdone;
+        for (long i = eq_done; i < nd; ++i) if (lived(i)) eq_max = std::max(eq_max, u.logpost[i]);
+        for (long i = eq_xdone; i < nx; ++i) eq_max = std::max(eq_max, u.extra_logpost[i]);
         for (size_t i = 0; i < eq_w.size();) {
             if (eq_w[i] < eq_max) {
-                if (draw() < std::exp(eq_w[i] - eq_max)) { eq_w[i] = eq_max; ++i; }
+                if (draw(eq_i[i], eq_x[i] != 0) < std::exp(eq_w[i] - eq_max)) { eq_w[i] = eq_max; ++i; }
                 else { eq_w[i] = eq_w.back(); eq_i[i] = eq_i.back(); eq_x[i] = eq_x.back(); eq_w.pop_back(); eq_i.pop_back(); eq_x.pop_back(); }
             } else ++i;
         }
-        for (long i = eq_done; i < u.ndead; ++i) {
+        for (long i = eq_done; i < nd; ++i) {
             if (!lived(i)) continue;                            // failed spawns never entered the stack
-            if (draw() < std::exp(u.logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(0); }
+            if (draw(i, false) < std::exp(u.logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(0); }
         }
-        for (long i = eq_xdone; i < u.n_extra; ++i)
-            if (draw() < std::exp(u.extra_logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(1); }
-        eq_done = u.ndead; eq_xdone = u.n_extra;
+        for (long i = eq_xdone; i < nx; ++i)
+            if (draw(i, true) < std::exp(u.extra_logpost[i] - eq_max)) { eq_w.push_back(eq_max); eq_i.push_back(i); eq_x.push_back(1); }
+        eq_done = nd; eq_xdone = nx;
     }
 
     void posterior_files(const pchip_update &u)
@@ -722,6 +753,19 @@ static void c_interface_impl(
         std::printf("| ndead  = %12ld                              |\n", r.ndead);
         std::printf("| log(Z) = %18.5f +/- %18.5f |\n", r.logZ, std::sqrt(std::fabs(r.varlogZ)));
         std::printf("|____________________________________________________|\n");
+        // (behind the reference's box, for the two things a caller of the drop-in cannot see from its numbers)
+        if (r.ncluster_peak > 1) {
+            std::printf("polychord_hip: up to %d clusters were alive at once.  The error above is this run's own estimate (run_time_info.f90:652-678);\n"
+                        "               WHICH modes a run finds adds run-to-run scatter it does not contain -- measured 4 x the reported error on a 10-D\n"
+                        "               Rastrigin, for the reference binary as for this engine.  Repeats with different seeds, combined, carry it\n"
+                        "               (pchip_run_repeats / polychordlite_amd.repeats.run_repeats).\n", r.ncluster_peak);
+            if (r.batch != 1 && !s.sequential_rng)
+                std::printf("polychord_hip: chains in flight when the list of clusters changed: %s\n",
+                            r.epoch_discard ? "all discarded -- the reference farm's rule (nested_sampling.F90:313)"
+                                            : "only those seeded in the cluster that ended were lost -- THIS ENGINE's rule, not the reference farm's\n"
+                                              "               (nested_sampling.F90:313 discards them all; polychord_hip_set_option(\"epoch_discard\", 1) selects that: same\n"
+                                              "               distribution of results, 1.7 x the likelihood evaluations at 10-D Rastrigin)");
+        }
     }
     if (feedback >= 1) {
         std::printf("polychord_hip: nlike = %ld  (%.3f s on the device, %d chains per nursery)\n", r.nlike, r.t_total, r.batch);

@@ -420,9 +420,24 @@ struct CohortStreams {
         return b;
     }
     void take(int dev, int c, bool main_stream = false) { if (c >= 0) used.emplace_back(dev, c + (main_stream ? 1000 : 0)); }
-    void give(int dev, int c) { for (size_t i = 0; i < used.size(); ++i) if (used[i].first == dev && used[i].second % 1000 == c) { used.erase(used.begin() + (long)i); return; } }
+    // (the exact entry that was taken: by class alone a group handing back its SIDE stream's class could erase another group's MAIN entry of the
+    //  same class, and busy(dev, mains_only) then misreports which hardware queues hold main streams)
+    void give(int dev, int c, bool main_stream = false)
+    {
+        if (c < 0) return;
+        const int v = c + (main_stream ? 1000 : 0);
+        for (size_t i = 0; i < used.size(); ++i) if (used[i].first == dev && used[i].second == v) { used.erase(used.begin() + (long)i); return; }
+    }
 };
 static CohortStreams &cstreams() { static CohortStreams *p = new CohortStreams; return *p; }
+// what a scheduler group holds of the table above, given back when the group is done -- or when anything between the take and that point throws
+struct CohortLease {
+    int dev, cls_main = -1, cls_side = -1; bool held = false;
+    explicit CohortLease(int d) : dev(d) {}
+    void hold(int cm, int cs) { cls_main = cm; cls_side = cs; held = true; }      // (the caller holds cstreams().m: take() has just been called)
+    void release() { if (!held) return; held = false; std::lock_guard<std::mutex> gq(cstreams().m); cstreams().give(dev, cls_main, true); cstreams().give(dev, cls_side); }
+    ~CohortLease() { release(); }
+};
 // called before several scheduler groups start on a device, while it is idle: the pool gets at least `want` streams whose hardware-queue
 // class is known (a group takes four: main, side, two for copies), so that no group has to class a stream while another group's kernels run
 extern "C" void pc_prepare_streams(int dev, int want)
@@ -756,7 +771,7 @@ struct Engine {
     std::vector<double> hm_dead, hm_logw; int hm_ndead = 0;
     std::vector<unsigned> hm_cuid;              // cluster uid every dead point died in
     // boost_posterior: phantoms removed by a clean that were kept as posterior samples (run_time_info.f90:857-870)
-    std::vector<double> pp_rows, pp_logpost; std::vector<unsigned> pp_cuid; int nd_last_update = 0;
+    std::vector<double> pp_rows, pp_logpost; std::vector<unsigned> pp_cuid; std::vector<unsigned long long> pp_uid; int nd_last_update = 0;
     // cluster genealogy: child uid, parent uid, log of the evidence fraction the child received (add_cluster)
     std::vector<unsigned> split_child, split_parent; std::vector<double> split_logfrac;
     std::vector<double> h_lo, h_hi;
@@ -789,6 +804,7 @@ struct Engine {
     double *c_Sm = nullptr; int *c_pts = nullptr, *c_gidx = nullptr, *c_knn = nullptr, *c_lab = nullptr, *c_out = nullptr, *c_cnt = nullptr;
     unsigned *c_olduid = nullptr; int c_cap = 0;
     long nsplits = 0; int ncluster_peak = 1;
+    long path[PCHIP_PATH_COUNT] = {};          // launches per kernel variant (pchip_result.path): counted where the choice is made
     Timing tm;
     KTimer kt;
     int B = 0, dev = 0;
@@ -1363,7 +1379,7 @@ struct Engine {
             u.dead_cluster = nd > 0 ? hm_cuid.data() : &dummy_u; u.cluster_uid = ua.data(); u.cluster_uid_dead = ud.data();
             u.nsplit = (int)split_child.size(); u.split_child = split_child.data(); u.split_parent = split_parent.data();
             u.split_logfrac = split_logfrac.data();
-            u.n_extra = (int)pp_logpost.size(); u.extra = pp_rows.data(); u.extra_logpost = pp_logpost.data(); u.extra_cluster = pp_cuid.data();
+            u.n_extra = (int)pp_logpost.size(); u.extra = pp_rows.data(); u.extra_logpost = pp_logpost.data(); u.extra_cluster = pp_cuid.data(); u.extra_uid = pp_uid.data();
             on_update(hook_user, &u);
         }
     }
@@ -1408,7 +1424,7 @@ struct Engine {
             pp_rows.resize(o + np + 2);
             std::memcpy(pp_rows.data() + o, row.data() + S.p0, sizeof(double) * np);
             pp_rows[o + np] = row[S.b0]; pp_rows[o + np + 1] = row[S.l0];
-            pp_logpost.push_back(pickw[k] + row[S.l0]); pp_cuid.push_back(phC[pick[k]]);
+            pp_logpost.push_back(pickw[k] + row[S.l0]); pp_cuid.push_back(phC[pick[k]]); pp_uid.push_back(phU[pick[k]]);
         }
     }
 
@@ -1432,7 +1448,10 @@ struct Engine {
         // (clustering alone: the block comes with the counts below, in the same wait)
         const bool ctl_late = cfg.do_clustering && !(dumper || on_update || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post);
         if (!ctl_late && (dumper || on_update || cfg.do_clustering || cfg.resume_write || cfg.boost_posterior != 0.0 || seq_post)) { const int st_keep = h_ctl->status; read_ctl(); h_ctl->status = st_keep; }
-        call_dumper();
+        // (the reference makes update_posteriors -- clean_phantoms with it -- BEFORE it writes files and calls the dumper,
+        //  nested_sampling.F90:325-336: when phantoms can join the posterior (boost_posterior) the hook waits for this update's)
+        const bool hook_late = cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals);
+        if (!hook_late) call_dumper();
         const int nph = S.pool ? (int)pool_cursor : h_ctl->nphantom;
         static const bool fused_off = std::getenv("PC_UPDATE_FUSED_OFF") != nullptr;
         if (!fused_off && !(cfg.ablate & 8) && nph > 0 && !cfg.do_clustering && cfg.boost_posterior == 0.0 && pc_update_fused_ok(&S, h_ctl->ncluster)) {
@@ -1445,6 +1464,7 @@ struct Engine {
                 HIPCHK(hipMemcpyAsync(upd_shift, half.data(), sizeof(double) * S.D, hipMemcpyHostToDevice, st));
                 HIPCHK(hipStreamSynchronize(st));
             }
+            path[PCHIP_PATH_UPDATE_FUSED]++;
             hipEvent_t e0 = kt.begin(KT_CLEAN);
             if (co) co->rec(CK_UPDATE, S, {keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift}, {(long long)pc_update_fused_grid(&S, nph, deferred ? 1 : 0), deferred ? 1LL : 0LL}, {0, nph, (nph + 255) / 256});
             else pc_launch_update_fused(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, upd_part, upd_shift, deferred ? 1 : 0, st);
@@ -1463,12 +1483,14 @@ struct Engine {
             return;
         }
         if (deferred) engine_fail(PC_RC_DEVICE, "deferred update without the fused update path");
+        path[PCHIP_PATH_UPDATE_STEPS]++;
         hipEvent_t e0 = kt.begin(KT_CLEAN);
         // (in step with other runs: the clean of all runs that update in this round is one launch, like the pool compaction)
         if (co && nph > 0) co->rec(CK_COMPACT, S, {keep, blk, d_total, ph2, phL2, phC2, phU2}, {}, {0, nph, (nph + 255) / 256});
         else { direct_op(); pc_launch_clean(&S, nph, keep, blk, d_total, ph2, phL2, phC2, phU2, nullptr, st); }
         kt.end(KT_CLEAN, e0);
         if (cfg.boost_posterior != 0.0 && (cfg.posteriors || cfg.equals)) collect_phantom_posteriors(nph);
+        if (hook_late) call_dumper();
         // The surviving count is written to the control block on the device.  Without clustering / resume files
         // nothing on the host needs it before the next round's read-back, so the update costs no extra sync: the
         // covariance grid is sized with the pre-clean count and the kernels clamp to the device value.
@@ -1882,7 +1904,7 @@ struct Engine {
         ndiscarded = (long)attempt - nprior;
         cb_eval_seconds = attempt ? t_eval / attempt : -1.0;
         call_dumper(2);
-        if (nprior > cfg.nlive) { pc_launch_consume(&S, 2, 0, st); read_ctl(); }
+        if (nprior > cfg.nlive) { path[PCHIP_PATH_CONSUME_GENERAL]++; pc_launch_consume(&S, 2, 0, st); read_ctl(); }
     }
 
     // one nursery batch in callback mode: tick the chains until all of them are done
@@ -1970,7 +1992,7 @@ struct Engine {
         dfree(rows); dfree(rl);
         call_dumper(2);                // write_prior_file, nested_sampling.F90:197
         if (nprior > cfg.nlive) {      // nested_sampling.F90:201-205
-            pc_launch_consume(&S, 2, 0, st);
+            path[PCHIP_PATH_CONSUME_GENERAL]++; pc_launch_consume(&S, 2, 0, st);
             read_ctl();
         }
     }
@@ -2082,6 +2104,8 @@ struct Engine {
         }
         std::fclose(f);
         if (!good) { split_child.clear(); split_parent.clear(); split_logfrac.clear(); pp_rows.clear(); pp_logpost.clear(); pp_cuid.clear(); }
+        // (the kept phantoms' ids do not travel in the sidecar: after a resume the earlier ones are numbered -- ids only key the equal-weight trials)
+        pp_uid.resize(pp_logpost.size()); for (size_t k = 0; k < pp_uid.size(); ++k) pp_uid[k] = (1ull << 62) | k;
         sc.ok = good;
         return sc;
     }
@@ -2224,7 +2248,7 @@ struct Engine {
                 resumed = true;
                 int ntot = 0;
                 for (int v : rs.nlive) ntot += v;
-                if (ntot > cfg.nlive && rs.ncluster == 1) { pc_launch_consume(&S, 2, 0, st); read_ctl(); ntot = cfg.nlive; }   // nested_sampling.F90:201-205
+                if (ntot > cfg.nlive && rs.ncluster == 1) { path[PCHIP_PATH_CONSUME_GENERAL]++; pc_launch_consume(&S, 2, 0, st); read_ctl(); ntot = cfg.nlive; }   // nested_sampling.F90:201-205
                 resume_static = (ntot == cfg.nlive);
                 resume_batch0 = (unsigned)rs.ndead;
             }
@@ -2324,16 +2348,18 @@ struct Engine {
             // next to other runs of this device (or settings.ablate bit 6): the lane = chain kernel (pc_slice_t.hip), the same
             // numbers from 1/60 of the wavefronts
             else if (fused_slice && !spec && (multi || (cfg.ablate & 64)) && pc_slice_t_ok(&S, h_ctl->ncluster)) {
+                path[PCHIP_PATH_SLICE_LANE]++;
                 if (co) co->rec(CK_SLICE, S, {}, {(long long)B}, {(int)batch, 0, 0, bases_seq}); else (void)pc_launch_slice_t(&S, batch, B, st);
                 // in step with other runs: the bases of the next nurseries on the runs' second stream, next to this round's kernels
                 if (co && co->st2 && splittable && raw_depth >= 2 && pc_bases_t_ok(&S)) bases_ahead(batch);
             }
             else if (co && !callback_mode && !spec && cohort_general_ok() && (fused_slice || !splittable)) {
                 // in step with other runs, any device likelihood / several clusters: the one-run kernel with the run in the grid
+                path[PCHIP_PATH_SLICE_WAVE]++;
                 co->rec(CK_SLICE_G, S, {}, {(long long)B, fused_slice ? 1LL : 0LL}, {(int)batch, 0, 0, fused_slice ? bases_seq : 0});
                 if (fused_slice && co->st2 && raw_depth >= 2 && pc_bases_t_ok(&S)) bases_ahead(batch);
             }
-            else if ((co ? (co->flush(), co->wait_next(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
+            else if ((path[PCHIP_PATH_SLICE_WAVE]++, co ? (co->flush(), co->wait_next(), 0) : 0) || (fused_slice ? pc_launch_slice_fused(&S, batch, B, st) : pc_launch_slice(&S, batch, B, st))) { std::fprintf(stderr, "polychord_hip: nDims unsupported\n"); r_rc = 3; return false; }
             S.spec_guard = 0;
             kt.end(KT_SLICE, e1);
             if (split && !spec) side_prefetch(batch);      // (speculative: only once the device is known to have taken the nursery)
@@ -2458,13 +2484,14 @@ struct Engine {
             if (par_ok && h_ctl->ncluster == 1) {
                 // the parallel contraction keeps the sorted order of the live set up to date itself
                 rc2 = 0; S.nn_valid = 0;                     // (the one-cluster kernels do not keep the list bookkeeping)
+                path[PCHIP_PATH_CONSUME_PAR]++;
                 if (co) { if (!sort_valid) { co->rec(CK_SORT, S, {}, {}, {}); sort_valid = true; } co->rec(CK_CONSUME, S, {}, {}, {}); }
                 else {
                 if (!sort_valid) { rc2 = pc_launch_sort_live(&S, st); sort_valid = true; }
                 rc2 = rc2 || pc_launch_consume_par(&S, st);      // also lays out the phantoms
                 }
             }
-            else if (use_fast) { if (co) co->flush(); sort_valid = false; S.nn_valid = 0; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
+            else if (use_fast) { if (co) co->flush(); sort_valid = false; S.nn_valid = 0; path[PCHIP_PATH_CONSUME_FAST]++; rc2 = pc_launch_consume_fast(&S, 0, st); pc_launch_ph_prepare(&S, st); }
             else {
                 sort_valid = false;
                 // several clusters: rank the possible nearest neighbours of every baby still in the nursery once, on
@@ -2478,7 +2505,8 @@ struct Engine {
                                     pc_consume_cl_fits(&S, h_ctl->ncluster);
                 if (co && use_cl && cohort_general_ok()) {
                     // in step with other runs: lists, sort and the one-wave contraction once for all runs with several clusters
-                    if (want_nn) { co->rec(CK_NN, S, {}, {}, {0, nursery_left}); S.nn_valid = 1; }
+                    if (want_nn) { co->rec(CK_NN, S, {}, {}, {0, nursery_left}); S.nn_valid = 1; path[PCHIP_PATH_NN_LISTS]++; }
+                    path[PCHIP_PATH_CONSUME_CL]++;
                     co->rec(CK_SORT, S, {}, {}, {});
                     co->rec(CK_CONSUME_CL, S, {}, {h_ctl->ncluster > 64 ? 1LL : 0LL}, {});
                     rc2 = 0;
@@ -2490,8 +2518,9 @@ struct Engine {
                     // (the sorted order first: its ranks tell the lists' kernel which candidates cannot die before a chain is looked at)
                     if (!sorted_now) sorted_now = pc_launch_sort_live(&S, st) == 0;
                     pc_launch_nn_lists(&S, nursery_left, sorted_now ? 1 : 0, st);
-                    S.nn_valid = 1;
+                    S.nn_valid = 1; path[PCHIP_PATH_NN_LISTS]++;
                 }
+                path[use_cl ? PCHIP_PATH_CONSUME_CL : PCHIP_PATH_CONSUME_GENERAL]++;
                 if (use_cl) {
                     rc2 = (sorted_now ? 0 : pc_launch_sort_live(&S, st)) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
                 } else
@@ -2621,13 +2650,16 @@ struct Engine {
         if (h_ctl->ncluster == 0) {
             // a finished run read back from its .resume file: nothing to kill
         } else if (par_ok && h_ctl->ncluster == 1) {
+            path[PCHIP_PATH_KILLOFF_PAR]++;
             if (co && sort_valid) { co->rec(CK_FINAL, S, {}, {}, {}); if (!fused_final) co->flush(); }      // (fused: the caller launches the kill-off of all runs that end now, then calls end_a2)
             else {
             if (!sort_valid) (void)pc_launch_sort_live(&S, st);
             (void)pc_launch_final_par(&S, st);
             }
         } else if (h_ctl->ncluster > 1 && pc_launch_killoff_cl(&S, h_ctl->ncluster, st) == 0) {      // (several clusters: the deaths in sorted order by one wavefront, pc_clus.hip)
-        } else if (!(fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0)) pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st);   // (the general kernel: four waves, a death's jobs side by side)
+            path[PCHIP_PATH_KILLOFF_CL]++;
+        } else if (fast_ok && h_ctl->ncluster == 1 && pc_launch_consume_fast(&S, 1, st) == 0) path[PCHIP_PATH_KILLOFF_FAST]++;
+        else { path[PCHIP_PATH_KILLOFF_GENERAL]++; pc_launch_consume(&S, 1, (h_ctl->ncluster > 1 && !S.seq_mode) ? 1 : 0, st); }   // (the general kernel: four waves, a death's jobs side by side)
         if (!fused_final) end_a2();
     }
     void end_a2()
@@ -2680,6 +2712,8 @@ struct Engine {
         out->varlogZ = h_ctl->logZ2 - 2 * h_ctl->logZ;
         out->ndead = h_ctl->ndead; out->nlike = h_ctl->nlike; out->niter = h_ctl->niter;
         out->nlike_failed = h_ctl->nlike_failed; out->ncluster_peak = ncluster_peak; out->epoch_discard = S.epoch_discard;
+        path[PCHIP_PATH_NN_FALLBACKS] = (long)h_ctl->nn_fallbacks; path[PCHIP_PATH_POOL_MODE] = S.pool; path[PCHIP_PATH_DEFER_UPDATE] = S.defer_update;
+        for (int k = 0; k < PCHIP_PATH_COUNT; ++k) out->path[k] = path[k];
         grade_counts(out->nlike_grade);
         out->ncluster = nc_end; out->ncluster_dead = h_ctl->ncluster_dead; out->nbatches = tm.batches;
         out->nrounds = tm.rounds; out->nupdates = tm.updates; out->nTotal = nT; out->batch = B;
@@ -2936,6 +2970,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         int devq = 0; (void)hipGetDevice(&devq); devq &= 63;
         int cls_main = -1, cls_side = -1;
         bool cohort_loaded = false;
+        CohortLease lease(devq);
         if (prio_off || plo == phi) {
             hipStream_t want, want2;
             { std::lock_guard<std::mutex> g(last_m); want = last_st[devq]; want2 = last_st2[devq]; }
@@ -2957,7 +2992,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
                 cls_side = loaded ? sclasses().known(co.st2) : sclasses().classify(co.st2);
             }
             cohort_loaded = loaded;
-            cstreams().take(devq, cls_main, true); cstreams().take(devq, cls_side);
+            cstreams().take(devq, cls_main, true); cstreams().take(devq, cls_side); lease.hold(cls_main, cls_side);
             { std::lock_guard<std::mutex> g(last_m); last_st[devq] = co.st; last_st2[devq] = co.st2; }
             if (prof) std::fprintf(stderr, "polychord_hip dbg cohort: priority range %.2f ms, main stream %.2f ms, side stream %.2f ms\n", std::chrono::duration<double>(Tp1 - Tpre).count() * 1e3, std::chrono::duration<double>(Tp2 - Tp1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - Tp2).count() * 1e3); }
         else { HIPCHK(hipStreamCreateWithPriority(&co.st, hipStreamNonBlocking, phi)); if (!side_off) HIPCHK(hipStreamCreateWithPriority(&co.st2, hipStreamNonBlocking, plo)); own_streams = true; }
@@ -3188,7 +3223,7 @@ static int pc_run_cohort(const pchip_settings *s, const pchip_like *like, const 
         co.destroy();
         if (h_totals) hfree(h_totals);
         (void)hipStreamSynchronize(co.st);
-        { std::lock_guard<std::mutex> gq(cstreams().m); cstreams().give(devq, cls_main); cstreams().give(devq, cls_side); }
+        lease.release();
         if (own_streams) (void)hipStreamDestroy(co.st); else hpool().put_stream(co.st);
         if (co.st2) { (void)hipStreamSynchronize(co.st2); if (own_streams) (void)hipStreamDestroy(co.st2); else hpool().put_stream(co.st2); hpool().put_sync_event(co.ev_up); hpool().put_sync_event(co.ev_next); }
         for (int q = 0; q < 2; ++q) if (co.stc[q]) { (void)hipStreamSynchronize(co.stc[q]); hpool().put_stream(co.stc[q]); co.stc[q] = nullptr; }

@@ -501,7 +501,22 @@ struct PackJob {
 
 }  // namespace
 
-struct pchip_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
+struct pchip_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; pchip_allgather_fn fn = nullptr; void *user = nullptr; };
+// the one collective of the exchange: every rank's `bytes` at `send` -> all ranks' blocks, rank after rank, at `recv` (device memory both).
+// RCCL (ncclAllGather on the stream), or the caller's own all-gather (pchip_comm_create_with: called with the stream drained, returns when
+// `recv` is filled).  0, or a message and 2.
+static int comm_all_gather(pchip_comm *c, const void *send, void *recv, size_t count, bool words, hipStream_t st, const char *what)
+{
+    if (c->fn) {
+        if (hipStreamSynchronize(st) != hipSuccess) { std::fprintf(stderr, "polychord_hip: comm merge: %s: the stream failed before the exchange\n", what); return 2; }
+        const int e = c->fn(c->user, send, recv, count * 8);
+        if (e != 0) { std::fprintf(stderr, "polychord_hip: comm merge: %s: the caller's all-gather returned %d\n", what, e); return 2; }
+        return 0;
+    }
+    const ncclResult_t e = rccl().AllGather(send, recv, count, words ? ncclInt64 : ncclDouble, c->comm, st);
+    if (e != ncclSuccess) { std::fprintf(stderr, "polychord_hip: comm merge: %s: %s\n", what, rccl().GetErrorString(e)); return 2; }
+    return 0;
+}
 
 // The lived records of a run picked where they were made (settings.device_records; called by the engine at the end of a run, on the
 // run's device, behind everything that wrote the arrays): flags, offsets, scatter into `block` -- rows [cap][nT] | entry [cap] | own log
@@ -725,7 +740,10 @@ int pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const 
     const bool device_like = like->kind != PCHIP_LIKE_CALLBACK && prior->kind == 1 && !std::getenv("PC_REPEATS_THREADS");
     // (the runs leave their lived records on the device for the merge below: no second trip over the host link)
     pchip_settings s_loc = *s;
-    if (merged && !std::getenv("PC_DEVICE_RECORDS_OFF")) s_loc.device_records = 1;
+    // (set here, freed here: a caller that did not ask for the device block must not find its results pinning ndead x (nTotal + 2) doubles
+    //  of device memory each until it frees them -- see below, behind the union)
+    const bool records_are_mine = merged && !s->device_records && !std::getenv("PC_DEVICE_RECORDS_OFF");
+    if (records_are_mine) s_loc.device_records = 1;
     s = &s_loc;
     if (device_like) {
         // seeds dealt round-robin to the devices: run k on devs[k % ndev] (what the merge below assumes)
@@ -836,6 +854,16 @@ int pchip_run_repeats_ex(const pchip_settings *s, const pchip_like *like, const 
         }
         for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); if (hipDeviceSynchronize() != hipSuccess) rc = rc ? rc : 2; }
         for (size_t d = 0; d < devs.size(); ++d) { (void)hipSetDevice(devs[d]); std::vector<void *> v; v.swap(scratch[d].v); for (void *p : v) pc_cache_dev_free(p); }
+        // the runs' device blocks have been copied into the union's buffer (or the packing failed): unless the CALLER asked for them
+        // (settings.device_records), they go back now, each with its own device current -- before the merge takes its working set
+        if (records_are_mine)
+            for (int k = 0; k < nseeds; ++k) {
+                pchip_result &r = results[k];
+                if (!r.d_records) continue;
+                (void)hipSetDevice(r.records_device);
+                pc_cache_dev_free(r.d_records);
+                r.d_records = nullptr; r.n_records = 0; r.records_cap = 0;
+            }
         (void)hipSetDevice(devs[0]);
         if (rc == 0) {
             std::vector<double> lz((size_t)nseeds), vz((size_t)nseeds);
@@ -886,6 +914,22 @@ int pchip_comm_create(const char *id128, int nranks, int rank, int device, pchip
     return 0;
 }
 
+// A communicator over the CALLER's collective: `all_gather(user, send, recv, bytes)` must place every rank's `bytes` at `send` (device
+// memory of `device`) into `recv` (device memory, nranks * bytes, rank after rank) on ALL ranks and return 0 when `recv` is complete.
+// For hosts that bring their own transport -- a GPU-aware MPI_Allgather under the reference's MPI launcher (mpi_utils.F90), torch.distributed
+// -- and for the tests, which drive pchip_comm_merge_many with several ranks on ONE GPU, where RCCL refuses to form a communicator.
+int pchip_comm_create_with(pchip_allgather_fn all_gather, void *user, int nranks, int rank, int device, pchip_comm **out)
+{
+    *out = nullptr;
+    if (!all_gather || nranks < 1 || rank < 0 || rank >= nranks) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { std::fprintf(stderr, "polychord_hip: comm: device %d of %d\n", device, ndev); return 2; }
+    pchip_comm *c = new pchip_comm;
+    c->nranks = nranks; c->rank = rank; c->device = device; c->fn = all_gather; c->user = user;
+    *out = c;
+    return 0;
+}
+
 void pchip_comm_destroy(pchip_comm *c)
 {
     if (!c) return;
@@ -911,7 +955,7 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
     std::memset(out, 0, sizeof(*out));
     if (nruns < 1 || !runs) return 1;
     const int R = c ? c->nranks : 1, nT = 2 * nDims + nDerived + 2, me = c ? c->rank : 0;
-    const bool coll = c && c->comm;
+    const bool coll = c && (c->comm || c->fn);
     // A rank that fails on its own (its records, its memory) still takes part in the exchange and says so there: the header's all-gather
     // carries -1 for it, a one-word all-gather behind the second phase's allocations its status, and every rank returns the error
     // together -- a rank that left early would leave the others waiting in ncclAllGather for ever.
@@ -924,7 +968,7 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
     hipStream_t st = nullptr;
     DevBuf B;
     auto fail = [&](const char *what, int code) { std::fprintf(stderr, "polychord_hip: comm merge: %s (%s)\n", what, hipGetErrorString(hipGetLastError())); return code; };
-    auto nfail = [&](const char *what, ncclResult_t e) { std::fprintf(stderr, "polychord_hip: comm merge: %s: %s\n", what, rccl().GetErrorString(e)); return 2; };
+
     std::vector<PackJob> J((size_t)nruns);
     long long mine_total = 0;
     for (int j = 0; j < nruns && !local_err; ++j) {
@@ -938,8 +982,7 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
     auto gather_words = [&](const long long *mine, int nw, std::vector<long long> &all, long long *d_buf, const char *what) -> int {
         // every rank's nw words -> all [R][nw]
         if (hipMemcpyAsync(d_buf, mine, sizeof(long long) * nw, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
-        const ncclResult_t e = rccl().AllGather(d_buf, d_buf + nw, (size_t)nw, ncclInt64, c->comm, st);
-        if (e != ncclSuccess) return nfail(what, e);
+        if (const int e = comm_all_gather(c, d_buf, d_buf + nw, (size_t)nw, true, st, what)) return e;
         all.assign((size_t)nw * R, 0);
         if (hipMemcpyAsync(all.data(), d_buf + nw, sizeof(long long) * nw * R, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(what, 2);
         return 0;
@@ -1023,8 +1066,7 @@ int pchip_comm_merge_many(pchip_comm *c, const pchip_result *runs, int nruns, do
             for (int q = 0; q < R; ++q) if (all[(size_t)q] != 0 && !worst) { worst = (int)all[(size_t)q]; if (q != me) std::fprintf(stderr, "polychord_hip: comm merge: rank %d failed (code %d)\n", q, worst); }
             if (worst) return local_err ? local_err : worst;
         }
-        const ncclResult_t e = rccl().AllGather(send, recv, per, ncclDouble, c->comm, st);       // the exchange: one padded block per rank over xGMI
-        if (e != ncclSuccess) return nfail("ncclAllGather (records)", e);
+        if (const int e = comm_all_gather(c, send, recv, per, false, st, "ncclAllGather (records)")) return e;       // the exchange: one padded block per rank over xGMI
         if (hipMemcpyAsync(d_off, off_rank.data(), sizeof(long long) * (R + 1), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload", 2);
         if (ntot > 0) hipLaunchKernelGGL(k_unpad, dim3((unsigned)ntot), dim3(64), 0, st, (const double *)recv, nmax, nT, R, (const long long *)d_off, ra, ea, ea + na);
         rows_all = ra; entry_all = ea; ownw_all = ea + na;

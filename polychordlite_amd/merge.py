@@ -112,6 +112,12 @@ def merge_records(nDims, nDerived, counts, rows, entry, on_device=False, want_ro
     records' own log weights, the runs' evidences, did it end with clusters) -- with them a union that holds a clustered run quotes the
     runs' own evidences and weights (evidence_rule 1).  write = (base_dir, file_root): also <root>.stats / _dead-birth.txt / .txt."""
     lib = _lib()
+    own = (ownw, run_logZ, run_varlogZ, run_clustered)
+    if any(x is not None for x in own) and not all(x is not None for x in own):
+        # (some of the four: the _ex path would index None, and ownw alone would silently quote evidence_rule 0 for a clustered run)
+        raise ValueError("merge_records: ownw, run_logZ, run_varlogZ and run_clustered go together (all four, or none)")
+    if run_logZ is not None and not (len(run_logZ) == len(run_varlogZ) == len(run_clustered) == len(counts)):
+        raise ValueError("merge_records: run_logZ / run_varlogZ / run_clustered need one entry per run")
     cnt = (C.c_long * len(counts))(*[int(c) for c in counts])
     m = Merged()
     if on_device:
@@ -179,6 +185,74 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong)
+_HIP_H2D, _HIP_D2H, _HIP_D2D = 1, 2, 3
+
+
+def hip_runtime():
+    """the HIP runtime the library itself runs on (ctypes): hipMemcpy / hipSetDevice for the all-gathers written in Python below"""
+    hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipSetDevice.argtypes = [C.c_int]
+    return hip
+
+
+class CallbackComm:
+    """pchip_comm_create_with: the library's exchange (header, counts, status, ONE padded block per rank, unpad, merge -- pchip_comm_merge_many,
+    every statement of it) over the CALLER's all-gather instead of RCCL.  all_gather(send_ptr, recv_ptr, nbytes) -> 0: every rank's nbytes of
+    device memory at send_ptr into recv_ptr (device, world * nbytes, rank after rank) on all ranks.  Used like `Comm` (comm_merge,
+    comm_merge_many, run_repeats(comm=...))."""
+
+    def __init__(self, rank, world, device, all_gather):
+        lib = _lib()
+        self.lib, self.rank, self.world, self.device, self.h = lib, rank, world, device, C.c_void_p()
+
+        def cb(user, send, recv, nbytes):
+            try:
+                return int(all_gather(send, recv, int(nbytes)) or 0)
+            except Exception as e:      # noqa: BLE001 -- an exception must not cross the C frames: the library turns the code into its error
+                import sys
+                sys.stderr.write("CallbackComm: all_gather raised %s: %s\n" % (type(e).__name__, e))
+                return 1
+        self._cb = ALLGATHER_FN(cb)                                   # (kept alive as long as the communicator)
+        lib.pchip_comm_create_with.argtypes = [ALLGATHER_FN, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.pchip_comm_create_with.restype = C.c_int
+        if lib.pchip_comm_create_with(self._cb, None, world, rank, device, C.byref(self.h)) != 0:
+            raise RuntimeError("pchip_comm_create_with failed")
+
+    library = "caller's all-gather"
+
+    def close(self):
+        if self.h:
+            self.lib.pchip_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_all_gather(dist, torch, device_ordinal):
+    """an all-gather for CallbackComm over torch.distributed on HOST tensors (gloo): device -> host, all_gather_into_tensor, host -> device.
+    What lets `bench.py --gpus 2 --backend gloo` run two ranks on ONE GPU through the library's whole exchange path (RCCL forms no
+    communicator with two ranks on a device); never the product path between GPUs."""
+    hip = hip_runtime()
+
+    def all_gather(send, recv, nbytes):
+        world = dist.get_world_size()
+        hip.hipSetDevice(device_ordinal)
+        mine = torch.empty(nbytes, dtype=torch.uint8)
+        if hip.hipMemcpy(mine.data_ptr(), send, nbytes, _HIP_D2H) != 0:
+            return 2
+        out = torch.empty(nbytes * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, mine)
+        return 0 if hip.hipMemcpy(recv, out.data_ptr(), nbytes * world, _HIP_H2D) == 0 else 2
+    return all_gather
 
 
 def comm_merge(run, comm, nDims, nDerived, want_rows=False, write=None, logzero=None):

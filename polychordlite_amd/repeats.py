@@ -15,14 +15,18 @@ from . import _ctypes_api as api
 from . import merge as mg
 
 
-def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, want_rows=False, write=None, comm=None):
+def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, want_rows=False, write=None, comm=None, agree=None):
     """One nested-sampling run per seed, at most `max_in_flight` at a time per device, on `devices` (HIP ordinals of this
     process; None = the device of `settings`), merged.  comm (merge.Comm, one rank per GPU): every rank makes its own seeds' runs and
     the union of ALL ranks' runs is merged on every rank (pchip_comm_merge_many: one RCCL all-gather of the lived records).
 
     Returns (merged, runs): merged = {"n_runs", "logZ", "logZerr", "evidence_rule", "logZ_replay", "post_mean", "post_var", "logweights",
     "nlive", "records", "nlike", "nlike_local", "t_runs_s", "t_merge_s"[, "rows"]}; runs = the per-seed result dicts of `_ctypes_api.run`
-    (this rank's)."""
+    (this rank's).
+
+    agree (with comm): `agree(ok) -> bool`, a collective of the caller's (e.g. an all-reduce of a failure flag over torch.distributed) that
+    EVERY rank calls exactly once between its local runs and the exchange.  A rank whose runs failed must not leave the others waiting in
+    the all-gather: when any rank reports a failure every rank raises here, before the exchange, and the collectives stay matched."""
     seeds = [int(s) for s in seeds]
     if not seeds:
         raise ValueError("run_repeats needs at least one seed")
@@ -45,6 +49,12 @@ def run_repeats(settings, like, prior, seeds, max_in_flight=4, devices=None, wan
         settings = s2
     rc = f(C.byref(settings), C.byref(like), C.byref(prior), n, sd, len(devs), dv, int(max_in_flight), 1 if (want_rows or write) else 0, res,
            C.byref(m) if comm is None else None)
+    if comm is not None and agree is not None:
+        if not agree(rc == 0):
+            if rc == 0:                                               # (a failed call has freed its results itself)
+                for k in range(n):
+                    lib.pchip_result_free(C.byref(res[k]))
+            raise RuntimeError(f"run_repeats: the runs of at least one rank failed (this rank: code {rc}); the exchange was skipped on every rank")
     if rc != 0:
         raise RuntimeError(f"pchip_run_repeats failed with code {rc}")
     t_runs = time.perf_counter() - t0

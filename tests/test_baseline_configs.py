@@ -5,6 +5,8 @@
   C3  10-D Rastrigin, nlive 1000, num_repeats 30, kNN clustering (likelihoods/examples/rastrigin.f90:20-35,
       clustering.f90:15-97, run_time_info.f90:913-949): an oracle prefix long enough to split clusters, full runs
       against runs of the reference binary (tests/golden/ref_c3_seeds.json) and the analytic evidence
+  C4  30-D twin Gaussian, nlive 500, num_repeats 40, kNN clustering (twin_gaussian.f90:14-56): an oracle prefix through the
+      split of the two modes (the statistics against the reference binary's 32 runs: test_gpu_parity.py)
   C5  100-D correlated Gaussian, nlive 5000, num_repeats 200 (random_gaussian.f90:17-30, run_time_info.f90:601-641):
       an oracle prefix at the real nlive and nDims and one full run checked through size-independent properties
 
@@ -65,6 +67,20 @@ def _replay_properties(g, D, clustered=False):
     assert abs(np.log(np.exp(lw - lw.max()).sum()) + lw.max() - g["logZ"]) < 3.0 * g["logZerr"] + 1e-6
 
 
+def _paths(g, **want):
+    """pchip_result.path: which kernels the run went through.  A shape that silently drops to the general serial kernel (an LDS layout
+    that no longer fits, a guard that no longer holds) produces the same numbers -- only these counters tell (two such fallbacks shipped
+    green in round 5).  want: name = exact count, or (lo, hi), or ">0"."""
+    p = g["path"]
+    for k, v in want.items():
+        if v == ">0":
+            assert p[k] > 0, (k, p)
+        elif isinstance(v, tuple):
+            assert v[0] <= p[k] <= v[1], (k, p)
+        else:
+            assert p[k] == v, (k, p)
+
+
 def test_c2_production_shape_matches_oracle(engine):
     """BASELINE configs[1] exactly as bench.py runs it (batch = 0 -> 1000 chains per nursery, parallel contraction at
     full width), stopped after 3 nlive deaths: same trajectory as the oracle, row for row"""
@@ -79,6 +95,9 @@ def test_c2_production_shape_matches_oracle(engine):
     o = orc.run(so, Lo, Po)
     _same_trajectory(g, o)
     assert g["ndead"] == 8000 and g["nbatches"] >= 6
+    # the production path: parallel contraction + its kill-off, fused update, pool mode, deferred update -- and nothing else
+    _paths(g, consume_par=">0", consume_general=0, consume_cl=0, consume_fast=0, killoff_par=1, killoff_general=0, killoff_fast=0,
+           update_fused=">0", update_steps=0, slice_wave=">0", pool_mode=1, defer_update=1)
 
 
 def test_c3_prefix_matches_oracle(engine):
@@ -96,6 +115,30 @@ def test_c3_prefix_matches_oracle(engine):
     _same_trajectory(g, o)
     assert g["ncluster"] >= 4 and g["ndead"] >= 20000
     assert np.allclose(g["logZp"], o["logZp"], atol=1e-8)
+    # one cluster: the parallel contraction; several: k_consume_cl and its kill-off; the general kernel never
+    _paths(g, consume_par=">0", consume_cl=">0", consume_general=0, consume_fast=0, killoff_cl=1, killoff_general=0, nn_lists=">0",
+           update_steps=">0")
+    assert g["path"]["nn_fallbacks"] <= 0.002 * g["niter"], g["path"]
+
+
+def test_c4_prefix_matches_oracle(engine):
+    """BASELINE configs[3] at its size (ini/twin_gaussian.ini at 30-D: nlive 500, num_repeats 40, kNN clustering, engine default
+    nursery of 250 chains; twin_gaussian.f90:14-56): the oracle walked next to the engine through the split of the two modes
+    (before death 17 000 with this seed) and six live sets' worth of deaths beyond it -- k_nhats_q's two halves (nDims 25 ... 64),
+    k_consume_cl at nlive 500 / 250 chains, the clustered kill-off: same trajectory, row for row"""
+    api = engine
+    kw = dict(nlive=500, num_repeats=40, seed=11, do_clustering=1, max_ndead=20000)
+    s = _settings(api, 30, 1, batch=0, **kw)
+    L, P, keep = api.make_problem("twin_gaussian", 30, 1, -1.0, 1.0)
+    g = api.run(s, L, P)
+    assert g["batch"] == 250
+    so = orc.settings(30, 1, batch=250, **kw)
+    Lo, Po, keep2 = orc.make_problem("twin_gaussian", 30, -1.0, 1.0)
+    o = orc.run(so, Lo, Po)
+    assert o["ncluster"] == 2 and o["ndead"] >= 20000
+    _same_trajectory(g, o)
+    assert np.allclose(g["logZp"], o["logZp"], atol=1e-8)
+    _paths(g, consume_par=">0", consume_cl=">0", consume_general=0, consume_fast=0, killoff_cl=1, killoff_general=0, nn_lists=">0")
 
 
 def test_c3_full_runs_against_the_reference_binary(engine, golden):
@@ -159,6 +202,7 @@ def test_c5_prefix_matches_oracle(engine):
     o = orc.run(so, Lo, Po)
     _same_trajectory(g, o, ztol=1e-6)
     assert g["ndead"] == 2048 + 5000
+    _paths(g, consume_par=">0", consume_general=0, consume_fast=0, killoff_par=1, killoff_general=0, update_steps=0)
 
 
 def _bench_matrix(api, D=100):

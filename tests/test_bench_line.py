@@ -91,6 +91,31 @@ def test_rank_bootstrap_two_processes_over_gloo():
     assert p2.returncode != 0 and "WORLD_SIZE=3" in p2.stderr
 
 
+@pytest.mark.gpu
+def test_two_ranks_through_the_whole_harness_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo` on the GPU box: two ranks (they share the visible GPU; RCCL forms no communicator with two
+    ranks on one device), the process group over gloo, and the library's exchange over that group's all-gather (pchip_comm_create_with) --
+    so the N > 1 code of the harness AND of the library runs with world_size 2 before the driver's 8-GPU run: the early record, the timed
+    region's barrier + max over ranks, the sums of the ranks' counters, R runs per rank in step with one exchange of all N R runs
+    (roofline.in_step_multi), the agreement between the ranks before it.  No scaling claim: the record says the ranks share a GPU."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--nlive", "400",
+                        "--runs-per-gpu", "3", "--no-cpu", "--full-out", ""], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    early, j = lines[0], lines[-1]
+    assert early.get("partial") and early["n_gpus"] == 2 and early["value"] > 0
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and "SHARE" in j["config"]["parallelism"] and "partial" not in j
+    assert abs(j["value"] / early["value"] - 1.0) < 1e-5                  # the same timed region
+    assert j["merged"]["n_runs"] == 2                                        # the last step's run of BOTH ranks in the union
+    m = j["roofline"]["in_step_multi"]
+    assert "error" not in m and m["n_gpus"] == 2 and m["runs_per_gpu"] == 3 and m["runs"] == 6 and m["value"] > 0 and m["exchange_ms"] > 0
+    assert abs(m["merged_logZ"]) < 5 * m["merged_logZerr"] + 0.2             # six runs of the 20-D Gaussian (analytic log Z = 0)
+    assert "leg_errors" not in j, j.get("leg_errors")
+
+
 @pytest.mark.parametrize("name", ["r05_bench.json", "r05_bench_c3.json", "r05_bench_c4.json", "r05_bench_c5.json"])
 def test_the_lines_bench_py_printed_on_the_gpu_box(name):
     """the committed last lines of `python bench.py [--workload cN]` as they came off the MI355X: one line, < 6 KB, the driver's fields"""

@@ -418,6 +418,116 @@ def test_library_rccl_exchange_one_rank(engine):
     assert e["logZ"] == c["logZ"] and np.array_equal(e["rows"], c["rows"])
 
 
+class _ThreadGather:
+    """an all-gather between THREADS of this process whose ranks share a GPU: every rank posts its send block, all meet, each copies every
+    block into its own receive buffer device-to-device (rank after rank: the layout ncclAllGather delivers), all meet again"""
+
+    def __init__(self, world):
+        import threading
+        from polychordlite_amd import merge as mg
+        self.world, self.bar, self.post, self.hip, self.calls = world, threading.Barrier(world, timeout=120), [None] * world, mg.hip_runtime(), 0
+
+    def rank(self, r):
+        def all_gather(send, recv, nbytes):
+            self.post[r] = (send, nbytes)
+            self.bar.wait()
+            for q in range(self.world):
+                assert self.post[q][1] == nbytes                       # every rank came with the same block size (padded to the largest)
+                if self.hip.hipMemcpy(recv + q * nbytes, self.post[q][0], nbytes, 3) != 0:
+                    return 2
+            if r == 0:
+                self.calls += 1
+            self.bar.wait()
+            return 0
+        return all_gather
+
+
+def _ranks_in_threads(world, body):
+    """body(rank) on `world` threads; returns their results (an exception object where one was raised); a rank that hangs fails the test"""
+    import threading
+    out = [None] * world
+
+    def run(r):
+        try:
+            out[r] = body(r)
+        except Exception as e:      # noqa: BLE001
+            out[r] = e
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(300)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting in the exchange"
+    return out
+
+
+@pytest.mark.gpu
+def test_exchange_path_with_two_ranks_on_one_gpu(engine):
+    """pchip_comm_merge_many with nranks = 2 -- the path no test had ever run with more than one rank (RCCL forms no communicator with two
+    ranks on one device, and the box has one): header all-gather, six words per run, the status word, ONE padded block per rank
+    [nmax][nTotal] | entry | own log weight, k_unpad, the device merge -- every statement of it, over a communicator whose all-gather is
+    the caller's (pchip_comm_create_with; here: two threads, device-to-device copies in ncclAllGather's layout).  Ragged: rank 0 holds two
+    runs (their records left on the device: settings.device_records), rank 1 one CLUSTERED run with three times the records (host arrays,
+    packed by the library) -- every rank must get, bit for bit, pchip_merge_records_ex of the union in rank order."""
+    from polychordlite_amd import merge as mg
+    api = engine
+    lib = api.load()
+    D, nDer = 2, 0
+    s0 = api.Settings(); lib.pchip_settings_default(C.byref(s0), D, nDer)
+    L, P, keep = api.make_problem("rastrigin", D, nDer, -5.12, 5.12)
+    def make(nlive, batch, clus, seed, on_device):
+        s0.nlive, s0.num_repeats, s0.batch, s0.do_clustering, s0.seed, s0.device_records = nlive, 6, batch, clus, seed, on_device
+        return api.run(s0, L, P)
+    mine = [[make(80, 1, 0, 4, 1), make(120, 8, 0, 5, 1)], [make(300, 40, 1, 3, 0)]]
+    assert mine[0][0]["n_records"] and mine[1][0]["n_records"] is None and mine[1][0]["ncluster_peak"] > 1
+    tg = _ThreadGather(2)
+    comms = [mg.CallbackComm(r, 2, 0, tg.rank(r)) for r in range(2)]
+    try:
+        got = _ranks_in_threads(2, lambda r: mg.comm_merge_many(mine[r], comms[r], D, nDer, want_rows=True))
+    finally:
+        for c in comms: c.close()
+    for g in got:
+        assert not isinstance(g, Exception), g
+    assert tg.calls == 4                                              # header, counts, status, records
+    union = mine[0] + mine[1]
+    recs = [mg.lived_records(r) for r in union]
+    ownw = np.concatenate([r["logweights"][r["logweights"] > r["logzero"]] for r in union])
+    ref = mg.merge_records(D, nDer, [x.shape[0] for x, _ in recs], np.concatenate([x for x, _ in recs]), np.concatenate([e for _, e in recs]), want_rows=True,
+                           ownw=ownw, run_logZ=[r["logZ"] for r in union], run_varlogZ=[r["varlogZ"] for r in union], run_clustered=[mg.clustered(r) for r in union])
+    assert ref["evidence_rule"] == 1 and recs[2][0].shape[0] > recs[0][0].shape[0] + recs[1][0].shape[0]      # (ragged: rank 1's block sets the padding)
+    for g in got:
+        assert g["n_runs"] == 3 and g["records"] == ref["records"] and g["evidence_rule"] == 1
+        assert g["logZ"] == ref["logZ"] and g["varlogZ"] == ref["varlogZ"] and g["logZ_replay"] == ref["logZ_replay"]
+        assert np.array_equal(g["rows"], ref["rows"]) and np.array_equal(g["logweights"], ref["logweights"]) and np.array_equal(g["nlive"], ref["nlive"])
+        assert np.array_equal(g["post_mean"], ref["post_mean"])
+        assert g["nlike"] == sum(r["nlike"] for r in union) and g["ndead_all"] == sum(r["ndead"] for r in union)
+
+
+@pytest.mark.gpu
+def test_a_failed_rank_ends_the_exchange_on_every_rank(engine):
+    """a rank that cannot pack its records (here: rows of the wrong width) still takes part in the header all-gather and says so there
+    (count -1): EVERY rank returns an error, none is left waiting in the next collective -- with two real ranks; and a rank whose
+    all-gather itself fails takes its error code back"""
+    from polychordlite_amd import merge as mg
+    api = engine
+    _, _, _, _, good = _engine_runs(api, [7], D=2, nDer=0, nlive=80, nr=6, batch=8, kind="rastrigin", box=(-5.12, 5.12))
+    _, _, _, _, wide = _engine_runs(api, [8], nlive=80)                                   # 6-D + 1 derived: 15 columns, not 6
+    mine = [good, wide]
+    tg = _ThreadGather(2)
+    comms = [mg.CallbackComm(r, 2, 0, tg.rank(r)) for r in range(2)]
+    try:
+        got = _ranks_in_threads(2, lambda r: mg.comm_merge_many(mine[r], comms[r], 2, 0))
+    finally:
+        for c in comms: c.close()
+    assert all(isinstance(g, RuntimeError) for g in got), got
+    assert tg.calls == 1                                              # the header's all-gather, and no collective after it
+    # the collective itself fails on one rank (its transport): that rank returns the error; one rank only, so nobody waits
+    bad = mg.CallbackComm(0, 1, 0, lambda send, recv, n: 5)
+    try:
+        with pytest.raises(RuntimeError):
+            mg.comm_merge_many(good, bad, 2, 0)
+    finally:
+        bad.close()
+
+
 @pytest.mark.gpu
 def test_lived_records_follow_the_runs_logzero(engine):
     """failed spawns carry logweight = settings.logzero, whatever it is: with logzero = -1e20 the Python selection and the
@@ -601,7 +711,13 @@ def test_lived_records_left_on_the_device(engine):
             m0, r0 = run_repeats(s, L, P, seeds, max_in_flight=3, want_rows=True)
         finally:
             del os.environ["PC_DEVICE_RECORDS_OFF"]
-        assert all(x["n_records"] is not None for x in r1) and all(x["n_records"] is None for x in r0)
+        # (the library asked for the device blocks itself and gave them back behind the union: a caller that did not ask must not find
+        #  its results pinning device memory -- ADVICE round 5; a caller that did ask keeps them)
+        assert all(x["n_records"] is None for x in r1) and all(x["n_records"] is None for x in r0)
+        s.device_records = 1
+        m3, r3 = run_repeats(s, L, P, seeds, max_in_flight=3, want_rows=True)
+        s.device_records = 0
+        assert all(x["n_records"] is not None for x in r3) and m3["logZ"] == m1["logZ"] and np.array_equal(m3["rows"], m1["rows"])
         assert m1["logZ"] == m0["logZ"] and np.array_equal(m1["rows"], m0["rows"]) and np.array_equal(m1["logweights"], m0["logweights"])
         m2, _ = run_repeats(s, L, P, seeds, max_in_flight=3)                        # without the merged rows: the same evidence
         assert m2["logZ"] == m1["logZ"] and "rows" not in m2 and np.array_equal(m2["post_mean"], m1["post_mean"])

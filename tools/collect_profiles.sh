@@ -15,6 +15,14 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$o
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o p -- $BENCH > "$out/write.log" 2>&1
 python tools/pmc_summary.py "$out/fetch" "$out/write" "profiles/${tag}_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $BENCH (one pass per counter)"
 cp "profiles/${tag}_pmc.json" "profiles/${tag}_kernel_stats.csv" gpurun_out/
+# the same three passes for the path ANY device functor takes: the built-in Gaussian evaluated with one reduction per trial (settings.ablate
+# bit 0 through PC_ABLATE=1: k_slice<.., LEAN = 0>), i.e. without the closed form along the chord that `value` enjoys
+timeout 400 env PC_ABLATE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/gstats" -o p -- $BENCH > "$out/gstats.log" 2>&1
+cp "$(find "$out/gstats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_general_kernel_stats.csv"
+timeout 400 env PC_ABLATE=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/gfetch" -o p -- $BENCH > "$out/gfetch.log" 2>&1
+timeout 400 env PC_ABLATE=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/gwrite" -o p -- $BENCH > "$out/gwrite.log" 2>&1
+python tools/pmc_summary.py "$out/gfetch" "$out/gwrite" "profiles/${tag}_general_pmc.json" "PC_ABLATE=1 rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $BENCH (one pass per counter; the general-functor path)"
+cp "profiles/${tag}_general_pmc.json" "profiles/${tag}_general_kernel_stats.csv" gpurun_out/
 # the bench line itself (same command plus the CPU baseline and the concurrent-runs capacity figure), with the PMC file in place
 timeout 600 python bench.py --steps 20 --warmup 5 --full-out "gpurun_out/${tag}_bench_full.json" > "profiles/${tag}_bench.json" 2> "$out/bench.log"      # (the compact record the driver parses; the full one beside it)
 [ -s "profiles/${tag}_bench.json" ] || { rm -f "profiles/${tag}_bench.json"; echo "collect_profiles.sh: bench.py printed no line:" >&2; tail -5 "$out/bench.log" >&2; }
