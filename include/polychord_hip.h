@@ -132,7 +132,8 @@ typedef struct {
                            next to other runs of its device (bit 6: lane-per-chain sampling, pc_slice_t.hip; bit 7: lane-per-vector bases); bit 8 = the one-wave
                            contraction of clustered runs ends its launch at a cluster's death (the host relaunches for the rest of the nursery) instead
                            of sorting the live set itself and going on; bit 9 = the kill-off of a run that ends with several clusters by the general
-                           contraction kernel instead of the one-wave kernel k_killoff_cl (the same bits) */
+                           contraction kernel instead of the one-wave kernel k_killoff_cl (the same bits); bit 10 = several clusters: the contraction whose ONE
+                           wavefront decides chain after chain (k_consume_cl) instead of the one with parallel decisions (k_consume_clp): the same run */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the
@@ -199,10 +200,10 @@ typedef struct {
     /* Which kernels the run went through: launches per variant, counted where the host chooses (PCHIP_PATH_* below).  A shape that
        silently leaves a fast path -- an LDS layout that no longer fits, a guard that no longer holds -- shows up here and nowhere
        else: its numbers are the same.  tests/test_baseline_configs.py holds the BASELINE shapes to their paths. */
-    long path[16];
+    long path[24];
 } pchip_result;
 enum { PCHIP_PATH_CONSUME_PAR = 0,      /* one cluster: the parallel contraction k_consume_par (pc_par.hip) */
-       PCHIP_PATH_CONSUME_CL = 1,       /* several clusters: k_consume_cl (pc_clus.hip) */
+       PCHIP_PATH_CONSUME_CL = 1,       /* several clusters: k_consume_clp, decisions in parallel (pc_clus.hip, pc_consume_clp_body.inc) */
        PCHIP_PATH_CONSUME_GENERAL = 2,  /* the general serial kernel k_consume (pc_contract.hip): dynamic nlive, sequential test mode, shapes beyond the LDS */
        PCHIP_PATH_CONSUME_FAST = 3,     /* one cluster, one wavefront: k_consume_fast (B > 1024) */
        PCHIP_PATH_KILLOFF_PAR = 4, PCHIP_PATH_KILLOFF_CL = 5, PCHIP_PATH_KILLOFF_GENERAL = 6, PCHIP_PATH_KILLOFF_FAST = 7,   /* the final kill-off's kernel */
@@ -214,7 +215,9 @@ enum { PCHIP_PATH_CONSUME_PAR = 0,      /* one cluster: the parallel contraction
        PCHIP_PATH_NN_FALLBACKS = 13,    /* chains whose candidate lists held no living entry: the full search inside the contraction */
        PCHIP_PATH_POOL_MODE = 14,       /* 1: babies written straight into the phantom array */
        PCHIP_PATH_DEFER_UPDATE = 15,    /* 1: the contraction runs past update triggers */
-       PCHIP_PATH_COUNT = 16 };
+       PCHIP_PATH_CONSUME_CL_SERIAL = 16,   /* several clusters: k_consume_cl, one wavefront deciding chain after chain (settings.ablate bit 10, or an LDS
+                                               block the parallel kernel's tables push over the limit) */
+       PCHIP_PATH_COUNT = 24 };
 
 /* snapshot handed to the update hook: what the reference's file writers see at every update
    (nested_sampling.F90:323-340, read_write.F90) -- host memory owned by the engine, valid during the call */

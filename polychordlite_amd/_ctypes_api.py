@@ -59,13 +59,13 @@ class Result(C.Structure):
                 ("nlike_grade", C.c_long * 8), ("live_cluster", C.POINTER(C.c_int)),
                 ("nlike_failed", C.c_long), ("ncluster_peak", C.c_int), ("epoch_discard", C.c_int),
                 ("d_records", C.c_void_p), ("n_records", C.c_long), ("records_cap", C.c_long), ("records_device", C.c_int),
-                ("path", C.c_long * 16)]
+                ("path", C.c_long * 24)]
 
 
 # pchip_result.path[]: launches per kernel variant (include/polychord_hip.h PCHIP_PATH_*)
 PATH_NAMES = ("consume_par", "consume_cl", "consume_general", "consume_fast", "killoff_par", "killoff_cl", "killoff_general",
               "killoff_fast", "update_fused", "update_steps", "slice_wave", "slice_lane", "nn_lists", "nn_fallbacks", "pool_mode",
-              "defer_update")
+              "defer_update", "consume_cl_serial")
 
 
 _lib = None

@@ -109,7 +109,9 @@ __device__ __forceinline__ double cl_log(double ref, double v, double logzero)
 // the live slots by (logL, list position), free slots last -- k_sort_live's order (pc_fast.hip sort_live_body: the same comparator, a
 // bitonic network over the next power of two), by this workgroup, in LDS that holds nothing any more; sort_slot / sort_key as that kernel
 // leaves them (the ranks it also writes serve the candidate lists of the NEXT nursery, which the host sorts for)
-__device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem)
+template <int NT> __device__ __forceinline__ void cl_sort_live_nt(const PcState &S, char *smem);
+__device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem);
+template <int NT> __device__ __forceinline__ void cl_sort_live_nt(const PcState &S, char *smem)
 {
     int npow2 = 2;
     while (npow2 < S.Ncap) npow2 <<= 1;
@@ -117,14 +119,14 @@ __device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem)
     int *kp = (int *)(kv + npow2);          // [npow2] list position
     int *ks = kp + npow2;                   // [npow2] slot
     const int tid = threadIdx.x;
-    for (int i = tid; i < npow2; i += CL_NT) {
+    for (int i = tid; i < npow2; i += NT) {
         const bool used = i < S.Ncap && S.live_cluster[i] >= 0;
         kv[i] = used ? S.live_logL[i] : PC_HUGE; kp[i] = used ? S.live_pos[i] : 0x7fffffff; ks[i] = i < S.Ncap ? i : -1;
     }
     __syncthreads();
     for (int k = 2; k <= npow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow2; i += CL_NT) {
+            for (int i = tid; i < npow2; i += NT) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool up = (i & k) == 0;
@@ -136,8 +138,9 @@ __device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem)
             __syncthreads();
         }
     const int NS = (S.Ncap + 63) & ~63;
-    for (int i = tid; i < NS; i += CL_NT) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
+    for (int i = tid; i < NS; i += NT) { S.sort_slot[i] = (i < npow2) ? ks[i] : -1; S.sort_key[i] = (i < npow2) ? d2key(kv[i]) : KEY_HUGE; }
 }
+__device__ __forceinline__ void cl_sort_live(const PcState &S, char *smem) { cl_sort_live_nt<CL_NT>(S, smem); }
 
 template <int J>
 __global__ __launch_bounds__(CL_NT) void k_consume_cl(PcState S)
@@ -156,6 +159,57 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_consume_clp -- the same contraction with its decisions made in parallel (pc_consume_clp_body.inc, round 6): eight waves; wave 0 resolves the
+// acceptance vector 64 steps at a time, all waves derive what the consumed chains leave behind, waves 1 - 3 follow with the evidence work of
+// k_consume_cl.  k_consume_cl stays: the arbiter next to the general kernel (settings.ablate bit 10) and the fallback for shapes whose LDS
+// block this kernel's extra tables push over the limit.
+#define CLP_NT 512
+#define CLP_NEVER 0x7FFu
+struct ClSL { double L, e; };                                  // sorted snapshot: logL, exp(logL - Lhi)
+// a candidate's entry: cluster + 1 (0: not alive at any step of the launch) | step of birth + 1 (0: alive when the launch begins) << 8 | step of death << 19
+__device__ __forceinline__ unsigned clp_tag(int cluster, int birth1, unsigned death) { return (unsigned)(cluster + 1) | ((unsigned)birth1 << 8) | (death << 19); }
+struct ClpLayout {
+    size_t slot, sL, sorted, sortSlot, cand, chain, head, own, logn, rcp, fg, masks, kmin, sCS, lst, lstOff, tag, evt,
+           idxOf, rxS, below, kacc, U, stepOf, accw, clN, clX, total;
+};
+__host__ __device__ inline ClpLayout clp_layout(int Ncap, int B, int nr)
+{
+    ClpLayout o{};
+    size_t p = 0;
+    const size_t NS = ((size_t)Ncap + 63) & ~(size_t)63, nw = ((size_t)nr + 63) / 64;
+    auto take = [&](size_t &field, size_t bytes) { field = p; p += (bytes + 15) & ~(size_t)15; };
+    take(o.slot, sizeof(ClSlot) * (size_t)Ncap); take(o.sL, 8 * (size_t)Ncap); take(o.sorted, sizeof(ClSL) * (NS + 1)); take(o.sortSlot, 2 * (NS + 1));
+    take(o.cand, sizeof(ClSL) * ((size_t)B + 1)); take(o.chain, sizeof(ClChain) * (size_t)B); take(o.head, sizeof(ClHead) * (size_t)B);
+    take(o.own, sizeof(ClOwn) * CL_MAXC); take(o.logn, 8 * ((size_t)Ncap + 4)); take(o.rcp, 8 * ((size_t)Ncap + 4)); take(o.fg, 8 * 2 * CL_MAXC);
+    take(o.masks, 8 * (size_t)B * nw); take(o.kmin, 8 * CL_MAXC);
+    take(o.sCS, 4 * (size_t)B); take(o.lst, 4 * ((size_t)Ncap + B)); take(o.lstOff, 4 * (CL_MAXC + 1)); take(o.tag, 4 * ((size_t)Ncap + B + 1));
+    take(o.evt, sizeof(ClEvt) * (size_t)B);
+    // (rxS / below: where snapshot and candidates interleave; behind the order of deaths the same bytes hold the deaths' link, slot and cluster pair)
+    take(o.idxOf, 2 * (size_t)Ncap); take(o.rxS, 2 * ((size_t)B + 2)); take(o.below, 2 * 2 * ((size_t)B + 2)); take(o.kacc, 2 * ((size_t)B + 2)); take(o.U, 2 * ((size_t)B + 2));
+    take(o.stepOf, 2 * ((size_t)B + 2));
+    take(o.accw, 8 * 16 + 4 * 20); take(o.clN, 4 * 4 * CL_MAXC); take(o.clX, 8 * 2 * CL_MAXC);
+    o.total = p;
+    return o;
+}
+__device__ __forceinline__ void clp_sort_live(const PcState &S, char *smem) { cl_sort_live_nt<CLP_NT>(S, smem); }
+
+template <int J>
+__global__ __launch_bounds__(CLP_NT) void k_consume_clp(PcState S)
+{
+#pragma clang fp contract(on)
+#include "pc_consume_clp_body.inc"
+}
+template <int J>
+__global__ __launch_bounds__(CLP_NT) void k_consume_clp_many(const PcManyRec *__restrict__ R)
+{
+    const PcState S = pc_many_state(R, blockIdx.y);
+    {
+#pragma clang fp contract(on)
+#include "pc_consume_clp_body.inc"
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // k_killoff_cl -- nested_sampling.F90:381-384 for a run that ends with several clusters: every remaining live point dies,
@@ -363,9 +417,26 @@ extern "C" int pc_consume_cl_fits(const PcState *S, int nc)
     return cl_layout(S->Ncap, S->B, S->nr).total + 1024 <= (size_t)160 * 1024;
 }
 
+// the kernel with parallel decisions: the same envelope, its own (larger) LDS block, at most 127 clusters in a death's packed record
+extern "C" int pc_consume_clp_fits(const PcState *S, int nc)
+{
+    static const bool off = std::getenv("PC_CONSUME_CLP_OFF") != nullptr;
+    if (off || (S->ablate & 1024) || !pc_consume_cl_fits(S, nc)) return 0;
+    int npow2 = 2;
+    while (npow2 < S->Ncap) npow2 <<= 1;
+    if ((size_t)npow2 * 16 + 1024 > (size_t)160 * 1024) return 0;      // (the in-kernel sort of the live set between passes)
+    return clp_layout(S->Ncap, S->B, S->nr).total + 1024 <= (size_t)160 * 1024;
+}
+
 // (the runs of a launch: one shape -- live points, chains, repeats -- and one width J of the per-cluster registers)
 extern "C" int pc_launch_consume_cl_many(const PcState *S, const PcManyRec *dR, int R, int wide, hipStream_t st)
 {
+    if (pc_consume_clp_fits(S, 2)) {
+        const size_t shp = clp_layout(S->Ncap, S->B, S->nr).total;
+        if (!wide) { pc_need_dyn_lds((const void *)k_consume_clp_many<1>, shp); hipLaunchKernelGGL(k_consume_clp_many<1>, dim3(1, R), dim3(CLP_NT), shp, st, dR); }
+        else { pc_need_dyn_lds((const void *)k_consume_clp_many<2>, shp); hipLaunchKernelGGL(k_consume_clp_many<2>, dim3(1, R), dim3(CLP_NT), shp, st, dR); }
+        return 0;
+    }
     const size_t sh = cl_layout(S->Ncap, S->B, S->nr).total;
     if (!wide) {
         pc_need_dyn_lds((const void *)k_consume_cl_many<1>, sh);
@@ -379,6 +450,12 @@ extern "C" int pc_launch_consume_cl_many(const PcState *S, const PcManyRec *dR, 
 
 extern "C" int pc_launch_consume_cl(const PcState *S, int nc, hipStream_t st)
 {
+    if (pc_consume_clp_fits(S, nc)) {
+        const size_t shp = clp_layout(S->Ncap, S->B, S->nr).total;
+        if (nc <= 64) { pc_need_dyn_lds((const void *)k_consume_clp<1>, shp); hipLaunchKernelGGL(k_consume_clp<1>, dim3(1), dim3(CLP_NT), shp, st, *S); }
+        else { pc_need_dyn_lds((const void *)k_consume_clp<2>, shp); hipLaunchKernelGGL(k_consume_clp<2>, dim3(1), dim3(CLP_NT), shp, st, *S); }
+        return 0;
+    }
     const size_t sh = cl_layout(S->Ncap, S->B, S->nr).total;
     if (nc <= 64) {
         pc_need_dyn_lds((const void *)k_consume_cl<1>, sh);

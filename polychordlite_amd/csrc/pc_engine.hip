@@ -74,6 +74,7 @@ int pc_launch_sort_live(const PcState *, hipStream_t);
 int pc_launch_consume_par(const PcState *, hipStream_t);
 int pc_launch_final_par(const PcState *, hipStream_t);
 int pc_consume_cl_fits(const PcState *, int);
+int pc_consume_clp_fits(const PcState *, int);
 int pc_launch_consume_cl(const PcState *, int, hipStream_t);
 int pc_launch_killoff_cl(const PcState *, int, hipStream_t);
 void pc_launch_ph_prepare(const PcState *, hipStream_t);
@@ -2506,7 +2507,7 @@ struct Engine {
                 if (co && use_cl && cohort_general_ok()) {
                     // in step with other runs: lists, sort and the one-wave contraction once for all runs with several clusters
                     if (want_nn) { co->rec(CK_NN, S, {}, {}, {0, nursery_left}); S.nn_valid = 1; path[PCHIP_PATH_NN_LISTS]++; }
-                    path[PCHIP_PATH_CONSUME_CL]++;
+                    path[pc_consume_clp_fits(&S, h_ctl->ncluster) ? PCHIP_PATH_CONSUME_CL : PCHIP_PATH_CONSUME_CL_SERIAL]++;
                     co->rec(CK_SORT, S, {}, {}, {});
                     co->rec(CK_CONSUME_CL, S, {}, {h_ctl->ncluster > 64 ? 1LL : 0LL}, {});
                     rc2 = 0;
@@ -2520,7 +2521,7 @@ struct Engine {
                     pc_launch_nn_lists(&S, nursery_left, sorted_now ? 1 : 0, st);
                     S.nn_valid = 1; path[PCHIP_PATH_NN_LISTS]++;
                 }
-                path[use_cl ? PCHIP_PATH_CONSUME_CL : PCHIP_PATH_CONSUME_GENERAL]++;
+                path[use_cl ? (pc_consume_clp_fits(&S, h_ctl->ncluster) ? PCHIP_PATH_CONSUME_CL : PCHIP_PATH_CONSUME_CL_SERIAL) : PCHIP_PATH_CONSUME_GENERAL]++;
                 if (use_cl) {
                     rc2 = (sorted_now ? 0 : pc_launch_sort_live(&S, st)) || pc_launch_consume_cl(&S, h_ctl->ncluster, st);
                 } else

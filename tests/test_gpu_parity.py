@@ -557,28 +557,40 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
                                                      ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12)),
                                                      ("rastrigin", 2, 0, 400, 70, (-5.12, 5.12)),          # two phantom-mask words per chain
                                                      ("rastrigin", 3, 0, 2400, 9, (-5.12, 5.12)),          # more than 64 clusters alive: two clusters per lane
+                                                     ("rastrigin", 3, 0, 1200, 9, (-5.12, 5.12)),          # ... in a live set the LDS-resident kernels take
                                                      ("twin_gaussian", 20, 1, 400, 10, (-1.0, 1.0))])      # steep: launches that end at their 300-nat window
 def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, box):
-    """several clusters: the one-wave contraction (pc_clus.hip: deaths from the sorted snapshot, evidence accumulators as
-    (m, s) pairs, one cluster per lane) against the general kernel it replaces (settings.ablate bit 5 sends every launch
-    there) -- the same run: every counter, every dead row, the evidences of all clusters, the live set"""
+    """several clusters, three kernels, one run: the contraction with its decisions made in parallel (k_consume_clp, pc_consume_clp_body.inc: the
+    acceptance vector as a fixed point over dominance counts, everything else from prefix sums and the merged order of deaths), the one
+    whose single wavefront decides chain after chain (k_consume_cl: settings.ablate bit 10) and the general kernel both replace (bit 5
+    sends every launch there) -- every counter, every dead row, the evidences of all clusters, the live set; the first two also the same
+    BITS in the evidences (the same statements in the same order on the evidence side)"""
     api = engine
     L, P, keep = api.make_problem(kind, D, nDer, *box)
     runs = []
-    for ab in (0, 32):
+    for ab in (0, 1024, 32):
         s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=21, batch=0, do_clustering=1)
         s.ablate = ab
         runs.append(api.run(s, L, P))
-    a, b = runs
+    a, c, b = runs
+    # (nlive 2400 / 1024 chains: no LDS-resident kernel takes a live set of that size with that nursery -- all three runs go through the general kernel,
+    #  which pchip_result.path now shows; the shape stays for the general kernel's own two-clusters-per-lane code)
+    if nlive < 2000:
+        assert a["path"]["consume_general"] == 0 and a["path"]["consume_cl"] > 0 and a["path"]["consume_cl_serial"] == 0
+    if nlive < 2000:
+        assert c["path"]["consume_cl_serial"] > 0 and c["path"]["consume_cl"] == 0
+    assert b["path"]["consume_general"] > 0 and b["path"]["consume_cl"] == 0
     assert a["ncluster_peak"] >= 2 and a["ncluster_dead"] >= 2          # clusters were found, and clusters died on the way
-    if D == 3: assert a["ncluster_peak"] > 64
-    for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak"):
-        assert a[k] == b[k], (k, a[k], b[k])
-    assert abs(a["logZ"] - b["logZ"]) < 1e-10 and abs(a["logZerr"] - b["logZerr"]) < 1e-10
-    assert np.array_equal(a["dead"][:, :-2], b["dead"][:, :-2]) and np.array_equal(a["dead"][:, -1], b["dead"][:, -1])
-    assert np.abs(a["logweights"] - b["logweights"]).max() < 1e-9
-    assert np.allclose(a["logZp"], b["logZp"], atol=1e-9) and np.allclose(a["varlogZp"], b["varlogZp"], atol=1e-9)
-    assert np.array_equal(a["live"], b["live"])
+    if D == 3 and nlive == 2400: assert a["ncluster_peak"] > 64
+    for b in (c, b):
+        for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak", "nlike_failed"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert abs(a["logZ"] - b["logZ"]) < 1e-10 and abs(a["logZerr"] - b["logZerr"]) < 1e-10
+        assert np.array_equal(a["dead"][:, :-2], b["dead"][:, :-2]) and np.array_equal(a["dead"][:, -1], b["dead"][:, -1])
+        assert np.abs(a["logweights"] - b["logweights"]).max() < 1e-9
+        assert np.allclose(a["logZp"], b["logZp"], atol=1e-9) and np.allclose(a["varlogZp"], b["varlogZp"], atol=1e-9)
+        assert np.array_equal(a["live"], b["live"])
+    assert a["logZ"] == c["logZ"] and np.array_equal(a["logweights"], c["logweights"]) and np.array_equal(a["dead"], c["dead"])
 
 
 @pytest.mark.gpu

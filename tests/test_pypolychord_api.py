@@ -793,9 +793,6 @@ def test_feedback_levels_print_like_the_reference(engine, tmp_path, capfd):
     box = run(0, "fb0")
     out0 = capfd.readouterr().out
     assert "| ndead  = %12d" % box.ndead in out0 and "| log(Z) =" in out0 and "lives      |" not in out0
-    # a run that held several clusters says, behind the reference's box, what its error does not contain and which rule it followed for
-    # chains in flight (the one engine-specific sampling rule at the drop-in boundary: include/polychord_hip.h pchip_settings.epoch_discard)
-    assert "clusters were alive at once" in out0 and "THIS ENGINE's rule" in out0 and "nested_sampling.F90:313" in out0
     loud = run(1, "fb1")
     out1 = capfd.readouterr().out
     assert "started sampling" in out1 and out1.count("lives      |") >= 3 and out1.count("log(Z)     =") >= 3
@@ -885,7 +882,7 @@ def test_posterior_samples_match_the_oracle(engine, tmp_path, kind, D, nDer, nli
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("discard", [0, 1])
-def test_epoch_rule_through_the_front_door(engine, tmp_path, discard):
+def test_epoch_rule_through_the_front_door(engine, tmp_path, discard, capfd):
     """polychord_hip_set_option("epoch_discard", 1) gives polychord_c_interface callers the reference farm's rule for chains in flight
     when the list of clusters changes (nested_sampling.F90:313); the default keeps the chains of the clusters the change left alone.
     Either way the run pypolychord.run_polychord makes is the oracle's run under that rule."""
@@ -896,9 +893,16 @@ def test_epoch_rule_through_the_front_door(engine, tmp_path, discard):
         s = pypolychord.PolyChordSettings(D, 0, nlive=nlive, num_repeats=nr, seed=23, do_clustering=True, read_resume=False,
                                           write_resume=False, write_dead=False, write_stats=True, posteriors=False, equals=False,
                                           write_prior=False, write_live=False, base_dir=str(tmp_path), file_root="e", feedback=0)
+        capfd.readouterr()
+        s.feedback = 0
         out = pypolychord.run_polychord(dl.Rastrigin(), D, 0, s, dl.UniformPrior(-5.12, 5.12))
+        box = capfd.readouterr().out
     finally:
         lib.polychord_hip_set_option(b"batch", 0.0); lib.polychord_hip_set_option(b"epoch_discard", 0.0)
+    # a run that held several clusters says, behind the reference's final box, what its error does not contain and which rule it followed
+    # for chains in flight (the one engine-specific sampling rule at the drop-in boundary: pchip_settings.epoch_discard)
+    assert "| log(Z) =" in box and "clusters were alive at once" in box and "nested_sampling.F90:313" in box
+    assert ("THIS ENGINE's rule" in box) == (discard == 0) and ("the reference farm's rule" in box) == (discard == 1)
     so = orc.settings(D, 0, nlive=nlive, num_repeats=nr, seed=23, batch=120, do_clustering=1, epoch_discard=discard)
     Lo, Po, keep = orc.make_problem("rastrigin", D, -5.12, 5.12)
     o = orc.run(so, Lo, Po)
