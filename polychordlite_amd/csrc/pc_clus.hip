@@ -172,7 +172,7 @@ struct ClSL { double L, e; };                                  // sorted snapsho
 __device__ __forceinline__ unsigned clp_tag(int cluster, int birth1, unsigned death) { return (unsigned)(cluster + 1) | ((unsigned)birth1 << 8) | (death << 19); }
 struct ClpLayout {
     size_t slot, sL, sorted, sortSlot, cand, chain, head, own, logn, rcp, fg, masks, kmin, sCS, lst, lstOff, tag, evt,
-           idxOf, rxS, below, kacc, U, stepOf, accw, clN, clX, total;
+           idxOf, rxS, below, kacc, U, stepOf, accw, clN, clX, ctot, total;
 };
 __host__ __device__ inline ClpLayout clp_layout(int Ncap, int B, int nr)
 {
@@ -189,7 +189,7 @@ __host__ __device__ inline ClpLayout clp_layout(int Ncap, int B, int nr)
     // (rxS / below: where snapshot and candidates interleave; behind the order of deaths the same bytes hold the deaths' link, slot and cluster pair)
     take(o.idxOf, 2 * (size_t)Ncap); take(o.rxS, 2 * ((size_t)B + 2)); take(o.below, 2 * 2 * ((size_t)B + 2)); take(o.kacc, 2 * ((size_t)B + 2)); take(o.U, 2 * ((size_t)B + 2));
     take(o.stepOf, 2 * ((size_t)B + 2));
-    take(o.accw, 8 * 16 + 4 * 20); take(o.clN, 4 * 4 * CL_MAXC); take(o.clX, 8 * 2 * CL_MAXC);
+    take(o.accw, 8 * 16 + 4 * 20); take(o.clN, 4 * 4 * CL_MAXC); take(o.clX, 8 * 2 * CL_MAXC); take(o.ctot, 2 * CL_MAXC * (((size_t)B + 63) / 64));
     o.total = p;
     return o;
 }

@@ -557,7 +557,7 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
                                                      ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12)),
                                                      ("rastrigin", 2, 0, 400, 70, (-5.12, 5.12)),          # two phantom-mask words per chain
                                                      ("rastrigin", 3, 0, 2400, 9, (-5.12, 5.12)),          # more than 64 clusters alive: two clusters per lane
-                                                     ("rastrigin", 3, 0, 1200, 9, (-5.12, 5.12)),          # ... in a live set the LDS-resident kernels take
+                                                     ("rastrigin", 2, 0, 1000, 6, (-5.12, 5.12)),          # ... in a live set the LDS-resident kernels take (121 modes, eight points a mode)
                                                      ("twin_gaussian", 20, 1, 400, 10, (-1.0, 1.0))])      # steep: launches that end at their 300-nat window
 def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, box):
     """several clusters, three kernels, one run: the contraction with its decisions made in parallel (k_consume_clp, pc_consume_clp_body.inc: the
@@ -581,7 +581,10 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
         assert c["path"]["consume_cl_serial"] > 0 and c["path"]["consume_cl"] == 0
     assert b["path"]["consume_general"] > 0 and b["path"]["consume_cl"] == 0
     assert a["ncluster_peak"] >= 2 and a["ncluster_dead"] >= 2          # clusters were found, and clusters died on the way
-    if D == 3 and nlive == 2400: assert a["ncluster_peak"] > 64
+    # (more than 64 clusters alive at once -- two clusters per lane in the LDS-resident kernels -- needs a live set those kernels' LDS does not take:
+    #  2400 points reach it, through the general kernel; the largest live set that fits holds 40 clusters at its peak)
+    if nlive == 2400: assert a["ncluster_peak"] > 64, a["ncluster_peak"]
+    if nlive == 1000: assert a["ncluster_peak"] > 32, a["ncluster_peak"]
     for b in (c, b):
         for k in ("ndead", "nlike", "niter", "ncluster", "ncluster_dead", "nupdates", "ncluster_peak", "nlike_failed"):
             assert a[k] == b[k], (k, a[k], b[k])
