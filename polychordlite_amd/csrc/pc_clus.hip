@@ -167,6 +167,7 @@ __global__ __launch_bounds__(CL_NT) void k_consume_cl_many(const PcManyRec *__re
 // block this kernel's extra tables push over the limit.
 #define CLP_NT 512
 #define CLP_NEVER 0x7FFu
+#define CLP_ALIVE 0x7fffffff
 struct ClSL { double L, e; };                                  // sorted snapshot: logL, exp(logL - Lhi)
 // a candidate's entry: cluster + 1 (0: not alive at any step of the launch) | step of birth + 1 (0: alive when the launch begins) << 8 | step of death << 19
 __device__ __forceinline__ unsigned clp_tag(int cluster, int birth1, unsigned death) { return (unsigned)(cluster + 1) | ((unsigned)birth1 << 8) | (death << 19); }
@@ -189,7 +190,7 @@ __host__ __device__ inline ClpLayout clp_layout(int Ncap, int B, int nr)
     // (rxS / below: where snapshot and candidates interleave; behind the order of deaths the same bytes hold the deaths' link, slot and cluster pair)
     take(o.idxOf, 2 * (size_t)Ncap); take(o.rxS, 2 * ((size_t)B + 2)); take(o.below, 2 * 2 * ((size_t)B + 2)); take(o.kacc, 2 * ((size_t)B + 2)); take(o.U, 2 * ((size_t)B + 2));
     take(o.stepOf, 2 * ((size_t)B + 2));
-    take(o.accw, 8 * 16 + 4 * 20); take(o.clN, 4 * 4 * CL_MAXC); take(o.clX, 8 * 2 * CL_MAXC); take(o.ctot, 2 * CL_MAXC * (((size_t)B + 63) / 64));
+    take(o.accw, 8 * 16 + 4 * 20); take(o.clN, 4 * 5 * CL_MAXC); take(o.clX, 8 * 2 * CL_MAXC); take(o.ctot, 2 * CL_MAXC * (((size_t)B + 63) / 64));
     o.total = p;
     return o;
 }
