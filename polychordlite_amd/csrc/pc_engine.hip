@@ -942,7 +942,7 @@ struct Engine {
         S.cl_list = dalloc<int>((size_t)maxc * Ncap); S.cl_n = dalloc<int>(maxc);
         S.logZp = dalloc<double>(maxc); S.logXp = dalloc<double>(maxc); S.logZXp = dalloc<double>(maxc);
         S.logZp2 = dalloc<double>(maxc); S.logZpXp = dalloc<double>(maxc); S.logLp = dalloc<double>(maxc);
-        S.XpXq = dalloc<double>((size_t)maxc * maxc); S.imin_slot = dalloc<int>(maxc);
+        S.XpXq = dalloc<double>(2 * (size_t)maxc * maxc); S.imin_slot = dalloc<int>(maxc);      // (the second half: k_consume_clp's copy of the matrix in linear space, made anew by every pass)
         S.lse_ref = dalloc<double>(maxc); S.lse_sum = dalloc<double>(maxc); S.death_thr = dalloc<double>(maxc);
         S.cl_uid = dalloc<unsigned>(maxc);
         S.chol = dalloc<double>((size_t)maxc * D * D); S.cov = dalloc<double>((size_t)maxc * D * D);
@@ -1289,7 +1289,7 @@ struct Engine {
         {   // the cross-volume matrix changes its leading dimension
             std::vector<double> o = dl(S.XpXq, (size_t)mo * mo), v((size_t)mn * mn, 0.0);
             for (int a = 0; a < mo; ++a) std::copy(o.begin() + (size_t)a * mo, o.begin() + (size_t)(a + 1) * mo, v.begin() + (size_t)a * mn);
-            dfree(S.XpXq); S.XpXq = dalloc<double>((size_t)mn * mn); ul(S.XpXq, v);
+            dfree(S.XpXq); S.XpXq = dalloc<double>(2 * (size_t)mn * mn); ul(S.XpXq, v);
         }
         {
             int *q = dalloc<int>((size_t)mn * Ncap);
