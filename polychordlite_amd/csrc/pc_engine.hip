@@ -2726,6 +2726,7 @@ struct Engine {
         if (dbg_lvl >= 3) std::fprintf(stderr, "polychord_hip dbg general: term %lld identify %lld kill+add %lld tail %lld cycles; %lld chains identified from the candidate lists, %lld of them fell back to the full search\n", h_ctl->gen_cyc[0], h_ctl->gen_cyc[1], h_ctl->gen_cyc[2], h_ctl->gen_cyc[3], h_ctl->nn_walks, h_ctl->nn_fallbacks);
         if (dbg_lvl == 4) std::fprintf(stderr, "polychord_hip dbg par: stage+search %lld rank-sort %lld accept %lld merge+slots %lld evidence %lld triggers %lld publish %lld cycles\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[4], h_ctl->dbg[5], h_ctl->dbg[6]);
         if (dbg_lvl == 4) std::fprintf(stderr, "polychord_hip dbg par: %lld evidence scans as pairs (terms beyond one scale)\n", h_ctl->dbg[7]);
+        if (dbg_lvl == 4 && h_ctl->wave_cyc[0]) std::fprintf(stderr, "polychord_hip dbg clp (several clusters; the line above then reads: decisions | order of deaths + slots | counts + volumes | volume sum + step 0's phantoms | prefix sums + commit | waves 1-3 | write back | passes): wave 1 %lld wave 2 %lld wave 3 %lld phantom wave %lld cycles\n", h_ctl->wave_cyc[0], h_ctl->wave_cyc[1], h_ctl->wave_cyc[2], h_ctl->wave_cyc[3]);
         if (dbg_lvl == 2) std::fprintf(stderr, "polychord_hip dbg: loop cycles %lld passB %lld (%lld flushes) accept-steps %lld (%lld) ins-rescan %lld (%lld) reject-steps cycles %lld\n", h_ctl->dbg[0], h_ctl->dbg[1], h_ctl->dbg[4], h_ctl->dbg[2], h_ctl->dbg[3], h_ctl->dbg[5], h_ctl->dbg[6], h_ctl->dbg[7]);
         if ((size_t)h_ctl->ndead > h_dead_cap) {          // the dead array grew beyond the first estimate
             HIPCHK(hipStreamSynchronize(st_copy));

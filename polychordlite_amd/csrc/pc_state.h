@@ -49,6 +49,7 @@ struct PcCtl {                   // written by the consume kernel, read by the h
     int chol_suspect, chol_pad;         // the blocked factorisation met a pivot it does not trust: the reference-order kernel behind it decides
     int spec_ok, upd_in;                // upd_in: lived deaths until the next update trigger, as the state stands after this launch (0 = not known); spec_ok: parallel contraction: number of the nursery that may be sampled at once (this one was consumed whole, no
                                         // update is due, the run goes on), or -1: what a speculatively enqueued k_slice asks first
+    long long wave_cyc[4];              // developer counters of k_consume_clp: cycles waves 1, 2, 3 spend in their loops over a pass's deaths, the phantom waves in theirs
 };
 
 #define PC_MAX_GRADE 8
