@@ -100,8 +100,8 @@ SLICE_CHAIN = {  # section: (dependent fp64 ops, LDS round trips, what)
     "stores": (2, 1, "cube -> theta: 2; LDS hop for the derived parameters' row"),
 }
 DEP_FP64_CYCLES, LDS_CYCLES, PHILOX_CYCLES_PER_SLICE, CLOCK_MHZ = 32.0, 70.0, 60.0, 2400.0
-SLICE_CYCLE_FILES = ("r05_slice_cycles.json", "r04_slice_cycles.json", "r03_slice_cycles.json")
-PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")
+SLICE_CYCLE_FILES = ("r06_slice_cycles.json", "r05_slice_cycles.json", "r04_slice_cycles.json", "r03_slice_cycles.json")
+PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")
 
 
 def committed_record(names, need):

@@ -116,7 +116,8 @@ def test_two_ranks_through_the_whole_harness_on_one_gpu():
     assert "leg_errors" not in j, j.get("leg_errors")
 
 
-@pytest.mark.parametrize("name", ["r05_bench.json", "r05_bench_c3.json", "r05_bench_c4.json", "r05_bench_c5.json"])
+@pytest.mark.parametrize("name", ["r05_bench.json", "r05_bench_c3.json", "r05_bench_c4.json", "r05_bench_c5.json",
+                                  "r06_bench.json", "r06_bench_c3.json", "r06_bench_c4.json", "r06_bench_c5.json"])
 def test_the_lines_bench_py_printed_on_the_gpu_box(name):
     """the committed last lines of `python bench.py [--workload cN]` as they came off the MI355X: one line, < 6 KB, the driver's fields"""
     text = open(os.path.join(ROOT, "profiles", name)).read().strip()
@@ -124,7 +125,14 @@ def test_the_lines_bench_py_printed_on_the_gpu_box(name):
     j = json.loads(text)
     assert j["roofline"]["frac"] > 0 and j["roofline"]["bound"] == "hbm" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "reference"
     assert j["unit"] == "likelihood evals/s" and j["dtype"] == "f64" and j["scaling"] == "weak" and j["n_gpus"] == 1 and j["vs_baseline"] is None
-    if name == "r05_bench.json":
+    if name == "r06_bench.json":
+        # round 6: the figure a user's own device functor gets and the reference-equivalent one stand at the top of the record, the general-functor
+        # sampling kernel has its own roofline entry, and the record says which kernels the run took
+        assert 0 < j["value_general_functor"] < j["value"] and 0 < j["value_reference_equivalent"] < j["value"]
+        assert j["general_functor"]["frac"] > 0 and j["general_functor"]["avg_launch_us"] > 0
+        assert j["paths"]["consume_par"] > 0 and "consume_general" not in j["paths"]
+        assert all(v["general_kernel_launches"] == 0 for v in j["other_configs"].values())
+    if name in ("r05_bench.json", "r06_bench.json"):
         assert j["metric"].startswith("likelihood evals/sec, 20D Gaussian nlive=2000") and j["config"]["batch_chains"] == 1000
         assert len(j["roofline"]["in_step"]) == 6 and j["roofline"]["in_step_multi"]["runs"] == 16
 
