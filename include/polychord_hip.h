@@ -133,7 +133,10 @@ typedef struct {
                            contraction of clustered runs ends its launch at a cluster's death (the host relaunches for the rest of the nursery) instead
                            of sorting the live set itself and going on; bit 9 = the kill-off of a run that ends with several clusters by the general
                            contraction kernel instead of the one-wave kernel k_killoff_cl (the same bits); bit 10 = several clusters: the contraction whose ONE
-                           wavefront decides chain after chain (k_consume_cl) instead of the one with parallel decisions (k_consume_clp): the same run */
+                           wavefront decides chain after chain (k_consume_cl) instead of the one with parallel decisions (k_consume_clp): the same run; bit 11 = k_consume_clp with
+                           update_evidence and the live evidence as sums over all of a pass's deaths (a walk per cluster, pair sums, prefix sums: phase C' of
+                           pc_consume_clp_body.inc) instead of death after death on two wavefronts -- the same run to rounding in <Z^2>; an experiment that is
+                           NOT the default: its walks are as long as the largest cluster's events, and at the BASELINE shapes that is no shorter */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

@@ -608,6 +608,15 @@ def test_clustered_contraction_kernels_agree(engine, kind, D, nDer, nlive, nr, b
         assert a8["logZ"] == c8["logZ"] and np.array_equal(a8["logweights"], c8["logweights"])
     else:
         assert abs(a8["logZ"] - c8["logZ"]) < 1e-12 and np.abs(a8["logweights"] - c8["logweights"]).max() < 1e-10
+    # the evidence as sums over all of a pass's deaths (bit 11: a walk per cluster, pair sums, prefix sums -- an experiment, not the default): <Z> and the
+    # log weights come out of the same statements in the same order, <Z^2> and <Z X_q> in another grouping (the reported log Z is 2 log<Z> - log<Z^2> / 2)
+    s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=21, batch=0, do_clustering=1)
+    s.ablate = 256 | 2048
+    a9 = api.run(s, L, P)
+    assert np.array_equal(a9["dead"], c8["dead"]) and np.array_equal(a9["live"], c8["live"]) and a9["ndead"] == c8["ndead"] and a9["nupdates"] == c8["nupdates"]
+    assert abs(a9["logZ"] - c8["logZ"]) < 1e-12 and abs(a9["logZerr"] - c8["logZerr"]) < 1e-10 and np.allclose(a9["logZp"], c8["logZp"], atol=1e-10)
+    if a9["path"]["nn_fallbacks"] == 0:
+        assert np.array_equal(a9["logweights"], c8["logweights"])
     assert a8["ndead"] == a["ndead"] and abs(a8["logZ"] - a["logZ"]) < 1e-10
 
 
