@@ -1250,12 +1250,12 @@ extern "C" int pc_slice_fusable(const PcState *S)
     return !off && S->D <= 24 && pc_nhats_splittable(S) && S->ngrade <= 1 && S->like.kind != PC_LIKE_CORR_GAUSSIAN && S->nr <= 1024;
 }
 
-// the functor variants of k_slice (LEAN = 3 Rastrigin, 4 twin Gaussian): one grade, keyed draws
+// the functor variants of k_slice (LEAN = 3 Rastrigin, 4 twin Gaussian, 5 the Gaussian when settings.ablate bit 0 asks for it as a functor): one grade, keyed draws
 static int slice_lean_functor(const PcState *S)
 {
     static const bool off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
     if (off || S->ngrade > 1 || S->seq_mode) return 0;
-    return S->like.kind == PC_LIKE_RASTRIGIN ? 3 : (S->like.kind == PC_LIKE_TWIN_GAUSSIAN ? 4 : 0);
+    return S->like.kind == PC_LIKE_RASTRIGIN ? 3 : (S->like.kind == PC_LIKE_TWIN_GAUSSIAN ? 4 : ((S->like.kind == PC_LIKE_GAUSSIAN && (S->ablate & 1)) ? 5 : 0));
 }
 
 extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchains, hipStream_t st)
@@ -1274,7 +1274,7 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, LN>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
 #define PC_SLICE_FUSED(NROWS, FW) { \
-        if (leanf == 3) PC_SLICE_FUSED_L(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_L(NROWS, FW, 4) else \
+        if (leanf == 3) PC_SLICE_FUSED_L(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_L(NROWS, FW, 4) else if (leanf == 5) PC_SLICE_FUSED_L(NROWS, FW, 5) else \
         if (lean) { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, 1>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
@@ -1302,7 +1302,7 @@ extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R
         const int FWv = D <= 8 ? 8 : (D <= 16 ? 16 : 24);
         const size_t sh = sh0 + (phi_lds ? tb : 0) + sizeof(double) * ((size_t)FWv * D + (size_t)S->nr * (D + 2));
         if (sh > 150 * 1024) return 1;
-        const int leanf = slice_lean_functor(S);
+        const int leanf = slice_lean_functor(S) == 5 ? 0 : slice_lean_functor(S);
 #define PC_SLICE_FUSED_ML(NROWS, FW, LN) { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice_many<1, NROWS, false, 1, FW, LN>, sh); \
         hipLaunchKernelGGL((k_slice_many<1, NROWS, false, 1, FW, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
@@ -1316,7 +1316,7 @@ extern "C" int pc_launch_slice_many(const PcState *S, const PcManyRec *dR, int R
     }
     if (S->like.kind == PC_LIKE_CORR_GAUSSIAN || S->ngrade > 1 || S->seq_mode || D > 64) return 1;
     const size_t sh = sh0 + (phi_lds ? tb : 0);
-    const int leanf = slice_lean_functor(S);
+    const int leanf = slice_lean_functor(S) == 5 ? 0 : slice_lean_functor(S);
 #define PC_SLICE_ML(DPL, NROWS, LN) { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice_many<DPL, NROWS, false, 1, 0, LN>, sh); \
         hipLaunchKernelGGL((k_slice_many<DPL, NROWS, false, 1, 0, LN>), dim3(nchains, R), dim3(64), sh, st, dR, phi_lds, 0); }
@@ -1376,7 +1376,7 @@ extern "C" int pc_launch_slice(const PcState *S, unsigned batch, int nchains, hi
 #define PC_SLICE_LAUNCHL(DPL, NROWS, LN) { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<DPL, NROWS, false, 1, 0, LN>, sh); \
         hipLaunchKernelGGL((k_slice<DPL, NROWS, false, 1, 0, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, mat_lds); }
-#define PC_SLICE_LAUNCH(DPL, NROWS) { if (DPL == 1 && leanf == 3) PC_SLICE_LAUNCHL(1, NROWS, 3) else if (DPL == 1 && leanf == 4) PC_SLICE_LAUNCHL(1, NROWS, 4) else \
+#define PC_SLICE_LAUNCH(DPL, NROWS) { if (DPL == 1 && leanf == 3) PC_SLICE_LAUNCHL(1, NROWS, 3) else if (DPL == 1 && leanf == 4) PC_SLICE_LAUNCHL(1, NROWS, 4) else if (DPL == 1 && leanf == 5) PC_SLICE_LAUNCHL(1, NROWS, 5) else \
         if (S->ngrade > 1 || S->seq_mode) PC_SLICE_LAUNCH1(DPL, NROWS, true) else PC_SLICE_LAUNCH1(DPL, NROWS, false) }
     if (D <= 16) PC_SLICE_LAUNCH(1, 1)
     else if (D <= 32) PC_SLICE_LAUNCH(1, 2)
