@@ -136,7 +136,9 @@ typedef struct {
                            wavefront decides chain after chain (k_consume_cl) instead of the one with parallel decisions (k_consume_clp): the same run; bit 11 = k_consume_clp with
                            update_evidence and the live evidence as sums over all of a pass's deaths (a walk per cluster, pair sums, prefix sums: phase C' of
                            pc_consume_clp_body.inc) instead of death after death on two wavefronts -- the same run to rounding in <Z^2>; an experiment that is
-                           NOT the default: its walks are as long as the largest cluster's events, and at the BASELINE shapes that is no shorter */
+                           NOT the default: its walks are as long as the largest cluster's events, and at the BASELINE shapes that is no shorter; bit 12 = runs in step
+                           (and bit 7): the deviates of a basis made in the registers of the Gram-Schmidt kernel (k_bases_own) instead of
+                           passing through HBM from a kernel of their own -- the same bases bit for bit, a third of the round's bytes less, NOT faster */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

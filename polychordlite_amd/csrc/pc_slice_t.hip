@@ -551,14 +551,68 @@ __device__ __forceinline__ double dot4(const double (&a)[D], const double (&b)[D
     return (pp[0] + pp[1]) + (pp[2] + pp[3]);
 }
 
+// The deviates of a thread's own vector, made where they are used (round 6): element d of vector i of basis b of a chain is position
+// e0(b) + i nDims + d of the chain's stream, two positions to a Philox call (random_utils.F90:251-263) -- what k_deviates_t writes to
+// nhat_raw and k_bases_packed reads back (105 + 99 MB of a launch of sixteen runs) stays in registers.  AS241 as there: the central
+// branch in line, the arguments that fall in a tail (15 %) collected in LDS -- a lane's own behind those of the lanes before it, so
+// that each finds its results again by counting -- and finished by the whole wavefront together: the same function values.
+#define BASES_TQ 768
+template <int DMAX>
+__device__ __forceinline__ void bases_own_deviates(const PcState &S, unsigned batch, int g, int i, bool active, double (&v)[DMAX], double *tq)
+{
+    constexpr int NK = DMAX / 2 + 1;
+    const int D = S.D, lane = threadIdx.x & 63;
+    const int chain = g / S.nb_total, basis = g - chain * S.nb_total;
+    const uint32_t ef = (uint32_t)pc_sel(S.g_e0, 0) + (uint32_t)basis * (uint32_t)(D * D) + (uint32_t)(i * D);
+    const int p = active ? (int)(ef & 1u) : 0;
+    const uint32_t c0 = ef >> 1;
+    const int nk = (D + 1 + (__any(p) ? 1 : 0)) / 2;          // calls a lane (wave-uniform)
+    double s[2 * NK];
+    unsigned tmask = 0u;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        s[2 * k] = 0.0; s[2 * k + 1] = 0.0;
+        if (k < nk) {
+            double ua = 0.5, ub = 0.5;
+            if (active) pc_uniform2(S.k0, S.k1, PC_DOM_NHAT, batch, (uint32_t)chain, c0 + (uint32_t)k, ua, ub);
+            const bool na = active && 2 * k - p >= 0 && 2 * k - p < D, nb = active && 2 * k + 1 - p < D;      // the positions my vector has
+            bool ta, tb;
+            const double xa = pc_inv_normal_central(ua, ta), xb = pc_inv_normal_central(ub, tb);
+            ta = ta && na; tb = tb && nb;
+            s[2 * k] = ta ? ua : xa; s[2 * k + 1] = tb ? ub : xb;
+            tmask |= (ta ? 1u : 0u) << (2 * k) | (tb ? 1u : 0u) << (2 * k + 1);
+        }
+    }
+    {
+        const int tcount = __popc(tmask);
+        int inc = tcount;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        const int total = __shfl(inc, 63), lbase = inc - tcount;
+        for (int w0 = 0; w0 < total; w0 += BASES_TQ) {        // (one round: a wavefront has ~200 tail arguments)
+            int c = lbase - w0;
+#pragma unroll
+            for (int j = 0; j < 2 * NK; ++j) if ((tmask >> j) & 1u) { if (c >= 0 && c < BASES_TQ) tq[c] = s[j]; c++; }
+            const int nq = min(BASES_TQ, total - w0);
+            for (int k = lane; k < nq; k += 64) tq[k] = pc_inv_normal_tail(tq[k]);
+            c = lbase - w0;
+#pragma unroll
+            for (int j = 0; j < 2 * NK; ++j) if ((tmask >> j) & 1u) { if (c >= 0 && c < BASES_TQ) s[j] = tq[c]; c++; }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? (p ? s[d + 1] : s[d]) : 0.0;
+}
+
 // step 2: thread = vector, as in k_nhats, but 64 / nDims bases to a wavefront (a basis keeps nDims of a wave's lanes busy) and
 // the deviates already made: every thread keeps its vector in registers, the pivot goes round through a few hundred bytes of
 // LDS, a barrier per Gram-Schmidt step.  The same operations per vector as k_nhats<DMAX, 64, 1>.
-template <int DMAX>
-__device__ __forceinline__ void bases_packed_body(const PcState &S, int nbases)
+template <int DMAX, bool OWN = false>
+__device__ __forceinline__ void bases_packed_body(const PcState &S, int nbases, unsigned batch = 0u)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double tq[OWN ? BASES_TQ : 1];
     const int D = S.D, per = 64 / D;
     const int tid = threadIdx.x, sub = tid / D, i = tid - sub * D;
     const int g = blockIdx.x * per + sub;
@@ -566,8 +620,11 @@ __device__ __forceinline__ void bases_packed_body(const PcState &S, int nbases)
     double *Q = (double *)smem + (size_t)(sub < per ? sub : 0) * 2 * DMAX;      // [2][DMAX] the pivot of this basis, double buffered
     double v[DMAX];
     double *raw = S.nhat_raw + ((size_t)(active ? g : 0) * D + i) * D;          // [chain][basis][vector][D], linear in the basis number
+    if constexpr (OWN) bases_own_deviates<DMAX>(S, batch, active ? g : 0, i, active, v, tq);
+    else {
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? raw[d] : 0.0;
+        for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? raw[d] : 0.0;
+    }
     {   // random_direction (random_utils.F90:276-298)
         const double inrm = 1.0 / sqrt(dot4_same<DMAX, (DMAX <= 16)>(v));
 #pragma unroll
@@ -609,6 +666,11 @@ template <int DMAX>
 __global__ __launch_bounds__(64) void k_bases_packed(PcState S, int nbases) { bases_packed_body<DMAX>(S, nbases); }
 template <int DMAX>
 __global__ __launch_bounds__(64) void k_bases_packed_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX>(pc_many_state(R, blockIdx.y), nbases); }
+// the two steps in one launch: deviates in registers (bases_own_deviates)
+template <int DMAX>
+__global__ __launch_bounds__(64) void k_bases_own(PcState S, unsigned batch, int nbases) { bases_packed_body<DMAX, true>(S, nbases, batch); }
+template <int DMAX>
+__global__ __launch_bounds__(64) void k_bases_own_many(const PcManyRec *R, int nbases) { bases_packed_body<DMAX, true>(pc_many_state(R, blockIdx.y), nbases, (unsigned)R[blockIdx.y].ia[0]); }
 
 // step 1, the deviates: a thread per call of the stream (two positions), no LDS, as wide as the nursery
 // Four stream calls (eight deviates) a thread.  AS241's central branch is two polynomials and a division; the tails (15 % of the
@@ -664,6 +726,17 @@ static int launch_bases_t(const PcState *S, const PcManyRec *dR, int R, unsigned
     const unsigned gdev = (unsigned)((ncalls + 256 * DEVT_CALLS - 1) / (256 * DEVT_CALLS));
     const int perw = 64 / DT, blocksw = (nbases + perw - 1) / perw;
     const size_t shw = sizeof(double) * (size_t)perw * 2 * DM;
+    // (settings.ablate bit 12 / PC_BASES_OWN: NOT the default -- measured with sixteen and sixty-four runs in step, one box, bench.py's process:
+    //  4.51 / 5.66 G evaluations a second against 4.54 / 5.80 by the two kernels.  A third of the round's HBM bytes less (the deviates' 105 MB
+    //  written and 99 MB read back per launch of sixteen runs), 173 us against 91 + 122 -- but the deviates are integer and fp64 issue, not
+    //  bytes, and a kernel whose workgroups live through a whole Gram-Schmidt keeps the main stream's k_apply_pool_many out of the compute
+    //  units where the short-lived workgroups of k_deviates_t let it in: 47 -> 150 us, and the rounds with an update wait for that chain)
+    static const bool own_env = std::getenv("PC_BASES_OWN") != nullptr;
+    if (own_env || (S->ablate & 4096)) {
+        if (dR) hipLaunchKernelGGL((k_bases_own_many<DM>), dim3(blocksw, R), dim3(64), shw, st, dR, nbases);
+        else hipLaunchKernelGGL((k_bases_own<DM>), dim3(blocksw), dim3(64), shw, st, *S, batch, nbases);
+        return 0;
+    }
     if (dR) {
         hipLaunchKernelGGL(k_deviates_t_many, dim3(gdev, R), dim3(256), 0, st, dR, nbases, NC);
         hipLaunchKernelGGL((k_bases_packed_many<DM>), dim3(blocksw, R), dim3(64), shw, st, dR, nbases);

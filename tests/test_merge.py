@@ -639,6 +639,30 @@ def test_runs_in_step_at_every_width(engine, D):
 
 
 @pytest.mark.gpu
+def test_bases_with_their_own_deviates_are_the_same_bases(engine):
+    """settings.ablate bit 12: runs in step whose Gram-Schmidt kernel makes its own deviates (k_bases_own: Philox and AS241 in the
+    registers the vectors live in, the tail arguments of a wavefront finished together) -- every run bit for bit the run it is alone,
+    whose bases come from k_nhats; nDims even and odd (an odd nDims puts every other vector on the second half of a Philox call)."""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    for D, nDer, nlive, nr in ((20, 2, 400, 40), (7, 1, 300, 14), (24, 0, 256, 24), (2, 0, 100, 6), (13, 3, 200, 26)):
+        L, P, keep = api.make_problem("gaussian", D, nDer)
+        def settings(seed, ablate):
+            s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+            s.nlive, s.num_repeats, s.seed, s.ablate = nlive, nr, seed, ablate
+            return s
+        seeds = [700 + D + j for j in range(4)]
+        singles = [api.run(settings(sd, 0), L, P) for sd in seeds]
+        merged, runs = run_repeats(settings(0, 4096), L, P, seeds, max_in_flight=len(seeds))
+        for one, r in zip(singles, runs):
+            assert r["path"]["slice_lane"] > 0 and one["path"]["slice_lane"] == 0
+            for k in ("ndead", "nlike", "niter", "nupdates", "nbatches"):
+                assert one[k] == r[k], (D, k, one[k], r[k])
+            assert one["logZ"] == r["logZ"] and np.array_equal(one["dead"], r["dead"], equal_nan=True) and np.array_equal(one["live"], r["live"], equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_a_failing_run_ends_the_runs_in_step_cleanly(engine):
     """one of several runs in step fails (injected: a device allocation during its setup): pchip_run_repeats reports the failure, gives
     every buffer back, and the next call -- the same seeds -- makes the runs as if nothing had happened"""
