@@ -1072,6 +1072,26 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
         if (__ballot(oB) != 0ull) lB = C.S.logzero; else if (lB > C.S.logzero) C.nlike++;
         return;
     }
+    if (kind != PC_LIKE_RASTRIGIN && kind != PC_LIKE_TWIN_GAUSSIAN) {
+        // any other functor (the quadratic built-ins when settings.ablate bit 0 takes their closed form away): the two points through
+        // like_eval, one call behind the other in the source, their reductions side by side in the schedule
+        // (until round 6 these kinds fell through to the twin-Gaussian sums below: an initial bracket judged by another likelihood never
+        //  stepped out, and the "general functor" figures were those of a run with 3.3 evaluations a slice instead of 4.5)
+        bool outA = false, outB = false;
+        double thA[DPL], thB[DPL];
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const double cA = x0[k] + tA * nh[k], cB = x0[k] + tB * nh[k];
+            if (C.ld.on[k]) { outA |= (cA < 0.0) | (cA > 1.0); outB |= (cB < 0.0) | (cB > 1.0); }
+            thA[k] = C.ld.lo[k] + C.ld.span[k] * cA; thB[k] = C.ld.lo[k] + C.ld.span[k] * cB;
+        }
+        const bool oa = __ballot(outA) != 0ull, ob = __ballot(outB) != 0ull;
+        lA = like_eval<DPL, NROWS, KIND>(C.S, thA, C.ld, C.lane, C.ybuf);
+        lB = like_eval<DPL, NROWS, KIND>(C.S, thB, C.ld, C.lane, C.ybuf);
+        if (oa) lA = C.S.logzero; else if (lA > C.S.logzero) C.nlike++;     // calculate.f90:36-38
+        if (ob) lB = C.S.logzero; else if (lB > C.S.logzero) C.nlike++;
+        return;
+    }
     bool outA = false, outB = false;
     double sA = 0.0, sB = 0.0, s2A = 0.0, s2B = 0.0;
 #pragma unroll

@@ -553,6 +553,35 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,nDer,nlive,nr,kind,box", [(20, 2, 2000, 40, "gaussian", None), (6, 1, 300, 12, "gaussian", (-0.25, 1.5)), (3, 0, 200, 9, "gaussian", None),
+                                                     (24, 2, 300, 24, "gaussian", None), (40, 0, 200, 10, "gaussian", None), (12, 0, 200, 12, "corr_gaussian", None),
+                                                     (70, 0, 150, 8, "corr_gaussian", None)])
+def test_the_quadratic_likelihoods_as_general_functors_are_the_same_run(engine, D, nDer, nlive, nr, kind, box):
+    """settings.ablate bit 0 takes the closed form along the chord away from the built-in Gaussians: every trial point is then a call of the
+    likelihood with a wave reduction, as for any device functor (the path bench.py's value_general_functor times).  The same run: every
+    counter exactly -- the evaluations of the initial bracket, the steps out and the shrinkage are the same points -- and every number to
+    round-off.  (Until round 6 the bracket's two ends of these kinds were summed by another likelihood's formula: no step out was ever
+    made, 3.3 evaluations a slice instead of 4.5 -- and no test looked.)"""
+    api = engine; olib = orc.load()
+    if kind == "gaussian": L, P, keep = api.make_problem("gaussian", D, nDer, *box) if box else api.make_problem("gaussian", D, nDer)
+    else:
+        ic = np.zeros((D, D)); ld = C.c_double()
+        olib.pc_random_invcov(4321, D, C.c_double(0.1), orc.dptr(ic), C.byref(ld))
+        L, P, keep = api.make_problem("corr_gaussian", D, nDer, invcov=ic, mean=np.full(D, 0.5), logdet=ld.value)
+    runs = []
+    for ab in (0, 1):
+        s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=21, batch=0, max_ndead=10 * nlive)
+        s.ablate = ab
+        runs.append(api.run(s, L, P))
+    a, b = runs
+    assert a["nupdates"] >= 3
+    for k in ("ndead", "nlike", "niter", "nbatches", "nupdates"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert abs(a["logZ"] - b["logZ"]) < 1e-10 * max(1.0, abs(a["logZ"])) and abs(a["logZerr"] - b["logZerr"]) < 1e-10
+    assert np.abs(a["dead"] - b["dead"]).max() < 1e-9 * max(1.0, np.abs(a["dead"]).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,nDer,nlive,nr,box", [("rastrigin", 4, 0, 400, 12, (-5.12, 5.12)), ("twin_gaussian", 8, 1, 300, 16, (-1.0, 1.0)),
                                                      ("rastrigin", 2, 0, 600, 6, (-5.12, 5.12)),
                                                      ("rastrigin", 2, 0, 400, 70, (-5.12, 5.12)),          # two phantom-mask words per chain
