@@ -16,7 +16,7 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$o
 python tools/pmc_summary.py "$out/fetch" "$out/write" "profiles/${tag}_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $BENCH (one pass per counter)"
 cp "profiles/${tag}_pmc.json" "profiles/${tag}_kernel_stats.csv" gpurun_out/
 # the same three passes for the path ANY device functor takes: the built-in Gaussian evaluated with one reduction per trial (settings.ablate
-# bit 0 through PC_ABLATE=1: k_slice<.., LEAN = 0>), i.e. without the closed form along the chord that `value` enjoys
+# bit 0 through PC_ABLATE=1: k_slice<.., LEAN = 5>), i.e. without the closed form along the chord that `value` enjoys
 timeout 400 env PC_ABLATE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/gstats" -o p -- $BENCH > "$out/gstats.log" 2>&1
 cp "$(find "$out/gstats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_general_kernel_stats.csv"
 timeout 400 env PC_ABLATE=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/gfetch" -o p -- $BENCH > "$out/gfetch.log" 2>&1
