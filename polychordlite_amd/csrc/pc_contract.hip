@@ -14,6 +14,7 @@
 #include "pc_state.h"
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // block-level helpers (NT threads; NT == 64 needs no barrier traffic)
@@ -262,21 +263,27 @@ __global__ __launch_bounds__(256) void k_nn_lists_many(const PcManyRec *__restri
 // the candidates of a nursery, once: every workgroup of k_nn_lists_d stages its tiles from this array with plain consecutive loads
 // (resolving slot -> occupant -> row per workgroup was a chain of three dependent global loads per staged point: at nDims = 10 a
 // workgroup spent four fifths of its time there)
-__device__ __forceinline__ void nn_gather_body(const PcState &S, int nleft)
+// (use_rank: k_sort_live has just ranked the live set -- the snapshot's points go to the place of their rank, death order, and the empty
+//  slots nowhere; k_nn_lists_d then finds the points that cannot die before a chain is looked at as ONE range.  Else: slot order.)
+__device__ __forceinline__ void nn_gather_body(const PcState &S, int nleft, int use_rank)
 {
     const int D = S.D, nr = S.nr, nT = S.nT, Ncap = S.Ncap;
     const int e = blockIdx.x * 256 + threadIdx.x, n = (Ncap + nleft) * D;
     if (e >= n) return;
     const int gi = e / D, d = e - gi * D;
-    int code = PC_NN_NONE; double v = 0.0;
+    int code = PC_NN_NONE, pos = gi; double v = 0.0;
     if (gi < Ncap) {
-        if (S.live_cluster[gi] >= 0) { code = gi; const int src = S.slot_src[gi]; v = (src >= 0) ? S.babies[((size_t)src * nr + (nr - 1)) * nT + d] : S.live[(size_t)gi * nT + d]; }
+        if (S.live_cluster[gi] >= 0) {
+            code = gi; const int src = S.slot_src[gi]; v = (src >= 0) ? S.babies[((size_t)src * nr + (nr - 1)) * nT + d] : S.live[(size_t)gi * nT + d];
+            if (use_rank) pos = S.nn_code[(size_t)Ncap + S.B + gi];
+        } else if (use_rank) return;
+        if (pos < 0 || pos >= Ncap) return;           // (a slot the sort did not see: not a candidate of this nursery)
     } else { const int c = gi - Ncap; code = -(1 + c); v = S.babies[((size_t)c * nr + (nr - 1)) * nT + d]; }
-    S.nn_pts[e] = v;
-    if (d == 0) S.nn_code[gi] = code;
+    S.nn_pts[(size_t)pos * D + d] = v;
+    if (d == 0) S.nn_code[pos] = code;
 }
-__global__ __launch_bounds__(256) void k_nn_gather(PcState S, int nleft) { nn_gather_body(S, nleft); }
-__global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R) { const PcManyView r = pc_many_view(R, blockIdx.y); nn_gather_body(r.S, r.ia[1]); }
+__global__ __launch_bounds__(256) void k_nn_gather(PcState S, int nleft, int use_rank) { nn_gather_body(S, nleft, use_rank); }
+__global__ __launch_bounds__(256) void k_nn_gather_many(const PcManyRec *__restrict__ R, int use_rank) { const PcManyView r = pc_many_view(R, blockIdx.y); nn_gather_body(r.S, r.ia[1], use_rank); }
 
 #define NND_SC 16                                   /* at most this many scanners per pair of babies */
 // Round 4: most of the candidates cannot die before the chain is looked at.  The deaths of a nursery take the snapshot's points in
@@ -296,22 +303,32 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
     const int w = blockIdx.x;                         // chain, w < nleft = entries still in the nursery
     double *pts = (double *)smem;                     // [tile_pts][DP]
     int *pcode = (int *)(pts + (size_t)tile_pts * DP);   // [tile_pts] code of each staged point, PC_NN_NONE = skip
-    int *psafe = pcode + tile_pts;                    // [tile_pts] 1: certainly alive when this chain is consumed
     double *md = (double *)smem;                      // [256][2][PC_NN_K] merge buffer: over the tile, once the last one has been scanned
     int *mc = (int *)(md + 256 * 2 * PC_NN_K);        // [256][2][PC_NN_K]
-    double *msd = (double *)smem;                     // [256][2] the scanners' nearest safe points (before the lists are laid down)
+    double *msd = (double *)smem;                     // [256][2] the scanners' nearest safe points (between the two scans)
     int *msc = (int *)(msd + 256 * 2);                // [256][2]
     if (w == 0) {                                     // liveness bookkeeping starts now
         for (int s = tid; s < Ncap; s += 256) S.nn_slot_owner[s] = -1;
         for (int c = tid; c < S.B; c += 256) S.nn_chain_slot[c] = -1;
     }
+#ifdef NND_DBG
+    long long nd_t[5] = {0, 0, 0, 0, 0}; long long nd_c = clock64(); const long long nd_start = nd_c;
+#define NND_MARK(i) { const long long t_ = clock64(); nd_t[i] += t_ - nd_c; nd_c = t_; }
+#else
+#define NND_MARK(i)
+#endif
     const int nc = S.ctl->ncluster;
     double Lg0 = S.logLp[0];
     for (int c = 1; c < nc; ++c) Lg0 = fmin(Lg0, S.logLp[c]);
     const double *blog = S.baby_logL + (size_t)w * nr;
     const int ncand = nleft - 1 - w;                  // chains w+1 .. nleft-1 are consumed before w
-    const int npts = Ncap + ncand;
-    const int *nn_rank = S.nn_code + (size_t)Ncap + S.B;      // [Ncap] rank of a slot's point in the snapshot's death order (k_sort_live)
+    // The gathered array (k_nn_gather).  use_rank: the snapshot's points stand in their death order (k_sort_live), n of them: the first
+    // min(ncand, n) may be dead by the time this chain is looked at, the others cannot.  Without a sorted order at hand: slot order, all
+    // of them uncertain (empty slots carry PC_NN_NONE).  Behind them, at Ncap, the last babies of the nursery's chains.
+    const int *nn_rank = S.nn_code + (size_t)Ncap + S.B;
+    const int nsnap = use_rank ? nn_rank[Ncap] : Ncap;
+    const int nunc = use_rank ? (ncand < nsnap ? ncand : nsnap) : Ncap;      // uncertain snapshot entries: [0, nunc)
+    const int nsafe = nsnap - nunc;                                          // safe ones: [nunc, nsnap)
     const int npair = (nr + 1) / 2;
     const int PG = npair < 256 ? npair : 256;         // pairs per pass
     const int nscan = (256 / PG) < NND_SC ? (256 / PG) : NND_SC;
@@ -330,7 +347,7 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
         double bda[PC_NN_K], bdb[PC_NN_K]; int bca[PC_NN_K], bcb[PC_NN_K];
 #pragma unroll
         for (int k = 0; k < PC_NN_K; ++k) { bda[k] = PC_HUGE; bdb[k] = PC_HUGE; bca[k] = PC_NN_NONE; bcb[k] = PC_NN_NONE; }
-        double sa = PC_HUGE, sb = PC_HUGE; int sca = PC_NN_NONE, scb = PC_NN_NONE;      // nearest safe point of this scanner
+        double sa = PC_HUGE, sb = PC_HUGE; int sca = PC_NN_NONE, scb = PC_NN_NONE;      // nearest safe point: this scanner's, then the pair's
         auto insert = [&](double (&bd)[PC_NN_K], int (&bc)[PC_NN_K], double d2, int code) __attribute__((always_inline)) {
             double cd = d2; int cc = code;                        // sorted insertion, registers only (the caller has compared with the last entry)
 #pragma unroll
@@ -341,66 +358,84 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
                 cd = td; cc = tc;
             }
         };
-        auto take = [&](double a0, double b0, int c0, int safe) __attribute__((always_inline)) {
-            if (c0 == PC_NN_NONE) return;
-            if (safe) {
-                if (a0 < sa) { sa = a0; sca = c0; }
-                if (b0 < sb) { sb = b0; scb = c0; }
-            } else {
-                if (minea && a0 < bda[PC_NN_K - 1] && a0 < sa) insert(bda, bca, a0, c0);
-                if (mineb && b0 < bdb[PC_NN_K - 1] && b0 < sb) insert(bdb, bcb, b0, c0);
+        // one scan over `count` candidates, entry v of it = entry first + v of the gathered array (v < split) or the baby of chain
+        // w + 1 + (v - split).  SAFE: a running minimum a point; else a sorted insertion for the few that beat the pair's nearest safe point.
+        auto scan = [&](auto safe_tag, int first, int split, int count) __attribute__((always_inline)) {
+            constexpr bool SAFE = decltype(safe_tag)::value;
+            // (no early way out for an empty slot: with the sums used only inside a branch the compiler moved each of them INTO it, one
+            //  dependent chain behind the other -- three times the latency of the four side by side)
+            auto take = [&](double a0, double b0, int c0) __attribute__((always_inline)) {
+                const bool is = c0 != PC_NN_NONE;
+                if constexpr (SAFE) {
+                    const bool ua = is & (a0 < sa), ub = is & (b0 < sb);
+                    sa = ua ? a0 : sa; sca = ua ? c0 : sca;
+                    sb = ub ? b0 : sb; scb = ub ? c0 : scb;
+                } else {
+                    if (is & minea & (a0 < bda[PC_NN_K - 1]) & (a0 < sa)) insert(bda, bca, a0, c0);
+                    if (is & mineb & (b0 < bdb[PC_NN_K - 1]) & (b0 < sb)) insert(bdb, bcb, b0, c0);
+                }
+            };
+            for (int t0 = 0; t0 < count; t0 += tile_pts) {
+                const int tn = min(tile_pts, count - t0);
+                __syncthreads();
+                NND_MARK(2)
+                for (int q = tid; q < tn; q += 256) { const int v = t0 + q; pcode[q] = S.nn_code[v < split ? first + v : Ncap + w + 1 + (v - split)]; }
+                for (int e = tid; e < tn * D; e += 256) {
+                    const int q = e / D, d = e - q * D, v = t0 + q;
+                    pts[(size_t)q * DP + d] = S.nn_pts[(size_t)(v < split ? first + v : Ncap + w + 1 + (v - split)) * D + d];
+                }
+                __syncthreads();
+                NND_MARK(1)
+                if (minea || mineb) {
+                    int q = p;
+                    for (; q + nscan < tn; q += 2 * nscan) {          // two points at a time: four sums in flight
+                        const int c0 = pcode[q], c1 = pcode[q + nscan];
+                        const double *y0 = pts + (size_t)q * DP, *y1 = pts + (size_t)(q + nscan) * DP;
+                        double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            const double u0 = y0[d], u1 = y1[d];
+                            const double ta0 = xa[d] - u0, tb0 = xb[d] - u0, ta1 = xa[d] - u1, tb1 = xb[d] - u1;
+                            a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); a1 = fma(ta1, ta1, a1); b1 = fma(tb1, tb1, b1);
+                        }
+                        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));      // (the four sums are made HERE, side by side)
+                        take(a0, b0, c0); take(a1, b1, c1);
+                    }
+                    if (q < tn) {
+                        const int c0 = pcode[q];
+                        const double *y0 = pts + (size_t)q * DP;
+                        double a0 = 0.0, b0 = 0.0;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) { const double u0 = y0[d]; const double ta0 = xa[d] - u0, tb0 = xb[d] - u0; a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); }
+                        take(a0, b0, c0);
+                    }
+                }
             }
         };
-        for (int t0 = 0; t0 < npts; t0 += tile_pts) {
-            const int tn = min(tile_pts, npts - t0);
-            __syncthreads();
-            // point t0 + q of this chain's candidates = entry t0 + q of the gathered array, the chains up to w skipped
-            for (int q = tid; q < tn; q += 256) {
-                const int gi = t0 + q;
-                pcode[q] = S.nn_code[gi < Ncap ? gi : gi + w + 1];
-                psafe[q] = (use_rank && gi < Ncap && nn_rank[gi] >= ncand) ? 1 : 0;
-            }
-            for (int e = tid; e < tn * D; e += 256) {
-                const int q = e / D, d = e - q * D, gi = t0 + q;
-                pts[(size_t)q * DP + d] = S.nn_pts[(size_t)(gi < Ncap ? gi : gi + w + 1) * D + d];
-            }
-            __syncthreads();
-            if (minea || mineb) {
-                int q = p;
-                for (; q + nscan < tn; q += 2 * nscan) {          // two points at a time: four sums in flight
-                    const int c0 = pcode[q], c1 = pcode[q + nscan], f0 = psafe[q], f1 = psafe[q + nscan];
-                    const double *y0 = pts + (size_t)q * DP, *y1 = pts + (size_t)(q + nscan) * DP;
-                    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const double u0 = y0[d], u1 = y1[d];
-                        const double ta0 = xa[d] - u0, tb0 = xb[d] - u0, ta1 = xa[d] - u1, tb1 = xb[d] - u1;
-                        a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); a1 = fma(ta1, ta1, a1); b1 = fma(tb1, tb1, b1);
-                    }
-                    take(a0, b0, c0, f0); take(a1, b1, c1, f1);
-                }
-                if (q < tn) {
-                    const int c0 = pcode[q], f0 = psafe[q];
-                    const double *y0 = pts + (size_t)q * DP;
-                    double a0 = 0.0, b0 = 0.0;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) { const double u0 = y0[d]; const double ta0 = xa[d] - u0, tb0 = xb[d] - u0; a0 = fma(ta0, ta0, a0); b0 = fma(tb0, tb0, b0); }
-                    take(a0, b0, c0, f0);
-                }
-            }
-        }
+        // Round 6: the safe points FIRST.  The list a walk needs is the uncertain candidates nearer than the pair's nearest safe point, and
+        // then that point; while safe and uncertain candidates came mixed, a scanner measured an uncertain one against the nearest safe
+        // point IT had seen so far, and nearly every iteration some lane of the wave made a sorted insertion -- eight compare-and-swap
+        // steps on two register arrays, four fifths of the scan's cycles at nDims = 10.  Now the snapshot stands in death order: the
+        // safe ones are a range, scanned first with a running minimum; the scanners' minima meet; and of the uncertain candidates
+        // only those nearer than the PAIR's nearest safe point are inserted -- a handful per baby.
+        scan(std::true_type{}, nunc, nsafe, nsafe);
         // the pair's nearest safe point: the scanners' minima meet (equal distances -- exact duplicates only -- go to the lower scanner)
         __syncthreads();                              // (the buffers lie over the tile)
+        NND_MARK(2)
         msd[tid * 2 + 0] = sa; msc[tid * 2 + 0] = sca; msd[tid * 2 + 1] = sb; msc[tid * 2 + 1] = scb;
         __syncthreads();
         double fs[2] = {PC_HUGE, PC_HUGE}; int fc[2] = {PC_NN_NONE, PC_NN_NONE};
-        if (act && p == 0) {
+        if (act) {
+            const int t0p = tid - p;                  // the pair's first scanner
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                for (int q = 0; q < nscan; ++q) { const double v = msd[(tid + q) * 2 + h]; if (v < fs[h]) { fs[h] = v; fc[h] = msc[(tid + q) * 2 + h]; } }
+                for (int q = 0; q < nscan; ++q) { const double v = msd[(t0p + q) * 2 + h]; if (v < fs[h]) { fs[h] = v; fc[h] = msc[(t0p + q) * 2 + h]; } }
         }
+        sa = fs[0]; sb = fs[1];
+        scan(std::false_type{}, 0, nunc, nunc + ncand);
         // merge the partial lists of a baby: each is sorted, nscan-way pick by the pair's first scanner, up to the nearest safe point
         __syncthreads();
+        NND_MARK(2)
 #pragma unroll
         for (int k = 0; k < PC_NN_K; ++k) {
             md[(tid * 2 + 0) * PC_NN_K + k] = bda[k]; mc[(tid * 2 + 0) * PC_NN_K + k] = bca[k];
@@ -439,7 +474,14 @@ __device__ __forceinline__ void nn_lists_d_body(const PcState &S, int nleft, int
             }
         }
         __syncthreads();
+        NND_MARK(3)
     }
+#ifdef NND_DBG
+    if (w == 0 && tid == 0) {      // (chain 0: the most candidates) set-up / staging / scanning / merges, and the whole kernel in nn_fallbacks
+        for (int x = 0; x < 4; ++x) atomicAdd((unsigned long long *)&S.ctl->gen_cyc[x], (unsigned long long)nd_t[x]);
+        atomicAdd((unsigned long long *)&S.ctl->nn_fallbacks, (unsigned long long)(clock64() - nd_start));
+    }
+#endif
 }
 template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d(PcState S, int nleft, int tile_pts, int use_rank) { nn_lists_d_body<D>(S, nleft, tile_pts, use_rank); }
 template <int D> __global__ __launch_bounds__(256) void k_nn_lists_d_many(const PcManyRec *__restrict__ R, int tile_pts, int use_rank)
@@ -452,9 +494,10 @@ static size_t nn_lists_d_lds(const PcState *S, int &tile)
 {
     const int DP = S->D | 1;
     const size_t merge = (sizeof(double) + sizeof(int)) * 256 * 2 * PC_NN_K;      // 48 KB, over the tile: three workgroups to a compute unit
-    tile = (int)((merge - 64) / (sizeof(double) * DP + 2 * sizeof(int)));
+    tile = (int)((merge - 64) / (sizeof(double) * DP + sizeof(int)));
     tile = tile < 32 ? 32 : (tile > 1024 ? 1024 : tile);
-    const size_t t = (sizeof(double) * DP + 2 * sizeof(int)) * (size_t)tile;
+    tile &= ~1;                                       // (the codes lie behind tile x DP doubles: eight-byte aligned either way)
+    const size_t t = (sizeof(double) * DP + sizeof(int)) * (size_t)tile;
     return (t > merge ? t : merge) + 64;
 }
 // nDims <= 32: the register kernel; dR == null: one run
@@ -465,8 +508,8 @@ static int nn_lists_d_dispatch(const PcState *S, const PcManyRec *dR, int R, int
     int tile;
     const size_t sh = nn_lists_d_lds(S, tile);
     if (!S->nn_pts) return 1;
-    if (dR) hipLaunchKernelGGL(k_nn_gather_many, dim3(((S->Ncap + nleft) * S->D + 255) / 256, R), dim3(256), 0, st, dR);
-    else hipLaunchKernelGGL(k_nn_gather, dim3(((S->Ncap + nleft) * S->D + 255) / 256), dim3(256), 0, st, *S, nleft);
+    if (dR) hipLaunchKernelGGL(k_nn_gather_many, dim3(((S->Ncap + nleft) * S->D + 255) / 256, R), dim3(256), 0, st, dR, use_rank);
+    else hipLaunchKernelGGL(k_nn_gather, dim3(((S->Ncap + nleft) * S->D + 255) / 256), dim3(256), 0, st, *S, nleft, use_rank);
     switch (S->D) {
 #define PC_NND(n) case n: \
         if (dR) { pc_need_dyn_lds((const void *)k_nn_lists_d_many<n>, sh); \

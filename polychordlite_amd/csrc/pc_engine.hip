@@ -968,7 +968,7 @@ struct Engine {
         S.nn_list = nullptr; S.nn_slot_owner = nullptr; S.nn_chain_slot = nullptr; S.nn_pts = nullptr; S.nn_code = nullptr; S.nn_valid = 0;
         if (c.do_clustering) {      // candidate lists of the nearest-cluster search (k_nn_lists)
             S.nn_list = dalloc<int>((size_t)B * nr * PC_NN_K); S.nn_slot_owner = dalloc<int>(Ncap); S.nn_chain_slot = dalloc<int>(B);
-            S.nn_pts = dalloc<double>((size_t)(Ncap + B) * D); S.nn_code = dalloc<int>((size_t)2 * Ncap + B);      // (codes of the candidates, then the ranks of the live points: k_sort_live)
+            S.nn_pts = dalloc<double>((size_t)(Ncap + B) * D); S.nn_code = dalloc<int>((size_t)2 * Ncap + B + 64);      // (codes of the candidates, then the ranks of the live points and their number: k_sort_live)
         }
         S.nhat = dalloc<double>((size_t)B * nr * D); S.nhat_w = dalloc<double>((size_t)B * nr);
         static const bool ms_off = std::getenv("PC_MS_PRE_OFF") != nullptr;

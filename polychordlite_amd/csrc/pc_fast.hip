@@ -91,7 +91,12 @@ __device__ __forceinline__ void sort_live_body(const PcState &S, int npow2)
     // candidates are certainly alive when a chain is looked at (behind the candidates' codes: [Ncap + B] codes, [Ncap] ranks)
     if (S.nn_code) {
         int *rank = S.nn_code + (size_t)S.Ncap + S.B;
-        for (int i = tid; i < npow2; i += 1024) { const int sl = ks[i]; if (sl >= 0 && sl < S.Ncap) rank[sl] = (kv[i] < PC_HUGE) ? i : 0x7fffffff; }
+        for (int i = tid; i < npow2; i += 1024) {
+            const int sl = ks[i]; if (sl >= 0 && sl < S.Ncap) rank[sl] = (kv[i] < PC_HUGE) ? i : 0x7fffffff;
+            // the number of live points, behind the ranks (free slots sort last)
+            if (kv[i] < PC_HUGE && (i + 1 == npow2 || !(kv[i + 1] < PC_HUGE))) rank[S.Ncap] = i + 1;
+            if (i == 0 && !(kv[0] < PC_HUGE)) rank[S.Ncap] = 0;
+        }
     }
 }
 __global__ __launch_bounds__(1024) void k_sort_live(PcState S, int npow2) { sort_live_body(S, npow2); }
