@@ -86,20 +86,16 @@ def random_correlated_gaussian(D, seed=12345, sigma0=0.1):
     return Q @ np.diag(sig ** -2) @ Q.T, np.full(D, 0.5), float(2.0 * np.log(sig).sum())
 
 
-# ---- latency model of the dominant kernel (the path is latency bound, not bandwidth bound: SURVEY 8d).  k_slice runs one
-# wavefront per chain with one cube coordinate per lane; a slice is a chain of DEPENDENT fp64 operations, and on a wave that has
-# its SIMD to itself a dependent fp64 operation issues every 32 cycles (tools/ubench.hip on this hardware: fma 32, LDS round
-# trip 70, exp 140, log 480, div 100 cycles at 2.4 GHz; profiles/r04_slice_cycles.json).  Dependent operations per slice of the
-# closed-form Gaussian chord (pc_sample.hip k_slice), section by section:
-SLICE_CHAIN = {  # section: (dependent fp64 ops, LDS round trips, what)
-    "take_over_and_philox": (2, 1, "next direction from LDS; one Philox4x32-10 call per four slices (10 rounds x ~3 integer ops / 4)"),
-    "coefficients_and_initial_bracket": (19, 0, "z = (lo + span x - mu)/sigma: 3; squares: 1; three wave sums side by side (4 DPP row steps + 2 cross-row): 6; "
-                                                "bracket ends: 2; closed form qnorm - (qa + t (2 qb + t qc))/2: 5; cube test: 2"),
-    "stepping_out": (8, 0, "PER EVALUATION beyond the bracket: position 1, closed form 5, cube test 2"),
-    "shrinkage": (21, 0, "four speculative positions, each 3 behind the previous: 12; closed form: 5; first-accepted select: 4"),
-    "stores": (2, 1, "cube -> theta: 2; LDS hop for the derived parameters' row"),
-}
-DEP_FP64_CYCLES, LDS_CYCLES, PHILOX_CYCLES_PER_SLICE, CLOCK_MHZ = 32.0, 70.0, 60.0, 2400.0
+# ---- issue model of the dominant kernel (the path is latency bound, not bandwidth bound: SURVEY 8d).  k_slice runs one wavefront per
+# chain, one wavefront per SIMD, one cube coordinate per lane.  A wavefront that has its SIMD to itself issues one vector instruction every
+# 5-6 cycles WHETHER OR NOT it depends on the one before (tools/dev/ubench_fp64.hip: dependent fma 5.8, eight independent chains 5.2 per
+# operation; rounds 2-5 quoted "32 cycles per dependent fp64 operation" from a loop of ONE operation -- 24 of them the loop's own -- and built
+# a dependent-chain model on it: withdrawn).  So a launch lasts as long as its longest wavefront has instructions:
+#     floor = instructions per wavefront (rocprofv3 SQ_INSTS_*: profiles/rNN_issue.json) x the single-wave issue interval,
+# against the wavefront's measured cycles (SQ_WAVE_CYCLES, in units of four clocks; and s_memtime inside the kernel, section by section).
+# What closes the gap is fewer instructions a slice, not shorter dependence chains or more bytes.
+ISSUE_INTERVAL_CYCLES, CLOCK_MHZ = 5.8, 2400.0
+ISSUE_FILES = ("r06_issue.json",)
 SLICE_CYCLE_FILES = ("r06_slice_cycles.json", "r05_slice_cycles.json", "r04_slice_cycles.json", "r03_slice_cycles.json")
 PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")
 
@@ -119,23 +115,28 @@ def committed_record(names, need):
 
 
 def latency_model(runs, kern):
-    """modelled minimum cycles per slice (dependent-operation count x measured single-wave latencies) next to the measured ones"""
+    """the issue floor of k_slice (instructions per wavefront x the interval at which one wavefront issues) next to its measured cycles"""
     ks = [k for k in kern if k["kernel"] == "k_slice"]
     nr = 40
     evals_per_slice = sum(r["nlike"] for r in runs) / max(sum(r["niter"] for r in runs), 1) / nr
-    e_out = max(evals_per_slice - 2.0 - 1.54, 0.0)        # 2 = the bracket's ends; 1.54 = counted shrink trials per slice (measured: slice_cycles.json)
-    model = {}
-    for name, (dep, lds, what) in SLICE_CHAIN.items():
-        n = dep * (e_out if name == "stepping_out" else 1.0)
-        model[name] = n * DEP_FP64_CYCLES + lds * LDS_CYCLES + (PHILOX_CYCLES_PER_SLICE if name == "take_over_and_philox" else 0.0)
-    out = {"unit": "shader cycles per slice (one wavefront = one chain, 2.4 GHz)", "model_min_by_section": model, "model_min": sum(model.values()),
-           "dependent_fp64_cycles": DEP_FP64_CYCLES, "lds_round_trip_cycles": LDS_CYCLES, "evaluations_per_slice": evals_per_slice,
-           "chain": {k: v[2] for k, v in SLICE_CHAIN.items()}}
-    m, src = committed_record(SLICE_CYCLE_FILES, ("cycles_per_slice", "cycles_per_slice_total"))
+    out = {"unit": "shader cycles per wavefront (= chain) per launch, 2.4 GHz", "issue_interval_cycles": ISSUE_INTERVAL_CYCLES,
+           "issue_interval_source": "tools/dev/ubench_fp64.hip: one wavefront, sixteen operations to a loop iteration: dependent fp64 fma 5.8 cycles an operation, "
+                                    "eight independent chains 5.2 -- issue bound either way", "evaluations_per_slice": evals_per_slice, "slices_per_launch": nr}
+    rec, src = committed_record(ISSUE_FILES, ("kernels",))
+    k = next((v for n, v in (rec["kernels"] if rec else {}).items() if n.startswith("k_slice")), None)
+    if k and k.get("SQ_WAVES"):
+        w = k["SQ_WAVES"]
+        ins = {c[9:].lower(): k.get(c, 0.0) / w for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")}
+        out["instructions_per_wavefront"] = ins
+        out["instructions_per_slice"] = sum(ins.values()) / nr               # (prologue and epilogue included: ~15 % of a launch's instructions)
+        out["model_min"] = sum(ins.values()) * ISSUE_INTERVAL_CYCLES
+        out["measured"] = 4.0 * k["SQ_WAVE_CYCLES"] / w                      # (the counter ticks every four clocks)
+        out["frac_of_model"] = out["model_min"] / out["measured"]
+        out["measured_source"] = "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / _SALU / _LDS / _SMEM / _VMEM / SQ_WAVES / SQ_WAVE_CYCLES, one pass each, tools/collect_issue_profile.sh)" % src
+    m, src2 = committed_record(SLICE_CYCLE_FILES, ("cycles_per_slice", "cycles_per_slice_total"))
     if m:
-        out["measured_by_section"] = m["cycles_per_slice"]; out["measured"] = m["cycles_per_slice_total"]
-        out["measured_source"] = "profiles/%s (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)" % src
-        out["frac_of_model"] = out["model_min"] / m["cycles_per_slice_total"]
+        out["slice_sections_cycles"] = m["cycles_per_slice"]; out["slice_cycles"] = m["cycles_per_slice_total"]
+        out["slice_sections_source"] = "profiles/%s (s_memtime inside k_slice, SLICE_DBG build, tools/collect_slice_dbg.sh)" % src2
     if ks:
         out["launch_cycles_per_slice_this_run"] = ks[0]["avg_launch_us"] * CLOCK_MHZ / nr      # whole launch / slices: includes seed choice, shuffle, whitening, derived parameters
     return out

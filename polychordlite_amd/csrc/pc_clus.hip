@@ -27,8 +27,8 @@
 //   * nothing is stored to HBM inside the loop (on gfx9 a wait for a prefetched load also waits for every store issued
 //     before it): plan records, phantom masks and slot sources collect in LDS and leave together.
 //
-// ONE wavefront runs the loop -- no barrier inside it, and on a single wave a dependent fp64 operation costs ~32 cycles, an
-// exp or a division a dozen of those: the loop is written so that what is left of them sits off the chain of decisions.
+// ONE wavefront runs the loop -- no barrier inside it, and a single wave issues an instruction every 5-6 cycles (tools/dev/ubench_fp64.hip; "32 cycles a dependent fp64
+// operation" until round 6 was a loop's own overhead), an exp or a division costs a hundred: the loop is written so that what is left of them sits off the chain of decisions.
 // The other three waves of the workgroup stage the state before and write it back after.  Anything outside this kernel's
 // envelope (dynamic nlive, the reference's list rule of the sequential-stream test mode, kill-off, live sets or cluster
 // counts beyond the LDS) stays with k_consume, which is also the arbiter: settings.ablate bit 5 sends every launch there,

@@ -255,8 +255,7 @@ __global__ __launch_bounds__(256) void k_nn_lists_many(const PcManyRec *__restri
 // device in step it is the heaviest kernel of a round (1.6 ms for sixteen runs at BASELINE configs[3]).  Here a thread holds TWO
 // babies' coordinates in registers (the loop over d is unrolled: one instantiation per nDims), the pairs of a chain share the
 // workgroup with as many scanners each as fit (num_repeats 40: 20 pairs x 12 scanners = 240 threads), a staged point is read
-// from LDS once for two babies, and a thread walks two points at a time (four independent sums in flight: a dependent fp64
-// operation issues every 32 cycles on a wave).  The same sums in the same order (d ascending, fused multiply-add of the
+// from LDS once for two babies, and a thread walks two points at a time (four sums side by side).  The same sums in the same order (d ascending, fused multiply-add of the
 // difference), the same lists: ties between different points -- exact duplicates only -- go to the lower scanner, then the
 // lower point, as above.
 // ------------------------------------------------------------------------------------------
@@ -1709,7 +1708,7 @@ __global__ __launch_bounds__(256) void k_cov_partial(PcState S, int nrows, int n
         __syncthreads();
         for (int p = tid; p < D * D; p += 256) {
             const int a = p / D, b = p % D;
-            // rows i, i+1, i+2, i+3 on four accumulators (a 256-deep dependent FMA chain costs ~32 cycles per row)
+            // rows i, i+1, i+2, i+3 on four accumulators (four independent rows to a pass)
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int i = 0;
             for (; i + 3 < n; i += 4) {

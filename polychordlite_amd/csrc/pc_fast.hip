@@ -3,7 +3,8 @@
 // Same decisions as k_consume (replace_point / delete_outermost_point / update_evidence /
 // more_samples_needed, src/polychord/run_time_info.f90:716-817,211-296, nested_sampling.F90:514-543),
 // organised around what the hardware can do (single-wave latencies measured with tools/ubench.hip:
-// dependent fp64 op 32 cycles, exp 140, log 480, LDS round trip 70):
+// an instruction every 5-6 cycles on a wave alone on its SIMD, exp ~120, log ~460, LDS round trip 70 -- round 6's numbers;
+// "dependent fp64 op 32 cycles" in earlier rounds included 24 cycles of the measuring loop):
 //
 //   k_sort_live     bitonic sort of the live slots by (logL, list position) in LDS: deaths happen in
 //                   ascending logL, so the serial pass below only walks a pointer.

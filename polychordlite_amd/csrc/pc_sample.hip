@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #endif
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) v[d] = (active && d < D) ? G[(size_t)i * D + d] : 0.0;
-    // dot products run on four partial sums: a dependent fp64 add costs ~32 cycles, a 20-term serial dot 640
+    // dot products run on four partial sums (the summation order every other kernel of these bases reproduces)
 #define PC_DOT4(RES, A, B) { double p0_ = 0.0, p1_ = 0.0, p2_ = 0.0, p3_ = 0.0; \
         _Pragma("unroll") for (int d = 0; d < DMAX; d += 4) { \
             p0_ += (A)[d] * (B)[d]; p1_ += (A)[d + 1] * (B)[d + 1]; p2_ += (A)[d + 2] * (B)[d + 2]; p3_ += (A)[d + 3] * (B)[d + 3]; } \

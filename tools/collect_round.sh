@@ -22,6 +22,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$o
 python tools/pmc_summary.py "$out/fetch" "$out/write" "gpurun_out/${tag}_concurrent16_pmc.json" "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- $CMD (one pass per counter)"
 tail -3 "$out/stats.log"
 bash tools/collect_slice_dbg.sh $tag > /dev/null 2>> gpurun_out/${tag}_collect_c2.log
+bash tools/collect_issue_profile.sh $tag > /dev/null 2>> gpurun_out/${tag}_collect_c2.log     # instruction counters of the metric configuration's kernels, single-wave issue intervals
 # the other BASELINE configurations through the same harness: their own line each (with the CPU baseline, the live PMC pass and -- c3, c4:
 # what north_star shards -- sixteen runs in step + the exchange as roofline.in_step_multi)
 for w in c3 c4 c5; do timeout 900 python bench.py --workload $w --steps 3 --warmup 1 --concurrent "" --full-out gpurun_out/${tag}_bench_${w}_full.json > gpurun_out/${tag}_bench_$w.json 2> /dev/null; done

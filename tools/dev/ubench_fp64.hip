@@ -1,35 +1,46 @@
+// tools/dev/ubench_fp64.hip -- developer micro-benchmark: fp64 latency and issue rate of ONE wavefront on MI355X, sixteen operations to a loop
+// iteration (tools/ubench.hip's "fma 32 cycles" is one operation plus ~24 cycles of loop: not a latency).  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#define R16(x) x x x x x x x x x x x x x x x x
 __global__ void k(double *out, long long *cyc, int n)
 {
     const int lane = threadIdx.x;
     double x0 = 1.0 + lane * 1e-9, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
-    long long t0 = clock64();
-    for (int i = 0; i < n; ++i) { x0 = fma(x0, 1.0000001, 1e-9); }
-    long long t1 = clock64();
-    for (int i = 0; i < n; ++i) { x0 = fma(x0, 1.0000001, 1e-9); x1 = fma(x1, 1.0000001, 1e-9); }
-    long long t2 = clock64();
-    for (int i = 0; i < n; ++i) { x0 = fma(x0, 1.0000001, 1e-9); x1 = fma(x1, 1.0000001, 1e-9); x2 = fma(x2, 1.0000001, 1e-9); x3 = fma(x3, 1.0000001, 1e-9); }
-    long long t3 = clock64();
-    for (int i = 0; i < n; ++i) { x0 = fma(x0, 1.0000001, 1e-9); x1 = fma(x1, 1.0000001, 1e-9); x2 = fma(x2, 1.0000001, 1e-9); x3 = fma(x3, 1.0000001, 1e-9);
-                                  x4 = fma(x4, 1.0000001, 1e-9); x5 = fma(x5, 1.0000001, 1e-9); x6 = fma(x6, 1.0000001, 1e-9); x7 = fma(x7, 1.0000001, 1e-9); }
-    long long t4 = clock64();
-    float f0 = 1.0f + lane * 1e-6f, f1 = f0 + 1;
-    for (int i = 0; i < n; ++i) { f0 = fmaf(f0, 1.0000001f, 1e-9f); }
-    long long t5 = clock64();
-    for (int i = 0; i < n; ++i) { x0 = x0 + 1e-9; x1 = x1 + 1e-9; x2 = x2 + 1e-9; x3 = x3 + 1e-9; }
-    long long t6 = clock64();
-    out[blockIdx.x * 64 + lane] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f0 + f1;
-    if (lane == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; cyc[2] = t3 - t2; cyc[3] = t4 - t3; cyc[4] = t5 - t4; cyc[5] = t6 - t5; }
+    const double c = 1.0000001, d = 1e-9;
+    long long t[12]; int q = 0;
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = fma(x0, c, d);) }                                        // dependent fma
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = x0 + d;) }                                               // dependent add
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = x0 * c;) }                                               // dependent mul
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = fma(x0, c, d); x1 = fma(x1, c, d);) }                    // 2 chains
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = fma(x0, c, d); x1 = fma(x1, c, d); x2 = fma(x2, c, d); x3 = fma(x3, c, d);) }      // 4 chains
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = fma(x0, c, d); x1 = fma(x1, c, d); x2 = fma(x2, c, d); x3 = fma(x3, c, d); x4 = fma(x4, c, d); x5 = fma(x5, c, d); x6 = fma(x6, c, d); x7 = fma(x7, c, d);) }
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = x0 + d; x1 = x1 + d; x2 = x2 + d; x3 = x3 + d;) }        // 4 independent adds
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = (x0 < x1) ? x0 + d : x1;) }                              // compare + select chain
+    t[q++] = clock64();
+    for (int i = 0; i < n; ++i) { R16(x0 = x0 + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x0), 3), __builtin_amdgcn_readlane(__double2loint(x0), 3));) }   // readlane + add chain
+    t[q++] = clock64();
+    out[blockIdx.x * blockDim.x + lane] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    if (lane == 0 && blockIdx.x == 0) for (int i = 0; i + 1 < q; ++i) cyc[i] = t[i + 1] - t[i];
 }
 int main()
 {
-    double *out; long long *cyc; hipMalloc(&out, 64 * 8 * 4096); hipMalloc(&cyc, 64);
-    const int n = 20000;
-    for (int waves = 1; waves <= 4; waves *= 2) {
-        hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, out, cyc, n); hipDeviceSynchronize();
-        long long c[8]; hipMemcpy(c, cyc, 48, hipMemcpyDeviceToHost);
-        printf("waves/WG %d: cycles per iteration: 1 chain %.1f, 2 chains %.1f, 4 chains %.1f, 8 chains %.1f; fp32 1 chain %.1f; 4 f64 adds %.1f\n", waves, (double)c[0] / n, (double)c[1] / n, (double)c[2] / n, (double)c[3] / n, (double)c[4] / n, (double)c[5] / n);
+    double *out; long long *cyc; (void)hipMalloc(&out, 64 * 8 * 4096); (void)hipMalloc(&cyc, 128);
+    const int n = 4000;
+    for (int waves = 1; waves <= 8; waves *= 2) {
+        hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, out, cyc, n); (void)hipDeviceSynchronize();
+        long long c[12]; (void)hipMemcpy(c, cyc, 96, hipMemcpyDeviceToHost);
+        const double u = 16.0 * n;
+        printf("waves/CU %d: cycles per operation (16 to an iteration): dependent fma %.1f add %.1f mul %.1f; per fma with 2 chains %.1f, 4 chains %.1f, 8 chains %.1f; per add with 4 chains %.1f; compare+add+select chain %.1f; 2 readlanes + add chain %.1f\n",
+               waves, c[0] / u, c[1] / u, c[2] / u, c[3] / u / 2, c[4] / u / 4, c[5] / u / 8, c[6] / u / 4, c[7] / u, c[8] / u);
     }
     return 0;
 }
