@@ -138,7 +138,9 @@ typedef struct {
                            pc_consume_clp_body.inc) instead of death after death on two wavefronts -- the same run to rounding in <Z^2>; an experiment that is
                            NOT the default: its walks are as long as the largest cluster's events, and at the BASELINE shapes that is no shorter; bit 12 = runs in step
                            (and bit 7): the deviates of a basis made in the registers of the Gram-Schmidt kernel (k_bases_own) instead of
-                           passing through HBM from a kernel of their own -- the same bases bit for bit, a third of the round's bytes less, NOT faster */
+                           passing through HBM from a kernel of their own -- the same bases bit for bit, a third of the round's bytes less, NOT faster; bit 13 = the
+                           fused sampling kernel with ONE wavefront a workgroup (a chain) instead of four chains and their four helper wavefronts
+                           (deck shuffle and whitening next to the seed choice instead of in front of it): the same numbers */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

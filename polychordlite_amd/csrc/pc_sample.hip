@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void eval_pair(ChainCtx<DPL, NROWS> &C, const double 
 #define PC_SLICE_ATTR
 #endif
 template <int DPL, int NROWS, bool SPECIAL, int WPB = 1, int FW = 0, int LEAN = 0>
-__global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
+__global__ PC_SLICE_ATTR __launch_bounds__(64 * WPB * ((FW > 0 && (LEAN == 1 || LEAN == 3 || LEAN == 5) && WPB == 4) ? 2 : 1)) void k_slice(PcState S, unsigned batch, int phi_lds, int mat_lds)
 {
 #include "pc_slice_body.inc"
 }
@@ -1290,13 +1290,25 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     static const bool lean_off = std::getenv("PC_SLICE_LEAN_OFF") != nullptr;
     const bool lean = !lean_off && S->like.kind == PC_LIKE_GAUSSIAN && !(S->ablate & 1) && phi_lds && S->nr <= 64 && !S->seq_mode && S->ngrade <= 1;
     const int leanf = slice_lean_functor(S);
+    // (a helper wavefront per chain for the lean variants whose deck lives in registers: pc_slice_body.inc; settings.ablate bit 13 / PC_SLICE_HELPER_OFF: without)
+    // four chains a workgroup with their four helper wavefronts (pc_slice_body.inc): the lean variants whose deck lives in registers, nurseries of a
+    // multiple of four chains; settings.ablate bit 13 / PC_SLICE_HELPER_OFF: one wavefront a workgroup as before (the same numbers)
+    static const bool helper_off = std::getenv("PC_SLICE_HELPER_OFF") != nullptr;
+    const size_t pw4 = ((size_t)D + S->nr + ((phi_lds || lean) ? (size_t)S->nr * (D + 1) : 0) + (size_t)FWv * D + (size_t)S->nr * (D + 2) + 1) & ~(size_t)1;
+    const size_t sh4 = 4 * sizeof(double) * pw4 + 16;
+    const bool help = !helper_off && !(S->ablate & 8192) && S->nr <= 64 && (nchains & 3) == 0 && sh4 <= 150 * 1024 && !S->spec_guard;
 #define PC_SLICE_FUSED_L(NROWS, FW, LN) { \
+        if ((LN == 3 || LN == 5) && help) { \
+        if (sh4 > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 4, FW, LN>, sh4); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 4, FW, LN>), dim3(nchains / 4), dim3(512), sh4, st, *S, batch, phi_lds, 0); } else { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, LN>, sh); \
-        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); }
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, LN>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } }
 #define PC_SLICE_FUSED(NROWS, FW) { \
         if (leanf == 3) PC_SLICE_FUSED_L(NROWS, FW, 3) else if (leanf == 4) PC_SLICE_FUSED_L(NROWS, FW, 4) else if (leanf == 5) PC_SLICE_FUSED_L(NROWS, FW, 5) else \
         if (lean) { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW, 1>, sh); \
+        if (help) { if (sh4 > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 4, FW, 1>, sh4); \
+        hipLaunchKernelGGL((k_slice<1, NROWS, false, 4, FW, 1>), dim3(nchains / 4), dim3(512), sh4, st, *S, batch, phi_lds, 0); } else \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW, 1>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } else { \
         if (sh > 48 * 1024) pc_need_dyn_lds((const void *)k_slice<1, NROWS, false, 1, FW>, sh); \
         hipLaunchKernelGGL((k_slice<1, NROWS, false, 1, FW>), dim3(nchains), dim3(64), sh, st, *S, batch, phi_lds, 0); } }

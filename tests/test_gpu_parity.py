@@ -553,6 +553,30 @@ def test_modes_change_no_number(engine, D, nDer, nlive, nr, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,nDer,nlive,nr,clus,box", [("gaussian", 20, 2, 2000, 40, 0, None), ("gaussian", 5, 1, 200, 10, 0, (-0.5, 1.5)), ("gaussian", 24, 0, 256, 48, 0, None),
+                                                          ("gaussian", 12, 3, 400, 24, 1, None), ("rastrigin", 4, 0, 400, 12, 1, (-5.12, 5.12)),
+                                                          ("rastrigin", 10, 0, 400, 30, 1, (-5.12, 5.12)), ("gaussian", 9, 2, 200, 64, 0, None)])
+def test_the_helper_wavefronts_change_no_number(engine, kind, D, nDer, nlive, nr, clus, box):
+    """the fused sampling kernel with four chains a workgroup and a helper wavefront each (deck shuffle and whitening next to the seed choice:
+    pc_slice_body.inc) against one wavefront a workgroup (settings.ablate bit 13): bit for bit the same run -- closed form, general functor
+    (bit 0), Rastrigin with clusters (several clusters: the helper leaves the whitening to the chain, whose seed names the factor)."""
+    api = engine
+    L, P, keep = api.make_problem(kind, D, nDer, *box) if box else api.make_problem(kind, D, nDer)
+    for base in ((0, 1) if kind == "gaussian" else (0,)):
+        runs = []
+        for ab in (base, base | 8192):
+            s = _settings(api, D, nDer, nlive=nlive, num_repeats=nr, seed=77, batch=0, do_clustering=clus, max_ndead=12 * nlive)
+            s.ablate = ab
+            runs.append(api.run(s, L, P))
+        a, b = runs
+        assert a["nupdates"] >= 3 and a["nbatches"] > 5
+        for k in ("ndead", "nlike", "niter", "nbatches", "nupdates", "ncluster", "ncluster_dead"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert a["logZ"] == b["logZ"] and a["logZerr"] == b["logZerr"]
+        assert np.array_equal(a["dead"], b["dead"], equal_nan=True) and np.array_equal(a["live"], b["live"], equal_nan=True) and np.array_equal(a["logweights"], b["logweights"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,nDer,nlive,nr,kind,box", [(20, 2, 2000, 40, "gaussian", None), (6, 1, 300, 12, "gaussian", (-0.25, 1.5)), (3, 0, 200, 9, "gaussian", None),
                                                      (24, 2, 300, 24, "gaussian", None), (40, 0, 200, 10, "gaussian", None), (12, 0, 200, 12, "corr_gaussian", None),
                                                      (70, 0, 150, 8, "corr_gaussian", None)])
