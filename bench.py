@@ -132,7 +132,9 @@ def latency_model(runs, kern):
         out["model_min"] = sum(ins.values()) * ISSUE_INTERVAL_CYCLES
         out["measured"] = 4.0 * k["SQ_WAVE_CYCLES"] / w                      # (the counter ticks every four clocks)
         out["frac_of_model"] = out["model_min"] / out["measured"]
-        out["measured_source"] = "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / _SALU / _LDS / _SMEM / _VMEM / SQ_WAVES / SQ_WAVE_CYCLES, one pass each, tools/collect_issue_profile.sh)" % src
+        out["measured_source"] = ("profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / _SALU / _LDS / _SMEM / _VMEM / SQ_WAVES / SQ_WAVE_CYCLES, one pass each, tools/collect_issue_profile.sh; "
+                                  "taken with settings.ablate bit 13 -- one wavefront a chain -- so that the counters are the chain's whole instruction stream: the product kernel "
+                                  "hands the deck's shuffle, the whitening and nine of ten Philox calls, ~2.5 k of these instructions, to a helper wavefront on another SIMD)") % src
     m, src2 = committed_record(SLICE_CYCLE_FILES, ("cycles_per_slice", "cycles_per_slice_total"))
     if m:
         out["slice_sections_cycles"] = m["cycles_per_slice"]; out["slice_cycles"] = m["cycles_per_slice_total"]
