@@ -980,7 +980,7 @@ struct Engine {
         const bool split_q = D > 64 && D <= 128 && S.ngrade <= 1 && !S.seq_mode && !split_off && !callback_mode;
         // 24 < nDims <= 64, one grade (round 5): k_nhats_q<8 / 16, 1> leaves a basis thread by thread, 16 HV^2 doubles
         const bool split_m = D > 24 && D <= 64 && S.ngrade <= 1 && !S.seq_mode && !split_off && !callback_mode;
-        const size_t raw_n = split_q ? (size_t)B * S.nb_total * 32 * 512 : split_m ? (size_t)B * S.nb_total * (D <= 32 ? 1024 : 4096) : (size_t)B * S.nb_total * D * D;
+        const size_t raw_n = split_q ? (size_t)B * S.nb_total * 32 * 512 : split_m ? (size_t)B * S.nb_total * (D <= 32 ? 1024 : 4096) : (size_t)B * S.nb_total * D * D + (size_t)B * 33 + 8;      // (+ the chains' deck records, 66 ints each: pc_deck_record, pc_sample.hip)
         S.nhat_raw = ((D <= 24 && !S.seq_mode && !split_off) || split_q || split_m) ? dalloc<double>(raw_n)
                    : (D > 128 ? dalloc<double>((size_t)B * S.nb_total * D * 256) : nullptr);   // k_nhats_big keeps its bases there
         // split launch: two buffers, so that the bases of nursery b + 1 can be drawn at any time while nursery b's are read

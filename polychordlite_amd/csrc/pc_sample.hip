@@ -182,6 +182,34 @@ __device__ __forceinline__ void select_seed(const PcState &S, unsigned batch, in
     if (S.seed_override) slot = chain;
 }
 
+// The deck of a chain (chordal_sampling.f90:135-142, random_utils.F90:505-532: the first direction stays, the others are Fisher-Yates shuffled),
+// keyed draws, num_repeats <= 64: the value for position p lives in lane p.  A pure function of (keys, nursery, chain): k_slice makes it, or finds
+// it behind the bases where k_nhats<.., 1> left it on the side stream (round 6) under a tag of those four numbers -- a matching tag IS the right deck,
+// whatever older run wrote it.
+__device__ __forceinline__ int pc_deck_keyed(const PcState &S, unsigned batch, int chain, int lane, int nr)
+{
+    int dk = lane, jv = 0;
+    if (lane >= 1 && lane < nr) {
+        const double u = pc_uniform(S.k0, S.k1, PC_DOM_SHUFFLE, batch, (uint32_t)chain, (uint32_t)lane);
+        int j = (int)ceil(u * lane);
+        jv = j < 1 ? 1 : (j > lane ? lane : j);
+    }
+    for (int i = nr - 1; i >= 1; --i) {
+        const int j = __builtin_amdgcn_readlane(jv, i);
+        const int di = __builtin_amdgcn_readlane(dk, i), dj = __builtin_amdgcn_readlane(dk, j);
+        dk = (lane == i) ? dj : ((lane == j) ? di : dk);
+    }
+    return dk;
+}
+// (everything the deck is a function of; a record that carries this tag carries that deck, whichever run, shape or buffer layout wrote it)
+__device__ __forceinline__ unsigned long long pc_deck_tag(const PcState &S, unsigned batch, int chain, int nr)
+{
+    return ((((unsigned long long)S.k0 << 32) | (unsigned long long)S.k1) ^ ((unsigned long long)batch * 0x9E3779B97F4A7C15ull)
+            ^ ((unsigned long long)(unsigned)chain * 0xC2B2AE3D27D4EB4Full) ^ ((unsigned long long)(unsigned)nr << 56)) | 1ull;
+}
+// behind the bases of a nursery (nDims <= 24: the engine allocates the tail): one record of 66 ints a chain, [tag lo, tag hi, deck[64]]
+__device__ __forceinline__ int *pc_deck_record(const PcState &S, int chain) { return (int *)(S.nhat_raw + (size_t)S.B * S.nb_total * S.D * S.D) + (size_t)chain * 66; }
+
 // PART 0: the whole kernel.  PART 1 / 2: the two halves of a split launch -- the orthonormal bases depend on nothing
 // but the keys and the batch number (1: they go to S.nhat_raw, on a side stream while the previous nursery is being
 // consumed), seed selection and whitening need the live set and the covariance of the moment (2).
@@ -216,6 +244,16 @@ __global__ __launch_bounds__(NT) void k_nhats(PcState S, unsigned batch)
 #ifdef NHATS_DBG
     ncyc[1] = clock64();
 #endif
+    if constexpr (PART == 1 && NT == 64) {
+        // drawn ahead with the bases: the chain's deck (k_slice's 39 dependent swaps, off its wavefront)
+        if (blockIdx.x == 0 && S.D <= 24 && S.ngrade <= 1 && !S.seq_mode && nr <= 64) {
+            const int dk = pc_deck_keyed(S, batch, chain, tid, nr);
+            int *rec = pc_deck_record(S, chain);
+            rec[2 + tid] = dk;
+            const unsigned long long tg = pc_deck_tag(S, batch, chain, nr);
+            if (tid == 0) { rec[0] = (int)(unsigned)tg; rec[1] = (int)(unsigned)(tg >> 32); }
+        }
+    }
     const int i = tid;
     const bool active = i < Dg;
     double v[DMAX];
