@@ -210,6 +210,54 @@ __device__ __forceinline__ unsigned long long pc_deck_tag(const PcState &S, unsi
 // behind the bases of a nursery (nDims <= 24: the engine allocates the tail): one record of 66 ints a chain, [tag lo, tag hi, deck[64]]
 __device__ __forceinline__ int *pc_deck_record(const PcState &S, int chain) { return (int *)(S.nhat_raw + (size_t)S.B * S.nb_total * S.D * S.D) + (size_t)chain * 66; }
 
+// select_seed by a whole wavefront (several clusters): the same numbers -- every exponential and quotient has the operands of the loops above and
+// every sum their order -- with the clusters' volumes loaded and exponentiated a lane each and only the additions in sequence (v_readlane): one
+// thread's three loops of a dependent global load + exponential per cluster were ~30 k cycles in front of every chain at two dozen clusters.
+__device__ __forceinline__ void select_seed_wave(const PcState &S, unsigned batch, int chain, int lane, int &sel, int &slot)
+{
+    const int nc = S.ctl->ncluster;
+    if (nc == 1 || S.seq_mode) {
+        int a = 0, b = 0;
+        if (lane == 0) select_seed(S, batch, chain, a, b);
+        sel = __builtin_amdgcn_readfirstlane(a); slot = __builtin_amdgcn_readfirstlane(b);
+        return;
+    }
+    double m = -PC_HUGE;
+    for (int c0 = 0; c0 < nc; c0 += 64) { const int c = c0 + lane; m = fmax(m, c < nc ? S.logXp[c] : -PC_HUGE); }
+    m = wave_max(m);
+    double sum = 0.0;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        const int c = c0 + lane;
+        const double e = c < nc ? exp(S.logXp[c] - m) : 0.0;
+        const int n = nc - c0 < 64 ? nc - c0 : 64;
+        for (int q = 0; q < n; ++q) sum += readlane_f64(e, q);
+    }
+    const double lse = m + log(sum);
+    double norm = 0.0;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        const int c = c0 + lane;
+        const double t = c < nc ? exp(S.logXp[c] - lse) : 0.0;
+        const int n = nc - c0 < 64 ? nc - c0 : 64;
+        for (int q = 0; q < n; ++q) norm += readlane_f64(t, q);
+    }
+    const double u = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 0u);
+    double cdf = 0.0;
+    sel = nc - 1;
+    bool found = false;
+    for (int c0 = 0; c0 < nc && !found; c0 += 64) {
+        const int c = c0 + lane;
+        const double r = c < nc ? exp(S.logXp[c] - lse) / norm : 0.0;
+        const int n = nc - c0 < 64 ? nc - c0 : 64;
+        for (int q = 0; q < n; ++q) { cdf += readlane_f64(r, q); if (u < cdf) { sel = c0 + q; found = true; break; } }
+    }
+    const double u2 = pc_uniform(S.k0, S.k1, PC_DOM_SEED, batch, (uint32_t)chain, 1u);
+    const int n = S.cl_n[sel];
+    int idx = (int)ceil(u2 * n);
+    idx = idx < 1 ? 1 : (idx > n ? n : idx);
+    slot = S.cl_list[(size_t)sel * S.Ncap + idx - 1];
+    if (S.seed_override) slot = chain;
+}
+
 // PART 0: the whole kernel.  PART 1 / 2: the two halves of a split launch -- the orthonormal bases depend on nothing
 // but the keys and the batch number (1: they go to S.nhat_raw, on a side stream while the previous nursery is being
 // consumed), seed selection and whitening need the live set and the covariance of the moment (2).
