@@ -140,7 +140,9 @@ typedef struct {
                            (and bit 7): the deviates of a basis made in the registers of the Gram-Schmidt kernel (k_bases_own) instead of
                            passing through HBM from a kernel of their own -- the same bases bit for bit, a third of the round's bytes less, NOT faster; bit 13 = the
                            fused sampling kernel with ONE wavefront a workgroup (a chain) instead of four chains and their four helper wavefronts
-                           (deck shuffle and whitening next to the seed choice instead of in front of it): the same numbers */
+                           (deck shuffle and whitening next to the seed choice instead of in front of it): the same numbers; bit 14 = with the helper, the closed
+                           form's s.M.s of a direction reduced by the chain at the head of its slice instead of taken from the table the helper made with the
+                           whitening (the same bits: the table's sums follow the wave butterfly's order) */
     const char *resume_write;  /* path of a .resume file (reference grammar, read_write.F90:219-288) rewritten at every
                                   update and at the end; NULL = off */
     int sequential_rng; /* tests: ONE Philox stream consumed in the reference's program order (forces batch = 1 and the

@@ -1380,7 +1380,7 @@ extern "C" int pc_launch_slice_fused(const PcState *S, unsigned batch, int nchai
     // four chains a workgroup with their four helper wavefronts (pc_slice_body.inc): the lean variants whose deck lives in registers, nurseries of a
     // multiple of four chains; settings.ablate bit 13 / PC_SLICE_HELPER_OFF: one wavefront a workgroup as before (the same numbers)
     static const bool helper_off = std::getenv("PC_SLICE_HELPER_OFF") != nullptr;
-    const size_t pw4 = ((size_t)D + S->nr + ((phi_lds || lean) ? (size_t)S->nr * (D + 1) : 0) + (size_t)FWv * D + (size_t)S->nr * (D + 2) + (size_t)((S->nr + 3) / 4) * 128 + 1) & ~(size_t)1;
+    const size_t pw4 = ((size_t)D + S->nr + ((phi_lds || lean) ? (size_t)S->nr * (D + 1) : 0) + (size_t)FWv * D + (size_t)S->nr * (D + 2) + (size_t)((S->nr + 3) / 4) * 128 + (size_t)S->nr + 1) & ~(size_t)1;
     const size_t sh4 = 4 * sizeof(double) * pw4 + 16;
     const bool help = !helper_off && !(S->ablate & 8192) && S->nr <= 64 && (nchains & 3) == 0 && sh4 <= 150 * 1024 && !S->spec_guard;
 #define PC_SLICE_FUSED_L(NROWS, FW, LN) { \
