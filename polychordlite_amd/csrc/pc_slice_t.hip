@@ -208,7 +208,11 @@ __device__ __forceinline__ void slice_t_body(const PcState &S, unsigned batch, i
                     f2 += fstep; src += sstep; dst += dstep;
                     if (f2 >= H) { f2 -= H; src += swrap; dst += dwrap; }
                     const double2 nxt = (i + 1 < H) ? make_double2(src[0], src[1]) : cur;
-                    *(double2 *)d0 = cur;
+                    {   // (through the L2, system scope: the launch does not end on the write-back of the runs' rows -- as k_slice, round 6)
+                        typedef double st_v2d __attribute__((ext_vector_type(2)));
+                        const st_v2d v2 = {cur.x, cur.y};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d0), "v"(v2) : "memory");
+                    }
                     cur = nxt;
                 }
             } else {
