@@ -2605,8 +2605,9 @@ struct Engine {
             // 6 us per launch: 72 against 66 us)
             if (h_ctl->status == PC_ST_UPDATE || (h_ctl->upd_pending && h_ctl->status == PC_ST_RUNNING)) {
                 do_update(h_ctl->status != PC_ST_UPDATE); h_ctl->status = PC_ST_RUNNING; h_ctl->upd_pending = 0;
-                // (in step with other runs: every few updates -- a copy request costs the one thread that drives them all ~10 us)
-                if (!co || (size_t)h_ctl->ndead >= h_dead_copied + 4 * (size_t)cfg.nlive) {
+                // (every few updates: in step with other runs a copy request costs the one thread that drives them all ~10 us, and a run on its own
+                //  finds the k_slice next to a copy as much longer as the copy lasts -- four copies of a run's thirty-one: 11.40 -> 11.33 ms, three A/B pairs)
+                if ((size_t)h_ctl->ndead >= h_dead_copied + 4 * (size_t)cfg.nlive) {
                 if (!ev_apply) ev_apply = hpool().get_sync_event();
                 HIPCHK(hipEventRecord(ev_apply, st));       // the dead rows of the rounds so far are in place behind this point
                 stream_dead();
