@@ -770,6 +770,7 @@ __global__ __launch_bounds__(512) void k_basis(PcState S, unsigned batch)
     typedef double v2d __attribute__((ext_vector_type(2)));
     constexpr int NM = 4 * NT, NS = 130, RAWB = 32 * 512;
     __shared__ __attribute__((aligned(16))) double Qp[2][16 * NS];
+    __builtin_amdgcn_s_setprio(3);                 // (the side stream's kernel is the one the run waits for: section 5d)
     const int D = S.D;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int chain = blockIdx.y, basis = blockIdx.x;
