@@ -663,6 +663,29 @@ def test_bases_with_their_own_deviates_are_the_same_bases(engine):
 
 
 @pytest.mark.gpu
+def test_deck_records_against_stale_memory(engine):
+    """k_nhats leaves every chain's deck behind the bases of a nursery under a tag of what the deck is a function of (keys, nursery, chain,
+    num_repeats: pc_deck_record), and k_slice takes a record whose tag it finds.  The engine's blocks come back from a cache: one process,
+    one seed, shapes that change from call to call, so that older records of the same keys lie where new ones are looked for -- every run
+    alone (decks from the records) against the same run in step with a second one (lane-per-chain kernels: decks made in the kernel)."""
+    from polychordlite_amd.repeats import run_repeats
+    api = engine
+    lib = api.load()
+    for D, nDer, nlive, nr in ((8, 0, 200, 16), (8, 0, 200, 8), (8, 0, 200, 16), (8, 0, 100, 16), (8, 0, 200, 32), (12, 1, 200, 16), (8, 0, 200, 16), (8, 0, 200, 9)):
+        L, P, keep = api.make_problem("gaussian", D, nDer)
+        def settings(seed):
+            s = api.Settings(); lib.pchip_settings_default(C.byref(s), D, nDer)
+            s.nlive, s.num_repeats, s.seed = nlive, nr, seed
+            return s
+        one = api.run(settings(5), L, P)
+        merged, runs = run_repeats(settings(0), L, P, [5, 6], max_in_flight=2)
+        assert one["path"]["slice_wave"] > 0 and runs[0]["path"]["slice_lane"] > 0
+        for k in ("ndead", "nlike", "niter", "nbatches"):
+            assert one[k] == runs[0][k], (D, nlive, nr, k, one[k], runs[0][k])
+        assert one["logZ"] == runs[0]["logZ"] and np.array_equal(one["dead"], runs[0]["dead"], equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_a_failing_run_ends_the_runs_in_step_cleanly(engine):
     """one of several runs in step fails (injected: a device allocation during its setup): pchip_run_repeats reports the failure, gives
     every buffer back, and the next call -- the same seeds -- makes the runs as if nothing had happened"""
